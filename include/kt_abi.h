@@ -1,0 +1,206 @@
+/*
+ * kt_abi.h -- C-ABI of libkt_hip.so: the MI355X (gfx950) replacement for Kintinuous's device operator
+ * API.  The reference has no FFI; its seam is the header src/frontend/cuda/internal.h:295-536 (free
+ * functions over DeviceArray2D / PtrStep views, implemented in src/frontend/cuda/ *.cu) plus the
+ * container classes in src/frontend/cuda/containers/.  Each entry point below names the reference
+ * function it replaces.  kintinuous_amd/host/internal.h re-creates the reference's C++ names as inline
+ * wrappers over these calls.
+ *
+ * Conventions
+ *   - every function returns an int status: KT_OK (0) or a KT_ERR_* code; kt_last_error() gives the text.
+ *     (The reference prints and exit(0)s on any CUDA error, internal.h:76-86; the C++ wrappers keep that.)
+ *   - all image / map / volume pointers are DEVICE pointers (hipMalloc'ed: kt_malloc, or any other HIP
+ *     allocation, e.g. a torch tensor's data_ptr) unless the parameter name ends in _host.
+ *   - all buffers are dense: row pitch == cols * sizeof(T)  (the reference's volume kernels assume it,
+ *     tsdf_volume.cu:612; reduce.cu:444,767).
+ *   - vmap / nmap: float[3*rows][cols] (x, y, z planes stacked by rows; invalid = NaN in the x plane).
+ *   - tsdf volume: int16[N^3], index x + y*N + z*N*N, storage wrapped by voxel_wrap (tsdf_volume.cu:612);
+ *     colour volume: uint8[N^3][4] = r, g, b, weight (the voxel weight lives in .w).
+ *   - VOL (internal.h:243) and the image resolution are runtime parameters (N, cols, rows).
+ *   - work is enqueued on the context's HIP stream; functions with *_host outputs synchronise that stream
+ *     before returning, the others return right after the launch (call kt_sync to wait).
+ *   - not thread-safe per context; use one context per host thread / per GPU (the reference is single
+ *     GPU-thread too).
+ */
+#ifndef KT_ABI_H_
+#define KT_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KT_OK 0
+#define KT_ERR_HIP 1      /* a HIP runtime call or launch failed */
+#define KT_ERR_ARG 2      /* bad argument */
+#define KT_ERR_NOMEM 3
+#define KT_ERR_STATE 4
+
+typedef struct kt_ctx kt_ctx;
+
+typedef struct { float fx, fy, cx, cy; } kt_intr;   /* Intr, internal.h:249-260 */
+typedef struct { float m[9]; } kt_mat33;            /* Mat33, internal.h:279-282, row-major */
+typedef struct { float v[29]; } kt_jtj;             /* JtJJtrSE3, internal.h:98-149 */
+typedef struct {                                    /* DataTerm, internal.h:90-96 (16 bytes) */
+    int16_t zero_x, zero_y, one_x, one_y;
+    float diff;
+    uint8_t valid, pad[3];
+} kt_dataterm;
+typedef struct {                                    /* PointXYZRGB, internal.h:156-184 (32 bytes) */
+    float x, y, z, pad0;
+    uint8_t b, g, r, a;
+    uint32_t pad1[3];
+} kt_point_xyzrgb;
+
+/* ---- context / memory: replaces containers/device_memory.cpp, initialization.cpp, cudaSetDevice ---- */
+const char* kt_last_error(void);
+const char* kt_version(void);
+int kt_device_count(int* count);
+int kt_ctx_create(int device, kt_ctx** out);           /* cudaSetDevice(gpu) TrackerInterface.cpp:48 + a private stream */
+int kt_ctx_destroy(kt_ctx* ctx);
+int kt_ctx_set_stream(kt_ctx* ctx, void* hip_stream);  /* run on a caller-owned hipStream_t (e.g. torch's) */
+void* kt_ctx_stream(kt_ctx* ctx);
+int kt_sync(kt_ctx* ctx);                              /* cudaDeviceSynchronize at the end of the reference wrappers */
+int kt_malloc(kt_ctx* ctx, size_t bytes, void** dptr); /* DeviceMemory::create  device_memory.cpp:98-117 */
+int kt_free(kt_ctx* ctx, void* dptr);                  /* DeviceMemory::release */
+int kt_memset(kt_ctx* ctx, void* dptr, int value, size_t bytes);
+int kt_upload(kt_ctx* ctx, void* dst, const void* src_host, size_t bytes);      /* DeviceMemory::upload */
+int kt_download(kt_ctx* ctx, void* dst_host, const void* src, size_t bytes);    /* DeviceMemory::download */
+/* DeviceMemory2D::upload/download with a host pitch (device side dense)  device_memory.cpp:206-227 */
+int kt_upload2d(kt_ctx* ctx, void* dst, const void* src_host, size_t host_pitch, size_t row_bytes, int rows);
+int kt_download2d(kt_ctx* ctx, void* dst_host, size_t host_pitch, const void* src, size_t row_bytes, int rows);
+
+/* ---- image-side kernels ---- */
+/* bilateralFilter  internal.h:299 / bilateral_pyrdown.cu:332-342 */
+int kt_bilateral_filter(kt_ctx* ctx, const uint16_t* src, uint16_t* dst, int cols, int rows);
+/* pyrDown  internal.h:307 / bilateral_pyrdown.cu:344-354; dst is (scols/2) x (srows/2) */
+int kt_pyr_down(kt_ctx* ctx, const uint16_t* src, int scols, int srows, uint16_t* dst);
+/* createVMap  internal.h:328 / maps.cu:122-137 */
+int kt_create_vmap(kt_ctx* ctx, const kt_intr* intr, const uint16_t* depth, int cols, int rows, float* vmap);
+/* createNMap  internal.h:335 / maps.cu:139-154 */
+int kt_create_nmap(kt_ctx* ctx, const float* vmap, int cols, int rows, float* nmap);
+/* tranformMaps  internal.h:346 / maps.cu:203-223 */
+int kt_transform_maps(kt_ctx* ctx, const float* vmap_src, const float* nmap_src, int cols, int rows,
+                      const kt_mat33* Rmat, const float tvec[3], float* vmap_dst, float* nmap_dst);
+/* resizeVMap / resizeNMap  internal.h:453,460 / maps.cu:279-308; out is (in_cols/2) x (in_rows/2) */
+int kt_resize_vmap(kt_ctx* ctx, const float* in, int in_cols, int in_rows, float* out);
+int kt_resize_nmap(kt_ctx* ctx, const float* in, int in_cols, int in_rows, float* out);
+/* shortDepthToMetres  internal.h:313 / bilateral_pyrdown.cu:404-411 */
+int kt_depth_to_metres(kt_ctx* ctx, const uint16_t* src, float* dst, int cols, int rows, int cutoff);
+/* imageBGRToIntensity  internal.h:315 / bilateral_pyrdown.cu:413-420; src = rgb24 */
+int kt_bgr_to_intensity(kt_ctx* ctx, const uint8_t* src_rgb24, uint8_t* dst, int cols, int rows);
+/* pyrDownGaussF  internal.h:309 / bilateral_pyrdown.cu:356-377 */
+int kt_pyr_down_gauss_f32(kt_ctx* ctx, const float* src, int scols, int srows, float* dst);
+/* pyrDownUcharGauss  internal.h:311 / bilateral_pyrdown.cu:379-402 */
+int kt_pyr_down_gauss_u8(kt_ctx* ctx, const uint8_t* src, int scols, int srows, uint8_t* dst);
+/* computeDerivativeImages  internal.h:301 / bilateral_pyrdown.cu:300-330 */
+int kt_derivative_images(kt_ctx* ctx, const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy);
+/* projectToPointCloud  internal.h:317-320 / maps.cu:329-344; cloud = float[rows][cols][3]; intrinsics of level 0 */
+int kt_project_to_cloud(kt_ctx* ctx, const float* depth, int cols, int rows, float* cloud_xyz,
+                        double fx, double fy, double cx, double cy, int level);
+
+/* ---- tracking reductions ---- */
+/* icpStep  internal.h:485-502 / reduce.cu:347-419.  A_host[36] row-major symmetric, b_host[6], residual_host[2]
+ * = {sum residual^2, inlier count}.  The reference's `sum`/`out` scratch arrays live in the context. */
+int kt_icp_step(kt_ctx* ctx, const kt_mat33* Rcurr, const float tcurr[3], const float* vmap_curr, const float* nmap_curr,
+                const kt_mat33* Rprev_inv, const float tprev[3], const kt_intr* intr,
+                const float* vmap_g_prev, const float* nmap_g_prev, int cols, int rows,
+                float dist_thres, float angle_thres, float* A_host, float* b_host, float* residual_host);
+/* computeRgbResidual  internal.h:519-534 / reduce.cu:798-864 */
+int kt_rgb_residual(kt_ctx* ctx, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
+                    const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
+                    int cols, int rows, kt_dataterm* corres_img, float max_depth_delta, const float kt[3],
+                    const kt_mat33* krkinv, int* sigma_sum_host, int* count_host);
+/* rgbStep  internal.h:504-517 / reduce.cu:555-607 */
+int kt_rgb_step(kt_ctx* ctx, const kt_dataterm* corres_img, float sigma, const float* cloud_xyz, float fx, float fy,
+                const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows,
+                float* A_host, float* b_host);
+
+/* ---- volume kernels ---- */
+/* initVolume / initColorVolume  internal.h:353,417 / tsdf_volume.cu:468-479, 76-87 */
+int kt_init_volume(kt_ctx* ctx, int16_t* volume, int N);
+int kt_init_color_volume(kt_ctx* ctx, uint8_t* color_volume, int N);
+/* integrateTsdfVolume  internal.h:404-409 / tsdf_volume.cu:642-674.  colors = rgb24, nmap_curr = level-0 normal map */
+int kt_integrate_tsdf(kt_ctx* ctx, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
+                      const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
+                      int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
+                      const uint8_t* colors_rgb24, const float* nmap_curr, int angle_color, int N);
+/* raycast  internal.h:429-431 / ray_caster.cu:433-471.  vmap_curr_color = uint8[rows][cols][4] */
+int kt_raycast(kt_ctx* ctx, const kt_intr* intr, const kt_mat33* Rcurr, const float tcurr[3], float tranc_dist,
+               const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
+               const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N);
+/* clearVolume{X,Y,Z}{,Back}{,c}  internal.h:355-389 / tsdf_volume.cu:117-448.
+ * axis 0/1/2 = X/Y/Z, back = the ...Back variants, elem_size 2 = tsdf (short), 4 = colour (uchar4, the ...c variants) */
+int kt_clear_volume(kt_ctx* ctx, void* volume, int elem_size, int N, int axis, int back,
+                    int current_voxel_wrap, int delta_voxel_wrap);
+/* extractCloudSlice  internal.h:463-476 / extract.cu:325-419.  Output order is unspecified (as in the reference). */
+int kt_extract_cloud_slice(kt_ctx* ctx, const int16_t* volume, const float volume_size[3], kt_point_xyzrgb* output,
+                           size_t output_capacity, const int voxel_wrap[3], const uint8_t* color_volume,
+                           int minX, int maxX, int minY, int maxY, int minZ, int maxZ, int subsample,
+                           const int real_voxel_wrap[3], int N, size_t* count_host);
+
+/* ---- frame-level tracker (KintinuousTracker::processFrame, KintinuousTracker.cpp:444-915) ----
+ * Device-resident fast path: the whole per-frame pipeline is enqueued on the context stream, the ICP /
+ * RGB-D Gauss-Newton iterations solve and update the pose on the device (no host round trip per
+ * iteration).  The host-side C++ class KintinuousTracker (kintinuous_amd/host) is a thin shell over it. */
+typedef struct kt_tracker kt_tracker;
+typedef struct {
+    int cols, rows, N;
+    float fx, fy, cx, cy;
+    float volume_size;   /* -s  (ConfigArgs.h:117) */
+    int voxel_shift;     /* -t  */
+    int overlap;         /* 2 = TrackerInterface::enableOverlap(), 0 with -no */
+    int static_mode;     /* -sm */
+    int use_rgbd;        /* -r  */
+    int use_rgbd_icp;    /* -ri */
+    int fast_odometry;   /* -fod */
+    int disable_color_angle; /* -dc */
+    int max_slice_points;    /* 0 = 3 * cols * rows (KintinuousTracker.cpp:77) */
+} kt_tracker_config;
+
+int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** out);
+int kt_tracker_destroy(kt_tracker* t);
+int kt_tracker_reset(kt_tracker* t);
+/* processFrame with device-resident inputs: depth u16 [rows][cols] (mm), rgb24 [rows][cols][3] */
+int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_dev, const uint8_t* rgb24_dev, uint64_t timestamp);
+/* TrackerInterface::process upload path (TrackerInterface.cpp:90-91): host frame -> device -> processFrame */
+int kt_tracker_process_frame_host(kt_tracker* t, const uint16_t* depth_host, const uint8_t* rgb24_host, uint64_t timestamp);
+int kt_tracker_finalise(kt_tracker* t);
+/* rmats_.back() (row-major 3x3), tvecs_.back(), currentGlobalCamera */
+int kt_tracker_get_pose(kt_tracker* t, float R_host[9], float t_host[3], float global_cam_host[3]);
+int kt_tracker_num_poses(kt_tracker* t);
+/* densePoseGraph[i]: timestamp, row-major 4x4 [R | currentGlobalCamera], isLoopPose */
+int kt_tracker_get_dense_pose(kt_tracker* t, int i, uint64_t* ts, float pose16_host[16], int* is_loop);
+int kt_tracker_get_voxel_wrap(kt_tracker* t, int wrap_host[3]);
+int kt_tracker_num_slices(kt_tracker* t);
+int kt_tracker_slice_info(kt_tracker* t, int i, size_t* n_points, int* dimension);
+int kt_tracker_slice_points(kt_tracker* t, int i, kt_point_xyzrgb* out_host);
+/* device pointers of the tracker's volume / maps, for inspection and parity tests */
+int16_t* kt_tracker_volume(kt_tracker* t);
+uint8_t* kt_tracker_color_volume(kt_tracker* t);
+float* kt_tracker_vmap_g_prev(kt_tracker* t, int level);
+float* kt_tracker_nmap_g_prev(kt_tracker* t, int level);
+float kt_tracker_trunc_dist(kt_tracker* t);
+/* profiling: on = 0 off, 1 = time only the tsdf23 voxel kernel (2 event records per frame), 2 = all stages.
+ * kt_tracker_stage_ms returns the MEAN milliseconds per frame since profiling was enabled (hipEvent pairs on
+ * the context stream) for: 0 pyramid, 1 odometry, 2 shift, 3 integrate (scaleDepth + tsdf23), 4 raycast,
+ * 5 predicted-map resize, 6 the tsdf23 kernel alone; kt_tracker_stage_counts the number of samples of each. */
+int kt_tracker_enable_profiling(kt_tracker* t, int on);
+int kt_tracker_stage_ms(kt_tracker* t, float ms_host[7]);
+int kt_tracker_stage_counts(kt_tracker* t, long long n_host[7]);
+/* counters of the last frame (costs two extra syncs per frame; off by default): U = voxels that passed the
+ * integrate update predicate, S = ray-march steps */
+int kt_tracker_enable_counts(kt_tracker* t, int on);
+int kt_tracker_last_counts(kt_tracker* t, unsigned long long* U, unsigned long long* S);
+
+/* ---- multi-GPU: independent streams, one tracker per GPU; poses are gathered by the caller's
+ * collective (bench.py / the CLI use RCCL all_gather on the buffer filled here) ---- */
+/* copies the last k dense poses (k*16 floats, row-major 4x4) into a DEVICE buffer for the gather */
+int kt_tracker_export_poses_device(kt_tracker* t, int k, float* dst_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KT_ABI_H_ */

@@ -1,0 +1,416 @@
+"""ctypes binding of libkt_hip.so (include/kt_abi.h) -- used by tests/, bench.py and the smoke test.
+
+This is plumbing only: device buffers are raw HIP allocations made through the C-ABI (kt_malloc) and
+moved with kt_upload / kt_download; numpy arrays live on the host.  There is NO CPU fallback: if the HIP
+library is missing or fails to load, importing `lib()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkt_hip.so")
+
+KT_OK = 0
+
+
+class KtError(RuntimeError):
+    pass
+
+
+class Intr(C.Structure):  # kt_intr
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+    def level(self, l: int) -> "Intr":  # Intr::operator(), internal.h:255-259 (float division)
+        d = np.float32(1 << l)
+        return Intr(np.float32(self.fx) / d, np.float32(self.fy) / d, np.float32(self.cx) / d, np.float32(self.cy) / d)
+
+
+class Mat33(C.Structure):  # kt_mat33
+    _fields_ = [("m", C.c_float * 9)]
+
+    @staticmethod
+    def from_np(a) -> "Mat33":
+        a = np.asarray(a, dtype=np.float32).reshape(9)
+        return Mat33((C.c_float * 9)(*a.tolist()))
+
+
+class TrackerConfig(C.Structure):  # kt_tracker_config
+    _fields_ = [
+        ("cols", C.c_int), ("rows", C.c_int), ("N", C.c_int),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("volume_size", C.c_float), ("voxel_shift", C.c_int), ("overlap", C.c_int), ("static_mode", C.c_int),
+        ("use_rgbd", C.c_int), ("use_rgbd_icp", C.c_int), ("fast_odometry", C.c_int), ("disable_color_angle", C.c_int),
+        ("max_slice_points", C.c_int),
+    ]
+
+
+DATATERM_DTYPE = np.dtype([("zero", np.int16, 2), ("one", np.int16, 2), ("diff", np.float32), ("valid", np.uint8), ("pad", np.uint8, 3)])
+POINT_DTYPE = np.dtype([("xyz", np.float32, 3), ("pad0", np.float32), ("bgra", np.uint8, 4), ("pad1", np.uint32, 3)])
+assert DATATERM_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 32
+
+_vp, _i, _f, _d, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint64
+_pf = C.POINTER(C.c_float)
+_pi = C.POINTER(C.c_int)
+_pI = C.POINTER(Intr)
+_pM = C.POINTER(Mat33)
+
+_PROTOS = {
+    "kt_last_error": (C.c_char_p, []),
+    "kt_version": (C.c_char_p, []),
+    "kt_device_count": (_i, [_pi]),
+    "kt_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "kt_ctx_destroy": (_i, [_vp]),
+    "kt_ctx_set_stream": (_i, [_vp, _vp]),
+    "kt_ctx_stream": (_vp, [_vp]),
+    "kt_sync": (_i, [_vp]),
+    "kt_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "kt_free": (_i, [_vp, _vp]),
+    "kt_memset": (_i, [_vp, _vp, _i, _sz]),
+    "kt_upload": (_i, [_vp, _vp, _vp, _sz]),
+    "kt_download": (_i, [_vp, _vp, _vp, _sz]),
+    "kt_upload2d": (_i, [_vp, _vp, _vp, _sz, _sz, _i]),
+    "kt_download2d": (_i, [_vp, _vp, _sz, _vp, _sz, _i]),
+    "kt_bilateral_filter": (_i, [_vp, _vp, _vp, _i, _i]),
+    "kt_pyr_down": (_i, [_vp, _vp, _i, _i, _vp]),
+    "kt_create_vmap": (_i, [_vp, _pI, _vp, _i, _i, _vp]),
+    "kt_create_nmap": (_i, [_vp, _vp, _i, _i, _vp]),
+    "kt_transform_maps": (_i, [_vp, _vp, _vp, _i, _i, _pM, _pf, _vp, _vp]),
+    "kt_resize_vmap": (_i, [_vp, _vp, _i, _i, _vp]),
+    "kt_resize_nmap": (_i, [_vp, _vp, _i, _i, _vp]),
+    "kt_depth_to_metres": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "kt_bgr_to_intensity": (_i, [_vp, _vp, _vp, _i, _i]),
+    "kt_pyr_down_gauss_f32": (_i, [_vp, _vp, _i, _i, _vp]),
+    "kt_pyr_down_gauss_u8": (_i, [_vp, _vp, _i, _i, _vp]),
+    "kt_derivative_images": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "kt_project_to_cloud": (_i, [_vp, _vp, _i, _i, _vp, _d, _d, _d, _d, _i]),
+    "kt_icp_step": (_i, [_vp, _pM, _pf, _vp, _vp, _pM, _pf, _pI, _vp, _vp, _i, _i, _f, _f, _pf, _pf, _pf]),
+    "kt_rgb_residual": (_i, [_vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _pf, _pM, _pi, _pi]),
+    "kt_rgb_step": (_i, [_vp, _vp, _f, _vp, _f, _f, _vp, _vp, _f, _i, _i, _pf, _pf]),
+    "kt_init_volume": (_i, [_vp, _vp, _i]),
+    "kt_init_color_volume": (_i, [_vp, _vp, _i]),
+    "kt_integrate_tsdf": (_i, [_vp, _vp, _i, _i, _pI, _pf, _pM, _pf, _f, _vp, _vp, _pi, _vp, _vp, _vp, _i, _i]),
+    "kt_raycast": (_i, [_vp, _pI, _pM, _pf, _f, _pf, _vp, _vp, _vp, _i, _i, _pi, _vp, _vp, _i]),
+    "kt_clear_volume": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "kt_extract_cloud_slice": (_i, [_vp, _vp, _pf, _vp, _sz, _pi, _vp, _i, _i, _i, _i, _i, _i, _i, _pi, _i, C.POINTER(_sz)]),
+    "kt_tracker_create": (_i, [_vp, C.POINTER(TrackerConfig), C.POINTER(_vp)]),
+    "kt_tracker_destroy": (_i, [_vp]),
+    "kt_tracker_reset": (_i, [_vp]),
+    "kt_tracker_process_frame": (_i, [_vp, _vp, _vp, _u64]),
+    "kt_tracker_process_frame_host": (_i, [_vp, _vp, _vp, _u64]),
+    "kt_tracker_finalise": (_i, [_vp]),
+    "kt_tracker_get_pose": (_i, [_vp, _pf, _pf, _pf]),
+    "kt_tracker_num_poses": (_i, [_vp]),
+    "kt_tracker_get_dense_pose": (_i, [_vp, _i, C.POINTER(_u64), _pf, _pi]),
+    "kt_tracker_get_voxel_wrap": (_i, [_vp, _pi]),
+    "kt_tracker_num_slices": (_i, [_vp]),
+    "kt_tracker_slice_info": (_i, [_vp, _i, C.POINTER(_sz), _pi]),
+    "kt_tracker_slice_points": (_i, [_vp, _i, _vp]),
+    "kt_tracker_volume": (_vp, [_vp]),
+    "kt_tracker_color_volume": (_vp, [_vp]),
+    "kt_tracker_vmap_g_prev": (_vp, [_vp, _i]),
+    "kt_tracker_nmap_g_prev": (_vp, [_vp, _i]),
+    "kt_tracker_trunc_dist": (_f, [_vp]),
+    "kt_tracker_enable_profiling": (_i, [_vp, _i]),
+    "kt_tracker_stage_ms": (_i, [_vp, _pf]),
+    "kt_tracker_stage_counts": (_i, [_vp, C.POINTER(C.c_longlong)]),
+    "kt_tracker_enable_counts": (_i, [_vp, _i]),
+    "kt_tracker_last_counts": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "kt_tracker_export_poses_device": (_i, [_vp, _i, _vp]),
+}
+
+ABI_SYMBOLS = tuple(_PROTOS.keys())
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libkt_hip.so (built by __graft_entry__.build()).  Raises if it is missing: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KtError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _chk(status: int) -> None:
+    if status != KT_OK:
+        raise KtError(f"kt status {status}: {lib().kt_last_error().decode(errors='replace')}")
+
+
+def _fp(a) -> "C.Array":
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    return (C.c_float * a.size)(*a.tolist())
+
+
+def _ip(a) -> "C.Array":
+    a = np.ascontiguousarray(a, dtype=np.int32).reshape(-1)
+    return (C.c_int * a.size)(*a.tolist())
+
+
+class DevBuf:
+    """A raw device allocation owned through kt_malloc / kt_free."""
+
+    def __init__(self, ctx: "Ctx", nbytes: int, ptr: Optional[int] = None):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        self.owned = ptr is None
+        if ptr is None:
+            p = _vp()
+            _chk(lib().kt_malloc(ctx.h, self.nbytes, C.byref(p)))
+            ptr = p.value
+        self.ptr = ptr
+
+    def free(self) -> None:
+        if self.owned and self.ptr:
+            lib().kt_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Ctx:
+    """kt_ctx: one device + one stream."""
+
+    def __init__(self, device: int = 0):
+        h = _vp()
+        _chk(lib().kt_ctx_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self) -> None:
+        if self.h:
+            lib().kt_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self) -> None:
+        _chk(lib().kt_sync(self.h))
+
+    # ---- memory --------------------------------------------------------------------------------
+    def empty(self, nbytes: int) -> DevBuf:
+        return DevBuf(self, nbytes)
+
+    def zeros(self, nbytes: int) -> DevBuf:
+        b = DevBuf(self, nbytes)
+        _chk(lib().kt_memset(self.h, b.ptr, 0, nbytes))
+        return b
+
+    def upload(self, a: np.ndarray, into: Optional[DevBuf] = None) -> DevBuf:
+        a = np.ascontiguousarray(a)
+        b = into if into is not None else DevBuf(self, a.nbytes)
+        _chk(lib().kt_upload(self.h, b.ptr, a.ctypes.data, a.nbytes))
+        return b
+
+    def download(self, b, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        ptr = b.ptr if isinstance(b, DevBuf) else int(b)
+        _chk(lib().kt_download(self.h, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    # ---- image ops -----------------------------------------------------------------------------
+    def bilateral_filter(self, src: DevBuf, dst: DevBuf, cols: int, rows: int) -> None:
+        _chk(lib().kt_bilateral_filter(self.h, src.ptr, dst.ptr, cols, rows))
+
+    def pyr_down(self, src: DevBuf, scols: int, srows: int, dst: DevBuf) -> None:
+        _chk(lib().kt_pyr_down(self.h, src.ptr, scols, srows, dst.ptr))
+
+    def create_vmap(self, intr: Intr, depth: DevBuf, cols: int, rows: int, vmap: DevBuf) -> None:
+        _chk(lib().kt_create_vmap(self.h, C.byref(intr), depth.ptr, cols, rows, vmap.ptr))
+
+    def create_nmap(self, vmap: DevBuf, cols: int, rows: int, nmap: DevBuf) -> None:
+        _chk(lib().kt_create_nmap(self.h, vmap.ptr, cols, rows, nmap.ptr))
+
+    def transform_maps(self, vs, ns, cols, rows, R, t, vd, nd) -> None:
+        _chk(lib().kt_transform_maps(self.h, vs.ptr, ns.ptr, cols, rows, C.byref(Mat33.from_np(R)), _fp(t), vd.ptr, nd.ptr))
+
+    def resize_vmap(self, src, in_cols, in_rows, dst) -> None:
+        _chk(lib().kt_resize_vmap(self.h, src.ptr, in_cols, in_rows, dst.ptr))
+
+    def resize_nmap(self, src, in_cols, in_rows, dst) -> None:
+        _chk(lib().kt_resize_nmap(self.h, src.ptr, in_cols, in_rows, dst.ptr))
+
+    def depth_to_metres(self, src, dst, cols, rows, cutoff) -> None:
+        _chk(lib().kt_depth_to_metres(self.h, src.ptr, dst.ptr, cols, rows, cutoff))
+
+    def bgr_to_intensity(self, src, dst, cols, rows) -> None:
+        _chk(lib().kt_bgr_to_intensity(self.h, src.ptr, dst.ptr, cols, rows))
+
+    def pyr_down_gauss_f32(self, src, scols, srows, dst) -> None:
+        _chk(lib().kt_pyr_down_gauss_f32(self.h, src.ptr, scols, srows, dst.ptr))
+
+    def pyr_down_gauss_u8(self, src, scols, srows, dst) -> None:
+        _chk(lib().kt_pyr_down_gauss_u8(self.h, src.ptr, scols, srows, dst.ptr))
+
+    def derivative_images(self, src, cols, rows, dx, dy) -> None:
+        _chk(lib().kt_derivative_images(self.h, src.ptr, cols, rows, dx.ptr, dy.ptr))
+
+    def project_to_cloud(self, depth, cols, rows, cloud, fx, fy, cx, cy, level) -> None:
+        _chk(lib().kt_project_to_cloud(self.h, depth.ptr, cols, rows, cloud.ptr, fx, fy, cx, cy, level))
+
+    # ---- tracking ------------------------------------------------------------------------------
+    def icp_step(self, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr: Intr, vmap_g_prev, nmap_g_prev, cols, rows,
+                 dist_thres, angle_thres) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        A = (C.c_float * 36)()
+        b = (C.c_float * 6)()
+        r = (C.c_float * 2)()
+        _chk(lib().kt_icp_step(self.h, C.byref(Mat33.from_np(Rcurr)), _fp(tcurr), vmap_curr.ptr, nmap_curr.ptr,
+                               C.byref(Mat33.from_np(Rprev_inv)), _fp(tprev), C.byref(intr), vmap_g_prev.ptr, nmap_g_prev.ptr,
+                               cols, rows, dist_thres, angle_thres, A, b, r))
+        return (np.array(A, dtype=np.float32).reshape(6, 6), np.array(b, dtype=np.float32), np.array(r, dtype=np.float32))
+
+    def rgb_residual(self, min_scale, dIdx, dIdy, last_depth, next_depth, last_image, next_image, cols, rows, corres,
+                     max_depth_delta, kt, krkinv) -> Tuple[int, int]:
+        sigma, count = C.c_int(0), C.c_int(0)
+        _chk(lib().kt_rgb_residual(self.h, min_scale, dIdx.ptr, dIdy.ptr, last_depth.ptr, next_depth.ptr, last_image.ptr,
+                                   next_image.ptr, cols, rows, corres.ptr, max_depth_delta, _fp(kt),
+                                   C.byref(Mat33.from_np(krkinv)), C.byref(sigma), C.byref(count)))
+        return sigma.value, count.value
+
+    def rgb_step(self, corres, sigma, cloud, fx, fy, dIdx, dIdy, sobel_scale, cols, rows) -> Tuple[np.ndarray, np.ndarray]:
+        A = (C.c_float * 36)()
+        b = (C.c_float * 6)()
+        _chk(lib().kt_rgb_step(self.h, corres.ptr, sigma, cloud.ptr, fx, fy, dIdx.ptr, dIdy.ptr, sobel_scale, cols, rows, A, b))
+        return np.array(A, dtype=np.float32).reshape(6, 6), np.array(b, dtype=np.float32)
+
+    # ---- volume --------------------------------------------------------------------------------
+    def init_volume(self, vol: DevBuf, N: int) -> None:
+        _chk(lib().kt_init_volume(self.h, vol.ptr, N))
+
+    def init_color_volume(self, cvol: DevBuf, N: int) -> None:
+        _chk(lib().kt_init_color_volume(self.h, cvol.ptr, N))
+
+    def integrate_tsdf(self, depth, cols, rows, intr: Intr, volume_size, Rcurr_inv, tcurr, tranc_dist, volume, depth_scaled,
+                       voxel_wrap, color_volume, colors, nmap_curr, angle_color, N) -> None:
+        _chk(lib().kt_integrate_tsdf(self.h, depth.ptr, cols, rows, C.byref(intr), _fp(volume_size), C.byref(Mat33.from_np(Rcurr_inv)),
+                                     _fp(tcurr), tranc_dist, volume.ptr, depth_scaled.ptr, _ip(voxel_wrap), color_volume.ptr,
+                                     colors.ptr, nmap_curr.ptr, int(angle_color), N))
+
+    def raycast(self, intr: Intr, Rcurr, tcurr, tranc_dist, volume_size, volume, vmap, nmap, cols, rows, voxel_wrap, vmap_color,
+                color_volume, N) -> None:
+        _chk(lib().kt_raycast(self.h, C.byref(intr), C.byref(Mat33.from_np(Rcurr)), _fp(tcurr), tranc_dist, _fp(volume_size),
+                              volume.ptr, vmap.ptr, nmap.ptr, cols, rows, _ip(voxel_wrap), vmap_color.ptr, color_volume.ptr, N))
+
+    def clear_volume(self, vol, elem_size, N, axis, back, current_wrap, delta_wrap) -> None:
+        _chk(lib().kt_clear_volume(self.h, vol.ptr, elem_size, N, axis, int(back), current_wrap, delta_wrap))
+
+    def extract_cloud_slice(self, volume, volume_size, out: DevBuf, cap: int, voxel_wrap, color_volume, minX, maxX, minY, maxY,
+                            minZ, maxZ, subsample, real_voxel_wrap, N) -> int:
+        n = _sz(0)
+        _chk(lib().kt_extract_cloud_slice(self.h, volume.ptr, _fp(volume_size), out.ptr, cap, _ip(voxel_wrap), color_volume.ptr,
+                                          minX, maxX, minY, maxY, minZ, maxZ, subsample, _ip(real_voxel_wrap), N, C.byref(n)))
+        return int(n.value)
+
+
+class Tracker:
+    """kt_tracker: device-resident KintinuousTracker::processFrame."""
+
+    STAGES = ("pyramid", "odometry", "shift", "integrate", "raycast", "resize", "tsdf23")
+
+    def __init__(self, ctx: Ctx, cfg: TrackerConfig):
+        self.ctx, self.cfg = ctx, cfg
+        h = _vp()
+        _chk(lib().kt_tracker_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def close(self) -> None:
+        if self.h:
+            lib().kt_tracker_destroy(self.h)
+            self.h = None
+
+    def reset(self) -> None:
+        _chk(lib().kt_tracker_reset(self.h))
+
+    def process_frame(self, depth_dev, rgb_dev, timestamp: int) -> None:
+        d = depth_dev.ptr if isinstance(depth_dev, DevBuf) else int(depth_dev)
+        r = rgb_dev.ptr if isinstance(rgb_dev, DevBuf) else int(rgb_dev)
+        _chk(lib().kt_tracker_process_frame(self.h, d, r, timestamp))
+
+    def process_frame_host(self, depth: np.ndarray, rgb: np.ndarray, timestamp: int) -> None:
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        _chk(lib().kt_tracker_process_frame_host(self.h, depth.ctypes.data, rgb.ctypes.data, timestamp))
+
+    def finalise(self) -> None:
+        _chk(lib().kt_tracker_finalise(self.h))
+
+    def pose(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        R, t, g = (C.c_float * 9)(), (C.c_float * 3)(), (C.c_float * 3)()
+        _chk(lib().kt_tracker_get_pose(self.h, R, t, g))
+        return np.array(R, dtype=np.float32).reshape(3, 3), np.array(t, dtype=np.float32), np.array(g, dtype=np.float32)
+
+    def num_poses(self) -> int:
+        return lib().kt_tracker_num_poses(self.h)
+
+    def dense_pose(self, i: int) -> Tuple[int, np.ndarray, bool]:
+        ts, p, il = _u64(0), (C.c_float * 16)(), C.c_int(0)
+        _chk(lib().kt_tracker_get_dense_pose(self.h, i, C.byref(ts), p, C.byref(il)))
+        return ts.value, np.array(p, dtype=np.float32).reshape(4, 4), bool(il.value)
+
+    def voxel_wrap(self) -> np.ndarray:
+        w = (C.c_int * 3)()
+        _chk(lib().kt_tracker_get_voxel_wrap(self.h, w))
+        return np.array(w, dtype=np.int32)
+
+    def num_slices(self) -> int:
+        return lib().kt_tracker_num_slices(self.h)
+
+    def slice(self, i: int) -> Tuple[np.ndarray, int]:
+        n, dim = _sz(0), C.c_int(0)
+        _chk(lib().kt_tracker_slice_info(self.h, i, C.byref(n), C.byref(dim)))
+        out = np.zeros(n.value, dtype=POINT_DTYPE)
+        if n.value:
+            _chk(lib().kt_tracker_slice_points(self.h, i, out.ctypes.data))
+        return out, dim.value
+
+    def volume(self) -> np.ndarray:
+        N = self.cfg.N
+        return self.ctx.download(lib().kt_tracker_volume(self.h), np.int16, (N, N, N))
+
+    def color_volume(self) -> np.ndarray:
+        N = self.cfg.N
+        return self.ctx.download(lib().kt_tracker_color_volume(self.h), np.uint8, (N, N, N, 4))
+
+    def vmap_g_prev(self, level: int = 0) -> np.ndarray:
+        c, r = self.cfg.cols >> level, self.cfg.rows >> level
+        return self.ctx.download(lib().kt_tracker_vmap_g_prev(self.h, level), np.float32, (3 * r, c))
+
+    def nmap_g_prev(self, level: int = 0) -> np.ndarray:
+        c, r = self.cfg.cols >> level, self.cfg.rows >> level
+        return self.ctx.download(lib().kt_tracker_nmap_g_prev(self.h, level), np.float32, (3 * r, c))
+
+    def trunc_dist(self) -> float:
+        return float(lib().kt_tracker_trunc_dist(self.h))
+
+    def enable_profiling(self, mode: int) -> None:
+        _chk(lib().kt_tracker_enable_profiling(self.h, mode))
+
+    def stage_ms(self) -> dict:
+        ms = (C.c_float * 7)()
+        n = (C.c_longlong * 7)()
+        _chk(lib().kt_tracker_stage_ms(self.h, ms))
+        _chk(lib().kt_tracker_stage_counts(self.h, n))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.STAGES)}
+
+    def enable_counts(self, on: bool) -> None:
+        _chk(lib().kt_tracker_enable_counts(self.h, int(on)))
+
+    def last_counts(self) -> Tuple[int, int]:
+        U, S = C.c_ulonglong(0), C.c_ulonglong(0)
+        _chk(lib().kt_tracker_last_counts(self.h, C.byref(U), C.byref(S)))
+        return int(U.value), int(S.value)
+
+    def export_poses_device(self, k: int, dst_ptr: int) -> None:
+        _chk(lib().kt_tracker_export_poses_device(self.h, k, dst_ptr))

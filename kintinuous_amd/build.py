@@ -1,0 +1,69 @@
+"""Builds libkt_hip.so (the HIP kernels + C-ABI) in-tree with hipcc for gfx950.
+
+No CPU fallback exists: if hipcc is missing this raises.  The .so is git-ignored but travels with the
+gpurun snapshot, so GPU boxes use the file built here.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+OUT = os.path.join(_HERE, "libkt_hip.so")
+BUILD_DIR = os.path.join(os.path.dirname(_HERE), "build")
+SOURCES = ["kt_context.hip", "kt_image.hip", "kt_volume.hip", "kt_track.hip", "kt_tracker.hip"]
+# -ffp-contract=off: a*b+c fuses only where __builtin_fmaf is written (bit-parity with the oracle);
+# IEEE division / sqrt are hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libkt_hip.so cannot be built (there is no CPU fallback)")
+
+
+def _deps():
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "kt_abi.h"))
+    return files
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(f) > t for f in _deps())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return OUT
+    cc = hipcc()
+    os.makedirs(BUILD_DIR, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(BUILD_DIR, os.path.splitext(src)[0] + ".o")
+        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+        if verbose and r.stderr:
+            sys.stderr.write(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,133 @@
+// kt_common.hpp -- shared host/device helpers for libkt_hip.so (gfx950 only).
+//
+// Arithmetic contract (matches oracle/kt_oracle.h, restated independently here): IEEE binary32,
+// correctly rounded '/' and sqrtf (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), built with
+// -ffp-contract=off so a*b+c fuses ONLY where __builtin_fmaf is written; rsqrtf -> 1/sqrtf;
+// __expf -> kt_expf (explicit fmaf chain); CUDA __float2int_r{n,z,d} semantics (saturate, NaN -> 0)
+// come for free from v_cvt_i32_f32.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kt_abi.h"
+
+#define KT_DIVISOR 32767                 // internal.h:237
+#define KT_RGB_VIEW_ANGLE_WEIGHT 0.75f   // internal.h:241
+#define KT_MAX_WEIGHT 128.0f             // tsdf_volume.cu:481-488
+#define KT_LEVELS 4                      // ICPOdometry.h:52
+
+struct kt_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    // scratch for reductions: per-block partials (double[blocks][32]) + final (float[32]) + ticket counter
+    double* red_partials;
+    float* red_out;        // device, 32 floats
+    float* red_out_host;   // pinned host mirror
+    unsigned int* counters;  // device: [0] ticket, [1] extract global count, [2..] spare
+    int* int_out_host;       // pinned, small
+    int red_max_blocks;
+};
+
+void kt_set_error(const char* fmt, ...);
+int kt_check(hipError_t e, const char* what, const char* file, int line);
+#define KT_HIP(expr)                                                        \
+    do {                                                                    \
+        int _s = kt_check((expr), #expr, __FILE__, __LINE__);               \
+        if (_s != KT_OK) return _s;                                         \
+    } while (0)
+#define KT_LAUNCH_CHECK() KT_HIP(hipGetLastError())
+#define KT_ARG(cond)                                                        \
+    do {                                                                    \
+        if (!(cond)) { kt_set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__); return KT_ERR_ARG; } \
+    } while (0)
+
+static inline int kt_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers ------------------------------------------------------------------------------
+#ifdef __HIPCC__
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ float kt_nan() { return __int_as_float(0x7fffffff); }  // limits.hpp quiet_NaN
+__device__ __forceinline__ bool kt_isnan(float x) { return x != x; }
+
+// v_cvt_i32_f32: truncates, saturates, NaN -> 0  (== CUDA cvt.r*i.s32.f32 after the rounding step)
+__device__ __forceinline__ int kt_cvt_i32(float x)
+{
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ int kt_f2i_rn(float x) { return kt_cvt_i32(__builtin_rintf(x)); }
+__device__ __forceinline__ int kt_f2i_rz(float x) { return kt_cvt_i32(x); }
+__device__ __forceinline__ int kt_f2i_rd(float x) { return kt_cvt_i32(__builtin_floorf(x)); }
+// float -> uchar, cvt.rzi.u8.f32: truncate, clamp [0,255], NaN -> 0
+__device__ __forceinline__ unsigned char kt_f2u8_rz(float x)
+{
+    int v = kt_cvt_i32(x);
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    return (unsigned char)v;
+}
+__device__ __forceinline__ short kt_f2s16_rz(float x)
+{
+    int v = kt_cvt_i32(x);
+    v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+    return (short)v;
+}
+
+// restatement of __expf (bilateral_pyrdown.cu:89); same steps as the oracle's kto_expf
+__device__ __forceinline__ float kt_expf(float x)
+{
+    float t = x * 1.44269504088896341f;
+    if (!(t >= -125.0f)) return 0.0f;
+    float n = __builtin_rintf(t);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
+    float r2 = r * r;
+    float e = __builtin_fmaf(p, r2, r) + 1.0f;
+    float s = __int_as_float(((int)n + 127) << 23);
+    return e * s;
+}
+
+// vector_math.hpp:53-61 with the mul+add contraction nvcc applies written out explicitly
+__device__ __forceinline__ float kt_dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.x, b.x, a.y * b.y)); }
+__device__ __forceinline__ f3 kt_cross(f3 a, f3 b)
+{
+    f3 o;
+    o.x = __builtin_fmaf(a.y, b.z, -(a.z * b.y));
+    o.y = __builtin_fmaf(a.z, b.x, -(a.x * b.z));
+    o.z = __builtin_fmaf(a.x, b.y, -(a.y * b.x));
+    return o;
+}
+__device__ __forceinline__ f3 kt_sub(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 kt_add(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 kt_mul(const kt_mat33& m, f3 v)
+{
+    f3 o;
+    o.x = __builtin_fmaf(m.m[2], v.z, __builtin_fmaf(m.m[0], v.x, m.m[1] * v.y));
+    o.y = __builtin_fmaf(m.m[5], v.z, __builtin_fmaf(m.m[3], v.x, m.m[4] * v.y));
+    o.z = __builtin_fmaf(m.m[8], v.z, __builtin_fmaf(m.m[6], v.x, m.m[7] * v.y));
+    return o;
+}
+__device__ __forceinline__ f3 kt_normalized(f3 v)
+{
+    float inv = 1.0f / __builtin_sqrtf(kt_dot(v, v));  // rsqrtf restated
+    return {v.x * inv, v.y * inv, v.z * inv};
+}
+
+// device.hpp:61-83
+__device__ __forceinline__ short kt_pack_tsdf(float tsdf)
+{
+    int v = kt_f2i_rz(tsdf * KT_DIVISOR);
+    v = v < -KT_DIVISOR ? -KT_DIVISOR : (v > KT_DIVISOR ? KT_DIVISOR : v);
+    return (short)v;
+}
+__device__ __forceinline__ float kt_unpack_tsdf(short v) { return (float)v / KT_DIVISOR; }
+#endif  // __HIPCC__

@@ -1,0 +1,407 @@
+// kt_image.hip -- image-side kernels for gfx950: bilateral depth filter (a1), depth pyramid (a2),
+// vertex / normal maps (a3, a4), rigid map transform (a5), map down-sampling (a13) and the RGB-D
+// odometry image pyramids (a10 helpers).  Reference: src/frontend/cuda/bilateral_pyrdown.cu, maps.cu.
+// Results are bit-identical to the oracle's restatement (same operation order, explicit fmaf sites).
+#include "kt_common.hpp"
+
+// ================================================================================================
+// a1  bilateralFilter -> bilateralKernel              bilateral_pyrdown.cu:59-99, 332-342
+// 16x16 output tile per 256-thread block, 28x28 input tile (radius 6 halo) staged once in LDS instead
+// of 169 global re-reads per pixel.  The tap loop keeps the reference's order (cy outer, cx inner) and
+// its clipped, upper-exclusive window (quirk A.5), so the float sums are bit-identical.
+// ================================================================================================
+#define KT_BIL_R 6
+#define KT_BIL_T 16
+#define KT_BIL_W (KT_BIL_T + 2 * KT_BIL_R)
+
+__global__ __launch_bounds__(256) void kt_bilateral_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int cols,
+                                                           int rows, float sigma_space2_inv_half, float sigma_color2_inv_half)
+{
+    __shared__ int tile[KT_BIL_W][KT_BIL_W + 1];
+    const int bx = blockIdx.x * KT_BIL_T, by = blockIdx.y * KT_BIL_T;
+    for (int i = threadIdx.x; i < KT_BIL_W * KT_BIL_W; i += 256) {
+        const int ty = i / KT_BIL_W, tx = i - ty * KT_BIL_W;
+        const int gx = bx + tx - KT_BIL_R, gy = by + ty - KT_BIL_R;
+        tile[ty][tx] = (gx >= 0 && gy >= 0 && gx < cols && gy < rows) ? (int)src[gy * cols + gx] : 0;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = bx + lx, y = by + ly;
+    if (x >= cols || y >= rows) return;
+    const int D = KT_BIL_R * 2 + 1;
+    const int value = tile[ly + KT_BIL_R][lx + KT_BIL_R];
+    const int tx = min(x - D / 2 + D, cols - 1);
+    const int ty = min(y - D / 2 + D, rows - 1);
+    float sum1 = 0, sum2 = 0;
+    for (int cy = max(y - D / 2, 0); cy < ty; ++cy) {
+        const int* row = tile[cy - by + KT_BIL_R];
+        const int dy2 = (y - cy) * (y - cy);
+        for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
+            const int tmp = row[cx - bx + KT_BIL_R];
+            const float space2 = (float)((x - cx) * (x - cx) + dy2);
+            const float color2 = (float)(int)((unsigned)(value - tmp) * (unsigned)(value - tmp));
+            const float weight = kt_expf(-__builtin_fmaf(space2, sigma_space2_inv_half, color2 * sigma_color2_inv_half));
+            sum1 = __builtin_fmaf((float)tmp, weight, sum1);
+            sum2 += weight;
+        }
+    }
+    const int res = kt_f2i_rn(sum1 / sum2);
+    dst[y * cols + x] = (uint16_t)max(0, min(res, 32767));
+}
+
+extern "C" int kt_bilateral_filter(kt_ctx* c, const uint16_t* src, uint16_t* dst, int cols, int rows)
+{
+    KT_ARG(c && src && dst && cols > 0 && rows > 0);
+    const float sigma_color = 30.0f, sigma_space = 4.5f;  // bilateral_pyrdown.cu:56-57
+    hipLaunchKernelGGL(kt_bilateral_kernel, dim3(kt_div_up(cols, KT_BIL_T), kt_div_up(rows, KT_BIL_T)), dim3(256), 0, c->stream, src,
+                       dst, cols, rows, 0.5f / (sigma_space * sigma_space), 0.5f / (sigma_color * sigma_color));
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// ================================================================================================
+// a2  pyrDown -> pyrDownGaussKernel                   bilateral_pyrdown.cu:101-136, 344-354
+// ================================================================================================
+__global__ __launch_bounds__(256) void kt_pyr_down_kernel(const uint16_t* __restrict__ src, int scols, int srows,
+                                                          uint16_t* __restrict__ dst, int dcols, int drows)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dcols || y >= drows) return;
+    const int D = 5;
+    const float sigma_color = 30.0f;
+    const int center = src[(2 * y) * scols + 2 * x];
+    const int x_mi = max(0, 2 * x - D / 2) - 2 * x;
+    const int y_mi = max(0, 2 * y - D / 2) - 2 * y;
+    const int x_ma = min(scols, 2 * x - D / 2 + D) - 2 * x;
+    const int y_ma = min(srows, 2 * y - D / 2 + D) - 2 * y;
+    float sum = 0, wall = 0;
+    for (int yi = y_mi; yi < y_ma; ++yi)
+        for (int xi = x_mi; xi < x_ma; ++xi) {
+            const int val = src[(2 * y + yi) * scols + 2 * x + xi];
+            if ((float)abs(val - center) < 3 * sigma_color) {
+                const int axi = abs(xi), ayi = abs(yi);
+                const float wx = axi == 0 ? 0.375f : (axi == 1 ? 0.25f : 0.0625f);
+                const float wy = ayi == 0 ? 0.375f : (ayi == 1 ? 0.25f : 0.0625f);
+                sum = __builtin_fmaf((float)val * wx, wy, sum);
+                wall = __builtin_fmaf(wx, wy, wall);
+            }
+        }
+    dst[y * dcols + x] = (uint16_t)kt_f2i_rz(sum / wall);  // static_cast<int>: truncation (quirk A.6)
+}
+
+extern "C" int kt_pyr_down(kt_ctx* c, const uint16_t* src, int scols, int srows, uint16_t* dst)
+{
+    KT_ARG(c && src && dst && scols > 1 && srows > 1);
+    const int dcols = scols / 2, drows = srows / 2;
+    hipLaunchKernelGGL(kt_pyr_down_kernel, dim3(kt_div_up(dcols, 64), kt_div_up(drows, 4)), dim3(256), 0, c->stream, src, scols, srows,
+                       dst, dcols, drows);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// ================================================================================================
+// a3  createVMap -> computeVmapKernel                 maps.cu:56-80, 122-137
+// ================================================================================================
+__global__ __launch_bounds__(256) void kt_vmap_kernel(const uint16_t* __restrict__ depth, float* __restrict__ vmap, int cols, int rows,
+                                                      float fx_inv, float fy_inv, float cx, float cy)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= cols || v >= rows) return;
+    const float z = (float)depth[v * cols + u] / 1000.f;
+    if (z != 0) {
+        vmap[v * cols + u] = z * ((float)u - cx) * fx_inv;
+        vmap[(v + rows) * cols + u] = z * ((float)v - cy) * fy_inv;
+        vmap[(v + 2 * rows) * cols + u] = z;
+    } else
+        vmap[v * cols + u] = kt_nan();  // x plane only (quirk A.7)
+}
+
+extern "C" int kt_create_vmap(kt_ctx* c, const kt_intr* intr, const uint16_t* depth, int cols, int rows, float* vmap)
+{
+    KT_ARG(c && intr && depth && vmap && cols > 0 && rows > 0);
+    hipLaunchKernelGGL(kt_vmap_kernel, dim3(kt_div_up(cols, 64), kt_div_up(rows, 4)), dim3(256), 0, c->stream, depth, vmap, cols, rows,
+                       1.f / intr->fx, 1.f / intr->fy, intr->cx, intr->cy);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// ================================================================================================
+// a4  createNMap -> computeNmapKernel                 maps.cu:82-120, 139-154
+// ================================================================================================
+__global__ __launch_bounds__(256) void kt_nmap_kernel(int rows, int cols, const float* __restrict__ vmap, float* __restrict__ nmap)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= cols || v >= rows) return;
+    if (u == cols - 1 || v == rows - 1) { nmap[v * cols + u] = kt_nan(); return; }
+    f3 v00, v01, v10;
+    v00.x = vmap[v * cols + u];
+    v01.x = vmap[v * cols + u + 1];
+    v10.x = vmap[(v + 1) * cols + u];
+    if (!kt_isnan(v00.x) && !kt_isnan(v01.x) && !kt_isnan(v10.x)) {
+        v00.y = vmap[(v + rows) * cols + u];
+        v01.y = vmap[(v + rows) * cols + u + 1];
+        v10.y = vmap[(v + 1 + rows) * cols + u];
+        v00.z = vmap[(v + 2 * rows) * cols + u];
+        v01.z = vmap[(v + 2 * rows) * cols + u + 1];
+        v10.z = vmap[(v + 1 + 2 * rows) * cols + u];
+        const f3 r = kt_normalized(kt_cross(kt_sub(v01, v00), kt_sub(v10, v00)));
+        nmap[v * cols + u] = r.x;
+        nmap[(v + rows) * cols + u] = r.y;
+        nmap[(v + 2 * rows) * cols + u] = r.z;
+    } else
+        nmap[v * cols + u] = kt_nan();
+}
+
+extern "C" int kt_create_nmap(kt_ctx* c, const float* vmap, int cols, int rows, float* nmap)
+{
+    KT_ARG(c && vmap && nmap && cols > 0 && rows > 0);
+    hipLaunchKernelGGL(kt_nmap_kernel, dim3(kt_div_up(cols, 64), kt_div_up(rows, 4)), dim3(256), 0, c->stream, rows, cols, vmap, nmap);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// ================================================================================================
+// a5  tranformMaps -> tranformMapsKernel              maps.cu:156-223
+// ================================================================================================
+__global__ __launch_bounds__(256) void kt_transform_maps_kernel(int rows, int cols, const float* __restrict__ vmap_src,
+                                                                const float* __restrict__ nmap_src, const kt_mat33 R, const f3 t,
+                                                                float* __restrict__ vmap_dst, float* __restrict__ nmap_dst)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    f3 vs;
+    float vd0 = kt_nan();
+    vs.x = vmap_src[y * cols + x];
+    if (!kt_isnan(vs.x)) {
+        vs.y = vmap_src[(y + rows) * cols + x];
+        vs.z = vmap_src[(y + 2 * rows) * cols + x];
+        const f3 o = kt_add(kt_mul(R, vs), t);
+        vd0 = o.x;
+        vmap_dst[(y + rows) * cols + x] = o.y;
+        vmap_dst[(y + 2 * rows) * cols + x] = o.z;
+    }
+    vmap_dst[y * cols + x] = vd0;
+    f3 ns;
+    float nd0 = kt_nan();
+    ns.x = nmap_src[y * cols + x];
+    if (!kt_isnan(ns.x)) {
+        ns.y = nmap_src[(y + rows) * cols + x];
+        ns.z = nmap_src[(y + 2 * rows) * cols + x];
+        const f3 o = kt_mul(R, ns);
+        nd0 = o.x;
+        nmap_dst[(y + rows) * cols + x] = o.y;
+        nmap_dst[(y + 2 * rows) * cols + x] = o.z;
+    }
+    nmap_dst[y * cols + x] = nd0;
+}
+
+extern "C" int kt_transform_maps(kt_ctx* c, const float* vmap_src, const float* nmap_src, int cols, int rows, const kt_mat33* Rmat,
+                                 const float tvec[3], float* vmap_dst, float* nmap_dst)
+{
+    KT_ARG(c && vmap_src && nmap_src && Rmat && tvec && vmap_dst && nmap_dst && cols > 0 && rows > 0);
+    const f3 t = {tvec[0], tvec[1], tvec[2]};
+    hipLaunchKernelGGL(kt_transform_maps_kernel, dim3(kt_div_up(cols, 64), kt_div_up(rows, 4)), dim3(256), 0, c->stream, rows, cols,
+                       vmap_src, nmap_src, *Rmat, t, vmap_dst, nmap_dst);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// ================================================================================================
+// a13 resizeVMap / resizeNMap -> resizeMapKernel<normalize>   maps.cu:225-308
+// ================================================================================================
+template <bool NORMALIZE>
+__global__ __launch_bounds__(256) void kt_resize_map_kernel(int drows, int dcols, int srows, int scols, const float* __restrict__ in,
+                                                            float* __restrict__ out)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dcols || y >= drows) return;
+    const int xs = x * 2, ys = y * 2;
+    // each lane reads 2 adjacent floats per row: 8-byte loads
+    const float2 x0 = *(const float2*)&in[(ys + 0) * scols + xs];
+    const float2 x1 = *(const float2*)&in[(ys + 1) * scols + xs];
+    if (kt_isnan(x0.x) || kt_isnan(x0.y) || kt_isnan(x1.x) || kt_isnan(x1.y)) {
+        out[y * dcols + x] = kt_nan();
+        return;
+    }
+    f3 n;
+    n.x = (x0.x + x0.y + x1.x + x1.y) / 4;
+    const float2 y0 = *(const float2*)&in[(ys + srows + 0) * scols + xs];
+    const float2 y1 = *(const float2*)&in[(ys + srows + 1) * scols + xs];
+    n.y = (y0.x + y0.y + y1.x + y1.y) / 4;
+    const float2 z0 = *(const float2*)&in[(ys + 2 * srows + 0) * scols + xs];
+    const float2 z1 = *(const float2*)&in[(ys + 2 * srows + 1) * scols + xs];
+    n.z = (z0.x + z0.y + z1.x + z1.y) / 4;
+    if (NORMALIZE) n = kt_normalized(n);
+    out[y * dcols + x] = n.x;
+    out[(y + drows) * dcols + x] = n.y;
+    out[(y + 2 * drows) * dcols + x] = n.z;
+}
+
+static int kt_resize_map(kt_ctx* c, const float* in, int in_cols, int in_rows, float* out, bool normalize)
+{
+    KT_ARG(c && in && out && in_cols > 1 && in_rows > 1 && (in_cols % 2) == 0);
+    const int dcols = in_cols / 2, drows = in_rows / 2;
+    dim3 g(kt_div_up(dcols, 64), kt_div_up(drows, 4)), b(256);
+    if (normalize) hipLaunchKernelGGL(kt_resize_map_kernel<true>, g, b, 0, c->stream, drows, dcols, in_rows, in_cols, in, out);
+    else hipLaunchKernelGGL(kt_resize_map_kernel<false>, g, b, 0, c->stream, drows, dcols, in_rows, in_cols, in, out);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+extern "C" int kt_resize_vmap(kt_ctx* c, const float* in, int in_cols, int in_rows, float* out) { return kt_resize_map(c, in, in_cols, in_rows, out, false); }
+extern "C" int kt_resize_nmap(kt_ctx* c, const float* in, int in_cols, int in_rows, float* out) { return kt_resize_map(c, in, in_cols, in_rows, out, true); }
+
+// ================================================================================================
+// a10 helpers: RGB-D image pyramids
+// ================================================================================================
+// shortDepthToMetres -> short2FloatKernel             bilateral_pyrdown.cu:231-242, 404-411
+__global__ __launch_bounds__(256) void kt_depth_to_metres_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, int n, int cutoff)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = src[i];
+    dst[i] = (s > cutoff || s <= 0) ? kt_nan() : ((float)s) / 1000.0f;
+}
+extern "C" int kt_depth_to_metres(kt_ctx* c, const uint16_t* src, float* dst, int cols, int rows, int cutoff)
+{
+    KT_ARG(c && src && dst && cols > 0 && rows > 0);
+    const int n = cols * rows;
+    hipLaunchKernelGGL(kt_depth_to_metres_kernel, dim3(kt_div_up(n, 256)), dim3(256), 0, c->stream, src, dst, n, cutoff);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// imageBGRToIntensity -> bgr2IntensityKernel          bilateral_pyrdown.cu:244-258, 413-420
+__global__ __launch_bounds__(256) void kt_bgr_to_intensity_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float r = (float)src[3 * i + 0], g = (float)src[3 * i + 1], b = (float)src[3 * i + 2];  // PixelRGB r,g,b = bytes 0,1,2
+    const int value = kt_f2i_rz(__builtin_fmaf(g, 0.587f, __builtin_fmaf(r, 0.114f, b * 0.299f)));
+    dst[i] = (uint8_t)value;
+}
+extern "C" int kt_bgr_to_intensity(kt_ctx* c, const uint8_t* src, uint8_t* dst, int cols, int rows)
+{
+    KT_ARG(c && src && dst && cols > 0 && rows > 0);
+    const int n = cols * rows;
+    hipLaunchKernelGGL(kt_bgr_to_intensity_kernel, dim3(kt_div_up(n, 256)), dim3(256), 0, c->stream, src, dst, n);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+__device__ __forceinline__ float kt_gauss5(int r, int cidx)
+{
+    // {1,4,6,4,1} outer {1,4,6,4,1}  (bilateral_pyrdown.cu:363-367)
+    const int a = r == 0 || r == 4 ? 1 : (r == 2 ? 6 : 4);
+    const int b = cidx == 0 || cidx == 4 ? 1 : (cidx == 2 ? 6 : 4);
+    return (float)(a * b);
+}
+
+// pyrDownGaussF -> pyrDownKernelGaussF                bilateral_pyrdown.cu:199-229, 356-377
+// pyrDownUcharGauss -> pyrDownKernelIntensityGauss    bilateral_pyrdown.cu:171-197, 379-402
+template <typename T>
+__global__ __launch_bounds__(256) void kt_pyr_down_gauss_kernel(const T* __restrict__ src, int scols, int srows, T* __restrict__ dst,
+                                                                int dcols, int drows)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dcols || y >= drows) return;
+    const int D = 5;
+    const int tx = min(2 * x - D / 2 + D, scols - 1);  // exclusive and clipped to cols-1 (quirk A.5)
+    const int ty = min(2 * y - D / 2 + D, srows - 1);
+    float sum = 0;
+    int count = 0;
+    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+            const float g = kt_gauss5(ty - cy - 1, tx - cx - 1);  // weights indexed from the clipped bound
+            if (sizeof(T) == 4) {
+                const float s = (float)src[cy * scols + cx];
+                if (!kt_isnan(s)) {
+                    sum = __builtin_fmaf(s, g, sum);
+                    count = kt_f2i_rz((float)count + g);
+                }
+            } else {
+                sum = __builtin_fmaf((float)src[cy * scols + cx], g, sum);
+                count = kt_f2i_rz((float)count + g);
+            }
+        }
+    if (sizeof(T) == 4) dst[y * dcols + x] = (T)(sum / (float)count);
+    else dst[y * dcols + x] = (T)kt_f2u8_rz(sum / (float)count);
+}
+extern "C" int kt_pyr_down_gauss_f32(kt_ctx* c, const float* src, int scols, int srows, float* dst)
+{
+    KT_ARG(c && src && dst && scols > 1 && srows > 1);
+    const int dcols = scols / 2, drows = srows / 2;
+    hipLaunchKernelGGL(kt_pyr_down_gauss_kernel<float>, dim3(kt_div_up(dcols, 64), kt_div_up(drows, 4)), dim3(256), 0, c->stream, src, scols,
+                       srows, dst, dcols, drows);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+extern "C" int kt_pyr_down_gauss_u8(kt_ctx* c, const uint8_t* src, int scols, int srows, uint8_t* dst)
+{
+    KT_ARG(c && src && dst && scols > 1 && srows > 1);
+    const int dcols = scols / 2, drows = srows / 2;
+    hipLaunchKernelGGL(kt_pyr_down_gauss_kernel<uint8_t>, dim3(kt_div_up(dcols, 64), kt_div_up(drows, 4)), dim3(256), 0, c->stream, src, scols,
+                       srows, dst, dcols, drows);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// computeDerivativeImages -> applyKernel              bilateral_pyrdown.cu:271-330
+__global__ __launch_bounds__(256) void kt_derivative_kernel(const uint8_t* __restrict__ src, int cols, int rows, int16_t* __restrict__ dx,
+                                                            int16_t* __restrict__ dy)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const float a = (float)0.52201, b = (float)0.79451;
+    const float gsx[9] = {a, 0.f, -a, b, -0.f, -b, a, 0.f, -a};
+    const float gsy[9] = {a, b, a, 0.f, 0.f, 0.f, -a, -b, -a};
+    float dxVal = 0, dyVal = 0;
+    int k = 8;  // border taps consume the kernel from index 8 downwards (quirk)
+    for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); j++)
+        for (int i = max(x - 1, 0); i <= min(x + 1, cols - 1); i++) {
+            const float s = (float)src[j * cols + i];
+            dxVal = __builtin_fmaf(s, gsx[k], dxVal);
+            dyVal = __builtin_fmaf(s, gsy[k], dyVal);
+            --k;
+        }
+    dx[y * cols + x] = kt_f2s16_rz(dxVal);
+    dy[y * cols + x] = kt_f2s16_rz(dyVal);
+}
+extern "C" int kt_derivative_images(kt_ctx* c, const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy)
+{
+    KT_ARG(c && src && dx && dy && cols > 0 && rows > 0);
+    hipLaunchKernelGGL(kt_derivative_kernel, dim3(kt_div_up(cols, 64), kt_div_up(rows, 4)), dim3(256), 0, c->stream, src, cols, rows, dx, dy);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// projectToPointCloud -> projectPointsKernel          maps.cu:310-344
+__global__ __launch_bounds__(256) void kt_project_kernel(const float* __restrict__ depth, int cols, int rows, float* __restrict__ cloud,
+                                                         double invFx, double invFy, double cx, double cy)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const float z = depth[y * cols + x];
+    float* o = &cloud[3 * (y * cols + x)];
+    o[0] = (float)(((double)x - cx) * (double)z * invFx);
+    o[1] = (float)(((double)y - cy) * (double)z * invFy);
+    o[2] = z;
+}
+extern "C" int kt_project_to_cloud(kt_ctx* c, const float* depth, int cols, int rows, float* cloud, double fx, double fy, double cx,
+                                   double cy, int level)
+{
+    KT_ARG(c && depth && cloud && cols > 0 && rows > 0 && level >= 0);
+    const int div = 1 << level;  // IntrDoublePrecision::operator() internal.h:268-272
+    const double lfx = fx / div, lfy = fy / div, lcx = cx / div, lcy = cy / div;
+    hipLaunchKernelGGL(kt_project_kernel, dim3(kt_div_up(cols, 64), kt_div_up(rows, 4)), dim3(256), 0, c->stream, depth, cols, rows, cloud,
+                       1.0f / lfx, 1.0f / lfy, lcx, lcy);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}

@@ -1,0 +1,26 @@
+// kt_internal.hpp -- library-internal (non-ABI) entry points shared between the .hip translation units.
+#pragma once
+
+#include "kt_track.hpp"
+
+int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
+                           const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
+                           int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
+                           const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev);
+int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const float tcurr[3], float tranc_dist,
+                    const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
+                    const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,
+                    unsigned long long* steps_dev);
+int kt_extract_cloud_slice_async(kt_ctx* c, const int16_t* volume, const float volume_size[3], kt_point_xyzrgb* output,
+                                 size_t output_capacity, const int voxel_wrap[3], const uint8_t* color_volume, int minX, int maxX,
+                                 int minY, int maxY, int minZ, int maxZ, int subsample, const int real_voxel_wrap[3], int N,
+                                 unsigned int* count_dev);
+int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
+                       const float* vmap_g_prev, const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres,
+                       int mode);
+int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
+                           const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
+                           int cols, int rows, kt_dataterm* corres_img, float max_depth_delta);
+int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corres_img, const float* cloud, float fx, float fy,
+                       const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows, int mode,
+                       const kt_level_k* next_k);

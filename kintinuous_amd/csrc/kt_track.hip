@@ -1,0 +1,490 @@
+// kt_track.hip -- tracking reductions for gfx950: projective point-to-plane ICP (a6), RGB-D photometric
+// correspondence (a8) and its Jacobian reduction (a9), plus the device-side Gauss-Newton step (a7/a10:
+// 6x6 LDL^T in double, Rodrigues, SE(3) update) that lets all iterations of a frame run back to back
+// without a host round trip.  Reference: src/frontend/cuda/reduce.cu, src/frontend/ICPOdometry.cpp,
+// RGBDOdometry.cpp, OdometryProvider.h.
+//
+// Reduction shape (wave64): every thread accumulates its pixels' 29 products in float (as the reference
+// does per thread), a 64-lane __shfl_down tree folds the wave, the 4 waves of a block and then the
+// blocks are folded in double in a FIXED order (deterministic run to run).  The last block to finish
+// (device-scope ticket, agent-scope release/acquire per cdna_hip_programming.md Guideline 16) produces the
+// final sums and, in the device-resident path, solves and updates the pose.  The summation tree differs
+// from the reference's 32-lane/64x128 geometry, so A and b agree with the oracle to float rounding
+// (~1e-6 relative), not bit for bit; everything per-pixel is bit-identical.
+#include "kt_internal.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// block / grid reduction
+// ------------------------------------------------------------------------------------------------
+#define KT_RED_THREADS 256
+#define KT_RED_SLOTS 32   // 29 used
+
+__device__ __forceinline__ float kt_wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Folds per-thread acc[29] over the grid.  Returns true (block-uniformly) in the block that retired last;
+// in that block total[0..28] (LDS, double) holds the grid sums.
+__device__ __forceinline__ bool kt_grid_reduce29(const float (&acc)[29], double* __restrict__ partials, unsigned int* __restrict__ ticket,
+                                                 double (&total)[KT_RED_SLOTS])
+{
+    __shared__ float wave_part[4][KT_RED_SLOTS];
+    __shared__ double fold[8][KT_RED_SLOTS];
+    __shared__ bool is_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 29; ++k) {
+        const float s = kt_wave_sum(acc[k]);
+        if (lane == 0) wave_part[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 29) {
+        const int k = threadIdx.x;
+        const double s = (((double)wave_part[0][k] + (double)wave_part[1][k]) + (double)wave_part[2][k]) + (double)wave_part[3][k];
+        partials[(size_t)blockIdx.x * KT_RED_SLOTS + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // publish this block's partials: agent-scope release, drain, then the ticket (device-scope atomic)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = atomicAdd(ticket, 1u);
+        is_last = (t == gridDim.x - 1);
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale lines before re-reading partials
+            *ticket = 0;                                        // re-arm for the next launch on this stream
+        }
+    }
+    __syncthreads();
+    if (!is_last) return false;
+    // fixed-order fold over blocks: 8 interleaved chains per component, then a fixed 8-way tree
+    const int k = threadIdx.x & 31, j = threadIdx.x >> 5;
+    double s = 0.0;
+    if (k < 29)
+        for (int b = j; b < (int)gridDim.x; b += 8) s += partials[(size_t)b * KT_RED_SLOTS + k];
+    fold[j][k] = s;
+    __syncthreads();
+    if (threadIdx.x < KT_RED_SLOTS) {
+        const int c = threadIdx.x;
+        total[c] = ((fold[0][c] + fold[1][c]) + (fold[2][c] + fold[3][c])) + ((fold[4][c] + fold[5][c]) + (fold[6][c] + fold[7][c]));
+    }
+    __syncthreads();
+    return true;
+}
+
+__device__ __forceinline__ void kt_outer29(const float (&row)[7], bool found, float (&acc)[29])
+{
+    // JtJJtrSE3 products, reduce.cu:279-319
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = i; j < 7; ++j) acc[s++] += row[i] * row[j];
+    acc[28] += found ? 1.0f : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a6  icpStep -> icpKernel + reduceSum                reduce.cu:186-419
+// ------------------------------------------------------------------------------------------------
+struct kt_icp_args {
+    const float* vmap_curr; const float* nmap_curr;
+    const float* vmap_g_prev; const float* nmap_g_prev;
+    kt_intr intr;
+    int cols, rows;
+    float dist_thres, angle_thres;
+    // pose: either immediate (host path) or read from the device state (device-resident path)
+    kt_mat33 Rcurr; float tcurr[3];
+    kt_mat33 Rprev_inv; float tprev[3];
+    kt_track_state* state;     // nullptr on the host path
+    double* partials; unsigned int* ticket;
+    float* out29;              // host path: 29 floats
+    int mode;                  // KT_MODE_*
+};
+
+__device__ __forceinline__ void kt_icp_pixel(const kt_icp_args& a, const kt_mat33& Rcurr, const f3 tcurr, const kt_mat33& Rprev_inv,
+                                             const f3 tprev, int i, float (&acc)[29])
+{
+    const int cols = a.cols, rows = a.rows;
+    const int y = i / cols, x = i - y * cols;
+    float row[7] = {0, 0, 0, 0, 0, 0, 0};
+    bool found = false;
+    // search(): reduce.cu:213-254
+    const f3 vcurr = {a.vmap_curr[y * cols + x], a.vmap_curr[(y + rows) * cols + x], a.vmap_curr[(y + 2 * rows) * cols + x]};
+    const f3 vcurr_g = kt_add(kt_mul(Rcurr, vcurr), tcurr);
+    const f3 vcurr_cp = kt_mul(Rprev_inv, kt_sub(vcurr_g, tprev));
+    const int ux = kt_f2i_rn(vcurr_cp.x * a.intr.fx / vcurr_cp.z + a.intr.cx);
+    const int uy = kt_f2i_rn(vcurr_cp.y * a.intr.fy / vcurr_cp.z + a.intr.cy);
+    if (!(ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0)) {
+        const f3 vprev_g = {a.vmap_g_prev[uy * cols + ux], a.vmap_g_prev[(uy + rows) * cols + ux], a.vmap_g_prev[(uy + 2 * rows) * cols + ux]};
+        const f3 ncurr = {a.nmap_curr[y * cols + x], a.nmap_curr[(y + rows) * cols + x], a.nmap_curr[(y + 2 * rows) * cols + x]};
+        const f3 ncurr_g = kt_mul(Rcurr, ncurr);
+        const f3 nprev_g = {a.nmap_g_prev[uy * cols + ux], a.nmap_g_prev[(uy + rows) * cols + ux], a.nmap_g_prev[(uy + 2 * rows) * cols + ux]};
+        const f3 dv = kt_sub(vprev_g, vcurr_g);
+        const float dist = __builtin_sqrtf(kt_dot(dv, dv));
+        const f3 cr = kt_cross(ncurr_g, nprev_g);
+        const float sine = __builtin_sqrtf(kt_dot(cr, cr));
+        found = (sine < a.angle_thres && dist <= a.dist_thres && !kt_isnan(ncurr.x) && !kt_isnan(nprev_g.x));
+        if (found) {
+            // getProducts(): reduce.cu:256-277
+            const f3 s_cp = kt_mul(Rprev_inv, kt_sub(vcurr_g, tprev));
+            const f3 d_cp = kt_mul(Rprev_inv, kt_sub(vprev_g, tprev));
+            const f3 n_cp = kt_mul(Rprev_inv, nprev_g);
+            const f3 sxn = kt_cross(s_cp, n_cp);
+            row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
+            row[3] = sxn.x; row[4] = sxn.y; row[5] = sxn.z;
+            row[6] = kt_dot(n_cp, kt_sub(s_cp, d_cp));
+        }
+    }
+    kt_outer29(row, found, acc);
+}
+
+__global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_args a)
+{
+    kt_mat33 Rcurr, Rprev_inv;
+    f3 tcurr, tprev;
+    if (a.state) {
+        // pose produced by the previous iteration's epilogue (kernel boundary orders the accesses)
+        for (int k = 0; k < 9; ++k) { Rcurr.m[k] = a.state->Rcurr[k]; Rprev_inv.m[k] = a.state->Rprev_inv[k]; }
+        tcurr = {a.state->tcurr[0], a.state->tcurr[1], a.state->tcurr[2]};
+        tprev = {a.state->tprev[0], a.state->tprev[1], a.state->tprev[2]};
+    } else {
+        Rcurr = a.Rcurr; Rprev_inv = a.Rprev_inv;
+        tcurr = {a.tcurr[0], a.tcurr[1], a.tcurr[2]};
+        tprev = {a.tprev[0], a.tprev[1], a.tprev[2]};
+    }
+    float acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) acc[k] = 0.f;
+    const int n = a.cols * a.rows;
+    for (int i = blockIdx.x * KT_RED_THREADS + threadIdx.x; i < n; i += gridDim.x * KT_RED_THREADS)
+        kt_icp_pixel(a, Rcurr, tcurr, Rprev_inv, tprev, i, acc);
+    __shared__ double total[KT_RED_SLOTS];
+    if (!kt_grid_reduce29(acc, a.partials, a.ticket, total)) return;
+    if (a.mode == KT_MODE_HOST) {
+        if (threadIdx.x < 29) a.out29[threadIdx.x] = (float)total[threadIdx.x];
+    } else if (threadIdx.x == 0) {
+        float h[29];
+        for (int k = 0; k < 29; ++k) h[k] = (float)total[k];
+        if (a.mode == KT_MODE_ICP_SOLVE) {
+            // ICPOdometry.cpp:127-178
+            __shared__ double dA[36], db[6];
+            kt_unpack29_d(h, dA, db);
+            a.state->last_residual[0] = h[27];
+            a.state->last_residual[1] = h[28];
+            kt_solve_and_update(a.state, dA, db);
+        } else {  // KT_MODE_ICP_STASH: joint RGB-D + ICP, the rgb kernel's epilogue combines and solves
+            for (int k = 0; k < 29; ++k) a.state->icp29[k] = h[k];
+        }
+    }
+}
+
+static int kt_red_grid(int n)
+{
+    int g = kt_div_up(n, KT_RED_THREADS);
+    if (g > 512) g = 512;
+    if (g < 1) g = 1;
+    return g;
+}
+
+int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
+{
+    a.partials = c->red_partials;
+    a.ticket = &c->counters[0];
+    hipLaunchKernelGGL(kt_icp_kernel, dim3(kt_red_grid(a.cols * a.rows)), dim3(KT_RED_THREADS), 0, c->stream, a);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// host unpack of the 29 sums, reduce.cu:401-418
+static void kt_unpack29_host(const float* h, float* A, float* b, float* residual)
+{
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const float value = h[shift++];
+            if (j == 6) b[i] = value;
+            else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+    if (residual) { residual[0] = h[27]; residual[1] = h[28]; }
+}
+
+extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3], const float* vmap_curr, const float* nmap_curr,
+                           const kt_mat33* Rprev_inv, const float tprev[3], const kt_intr* intr, const float* vmap_g_prev,
+                           const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres, float* A_host,
+                           float* b_host, float* residual_host)
+{
+    KT_ARG(c && Rcurr && tcurr && vmap_curr && nmap_curr && Rprev_inv && tprev && intr && vmap_g_prev && nmap_g_prev && A_host && b_host);
+    KT_ARG(cols > 0 && rows > 0);
+    kt_icp_args a;
+    a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
+    a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
+    a.Rcurr = *Rcurr; a.Rprev_inv = *Rprev_inv;
+    for (int k = 0; k < 3; ++k) { a.tcurr[k] = tcurr[k]; a.tprev[k] = tprev[k]; }
+    a.state = nullptr; a.out29 = c->red_out; a.mode = KT_MODE_HOST;
+    int s = kt_icp_launch(c, a);
+    if (s != KT_OK) return s;
+    KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * 29, hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    kt_unpack29_host(c->red_out_host, A_host, b_host, residual_host);
+    return KT_OK;
+}
+
+int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
+                       const float* vmap_g_prev, const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres,
+                       int mode)
+{
+    kt_icp_args a;
+    a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
+    a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
+    a.state = state; a.out29 = nullptr; a.mode = mode;
+    return kt_icp_launch(c, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8  computeRgbResidual -> residualKernel            reduce.cu:668-864
+// int2 {count, sum diff^2} reduction: integer sums are order-independent, one atomic pair per wave.
+// ------------------------------------------------------------------------------------------------
+struct kt_residual_args {
+    float min_scale;
+    const int16_t* dIdx; const int16_t* dIdy;
+    const float* last_depth; const float* next_depth;
+    const uint8_t* last_image; const uint8_t* next_image;
+    kt_dataterm* corres;
+    float max_depth_delta;
+    float kt_[3]; kt_mat33 krkinv;
+    kt_track_state* state;   // device path: krkinv / kt read from the state, sigma written back
+    int cols, rows;
+    int* out2;               // {count, sigma}; must be zero at launch
+    unsigned int* ticket;
+};
+
+__global__ __launch_bounds__(256) void kt_residual_kernel(const kt_residual_args a)
+{
+    const int cols = a.cols, rows = a.rows, n = cols * rows;
+    float K[9], kt[3];
+    if (a.state) {
+        for (int q = 0; q < 9; ++q) K[q] = a.state->krkinv[q];
+        for (int q = 0; q < 3; ++q) kt[q] = a.state->kt[q];
+    } else {
+        for (int q = 0; q < 9; ++q) K[q] = a.krkinv.m[q];
+        for (int q = 0; q < 3; ++q) kt[q] = a.kt_[q];
+    }
+    int cnt = 0;
+    unsigned int sig = 0;  // wraps modulo 2^32 like the reference's int sum
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        const int i = k / cols, j0 = k - i * cols;
+        kt_dataterm corres;
+        corres.zero_x = corres.zero_y = corres.one_x = corres.one_y = 0;
+        corres.diff = 0.f;
+        corres.valid = 0;
+        corres.pad[0] = corres.pad[1] = corres.pad[2] = 0;
+        if (j0 < cols - 5 && i < rows - 1) {
+            bool valid = true;
+            for (int u = max(i - 2, 0); u < min(i + 2, rows); u++)
+                for (int v = max(j0 - 2, 0); v < min(j0 + 2, cols); v++) valid = valid && (a.next_image[u * cols + v] > 0);
+            if (valid) {
+                const int valx = a.dIdx[i * cols + j0], valy = a.dIdy[i * cols + j0];
+                const float mTwo = (float)((valx * valx) + (valy * valy));
+                if (mTwo >= a.min_scale) {
+                    const int y = i, x = j0;
+                    const float d1 = a.next_depth[y * cols + x];
+                    if (!kt_isnan(d1)) {
+                        const float xf = (float)x, yf = (float)y;
+                        const float transformed_d1 = __builtin_fmaf(d1, __builtin_fmaf(K[6], xf, K[7] * yf) + K[8], kt[2]);
+                        const int u0 = kt_f2i_rn(__builtin_fmaf(d1, __builtin_fmaf(K[0], xf, K[1] * yf) + K[2], kt[0]) / transformed_d1);
+                        const int v0 = kt_f2i_rn(__builtin_fmaf(d1, __builtin_fmaf(K[3], xf, K[4] * yf) + K[5], kt[1]) / transformed_d1);
+                        if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+                            const float d0 = a.last_depth[v0 * cols + u0];
+                            const uint8_t li = a.last_image[v0 * cols + u0];
+                            if (d0 > 0 && fabsf(transformed_d1 - d0) <= a.max_depth_delta && li != 0) {
+                                corres.zero_x = (int16_t)u0; corres.zero_y = (int16_t)v0;
+                                corres.one_x = (int16_t)x; corres.one_y = (int16_t)y;
+                                corres.diff = (float)a.next_image[y * cols + x] - (float)li;
+                                corres.valid = 1;
+                                cnt += 1;
+                                sig += (unsigned int)kt_f2i_rz(corres.diff * corres.diff);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // one 16-byte store per DataTerm (written for every pixel, quirk A.19)
+        *(int4*)&a.corres[k] = *(const int4*)&corres;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off, 64);
+        sig += __shfl_down(sig, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicAdd(&a.out2[0], cnt);
+        atomicAdd(&a.out2[1], (int)sig);
+    }
+    if (a.state) {
+        // device path: the last block turns {count, sigma} into sigmaVal (RGBDOdometry.cpp:253 quirk) for rgbStep
+        __shared__ bool is_last;
+        __threadfence();   // this wave's atomics are performed before the block's ticket
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int t = atomicAdd(a.ticket, 1u);
+            is_last = (t == gridDim.x - 1);
+            if (is_last) {
+                *a.ticket = 0;
+                const int count = atomicAdd(&a.out2[0], 0);   // device-scope RMW reads: coherent across XCDs
+                const int sigma = atomicAdd(&a.out2[1], 0);
+                a.state->sigma_val = __builtin_sqrtf(((float)sigma / (float)count == 0) ? 1.0f : (float)count);
+                a.state->rgb_count = count;
+                a.state->rgb_sigma = sigma;
+                atomicExch(&a.out2[0], 0);
+                atomicExch(&a.out2[1], 0);
+            }
+        }
+    }
+}
+
+extern "C" int kt_rgb_residual(kt_ctx* c, float min_scale, const int16_t* dIdx, const int16_t* dIdy, const float* last_depth,
+                               const float* next_depth, const uint8_t* last_image, const uint8_t* next_image, int cols, int rows,
+                               kt_dataterm* corres_img, float max_depth_delta, const float kt[3], const kt_mat33* krkinv,
+                               int* sigma_sum_host, int* count_host)
+{
+    KT_ARG(c && dIdx && dIdy && last_depth && next_depth && last_image && next_image && corres_img && kt && krkinv && sigma_sum_host && count_host);
+    KT_ARG(cols > 0 && rows > 0);
+    int* out2 = (int*)&c->counters[4];
+    KT_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(int), c->stream));
+    kt_residual_args a;
+    a.min_scale = min_scale; a.dIdx = dIdx; a.dIdy = dIdy; a.last_depth = last_depth; a.next_depth = next_depth;
+    a.last_image = last_image; a.next_image = next_image; a.corres = corres_img; a.max_depth_delta = max_depth_delta;
+    for (int k = 0; k < 3; ++k) a.kt_[k] = kt[k];
+    a.krkinv = *krkinv; a.state = nullptr; a.cols = cols; a.rows = rows; a.out2 = out2; a.ticket = &c->counters[6];
+    int g = kt_div_up(cols * rows, 256);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(kt_residual_kernel, dim3(g), dim3(256), 0, c->stream, a);
+    KT_LAUNCH_CHECK();
+    KT_HIP(hipMemcpyAsync(c->int_out_host, out2, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    *count_host = c->int_out_host[0];
+    *sigma_sum_host = c->int_out_host[1];
+    return KT_OK;
+}
+
+int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
+                           const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
+                           int cols, int rows, kt_dataterm* corres_img, float max_depth_delta)
+{
+    kt_residual_args a;
+    a.min_scale = min_scale; a.dIdx = dIdx; a.dIdy = dIdy; a.last_depth = last_depth; a.next_depth = next_depth;
+    a.last_image = last_image; a.next_image = next_image; a.corres = corres_img; a.max_depth_delta = max_depth_delta;
+    a.state = state; a.cols = cols; a.rows = rows; a.out2 = (int*)&c->counters[4]; a.ticket = &c->counters[6];
+    int g = kt_div_up(cols * rows, 256);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(kt_residual_kernel, dim3(g), dim3(256), 0, c->stream, a);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a9  rgbStep -> rgbKernel + reduceSum                reduce.cu:423-607
+// ------------------------------------------------------------------------------------------------
+struct kt_rgb_args {
+    const kt_dataterm* corres;
+    float sigma;
+    const float* cloud;
+    float fx, fy;
+    const int16_t* dIdx; const int16_t* dIdy;
+    float sobel_scale;
+    int cols, rows;
+    kt_track_state* state;
+    double* partials; unsigned int* ticket;
+    float* out29;
+    int mode;              // KT_MODE_HOST, KT_MODE_RGB_SOLVE, KT_MODE_JOINT_SOLVE
+    kt_level_k next_k;     // intrinsics of the level the NEXT iteration runs at (for K R K^-1, K t)
+};
+
+__global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_args a)
+{
+    const float sigma = a.state ? a.state->sigma_val : a.sigma;
+    const float flt_eps = 1.19209290E-07F;
+    float acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) acc[k] = 0.f;
+    const int n = a.cols * a.rows, cols = a.cols;
+    for (int i = blockIdx.x * KT_RED_THREADS + threadIdx.x; i < n; i += gridDim.x * KT_RED_THREADS) {
+        const int4 raw = *(const int4*)&a.corres[i];
+        const kt_dataterm c = *(const kt_dataterm*)&raw;
+        float row[7] = {0, 0, 0, 0, 0, 0, 0};
+        const bool found = c.valid != 0;
+        if (found) {
+            float w = sigma + fabsf(c.diff);
+            w = w > flt_eps ? 1.0f / w : 1.0f;
+            if (sigma == -1) w = 1;
+            row[6] = -w * c.diff;
+            const float* cp = &a.cloud[3 * (c.zero_y * cols + c.zero_x)];
+            const float X = cp[0], Y = cp[1], Z = cp[2];
+            const float invz = (float)(1.0 / (double)Z);
+            const float dI_dx_val = w * a.sobel_scale * (float)a.dIdx[c.one_y * cols + c.one_x];
+            const float dI_dy_val = w * a.sobel_scale * (float)a.dIdy[c.one_y * cols + c.one_x];
+            const float v0 = dI_dx_val * a.fx * invz;
+            const float v1 = dI_dy_val * a.fy * invz;
+            const float v2 = -__builtin_fmaf(v0, X, v1 * Y) * invz;
+            row[0] = v0; row[1] = v1; row[2] = v2;
+            row[3] = __builtin_fmaf(-Z, v1, Y * v2);
+            row[4] = __builtin_fmaf(Z, v0, -(X * v2));
+            row[5] = __builtin_fmaf(-Y, v0, X * v1);
+        }
+        kt_outer29(row, found, acc);
+    }
+    __shared__ double total[KT_RED_SLOTS];
+    if (!kt_grid_reduce29(acc, a.partials, a.ticket, total)) return;
+    if (a.mode == KT_MODE_HOST) {
+        if (threadIdx.x < 29) a.out29[threadIdx.x] = (float)total[threadIdx.x];
+    } else if (threadIdx.x == 0) {
+        float h[29];
+        for (int k = 0; k < 29; ++k) h[k] = (float)total[k];
+        __shared__ double dA[36], db[6];
+        kt_unpack29_d(h, dA, db);
+        if (a.mode == KT_MODE_JOINT_SOLVE) {
+            // RGBDOdometry.cpp:316-321: A = A_rgbd + w*w*A_icp, b = b_rgbd + w*b_icp, w = 10
+            __shared__ double iA[36], ib[6];
+            kt_unpack29_d(a.state->icp29, iA, ib);
+            const double w = 10;
+            for (int k = 0; k < 36; ++k) dA[k] = dA[k] + w * w * iA[k];
+            for (int k = 0; k < 6; ++k) db[k] = db[k] + w * ib[k];
+        }
+        kt_solve_and_update(a.state, dA, db);
+        kt_update_krk(a.state, a.next_k);
+    }
+}
+
+extern "C" int kt_rgb_step(kt_ctx* c, const kt_dataterm* corres_img, float sigma, const float* cloud, float fx, float fy,
+                           const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows, float* A_host,
+                           float* b_host)
+{
+    KT_ARG(c && corres_img && cloud && dIdx && dIdy && A_host && b_host && cols > 0 && rows > 0);
+    kt_rgb_args a;
+    a.corres = corres_img; a.sigma = sigma; a.cloud = cloud; a.fx = fx; a.fy = fy; a.dIdx = dIdx; a.dIdy = dIdy;
+    a.sobel_scale = sobel_scale; a.cols = cols; a.rows = rows; a.state = nullptr;
+    a.partials = c->red_partials; a.ticket = &c->counters[0]; a.out29 = c->red_out; a.mode = KT_MODE_HOST;
+    hipLaunchKernelGGL(kt_rgb_kernel, dim3(kt_red_grid(cols * rows)), dim3(KT_RED_THREADS), 0, c->stream, a);
+    KT_LAUNCH_CHECK();
+    KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * 29, hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    kt_unpack29_host(c->red_out_host, A_host, b_host, nullptr);
+    return KT_OK;
+}
+
+int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corres_img, const float* cloud, float fx, float fy,
+                       const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows, int mode,
+                       const kt_level_k* next_k)
+{
+    kt_rgb_args a;
+    a.corres = corres_img; a.sigma = 0.f; a.cloud = cloud; a.fx = fx; a.fy = fy; a.dIdx = dIdx; a.dIdy = dIdy;
+    a.sobel_scale = sobel_scale; a.cols = cols; a.rows = rows; a.state = state;
+    a.partials = c->red_partials; a.ticket = &c->counters[0]; a.out29 = nullptr; a.mode = mode;
+    a.next_k = *next_k;
+    hipLaunchKernelGGL(kt_rgb_kernel, dim3(kt_red_grid(cols * rows)), dim3(KT_RED_THREADS), 0, c->stream, a);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}

@@ -1,0 +1,194 @@
+// kt_track.hpp -- device-resident Gauss-Newton state and the per-iteration solve / pose update that the
+// reference performs on the host (ICPOdometry.cpp:127-178, RGBDOdometry.cpp:213-231, 311-373,
+// OdometryProvider.h:54-68), restated so it can run in the epilogue of the reduction kernels.
+// The same inline functions are compiled for the host (frame set-up in kt_tracker.hip).
+// Third-party math restated: Eigen LDLT<6x6 double> (pivoted, pseudo-inverse of D), cv::Rodrigues,
+// Eigen Isometry3f compose / inverse (float, no FMA: the reference host build is -msse3).
+#pragma once
+
+#include "kt_common.hpp"
+
+#include <float.h>
+#include <math.h>
+
+enum { KT_MODE_HOST = 0, KT_MODE_ICP_SOLVE = 1, KT_MODE_ICP_STASH = 2, KT_MODE_RGB_SOLVE = 3, KT_MODE_JOINT_SOLVE = 4 };
+
+struct kt_level_k { double fx, fy, cx, cy; };  // IntrDoublePrecision at a pyramid level, internal.h:262-273
+
+struct kt_track_state {
+    float Rcurr[9], tcurr[3];                 // current estimate (ICPOdometry.cpp:73-74)
+    float Rprev[9], tprev[3], Rprev_inv[9];   // previous pose and its inverse (:70-83)
+    double resultRt[16];                      // accumulated increment, carried across levels (:85, :144)
+    float krkinv[9], kt[3];                   // K R K^-1 and K t for computeRgbResidual (RGBDOdometry.cpp:213-231)
+    float sigma_val;                          // RGBDOdometry.cpp:253
+    int rgb_count, rgb_sigma;
+    float icp29[29];                          // ICP sums stashed for the joint solve
+    float last_residual[2];
+    float pad;
+};
+
+#ifdef __HIPCC__
+#define KT_HD __host__ __device__ __forceinline__
+#else
+#define KT_HD inline
+#endif
+
+// reduce.cu:401-418 unpack, straight into the double system of ICPOdometry.cpp:127-128
+KT_HD void kt_unpack29_d(const float* h, double* A, double* b)
+{
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const double value = (double)h[shift++];
+            if (j == 6) b[i] = value;
+            else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+}
+
+// Eigen LDLT<Matrix<double,6,6>>::compute + solve: pivot on the largest remaining diagonal, D^-1 as a
+// pseudo-inverse (entries below max|D| * eps are dropped).  A is overwritten.
+KT_HD void kt_ldlt_solve6(double* A, const double* bin, double* x)
+{
+    const int n = 6;
+    int tr[6];
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double big = fabs(A[k * n + k]);
+        for (int i = k + 1; i < n; ++i)
+            if (fabs(A[i * n + i]) > big) { big = fabs(A[i * n + i]); p = i; }
+        tr[k] = p;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) { const double t = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = t; }
+            for (int i = 0; i < n; ++i) { const double t = A[i * n + k]; A[i * n + k] = A[i * n + p]; A[i * n + p] = t; }
+        }
+        double d = A[k * n + k];
+        for (int j = 0; j < k; ++j) d -= A[k * n + j] * A[k * n + j] * A[j * n + j];
+        A[k * n + k] = d;
+        for (int i = k + 1; i < n; ++i) {
+            double s = A[i * n + k];
+            for (int j = 0; j < k; ++j) s -= A[i * n + j] * A[k * n + j] * A[j * n + j];
+            A[i * n + k] = (d != 0.0) ? s / d : s;
+        }
+    }
+    for (int i = 0; i < n; ++i) x[i] = bin[i];
+    for (int k = 0; k < n; ++k)
+        if (tr[k] != k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) x[i] -= A[i * n + j] * x[j];
+    double maxd = 0;
+    for (int i = 0; i < n; ++i)
+        if (fabs(A[i * n + i]) > maxd) maxd = fabs(A[i * n + i]);
+    double tol = maxd * DBL_EPSILON;
+    if (tol < 1.0 / DBL_MAX) tol = 1.0 / DBL_MAX;
+    for (int i = 0; i < n; ++i) x[i] = (fabs(A[i * n + i]) > tol) ? x[i] / A[i * n + i] : 0.0;
+    for (int i = n - 1; i >= 0; --i)
+        for (int j = i + 1; j < n; ++j) x[i] -= A[j * n + i] * x[j];
+    for (int k = n - 1; k >= 0; --k)
+        if (tr[k] != k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+}
+
+// cv::Rodrigues (rotation vector -> matrix), OdometryProvider.h:54-68
+KT_HD void kt_rodrigues(const double* r, double* R)
+{
+    const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (theta < DBL_EPSILON) {
+        for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    const double rx = r[0] * itheta, ry = r[1] * itheta, rz = r[2] * itheta;
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+    const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+    for (int k = 0; k < 9; ++k) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+}
+
+// Eigen Matrix3f::inverse() (cofactor form), ICPOdometry.cpp:81
+KT_HD void kt_mat33_inverse(const float* m, float* out)
+{
+#define KT_M(i, j) m[(i) * 3 + (j)]
+#define KT_COF(i, j) (KT_M(((i) + 1) % 3, ((j) + 1) % 3) * KT_M(((i) + 2) % 3, ((j) + 2) % 3) - KT_M(((i) + 1) % 3, ((j) + 2) % 3) * KT_M(((i) + 2) % 3, ((j) + 1) % 3))
+    const float c00 = KT_COF(0, 0), c10 = KT_COF(1, 0), c20 = KT_COF(2, 0);
+    const float det = (c00 * KT_M(0, 0) + c10 * KT_M(1, 0)) + c20 * KT_M(2, 0);
+    const float invdet = 1.0f / det;
+    float r[9];
+    r[0] = c00 * invdet; r[1] = c10 * invdet; r[2] = c20 * invdet;
+    r[3] = KT_COF(0, 1) * invdet; r[4] = KT_COF(1, 1) * invdet; r[5] = KT_COF(2, 1) * invdet;
+    r[6] = KT_COF(0, 2) * invdet; r[7] = KT_COF(1, 2) * invdet; r[8] = KT_COF(2, 2) * invdet;
+#undef KT_COF
+#undef KT_M
+    for (int k = 0; k < 9; ++k) out[k] = r[k];
+}
+
+// x (6, double) -> resultRt = [Rodrigues | t] * resultRt;  T_curr = T_prev * inverse([R | t]) in float
+// (ICPOdometry.cpp:133-178 == RGBDOdometry.cpp:328-373)
+KT_HD void kt_pose_update(const double* x, double* resultRt, const float* Rprev, const float* tprev, float* Rcurr, float* tcurr)
+{
+    double currRt[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double R[9];
+    kt_rodrigues(&x[3], R);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) currRt[i * 4 + j] = R[i * 3 + j];
+        currRt[i * 4 + 3] = x[i];
+    }
+    double prod[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += currRt[i * 4 + k] * resultRt[k * 4 + j];
+            prod[i * 4 + j] = s;
+        }
+    for (int k = 0; k < 16; ++k) resultRt[k] = prod[k];
+    float rot[9], trans[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) rot[i * 3 + j] = (float)resultRt[i * 4 + j];
+        trans[i] = (float)resultRt[i * 4 + 3];
+    }
+    float rinv[9], tinv[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) rinv[i * 3 + j] = rot[j * 3 + i];
+    for (int i = 0; i < 3; ++i) tinv[i] = -((rinv[i * 3 + 0] * trans[0] + rinv[i * 3 + 1] * trans[1]) + rinv[i * 3 + 2] * trans[2]);
+    float Rn[9], tn[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = (Rprev[i * 3 + 0] * rinv[0 * 3 + j] + Rprev[i * 3 + 1] * rinv[1 * 3 + j]) + Rprev[i * 3 + 2] * rinv[2 * 3 + j];
+    for (int i = 0; i < 3; ++i) tn[i] = ((Rprev[i * 3 + 0] * tinv[0] + Rprev[i * 3 + 1] * tinv[1]) + Rprev[i * 3 + 2] * tinv[2]) + tprev[i];
+    for (int k = 0; k < 9; ++k) Rcurr[k] = Rn[k];
+    for (int k = 0; k < 3; ++k) tcurr[k] = tn[k];
+}
+
+// K R K^-1 and K t from the inverse of the accumulated increment (RGBDOdometry.cpp:213-231)
+KT_HD void kt_compute_krk(const double* resultRt, const kt_level_k k, float* krkinv, float* kt)
+{
+    const double K[9] = {k.fx, 0, k.cx, 0, k.fy, k.cy, 0, 0, 1};
+    const double Kinv[9] = {1.0 / K[0], 0, -K[2] / K[0], 0, 1.0 / K[4], -K[5] / K[4], 0, 0, 1};
+    double Rinv[9], tinv[3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) Rinv[a * 3 + b] = resultRt[b * 4 + a];
+    for (int a = 0; a < 3; ++a) tinv[a] = -(Rinv[a * 3 + 0] * resultRt[3] + Rinv[a * 3 + 1] * resultRt[7] + Rinv[a * 3 + 2] * resultRt[11]);
+    double KR[9], KRK[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int q = 0; q < 3; ++q) s += K[i * 3 + q] * Rinv[q * 3 + j];
+            KR[i * 3 + j] = s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int q = 0; q < 3; ++q) s += KR[i * 3 + q] * Kinv[q * 3 + j];
+            KRK[i * 3 + j] = s;
+        }
+    for (int a = 0; a < 3; ++a) kt[a] = (float)(K[a * 3 + 0] * tinv[0] + K[a * 3 + 1] * tinv[1] + K[a * 3 + 2] * tinv[2]);
+    for (int n = 0; n < 9; ++n) krkinv[n] = (float)KRK[n];
+}
+
+#ifdef __HIPCC__
+// executed by ONE thread in the epilogue of the last block; A, b live in LDS-backed arrays
+__device__ inline void kt_solve_and_update(kt_track_state* st, double* dA, const double* db)
+{
+    double x[6];
+    kt_ldlt_solve6(dA, db, x);
+    kt_pose_update(x, st->resultRt, st->Rprev, st->tprev, st->Rcurr, st->tcurr);
+}
+__device__ inline void kt_update_krk(kt_track_state* st, const kt_level_k k) { kt_compute_krk(st->resultRt, k, st->krkinv, st->kt); }
+#endif

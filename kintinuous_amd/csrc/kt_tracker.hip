@@ -1,0 +1,681 @@
+// kt_tracker.hip -- KintinuousTracker::processFrame (src/frontend/KintinuousTracker.cpp:444-915) as a
+// device-resident pipeline on one HIP stream: pyramid build -> odometry (all Gauss-Newton iterations
+// enqueued back to back, solved on the device) -> ONE host sync for the pose -> cyclical-volume shift
+// (slab extract + clear) -> integrate -> raycast -> predicted-map pyramid.  The reference performs 19
+// blocking host round trips per frame (reduce.cu:398-401); this path performs one.
+// Host-side state (pose lists, shift decision, slices, dense pose graph) restates
+// KintinuousTracker.cpp:71-182, 262-382, 575-667, 1003-1048, 1075-1085, 1156-1208.
+#include "kt_internal.hpp"
+
+#include <limits.h>
+#include <string.h>
+
+#include <vector>
+
+namespace {
+
+struct DensePose { uint64_t ts; float pose[16]; int is_loop; };   // KintinuousTracker.h:151-169
+struct Slice { std::vector<kt_point_xyzrgb> pts; int dim; };      // CloudSlice.h:28-129 (cloud + dimension)
+
+enum { ST_PYRAMID = 0, ST_ODOMETRY, ST_SHIFT, ST_INTEGRATE, ST_RAYCAST, ST_RESIZE, ST_TSDF23, ST_COUNT };
+
+}  // namespace
+
+struct kt_tracker {
+    kt_ctx* ctx;
+    kt_tracker_config cfg;
+    kt_intr intr;
+    int N;
+    float volume_size[3], voxel_size[3];
+    float tranc_dist;
+    float volume_basis[3];
+    float initial_rotation[9];
+    int voxel_wrap[3], v_wrap_copy[3];
+    int global_time;
+    bool parked;
+    float Rlast[9], tlast[3];          // rmats_.back(), tvecs_.back()
+    float current_global_camera[3];
+    // device buffers (KintinuousTracker.h:185-222)
+    int16_t* tsdf; uint8_t* color;
+    uint16_t* depths_curr[KT_LEVELS];
+    float *vmaps_curr[KT_LEVELS], *nmaps_curr[KT_LEVELS], *vmaps_g_prev[KT_LEVELS], *nmaps_g_prev[KT_LEVELS];
+    uint8_t* vmap_curr_color;
+    float* depth_raw_scaled;
+    kt_point_xyzrgb* cloud_device; size_t cloud_cap;
+    // RGBDOdometry buffers (RGBDOdometry.h:96-111)
+    float *last_depth[KT_LEVELS], *next_depth[KT_LEVELS];
+    uint8_t *last_image[KT_LEVELS], *next_image[KT_LEVELS];
+    int16_t *next_dIdx[KT_LEVELS], *next_dIdy[KT_LEVELS];
+    float* point_clouds[KT_LEVELS];
+    kt_dataterm* corres[KT_LEVELS];
+    // device-resident Gauss-Newton state + pinned mirror
+    kt_track_state* state_dev; kt_track_state* state_host;
+    // staging for the host-frame entry point
+    uint16_t* depth_stage; uint8_t* rgb_stage;
+    uint16_t* depth_stage_host; uint8_t* rgb_stage_host;  // pinned
+    // outputs
+    std::vector<DensePose> poses;
+    std::vector<Slice> slices;
+    // profiling / counters
+    int profiling;
+    hipEvent_t ev[ST_COUNT][2]; bool ev_rec[ST_COUNT];
+    double stage_ms_sum[ST_COUNT]; long long stage_n[ST_COUNT]; float stage_ms_last[ST_COUNT];
+    int counting;
+    unsigned int* upd_dev; unsigned long long* steps_dev;
+    unsigned long long last_U, last_S;
+};
+
+static int lvl_cols(const kt_tracker* t, int l) { return t->cfg.cols >> l; }
+static int lvl_rows(const kt_tracker* t, int l) { return t->cfg.rows >> l; }
+static kt_intr lvl_intr(kt_intr k, int l)  // Intr::operator() internal.h:255-259
+{
+    const int div = 1 << l;
+    kt_intr r = {k.fx / div, k.fy / div, k.cx / div, k.cy / div};
+    return r;
+}
+
+#define KT_TRY(expr) do { int _s = (expr); if (_s != KT_OK) return _s; } while (0)
+
+template <typename T>
+static int dev_alloc(T** p, size_t count, bool zero)
+{
+    KT_HIP(hipMalloc((void**)p, (count ? count : 1) * sizeof(T)));
+    if (zero) KT_HIP(hipMemset(*p, 0, (count ? count : 1) * sizeof(T)));
+    return KT_OK;
+}
+
+static void compute_global_camera(kt_tracker* t, const float* tcurr)
+{
+    // KintinuousTracker.cpp:581-595 (and :274-287 in reset())
+    for (int k = 0; k < 3; ++k) {
+        const float initial_trans = (float)((double)t->volume_basis[k] - (double)t->cfg.volume_size * 0.5);
+        t->current_global_camera[k] = initial_trans;
+        t->current_global_camera[k] += (float)t->voxel_wrap[k] * t->voxel_size[k];
+        if (tcurr) t->current_global_camera[k] += tcurr[k] - t->volume_basis[k];
+    }
+}
+
+static void v_wrap_copy_update(kt_tracker* t)
+{
+    // vWrapCopyUpdate KintinuousTracker.cpp:1075-1085
+    for (int k = 0; k < 3; ++k) {
+        t->v_wrap_copy[k] = t->voxel_wrap[k];
+        if (t->v_wrap_copy[k] < 0) t->v_wrap_copy[k] = t->N - ((-t->v_wrap_copy[k]) % t->N);
+    }
+}
+
+static void push_pose(kt_tracker* t, uint64_t ts, const float* R, int is_loop)
+{
+    DensePose p;
+    p.ts = ts;
+    p.is_loop = is_loop;
+    for (int i = 0; i < 16; ++i) p.pose[i] = (i % 5 == 0) ? 1.f : 0.f;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) p.pose[i * 4 + j] = R[i * 3 + j];
+        p.pose[i * 4 + 3] = t->current_global_camera[i];
+    }
+    t->poses.push_back(p);
+}
+
+// ---- profiling helpers ---------------------------------------------------------------------------
+static int ev_begin(kt_tracker* t, int st)
+{
+    if (t->profiling >= 2 || (t->profiling == 1 && st == ST_TSDF23)) {
+        KT_HIP(hipEventRecord(t->ev[st][0], t->ctx->stream));
+    }
+    return KT_OK;
+}
+static int ev_end(kt_tracker* t, int st)
+{
+    if (t->profiling >= 2 || (t->profiling == 1 && st == ST_TSDF23)) {
+        KT_HIP(hipEventRecord(t->ev[st][1], t->ctx->stream));
+        t->ev_rec[st] = true;
+    }
+    return KT_OK;
+}
+// call only right after a stream synchronisation: every recorded pair is complete
+static void ev_collect(kt_tracker* t)
+{
+    if (!t->profiling) return;
+    for (int st = 0; st < ST_COUNT; ++st)
+        if (t->ev_rec[st]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, t->ev[st][0], t->ev[st][1]) == hipSuccess) {
+                t->stage_ms_sum[st] += ms;
+                t->stage_n[st] += 1;
+                t->stage_ms_last[st] = ms;
+            }
+            t->ev_rec[st] = false;
+        }
+}
+
+extern "C" {
+
+int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** out)
+{
+    KT_ARG(ctx && cfg && out);
+    KT_ARG(cfg->cols > 0 && cfg->rows > 0 && cfg->N > 0 && cfg->volume_size > 0);
+    KT_ARG((cfg->cols % 8) == 0 && (cfg->rows % 8) == 0);  // 4 pyramid levels
+    KT_HIP(hipSetDevice(ctx->device));
+    kt_tracker* t = new kt_tracker();
+    t->ctx = ctx;
+    t->cfg = *cfg;
+    t->N = cfg->N;
+    // KintinuousTracker ctor, KintinuousTracker.cpp:71-182
+    t->intr.fx = cfg->fx; t->intr.fy = cfg->fy; t->intr.cx = cfg->cx; t->intr.cy = cfg->cy;
+    for (int k = 0; k < 3; ++k) {
+        t->volume_size[k] = cfg->volume_size;
+        t->voxel_size[k] = cfg->volume_size / (float)cfg->N;
+    }
+    for (int k = 0; k < 9; ++k) t->initial_rotation[k] = (k % 4 == 0) ? 1.f : 0.f;
+    for (int k = 0; k < 3; ++k) t->volume_basis[k] = t->volume_size[k] * 0.5f;
+    if (cfg->static_mode)  // :101-110
+        t->volume_basis[2] = t->volume_size[2] * 0.5f - (float)(((double)t->volume_size[2] * 0.5) + 0.45);
+    const float default_tranc = fmaxf(0.01f, t->volume_size[0] / 100.0f);               // :112
+    const float mc = fmaxf(t->voxel_size[0], fmaxf(t->voxel_size[1], t->voxel_size[2]));
+    t->tranc_dist = fmaxf(default_tranc, 2.1f * mc);                                    // TSDFVolume.cpp:89-97
+    t->voxel_wrap[0] = t->voxel_wrap[1] = t->voxel_wrap[2] = 0;
+
+    const size_t nvox = (size_t)cfg->N * cfg->N * cfg->N;
+    const size_t P = (size_t)cfg->cols * cfg->rows;
+    KT_TRY(dev_alloc(&t->tsdf, nvox, false));
+    KT_TRY(dev_alloc(&t->color, nvox * 4, false));
+    for (int l = 0; l < KT_LEVELS; ++l) {  // allocateBuffers :356-382; zero-filled so "stale" planes are defined
+        const size_t p = (size_t)lvl_cols(t, l) * lvl_rows(t, l);
+        KT_TRY(dev_alloc(&t->depths_curr[l], p, true));
+        KT_TRY(dev_alloc(&t->vmaps_curr[l], 3 * p, true));
+        KT_TRY(dev_alloc(&t->nmaps_curr[l], 3 * p, true));
+        KT_TRY(dev_alloc(&t->vmaps_g_prev[l], 3 * p, true));
+        KT_TRY(dev_alloc(&t->nmaps_g_prev[l], 3 * p, true));
+        const bool rgbd = cfg->use_rgbd || cfg->use_rgbd_icp;
+        const size_t q = rgbd ? p : 0;
+        KT_TRY(dev_alloc(&t->last_depth[l], q, true));
+        KT_TRY(dev_alloc(&t->next_depth[l], q, true));
+        KT_TRY(dev_alloc(&t->last_image[l], q, true));
+        KT_TRY(dev_alloc(&t->next_image[l], q, true));
+        KT_TRY(dev_alloc(&t->next_dIdx[l], q, true));
+        KT_TRY(dev_alloc(&t->next_dIdy[l], q, true));
+        KT_TRY(dev_alloc(&t->point_clouds[l], 3 * q, true));
+        KT_TRY(dev_alloc(&t->corres[l], q, true));
+    }
+    KT_TRY(dev_alloc(&t->vmap_curr_color, P * 4, true));
+    KT_TRY(dev_alloc(&t->depth_raw_scaled, P, true));
+    t->cloud_cap = cfg->max_slice_points > 0 ? (size_t)cfg->max_slice_points : P * 3;  // cloud_device_(numPixels * 3) :77
+    KT_TRY(dev_alloc(&t->cloud_device, t->cloud_cap, false));
+    KT_TRY(dev_alloc(&t->state_dev, 1, true));
+    KT_HIP(hipHostMalloc((void**)&t->state_host, sizeof(kt_track_state), hipHostMallocDefault));
+    KT_TRY(dev_alloc(&t->depth_stage, P, true));
+    KT_TRY(dev_alloc(&t->rgb_stage, P * 3, true));
+    KT_HIP(hipHostMalloc((void**)&t->depth_stage_host, P * sizeof(uint16_t), hipHostMallocDefault));
+    KT_HIP(hipHostMalloc((void**)&t->rgb_stage_host, P * 3, hipHostMallocDefault));
+    KT_TRY(dev_alloc(&t->upd_dev, 4, true));
+    KT_TRY(dev_alloc(&t->steps_dev, 2, true));
+    t->profiling = 0;
+    t->counting = 0;
+    for (int s = 0; s < ST_COUNT; ++s) {
+        KT_HIP(hipEventCreate(&t->ev[s][0]));
+        KT_HIP(hipEventCreate(&t->ev[s][1]));
+        t->ev_rec[s] = false;
+    }
+    KT_TRY(kt_tracker_reset(t));
+    *out = t;
+    return KT_OK;
+}
+
+int kt_tracker_destroy(kt_tracker* t)
+{
+    if (!t) return KT_OK;
+    (void)hipStreamSynchronize(t->ctx->stream);
+    (void)hipFree(t->tsdf); (void)hipFree(t->color);
+    for (int l = 0; l < KT_LEVELS; ++l) {
+        (void)hipFree(t->depths_curr[l]); (void)hipFree(t->vmaps_curr[l]); (void)hipFree(t->nmaps_curr[l]);
+        (void)hipFree(t->vmaps_g_prev[l]); (void)hipFree(t->nmaps_g_prev[l]);
+        (void)hipFree(t->last_depth[l]); (void)hipFree(t->next_depth[l]); (void)hipFree(t->last_image[l]); (void)hipFree(t->next_image[l]);
+        (void)hipFree(t->next_dIdx[l]); (void)hipFree(t->next_dIdy[l]); (void)hipFree(t->point_clouds[l]); (void)hipFree(t->corres[l]);
+    }
+    (void)hipFree(t->vmap_curr_color); (void)hipFree(t->depth_raw_scaled); (void)hipFree(t->cloud_device);
+    (void)hipFree(t->state_dev); (void)hipHostFree(t->state_host);
+    (void)hipFree(t->depth_stage); (void)hipFree(t->rgb_stage);
+    (void)hipHostFree(t->depth_stage_host); (void)hipHostFree(t->rgb_stage_host);
+    (void)hipFree(t->upd_dev); (void)hipFree(t->steps_dev);
+    for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(t->ev[s][0]); (void)hipEventDestroy(t->ev[s][1]); }
+    delete t;
+    return KT_OK;
+}
+
+int kt_tracker_reset(kt_tracker* t)
+{
+    // KintinuousTracker::reset :262-354
+    KT_ARG(t);
+    t->global_time = 0;
+    memcpy(t->Rlast, t->initial_rotation, sizeof(t->Rlast));
+    memcpy(t->tlast, t->volume_basis, sizeof(t->tlast));
+    compute_global_camera(t, nullptr);
+    t->voxel_wrap[0] = t->voxel_wrap[1] = t->voxel_wrap[2] = 0;
+    t->poses.clear();
+    t->slices.clear();
+    t->parked = t->cfg.static_mode != 0;
+    KT_TRY(kt_init_volume(t->ctx, t->tsdf, t->N));
+    KT_TRY(kt_init_color_volume(t->ctx, t->color, t->N));
+    memset(t->stage_ms_sum, 0, sizeof(t->stage_ms_sum));
+    memset(t->stage_n, 0, sizeof(t->stage_n));
+    memset(t->stage_ms_last, 0, sizeof(t->stage_ms_last));
+    t->last_U = t->last_S = 0;
+    KT_HIP(hipStreamSynchronize(t->ctx->stream));
+    return KT_OK;
+}
+
+}  // extern "C"
+
+// ---- odometry set-up shared by ICP and RGB-D ------------------------------------------------------
+static int odometry_begin(kt_tracker* t, const kt_level_k* first_k)
+{
+    kt_track_state* s = t->state_host;
+    memset(s, 0, sizeof(*s));
+    memcpy(s->Rprev, t->Rlast, sizeof(s->Rprev));
+    memcpy(s->tprev, t->tlast, sizeof(s->tprev));
+    memcpy(s->Rcurr, t->Rlast, sizeof(s->Rcurr));
+    memcpy(s->tcurr, t->tlast, sizeof(s->tcurr));
+    kt_mat33_inverse(s->Rprev, s->Rprev_inv);  // ICPOdometry.cpp:81
+    for (int k = 0; k < 16; ++k) s->resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (first_k) kt_compute_krk(s->resultRt, *first_k, s->krkinv, s->kt);
+    KT_HIP(hipMemcpyAsync(t->state_dev, s, sizeof(*s), hipMemcpyHostToDevice, t->ctx->stream));
+    return KT_OK;
+}
+
+static int odometry_end(kt_tracker* t, float* Rcurr, float* tcurr)
+{
+    KT_HIP(hipMemcpyAsync(t->state_host, t->state_dev, sizeof(kt_track_state), hipMemcpyDeviceToHost, t->ctx->stream));
+    KT_HIP(hipStreamSynchronize(t->ctx->stream));  // the ONE host sync of the frame
+    ev_collect(t);
+    memcpy(Rcurr, t->state_host->Rcurr, 9 * sizeof(float));
+    memcpy(tcurr, t->state_host->tcurr, 3 * sizeof(float));
+    return KT_OK;
+}
+
+// ICPOdometry::getIncrementalTransformation, ICPOdometry.cpp:68-186
+static int icp_odometry(kt_tracker* t, float* tcurr, float* Rcurr)
+{
+    int iters[KT_LEVELS] = {10, 5, 4, 0};
+    if (t->cfg.fast_odometry) { iters[0] = 0; iters[1] = 10; iters[2] = 5; iters[3] = 0; }
+    const float dist_thres = 0.10f;
+    const float angle_thres = (float)sin(20.f * 3.14159254f / 180.f);  // ICPOdometry.h:35-36
+    KT_TRY(odometry_begin(t, nullptr));
+    for (int l = KT_LEVELS - 1; l >= 0; --l) {
+        const kt_intr li = lvl_intr(t->intr, l);
+        for (int it = 0; it < iters[l]; ++it)
+            KT_TRY(kt_icp_step_device(t->ctx, t->state_dev, t->vmaps_curr[l], t->nmaps_curr[l], &li, t->vmaps_g_prev[l],
+                                      t->nmaps_g_prev[l], lvl_cols(t, l), lvl_rows(t, l), dist_thres, angle_thres, KT_MODE_ICP_SOLVE));
+    }
+    return odometry_end(t, Rcurr, tcurr);
+}
+
+// RGBDOdometry::populateRGBDData, RGBDOdometry.cpp:140-158
+static int populate_rgbd(kt_tracker* t, const uint16_t* depth, const uint8_t* rgb, float** dd, uint8_t** di)
+{
+    KT_TRY(kt_depth_to_metres(t->ctx, depth, dd[0], t->cfg.cols, t->cfg.rows, (int)(6.0 * 1000)));
+    for (int l = 0; l + 1 < KT_LEVELS; ++l) KT_TRY(kt_pyr_down_gauss_f32(t->ctx, dd[l], lvl_cols(t, l), lvl_rows(t, l), dd[l + 1]));
+    KT_TRY(kt_bgr_to_intensity(t->ctx, rgb, di[0], t->cfg.cols, t->cfg.rows));
+    for (int l = 0; l + 1 < KT_LEVELS; ++l) KT_TRY(kt_pyr_down_gauss_u8(t->ctx, di[l], lvl_cols(t, l), lvl_rows(t, l), di[l + 1]));
+    return KT_OK;
+}
+
+// RGBDOdometry::getIncrementalTransformation, RGBDOdometry.cpp:165-393
+static int rgbd_odometry(kt_tracker* t, const uint16_t* depth, const uint8_t* rgb, float* tcurr, float* Rcurr)
+{
+    int iters[KT_LEVELS];
+    if (!t->cfg.use_rgbd_icp) {
+        iters[0] = 10; iters[1] = 7; iters[2] = 7; iters[3] = 7;
+        if (t->cfg.fast_odometry) { iters[0] = 0; iters[1] = 10; iters[2] = 7; iters[3] = 0; }
+    } else {
+        iters[0] = 10; iters[1] = 5; iters[2] = 4; iters[3] = 0;
+        if (t->cfg.fast_odometry) { iters[0] = 0; iters[1] = 10; iters[2] = 7; iters[3] = 0; }
+    }
+    const float min_grad[KT_LEVELS] = {12, 5, 3, 1};
+    const double SOBEL_SCALE = 1.0 / pow(2.0, 3), MAX_DEPTH_DELTA = 0.07;
+    const float dist_thres = 0.10f;
+    const float angle_thres = (float)sin(20.f * 3.14159254f / 180.f);
+    const float tprev[3] = {t->tlast[0], t->tlast[1], t->tlast[2]};
+    float Rprev[9];
+    memcpy(Rprev, t->Rlast, sizeof(Rprev));
+
+    KT_TRY(populate_rgbd(t, depth, rgb, t->next_depth, t->next_image));
+    for (int l = 0; l < KT_LEVELS; ++l)
+        KT_TRY(kt_derivative_images(t->ctx, t->next_image[l], lvl_cols(t, l), lvl_rows(t, l), t->next_dIdx[l], t->next_dIdy[l]));
+
+    const double ifx = t->intr.fx, ify = t->intr.fy, icx = t->intr.cx, icy = t->intr.cy;  // RGBDOdometry.cpp:72-75
+    kt_level_k lk[KT_LEVELS];
+    for (int l = 0; l < KT_LEVELS; ++l) {
+        const int div = 1 << l;
+        lk[l].fx = ifx / div; lk[l].fy = ify / div; lk[l].cx = icx / div; lk[l].cy = icy / div;
+    }
+    // flatten the (level, iteration) schedule so each solve epilogue knows the NEXT iteration's level
+    int sched[64], ns = 0;
+    for (int l = KT_LEVELS - 1; l >= 0; --l)
+        for (int j = 0; j < iters[l]; ++j) sched[ns++] = l;
+    KT_TRY(odometry_begin(t, ns ? &lk[sched[0]] : nullptr));
+    int done_cloud[KT_LEVELS] = {0, 0, 0, 0};
+    for (int l = KT_LEVELS - 1; l >= 0; --l)  // projectToPointCloud is issued once per level (:186) even when it has 0 iterations
+        if (!done_cloud[l]) {
+            KT_TRY(kt_project_to_cloud(t->ctx, t->last_depth[l], lvl_cols(t, l), lvl_rows(t, l), t->point_clouds[l], ifx, ify, icx, icy, l));
+            done_cloud[l] = 1;
+        }
+    for (int q = 0; q < ns; ++q) {
+        const int l = sched[q];
+        const int cols = lvl_cols(t, l), rows = lvl_rows(t, l);
+        const float min_scale = (float)(pow(min_grad[l], 2.0) / pow(SOBEL_SCALE, 2.0));
+        KT_TRY(kt_rgb_residual_device(t->ctx, t->state_dev, min_scale, t->next_dIdx[l], t->next_dIdy[l], t->last_depth[l],
+                                      t->next_depth[l], t->last_image[l], t->next_image[l], cols, rows, t->corres[l],
+                                      (float)MAX_DEPTH_DELTA));
+        const kt_intr li = lvl_intr(t->intr, l);
+        if (t->cfg.use_rgbd_icp)
+            KT_TRY(kt_icp_step_device(t->ctx, t->state_dev, t->vmaps_curr[l], t->nmaps_curr[l], &li, t->vmaps_g_prev[l],
+                                      t->nmaps_g_prev[l], cols, rows, dist_thres, angle_thres, KT_MODE_ICP_STASH));
+        const kt_level_k* nk = &lk[q + 1 < ns ? sched[q + 1] : l];
+        KT_TRY(kt_rgb_step_device(t->ctx, t->state_dev, t->corres[l], t->point_clouds[l], li.fx, li.fy, t->next_dIdx[l], t->next_dIdy[l],
+                                  (float)SOBEL_SCALE, cols, rows, t->cfg.use_rgbd_icp ? KT_MODE_JOINT_SOLVE : KT_MODE_RGB_SOLVE, nk));
+    }
+    KT_TRY(odometry_end(t, Rcurr, tcurr));
+    for (int l = 0; l < KT_LEVELS; ++l) {  // swap last/next :377-381
+        float* fd = t->last_depth[l]; t->last_depth[l] = t->next_depth[l]; t->next_depth[l] = fd;
+        uint8_t* ui = t->last_image[l]; t->last_image[l] = t->next_image[l]; t->next_image[l] = ui;
+    }
+    const float d[3] = {tcurr[0] - tprev[0], tcurr[1] - tprev[1], tcurr[2] - tprev[2]};
+    if (sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) > 0.3) {  // :383-387
+        memcpy(Rcurr, Rprev, sizeof(Rprev));
+        memcpy(tcurr, tprev, sizeof(tprev));
+    }
+    return KT_OK;
+}
+
+static int voxel_trans(float translation, float voxel, int thresh)
+{
+    // KintinuousTracker.cpp:640-667
+    const int f = (int)floorf(translation / voxel);
+    if (f < 0) return (-thresh > f) ? -thresh : f;
+    return thresh < f ? thresh : f;
+}
+
+// fetchCloud + download (TSDFVolume.cpp:135-172, KintinuousTracker.cpp:1164-1166): returns the slice on the host
+static int fetch_slice(kt_tracker* t, const int lo[3], const int hi[3], int dim)
+{
+    kt_ctx* c = t->ctx;
+    KT_TRY(kt_extract_cloud_slice_async(c, t->tsdf, t->volume_size, t->cloud_device, t->cloud_cap, t->v_wrap_copy, t->color, lo[0], hi[0],
+                                        lo[1], hi[1], lo[2], hi[2], 1, t->voxel_wrap, t->N, &c->counters[1]));
+    KT_HIP(hipMemcpyAsync(c->int_out_host, &c->counters[1], sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    size_t n = (size_t)(unsigned int)c->int_out_host[0];
+    if (n > t->cloud_cap) n = t->cloud_cap;
+    t->slices.emplace_back();
+    Slice& s = t->slices.back();
+    s.dim = dim;
+    s.pts.resize(n);
+    if (n) {
+        KT_HIP(hipMemcpyAsync(s.pts.data(), t->cloud_device, n * sizeof(kt_point_xyzrgb), hipMemcpyDeviceToHost, c->stream));
+        KT_HIP(hipStreamSynchronize(c->stream));
+    }
+    return KT_OK;
+}
+
+extern "C" {
+
+int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors, uint64_t timestamp)
+{
+    KT_ARG(t && depth_raw && colors);
+    kt_ctx* c = t->ctx;
+    const int cols = t->cfg.cols, rows = t->cfg.rows, N = t->N;
+    const bool icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
+    const bool rgbd = !icp;
+    const int angle_color = !t->cfg.disable_color_angle;
+
+    // [A] pyramid build, KintinuousTracker.cpp:465-479
+    KT_TRY(ev_begin(t, ST_PYRAMID));
+    if (icp || t->cfg.use_rgbd_icp || !t->cfg.disable_color_angle) {
+        KT_TRY(kt_bilateral_filter(c, depth_raw, t->depths_curr[0], cols, rows));
+        for (int l = 1; l < KT_LEVELS; ++l) KT_TRY(kt_pyr_down(c, t->depths_curr[l - 1], lvl_cols(t, l - 1), lvl_rows(t, l - 1), t->depths_curr[l]));
+        for (int l = 0; l < KT_LEVELS; ++l) {
+            const kt_intr li = lvl_intr(t->intr, l);
+            KT_TRY(kt_create_vmap(c, &li, t->depths_curr[l], lvl_cols(t, l), lvl_rows(t, l), t->vmaps_curr[l]));
+            KT_TRY(kt_create_nmap(c, t->vmaps_curr[l], lvl_cols(t, l), lvl_rows(t, l), t->nmaps_curr[l]));
+        }
+    }
+    KT_TRY(ev_end(t, ST_PYRAMID));
+
+    if (t->global_time == 0) {  // [B] :481-557
+        kt_mat33 Rcam, Rcam_inv;
+        memcpy(Rcam.m, t->Rlast, sizeof(Rcam.m));
+        kt_mat33_inverse(Rcam.m, Rcam_inv.m);
+        const int empty[3] = {0, 0, 0};
+        if (rgbd) KT_TRY(populate_rgbd(t, depth_raw, colors, t->last_depth, t->last_image));  // firstRun
+        if (t->counting) KT_HIP(hipMemsetAsync(t->upd_dev, 0, sizeof(unsigned int), c->stream));
+        KT_TRY(ev_begin(t, ST_INTEGRATE));
+        KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rcam_inv, t->tlast, t->tranc_dist, t->tsdf,
+                                      t->depth_raw_scaled, empty, t->color, colors, t->nmaps_curr[0], angle_color, N,
+                                      t->counting ? t->upd_dev : nullptr));
+        KT_TRY(ev_end(t, ST_INTEGRATE));
+        for (int l = 0; l < KT_LEVELS; ++l)
+            KT_TRY(kt_transform_maps(c, t->vmaps_curr[l], t->nmaps_curr[l], lvl_cols(t, l), lvl_rows(t, l), &Rcam, t->tlast, t->vmaps_g_prev[l],
+                                     t->nmaps_g_prev[l]));
+        ++t->global_time;
+        push_pose(t, timestamp, t->Rlast, 1);
+        if (t->counting) {
+            unsigned int u = 0;
+            KT_HIP(hipMemcpyAsync(&u, t->upd_dev, sizeof(u), hipMemcpyDeviceToHost, c->stream));
+            KT_HIP(hipStreamSynchronize(c->stream));
+            t->last_U = u;
+            t->last_S = 0;
+        }
+        return KT_OK;
+    }
+
+    // [C] odometry :564-572
+    float Rcurr[9], tcurr[3];
+    KT_TRY(ev_begin(t, ST_ODOMETRY));
+    if (icp) KT_TRY(icp_odometry(t, tcurr, Rcurr));
+    else KT_TRY(rgbd_odometry(t, depth_raw, colors, tcurr, Rcurr));
+    // (the odometry end event is recorded after the readback; it is harmless that it trails the sync)
+    KT_TRY(ev_end(t, ST_ODOMETRY));
+
+    // [D] rmats_/tvecs_ push, currentGlobalCamera :574-595
+    memcpy(t->Rlast, Rcurr, sizeof(Rcurr));
+    memcpy(t->tlast, tcurr, sizeof(tcurr));
+    compute_global_camera(t, tcurr);
+    kt_mat33 Rc, Rc_inv;
+    memcpy(Rc.m, Rcurr, sizeof(Rc.m));
+    kt_mat33_inverse(Rc.m, Rc_inv.m);
+
+    // [F] shift decision :627-667 and the three axis blocks :669-833
+    float current_translation[3];
+    for (int k = 0; k < 3; ++k) current_translation[k] = t->tlast[k] - t->volume_basis[k];
+    const int thresh = t->parked ? INT_MAX : t->cfg.voxel_shift;
+    int vt[3];
+    for (int k = 0; k < 3; ++k) vt[k] = voxel_trans(current_translation[k], t->voxel_size[k], thresh);
+    const int ov = t->cfg.overlap;
+    bool any_shift = false;
+    for (int axis = 0; axis < 3; ++axis) {
+        v_wrap_copy_update(t);
+        bool cycled = false;
+        int lo[3] = {0, 0, 0}, hi[3] = {N, N, N};
+        int dim = 0;
+        if (vt[axis] >= thresh) {
+            if (!any_shift) { KT_TRY(ev_begin(t, ST_SHIFT)); any_shift = true; }
+            lo[axis] = 0; hi[axis] = vt[axis] + 1 + ov;
+            dim = axis * 2;  // XPlus / YPlus / ZPlus, CloudSlice.h:33-36
+            KT_TRY(fetch_slice(t, lo, hi, dim));
+            KT_TRY(kt_clear_volume(c, t->tsdf, 2, N, axis, 0, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
+            KT_TRY(kt_clear_volume(c, t->color, 4, N, axis, 0, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
+            cycled = true;
+        } else if (vt[axis] <= -thresh) {
+            if (!any_shift) { KT_TRY(ev_begin(t, ST_SHIFT)); any_shift = true; }
+            if (axis == 2) { lo[2] = N + (vt[2] - ov) - 1; hi[2] = N - 1; }  // z-minus off by one :805
+            else { lo[axis] = N + (vt[axis] - ov); hi[axis] = N; }
+            dim = axis * 2 + 1;
+            KT_TRY(fetch_slice(t, lo, hi, dim));
+            KT_TRY(kt_clear_volume(c, t->tsdf, 2, N, axis, 1, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
+            KT_TRY(kt_clear_volume(c, t->color, 4, N, axis, 1, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
+            cycled = true;
+        }
+        if (cycled) {
+            // mutexOutCloudBuffer :1156-1208
+            float voxel_trans_size[3] = {0, 0, 0};
+            voxel_trans_size[axis] = t->voxel_size[axis] * (float)vt[axis];
+            for (int k = 0; k < 3; ++k) t->tlast[k] -= voxel_trans_size[k];
+            t->voxel_wrap[axis] += vt[axis];
+            for (int k = 0; k < 3; ++k) tcurr[k] -= voxel_trans_size[k];
+        }
+    }
+    v_wrap_copy_update(t);
+    if (any_shift) KT_TRY(ev_end(t, ST_SHIFT));
+
+    // [H] integrate: raw depth, current-frame level-0 normals :864-876
+    if (t->counting) {
+        KT_HIP(hipMemsetAsync(t->upd_dev, 0, sizeof(unsigned int), c->stream));
+        KT_HIP(hipMemsetAsync(t->steps_dev, 0, sizeof(unsigned long long), c->stream));
+    }
+    KT_TRY(ev_begin(t, ST_INTEGRATE));
+    KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rc_inv, tcurr, t->tranc_dist, t->tsdf,
+                                  t->depth_raw_scaled, t->v_wrap_copy, t->color, colors, t->nmaps_curr[0], angle_color, N,
+                                  t->counting ? t->upd_dev : nullptr));
+    KT_TRY(ev_end(t, ST_INTEGRATE));
+    v_wrap_copy_update(t);
+    // [I] raycast :880-890
+    KT_TRY(ev_begin(t, ST_RAYCAST));
+    KT_TRY(kt_raycast_impl(c, &t->intr, &Rc, tcurr, t->tranc_dist, t->volume_size, t->tsdf, t->vmaps_g_prev[0], t->nmaps_g_prev[0], cols, rows,
+                           t->v_wrap_copy, t->vmap_curr_color, t->color, N, t->counting ? t->steps_dev : nullptr));
+    KT_TRY(ev_end(t, ST_RAYCAST));
+    // [J] predicted-map pyramid :892-899
+    KT_TRY(ev_begin(t, ST_RESIZE));
+    if (icp || t->cfg.use_rgbd_icp)
+        for (int l = 1; l < KT_LEVELS; ++l) {
+            KT_TRY(kt_resize_vmap(c, t->vmaps_g_prev[l - 1], lvl_cols(t, l - 1), lvl_rows(t, l - 1), t->vmaps_g_prev[l]));
+            KT_TRY(kt_resize_nmap(c, t->nmaps_g_prev[l - 1], lvl_cols(t, l - 1), lvl_rows(t, l - 1), t->nmaps_g_prev[l]));
+        }
+    KT_TRY(ev_end(t, ST_RESIZE));
+    ++t->global_time;
+    push_pose(t, timestamp, Rcurr, 0);  // [K] :903-909
+    if (t->counting) {
+        unsigned int u = 0;
+        unsigned long long s = 0;
+        KT_HIP(hipMemcpyAsync(&u, t->upd_dev, sizeof(u), hipMemcpyDeviceToHost, c->stream));
+        KT_HIP(hipMemcpyAsync(&s, t->steps_dev, sizeof(s), hipMemcpyDeviceToHost, c->stream));
+        KT_HIP(hipStreamSynchronize(c->stream));
+        t->last_U = u;
+        t->last_S = s;
+    }
+    return KT_OK;
+}
+
+int kt_tracker_process_frame_host(kt_tracker* t, const uint16_t* depth_host, const uint8_t* rgb_host, uint64_t timestamp)
+{
+    // TrackerInterface::process upload, TrackerInterface.cpp:90-91 (pinned staging + async copies instead of blocking cudaMemcpy2D)
+    KT_ARG(t && depth_host && rgb_host);
+    const size_t P = (size_t)t->cfg.cols * t->cfg.rows;
+    KT_HIP(hipStreamSynchronize(t->ctx->stream));  // staging buffers are reused
+    memcpy(t->depth_stage_host, depth_host, P * sizeof(uint16_t));
+    memcpy(t->rgb_stage_host, rgb_host, P * 3);
+    KT_HIP(hipMemcpyAsync(t->depth_stage, t->depth_stage_host, P * sizeof(uint16_t), hipMemcpyHostToDevice, t->ctx->stream));
+    KT_HIP(hipMemcpyAsync(t->rgb_stage, t->rgb_stage_host, P * 3, hipMemcpyHostToDevice, t->ctx->stream));
+    return kt_tracker_process_frame(t, t->depth_stage, t->rgb_stage, timestamp);
+}
+
+int kt_tracker_finalise(kt_tracker* t)
+{
+    // finalise :1003-1048
+    KT_ARG(t);
+    v_wrap_copy_update(t);
+    const int lo[3] = {0, 0, 0}, hi[3] = {t->N, t->N, t->N};
+    return fetch_slice(t, lo, hi, 7 /* CloudSlice::FINAL */);
+}
+
+int kt_tracker_get_pose(kt_tracker* t, float* R, float* tv, float* gc)
+{
+    KT_ARG(t && R && tv && gc);
+    memcpy(R, t->Rlast, sizeof(t->Rlast));
+    memcpy(tv, t->tlast, sizeof(t->tlast));
+    memcpy(gc, t->current_global_camera, sizeof(t->current_global_camera));
+    return KT_OK;
+}
+int kt_tracker_num_poses(kt_tracker* t) { return t ? (int)t->poses.size() : 0; }
+int kt_tracker_get_dense_pose(kt_tracker* t, int i, uint64_t* ts, float* pose16, int* is_loop)
+{
+    KT_ARG(t && i >= 0 && i < (int)t->poses.size() && ts && pose16 && is_loop);
+    *ts = t->poses[i].ts;
+    memcpy(pose16, t->poses[i].pose, sizeof(t->poses[i].pose));
+    *is_loop = t->poses[i].is_loop;
+    return KT_OK;
+}
+int kt_tracker_get_voxel_wrap(kt_tracker* t, int* wrap)
+{
+    KT_ARG(t && wrap);
+    memcpy(wrap, t->voxel_wrap, sizeof(t->voxel_wrap));
+    return KT_OK;
+}
+int kt_tracker_num_slices(kt_tracker* t) { return t ? (int)t->slices.size() : 0; }
+int kt_tracker_slice_info(kt_tracker* t, int i, size_t* n_points, int* dimension)
+{
+    KT_ARG(t && i >= 0 && i < (int)t->slices.size() && n_points && dimension);
+    *n_points = t->slices[i].pts.size();
+    *dimension = t->slices[i].dim;
+    return KT_OK;
+}
+int kt_tracker_slice_points(kt_tracker* t, int i, kt_point_xyzrgb* out)
+{
+    KT_ARG(t && i >= 0 && i < (int)t->slices.size() && out);
+    if (!t->slices[i].pts.empty()) memcpy(out, t->slices[i].pts.data(), t->slices[i].pts.size() * sizeof(kt_point_xyzrgb));
+    return KT_OK;
+}
+int16_t* kt_tracker_volume(kt_tracker* t) { return t ? t->tsdf : nullptr; }
+uint8_t* kt_tracker_color_volume(kt_tracker* t) { return t ? t->color : nullptr; }
+float* kt_tracker_vmap_g_prev(kt_tracker* t, int l) { return (t && l >= 0 && l < KT_LEVELS) ? t->vmaps_g_prev[l] : nullptr; }
+float* kt_tracker_nmap_g_prev(kt_tracker* t, int l) { return (t && l >= 0 && l < KT_LEVELS) ? t->nmaps_g_prev[l] : nullptr; }
+float kt_tracker_trunc_dist(kt_tracker* t) { return t ? t->tranc_dist : 0.f; }
+
+int kt_tracker_enable_profiling(kt_tracker* t, int on)
+{
+    KT_ARG(t);
+    KT_HIP(hipStreamSynchronize(t->ctx->stream));
+    ev_collect(t);
+    t->profiling = on;
+    memset(t->stage_ms_sum, 0, sizeof(t->stage_ms_sum));
+    memset(t->stage_n, 0, sizeof(t->stage_n));
+    return KT_OK;
+}
+int kt_tracker_stage_ms(kt_tracker* t, float* ms)
+{
+    KT_ARG(t && ms);
+    KT_HIP(hipStreamSynchronize(t->ctx->stream));
+    ev_collect(t);
+    for (int s = 0; s < ST_COUNT; ++s) ms[s] = t->stage_n[s] ? (float)(t->stage_ms_sum[s] / (double)t->stage_n[s]) : 0.f;
+    return KT_OK;
+}
+int kt_tracker_stage_counts(kt_tracker* t, long long* n)
+{
+    KT_ARG(t && n);
+    for (int s = 0; s < ST_COUNT; ++s) n[s] = t->stage_n[s];
+    return KT_OK;
+}
+int kt_tracker_enable_counts(kt_tracker* t, int on)
+{
+    KT_ARG(t);
+    t->counting = on;
+    return KT_OK;
+}
+int kt_tracker_last_counts(kt_tracker* t, unsigned long long* U, unsigned long long* S)
+{
+    KT_ARG(t && U && S);
+    *U = t->last_U;
+    *S = t->last_S;
+    return KT_OK;
+}
+
+int kt_tracker_export_poses_device(kt_tracker* t, int k, float* dst_dev)
+{
+    KT_ARG(t && k > 0 && dst_dev && k <= (int)t->poses.size());
+    std::vector<float> tmp((size_t)k * 16);
+    for (int i = 0; i < k; ++i) memcpy(&tmp[(size_t)i * 16], t->poses[t->poses.size() - k + i].pose, 16 * sizeof(float));
+    KT_HIP(hipMemcpyAsync(dst_dev, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, t->ctx->stream));
+    KT_HIP(hipStreamSynchronize(t->ctx->stream));
+    return KT_OK;
+}
+
+}  // extern "C"

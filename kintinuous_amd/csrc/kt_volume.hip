@@ -1,0 +1,758 @@
+// kt_volume.hip -- cyclical TSDF volume kernels for gfx950: integrate (a11), raycast (a12),
+// slab clear (a14), cloud-slice extraction (a15), volume init.  Hand-written wave64 HIP; no MFMA
+// (there is no dense contraction on this path).  Reference: src/frontend/cuda/tsdf_volume.cu,
+// ray_caster.cu, extract.cu (file:line cited per kernel).  Results are bit-identical to the oracle's
+// restatement of those files: same operation order, explicit fmaf sites, IEEE div/sqrt.
+//
+// HBM layout: tsdf = int16[N^3] (x fastest), colour+weight = uchar4[N^3]; storage index is the logical
+// index rotated by voxel_wrap (tsdf_volume.cu:612).  Kernels are laid out so that the 64 lanes of a
+// wave own 64 consecutive STORAGE x of one (y, z) line: 128 B of tsdf + 256 B of colour per access.
+#include "kt_common.hpp"
+
+// ================================================================================================
+// init  (initVolume / initColorVolume, tsdf_volume.cu:56-87, 450-479): pack_tsdf(0) == 0, uchar4(0)
+// ================================================================================================
+extern "C" int kt_init_volume(kt_ctx* c, int16_t* volume, int N)
+{
+    KT_ARG(c && volume && N > 0);
+    KT_HIP(hipMemsetAsync(volume, 0, (size_t)N * N * N * sizeof(int16_t), c->stream));
+    return KT_OK;
+}
+extern "C" int kt_init_color_volume(kt_ctx* c, uint8_t* cv, int N)
+{
+    KT_ARG(c && cv && N > 0);
+    KT_HIP(hipMemsetAsync(cv, 0, (size_t)N * N * N * 4, c->stream));
+    return KT_OK;
+}
+
+// ================================================================================================
+// a11  integrateTsdfVolume = scaleDepth + tsdf23      tsdf_volume.cu:490-674
+// ================================================================================================
+// Per-pixel record consumed by the voxel kernel: everything tsdf23 gathers per projected pixel
+// (scaled depth with the no-colour sign flag, the colour weight derived from |n_z|, rgb, normal-valid)
+// packed into ONE 16-byte gather instead of 8 scalar gathers.  All fields are computed with exactly
+// the reference's expressions, only earlier.
+struct __attribute__((aligned(16))) kt_pixrec {
+    float dp;        // scaleDepth output (negative = "no colour", tsdf_volume.cu:520-527)
+    float wrkc;      // (angleColor ? min(1, |n_z| / 0.75) : 1) * 2       tsdf_volume.cu:625
+    uint32_t rgbf;   // r | g<<8 | b<<16 | (isnan(n_x) ? 1<<24 : 0)
+    uint32_t pad;
+};
+
+struct kt_integrate_tables {  // incremental z walk of tsdf23 (quirk A.17), identical for every column
+    float* vgz;      // v_g_z after z increments
+    float* zs;       // z_scaled after z increments
+};
+
+__global__ __launch_bounds__(256) void kt_scale_depth_kernel(const uint16_t* __restrict__ depth, float* __restrict__ scaled,
+                                                             kt_pixrec* __restrict__ rec, const uint8_t* __restrict__ colors,
+                                                             const float* __restrict__ nmap, int cols, int rows, kt_intr intr,
+                                                             int angle_color, float* __restrict__ vgz, float* __restrict__ zs,
+                                                             int N, float cell_z, float tz)
+{
+    // one thread of block 0 also produces the z-walk tables (a serial chain of N float adds)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0 && vgz) {
+        float v_g_z = __builtin_fmaf(0 + 0.5f, cell_z, -tz);
+        float z_scaled = 0;
+        for (int z = 0; z < N; ++z) {
+            vgz[z] = v_g_z;
+            zs[z] = z_scaled;
+            v_g_z += cell_z;
+            z_scaled += cell_z;
+        }
+    }
+    int x = threadIdx.x + blockIdx.x * blockDim.x;
+    int y = threadIdx.y + blockIdx.y * blockDim.y;
+    if (x >= cols || y >= rows) return;
+    int Dp = depth[y * cols + x];
+    float xl = ((float)x - intr.cx) / intr.fx;
+    float yl = ((float)y - intr.cy) / intr.fy;
+    float lambda = __builtin_sqrtf(__builtin_fmaf(xl, xl, yl * yl) + 1);
+    float out;
+    if (angle_color) {
+        const int ky = 7, kx = 7;
+        int ty = min(y - ky / 2 + ky, rows - 1);
+        int tx = min(x - kx / 2 + kx, cols - 1);
+        int count = 0;
+        for (int cy = max(y - ky / 2, 0); cy < ty; ++cy)
+            for (int cx = max(x - kx / 2, 0); cx < tx; ++cx)
+                if (abs(Dp - (int)depth[cy * cols + cx]) > 200 || Dp == 0) count++;
+        out = (count > 5) ? (float)(-Dp) * lambda / 1000.f : (float)Dp * lambda / 1000.f;
+    } else
+        out = (float)Dp * lambda / 1000.f;
+    scaled[y * cols + x] = out;
+    if (rec) {
+        float nx = nmap[y * cols + x];
+        float nz = nmap[(y + 2 * rows) * cols + x];
+        if (nz < 0) nz = -nz;
+        kt_pixrec r;
+        r.dp = out;
+        r.wrkc = (angle_color ? fminf(1.0f, nz / KT_RGB_VIEW_ANGLE_WEIGHT) : 1.0f) * 2.0f;
+        const uint8_t* c = &colors[3 * (y * cols + x)];
+        r.rgbf = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | (kt_isnan(nx) ? (1u << 24) : 0u);
+        r.pad = 0;
+        rec[y * cols + x] = r;
+    }
+}
+
+struct kt_tsdf23_args {
+    const kt_pixrec* rec;
+    int16_t* volume;
+    uchar4* color;
+    const float* vgz;
+    const float* zs;
+    unsigned int* updated;  // optional counter (U of SURVEY 8d)
+    kt_mat33 Ri;            // Rcurr_inv
+    float tx, ty, tz;
+    kt_intr intr;
+    float cell_x, cell_y, cell_z;
+    float tranc_dist;
+    int wx, wy, wz;         // voxel wrap, normalised to [0, N)
+    int cols, rows, N;
+};
+
+// Conservative z-interval of one voxel column inside the (margin-padded) view frustum.  Only used to
+// skip iterations whose in-image test must fail; every kept iteration runs the reference's exact test,
+// so results do not depend on how tight this is.  p(z) = A + z*B in camera coordinates.
+__device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float& lo, float& hi)
+{
+    // alpha + beta * z >= 0
+    if (beta > 1e-12f) lo = fmaxf(lo, -alpha / beta);
+    else if (beta < -1e-12f) hi = fminf(hi, -alpha / beta);
+    else if (alpha < 0) { lo = 1e30f; hi = -1e30f; }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void kt_tsdf23_kernel(const kt_tsdf23_args a)
+{
+    const int N = a.N;
+    // storage coordinates of this column; logical = storage - wrap (mod N)
+    const int sx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (sx >= N || sy >= N) return;
+    int x = sx - a.wx; if (x < 0) x += N;
+    int y = sy - a.wy; if (y < 0) y += N;
+
+    const float* Ri = a.Ri.m;
+    float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
+    float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
+    float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
+    float v_g_part_norm = __builtin_fmaf(v_g_x, v_g_x, v_g_y * v_g_y);
+    float v_x = __builtin_fmaf(Ri[2], v_g_z0, __builtin_fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * a.intr.fx;
+    float v_y = __builtin_fmaf(Ri[5], v_g_z0, __builtin_fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * a.intr.fy;
+    float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
+    const float Rcurr_inv_0_z_scaled = Ri[2] * a.cell_z * a.intr.fx;
+    const float Rcurr_inv_1_z_scaled = Ri[5] * a.cell_z * a.intr.fy;
+    const float tranc_dist_inv = 1.0f / a.tranc_dist;
+
+    // ---- conservative z interval -------------------------------------------------------------
+    int z0, z1;
+    {
+        // camera coordinates (unscaled) at z index 0 and the per-index step
+        float ax = Ri[0] * v_g_x + Ri[1] * v_g_y + Ri[2] * v_g_z0;
+        float ay = Ri[3] * v_g_x + Ri[4] * v_g_y + Ri[5] * v_g_z0;
+        float az = Ri[6] * v_g_x + Ri[7] * v_g_y + Ri[8] * v_g_z0;
+        float bx = Ri[2] * a.cell_z, by = Ri[5] * a.cell_z, bz = Ri[8] * a.cell_z;
+        const float m = 8.0f;         // pixel margin
+        const float znear = 0.05f;    // below this depth the pixel bounds are not trusted
+        float lo = 0.0f, hi = (float)(N - 1);
+        // frustum part: p_z >= znear and the four image sides padded by m pixels
+        float flo = lo, fhi = hi;
+        kt_clip_halfline(az - znear, bz, flo, fhi);
+        float ul = -0.5f - m - a.intr.cx, uh = (float)a.cols - 0.5f + m - a.intr.cx;
+        float vl = -0.5f - m - a.intr.cy, vh = (float)a.rows - 0.5f + m - a.intr.cy;
+        kt_clip_halfline(a.intr.fx * ax - ul * az, a.intr.fx * bx - ul * bz, flo, fhi);
+        kt_clip_halfline(uh * az - a.intr.fx * ax, uh * bz - a.intr.fx * bx, flo, fhi);
+        kt_clip_halfline(a.intr.fy * ay - vl * az, a.intr.fy * by - vl * bz, flo, fhi);
+        kt_clip_halfline(vh * az - a.intr.fy * ay, vh * bz - a.intr.fy * by, flo, fhi);
+        // near slab: -cell <= p_z <= znear, kept unconditionally (pixel coordinates ill-conditioned there)
+        float nlo = lo, nhi = hi;
+        kt_clip_halfline(az + a.cell_z + a.cell_x + a.cell_y, bz, nlo, nhi);
+        kt_clip_halfline(znear - az, -bz, nlo, nhi);
+        float l = 1e30f, h = -1e30f;
+        if (flo <= fhi) { l = fminf(l, flo); h = fmaxf(h, fhi); }
+        if (nlo <= nhi) { l = fminf(l, nlo); h = fmaxf(h, nhi); }
+        if (l > h) return;
+        z0 = max(0, (int)floorf(l) - 2);
+        z1 = min(N, (int)ceilf(h) + 3);
+        if (z0 >= z1) return;
+    }
+
+    // ---- replay the incremental walk up to z0 (quirk A.17: values are built by repeated +=) ----
+    for (int z = 0; z < z0; ++z) {
+        v_x += Rcurr_inv_0_z_scaled;
+        v_y += Rcurr_inv_1_z_scaled;
+    }
+
+    const size_t plane = (size_t)N * N;
+    const size_t col_base = (size_t)sx + (size_t)sy * N;
+    int sz = z0 + a.wz; if (sz >= N) sz -= N;
+    unsigned int n_upd = 0;
+
+    for (int z = z0; z < z1; ++z, v_x += Rcurr_inv_0_z_scaled, v_y += Rcurr_inv_1_z_scaled, sz = (sz + 1 == N) ? 0 : sz + 1) {
+        const float v_g_z = a.vgz[z];
+        const float z_scaled = a.zs[z];
+        float inv_z = 1.0f / __builtin_fmaf(Ri[8], z_scaled, v_z);
+        if (inv_z < 0) continue;
+        int coo_x = kt_f2i_rn(__builtin_fmaf(v_x, inv_z, a.intr.cx));
+        int coo_y = kt_f2i_rn(__builtin_fmaf(v_y, inv_z, a.intr.cy));
+        if (coo_x >= 0 && coo_y >= 0 && coo_x < a.cols && coo_y < a.rows) {
+            const kt_pixrec r = a.rec[coo_y * a.cols + coo_x];
+            float Dp_scaled = r.dp;
+            bool no_color = false;
+            if (Dp_scaled < 0.0f) { Dp_scaled = -Dp_scaled; no_color = true; }
+            float sdf = Dp_scaled - __builtin_sqrtf(__builtin_fmaf(v_g_z, v_g_z, v_g_part_norm));
+            if (Dp_scaled != 0 && sdf >= -a.tranc_dist) {
+                float tsdf = fminf(1.0f, sdf * tranc_dist_inv);
+                const size_t idx = col_base + (size_t)sz * plane;
+                float tsdf_prev = kt_unpack_tsdf(a.volume[idx]);
+                uchar4 c = a.color[idx];
+                float weight_prev = (float)c.w;
+                a.volume[idx] = kt_pack_tsdf(__builtin_fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
+                uchar4 o = c;
+                o.w = kt_f2u8_rz(fminf(weight_prev + 1.0f, KT_MAX_WEIGHT));
+                if (COUNT) ++n_upd;
+                const bool normal_nan = (r.rgbf >> 24) & 1u;
+                if ((!normal_nan && !no_color) || (c.x == 0 && c.y == 0 && c.z == 0)) {
+                    const float Wrkc = r.wrkc;
+                    const float den = weight_prev + Wrkc;
+                    float new_x = __builtin_fmaf((float)c.x, weight_prev, Wrkc * (float)(r.rgbf & 0xffu)) / den;
+                    float new_y = __builtin_fmaf((float)c.y, weight_prev, Wrkc * (float)((r.rgbf >> 8) & 0xffu)) / den;
+                    float new_z = __builtin_fmaf((float)c.z, weight_prev, Wrkc * (float)((r.rgbf >> 16) & 0xffu)) / den;
+                    o.x = (unsigned char)min(255, max(0, kt_f2i_rn(new_x)));
+                    o.y = (unsigned char)min(255, max(0, kt_f2i_rn(new_y)));
+                    o.z = (unsigned char)min(255, max(0, kt_f2i_rn(new_z)));
+                }
+                a.color[idx] = o;
+            }
+        }
+    }
+    if (COUNT) {
+        // wave-level sum, one atomic per wave
+        for (int off = 32; off > 0; off >>= 1) n_upd += __shfl_down(n_upd, off, 64);
+        if ((threadIdx.x & 63) == 0 && n_upd) atomicAdd(a.updated, n_upd);
+    }
+}
+
+// scratch owned by the context for integrate (pixel records + z tables), grown on demand
+struct kt_integrate_scratch {
+    kt_pixrec* rec = nullptr; size_t rec_px = 0;
+    float* vgz = nullptr; float* zs = nullptr; int tabN = 0;
+};
+static thread_local kt_integrate_scratch g_scratch;  // one GPU thread per context (SURVEY 8b threading)
+
+static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
+{
+    kt_integrate_scratch& s = g_scratch;
+    if (s.rec_px < px) {
+        if (s.rec) KT_HIP(hipFree(s.rec));
+        s.rec = nullptr; s.rec_px = 0;
+        KT_HIP(hipMalloc((void**)&s.rec, px * sizeof(kt_pixrec)));
+        s.rec_px = px;
+    }
+    if (s.tabN < N) {
+        if (s.vgz) KT_HIP(hipFree(s.vgz));
+        if (s.zs) KT_HIP(hipFree(s.zs));
+        s.vgz = s.zs = nullptr; s.tabN = 0;
+        KT_HIP(hipMalloc((void**)&s.vgz, sizeof(float) * N));
+        KT_HIP(hipMalloc((void**)&s.zs, sizeof(float) * N));
+        s.tabN = N;
+    }
+    return KT_OK;
+}
+
+// shared by the C entry point and the tracker (which wants the update count for the roofline report)
+int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
+                           const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
+                           int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
+                           const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev)
+{
+    KT_ARG(c && depth_raw && intr && volume_size && Rcurr_inv && tcurr && volume && depth_raw_scaled && voxel_wrap &&
+           color_volume && colors && nmap_curr && N > 0 && cols > 0 && rows > 0);
+    int s = kt_integrate_scratch_reserve(c, (size_t)cols * rows, N);
+    if (s != KT_OK) return s;
+    const float cell_x = volume_size[0] / N, cell_y = volume_size[1] / N, cell_z = volume_size[2] / N;
+    dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8));
+    hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, g_scratch.rec, colors, nmap_curr,
+                       cols, rows, *intr, angle_color, g_scratch.vgz, g_scratch.zs, N, cell_z, tcurr[2]);
+    KT_LAUNCH_CHECK();
+    kt_tsdf23_args a;
+    a.rec = g_scratch.rec;
+    a.volume = volume;
+    a.color = (uchar4*)color_volume;
+    a.vgz = g_scratch.vgz;
+    a.zs = g_scratch.zs;
+    a.updated = updated_dev;
+    a.Ri = *Rcurr_inv;
+    a.tx = tcurr[0]; a.ty = tcurr[1]; a.tz = tcurr[2];
+    a.intr = *intr;
+    a.cell_x = cell_x; a.cell_y = cell_y; a.cell_z = cell_z;
+    a.tranc_dist = tranc_dist;
+    for (int k = 0; k < 3; ++k) KT_ARG(voxel_wrap[k] >= 0);  // vWrapCopy is always normalised (KintinuousTracker.cpp:1075-1085)
+    a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
+    a.cols = cols; a.rows = rows; a.N = N;
+    dim3 b(256), g(kt_div_up(N, 64), kt_div_up(N, 4));
+    if (updated_dev) hipLaunchKernelGGL(kt_tsdf23_kernel<true>, g, b, 0, c->stream, a);
+    else hipLaunchKernelGGL(kt_tsdf23_kernel<false>, g, b, 0, c->stream, a);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+extern "C" int kt_integrate_tsdf(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
+                                 const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
+                                 int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
+                                 const uint8_t* colors, const float* nmap_curr, int angle_color, int N)
+{
+    return kt_integrate_tsdf_impl(c, depth_raw, cols, rows, intr, volume_size, Rcurr_inv, tcurr, tranc_dist, volume,
+                                  depth_raw_scaled, voxel_wrap, color_volume, colors, nmap_curr, angle_color, N, nullptr);
+}
+
+// ================================================================================================
+// a12  raycast -> rayCastKernel                       ray_caster.cu:56-471
+// ================================================================================================
+struct kt_raycast_args {
+    kt_mat33 R;
+    float tx, ty, tz;
+    float time_step;
+    float vsx, vsy, vsz;        // volume size
+    float cx_, cy_, cz_;        // cell size
+    int cols, rows, N;
+    const int16_t* volume;
+    const uchar4* color;
+    kt_intr intr;
+    float* vmap; float* nmap;
+    int wx, wy, wz;
+    uchar4* vmap_color;
+    unsigned long long* steps;  // optional march-step counter (S of SURVEY 8d)
+};
+
+struct kt_rc {
+    const kt_raycast_args& a;
+    __device__ __forceinline__ size_t index(int x, int y, int z) const
+    {
+        int X = x + a.wx; if (X >= a.N) X -= a.N;
+        int Y = y + a.wy; if (Y >= a.N) Y -= a.N;
+        int Z = z + a.wz; if (Z >= a.N) Z -= a.N;
+        return (size_t)X + (size_t)Y * a.N + (size_t)Z * a.N * a.N;
+    }
+    __device__ __forceinline__ void voxel(float px, float py, float pz, int& gx, int& gy, int& gz) const
+    {
+        gx = kt_f2i_rd(px / a.cx_);
+        gy = kt_f2i_rd(py / a.cy_);
+        gz = kt_f2i_rd(pz / a.cz_);
+    }
+    // interpolateTrilineary / ...Color / ...Heat bodies, ray_caster.cu:160-296.  CH < 0: tsdf.
+    template <int CH>
+    __device__ __forceinline__ bool trilinear(float px, float py, float pz, float& out) const
+    {
+        int gx, gy, gz;
+        voxel(px, py, pz, gx, gy, gz);
+        const int N = a.N;
+        if (gx <= 0 || gx >= N - 1) return false;
+        if (gy <= 0 || gy >= N - 1) return false;
+        if (gz <= 0 || gz >= N - 1) return false;
+        float vx = ((float)gx + 0.5f) * a.cx_;
+        float vy = ((float)gy + 0.5f) * a.cy_;
+        float vz = ((float)gz + 0.5f) * a.cz_;
+        gx = (px < vx) ? (gx - 1) : gx;
+        gy = (py < vy) ? (gy - 1) : gy;
+        gz = (pz < vz) ? (gz - 1) : gz;
+        float fa = __builtin_fmaf(-((float)gx + 0.5f), a.cx_, px) / a.cx_;
+        float fb = __builtin_fmaf(-((float)gy + 0.5f), a.cy_, py) / a.cy_;
+        float fc = __builtin_fmaf(-((float)gz + 0.5f), a.cz_, pz) / a.cz_;
+        float r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dx = (k >> 2) & 1, dy = (k >> 1) & 1, dz = k & 1;
+            const size_t i = index(gx + dx, gy + dy, gz + dz);
+            if (CH < 0) r[k] = kt_unpack_tsdf(a.volume[i]);
+            else {
+                const uchar4 c = a.color[i];
+                r[k] = (float)(CH == 0 ? c.x : CH == 1 ? c.y : CH == 2 ? c.z : c.w);
+            }
+        }
+        const float ia = 1 - fa, ib = 1 - fb, ic = 1 - fc;
+        float res = __builtin_fmaf(r[0] * ia * ib, ic, r[1] * ia * ib * fc);
+        res = __builtin_fmaf(r[2] * ia * fb, ic, res);
+        res = __builtin_fmaf(r[3] * ia * fb, fc, res);
+        res = __builtin_fmaf(r[4] * fa * ib, ic, res);
+        res = __builtin_fmaf(r[5] * fa * ib, fc, res);
+        res = __builtin_fmaf(r[6] * fa * fb, ic, res);
+        res = __builtin_fmaf(r[7] * fa * fb, fc, res);
+        out = res;
+        return true;
+    }
+    __device__ __forceinline__ float tsdf_at(float px, float py, float pz) const
+    {
+        float r;
+        return trilinear<-1>(px, py, pz, r) ? r : kt_nan();
+    }
+};
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a)
+{
+    // a 256-thread block covers a 16x16 pixel tile; each wave an 8x8 sub-tile (coherent gathers)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (x >= a.cols || y >= a.rows) return;
+    const kt_rc rc{a};
+    const int cols = a.cols, rows = a.rows, N = a.N;
+    unsigned int steps = 0;
+
+    float out_vx = kt_nan(), out_nx = kt_nan();
+    bool hit = false, has_normal = false;
+    float vfx = 0, vfy = 0, vfz = 0, nx = 0, ny = 0, nz = 0;
+    uchar4 colr = make_uchar4(0, 0, 0, 0);
+
+    const f3 rs = {a.tx, a.ty, a.tz};
+    f3 rnl = {((float)x - a.intr.cx) / a.intr.fx, ((float)y - a.intr.cy) / a.intr.fy, 1.0f};
+    f3 ray_next = kt_add(kt_mul(a.R, rnl), rs);
+    f3 rd = kt_normalized(kt_sub(ray_next, rs));
+    rd.x = (rd.x == 0.f) ? (float)1e-15 : rd.x;
+    rd.y = (rd.y == 0.f) ? (float)1e-15 : rd.y;
+    rd.z = (rd.z == 0.f) ? (float)1e-15 : rd.z;
+    // getMinTime / getMaxTime  ray_caster.cu:56-74
+    float txmin = ((rd.x > 0 ? 0.f : a.vsx) - rs.x) / rd.x;
+    float tymin = ((rd.y > 0 ? 0.f : a.vsy) - rs.y) / rd.y;
+    float tzmin = ((rd.z > 0 ? 0.f : a.vsz) - rs.z) / rd.z;
+    float txmax = ((rd.x > 0 ? a.vsx : 0.f) - rs.x) / rd.x;
+    float tymax = ((rd.y > 0 ? a.vsy : 0.f) - rs.y) / rd.y;
+    float tzmax = ((rd.z > 0 ? a.vsz : 0.f) - rs.z) / rd.z;
+    float time_start_volume = fmaxf(fmaxf(txmin, tymin), tzmin);
+    float time_exit_volume = fminf(fminf(txmax, tymax), tzmax);
+    time_start_volume = fmaxf(time_start_volume, 0.f);
+    if (time_start_volume < time_exit_volume) {
+        float time_curr = time_start_volume;
+        int gx, gy, gz;
+        rc.voxel(__builtin_fmaf(rd.x, time_curr, rs.x), __builtin_fmaf(rd.y, time_curr, rs.y), __builtin_fmaf(rd.z, time_curr, rs.z), gx, gy, gz);
+        gx = max(0, min(gx, N - 1)); gy = max(0, min(gy, N - 1)); gz = max(0, min(gz, N - 1));
+        // only the SIGN of the nearest-voxel tsdf steers the march: compare the packed shorts directly
+        int tsdf = a.volume[rc.index(gx, gy, gz)];
+        const float max_time = 3 * (a.vsx + a.vsy + a.vsz);
+        for (; time_curr < max_time; time_curr += a.time_step) {
+            const int tsdf_prev = tsdf;
+            const float tn = time_curr + a.time_step;
+            const float px = __builtin_fmaf(rd.x, tn, rs.x), py = __builtin_fmaf(rd.y, tn, rs.y), pz = __builtin_fmaf(rd.z, tn, rs.z);
+            rc.voxel(px, py, pz, gx, gy, gz);
+            if (!(gx >= 0 && gy >= 0 && gz >= 0 && gx < N && gy < N && gz < N)) break;  // checkInds
+            tsdf = a.volume[rc.index(gx, gy, gz)];
+            if (COUNT) ++steps;
+            if (tsdf_prev < 0 && tsdf > 0) break;
+            if (tsdf_prev > 0 && tsdf < 0) {  // zero crossing
+                float Ftdt = rc.tsdf_at(px, py, pz);
+                if (kt_isnan(Ftdt)) break;
+                const float qx = __builtin_fmaf(rd.x, time_curr, rs.x), qy = __builtin_fmaf(rd.y, time_curr, rs.y), qz = __builtin_fmaf(rd.z, time_curr, rs.z);
+                float Ft = rc.tsdf_at(qx, qy, qz);
+                if (kt_isnan(Ft)) break;
+                float Ts = time_curr - a.time_step * Ft / (Ftdt - Ft);
+                vfx = __builtin_fmaf(rd.x, Ts, rs.x); vfy = __builtin_fmaf(rd.y, Ts, rs.y); vfz = __builtin_fmaf(rd.z, Ts, rs.z);
+                hit = true;
+                out_vx = vfx;
+                int hx, hy, hz;
+                rc.voxel(qx, qy, qz, hx, hy, hz);
+                float col;
+                colr.x = rc.trilinear<0>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
+                colr.y = rc.trilinear<1>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
+                colr.z = rc.trilinear<2>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
+                colr.w = rc.trilinear<3>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
+                if (hx > 1 && hy > 1 && hz > 1 && hx < N - 2 && hy < N - 2 && hz < N - 2) {
+                    float Fx1 = rc.tsdf_at(vfx + a.cx_, vfy, vfz), Fx2 = rc.tsdf_at(vfx - a.cx_, vfy, vfz);
+                    float Fy1 = rc.tsdf_at(vfx, vfy + a.cy_, vfz), Fy2 = rc.tsdf_at(vfx, vfy - a.cy_, vfz);
+                    float Fz1 = rc.tsdf_at(vfx, vfy, vfz + a.cz_), Fz2 = rc.tsdf_at(vfx, vfy, vfz - a.cz_);
+                    f3 n = kt_normalized({Fx1 - Fx2, Fy1 - Fy2, Fz1 - Fz2});
+                    nx = n.x; ny = n.y; nz = n.z;
+                    has_normal = true;
+                    out_nx = nx;
+                }
+                break;
+            }
+        }
+    }
+    // unhit pixels: NaN in the x planes only, y/z planes and the colour map keep their previous content
+    a.vmap[y * cols + x] = out_vx;
+    a.nmap[y * cols + x] = out_nx;
+    if (hit) {
+        a.vmap[(y + rows) * cols + x] = vfy;
+        a.vmap[(y + 2 * rows) * cols + x] = vfz;
+        a.vmap_color[y * cols + x] = colr;
+        if (has_normal) {
+            a.nmap[(y + rows) * cols + x] = ny;
+            a.nmap[(y + 2 * rows) * cols + x] = nz;
+        }
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) steps += __shfl_down(steps, off, 64);
+        if (lane == 0 && steps) atomicAdd(a.steps, (unsigned long long)steps);
+    }
+}
+
+int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const float tcurr[3], float tranc_dist,
+                    const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
+                    const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,
+                    unsigned long long* steps_dev)
+{
+    KT_ARG(c && intr && Rcurr && tcurr && volume_size && volume && vmap && nmap && voxel_wrap && vmap_curr_color && color_volume);
+    KT_ARG(N > 0 && cols > 0 && rows > 0);
+    kt_raycast_args a;
+    a.R = *Rcurr;
+    a.tx = tcurr[0]; a.ty = tcurr[1]; a.tz = tcurr[2];
+    a.time_step = tranc_dist * 0.8f;  // ray_caster.cu:444
+    a.vsx = volume_size[0]; a.vsy = volume_size[1]; a.vsz = volume_size[2];
+    a.cx_ = volume_size[0] / N; a.cy_ = volume_size[1] / N; a.cz_ = volume_size[2] / N;
+    a.cols = cols; a.rows = rows; a.N = N;
+    a.volume = volume;
+    a.color = (const uchar4*)color_volume;
+    a.intr = *intr;
+    a.vmap = vmap; a.nmap = nmap;
+    for (int k = 0; k < 3; ++k) KT_ARG(voxel_wrap[k] >= 0);
+    a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
+    a.vmap_color = (uchar4*)vmap_curr_color;
+    a.steps = steps_dev;
+    dim3 b(256), g(kt_div_up(cols, 16), kt_div_up(rows, 16));
+    if (steps_dev) hipLaunchKernelGGL(kt_raycast_kernel<true>, g, b, 0, c->stream, a);
+    else hipLaunchKernelGGL(kt_raycast_kernel<false>, g, b, 0, c->stream, a);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+extern "C" int kt_raycast(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const float tcurr[3], float tranc_dist,
+                          const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
+                          const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N)
+{
+    return kt_raycast_impl(c, intr, Rcurr, tcurr, tranc_dist, volume_size, volume, vmap, nmap, cols, rows, voxel_wrap,
+                           vmap_curr_color, color_volume, N, nullptr);
+}
+
+// ================================================================================================
+// a14  clearVolume{X,Y,Z}{,Back}{,c}                  tsdf_volume.cu:88-448
+// The reference launches one thread per (x,y) [or (x,z)] walking the slab; here every wave clears
+// 64 consecutive storage x of one line, 16 bytes per lane where the slab is contiguous in x.
+// The set of cleared voxels reproduces the reference's launch geometry (incl. quirk A.15).
+// ================================================================================================
+struct kt_clear_args {
+    void* vol; int elem_size; int N;
+    int axis;     // 0 x, 1 y, 2 z
+    int start;    // first storage index along the axis
+    int count;    // number of planes (walk length), consecutive modulo N
+    int xthreads; // X variants: number of x "threads" the reference launched (multiple of 16)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void kt_clear_kernel(const kt_clear_args a)
+{
+    const int N = a.N;
+    T* vol = (T*)a.vol;
+    if (a.axis == 0) {
+        // grid: (ceil(count / 64), N, N): x index inside the slab, y, z
+        const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+        const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+        const int z = blockIdx.z;
+        if (i >= a.count || i >= a.xthreads || y >= N) return;
+        int x = a.start + i; if (x >= N) x -= N;
+        vol[(size_t)x + (size_t)y * N + (size_t)z * N * N] = T(0);
+    } else {
+        // grid: (ceil(N/64), ceil(N/4), count): storage x, the free axis, plane inside the slab
+        const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+        const int o = blockIdx.y * 4 + (threadIdx.x >> 6);
+        const int p = blockIdx.z;
+        if (x >= N || o >= N) return;
+        int s = a.start + p; if (s >= N) s -= N;
+        const size_t idx = a.axis == 1 ? (size_t)x + (size_t)s * N + (size_t)o * N * N
+                                        : (size_t)x + (size_t)o * N + (size_t)s * N * N;
+        vol[idx] = T(0);
+    }
+}
+
+static int kt_wrap_base(int currentVoxelWrap, int N)
+{
+    return currentVoxelWrap > 0 ? currentVoxelWrap % N : N - ((-currentVoxelWrap) % N);
+}
+
+extern "C" int kt_clear_volume(kt_ctx* c, void* volume, int elem_size, int N, int axis, int back, int currentVoxelWrap,
+                               int deltaVoxelWrap)
+{
+    KT_ARG(c && volume && (elem_size == 2 || elem_size == 4) && N > 0 && axis >= 0 && axis <= 2);
+    kt_clear_args a;
+    a.vol = volume; a.elem_size = elem_size; a.N = N; a.axis = axis; a.xthreads = N;
+    const int base = kt_wrap_base(currentVoxelWrap, N);
+    if (!back) {
+        // clearVolumeIn{Y,Z}: walk bottom, bottom+1, ... for numUp+1 planes  (tsdf_volume.cu:240-262, 345-367)
+        const int numUp = -(currentVoxelWrap - deltaVoxelWrap);
+        a.start = base % N;
+        a.count = numUp + 1;
+    } else {
+        // clearVolumeIn{Y,Z}Back: walk top, top-1, ... for numDown+1 planes   (tsdf_volume.cu:290-317, 395-422)
+        const int top = (base + N) % N;
+        const int numDown = currentVoxelWrap - deltaVoxelWrap;
+        a.count = numDown + 1;
+        int bottom = (top - numDown) % N;
+        if (bottom < 0) bottom += N;
+        a.start = bottom;
+    }
+    if (a.count <= 0) return KT_OK;
+    if (a.count > N) a.count = N;
+    if (axis == 0) {
+        // clearVolumeX / XBack launch geometry (tsdf_volume.cu:117-237): only ceil(r/16)*16 x-threads exist
+        int remainder = (deltaVoxelWrap - currentVoxelWrap) % 16;
+        if (remainder != 0) remainder = (deltaVoxelWrap - currentVoxelWrap) + 16 - remainder;
+        else remainder = abs(deltaVoxelWrap - currentVoxelWrap);
+        int grid_x = (remainder + 15) / 16;
+        if (grid_x <= 0) return KT_OK;
+        a.xthreads = grid_x * 16;
+    }
+    dim3 b(256), g;
+    if (axis == 0) g = dim3(kt_div_up(a.count, 64), kt_div_up(N, 4), N);
+    else g = dim3(kt_div_up(N, 64), kt_div_up(N, 4), a.count);
+    if (elem_size == 2) hipLaunchKernelGGL(kt_clear_kernel<int16_t>, g, b, 0, c->stream, a);
+    else hipLaunchKernelGGL(kt_clear_kernel<uint32_t>, g, b, 0, c->stream, a);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// ================================================================================================
+// a15  extractCloudSlice -> extractKernelSlice        extract.cu:79-419
+// One thread per candidate voxel of the slab (x fastest); wave-level compaction with a 64-lane ballot
+// prefix and ONE global atomic per wave (the reference: 32-lane shared-memory scan + atomic per warp
+// per z-step).  Output order is unspecified in both.
+// ================================================================================================
+struct kt_extract_args {
+    const int16_t* volume; const uchar4* color;
+    kt_point_xyzrgb* out; unsigned int out_cap;
+    unsigned int* count;      // device counter
+    float cx, cy, cz;         // cell size
+    int wx, wy, wz;           // storage wrap (normalised)
+    int rwx, rwy, rwz;        // real voxel wrap (for the output offset)
+    int minX, maxX, minY, maxY, minZ, maxZ, subsample;
+    int nx, ny, nz;           // extents of the scanned box
+    int N;
+};
+
+__device__ __forceinline__ size_t kt_ex_index(const kt_extract_args& a, int x, int y, int z)
+{
+    // (x + wrap) % N with z + 1 possibly == N (wraps through the modulo, quirk of extract.cu:190-196)
+    int X = (x + a.wx) % a.N, Y = (y + a.wy) % a.N, Z = (z + a.wz) % a.N;
+    return (size_t)X + (size_t)Y * a.N + (size_t)Z * a.N * a.N;
+}
+
+__global__ __launch_bounds__(256) void kt_extract_kernel(const kt_extract_args a)
+{
+    const long long total = (long long)a.nx * a.ny * a.nz;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float4 pts[3];
+    uint32_t cols[3];
+    int local = 0;
+    if (tid < total) {
+        const int ix = (int)(tid % a.nx);
+        const int iy = (int)((tid / a.nx) % a.ny);
+        const int iz = (int)(tid / ((long long)a.nx * a.ny));
+        const int x = a.minX + ix, y = a.minY + iy, z = a.minZ + iz * a.subsample;
+        const int N = a.N;
+        if (x >= 0 && y >= 0 && x < N && y < N && x % a.subsample == 0 && y % a.subsample == 0) {
+            const size_t i0 = kt_ex_index(a, x, y, z);
+            const int W = a.color[i0].w;
+            const float F = kt_unpack_tsdf(a.volume[i0]);
+            if (W != 0 && F != 1.f) {
+                const float V[3] = {((float)x + 0.5f) * a.cx, ((float)y + 0.5f) * a.cy, ((float)z + 0.5f) * a.cz};
+                const float cell[3] = {a.cx, a.cy, a.cz};
+#pragma unroll
+                for (int axis = 0; axis < 3; ++axis) {
+                    const int nx = x + (axis == 0), ny = y + (axis == 1), nz = z + (axis == 2);
+                    if (axis == 0 && !(x + 1 < N)) continue;
+                    if (axis == 1 && !(y + 1 < N)) continue;
+                    const size_t in = kt_ex_index(a, nx, ny, nz);
+                    const uchar4 cn = a.color[in];
+                    const float Fn = kt_unpack_tsdf(a.volume[in]);
+                    if (!(cn.w != 0 && Fn != 1.f)) continue;
+                    if (!((F > 0 && Fn < 0) || (F < 0 && Fn > 0))) continue;
+                    float p[3] = {V[0], V[1], V[2]};
+                    const float Vn = V[axis] + cell[axis];
+                    const float d_inv = 1.f / (fabsf(F) + fabsf(Fn));
+                    p[axis] = __builtin_fmaf(V[axis], fabsf(Fn), Vn * fabsf(F)) * d_inv;
+                    pts[local] = make_float4(p[0], p[1], p[2], 0.f);
+                    // colour of the NEIGHBOUR voxel, alpha = weight of the base voxel; the point's byte order is
+                    // b,g,r,a with ptr->b = colour.x and ptr->r = colour.z (store_point_type, quirk A.14)
+                    cols[local] = (uint32_t)cn.x | ((uint32_t)cn.y << 8) | ((uint32_t)cn.z << 16) | ((uint32_t)W << 24);
+                    ++local;
+                }
+            }
+        }
+    }
+    // wave compaction: exclusive prefix of `local` over the 64 lanes
+    const int lane = threadIdx.x & 63;
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const int wave_total = __shfl(incl, 63, 64);
+    if (wave_total == 0) return;
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(a.count, (unsigned int)wave_total);
+    base = __shfl(base, 0, 64);
+    const unsigned int offs = base + (unsigned int)(incl - local);
+    for (int l = 0; l < local; ++l) {
+        const unsigned int o = offs + l;
+        if (o < a.out_cap) {
+            // store_point_type  extract.cu:307-317
+            float4 lo, hi;
+            lo.x = __builtin_fmaf((float)a.rwx, a.cx, pts[l].x) - ((a.cx * a.N) / 2);
+            lo.y = __builtin_fmaf((float)a.rwy, a.cy, pts[l].y) - ((a.cy * a.N) / 2);
+            lo.z = __builtin_fmaf((float)a.rwz, a.cz, pts[l].z) - ((a.cz * a.N) / 2);
+            lo.w = 0.f;
+            hi.x = __uint_as_float(cols[l]); hi.y = 0.f; hi.z = 0.f; hi.w = 0.f;
+            float4* dst = (float4*)&a.out[o];  // two 16-byte stores per 32-byte point
+            dst[0] = lo;
+            dst[1] = hi;
+        }
+    }
+}
+
+int kt_extract_cloud_slice_async(kt_ctx* c, const int16_t* volume, const float volume_size[3], kt_point_xyzrgb* output,
+                                 size_t output_capacity, const int voxel_wrap[3], const uint8_t* color_volume, int minX, int maxX,
+                                 int minY, int maxY, int minZ, int maxZ, int subsample, const int real_voxel_wrap[3], int N,
+                                 unsigned int* count_dev)
+{
+    KT_ARG(c && volume && volume_size && output && voxel_wrap && color_volume && real_voxel_wrap && count_dev);
+    KT_ARG(N > 0 && subsample > 0);
+    for (int k = 0; k < 3; ++k) KT_ARG(voxel_wrap[k] >= 0);
+    KT_HIP(hipMemsetAsync(count_dev, 0, sizeof(unsigned int), c->stream));
+    kt_extract_args a;
+    a.volume = volume; a.color = (const uchar4*)color_volume;
+    a.out = output; a.out_cap = (unsigned int)(output_capacity > 0xffffffffull ? 0xffffffffull : output_capacity);
+    a.count = count_dev;
+    a.cx = volume_size[0] / N; a.cy = volume_size[1] / N; a.cz = volume_size[2] / N;
+    a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
+    a.rwx = real_voxel_wrap[0]; a.rwy = real_voxel_wrap[1]; a.rwz = real_voxel_wrap[2];
+    a.minX = minX < 0 ? 0 : minX; a.maxX = maxX > N ? N : maxX;
+    a.minY = minY < 0 ? 0 : minY; a.maxY = maxY > N ? N : maxY;
+    a.minZ = minZ; a.maxZ = maxZ; a.subsample = subsample;
+    a.nx = a.maxX - a.minX; a.ny = a.maxY - a.minY;
+    a.nz = (maxZ - minZ + subsample - 1) / subsample;  // for (z = minZ; z < maxZ; z += subsample)
+    a.N = N;
+    if (a.nx <= 0 || a.ny <= 0 || a.nz <= 0) return KT_OK;
+    const long long total = (long long)a.nx * a.ny * a.nz;
+    const long long blocks = (total + 255) / 256;
+    KT_ARG(blocks < 0x7fffffffll);
+    hipLaunchKernelGGL(kt_extract_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+extern "C" int kt_extract_cloud_slice(kt_ctx* c, const int16_t* volume, const float volume_size[3], kt_point_xyzrgb* output,
+                                      size_t output_capacity, const int voxel_wrap[3], const uint8_t* color_volume, int minX,
+                                      int maxX, int minY, int maxY, int minZ, int maxZ, int subsample,
+                                      const int real_voxel_wrap[3], int N, size_t* count_host)
+{
+    KT_ARG(count_host);
+    int s = kt_extract_cloud_slice_async(c, volume, volume_size, output, output_capacity, voxel_wrap, color_volume, minX, maxX,
+                                         minY, maxY, minZ, maxZ, subsample, real_voxel_wrap, N, &c->counters[1]);
+    if (s != KT_OK) return s;
+    KT_HIP(hipMemcpyAsync(c->int_out_host, &c->counters[1], sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    size_t n = (size_t)(unsigned int)c->int_out_host[0];
+    *count_host = n < output_capacity ? n : output_capacity;  // output_count = min(output.size, global_count)
+    return KT_OK;
+}

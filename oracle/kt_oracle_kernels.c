@@ -1,0 +1,1009 @@
+/*
+ * kt_oracle_kernels.c -- CPU restatement of the reference's device kernels.
+ * TEST INFRASTRUCTURE ONLY (see kt_oracle.h).  PARITY UNPINNED (no reference golden vectors exist).
+ * Every function cites the reference file:line it follows (paths relative to /root/reference/src/).
+ * Build: gcc -O2 -ffp-contract=off -fopenmp (see oracle/Makefile).  Never build with -ffast-math.
+ */
+#include "kt_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KTO_DIVISOR 32767               /* internal.h:237 */
+#define KTO_RGB_VIEW_ANGLE_WEIGHT 0.75f /* internal.h:241 */
+#define KTO_MAX_WEIGHT 128.0f           /* tsdf_volume.cu:481-488 */
+
+static inline float kto_nan(void) { union { uint32_t u; float f; } c; c.u = 0x7fffffffu; return c.f; } /* limits.hpp */
+static inline int kto_isnan(float x) { return x != x; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* ------------------------------------------------------------------------------------------------
+ * CUDA float->int conversions: saturating, NaN -> 0.
+ * ---------------------------------------------------------------------------------------------- */
+int kto_f2i_rn(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT_MAX;
+    if (x <= -2147483648.0f) return INT_MIN;
+    return (int)rintf(x); /* default rounding mode: nearest-even */
+}
+int kto_f2i_rz(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT_MAX;
+    if (x <= -2147483648.0f) return INT_MIN;
+    return (int)truncf(x);
+}
+int kto_f2i_rd(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT_MAX;
+    if (x <= -2147483648.0f) return INT_MIN;
+    return (int)floorf(x);
+}
+/* float -> uchar as cvt.rzi.u8.f32: truncate, saturate to [0,255], NaN -> 0 */
+static inline uint8_t f2u8_rz(float x)
+{
+    if (x != x) return 0;
+    if (x <= 0.0f) return 0;
+    if (x >= 255.0f) return 255;
+    return (uint8_t)(int)x;
+}
+/* float -> short as cvt.rzi.s16.f32 */
+static inline int16_t f2s16_rz(float x)
+{
+    if (x != x) return 0;
+    if (x <= -32768.0f) return -32768;
+    if (x >= 32767.0f) return 32767;
+    return (int16_t)(int)x;
+}
+
+/* Restatement of __expf (bilateral_pyrdown.cu:89): exp(x) = 2^n * e^r, n = rint(x*log2e),
+ * r = x - n*ln2 (two-step Cody-Waite), e^r by the cephes degree-6 polynomial, every step an explicit
+ * fmaf so that the HIP kernel can repeat it bit for bit.  Results below 2^-125 flush to 0 (the reference
+ * is built with --ftz=true). Only called with x <= 0. */
+float kto_expf(float x)
+{
+    float t = x * 1.44269504088896341f;
+    if (!(t >= -125.0f)) return 0.0f; /* also catches NaN */
+    float n = rintf(t);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = fmaf(p, r, 1.3981999507E-3f);
+    p = fmaf(p, r, 8.3334519073E-3f);
+    p = fmaf(p, r, 4.1665795894E-2f);
+    p = fmaf(p, r, 1.6666665459E-1f);
+    p = fmaf(p, r, 5.0000001201E-1f);
+    float r2 = r * r;
+    float e = fmaf(p, r2, r) + 1.0f;
+    union { uint32_t u; float f; } s;
+    s.u = (uint32_t)((int)n + 127) << 23;
+    return e * s.f;
+}
+
+/* vector_math.hpp:53-61, with nvcc -fmad contraction written out (LLVM rule, see kt_oracle.h) */
+static inline float dot3(const float a[3], const float b[3])
+{
+    return fmaf(a[2], b[2], fmaf(a[0], b[0], a[1] * b[1]));
+}
+static inline void cross3(const float a[3], const float b[3], float o[3])
+{
+    o[0] = fmaf(a[1], b[2], -(a[2] * b[1]));
+    o[1] = fmaf(a[2], b[0], -(a[0] * b[2]));
+    o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+/* vector_math.hpp:98-102 */
+static inline void mat33_mul(const kto_mat33* m, const float v[3], float o[3])
+{
+    float r0 = dot3(&m->m[0], v), r1 = dot3(&m->m[3], v), r2 = dot3(&m->m[6], v);
+    o[0] = r0; o[1] = r1; o[2] = r2;
+}
+/* normalized(): v * rsqrtf(dot(v,v)), rsqrtf restated as 1/sqrtf (vector_math.hpp:83-91) */
+static inline void normalize3(float v[3])
+{
+    float inv = 1.0f / sqrtf(dot3(v, v));
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+
+/* ================================================================================================
+ * a1  bilateralFilter -> bilateralKernel            bilateral_pyrdown.cu:59-99, 332-342
+ * ============================================================================================== */
+void kto_bilateral_filter(const uint16_t* src, uint16_t* dst, int cols, int rows)
+{
+    const float sigma_color = 30.0f, sigma_space = 4.5f;                       /* :56-57 */
+    const float sigma_space2_inv_half = 0.5f / (sigma_space * sigma_space);     /* :338 */
+    const float sigma_color2_inv_half = 0.5f / (sigma_color * sigma_color);
+    const int R = 6, D = R * 2 + 1;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            int value = src[y * cols + x];
+            int tx = imin(x - D / 2 + D, cols - 1); /* exclusive, clipped to cols-1: quirk A.5 */
+            int ty = imin(y - D / 2 + D, rows - 1);
+            float sum1 = 0, sum2 = 0;
+            for (int cy = imax(y - D / 2, 0); cy < ty; ++cy)
+                for (int cx = imax(x - D / 2, 0); cx < tx; ++cx) {
+                    int tmp = src[cy * cols + cx];
+                    float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
+                    float color2 = (float)(int)((unsigned)(value - tmp) * (unsigned)(value - tmp));
+                    float weight = kto_expf(-fmaf(space2, sigma_space2_inv_half, color2 * sigma_color2_inv_half));
+                    sum1 = fmaf((float)tmp, weight, sum1);
+                    sum2 += weight;
+                }
+            int res = kto_f2i_rn(sum1 / sum2);
+            dst[y * cols + x] = (uint16_t)imax(0, imin(res, 32767));
+        }
+}
+
+/* ================================================================================================
+ * a2  pyrDown -> pyrDownGaussKernel                 bilateral_pyrdown.cu:101-136, 344-354
+ * ============================================================================================== */
+void kto_pyr_down(const uint16_t* src, int scols, int srows, uint16_t* dst)
+{
+    const int dcols = scols / 2, drows = srows / 2, D = 5;
+    const float sigma_color = 30.0f;
+    const float weights[3] = {0.375f, 0.25f, 0.0625f};
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < drows; ++y)
+        for (int x = 0; x < dcols; ++x) {
+            int center = src[(2 * y) * scols + 2 * x];
+            int x_mi = imax(0, 2 * x - D / 2) - 2 * x;
+            int y_mi = imax(0, 2 * y - D / 2) - 2 * y;
+            int x_ma = imin(scols, 2 * x - D / 2 + D) - 2 * x;
+            int y_ma = imin(srows, 2 * y - D / 2 + D) - 2 * y;
+            float sum = 0, wall = 0;
+            for (int yi = y_mi; yi < y_ma; ++yi)
+                for (int xi = x_mi; xi < x_ma; ++xi) {
+                    int val = src[(2 * y + yi) * scols + 2 * x + xi];
+                    if ((float)abs(val - center) < 3 * sigma_color) {
+                        float wx = weights[abs(xi)], wy = weights[abs(yi)];
+                        sum = fmaf((float)val * wx, wy, sum);
+                        wall = fmaf(wx, wy, wall);
+                    }
+                }
+            dst[y * dcols + x] = (uint16_t)kto_f2i_rz(sum / wall); /* static_cast<int>: truncation, quirk A.6 */
+        }
+}
+
+/* ================================================================================================
+ * a3  createVMap -> computeVmapKernel               maps.cu:56-80, 122-137
+ * ============================================================================================== */
+void kto_create_vmap(kto_intr intr, const uint16_t* depth, int cols, int rows, float* vmap)
+{
+    const float fx_inv = 1.f / intr.fx, fy_inv = 1.f / intr.fy, cx = intr.cx, cy = intr.cy;
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < rows; ++v)
+        for (int u = 0; u < cols; ++u) {
+            float z = (float)depth[v * cols + u] / 1000.f;
+            if (z != 0) {
+                vmap[v * cols + u] = z * ((float)u - cx) * fx_inv;
+                vmap[(v + rows) * cols + u] = z * ((float)v - cy) * fy_inv;
+                vmap[(v + 2 * rows) * cols + u] = z;
+            } else
+                vmap[v * cols + u] = kto_nan(); /* x plane only: quirk A.7 */
+        }
+}
+
+/* ================================================================================================
+ * a4  createNMap -> computeNmapKernel               maps.cu:82-120, 139-154
+ * ============================================================================================== */
+void kto_create_nmap(const float* vmap, int cols, int rows, float* nmap)
+{
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < rows; ++v)
+        for (int u = 0; u < cols; ++u) {
+            if (u == cols - 1 || v == rows - 1) { nmap[v * cols + u] = kto_nan(); continue; }
+            float v00[3], v01[3], v10[3];
+            v00[0] = vmap[v * cols + u];
+            v01[0] = vmap[v * cols + u + 1];
+            v10[0] = vmap[(v + 1) * cols + u];
+            if (!kto_isnan(v00[0]) && !kto_isnan(v01[0]) && !kto_isnan(v10[0])) {
+                v00[1] = vmap[(v + rows) * cols + u];
+                v01[1] = vmap[(v + rows) * cols + u + 1];
+                v10[1] = vmap[(v + 1 + rows) * cols + u];
+                v00[2] = vmap[(v + 2 * rows) * cols + u];
+                v01[2] = vmap[(v + 2 * rows) * cols + u + 1];
+                v10[2] = vmap[(v + 1 + 2 * rows) * cols + u];
+                float a[3] = {v01[0] - v00[0], v01[1] - v00[1], v01[2] - v00[2]};
+                float b[3] = {v10[0] - v00[0], v10[1] - v00[1], v10[2] - v00[2]};
+                float r[3];
+                cross3(a, b, r);
+                normalize3(r);
+                nmap[v * cols + u] = r[0];
+                nmap[(v + rows) * cols + u] = r[1];
+                nmap[(v + 2 * rows) * cols + u] = r[2];
+            } else
+                nmap[v * cols + u] = kto_nan();
+        }
+}
+
+/* ================================================================================================
+ * a5  tranformMaps -> tranformMapsKernel            maps.cu:156-223
+ * ============================================================================================== */
+void kto_transform_maps(const float* vmap_src, const float* nmap_src, int cols, int rows,
+                        const kto_mat33* R, const float t[3], float* vmap_dst, float* nmap_dst)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            float vs[3], vd0 = kto_nan();
+            vs[0] = vmap_src[y * cols + x];
+            if (!kto_isnan(vs[0])) {
+                vs[1] = vmap_src[(y + rows) * cols + x];
+                vs[2] = vmap_src[(y + 2 * rows) * cols + x];
+                float o[3];
+                mat33_mul(R, vs, o);
+                vd0 = o[0] + t[0];
+                vmap_dst[(y + rows) * cols + x] = o[1] + t[1];
+                vmap_dst[(y + 2 * rows) * cols + x] = o[2] + t[2];
+            }
+            vmap_dst[y * cols + x] = vd0;
+            float ns[3], nd0 = kto_nan();
+            ns[0] = nmap_src[y * cols + x];
+            if (!kto_isnan(ns[0])) {
+                ns[1] = nmap_src[(y + rows) * cols + x];
+                ns[2] = nmap_src[(y + 2 * rows) * cols + x];
+                float o[3];
+                mat33_mul(R, ns, o);
+                nd0 = o[0];
+                nmap_dst[(y + rows) * cols + x] = o[1];
+                nmap_dst[(y + 2 * rows) * cols + x] = o[2];
+            }
+            nmap_dst[y * cols + x] = nd0;
+        }
+}
+
+/* ================================================================================================
+ * a13 resizeVMap / resizeNMap -> resizeMapKernel<normalize>   maps.cu:225-308
+ * ============================================================================================== */
+static void resize_map(const float* in, int in_cols, int in_rows, float* out, int normalize)
+{
+    const int dcols = in_cols / 2, drows = in_rows / 2, srows = in_rows;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < drows; ++y)
+        for (int x = 0; x < dcols; ++x) {
+            int xs = x * 2, ys = y * 2;
+            float x00 = in[(ys + 0) * in_cols + xs + 0], x01 = in[(ys + 0) * in_cols + xs + 1];
+            float x10 = in[(ys + 1) * in_cols + xs + 0], x11 = in[(ys + 1) * in_cols + xs + 1];
+            if (kto_isnan(x00) || kto_isnan(x01) || kto_isnan(x10) || kto_isnan(x11)) {
+                out[y * dcols + x] = kto_nan();
+                continue;
+            }
+            float n[3];
+            n[0] = (x00 + x01 + x10 + x11) / 4;
+            float y00 = in[(ys + srows + 0) * in_cols + xs + 0], y01 = in[(ys + srows + 0) * in_cols + xs + 1];
+            float y10 = in[(ys + srows + 1) * in_cols + xs + 0], y11 = in[(ys + srows + 1) * in_cols + xs + 1];
+            n[1] = (y00 + y01 + y10 + y11) / 4;
+            float z00 = in[(ys + 2 * srows + 0) * in_cols + xs + 0], z01 = in[(ys + 2 * srows + 0) * in_cols + xs + 1];
+            float z10 = in[(ys + 2 * srows + 1) * in_cols + xs + 0], z11 = in[(ys + 2 * srows + 1) * in_cols + xs + 1];
+            n[2] = (z00 + z01 + z10 + z11) / 4;
+            if (normalize) normalize3(n);
+            out[y * dcols + x] = n[0];
+            out[(y + drows) * dcols + x] = n[1];
+            out[(y + 2 * drows) * dcols + x] = n[2];
+        }
+}
+void kto_resize_vmap(const float* in, int in_cols, int in_rows, float* out) { resize_map(in, in_cols, in_rows, out, 0); }
+void kto_resize_nmap(const float* in, int in_cols, int in_rows, float* out) { resize_map(in, in_cols, in_rows, out, 1); }
+
+/* ================================================================================================
+ * a10 helpers
+ * ============================================================================================== */
+/* shortDepthToMetres -> short2FloatKernel           bilateral_pyrdown.cu:231-242, 404-411 */
+void kto_depth_to_metres(const uint16_t* src, float* dst, int cols, int rows, int cutoff)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < cols * rows; ++i) {
+        int s = src[i];
+        dst[i] = (s > cutoff || s <= 0) ? kto_nan() : ((float)s) / 1000.0f;
+    }
+}
+/* imageBGRToIntensity -> bgr2IntensityKernel        bilateral_pyrdown.cu:244-258, 413-420.
+ * PixelRGB fields r,g,b are bytes 0,1,2 of the rgb24 pixel (internal.h:151-154). */
+void kto_bgr_to_intensity(const uint8_t* src, uint8_t* dst, int cols, int rows)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < cols * rows; ++i) {
+        float r = (float)src[3 * i + 0], g = (float)src[3 * i + 1], b = (float)src[3 * i + 2];
+        int value = kto_f2i_rz(fmaf(g, 0.587f, fmaf(r, 0.114f, b * 0.299f)));
+        dst[i] = (uint8_t)value;
+    }
+}
+static const float kGauss5x5[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
+/* pyrDownGaussF -> pyrDownKernelGaussF              bilateral_pyrdown.cu:199-229, 356-377 */
+void kto_pyr_down_gauss_f32(const float* src, int scols, int srows, float* dst)
+{
+    const int dcols = scols / 2, drows = srows / 2, D = 5;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < drows; ++y)
+        for (int x = 0; x < dcols; ++x) {
+            int tx = imin(2 * x - D / 2 + D, scols - 1);
+            int ty = imin(2 * y - D / 2 + D, srows - 1);
+            float sum = 0;
+            int count = 0;
+            for (int cy = imax(0, 2 * y - D / 2); cy < ty; ++cy)
+                for (int cx = imax(0, 2 * x - D / 2); cx < tx; ++cx) {
+                    float s = src[cy * scols + cx];
+                    if (!kto_isnan(s)) {
+                        float g = kGauss5x5[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                        sum = fmaf(s, g, sum);
+                        count = kto_f2i_rz((float)count + g); /* int += float */
+                    }
+                }
+            dst[y * dcols + x] = sum / (float)count;
+        }
+}
+/* pyrDownUcharGauss -> pyrDownKernelIntensityGauss  bilateral_pyrdown.cu:171-197, 379-402 */
+void kto_pyr_down_gauss_u8(const uint8_t* src, int scols, int srows, uint8_t* dst)
+{
+    const int dcols = scols / 2, drows = srows / 2, D = 5;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < drows; ++y)
+        for (int x = 0; x < dcols; ++x) {
+            int tx = imin(2 * x - D / 2 + D, scols - 1);
+            int ty = imin(2 * y - D / 2 + D, srows - 1);
+            float sum = 0;
+            int count = 0;
+            for (int cy = imax(0, 2 * y - D / 2); cy < ty; ++cy)
+                for (int cx = imax(0, 2 * x - D / 2); cx < tx; ++cx) {
+                    float g = kGauss5x5[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                    sum = fmaf((float)src[cy * scols + cx], g, sum);
+                    count = kto_f2i_rz((float)count + g);
+                }
+            dst[y * dcols + x] = f2u8_rz(sum / (float)count);
+        }
+}
+/* computeDerivativeImages -> applyKernel            bilateral_pyrdown.cu:271-330 */
+void kto_derivative_images(const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy)
+{
+    /* double literals narrowed to float, as in the reference's float gsx3x3[9] = {0.52201, ...} */
+    static const float gsx[9] = {(float)0.52201, (float)0.00000, (float)-0.52201, (float)0.79451, (float)-0.00000,
+                                 (float)-0.79451, (float)0.52201, (float)0.00000, (float)-0.52201};
+    static const float gsy[9] = {(float)0.52201, (float)0.79451, (float)0.52201, (float)0.00000, (float)0.00000,
+                                 (float)0.00000, (float)-0.52201, (float)-0.79451, (float)-0.52201};
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            float dxVal = 0, dyVal = 0;
+            int k = 8; /* border taps consume the kernel from index 8 downwards: quirk */
+            for (int j = imax(y - 1, 0); j <= imin(y + 1, rows - 1); j++)
+                for (int i = imax(x - 1, 0); i <= imin(x + 1, cols - 1); i++) {
+                    float s = (float)src[j * cols + i];
+                    dxVal = fmaf(s, gsx[k], dxVal);
+                    dyVal = fmaf(s, gsy[k], dyVal);
+                    --k;
+                }
+            dx[y * cols + x] = f2s16_rz(dxVal);
+            dy[y * cols + x] = f2s16_rz(dyVal);
+        }
+}
+/* projectToPointCloud -> projectPointsKernel        maps.cu:310-344 */
+void kto_project_to_cloud(const float* depth, int cols, int rows, float* cloud, double fx, double fy, double cx,
+                          double cy, int level)
+{
+    const int div = 1 << level; /* IntrDoublePrecision::operator() internal.h:268-272 */
+    const double lfx = fx / div, lfy = fy / div, lcx = cx / div, lcy = cy / div;
+    const double invFx = 1.0f / lfx, invFy = 1.0f / lfy;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            float z = depth[y * cols + x];
+            float* c = &cloud[3 * (y * cols + x)];
+            c[0] = (float)((x - lcx) * z * invFx);
+            c[1] = (float)((y - lcy) * z * invFy);
+            c[2] = z;
+        }
+}
+
+/* ================================================================================================
+ * 29-float reduction in the reference's exact summation order   reduce.cu:89-184
+ *   grid `blocks` x `threads` grid-stride partial sums -> warp shuffle tree (32 lanes) -> shared[32]
+ *   -> first-warp tree -> reduceSum<<<1,512>>> over the block partials (host MAX_THREADS == 512).
+ * `vals` = per-element 29-vectors, n elements.  order 1: plain double accumulation of the same floats.
+ * ============================================================================================== */
+static void warp_tree(float (*w)[29], int lanes_base)
+{
+    /* val += __shfl_down(val, offset) for offset 16,8,4,2,1; only the lanes feeding lane 0 matter */
+    for (int off = 16; off > 0; off /= 2)
+        for (int l = 0; l < off; ++l)
+            for (int k = 0; k < 29; ++k) w[lanes_base + l][k] += w[lanes_base + l + off][k];
+}
+static void block_reduce(float (*thr)[29], int nthreads, float out[29])
+{
+    /* blockReduceSum reduce.cu:131-164 */
+    int nwarps = nthreads / 32;
+    float shared[32][29];
+    memset(shared, 0, sizeof(shared));
+    for (int w = 0; w < nwarps; ++w) {
+        warp_tree(thr, w * 32);
+        memcpy(shared[w], thr[w * 32], sizeof(float) * 29);
+    }
+    /* threadIdx.x < blockDim.x / warpSize ? shared[lane] : zero; rows >= nwarps are already zero */
+    warp_tree(shared, 0);
+    memcpy(out, shared[0], sizeof(float) * 29);
+}
+static void reduce29(const float* vals, int n, int threads, int blocks, int order, float out[29])
+{
+    if (order == 1) {
+        double acc[29];
+        for (int k = 0; k < 29; ++k) acc[k] = 0;
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < 29; ++k) acc[k] += (double)vals[(size_t)i * 29 + k];
+        for (int k = 0; k < 29; ++k) out[k] = (float)acc[k];
+        return;
+    }
+    const int T = threads * blocks;
+    float(*thr)[29] = calloc((size_t)T, sizeof(*thr));
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < T; ++t)
+        for (int i = t; i < n; i += T)
+            for (int k = 0; k < 29; ++k) thr[t][k] += vals[(size_t)i * 29 + k];
+    float(*part)[29] = calloc(512, sizeof(*part)); /* reduceSum<<<1, 512>>>: thread i<blocks loads in[i] */
+    for (int b = 0; b < blocks; ++b) block_reduce(&thr[b * threads], threads, part[b]);
+    block_reduce(part, 512, out);
+    free(thr);
+    free(part);
+}
+/* host unpack, reduce.cu:401-418 */
+static void unpack29(const float h[29], float A[36], float b[6], float residual[2])
+{
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            float value = h[shift++];
+            if (j == 6) b[i] = value;
+            else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+    if (residual) { residual[0] = h[27]; residual[1] = h[28]; }
+}
+static inline void outer29(const float row[7], float found, float* v)
+{
+    int s = 0;
+    for (int i = 0; i < 7; ++i)
+        for (int j = i; j < 7; ++j) v[s++] = row[i] * row[j];
+    /* s == 28: aa..fg (27) + residual gg */
+    v[28] = found;
+}
+
+/* ================================================================================================
+ * a6  icpStep -> icpKernel + reduceSum              reduce.cu:186-419
+ * ============================================================================================== */
+void kto_icp_step(const kto_mat33* Rcurr, const float tcurr[3], const float* vmap_curr, const float* nmap_curr,
+                  const kto_mat33* Rprev_inv, const float tprev[3], kto_intr intr, const float* vmap_g_prev,
+                  const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres, int order,
+                  float A[36], float b[6], float residual[2])
+{
+    const int n = cols * rows;
+    float* vals = malloc((size_t)n * 29 * sizeof(float));
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        int y = i / cols, x = i - y * cols;
+        float row[7] = {0, 0, 0, 0, 0, 0, 0};
+        int found = 0;
+        /* search(): reduce.cu:213-254 */
+        float vcurr[3] = {vmap_curr[y * cols + x], vmap_curr[(y + rows) * cols + x], vmap_curr[(y + 2 * rows) * cols + x]};
+        float vcurr_g[3], tmp[3], vcurr_cp[3];
+        mat33_mul(Rcurr, vcurr, vcurr_g);
+        vcurr_g[0] += tcurr[0]; vcurr_g[1] += tcurr[1]; vcurr_g[2] += tcurr[2];
+        tmp[0] = vcurr_g[0] - tprev[0]; tmp[1] = vcurr_g[1] - tprev[1]; tmp[2] = vcurr_g[2] - tprev[2];
+        mat33_mul(Rprev_inv, tmp, vcurr_cp);
+        int ux = kto_f2i_rn(vcurr_cp[0] * intr.fx / vcurr_cp[2] + intr.cx);
+        int uy = kto_f2i_rn(vcurr_cp[1] * intr.fy / vcurr_cp[2] + intr.cy);
+        if (!(ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp[2] < 0)) {
+            float vprev_g[3] = {vmap_g_prev[uy * cols + ux], vmap_g_prev[(uy + rows) * cols + ux], vmap_g_prev[(uy + 2 * rows) * cols + ux]};
+            float ncurr[3] = {nmap_curr[y * cols + x], nmap_curr[(y + rows) * cols + x], nmap_curr[(y + 2 * rows) * cols + x]};
+            float ncurr_g[3];
+            mat33_mul(Rcurr, ncurr, ncurr_g);
+            float nprev_g[3] = {nmap_g_prev[uy * cols + ux], nmap_g_prev[(uy + rows) * cols + ux], nmap_g_prev[(uy + 2 * rows) * cols + ux]};
+            float dv[3] = {vprev_g[0] - vcurr_g[0], vprev_g[1] - vcurr_g[1], vprev_g[2] - vcurr_g[2]};
+            float dist = sqrtf(dot3(dv, dv));
+            float cr[3];
+            cross3(ncurr_g, nprev_g, cr);
+            float sine = sqrtf(dot3(cr, cr));
+            found = (sine < angle_thres && dist <= dist_thres && !kto_isnan(ncurr[0]) && !kto_isnan(nprev_g[0]));
+            if (found) {
+                /* getProducts(): reduce.cu:256-277 */
+                float s_cp[3], d_cp[3], n_cp[3], t2[3];
+                t2[0] = vcurr_g[0] - tprev[0]; t2[1] = vcurr_g[1] - tprev[1]; t2[2] = vcurr_g[2] - tprev[2];
+                mat33_mul(Rprev_inv, t2, s_cp);
+                t2[0] = vprev_g[0] - tprev[0]; t2[1] = vprev_g[1] - tprev[1]; t2[2] = vprev_g[2] - tprev[2];
+                mat33_mul(Rprev_inv, t2, d_cp);
+                mat33_mul(Rprev_inv, nprev_g, n_cp);
+                row[0] = n_cp[0]; row[1] = n_cp[1]; row[2] = n_cp[2];
+                cross3(s_cp, n_cp, &row[3]);
+                float sd[3] = {s_cp[0] - d_cp[0], s_cp[1] - d_cp[1], s_cp[2] - d_cp[2]};
+                row[6] = dot3(n_cp, sd);
+            }
+        }
+        outer29(row, (float)found, &vals[(size_t)i * 29]);
+    }
+    float h[29];
+    reduce29(vals, n, 128, 64, order, h); /* ICPOdometry.cpp:123-124: threads 128, blocks 64 */
+    free(vals);
+    unpack29(h, A, b, residual);
+}
+
+/* ================================================================================================
+ * a8  computeRgbResidual -> residualKernel          reduce.cu:668-864
+ * The int2 reduction is associative on integers, so summation order is irrelevant.
+ * invalid entries keep only .valid = 0 (the reference leaves the other fields uninitialised, A.19).
+ * ============================================================================================== */
+void kto_rgb_residual(float min_scale, const int16_t* dIdx, const int16_t* dIdy, const float* last_depth,
+                      const float* next_depth, const uint8_t* last_image, const uint8_t* next_image, int cols, int rows,
+                      kto_dataterm* corres_img, float max_depth_delta, const float kt[3], const kto_mat33* krkinv,
+                      int* sigma_sum, int* count)
+{
+    long long cnt = 0, sig = 0;
+    const float* K = krkinv->m;
+#pragma omp parallel for schedule(static) reduction(+ : cnt, sig)
+    for (int k = 0; k < cols * rows; ++k) {
+        int i = k / cols, j0 = k - i * cols;
+        kto_dataterm corres;
+        memset(&corres, 0, sizeof(corres));
+        if (j0 < cols - 5 && i < rows - 1) {
+            int valid = 1;
+            for (int u = imax(i - 2, 0); u < imin(i + 2, rows); u++)
+                for (int v = imax(j0 - 2, 0); v < imin(j0 + 2, cols); v++) valid = valid && (next_image[u * cols + v] > 0);
+            if (valid) {
+                int valx = dIdx[i * cols + j0], valy = dIdy[i * cols + j0];
+                float mTwo = (float)((valx * valx) + (valy * valy));
+                if (mTwo >= min_scale) {
+                    int y = i, x = j0;
+                    float d1 = next_depth[y * cols + x];
+                    if (!kto_isnan(d1)) {
+                        float xf = (float)x, yf = (float)y;
+                        float transformed_d1 = fmaf(d1, fmaf(K[6], xf, K[7] * yf) + K[8], kt[2]);
+                        int u0 = kto_f2i_rn(fmaf(d1, fmaf(K[0], xf, K[1] * yf) + K[2], kt[0]) / transformed_d1);
+                        int v0 = kto_f2i_rn(fmaf(d1, fmaf(K[3], xf, K[4] * yf) + K[5], kt[1]) / transformed_d1);
+                        if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+                            float d0 = last_depth[v0 * cols + u0];
+                            if (d0 > 0 && fabsf(transformed_d1 - d0) <= max_depth_delta && last_image[v0 * cols + u0] != 0) {
+                                corres.zero_x = (int16_t)u0; corres.zero_y = (int16_t)v0;
+                                corres.one_x = (int16_t)x; corres.one_y = (int16_t)y;
+                                corres.diff = (float)next_image[y * cols + x] - (float)last_image[v0 * cols + u0];
+                                corres.valid = 1;
+                                cnt += 1;
+                                sig += kto_f2i_rz(corres.diff * corres.diff);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        corres_img[k] = corres;
+    }
+    *count = (int)cnt;
+    *sigma_sum = (int)sig; /* int32 wrap-around as on the device */
+}
+
+/* ================================================================================================
+ * a9  rgbStep -> rgbKernel + reduceSum              reduce.cu:423-607
+ * ============================================================================================== */
+void kto_rgb_step(const kto_dataterm* corres_img, float sigma, const float* cloud, float fx, float fy,
+                  const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows, int order,
+                  float A[36], float b[6])
+{
+    const int n = cols * rows;
+    const float flt_eps = 1.19209290E-07F;
+    float* vals = malloc((size_t)n * 29 * sizeof(float));
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        const kto_dataterm* c = &corres_img[i];
+        float row[7] = {0, 0, 0, 0, 0, 0, 0};
+        int found = c->valid;
+        if (found) {
+            float w = sigma + fabsf(c->diff);
+            w = w > flt_eps ? 1.0f / w : 1.0f;
+            if (sigma == -1) w = 1;
+            row[6] = -w * c->diff;
+            const float* cp = &cloud[3 * (c->zero_y * cols + c->zero_x)];
+            float X = cp[0], Y = cp[1], Z = cp[2];
+            float invz = (float)(1.0 / (double)Z);
+            float dI_dx_val = w * sobel_scale * (float)dIdx[c->one_y * cols + c->one_x];
+            float dI_dy_val = w * sobel_scale * (float)dIdy[c->one_y * cols + c->one_x];
+            float v0 = dI_dx_val * fx * invz;
+            float v1 = dI_dy_val * fy * invz;
+            float v2 = -fmaf(v0, X, v1 * Y) * invz;
+            row[0] = v0; row[1] = v1; row[2] = v2;
+            row[3] = fmaf(-Z, v1, Y * v2);
+            row[4] = fmaf(Z, v0, -(X * v2));
+            row[5] = fmaf(-Y, v0, X * v1);
+        }
+        outer29(row, (float)found, &vals[(size_t)i * 29]);
+    }
+    float h[29];
+    reduce29(vals, n, 128, 64, order, h); /* RGBDOdometry.cpp:306-307 */
+    free(vals);
+    unpack29(h, A, b, NULL);
+}
+
+/* ================================================================================================
+ * volume helpers                                    device.hpp:61-83
+ * ============================================================================================== */
+static inline int16_t pack_tsdf(float tsdf)
+{
+    return (int16_t)imax(-KTO_DIVISOR, imin(KTO_DIVISOR, kto_f2i_rz(tsdf * KTO_DIVISOR)));
+}
+static inline float unpack_tsdf(int16_t v) { return (float)v / KTO_DIVISOR; }
+static inline size_t wrap_index(int x, int y, int z, const int w[3], int N)
+{
+    return (size_t)((x + w[0]) % N) + (size_t)((y + w[1]) % N) * N + (size_t)((z + w[2]) % N) * N * N;
+}
+
+/* initVolume / initColorVolume                      tsdf_volume.cu:56-87, 450-479 */
+void kto_init_volume(int16_t* vol, int N) { memset(vol, 0, (size_t)N * N * N * sizeof(int16_t)); }
+void kto_init_color_volume(uint8_t* cvol, int N) { memset(cvol, 0, (size_t)N * N * N * 4); }
+
+/* ================================================================================================
+ * a11 integrateTsdfVolume -> scaleDepth + tsdf23    tsdf_volume.cu:490-674
+ * ============================================================================================== */
+void kto_scale_depth(const uint16_t* depth, float* scaled, int cols, int rows, kto_intr intr, int angle_color)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            int Dp = depth[y * cols + x];
+            float xl = ((float)x - intr.cx) / intr.fx;
+            float yl = ((float)y - intr.cy) / intr.fy;
+            float lambda = sqrtf(fmaf(xl, xl, yl * yl) + 1);
+            if (angle_color) {
+                const int ky = 7, kx = 7;
+                int ty = imin(y - ky / 2 + ky, rows - 1);
+                int tx = imin(x - kx / 2 + kx, cols - 1);
+                int count = 0;
+                for (int cy = imax(y - ky / 2, 0); cy < ty; ++cy)
+                    for (int cx = imax(x - kx / 2, 0); cx < tx; ++cx)
+                        if (abs(Dp - (int)depth[cy * cols + cx]) > 200 || Dp == 0) count++;
+                if (count > 5) scaled[y * cols + x] = (float)(-Dp) * lambda / 1000.f;
+                else scaled[y * cols + x] = (float)Dp * lambda / 1000.f;
+            } else
+                scaled[y * cols + x] = (float)Dp * lambda / 1000.f;
+        }
+}
+
+long long kto_integrate_tsdf(const uint16_t* depth_raw, int cols, int rows, kto_intr intr, const float volume_size[3],
+                             const kto_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist, int16_t* volume,
+                             float* depth_scaled, const int voxel_wrap[3], uint8_t* color_volume,
+                             const uint8_t* colors, const float* nmap_curr, int angle_color, int N)
+{
+    kto_scale_depth(depth_raw, depth_scaled, cols, rows, intr, angle_color);
+    const float cell[3] = {volume_size[0] / N, volume_size[1] / N, volume_size[2] / N};
+    const float* Ri = Rcurr_inv->m;
+    long long updated = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : updated)
+    for (int y = 0; y < N; ++y)
+        for (int x = 0; x < N; ++x) {
+            float v_g_x = fmaf((float)x + 0.5f, cell[0], -tcurr[0]);
+            float v_g_y = fmaf((float)y + 0.5f, cell[1], -tcurr[1]);
+            float v_g_z = fmaf(0 + 0.5f, cell[2], -tcurr[2]);
+            float v_g_part_norm = fmaf(v_g_x, v_g_x, v_g_y * v_g_y);
+            float v_x = fmaf(Ri[2], v_g_z, fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * intr.fx;
+            float v_y = fmaf(Ri[5], v_g_z, fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * intr.fy;
+            float v_z = fmaf(Ri[8], v_g_z, fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
+            float z_scaled = 0;
+            float Rcurr_inv_0_z_scaled = Ri[2] * cell[2] * intr.fx;
+            float Rcurr_inv_1_z_scaled = Ri[5] * cell[2] * intr.fy;
+            float tranc_dist_inv = 1.0f / tranc_dist;
+            /* incremental float walk in z (also on `continue`): quirk A.17 */
+            for (int z = 0; z < N; ++z, v_g_z += cell[2], z_scaled += cell[2], v_x += Rcurr_inv_0_z_scaled, v_y += Rcurr_inv_1_z_scaled) {
+                float inv_z = 1.0f / fmaf(Ri[8], z_scaled, v_z);
+                if (inv_z < 0) continue;
+                int coo_x = kto_f2i_rn(fmaf(v_x, inv_z, intr.cx));
+                int coo_y = kto_f2i_rn(fmaf(v_y, inv_z, intr.cy));
+                if (coo_x >= 0 && coo_y >= 0 && coo_x < cols && coo_y < rows) {
+                    float Dp_scaled = depth_scaled[coo_y * cols + coo_x];
+                    int no_color = 0;
+                    if (Dp_scaled < 0.0) { Dp_scaled = -Dp_scaled; no_color = 1; }
+                    float sdf = Dp_scaled - sqrtf(fmaf(v_g_z, v_g_z, v_g_part_norm));
+                    if (Dp_scaled != 0 && sdf >= -tranc_dist) {
+                        float ncurr_x = nmap_curr[coo_y * cols + coo_x];
+                        float ncurr_z = nmap_curr[(coo_y + 2 * rows) * cols + coo_x];
+                        if (ncurr_z < 0) ncurr_z = -ncurr_z;
+                        float tsdf = fminf(1.0f, sdf * tranc_dist_inv);
+                        size_t idx = wrap_index(x, y, z, voxel_wrap, N);
+                        float tsdf_prev = unpack_tsdf(volume[idx]);
+                        uint8_t* pc = &color_volume[4 * idx];
+                        float weight_prev = (float)pc[3]; /* weight lives in colour.w: quirk A.1 */
+                        volume[idx] = pack_tsdf(fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
+                        pc[3] = f2u8_rz(fminf(weight_prev + 1.0f, KTO_MAX_WEIGHT));
+                        ++updated;
+                        if ((!kto_isnan(ncurr_x) && !no_color) || (pc[0] == 0 && pc[1] == 0 && pc[2] == 0)) {
+                            const float Wrkc = (angle_color ? fminf(1.0f, ncurr_z / KTO_RGB_VIEW_ANGLE_WEIGHT) : 1.0f) * 2.0f;
+                            const uint8_t* rgb = &colors[3 * (coo_y * cols + coo_x)];
+                            float new_x = fmaf((float)pc[0], weight_prev, Wrkc * (float)rgb[0]) / (weight_prev + Wrkc);
+                            float new_y = fmaf((float)pc[1], weight_prev, Wrkc * (float)rgb[1]) / (weight_prev + Wrkc);
+                            float new_z = fmaf((float)pc[2], weight_prev, Wrkc * (float)rgb[2]) / (weight_prev + Wrkc);
+                            pc[0] = (uint8_t)imin(255, imax(0, kto_f2i_rn(new_x)));
+                            pc[1] = (uint8_t)imin(255, imax(0, kto_f2i_rn(new_y)));
+                            pc[2] = (uint8_t)imin(255, imax(0, kto_f2i_rn(new_z)));
+                        }
+                    }
+                }
+            }
+        }
+    return updated;
+}
+
+/* ================================================================================================
+ * a12 raycast -> rayCastKernel                      ray_caster.cu:56-471
+ * ============================================================================================== */
+typedef struct {
+    const int16_t* volume; const uint8_t* cvol; int N; const int* wrap; float cell[3];
+} rc_ctx;
+static inline float rc_read_tsdf(const rc_ctx* c, int x, int y, int z) { return unpack_tsdf(c->volume[wrap_index(x, y, z, c->wrap, c->N)]); }
+static inline float rc_read_ch(const rc_ctx* c, int x, int y, int z, int ch) { return (float)c->cvol[4 * wrap_index(x, y, z, c->wrap, c->N) + ch]; }
+static inline void rc_get_voxel(const rc_ctx* c, const float p[3], int g[3])
+{
+    g[0] = kto_f2i_rd(p[0] / c->cell[0]);
+    g[1] = kto_f2i_rd(p[1] / c->cell[1]);
+    g[2] = kto_f2i_rd(p[2] / c->cell[2]);
+}
+/* shared body of interpolateTrilineary / interpolateColorTrilineary / interpolateHeatTrilineary
+ * (ray_caster.cu:160-296). ch < 0: tsdf; ch 0..3: colour channel.  Returns 0 when outside (caller maps). */
+static int rc_trilinear(const rc_ctx* c, const float point[3], int ch, float* out)
+{
+    int g[3];
+    rc_get_voxel(c, point, g);
+    const int N = c->N;
+    if (g[0] <= 0 || g[0] >= N - 1) return 0;
+    if (g[1] <= 0 || g[1] >= N - 1) return 0;
+    if (g[2] <= 0 || g[2] >= N - 1) return 0;
+    float vx = ((float)g[0] + 0.5f) * c->cell[0];
+    float vy = ((float)g[1] + 0.5f) * c->cell[1];
+    float vz = ((float)g[2] + 0.5f) * c->cell[2];
+    g[0] = (point[0] < vx) ? (g[0] - 1) : g[0];
+    g[1] = (point[1] < vy) ? (g[1] - 1) : g[1];
+    g[2] = (point[2] < vz) ? (g[2] - 1) : g[2];
+    float a = fmaf(-((float)g[0] + 0.5f), c->cell[0], point[0]) / c->cell[0];
+    float b = fmaf(-((float)g[1] + 0.5f), c->cell[1], point[1]) / c->cell[1];
+    float cc = fmaf(-((float)g[2] + 0.5f), c->cell[2], point[2]) / c->cell[2];
+    float r[8];
+    for (int k = 0; k < 8; ++k) {
+        int dx = (k >> 2) & 1, dy = (k >> 1) & 1, dz = k & 1; /* order 000,001,010,011,100,101,110,111 */
+        r[k] = ch < 0 ? rc_read_tsdf(c, g[0] + dx, g[1] + dy, g[2] + dz) : rc_read_ch(c, g[0] + dx, g[1] + dy, g[2] + dz, ch);
+    }
+    float ia = 1 - a, ib = 1 - b, ic = 1 - cc;
+    /* sum of 8 products, left-associated, each add contracted with the preceding product's last mul */
+    float res = fmaf(r[0] * ia * ib, ic, r[1] * ia * ib * cc);
+    res = fmaf(r[2] * ia * b, ic, res);
+    res = fmaf(r[3] * ia * b, cc, res);
+    res = fmaf(r[4] * a * ib, ic, res);
+    res = fmaf(r[5] * a * ib, cc, res);
+    res = fmaf(r[6] * a * b, ic, res);
+    res = fmaf(r[7] * a * b, cc, res);
+    *out = res;
+    return 1;
+}
+static inline float rc_interp_tsdf(const rc_ctx* c, const float p[3])
+{
+    float r;
+    return rc_trilinear(c, p, -1, &r) ? r : kto_nan();
+}
+
+long long kto_raycast(kto_intr intr, const kto_mat33* Rcurr, const float tcurr[3], float tranc_dist,
+                      const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
+                      const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N)
+{
+    rc_ctx c;
+    c.volume = volume; c.cvol = color_volume; c.N = N; c.wrap = voxel_wrap;
+    c.cell[0] = volume_size[0] / N; c.cell[1] = volume_size[1] / N; c.cell[2] = volume_size[2] / N;
+    const float time_step = tranc_dist * 0.8f; /* ray_caster.cu:444 */
+    long long steps = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : steps)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            vmap[y * cols + x] = kto_nan();
+            nmap[y * cols + x] = kto_nan();
+            const float* ray_start = tcurr;
+            float rn_[3] = {((float)x - intr.cx) / intr.fx, ((float)y - intr.cy) / intr.fy, 1};
+            float ray_next[3];
+            mat33_mul(Rcurr, rn_, ray_next);
+            ray_next[0] += tcurr[0]; ray_next[1] += tcurr[1]; ray_next[2] += tcurr[2];
+            float ray_dir[3] = {ray_next[0] - ray_start[0], ray_next[1] - ray_start[1], ray_next[2] - ray_start[2]};
+            normalize3(ray_dir);
+            for (int k = 0; k < 3; ++k) ray_dir[k] = (ray_dir[k] == 0.f) ? (float)1e-15 : ray_dir[k];
+            /* getMinTime / getMaxTime  ray_caster.cu:56-74 */
+            float tmin[3], tmax[3];
+            for (int k = 0; k < 3; ++k) {
+                tmin[k] = ((ray_dir[k] > 0 ? 0.f : volume_size[k]) - ray_start[k]) / ray_dir[k];
+                tmax[k] = ((ray_dir[k] > 0 ? volume_size[k] : 0.f) - ray_start[k]) / ray_dir[k];
+            }
+            float time_start_volume = fmaxf(fmaxf(tmin[0], tmin[1]), tmin[2]);
+            float time_exit_volume = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
+            time_start_volume = fmaxf(time_start_volume, 0.f);
+            if (time_start_volume >= time_exit_volume) continue;
+            float time_curr = time_start_volume;
+            float p[3];
+            int g[3];
+            for (int k = 0; k < 3; ++k) p[k] = fmaf(ray_dir[k], time_curr, ray_start[k]);
+            rc_get_voxel(&c, p, g);
+            g[0] = imax(0, imin(g[0], N - 1)); g[1] = imax(0, imin(g[1], N - 1)); g[2] = imax(0, imin(g[2], N - 1));
+            float tsdf = rc_read_tsdf(&c, g[0], g[1], g[2]);
+            const float max_time = 3 * (volume_size[0] + volume_size[1] + volume_size[2]);
+            for (; time_curr < max_time; time_curr += time_step) {
+                float tsdf_prev = tsdf;
+                float tn = time_curr + time_step;
+                for (int k = 0; k < 3; ++k) p[k] = fmaf(ray_dir[k], tn, ray_start[k]);
+                rc_get_voxel(&c, p, g);
+                /* checkInds: z tested against VOLUME_X (quirk A.13; all sides equal here) */
+                if (!(g[0] >= 0 && g[1] >= 0 && g[2] >= 0 && g[0] < N && g[1] < N && g[2] < N)) break;
+                tsdf = rc_read_tsdf(&c, g[0], g[1], g[2]);
+                ++steps;
+                if (tsdf_prev < 0.f && tsdf > 0.f) break;
+                if (tsdf_prev > 0.f && tsdf < 0.f) {
+                    float Ftdt = rc_interp_tsdf(&c, p);
+                    if (kto_isnan(Ftdt)) break;
+                    float p0[3];
+                    for (int k = 0; k < 3; ++k) p0[k] = fmaf(ray_dir[k], time_curr, ray_start[k]);
+                    float Ft = rc_interp_tsdf(&c, p0);
+                    if (kto_isnan(Ft)) break;
+                    float Ts = time_curr - time_step * Ft / (Ftdt - Ft);
+                    float vf[3];
+                    for (int k = 0; k < 3; ++k) vf[k] = fmaf(ray_dir[k], Ts, ray_start[k]);
+                    vmap[y * cols + x] = vf[0];
+                    vmap[(y + rows) * cols + x] = vf[1];
+                    vmap[(y + 2 * rows) * cols + x] = vf[2];
+                    int gg[3];
+                    rc_get_voxel(&c, p0, gg);
+                    /* colour + heat: float -> uchar truncation (quirk A.20); outside -> black / NaN -> 0 */
+                    uint8_t* pc = &vmap_curr_color[4 * (y * cols + x)];
+                    float col;
+                    for (int ch = 0; ch < 3; ++ch) pc[ch] = rc_trilinear(&c, vf, ch, &col) ? f2u8_rz(col) : 0;
+                    pc[3] = rc_trilinear(&c, vf, 3, &col) ? f2u8_rz(col) : 0;
+                    if (gg[0] > 1 && gg[1] > 1 && gg[2] > 1 && gg[0] < N - 2 && gg[1] < N - 2 && gg[2] < N - 2) {
+                        float n[3], t[3];
+                        for (int k = 0; k < 3; ++k) {
+                            t[0] = vf[0]; t[1] = vf[1]; t[2] = vf[2];
+                            t[k] += c.cell[k];
+                            float F1 = rc_interp_tsdf(&c, t);
+                            t[0] = vf[0]; t[1] = vf[1]; t[2] = vf[2];
+                            t[k] -= c.cell[k];
+                            float F2 = rc_interp_tsdf(&c, t);
+                            n[k] = F1 - F2;
+                        }
+                        normalize3(n);
+                        nmap[y * cols + x] = n[0];
+                        nmap[(y + rows) * cols + x] = n[1];
+                        nmap[(y + 2 * rows) * cols + x] = n[2];
+                    }
+                    break;
+                }
+            }
+        }
+    return steps;
+}
+
+/* ================================================================================================
+ * a14 clearVolume{X,Y,Z}{,Back}{,c}                 tsdf_volume.cu:88-448
+ * The launch geometry of the X variants is emulated (quirk A.15).
+ * ============================================================================================== */
+static inline void clear_voxel(void* vol, int elem_size, size_t idx)
+{
+    if (elem_size == 2) ((int16_t*)vol)[idx] = 0;
+    else ((uint32_t*)vol)[idx] = 0;
+}
+static int wrap_base(int currentVoxelWrap, int N)
+{
+    return currentVoxelWrap > 0 ? currentVoxelWrap % N : N - ((-currentVoxelWrap) % N);
+}
+void kto_clear_volume(void* vol, int elem_size, int N, int axis, int back, int currentVoxelWrap, int deltaVoxelWrap)
+{
+    if (axis == 0) {
+        /* clearVolumeX / clearVolumeXBack :117-237, kernel clearVolumeInX :88-115 */
+        int remainder = (deltaVoxelWrap - currentVoxelWrap) % 16;
+        if (remainder != 0) remainder = (deltaVoxelWrap - currentVoxelWrap) + 16 - remainder;
+        else remainder = abs(deltaVoxelWrap - currentVoxelWrap);
+        int grid_x = (remainder + 15) / 16; /* divUp(remainder, 16); negative remainder -> <= 0 blocks */
+        int bottom, num;
+        if (!back) {
+            bottom = wrap_base(currentVoxelWrap, N);
+            num = -(currentVoxelWrap - deltaVoxelWrap);
+        } else {
+            int base = wrap_base(currentVoxelWrap, N);
+            int top = (base + N) % N;
+            num = currentVoxelWrap - deltaVoxelWrap;
+            bottom = top - num;
+            if (bottom < 0) bottom = N + bottom;
+        }
+        int nthreads_x = grid_x * 16;
+        bottom %= N;
+        const int cachedWrap = (bottom + num) % N;
+        const int wrap = cachedWrap != bottom + num;
+        for (int tx = 0; tx < nthreads_x; ++tx) {
+            int x = (tx + bottom) % N;
+            if (!wrap ? (x >= bottom && x <= cachedWrap) : (x >= bottom || x <= cachedWrap))
+                for (int y = 0; y < N; ++y)
+                    for (int z = 0; z < N; ++z) clear_voxel(vol, elem_size, (size_t)x + (size_t)y * N + (size_t)z * N * N);
+        }
+        return;
+    }
+    /* Y and Z variants: N x N threads each walking the slab :239-448 (thread y is the z index in the Y kernels) */
+    for (int ty = 0; ty < N; ++ty)
+        for (int tx = 0; tx < N; ++tx) {
+            if (!back) {
+                int bottom = wrap_base(currentVoxelWrap, N);
+                int numUp = -(currentVoxelWrap - deltaVoxelWrap);
+                while (numUp >= 0) {
+                    size_t idx = axis == 1 ? (size_t)tx + (size_t)(bottom++ % N) * N + (size_t)ty * N * N
+                                           : (size_t)tx + (size_t)ty * N + (size_t)(bottom++ % N) * N * N;
+                    clear_voxel(vol, elem_size, idx);
+                    numUp--;
+                }
+            } else {
+                int base = wrap_base(currentVoxelWrap, N);
+                int top = (base + N) % N;
+                int numDown = currentVoxelWrap - deltaVoxelWrap;
+                while (numDown >= 0) {
+                    size_t idx = axis == 1 ? (size_t)tx + (size_t)(top-- % N) * N + (size_t)ty * N * N
+                                           : (size_t)tx + (size_t)ty * N + (size_t)(top-- % N) * N * N;
+                    clear_voxel(vol, elem_size, idx);
+                    if (top < 0) top = N - 1;
+                    numDown--;
+                }
+            }
+        }
+}
+
+/* ================================================================================================
+ * a15 extractCloudSlice -> extractKernelSlice       extract.cu:79-419
+ * Output order here is z-major then y, x (the reference's order is nondeterministic: atomicAdd
+ * compaction, extract.cu:255); compare as sorted sets.
+ * ============================================================================================== */
+typedef struct { const int16_t* vol; const uint8_t* cvol; const int* wrap; int N; } ex_ctx;
+static inline float ex_fetch(const ex_ctx* e, int x, int y, int z, int* weight)
+{
+    size_t i = wrap_index(x, y, z, e->wrap, e->N);
+    *weight = e->cvol[4 * i + 3];
+    return unpack_tsdf(e->vol[i]);
+}
+size_t kto_extract_cloud_slice(const int16_t* volume, const float volume_size[3], kto_point* out, size_t out_cap,
+                               const int voxel_wrap[3], const uint8_t* color_volume, int minX, int maxX, int minY,
+                               int maxY, int minZ, int maxZ, int subsample, const int real_voxel_wrap[3], int N)
+{
+    ex_ctx e = {volume, color_volume, voxel_wrap, N};
+    const float cell[3] = {volume_size[0] / N, volume_size[1] / N, volume_size[2] / N};
+    size_t count = 0;
+    for (int z = minZ; z < maxZ; z += subsample)
+        for (int y = imax(minY, 0); y < imin(maxY, N); ++y)
+            for (int x = imax(minX, 0); x < imin(maxX, N); ++x) {
+                if (x % subsample != 0 || y % subsample != 0) continue;
+                int W;
+                float F = ex_fetch(&e, x, y, z, &W);
+                if (!(W != 0 && F != 1.f)) continue;
+                float V[3] = {((float)x + 0.5f) * cell[0], ((float)y + 0.5f) * cell[1], ((float)z + 0.5f) * cell[2]};
+                for (int axis = 0; axis < 3; ++axis) {
+                    int nx = x + (axis == 0), ny = y + (axis == 1), nz = z + (axis == 2);
+                    if (axis == 0 && !(x + 1 < N)) continue;
+                    if (axis == 1 && !(y + 1 < N)) continue;
+                    /* z + 1 at z == N-1 wraps modulo N through the storage index (quirk) */
+                    int Wn;
+                    float Fn = ex_fetch(&e, nx, ny, nz, &Wn);
+                    if (!(Wn != 0 && Fn != 1.f)) continue;
+                    if (!((F > 0 && Fn < 0) || (F < 0 && Fn > 0))) continue;
+                    float p[3] = {V[0], V[1], V[2]};
+                    float Vn = V[axis] + cell[axis];
+                    float d_inv = 1.f / (fabsf(F) + fabsf(Fn));
+                    p[axis] = fmaf(V[axis], fabsf(Fn), Vn * fabsf(F)) * d_inv;
+                    size_t ni = wrap_index(nx, ny, nz, voxel_wrap, N);
+                    if (count < out_cap) {
+                        kto_point* o = &out[count];
+                        memset(o, 0, sizeof(*o));
+                        /* store_point_type extract.cu:307-317 */
+                        o->x = fmaf((float)real_voxel_wrap[0], cell[0], p[0]) - ((cell[0] * N) / 2);
+                        o->y = fmaf((float)real_voxel_wrap[1], cell[1], p[1]) - ((cell[1] * N) / 2);
+                        o->z = fmaf((float)real_voxel_wrap[2], cell[2], p[2]) - ((cell[2] * N) / 2);
+                        /* r = colour.x of the NEIGHBOUR, stored swapped: ptr->r = b, ptr->b = r (quirk A.14) */
+                        o->r = color_volume[4 * ni + 2];
+                        o->g = color_volume[4 * ni + 1];
+                        o->b = color_volume[4 * ni + 0];
+                        o->a = (uint8_t)W;
+                    }
+                    ++count;
+                }
+            }
+    return count < out_cap ? count : out_cap;
+}
