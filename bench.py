@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py -- RGB-D frames/s of the per-frame tracking + fusion hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under torch.distributed.run,
+one rank per GPU.  A "step" is ONE frame through KintinuousTracker::processFrame (pyramid build, 19 ICP Gauss-Newton
+iterations solved on the device, shift check, TSDF integrate, raycast, predicted-map pyramid) with the frame already
+resident in HBM.  Workload at every N: BASELINE.json configs[1] -- 640x480 synthetic orbit, ICP-only tracking, 512^3
+TSDF -- one independent stream per GPU (seed 1234 + rank), poses gathered once with an RCCL all_gather (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="orbit512", choices=["orbit512", "orbit256", "crabwalk512", "farwall768"])
+    ap.add_argument("--unique-frames", type=int, default=120, help="frames rendered; the trajectory is played ping-pong beyond that")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    # name: (synth config, image scale, N, tracker kwargs)
+    "orbit512": ("orbit", 1, 512, {}),
+    "orbit256": ("orbit", 1, 256, {}),
+    "crabwalk512": ("crabwalk", 1, 512, dict(volume_size=7.0, use_rgbd_icp=1)),
+    "farwall768": ("farwall", 2, 768, dict(static_mode=1)),
+}
+
+
+def pingpong(i, n):
+    """0,1,..,n-1,n-2,..,1,0,1,.. : stays a continuous camera motion for any number of steps."""
+    period = 2 * (n - 1)
+    j = i % period
+    return j if j < n else period - j
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    from kintinuous_amd import abi, build as kbuild, synth
+    if rank == 0 and kbuild.needs_build():
+        kbuild.build()
+    if dist is not None:
+        dist.barrier()
+
+    cfg_name, scale, N, kw = WORKLOADS[args.workload]
+    cam = synth.Camera.scaled(scale)
+    total_frames = args.steps + args.warmup
+    nuniq = max(2, min(args.unique_frames, total_frames))
+    seed = 1234 + rank
+    _, frames, traj, kw2 = synth.sequence(cfg_name, nuniq, cam, seed)
+    d = dict(volume_size=6.0, voxel_shift=14, overlap=2, static_mode=0, use_rgbd=0, use_rgbd_icp=0, fast_odometry=0, disable_color_angle=0)
+    d.update(kw2)
+    d.update(kw)
+
+    ctx = abi.Ctx(local_rank)
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, d["volume_size"], d["voxel_shift"], d["overlap"], d["static_mode"],
+                            d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0)
+    trk = abi.Tracker(ctx, cfg)
+    dev_frames = [(ctx.upload(dep), ctx.upload(rgb)) for (dep, rgb) in frames]  # inputs resident in HBM before the timed region
+
+    def step(i):
+        dd, dr = dev_frames[pingpong(i, nuniq)]
+        trk.process_frame(dd, dr, 33333 * i)
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.sync()
+    trk.enable_profiling(1)  # HIP events around the tsdf23 kernel only, on the stream it is launched on
+    if dist is not None:
+        import torch
+        dist.barrier()
+        torch.cuda.synchronize()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    pose_bytes = 0
+    if dist is not None:
+        import torch
+        k = min(args.steps, trk.num_poses())
+        mine = torch.empty(k * 16, dtype=torch.float32, device=f"cuda:{local_rank}")
+        trk.export_poses_device(k, mine.data_ptr())
+        allp = torch.empty(world * k * 16, dtype=torch.float32, device=f"cuda:{local_rank}")
+        dist.all_gather_into_tensor(allp, mine)  # the single RCCL gather of per-stream poses
+        pose_bytes = allp.numel() * 4
+    ctx.sync()
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    stage = trk.stage_ms()
+    tsdf23_ms, tsdf23_n = stage["tsdf23"]
+    # tracking must still be healthy at the end of the timed region (not a degenerate run)
+    R, t, _ = trk.pose()
+    Rg, cg = traj[pingpong(args.warmup + args.steps - 1, nuniq)]
+    basis = np.array([d["volume_size"] / 2] * 3)
+    if d["static_mode"]:
+        basis[2] = np.float32(d["volume_size"] * 0.5) - np.float32(d["volume_size"] * 0.5 + 0.45)
+    w = trk.voxel_wrap().astype(np.float64) * (d["volume_size"] / N)
+    pose_err = float(np.abs((t + w) - (cg + basis)).max())
+
+    # ---- untimed: per-stage breakdown and the U / S counters of a few frames ----------------------
+    trk.enable_profiling(2)
+    trk.enable_counts(True)
+    Us, Ss = [], []
+    base = args.warmup + args.steps
+    for i in range(base, base + 8):
+        step(i)
+        U, S = trk.last_counts()
+        Us.append(U)
+        Ss.append(S)
+    trk.enable_counts(False)
+    stage_all = trk.stage_ms()
+    trk.enable_profiling(0)
+    U = float(np.mean(Us))
+    P = cam.cols * cam.rows
+    # algorithmic bytes of the tsdf23 launch (DESIGN.md "integrate"): 12 B per updated voxel (2 B tsdf + 4 B colour/weight,
+    # read and written) + the per-pixel record gathered by the voxels (16 B, counted once per pixel)
+    bytes_tsdf23 = 12.0 * U + 16.0 * P
+    achieved = bytes_tsdf23 / (tsdf23_ms * 1e-3) / 1e9 if tsdf23_ms > 0 else 0.0
+    peak = 8000.0
+
+    out = {
+        "metric": "RGB-D frames/sec @640x480, 512^3 TSDF" if args.workload == "orbit512" else f"RGB-D frames/sec ({args.workload})",
+        "value": world * args.steps / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {cam.cols}x{cam.rows} synthetic {cfg_name} sequence, {'ICP+RGB-D' if d['use_rgbd_icp'] else 'ICP-only'} tracking, "
+                               f"{N}^3 TSDF, inputs resident in HBM, 1 stream per GPU (BASELINE.json configs[1])",
+                   "volume": N, "cols": cam.cols, "rows": cam.rows, "unique_frames": nuniq, "pose_err_m_at_end": pose_err,
+                   "pose_gather_bytes": pose_bytes},
+        "roofline": {"kernel": "kt_tsdf23_kernel", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
+                     "frac": achieved / peak, "traffic": None, "algorithmic_bytes_per_launch": bytes_tsdf23,
+                     "avg_launch_ms": tsdf23_ms, "launches_timed": tsdf23_n, "U_voxels_updated": U, "S_raycast_steps": float(np.mean(Ss))},
+        "stage_ms": {k: round(v[0], 4) for k, v in stage_all.items()},
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cam, N, d, frames, args.cpu_frames)
+
+    if rank == 0:
+        print(json.dumps(out))
+    trk.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cam, N, d, frames, nframes):
+    """The oracle (CPU restatement of the reference -- the reference has no CPU path) timed on this host's cores on the
+    first `nframes` frames of the same workload.  A reported baseline, not the target."""
+    cores = min(32, len(os.sched_getaffinity(0)))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    from oracle import oracle
+    oracle.build()
+    ocfg = oracle.OTrackerConfig(cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, d["volume_size"], d["voxel_shift"], d["overlap"],
+                                 d["static_mode"], d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0)
+    otr = oracle.OracleTracker(ocfg)
+    n = min(nframes, len(frames))
+    otr.process_frame(frames[0][0], frames[0][1], 0)  # frame 0 only integrates; not representative, excluded
+    t0 = time.perf_counter()
+    for k in range(1, n):
+        otr.process_frame(frames[k][0], frames[k][1], 33333 * k)
+    dt = time.perf_counter() - t0
+    stages = otr.stage_seconds()
+    otr.close()
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": (n - 1) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"frames 1..{n - 1} of the same sequence through oracle/ (OpenMP, {cores} threads) on {model}",
+            "stage_s_total": {k: round(v, 3) for k, v in stages.items()}}
+
+
+if __name__ == "__main__":
+    main()

@@ -4,47 +4,53 @@
 // without a host round trip.  Reference: src/frontend/cuda/reduce.cu, src/frontend/ICPOdometry.cpp,
 // RGBDOdometry.cpp, OdometryProvider.h.
 //
-// Reduction shape (wave64): every thread accumulates its pixels' 29 products in float (as the reference
-// does per thread), a 64-lane __shfl_down tree folds the wave, the 4 waves of a block and then the
-// blocks are folded in double in a FIXED order (deterministic run to run).  The last block to finish
-// (device-scope ticket, agent-scope release/acquire per cdna_hip_programming.md Guideline 16) produces the
-// final sums and, in the device-resident path, solves and updates the pose.  The summation tree differs
-// from the reference's 32-lane/64x128 geometry, so A and b agree with the oracle to float rounding
-// (~1e-6 relative), not bit for bit; everything per-pixel is bit-identical.
+// Reduction shape: the 29 float sums are folded in EXACTLY the reference's order (reduce.cu:89-184, 321-339): 64 x 128
+// "virtual threads" each accumulate pixels t, t + 8192, ... sequentially, a 32-lane __shfl_down tree folds each half of
+// a wave64 (one CUDA warp), the 4 warp results of a 128-thread block fold as (s0 + s2) + (s1 + s3), and the 64 block
+// partials fold like reduceSum<<<1, 512>>> does (two 32-lane trees, then s0 + s1).  A, b are therefore bit-identical to
+// the oracle (and, up to nvcc's approximate div/sqrt, to the reference), which keeps whole trajectories and the fused
+// volume bit-comparable.  The price is the reference's modest parallelism (128 waves); the per-thread pixel loop is
+// latency-pipelined instead.  The last block to finish (device-scope ticket, agent-scope release/acquire per
+// cdna_hip_programming.md Guideline 16) produces the final sums and, in the device-resident path, solves and updates
+// the pose on the device.
 #include "kt_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // block / grid reduction
 // ------------------------------------------------------------------------------------------------
-#define KT_RED_THREADS 256
-#define KT_RED_SLOTS 32   // 29 used
+#define KT_RED_THREADS 128  // icpStep / rgbStep launch geometry: <<<64, 128>>> (ICPOdometry.cpp:123-124, RGBDOdometry.cpp:306-307)
+#define KT_RED_BLOCKS 64
+#define KT_RED_SLOTS 32     // 29 used
 
-__device__ __forceinline__ float kt_wave_sum(float v)
+// warpReduceSum over one CUDA-warp-sized group (32 lanes), reduce.cu:89-129.  Lane 0 of each group ends with
+// ((..(v0 + v16) + (v8 + v24)) ..) exactly as the reference's tree; the other lanes are don't-care.
+__device__ __forceinline__ float kt_warp32_sum(float v)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
     return v;
 }
 
-// Folds per-thread acc[29] over the grid.  Returns true (block-uniformly) in the block that retired last;
-// in that block total[0..28] (LDS, double) holds the grid sums.
-__device__ __forceinline__ bool kt_grid_reduce29(const float (&acc)[29], double* __restrict__ partials, unsigned int* __restrict__ ticket,
-                                                 double (&total)[KT_RED_SLOTS])
+// Folds per-thread acc[29] over the 64 x 128 grid in the reference's order.  Returns true (block-uniformly) in the
+// block that retired last; in that block total[0..28] (LDS) holds the grid sums.
+__device__ __forceinline__ bool kt_grid_reduce29(const float (&acc)[29], float* __restrict__ partials, unsigned int* __restrict__ ticket,
+                                                 float (&total)[KT_RED_SLOTS])
 {
-    __shared__ float wave_part[4][KT_RED_SLOTS];
-    __shared__ double fold[8][KT_RED_SLOTS];
+    __shared__ float warp_part[4][KT_RED_SLOTS];
     __shared__ bool is_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane32 = threadIdx.x & 31, wid = threadIdx.x >> 5;
 #pragma unroll
     for (int k = 0; k < 29; ++k) {
-        const float s = kt_wave_sum(acc[k]);
-        if (lane == 0) wave_part[wave][k] = s;
+        const float s = kt_warp32_sum(acc[k]);
+        if (lane32 == 0) warp_part[wid][k] = s;
     }
     __syncthreads();
     if (threadIdx.x < 29) {
+        // blockReduceSum's second stage (reduce.cu:131-164): lanes 0..3 hold the warp sums, lanes 4..31 zero;
+        // offsets 16, 8, 4 add zeros, offset 2 gives s0+s2 and s1+s3, offset 1 adds them
         const int k = threadIdx.x;
-        const double s = (((double)wave_part[0][k] + (double)wave_part[1][k]) + (double)wave_part[2][k]) + (double)wave_part[3][k];
-        partials[(size_t)blockIdx.x * KT_RED_SLOTS + k] = s;
+        float s0 = warp_part[0][k] + 0.0f, s1 = warp_part[1][k] + 0.0f, s2 = warp_part[2][k] + 0.0f, s3 = warp_part[3][k] + 0.0f;
+        partials[(size_t)blockIdx.x * KT_RED_SLOTS + k] = (s0 + s2) + (s1 + s3);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -60,16 +66,16 @@ __device__ __forceinline__ bool kt_grid_reduce29(const float (&acc)[29], double*
     }
     __syncthreads();
     if (!is_last) return false;
-    // fixed-order fold over blocks: 8 interleaved chains per component, then a fixed 8-way tree
-    const int k = threadIdx.x & 31, j = threadIdx.x >> 5;
-    double s = 0.0;
-    if (k < 29)
-        for (int b = j; b < (int)gridDim.x; b += 8) s += partials[(size_t)b * KT_RED_SLOTS + k];
-    fold[j][k] = s;
-    __syncthreads();
-    if (threadIdx.x < KT_RED_SLOTS) {
-        const int c = threadIdx.x;
-        total[c] = ((fold[0][c] + fold[1][c]) + (fold[2][c] + fold[3][c])) + ((fold[4][c] + fold[5][c]) + (fold[6][c] + fold[7][c]));
+    // reduceSum<<<1, 512>>>(sum, out, 64) (reduce.cu:166-184): threads 0..63 hold 0 + in[i]; warps 0 and 1 fold with the
+    // 32-lane tree, every other warp is zero; the final first-warp tree reduces to s0 + s1.
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        for (int k = 0; k < 29; ++k) {
+            float v = 0.0f + partials[(size_t)lane * KT_RED_SLOTS + k];
+            v = kt_warp32_sum(v);
+            const float hi = __shfl(v, 32, 64);
+            if (lane == 0) total[k] = (v + 0.0f) + (hi + 0.0f);
+        }
     }
     __syncthreads();
     return true;
@@ -99,7 +105,7 @@ struct kt_icp_args {
     kt_mat33 Rcurr; float tcurr[3];
     kt_mat33 Rprev_inv; float tprev[3];
     kt_track_state* state;     // nullptr on the host path
-    double* partials; unsigned int* ticket;
+    float* partials; unsigned int* ticket;
     float* out29;              // host path: 29 floats
     int mode;                  // KT_MODE_*
 };
@@ -161,13 +167,13 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
     const int n = a.cols * a.rows;
     for (int i = blockIdx.x * KT_RED_THREADS + threadIdx.x; i < n; i += gridDim.x * KT_RED_THREADS)
         kt_icp_pixel(a, Rcurr, tcurr, Rprev_inv, tprev, i, acc);
-    __shared__ double total[KT_RED_SLOTS];
+    __shared__ float total[KT_RED_SLOTS];
     if (!kt_grid_reduce29(acc, a.partials, a.ticket, total)) return;
     if (a.mode == KT_MODE_HOST) {
-        if (threadIdx.x < 29) a.out29[threadIdx.x] = (float)total[threadIdx.x];
+        if (threadIdx.x < 29) a.out29[threadIdx.x] = total[threadIdx.x];
     } else if (threadIdx.x == 0) {
         float h[29];
-        for (int k = 0; k < 29; ++k) h[k] = (float)total[k];
+        for (int k = 0; k < 29; ++k) h[k] = total[k];
         if (a.mode == KT_MODE_ICP_SOLVE) {
             // ICPOdometry.cpp:127-178
             __shared__ double dA[36], db[6];
@@ -181,19 +187,11 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
     }
 }
 
-static int kt_red_grid(int n)
-{
-    int g = kt_div_up(n, KT_RED_THREADS);
-    if (g > 512) g = 512;
-    if (g < 1) g = 1;
-    return g;
-}
-
 int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
 {
-    a.partials = c->red_partials;
+    a.partials = (float*)c->red_partials;
     a.ticket = &c->counters[0];
-    hipLaunchKernelGGL(kt_icp_kernel, dim3(kt_red_grid(a.cols * a.rows)), dim3(KT_RED_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(kt_icp_kernel, dim3(KT_RED_BLOCKS), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
@@ -367,6 +365,7 @@ extern "C" int kt_rgb_residual(kt_ctx* c, float min_scale, const int16_t* dIdx, 
     KT_HIP(hipStreamSynchronize(c->stream));
     *count_host = c->int_out_host[0];
     *sigma_sum_host = c->int_out_host[1];
+    KT_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(int), c->stream));  // invariant: {count, sigma} are zero at rest (device path relies on it)
     return KT_OK;
 }
 
@@ -397,7 +396,7 @@ struct kt_rgb_args {
     float sobel_scale;
     int cols, rows;
     kt_track_state* state;
-    double* partials; unsigned int* ticket;
+    float* partials; unsigned int* ticket;
     float* out29;
     int mode;              // KT_MODE_HOST, KT_MODE_RGB_SOLVE, KT_MODE_JOINT_SOLVE
     kt_level_k next_k;     // intrinsics of the level the NEXT iteration runs at (for K R K^-1, K t)
@@ -436,13 +435,13 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_arg
         }
         kt_outer29(row, found, acc);
     }
-    __shared__ double total[KT_RED_SLOTS];
+    __shared__ float total[KT_RED_SLOTS];
     if (!kt_grid_reduce29(acc, a.partials, a.ticket, total)) return;
     if (a.mode == KT_MODE_HOST) {
-        if (threadIdx.x < 29) a.out29[threadIdx.x] = (float)total[threadIdx.x];
+        if (threadIdx.x < 29) a.out29[threadIdx.x] = total[threadIdx.x];
     } else if (threadIdx.x == 0) {
         float h[29];
-        for (int k = 0; k < 29; ++k) h[k] = (float)total[k];
+        for (int k = 0; k < 29; ++k) h[k] = total[k];
         __shared__ double dA[36], db[6];
         kt_unpack29_d(h, dA, db);
         if (a.mode == KT_MODE_JOINT_SOLVE) {
@@ -466,8 +465,8 @@ extern "C" int kt_rgb_step(kt_ctx* c, const kt_dataterm* corres_img, float sigma
     kt_rgb_args a;
     a.corres = corres_img; a.sigma = sigma; a.cloud = cloud; a.fx = fx; a.fy = fy; a.dIdx = dIdx; a.dIdy = dIdy;
     a.sobel_scale = sobel_scale; a.cols = cols; a.rows = rows; a.state = nullptr;
-    a.partials = c->red_partials; a.ticket = &c->counters[0]; a.out29 = c->red_out; a.mode = KT_MODE_HOST;
-    hipLaunchKernelGGL(kt_rgb_kernel, dim3(kt_red_grid(cols * rows)), dim3(KT_RED_THREADS), 0, c->stream, a);
+    a.partials = (float*)c->red_partials; a.ticket = &c->counters[0]; a.out29 = c->red_out; a.mode = KT_MODE_HOST;
+    hipLaunchKernelGGL(kt_rgb_kernel, dim3(KT_RED_BLOCKS), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * 29, hipMemcpyDeviceToHost, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
@@ -482,9 +481,9 @@ int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corr
     kt_rgb_args a;
     a.corres = corres_img; a.sigma = 0.f; a.cloud = cloud; a.fx = fx; a.fy = fy; a.dIdx = dIdx; a.dIdy = dIdy;
     a.sobel_scale = sobel_scale; a.cols = cols; a.rows = rows; a.state = state;
-    a.partials = c->red_partials; a.ticket = &c->counters[0]; a.out29 = nullptr; a.mode = mode;
+    a.partials = (float*)c->red_partials; a.ticket = &c->counters[0]; a.out29 = nullptr; a.mode = mode;
     a.next_k = *next_k;
-    hipLaunchKernelGGL(kt_rgb_kernel, dim3(kt_red_grid(cols * rows)), dim3(KT_RED_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(kt_rgb_kernel, dim3(KT_RED_BLOCKS), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }

@@ -1,0 +1,58 @@
+import os
+import sys
+
+# the oracle is OpenMP code: cap its threads (GPU boxes expose many more hardware threads than the job may use)
+os.environ.setdefault("OMP_NUM_THREADS", str(min(8, len(os.sched_getaffinity(0)))))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle
+    oracle.build()
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def ktlib():
+    """The HIP library.  Fails loudly (no fallback) when it is missing."""
+    from kintinuous_amd import abi
+    return abi.lib()
+
+
+@pytest.fixture(scope="session")
+def ctx(ktlib):
+    from kintinuous_amd import abi
+    c = abi.Ctx(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def small_scene():
+    """A 160x120 room frame pair + maps, shared by several tests."""
+    from kintinuous_amd import synth
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("room")
+    traj = synth.orbit_trajectory(8)
+    frames = [synth.render(scene, cam, R, c) for (R, c) in traj]
+    return cam, frames, traj
+
+
+def random_rotation(rng, max_angle):
+    from oracle import oracle
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    return oracle.rodrigues(axis * rng.uniform(0, max_angle)).astype(np.float32)

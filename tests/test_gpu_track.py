@@ -1,0 +1,129 @@
+"""GPU parity: tracking reductions through the C-ABI vs the oracle.
+Per-pixel work is bit-identical and the 29 float sums are folded in the reference's exact order (64 x 128 grid-stride
+partials, 32-lane shuffle trees, reduceSum<<<1,512>>>), so A, b, residual must equal the oracle's reference-order result
+BIT FOR BIT; the oracle's double-precision accumulation bounds the float summation error of both.
+Integer outputs (inlier count, DataTerm image, count / sigma) are exact."""
+import numpy as np
+import pytest
+
+from conftest import random_rotation
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame_maps(oracle, cam, depth, level):
+    from oracle.oracle import OIntr
+    d = oracle.bilateral_filter(depth)
+    for _ in range(level):
+        d = oracle.pyr_down(d)
+    v = oracle.create_vmap(OIntr(cam.fx, cam.fy, cam.cx, cam.cy).level(level), d)
+    return v, oracle.create_nmap(v)
+
+
+def _close(hip, ref_f, ref_d, name):
+    scale = np.abs(ref_d).max() + 1e-12
+    # the reference-order float result and the HIP result must both sit within float summation error of the double sum
+    assert np.abs(hip - ref_d).max() <= 2e-5 * scale, f"{name}: hip vs double {np.abs(hip - ref_d).max() / scale:.3e}"
+    assert np.abs(ref_f - ref_d).max() <= 2e-5 * scale, f"{name}: oracle float vs double {np.abs(ref_f - ref_d).max() / scale:.3e}"
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_icp_step(ctx, oracle_mod, small_scene, level):
+    from kintinuous_amd.abi import Intr
+    from oracle.oracle import OIntr
+    cam, frames, traj = small_scene
+    rng = np.random.default_rng(level)
+    vc, nc = _frame_maps(oracle_mod, cam, frames[1][0], level)
+    v0, n0 = _frame_maps(oracle_mod, cam, frames[0][0], level)
+    t0 = np.array([3, 3, 3], np.float32)
+    vg, ng = oracle_mod.transform_maps(v0, n0, np.eye(3), t0)
+    rows, cols = vc.shape[0] // 3, vc.shape[1]
+    Rprev = random_rotation(rng, 0.02)
+    Rprev_inv = oracle_mod.mat33_inverse(Rprev)
+    Rcurr = (random_rotation(rng, 0.01) @ Rprev).astype(np.float32)
+    tcurr = t0 + rng.uniform(-0.01, 0.01, 3).astype(np.float32)
+    dist, ang = 0.10, float(np.float32(np.sin(np.float32(20.0) * np.float32(3.14159254) / np.float32(180.0))))
+    oi, gi = OIntr(cam.fx, cam.fy, cam.cx, cam.cy).level(level), Intr(cam.fx, cam.fy, cam.cx, cam.cy).level(level)
+    Af, bf, rf = oracle_mod.icp_step(Rcurr, tcurr, vc, nc, Rprev_inv, t0, oi, vg, ng, dist, ang, order=0)
+    Ad, bd, rd = oracle_mod.icp_step(Rcurr, tcurr, vc, nc, Rprev_inv, t0, oi, vg, ng, dist, ang, order=1)
+    A, b, r = ctx.icp_step(Rcurr, tcurr, ctx.upload(vc), ctx.upload(nc), Rprev_inv, t0, gi, ctx.upload(vg), ctx.upload(ng), cols, rows, dist, ang)
+    assert rd[1] > 0.3 * rows * cols
+    assert r[1] == rd[1] == rf[1], "inlier count must be exact"
+    _close(A, Af, Ad, "A")
+    _close(b, bf, bd, "b")
+    assert abs(r[0] - rd[0]) <= 2e-5 * abs(rd[0])
+    assert np.array_equal(A.view(np.uint32), Af.view(np.uint32)), "A must match the reference-order float sums bit for bit"
+    assert np.array_equal(b.view(np.uint32), bf.view(np.uint32)) and np.array_equal(r.view(np.uint32), rf.view(np.uint32))
+    # run-to-run determinism of the fixed-order fold
+    A2, b2, r2 = ctx.icp_step(Rcurr, tcurr, ctx.upload(vc), ctx.upload(nc), Rprev_inv, t0, gi, ctx.upload(vg), ctx.upload(ng), cols, rows, dist, ang)
+    assert np.array_equal(A, A2) and np.array_equal(b, b2) and np.array_equal(r, r2)
+
+
+def test_icp_step_all_invalid(ctx, oracle_mod, small_scene):
+    from kintinuous_amd.abi import Intr
+    cam, _, _ = small_scene
+    rows, cols = cam.rows, cam.cols
+    nanmap = np.full((3 * rows, cols), np.nan, np.float32)
+    A, b, r = ctx.icp_step(np.eye(3), [3, 3, 3], ctx.upload(nanmap), ctx.upload(nanmap), np.eye(3), [3, 3, 3], Intr(cam.fx, cam.fy, cam.cx, cam.cy),
+                           ctx.upload(nanmap), ctx.upload(nanmap), cols, rows, 0.1, 0.34)
+    assert not A.any() and not b.any() and r[1] == 0
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_rgb_residual_and_step(ctx, oracle_mod, small_scene, level):
+    from kintinuous_amd.abi import DATATERM_DTYPE
+    cam, frames, traj = small_scene
+
+    def pyr(depth, rgb):
+        dm, im = oracle_mod.depth_to_metres(depth, 6000), oracle_mod.bgr_to_intensity(rgb)
+        for _ in range(level):
+            dm, im = oracle_mod.pyr_down_gauss_f32(dm), oracle_mod.pyr_down_gauss_u8(im)
+        return dm, im
+
+    ld, li = pyr(*frames[0])
+    nd, ni = pyr(*frames[1])
+    rows, cols = ni.shape
+    dx, dy = oracle_mod.derivative_images(ni)
+    div = 1 << level
+    K = np.array([[cam.fx / div, 0, cam.cx / div], [0, cam.fy / div, cam.cy / div], [0, 0, 1]])
+    Rinc = oracle_mod.rodrigues([0.002, -0.003, 0.001])
+    krk = (K @ Rinc @ np.linalg.inv(K)).astype(np.float32)
+    kt = (K @ np.array([0.004, -0.002, 0.003])).astype(np.float32)
+    min_scale = float(np.float32((12.0 if level == 0 else 5.0) ** 2 / 0.125 ** 2))
+    corres, sigma, count = oracle_mod.rgb_residual(min_scale, dx, dy, ld, nd, li, ni, np.float32(0.07), kt, krk)
+    gcor = ctx.zeros(rows * cols * 16)
+    gdx, gdy = ctx.upload(dx), ctx.upload(dy)
+    gs, gc = ctx.rgb_residual(min_scale, gdx, gdy, ctx.upload(ld), ctx.upload(nd), ctx.upload(li), ctx.upload(ni), cols, rows, gcor,
+                              float(np.float32(0.07)), kt, krk)
+    assert count > 50
+    assert (gs, gc) == (sigma, count)
+    got = ctx.download(gcor, DATATERM_DTYPE, (rows, cols))
+    assert np.array_equal(got["valid"], corres["valid"])
+    m = corres["valid"] == 1
+    for f in ("zero", "one"):
+        assert np.array_equal(got[f][m], corres[f][m])
+    assert np.array_equal(got["diff"][m].view(np.uint32), corres["diff"][m].view(np.uint32))
+    # rgbStep on the oracle's correspondence image
+    cloud = oracle_mod.project_to_cloud(ld, cam.fx, cam.fy, cam.cx, cam.cy, level)
+    sig_val = float(np.sqrt(np.float32(count)))
+    fx, fy = np.float32(cam.fx) / np.float32(div), np.float32(cam.fy) / np.float32(div)
+    Af, bf = oracle_mod.rgb_step(corres, sig_val, cloud, fx, fy, dx, dy, 0.125, order=0)
+    Ad, bd = oracle_mod.rgb_step(corres, sig_val, cloud, fx, fy, dx, dy, 0.125, order=1)
+    A, b = ctx.rgb_step(ctx.upload(corres), sig_val, ctx.upload(cloud), float(fx), float(fy), gdx, gdy, 0.125, cols, rows)
+    scale = np.abs(Ad).max()
+    assert np.abs(A - Ad).max() <= 2e-5 * scale and np.abs(Af - Ad).max() <= 2e-5 * scale
+    assert np.array_equal(A.view(np.uint32), Af.view(np.uint32)) and np.array_equal(b.view(np.uint32), bf.view(np.uint32))
+
+
+def test_conversion_semantics(ctx, oracle_mod):
+    """CUDA __float2int_r{n,z,d} saturate and map NaN to 0; gfx950's v_cvt_i32_f32 must agree with the oracle's
+    explicit emulation.  Exercised through createVMap-independent paths is awkward, so probe via bilateral + pyrDown
+    on crafted inputs (rn ties, truncation) and via raycast's floor (covered in test_gpu_volume)."""
+    # rn ties: a constant image filtered by the bilateral kernel returns itself; half-way values arise in pyrDown truncation
+    d = np.full((64, 64), 1001, np.uint16)
+    d[::2, ::2] = 1000
+    ref = oracle_mod.pyr_down(oracle_mod.bilateral_filter(d))
+    g0, g1 = ctx.empty(d.nbytes), ctx.empty(d.nbytes // 4)
+    ctx.bilateral_filter(ctx.upload(d), g0, 64, 64)
+    ctx.pyr_down(g0, 64, 64, g1)
+    assert np.array_equal(ref, ctx.download(g1, np.uint16, ref.shape))
