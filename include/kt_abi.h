@@ -101,6 +101,11 @@ int kt_derivative_images(kt_ctx* ctx, const uint8_t* src, int cols, int rows, in
 int kt_project_to_cloud(kt_ctx* ctx, const float* depth, int cols, int rows, float* cloud_xyz,
                         double fx, double fy, double cx, double cy, int level);
 
+/* Fused pyramid build (no single reference counterpart): pyrDown x3 + createVMap x4 + createNMap x4 in one launch,
+ * bit-identical to the separate calls (KintinuousTracker.cpp:469-478).  depth0 = bilateral-filtered level 0. */
+int kt_build_pyramid(kt_ctx* ctx, const kt_intr* intr, const uint16_t* depth0, int cols, int rows,
+                     uint16_t* const depths_out[3], float* const vmaps[4], float* const nmaps[4]);
+
 /* ---- tracking reductions ---- */
 /* icpStep  internal.h:485-502 / reduce.cu:347-419.  A_host[36] row-major symmetric, b_host[6], residual_host[2]
  * = {sum residual^2, inlier count}.  The reference's `sum`/`out` scratch arrays live in the context. */

@@ -88,6 +88,7 @@ _PROTOS = {
     "kt_pyr_down_gauss_u8": (_i, [_vp, _vp, _i, _i, _vp]),
     "kt_derivative_images": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "kt_project_to_cloud": (_i, [_vp, _vp, _i, _i, _vp, _d, _d, _d, _d, _i]),
+    "kt_build_pyramid": (_i, [_vp, _pI, _vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "kt_icp_step": (_i, [_vp, _pM, _pf, _vp, _vp, _pM, _pf, _pI, _vp, _vp, _i, _i, _f, _f, _pf, _pf, _pf]),
     "kt_rgb_residual": (_i, [_vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _pf, _pM, _pi, _pi]),
     "kt_rgb_step": (_i, [_vp, _vp, _f, _vp, _f, _f, _vp, _vp, _f, _i, _i, _pf, _pf]),
@@ -259,6 +260,12 @@ class Ctx:
 
     def project_to_cloud(self, depth, cols, rows, cloud, fx, fy, cx, cy, level) -> None:
         _chk(lib().kt_project_to_cloud(self.h, depth.ptr, cols, rows, cloud.ptr, fx, fy, cx, cy, level))
+
+    def build_pyramid(self, intr: Intr, depth0, cols, rows, depths_out, vmaps, nmaps) -> None:
+        d = (_vp * 3)(*[b.ptr for b in depths_out])
+        v = (_vp * 4)(*[b.ptr for b in vmaps])
+        n = (_vp * 4)(*[b.ptr for b in nmaps])
+        _chk(lib().kt_build_pyramid(self.h, C.byref(intr), depth0.ptr, cols, rows, d, v, n))
 
     # ---- tracking ------------------------------------------------------------------------------
     def icp_step(self, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr: Intr, vmap_g_prev, nmap_g_prev, cols, rows,

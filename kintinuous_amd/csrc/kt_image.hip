@@ -405,3 +405,161 @@ extern "C" int kt_project_to_cloud(kt_ctx* c, const float* depth, int cols, int 
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
+
+// ================================================================================================
+// Fused pyramid build: pyrDown x3 + createVMap x4 + createNMap x4 in ONE launch
+// (KintinuousTracker.cpp:469-478 issues 11 kernels for this; each is launch-latency bound at VGA).
+// One workgroup owns a 4x4 tile of level 3 (= 8x8 / 16x16 / 32x32 at levels 2 / 1 / 0).  The level-0 depth it needs,
+// including the 5x5 pyrDown halos of all three levels and the +1 neighbours of the normal map (61 x 61 pixels), is
+// staged in LDS; levels 1..3 are built tile-locally in LDS with exactly pyrDownGaussKernel's arithmetic, then vertex and
+// normal maps of all four levels are emitted from LDS.  Halo pixels are recomputed by neighbouring workgroups with
+// identical inputs, so every output is bit-identical to running the separate kernels.
+// ================================================================================================
+#define KT_PYR_T0 61
+#define KT_PYR_T1 29
+#define KT_PYR_T2 13
+#define KT_PYR_T3 5
+
+struct kt_pyr_args {
+    const uint16_t* d0;
+    uint16_t* d[3];          // depth levels 1..3
+    float* vmap[4]; float* nmap[4];
+    int cols, rows;          // level 0
+    float fx_inv[4], fy_inv[4], cx[4], cy[4];
+};
+
+// pyrDownGaussKernel body (bilateral_pyrdown.cu:101-136) reading the source level from an LDS tile whose (0,0) is the
+// source pixel (tox, toy); returns -1 for destinations outside the destination image.
+__device__ __forceinline__ int kt_pyr_px(const int* __restrict__ tile, int tw, int tox, int toy, int scols, int srows, int x, int y)
+{
+    const int dcols = scols / 2, drows = srows / 2;
+    if (x < 0 || y < 0 || x >= dcols || y >= drows) return -1;
+    const int D = 5;
+    const float sigma_color = 30.0f;
+    const int center = tile[(2 * y - toy) * tw + (2 * x - tox)];
+    const int x_mi = max(0, 2 * x - D / 2) - 2 * x;
+    const int y_mi = max(0, 2 * y - D / 2) - 2 * y;
+    const int x_ma = min(scols, 2 * x - D / 2 + D) - 2 * x;
+    const int y_ma = min(srows, 2 * y - D / 2 + D) - 2 * y;
+    float sum = 0, wall = 0;
+    for (int yi = y_mi; yi < y_ma; ++yi)
+        for (int xi = x_mi; xi < x_ma; ++xi) {
+            const int val = tile[(2 * y + yi - toy) * tw + (2 * x + xi - tox)];
+            if ((float)abs(val - center) < 3 * sigma_color) {
+                const int axi = abs(xi), ayi = abs(yi);
+                const float wx = axi == 0 ? 0.375f : (axi == 1 ? 0.25f : 0.0625f);
+                const float wy = ayi == 0 ? 0.375f : (ayi == 1 ? 0.25f : 0.0625f);
+                sum = __builtin_fmaf((float)val * wx, wy, sum);
+                wall = __builtin_fmaf(wx, wy, wall);
+            }
+        }
+    return (int)(uint16_t)kt_f2i_rz(sum / wall);
+}
+
+// computeVmapKernel + computeNmapKernel (maps.cu:56-120) for pixel (u, v) of a level whose depth sits in an LDS tile
+__device__ __forceinline__ void kt_emit_maps(const int* __restrict__ tile, int tw, int tox, int toy, int cols, int rows, int u, int v,
+                                             float fx_inv, float fy_inv, float cx, float cy, float* __restrict__ vmap, float* __restrict__ nmap)
+{
+    if (u >= cols || v >= rows) return;
+    const float z00 = (float)tile[(v - toy) * tw + (u - tox)] / 1000.f;
+    f3 v00 = {kt_nan(), 0.f, 0.f};
+    if (z00 != 0) {
+        v00 = {z00 * ((float)u - cx) * fx_inv, z00 * ((float)v - cy) * fy_inv, z00};
+        vmap[v * cols + u] = v00.x;
+        vmap[(v + rows) * cols + u] = v00.y;
+        vmap[(v + 2 * rows) * cols + u] = v00.z;
+    } else
+        vmap[v * cols + u] = kt_nan();
+    if (u == cols - 1 || v == rows - 1) { nmap[v * cols + u] = kt_nan(); return; }
+    const float z01 = (float)tile[(v - toy) * tw + (u + 1 - tox)] / 1000.f;
+    const float z10 = (float)tile[(v + 1 - toy) * tw + (u - tox)] / 1000.f;
+    if (z00 != 0 && z01 != 0 && z10 != 0) {
+        const f3 v01 = {z01 * ((float)(u + 1) - cx) * fx_inv, z01 * ((float)v - cy) * fy_inv, z01};
+        const f3 v10 = {z10 * ((float)u - cx) * fx_inv, z10 * ((float)(v + 1) - cy) * fy_inv, z10};
+        const f3 r = kt_normalized(kt_cross(kt_sub(v01, v00), kt_sub(v10, v00)));
+        nmap[v * cols + u] = r.x;
+        nmap[(v + rows) * cols + u] = r.y;
+        nmap[(v + 2 * rows) * cols + u] = r.z;
+    } else
+        nmap[v * cols + u] = kt_nan();
+}
+
+__global__ __launch_bounds__(256) void kt_pyramid_kernel(const kt_pyr_args a)
+{
+    __shared__ int t0[KT_PYR_T0 * KT_PYR_T0], t1[KT_PYR_T1 * KT_PYR_T1], t2[KT_PYR_T2 * KT_PYR_T2], t3[KT_PYR_T3 * KT_PYR_T3];
+    const int tid = threadIdx.x;
+    const int o3x = blockIdx.x * 4, o3y = blockIdx.y * 4;
+    const int o2x = 2 * o3x, o2y = 2 * o3y, o1x = 4 * o3x, o1y = 4 * o3y, o0x = 8 * o3x, o0y = 8 * o3y;
+    const int c0 = a.cols, r0 = a.rows, c1 = c0 / 2, r1 = r0 / 2, c2 = c1 / 2, r2 = r1 / 2, c3 = c2 / 2, r3 = r2 / 2;
+    // tile origins in their own level's pixel coordinates
+    const int t0x = o0x - 14, t0y = o0y - 14, t1x = o1x - 6, t1y = o1y - 6, t2x = o2x - 2, t2y = o2y - 2, t3x = o3x, t3y = o3y;
+    for (int i = tid; i < KT_PYR_T0 * KT_PYR_T0; i += 256) {
+        const int ly = i / KT_PYR_T0, lx = i - ly * KT_PYR_T0;
+        const int gx = t0x + lx, gy = t0y + ly;
+        t0[i] = (gx >= 0 && gy >= 0 && gx < c0 && gy < r0) ? (int)a.d0[gy * c0 + gx] : -1;
+    }
+    __syncthreads();
+    for (int i = tid; i < KT_PYR_T1 * KT_PYR_T1; i += 256) {
+        const int ly = i / KT_PYR_T1, lx = i - ly * KT_PYR_T1;
+        t1[i] = kt_pyr_px(t0, KT_PYR_T0, t0x, t0y, c0, r0, t1x + lx, t1y + ly);
+    }
+    __syncthreads();
+    for (int i = tid; i < KT_PYR_T2 * KT_PYR_T2; i += 256) {
+        const int ly = i / KT_PYR_T2, lx = i - ly * KT_PYR_T2;
+        t2[i] = kt_pyr_px(t1, KT_PYR_T1, t1x, t1y, c1, r1, t2x + lx, t2y + ly);
+    }
+    __syncthreads();
+    if (tid < KT_PYR_T3 * KT_PYR_T3) {
+        const int ly = tid / KT_PYR_T3, lx = tid - ly * KT_PYR_T3;
+        t3[tid] = kt_pyr_px(t2, KT_PYR_T2, t2x, t2y, c2, r2, t3x + lx, t3y + ly);
+    }
+    __syncthreads();
+    // ---- outputs: depth levels 1..3 of the owned tiles, vertex + normal maps of all levels --------
+    {   // level 0: 32 x 32 pixels, 4 per thread
+        for (int i = tid; i < 32 * 32; i += 256) {
+            const int ly = i >> 5, lx = i & 31;
+            kt_emit_maps(t0, KT_PYR_T0, t0x, t0y, c0, r0, o0x + lx, o0y + ly, a.fx_inv[0], a.fy_inv[0], a.cx[0], a.cy[0], a.vmap[0], a.nmap[0]);
+        }
+    }
+    {   // level 1: 16 x 16
+        const int ly = tid >> 4, lx = tid & 15;
+        const int u = o1x + lx, v = o1y + ly;
+        if (u < c1 && v < r1) a.d[0][v * c1 + u] = (uint16_t)t1[(v - t1y) * KT_PYR_T1 + (u - t1x)];
+        kt_emit_maps(t1, KT_PYR_T1, t1x, t1y, c1, r1, u, v, a.fx_inv[1], a.fy_inv[1], a.cx[1], a.cy[1], a.vmap[1], a.nmap[1]);
+    }
+    if (tid < 64) {  // level 2: 8 x 8
+        const int ly = tid >> 3, lx = tid & 7;
+        const int u = o2x + lx, v = o2y + ly;
+        if (u < c2 && v < r2) a.d[1][v * c2 + u] = (uint16_t)t2[(v - t2y) * KT_PYR_T2 + (u - t2x)];
+        kt_emit_maps(t2, KT_PYR_T2, t2x, t2y, c2, r2, u, v, a.fx_inv[2], a.fy_inv[2], a.cx[2], a.cy[2], a.vmap[2], a.nmap[2]);
+    } else if (tid < 80) {  // level 3: 4 x 4
+        const int q = tid - 64;
+        const int ly = q >> 2, lx = q & 3;
+        const int u = o3x + lx, v = o3y + ly;
+        if (u < c3 && v < r3) a.d[2][v * c3 + u] = (uint16_t)t3[(v - t3y) * KT_PYR_T3 + (u - t3x)];
+        kt_emit_maps(t3, KT_PYR_T3, t3x, t3y, c3, r3, u, v, a.fx_inv[3], a.fy_inv[3], a.cx[3], a.cy[3], a.vmap[3], a.nmap[3]);
+    }
+}
+
+extern "C" int kt_build_pyramid(kt_ctx* c, const kt_intr* intr, const uint16_t* depth0, int cols, int rows, uint16_t* const depths_out[3],
+                                float* const vmaps[4], float* const nmaps[4])
+{
+    KT_ARG(c && intr && depth0 && depths_out && vmaps && nmaps && cols > 0 && rows > 0);
+    KT_ARG((cols % 8) == 0 && (rows % 8) == 0);
+    kt_pyr_args a;
+    a.d0 = depth0;
+    for (int l = 0; l < 3; ++l) { KT_ARG(depths_out[l]); a.d[l] = depths_out[l]; }
+    for (int l = 0; l < 4; ++l) {
+        KT_ARG(vmaps[l] && nmaps[l]);
+        a.vmap[l] = vmaps[l]; a.nmap[l] = nmaps[l];
+        const int div = 1 << l;  // Intr::operator() internal.h:255-259, then createVMap's 1.f / fx (maps.cu:135)
+        const float fx = intr->fx / div, fy = intr->fy / div;
+        a.fx_inv[l] = 1.f / fx; a.fy_inv[l] = 1.f / fy;
+        a.cx[l] = intr->cx / div; a.cy[l] = intr->cy / div;
+    }
+    a.cols = cols; a.rows = rows;
+    const int c3 = cols / 8, r3 = rows / 8;
+    hipLaunchKernelGGL(kt_pyramid_kernel, dim3(kt_div_up(c3, 4), kt_div_up(r3, 4)), dim3(256), 0, c->stream, a);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}

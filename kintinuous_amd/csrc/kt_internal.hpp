@@ -10,7 +10,7 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
 int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const float tcurr[3], float tranc_dist,
                     const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
                     const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,
-                    unsigned long long* steps_dev);
+                    unsigned long long* steps_dev, float* const* vpyr, float* const* npyr);
 int kt_extract_cloud_slice_async(kt_ctx* c, const int16_t* volume, const float volume_size[3], kt_point_xyzrgb* output,
                                  size_t output_capacity, const int voxel_wrap[3], const uint8_t* color_volume, int minX, int maxX,
                                  int minY, int maxY, int minZ, int maxZ, int subsample, const int real_voxel_wrap[3], int N,
@@ -24,3 +24,7 @@ int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, co
 int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corres_img, const float* cloud, float fx, float fy,
                        const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows, int mode,
                        const kt_level_k* next_k);
+
+// optional HIP events recorded around the tsdf23 voxel kernel (set by the tracker when profiling)
+struct kt_event_hook { hipEvent_t ev[2]; bool on; };
+extern thread_local kt_event_hook kt_tsdf23_hook;

@@ -4,92 +4,135 @@
 // without a host round trip.  Reference: src/frontend/cuda/reduce.cu, src/frontend/ICPOdometry.cpp,
 // RGBDOdometry.cpp, OdometryProvider.h.
 //
-// Reduction shape: the 29 float sums are folded in EXACTLY the reference's order (reduce.cu:89-184, 321-339): 64 x 128
-// "virtual threads" each accumulate pixels t, t + 8192, ... sequentially, a 32-lane __shfl_down tree folds each half of
-// a wave64 (one CUDA warp), the 4 warp results of a 128-thread block fold as (s0 + s2) + (s1 + s3), and the 64 block
-// partials fold like reduceSum<<<1, 512>>> does (two 32-lane trees, then s0 + s1).  A, b are therefore bit-identical to
-// the oracle (and, up to nvcc's approximate div/sqrt, to the reference), which keeps whole trajectories and the fused
-// volume bit-comparable.  The price is the reference's modest parallelism (128 waves); the per-thread pixel loop is
-// latency-pipelined instead.  The last block to finish (device-scope ticket, agent-scope release/acquire per
-// cdna_hip_programming.md Guideline 16) produces the final sums and, in the device-resident path, solves and updates
-// the pose on the device.
+// Reduction shape.  The 29 float sums are folded in EXACTLY the reference's order (reduce.cu:89-184, 321-339): 64 x 128
+// "virtual threads" (vt) each accumulate pixels t, t + 8192, ... sequentially, a 32-lane __shfl_down tree folds each CUDA
+// warp, the 4 warp sums of a block fold as (s0 + s2) + (s1 + s3), and the 64 block partials fold like
+// reduceSum<<<1, 512>>> (two 32-lane trees, then s0 + s1).  A, b are therefore bit-identical to the oracle, which keeps
+// whole trajectories and the fused volume bit-comparable.
+// Only the 29 ADD chains per vt are inherently sequential; the per-pixel geometry (~220 VALU ops, two dependent gathers)
+// is not.  So one 1024-thread workgroup per CUDA WARP (256 workgroups = every CU of the MI355X):
+//   phase 1: its 32 vts' pixels are processed one per thread, fully parallel and coalesced (32 consecutive pixels per
+//            k-step); the 7-vector row + inlier flag of every pixel goes to LDS as rows[k][component][vt] (bank-conflict free);
+//   phase 2: thread (c, vt) owns product c of vt and walks k in order: acc += row[a_c] * row[b_c] -- 29 x 32 independent
+//            chains, exactly the reference's per-thread sums;
+//   tree:    lanes are laid out c-major, so each 32-lane half-wave holds one product of the 32 vts = one CUDA warp:
+//            ds_swizzle(xor 16) + DPP row_shl 8/4/2/1 reproduces warpReduceSum;
+//   hand-off: the 29 warp sums are stored write-through (sc1), drained, and a device-scope ticket elects the last
+//            workgroup (cdna_hip_programming.md G16 form R1, no fences); it folds blocks and the final tree with sc1
+//            loads and, in the device-resident path, solves the 6x6 system and updates the pose.
 #include "kt_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // block / grid reduction
 // ------------------------------------------------------------------------------------------------
-#define KT_RED_THREADS 128  // icpStep / rgbStep launch geometry: <<<64, 128>>> (ICPOdometry.cpp:123-124, RGBDOdometry.cpp:306-307)
-#define KT_RED_BLOCKS 64
-#define KT_RED_SLOTS 32     // 29 used
+#define KT_RED_THREADS 1024  // one workgroup per CUDA warp of the reference's <<<64, 128>>> launch (ICPOdometry.cpp:123-124)
+#define KT_RED_BLOCKS 256    // 64 CUDA blocks x 4 warps
+#define KT_VT_TOTAL 8192     // 64 x 128 virtual threads
+#define KT_KBATCH 40         // k-steps staged in LDS per pass: 40 x 8 x 32 floats = 40 KB
+#define KT_RED_SLOTS 32      // 29 used
 
 // warpReduceSum over one CUDA-warp-sized group (32 lanes), reduce.cu:89-129.  Lane 0 of each group ends with
 // ((..(v0 + v16) + (v8 + v24)) ..) exactly as the reference's tree; the other lanes are don't-care.
+// offset 16: ds_swizzle (lane ^ 16 inside each 32-lane half); offsets 8,4,2,1: DPP row_shl inside the 16-lane row.
+template <int CTRL>
+__device__ __forceinline__ float kt_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float kt_warp32_sum(float v)
 {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));  // and 0x1f, or 0, xor 0x10
+    v += kt_dpp<0x108>(v);  // row_shl:8  (lane l reads lane l + 8)
+    v += kt_dpp<0x104>(v);
+    v += kt_dpp<0x102>(v);
+    v += kt_dpp<0x101>(v);
     return v;
 }
 
-// Folds per-thread acc[29] over the 64 x 128 grid in the reference's order.  Returns true (block-uniformly) in the
-// block that retired last; in that block total[0..28] (LDS) holds the grid sums.
-__device__ __forceinline__ bool kt_grid_reduce29(const float (&acc)[29], float* __restrict__ partials, unsigned int* __restrict__ ticket,
-                                                 float (&total)[KT_RED_SLOTS])
+// product c (0..27) of the 7-vector row = row[KT_PA[c]] * row[KT_PB[c]]  (JtJJtrSE3 field order, internal.h:98-149)
+__device__ __constant__ unsigned char KT_PA[28] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6};
+__device__ __constant__ unsigned char KT_PB[28] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 6, 2, 3, 4, 5, 6, 3, 4, 5, 6, 4, 5, 6, 5, 6, 6};
+
+// Phases 2..end of the reduction.  RowFn(i, row[7]) -> found computes one pixel.  Returns true (workgroup-uniformly) in
+// the workgroup that retired last; there total[0..28] (LDS) holds the grid sums.
+template <typename RowFn>
+__device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, float* __restrict__ partials, unsigned int* __restrict__ ticket,
+                                            float (&total)[KT_RED_SLOTS])
 {
-    __shared__ float warp_part[4][KT_RED_SLOTS];
+    __shared__ float rows[KT_KBATCH][8][32];
     __shared__ bool is_last;
-    const int lane32 = threadIdx.x & 31, wid = threadIdx.x >> 5;
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * 32;           // first virtual thread of this CUDA warp
+    const int comp = tid >> 5, vt = tid & 31;  // phase-2 role
+    const int my_a = comp < 28 ? KT_PA[comp] : 7, my_b = comp < 28 ? KT_PB[comp] : 7;
+    // number of pixels of virtual thread t0 + vt: i = t, t + 8192, ... < n
+    const int nk_vt = (n - (t0 + vt) + KT_VT_TOTAL - 1) / KT_VT_TOTAL;
+    const int nk_blk = (n - t0 + KT_VT_TOTAL - 1) / KT_VT_TOTAL;
+    float acc = 0.f;
+    for (int kb = 0; kb < nk_blk; kb += KT_KBATCH) {
+        const int kcount = min(KT_KBATCH, nk_blk - kb);
+        // phase 1: one pixel per thread, 32 consecutive pixels per k
+        for (int p = tid; p < kcount * 32; p += KT_RED_THREADS) {
+            const int kl = p >> 5, v = p & 31;
+            const int i = t0 + v + (kb + kl) * KT_VT_TOTAL;
+            float row[7] = {0, 0, 0, 0, 0, 0, 0};
+            bool found = false;
+            if (i < n) found = fn(i, row);
 #pragma unroll
-    for (int k = 0; k < 29; ++k) {
-        const float s = kt_warp32_sum(acc[k]);
-        if (lane32 == 0) warp_part[wid][k] = s;
+            for (int q = 0; q < 7; ++q) rows[kl][q][v] = row[q];
+            rows[kl][7][v] = found ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        // phase 2: thread (comp, vt) accumulates its product in k order (the reference's per-thread sum.add)
+        if (comp < 29) {
+            const int kend = min(kcount, nk_vt - kb);
+            if (comp < 28) {
+                for (int kl = 0; kl < kend; ++kl) acc += rows[kl][my_a][vt] * rows[kl][my_b][vt];
+            } else {
+                for (int kl = 0; kl < kend; ++kl) acc += rows[kl][7][vt];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x < 29) {
-        // blockReduceSum's second stage (reduce.cu:131-164): lanes 0..3 hold the warp sums, lanes 4..31 zero;
-        // offsets 16, 8, 4 add zeros, offset 2 gives s0+s2 and s1+s3, offset 1 adds them
-        const int k = threadIdx.x;
-        float s0 = warp_part[0][k] + 0.0f, s1 = warp_part[1][k] + 0.0f, s2 = warp_part[2][k] + 0.0f, s3 = warp_part[3][k] + 0.0f;
-        partials[(size_t)blockIdx.x * KT_RED_SLOTS + k] = (s0 + s2) + (s1 + s3);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // publish this block's partials: agent-scope release, drain, then the ticket (device-scope atomic)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // warp tree: the 32 lanes of a half-wave hold product `comp` of the 32 virtual threads of this CUDA warp
+    const float wsum = kt_warp32_sum(acc);
+    if (comp < 29 && vt == 0) {
+        __hip_atomic_store(&partials[comp * KT_RED_BLOCKS + blockIdx.x], wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (tid == 0) {
         const unsigned int t = atomicAdd(ticket, 1u);
         is_last = (t == gridDim.x - 1);
-        if (is_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale lines before re-reading partials
-            *ticket = 0;                                        // re-arm for the next launch on this stream
-        }
+        if (is_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
     }
     __syncthreads();
     if (!is_last) return false;
-    // reduceSum<<<1, 512>>>(sum, out, 64) (reduce.cu:166-184): threads 0..63 hold 0 + in[i]; warps 0 and 1 fold with the
-    // 32-lane tree, every other warp is zero; the final first-warp tree reduces to s0 + s1.
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        for (int k = 0; k < 29; ++k) {
-            float v = 0.0f + partials[(size_t)lane * KT_RED_SLOTS + k];
-            v = kt_warp32_sum(v);
-            const float hi = __shfl(v, 32, 64);
-            if (lane == 0) total[k] = (v + 0.0f) + (hi + 0.0f);
+    // blockReduceSum second stage (reduce.cu:131-164) per CUDA block b: lanes 0..3 hold the warp sums, lanes 4..31 zero;
+    // offsets 16, 8, 4 add zeros, offset 2 gives s0+s2 and s1+s3, offset 1 adds them.  Then reduceSum<<<1, 512>>>
+    // (reduce.cu:166-184): threads 0..63 hold 0 + in[b]; warps 0 and 1 fold with the 32-lane tree, the rest is zero; the
+    // final first-warp tree reduces to s0 + s1.  Wave w handles products w and w + 16; lane = CUDA block b.
+    {
+        const int w = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int c = w + 16 * r;
+            if (c < 29) {
+                const float* pp = &partials[c * KT_RED_BLOCKS + 4 * lane];
+                const float s0 = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 0.0f;
+                const float s1 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 0.0f;
+                const float s2 = __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 0.0f;
+                const float s3 = __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 0.0f;
+                const float blk = (s0 + s2) + (s1 + s3);
+                const float tr = kt_warp32_sum(0.0f + blk);
+                const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tr), 0));
+                const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tr), 32));
+                if (lane == 0) total[c] = (lo + 0.0f) + (hi + 0.0f);
+            }
         }
     }
     __syncthreads();
     return true;
-}
-
-__device__ __forceinline__ void kt_outer29(const float (&row)[7], bool found, float (&acc)[29])
-{
-    // JtJJtrSE3 products, reduce.cu:279-319
-    int s = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i)
-#pragma unroll
-        for (int j = i; j < 7; ++j) acc[s++] += row[i] * row[j];
-    acc[28] += found ? 1.0f : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -110,65 +153,58 @@ struct kt_icp_args {
     int mode;                  // KT_MODE_*
 };
 
-__device__ __forceinline__ void kt_icp_pixel(const kt_icp_args& a, const kt_mat33& Rcurr, const f3 tcurr, const kt_mat33& Rprev_inv,
-                                             const f3 tprev, int i, float (&acc)[29])
-{
-    const int cols = a.cols, rows = a.rows;
-    const int y = i / cols, x = i - y * cols;
-    float row[7] = {0, 0, 0, 0, 0, 0, 0};
-    bool found = false;
-    // search(): reduce.cu:213-254
-    const f3 vcurr = {a.vmap_curr[y * cols + x], a.vmap_curr[(y + rows) * cols + x], a.vmap_curr[(y + 2 * rows) * cols + x]};
-    const f3 vcurr_g = kt_add(kt_mul(Rcurr, vcurr), tcurr);
-    const f3 vcurr_cp = kt_mul(Rprev_inv, kt_sub(vcurr_g, tprev));
-    const int ux = kt_f2i_rn(vcurr_cp.x * a.intr.fx / vcurr_cp.z + a.intr.cx);
-    const int uy = kt_f2i_rn(vcurr_cp.y * a.intr.fy / vcurr_cp.z + a.intr.cy);
-    if (!(ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0)) {
-        const f3 vprev_g = {a.vmap_g_prev[uy * cols + ux], a.vmap_g_prev[(uy + rows) * cols + ux], a.vmap_g_prev[(uy + 2 * rows) * cols + ux]};
-        const f3 ncurr = {a.nmap_curr[y * cols + x], a.nmap_curr[(y + rows) * cols + x], a.nmap_curr[(y + 2 * rows) * cols + x]};
+struct kt_icp_row {
+    const kt_icp_args& a;
+    kt_mat33 Rcurr, Rprev_inv;
+    f3 tcurr, tprev;
+    // search() + getProducts(), reduce.cu:213-277, for pixel i; fills row[7], returns found
+    __device__ __forceinline__ bool operator()(int i, float (&row)[7]) const
+    {
+        const int cols = a.cols, rows = a.rows;
+        const int plane = cols * rows;
+        const f3 vcurr = {a.vmap_curr[i], a.vmap_curr[i + plane], a.vmap_curr[i + 2 * plane]};  // y * cols + x == i
+        const f3 vcurr_g = kt_add(kt_mul(Rcurr, vcurr), tcurr);
+        const f3 vcurr_cp = kt_mul(Rprev_inv, kt_sub(vcurr_g, tprev));
+        const int ux = kt_f2i_rn(vcurr_cp.x * a.intr.fx / vcurr_cp.z + a.intr.cx);
+        const int uy = kt_f2i_rn(vcurr_cp.y * a.intr.fy / vcurr_cp.z + a.intr.cy);
+        if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0) return false;
+        const int g = uy * cols + ux;
+        const f3 vprev_g = {a.vmap_g_prev[g], a.vmap_g_prev[g + plane], a.vmap_g_prev[g + 2 * plane]};
+        const f3 ncurr = {a.nmap_curr[i], a.nmap_curr[i + plane], a.nmap_curr[i + 2 * plane]};
         const f3 ncurr_g = kt_mul(Rcurr, ncurr);
-        const f3 nprev_g = {a.nmap_g_prev[uy * cols + ux], a.nmap_g_prev[(uy + rows) * cols + ux], a.nmap_g_prev[(uy + 2 * rows) * cols + ux]};
+        const f3 nprev_g = {a.nmap_g_prev[g], a.nmap_g_prev[g + plane], a.nmap_g_prev[g + 2 * plane]};
         const f3 dv = kt_sub(vprev_g, vcurr_g);
         const float dist = __builtin_sqrtf(kt_dot(dv, dv));
         const f3 cr = kt_cross(ncurr_g, nprev_g);
         const float sine = __builtin_sqrtf(kt_dot(cr, cr));
-        found = (sine < a.angle_thres && dist <= a.dist_thres && !kt_isnan(ncurr.x) && !kt_isnan(nprev_g.x));
-        if (found) {
-            // getProducts(): reduce.cu:256-277
-            const f3 s_cp = kt_mul(Rprev_inv, kt_sub(vcurr_g, tprev));
-            const f3 d_cp = kt_mul(Rprev_inv, kt_sub(vprev_g, tprev));
-            const f3 n_cp = kt_mul(Rprev_inv, nprev_g);
-            const f3 sxn = kt_cross(s_cp, n_cp);
-            row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
-            row[3] = sxn.x; row[4] = sxn.y; row[5] = sxn.z;
-            row[6] = kt_dot(n_cp, kt_sub(s_cp, d_cp));
-        }
+        const bool found = (sine < a.angle_thres && dist <= a.dist_thres && !kt_isnan(ncurr.x) && !kt_isnan(nprev_g.x));
+        if (!found) return false;
+        const f3 s_cp = kt_mul(Rprev_inv, kt_sub(vcurr_g, tprev));
+        const f3 d_cp = kt_mul(Rprev_inv, kt_sub(vprev_g, tprev));
+        const f3 n_cp = kt_mul(Rprev_inv, nprev_g);
+        const f3 sxn = kt_cross(s_cp, n_cp);
+        row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
+        row[3] = sxn.x; row[4] = sxn.y; row[5] = sxn.z;
+        row[6] = kt_dot(n_cp, kt_sub(s_cp, d_cp));
+        return true;
     }
-    kt_outer29(row, found, acc);
-}
+};
 
 __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_args a)
 {
-    kt_mat33 Rcurr, Rprev_inv;
-    f3 tcurr, tprev;
+    kt_icp_row fn{a};
     if (a.state) {
         // pose produced by the previous iteration's epilogue (kernel boundary orders the accesses)
-        for (int k = 0; k < 9; ++k) { Rcurr.m[k] = a.state->Rcurr[k]; Rprev_inv.m[k] = a.state->Rprev_inv[k]; }
-        tcurr = {a.state->tcurr[0], a.state->tcurr[1], a.state->tcurr[2]};
-        tprev = {a.state->tprev[0], a.state->tprev[1], a.state->tprev[2]};
+        for (int k = 0; k < 9; ++k) { fn.Rcurr.m[k] = a.state->Rcurr[k]; fn.Rprev_inv.m[k] = a.state->Rprev_inv[k]; }
+        fn.tcurr = {a.state->tcurr[0], a.state->tcurr[1], a.state->tcurr[2]};
+        fn.tprev = {a.state->tprev[0], a.state->tprev[1], a.state->tprev[2]};
     } else {
-        Rcurr = a.Rcurr; Rprev_inv = a.Rprev_inv;
-        tcurr = {a.tcurr[0], a.tcurr[1], a.tcurr[2]};
-        tprev = {a.tprev[0], a.tprev[1], a.tprev[2]};
+        fn.Rcurr = a.Rcurr; fn.Rprev_inv = a.Rprev_inv;
+        fn.tcurr = {a.tcurr[0], a.tcurr[1], a.tcurr[2]};
+        fn.tprev = {a.tprev[0], a.tprev[1], a.tprev[2]};
     }
-    float acc[29];
-#pragma unroll
-    for (int k = 0; k < 29; ++k) acc[k] = 0.f;
-    const int n = a.cols * a.rows;
-    for (int i = blockIdx.x * KT_RED_THREADS + threadIdx.x; i < n; i += gridDim.x * KT_RED_THREADS)
-        kt_icp_pixel(a, Rcurr, tcurr, Rprev_inv, tprev, i, acc);
     __shared__ float total[KT_RED_SLOTS];
-    if (!kt_grid_reduce29(acc, a.partials, a.ticket, total)) return;
+    if (!kt_reduce29(fn, a.cols * a.rows, a.partials, a.ticket, total)) return;
     if (a.mode == KT_MODE_HOST) {
         if (threadIdx.x < 29) a.out29[threadIdx.x] = total[threadIdx.x];
     } else if (threadIdx.x == 0) {
@@ -176,7 +212,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
         for (int k = 0; k < 29; ++k) h[k] = total[k];
         if (a.mode == KT_MODE_ICP_SOLVE) {
             // ICPOdometry.cpp:127-178
-            __shared__ double dA[36], db[6];
+            double dA[36], db[6];
             kt_unpack29_d(h, dA, db);
             a.state->last_residual[0] = h[27];
             a.state->last_residual[1] = h[28];
@@ -402,51 +438,52 @@ struct kt_rgb_args {
     kt_level_k next_k;     // intrinsics of the level the NEXT iteration runs at (for K R K^-1, K t)
 };
 
-__global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_args a)
-{
-    const float sigma = a.state ? a.state->sigma_val : a.sigma;
-    const float flt_eps = 1.19209290E-07F;
-    float acc[29];
-#pragma unroll
-    for (int k = 0; k < 29; ++k) acc[k] = 0.f;
-    const int n = a.cols * a.rows, cols = a.cols;
-    for (int i = blockIdx.x * KT_RED_THREADS + threadIdx.x; i < n; i += gridDim.x * KT_RED_THREADS) {
+struct kt_rgb_row {
+    const kt_rgb_args& a;
+    float sigma;
+    // RGBReduction::getProducts, reduce.cu:441-486
+    __device__ __forceinline__ bool operator()(int i, float (&row)[7]) const
+    {
+        const float flt_eps = 1.19209290E-07F;
         const int4 raw = *(const int4*)&a.corres[i];
         const kt_dataterm c = *(const kt_dataterm*)&raw;
-        float row[7] = {0, 0, 0, 0, 0, 0, 0};
-        const bool found = c.valid != 0;
-        if (found) {
-            float w = sigma + fabsf(c.diff);
-            w = w > flt_eps ? 1.0f / w : 1.0f;
-            if (sigma == -1) w = 1;
-            row[6] = -w * c.diff;
-            const float* cp = &a.cloud[3 * (c.zero_y * cols + c.zero_x)];
-            const float X = cp[0], Y = cp[1], Z = cp[2];
-            const float invz = (float)(1.0 / (double)Z);
-            const float dI_dx_val = w * a.sobel_scale * (float)a.dIdx[c.one_y * cols + c.one_x];
-            const float dI_dy_val = w * a.sobel_scale * (float)a.dIdy[c.one_y * cols + c.one_x];
-            const float v0 = dI_dx_val * a.fx * invz;
-            const float v1 = dI_dy_val * a.fy * invz;
-            const float v2 = -__builtin_fmaf(v0, X, v1 * Y) * invz;
-            row[0] = v0; row[1] = v1; row[2] = v2;
-            row[3] = __builtin_fmaf(-Z, v1, Y * v2);
-            row[4] = __builtin_fmaf(Z, v0, -(X * v2));
-            row[5] = __builtin_fmaf(-Y, v0, X * v1);
-        }
-        kt_outer29(row, found, acc);
+        if (c.valid == 0) return false;
+        const int cols = a.cols;
+        float w = sigma + fabsf(c.diff);
+        w = w > flt_eps ? 1.0f / w : 1.0f;
+        if (sigma == -1) w = 1;
+        row[6] = -w * c.diff;
+        const float* cp = &a.cloud[3 * (c.zero_y * cols + c.zero_x)];
+        const float X = cp[0], Y = cp[1], Z = cp[2];
+        const float invz = (float)(1.0 / (double)Z);
+        const float dI_dx_val = w * a.sobel_scale * (float)a.dIdx[c.one_y * cols + c.one_x];
+        const float dI_dy_val = w * a.sobel_scale * (float)a.dIdy[c.one_y * cols + c.one_x];
+        const float v0 = dI_dx_val * a.fx * invz;
+        const float v1 = dI_dy_val * a.fy * invz;
+        const float v2 = -__builtin_fmaf(v0, X, v1 * Y) * invz;
+        row[0] = v0; row[1] = v1; row[2] = v2;
+        row[3] = __builtin_fmaf(-Z, v1, Y * v2);
+        row[4] = __builtin_fmaf(Z, v0, -(X * v2));
+        row[5] = __builtin_fmaf(-Y, v0, X * v1);
+        return true;
     }
+};
+
+__global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_args a)
+{
+    const kt_rgb_row fn{a, a.state ? a.state->sigma_val : a.sigma};
     __shared__ float total[KT_RED_SLOTS];
-    if (!kt_grid_reduce29(acc, a.partials, a.ticket, total)) return;
+    if (!kt_reduce29(fn, a.cols * a.rows, a.partials, a.ticket, total)) return;
     if (a.mode == KT_MODE_HOST) {
         if (threadIdx.x < 29) a.out29[threadIdx.x] = total[threadIdx.x];
     } else if (threadIdx.x == 0) {
         float h[29];
         for (int k = 0; k < 29; ++k) h[k] = total[k];
-        __shared__ double dA[36], db[6];
+        double dA[36], db[6];
         kt_unpack29_d(h, dA, db);
         if (a.mode == KT_MODE_JOINT_SOLVE) {
             // RGBDOdometry.cpp:316-321: A = A_rgbd + w*w*A_icp, b = b_rgbd + w*b_icp, w = 10
-            __shared__ double iA[36], ib[6];
+            double iA[36], ib[6];
             kt_unpack29_d(a.state->icp29, iA, ib);
             const double w = 10;
             for (int k = 0; k < 36; ++k) dA[k] = dA[k] + w * w * iA[k];

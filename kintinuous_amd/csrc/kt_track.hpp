@@ -183,12 +183,97 @@ KT_HD void kt_compute_krk(const double* resultRt, const kt_level_k k, float* krk
 }
 
 #ifdef __HIPCC__
-// executed by ONE thread in the epilogue of the last block; A, b live in LDS-backed arrays
-__device__ inline void kt_solve_and_update(kt_track_state* st, double* dA, const double* db)
+// Register-resident variant of kt_ldlt_solve6 for the kernel epilogues: identical operations in identical order, but
+// every array index is a compile-time constant (template-unrolled steps, pivot swaps as a chain of `if (p == c)`
+// with static indices), so the 6x6 system lives in VGPRs instead of scratch / LDS.
+template <int K>
+__device__ __forceinline__ void kt_ldlt_step(double (&A)[36], int (&tr)[6])
+{
+    int p = K;
+    double big = fabs(A[K * 6 + K]);
+#pragma unroll
+    for (int i = K + 1; i < 6; ++i) {
+        const double v = fabs(A[i * 6 + i]);
+        if (v > big) { big = v; p = i; }
+    }
+    tr[K] = p;
+#pragma unroll
+    for (int c = K + 1; c < 6; ++c)
+        if (p == c) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { const double t = A[K * 6 + j]; A[K * 6 + j] = A[c * 6 + j]; A[c * 6 + j] = t; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { const double t = A[i * 6 + K]; A[i * 6 + K] = A[i * 6 + c]; A[i * 6 + c] = t; }
+        }
+    double d = A[K * 6 + K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) d -= A[K * 6 + j] * A[K * 6 + j] * A[j * 6 + j];
+    A[K * 6 + K] = d;
+#pragma unroll
+    for (int i = K + 1; i < 6; ++i) {
+        double s = A[i * 6 + K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) s -= A[i * 6 + j] * A[K * 6 + j] * A[j * 6 + j];
+        A[i * 6 + K] = (d != 0.0) ? s / d : s;
+    }
+}
+
+__device__ __forceinline__ void kt_ldlt_solve6_reg(double (&A)[36], const double (&bin)[6], double (&x)[6])
+{
+    int tr[6];
+    kt_ldlt_step<0>(A, tr); kt_ldlt_step<1>(A, tr); kt_ldlt_step<2>(A, tr);
+    kt_ldlt_step<3>(A, tr); kt_ldlt_step<4>(A, tr); kt_ldlt_step<5>(A, tr);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = bin[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int c = k + 1; c < 6; ++c)
+            if (tr[k] == c) { const double t = x[k]; x[k] = x[c]; x[c] = t; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) x[i] -= A[i * 6 + j] * x[j];
+    double maxd = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (fabs(A[i * 6 + i]) > maxd) maxd = fabs(A[i * 6 + i]);
+    double tol = maxd * DBL_EPSILON;
+    if (tol < 1.0 / DBL_MAX) tol = 1.0 / DBL_MAX;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = (fabs(A[i * 6 + i]) > tol) ? x[i] / A[i * 6 + i] : 0.0;
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) x[i] -= A[j * 6 + i] * x[j];
+#pragma unroll
+    for (int k = 5; k >= 0; --k)
+#pragma unroll
+        for (int c = k + 1; c < 6; ++c)
+            if (tr[k] == c) { const double t = x[k]; x[k] = x[c]; x[c] = t; }
+}
+
+// executed by ONE thread in the epilogue of the last block
+__device__ __forceinline__ void kt_solve_and_update(kt_track_state* st, double (&dA)[36], const double (&db)[6])
 {
     double x[6];
-    kt_ldlt_solve6(dA, db, x);
-    kt_pose_update(x, st->resultRt, st->Rprev, st->tprev, st->Rcurr, st->tcurr);
+    kt_ldlt_solve6_reg(dA, db, x);
+    // local copies keep the pose update in registers; the state is written once at the end
+    double resultRt[16];
+    float Rprev[9], tprev[3], Rcurr[9], tcurr[3];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) resultRt[k] = st->resultRt[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rprev[k] = st->Rprev[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tprev[k] = st->tprev[k];
+    kt_pose_update(x, resultRt, Rprev, tprev, Rcurr, tcurr);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st->resultRt[k] = resultRt[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) st->Rcurr[k] = Rcurr[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st->tcurr[k] = tcurr[k];
 }
-__device__ inline void kt_update_krk(kt_track_state* st, const kt_level_k k) { kt_compute_krk(st->resultRt, k, st->krkinv, st->kt); }
+__device__ __forceinline__ void kt_update_krk(kt_track_state* st, const kt_level_k k) { kt_compute_krk(st->resultRt, k, st->krkinv, st->kt); }
 #endif

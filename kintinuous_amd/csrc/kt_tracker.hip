@@ -133,6 +133,13 @@ static int ev_end(kt_tracker* t, int st)
     }
     return KT_OK;
 }
+static void tsdf23_hook_arm(kt_tracker* t)
+{
+    kt_tsdf23_hook.on = t->profiling >= 1;
+    kt_tsdf23_hook.ev[0] = t->ev[ST_TSDF23][0];
+    kt_tsdf23_hook.ev[1] = t->ev[ST_TSDF23][1];
+    if (kt_tsdf23_hook.on) t->ev_rec[ST_TSDF23] = true;
+}
 // call only right after a stream synchronisation: every recorded pair is complete
 static void ev_collect(kt_tracker* t)
 {
@@ -285,6 +292,7 @@ static int odometry_begin(kt_tracker* t, const kt_level_k* first_k)
 
 static int odometry_end(kt_tracker* t, float* Rcurr, float* tcurr)
 {
+    KT_TRY(ev_end(t, ST_ODOMETRY));
     KT_HIP(hipMemcpyAsync(t->state_host, t->state_dev, sizeof(kt_track_state), hipMemcpyDeviceToHost, t->ctx->stream));
     KT_HIP(hipStreamSynchronize(t->ctx->stream));  // the ONE host sync of the frame
     ev_collect(t);
@@ -432,12 +440,8 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
     KT_TRY(ev_begin(t, ST_PYRAMID));
     if (icp || t->cfg.use_rgbd_icp || !t->cfg.disable_color_angle) {
         KT_TRY(kt_bilateral_filter(c, depth_raw, t->depths_curr[0], cols, rows));
-        for (int l = 1; l < KT_LEVELS; ++l) KT_TRY(kt_pyr_down(c, t->depths_curr[l - 1], lvl_cols(t, l - 1), lvl_rows(t, l - 1), t->depths_curr[l]));
-        for (int l = 0; l < KT_LEVELS; ++l) {
-            const kt_intr li = lvl_intr(t->intr, l);
-            KT_TRY(kt_create_vmap(c, &li, t->depths_curr[l], lvl_cols(t, l), lvl_rows(t, l), t->vmaps_curr[l]));
-            KT_TRY(kt_create_nmap(c, t->vmaps_curr[l], lvl_cols(t, l), lvl_rows(t, l), t->nmaps_curr[l]));
-        }
+        uint16_t* dl[3] = {t->depths_curr[1], t->depths_curr[2], t->depths_curr[3]};
+        KT_TRY(kt_build_pyramid(c, &t->intr, t->depths_curr[0], cols, rows, dl, t->vmaps_curr, t->nmaps_curr));
     }
     KT_TRY(ev_end(t, ST_PYRAMID));
 
@@ -449,6 +453,7 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
         if (rgbd) KT_TRY(populate_rgbd(t, depth_raw, colors, t->last_depth, t->last_image));  // firstRun
         if (t->counting) KT_HIP(hipMemsetAsync(t->upd_dev, 0, sizeof(unsigned int), c->stream));
         KT_TRY(ev_begin(t, ST_INTEGRATE));
+        tsdf23_hook_arm(t);
         KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rcam_inv, t->tlast, t->tranc_dist, t->tsdf,
                                       t->depth_raw_scaled, empty, t->color, colors, t->nmaps_curr[0], angle_color, N,
                                       t->counting ? t->upd_dev : nullptr));
@@ -473,8 +478,6 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
     KT_TRY(ev_begin(t, ST_ODOMETRY));
     if (icp) KT_TRY(icp_odometry(t, tcurr, Rcurr));
     else KT_TRY(rgbd_odometry(t, depth_raw, colors, tcurr, Rcurr));
-    // (the odometry end event is recorded after the readback; it is harmless that it trails the sync)
-    KT_TRY(ev_end(t, ST_ODOMETRY));
 
     // [D] rmats_/tvecs_ push, currentGlobalCamera :574-595
     memcpy(t->Rlast, Rcurr, sizeof(Rcurr));
@@ -533,6 +536,7 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
         KT_HIP(hipMemsetAsync(t->steps_dev, 0, sizeof(unsigned long long), c->stream));
     }
     KT_TRY(ev_begin(t, ST_INTEGRATE));
+    tsdf23_hook_arm(t);
     KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rc_inv, tcurr, t->tranc_dist, t->tsdf,
                                   t->depth_raw_scaled, t->v_wrap_copy, t->color, colors, t->nmaps_curr[0], angle_color, N,
                                   t->counting ? t->upd_dev : nullptr));
@@ -540,17 +544,14 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
     v_wrap_copy_update(t);
     // [I] raycast :880-890
     KT_TRY(ev_begin(t, ST_RAYCAST));
+    // [I] + [J]: raycast :880-890 with the predicted-map pyramid (resizeVMap / resizeNMap, :892-899) fused into its epilogue
+    const bool pyr = icp || t->cfg.use_rgbd_icp;
+    float* vp[3] = {t->vmaps_g_prev[1], t->vmaps_g_prev[2], t->vmaps_g_prev[3]};
+    float* np_[3] = {t->nmaps_g_prev[1], t->nmaps_g_prev[2], t->nmaps_g_prev[3]};
     KT_TRY(kt_raycast_impl(c, &t->intr, &Rc, tcurr, t->tranc_dist, t->volume_size, t->tsdf, t->vmaps_g_prev[0], t->nmaps_g_prev[0], cols, rows,
-                           t->v_wrap_copy, t->vmap_curr_color, t->color, N, t->counting ? t->steps_dev : nullptr));
+                           t->v_wrap_copy, t->vmap_curr_color, t->color, N, t->counting ? t->steps_dev : nullptr, pyr ? vp : nullptr,
+                           pyr ? np_ : nullptr));
     KT_TRY(ev_end(t, ST_RAYCAST));
-    // [J] predicted-map pyramid :892-899
-    KT_TRY(ev_begin(t, ST_RESIZE));
-    if (icp || t->cfg.use_rgbd_icp)
-        for (int l = 1; l < KT_LEVELS; ++l) {
-            KT_TRY(kt_resize_vmap(c, t->vmaps_g_prev[l - 1], lvl_cols(t, l - 1), lvl_rows(t, l - 1), t->vmaps_g_prev[l]));
-            KT_TRY(kt_resize_nmap(c, t->nmaps_g_prev[l - 1], lvl_cols(t, l - 1), lvl_rows(t, l - 1), t->nmaps_g_prev[l]));
-        }
-    KT_TRY(ev_end(t, ST_RESIZE));
     ++t->global_time;
     push_pose(t, timestamp, Rcurr, 0);  // [K] :903-909
     if (t->counting) {

@@ -7,7 +7,9 @@
 // HBM layout: tsdf = int16[N^3] (x fastest), colour+weight = uchar4[N^3]; storage index is the logical
 // index rotated by voxel_wrap (tsdf_volume.cu:612).  Kernels are laid out so that the 64 lanes of a
 // wave own 64 consecutive STORAGE x of one (y, z) line: 128 B of tsdf + 256 B of colour per access.
-#include "kt_common.hpp"
+#include "kt_internal.hpp"
+
+thread_local kt_event_hook kt_tsdf23_hook = {{nullptr, nullptr}, false};
 
 // ================================================================================================
 // init  (initVolume / initColorVolume, tsdf_volume.cu:56-87, 450-479): pack_tsdf(0) == 0, uchar4(0)
@@ -47,20 +49,8 @@ struct kt_integrate_tables {  // incremental z walk of tsdf23 (quirk A.17), iden
 __global__ __launch_bounds__(256) void kt_scale_depth_kernel(const uint16_t* __restrict__ depth, float* __restrict__ scaled,
                                                              kt_pixrec* __restrict__ rec, const uint8_t* __restrict__ colors,
                                                              const float* __restrict__ nmap, int cols, int rows, kt_intr intr,
-                                                             int angle_color, float* __restrict__ vgz, float* __restrict__ zs,
-                                                             int N, float cell_z, float tz)
+                                                             int angle_color)
 {
-    // one thread of block 0 also produces the z-walk tables (a serial chain of N float adds)
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0 && vgz) {
-        float v_g_z = __builtin_fmaf(0 + 0.5f, cell_z, -tz);
-        float z_scaled = 0;
-        for (int z = 0; z < N; ++z) {
-            vgz[z] = v_g_z;
-            zs[z] = z_scaled;
-            v_g_z += cell_z;
-            z_scaled += cell_z;
-        }
-    }
     int x = threadIdx.x + blockIdx.x * blockDim.x;
     int y = threadIdx.y + blockIdx.y * blockDim.y;
     if (x >= cols || y >= rows) return;
@@ -122,6 +112,13 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
     else if (alpha < 0) { lo = 1e30f; hi = -1e30f; }
 }
 
+// z-chunk per wave: the z range of a column is split over blockIdx.z so that enough waves are in flight to cover
+// HBM latency (only ~30% of the columns and ~40% of their z range lie inside the frustum).  Each chunk replays the
+// incremental float walk of v_x / v_y from z = 0 (quirk A.17: the values are defined by repeated +=), which is pure
+// ALU, then runs the reference loop body on its slice, 4 z-steps at a time with the loads of the 4 steps batched.
+#define KT_TSDF_ZCHUNK 32
+#define KT_TSDF_UNROLL 4
+
 template <bool COUNT>
 __global__ __launch_bounds__(256) void kt_tsdf23_kernel(const kt_tsdf23_args a)
 {
@@ -129,102 +126,144 @@ __global__ __launch_bounds__(256) void kt_tsdf23_kernel(const kt_tsdf23_args a)
     // storage coordinates of this column; logical = storage - wrap (mod N)
     const int sx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (sx >= N || sy >= N) return;
+    const bool col_ok = sx < N && sy < N;
     int x = sx - a.wx; if (x < 0) x += N;
     int y = sy - a.wy; if (y < 0) y += N;
 
     const float* Ri = a.Ri.m;
-    float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
-    float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
-    float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
-    float v_g_part_norm = __builtin_fmaf(v_g_x, v_g_x, v_g_y * v_g_y);
+    const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
+    const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
+    const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
+    const float v_g_part_norm = __builtin_fmaf(v_g_x, v_g_x, v_g_y * v_g_y);
     float v_x = __builtin_fmaf(Ri[2], v_g_z0, __builtin_fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * a.intr.fx;
     float v_y = __builtin_fmaf(Ri[5], v_g_z0, __builtin_fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * a.intr.fy;
-    float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
+    const float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
     const float Rcurr_inv_0_z_scaled = Ri[2] * a.cell_z * a.intr.fx;
     const float Rcurr_inv_1_z_scaled = Ri[5] * a.cell_z * a.intr.fy;
     const float tranc_dist_inv = 1.0f / a.tranc_dist;
 
-    // ---- conservative z interval -------------------------------------------------------------
+    // ---- conservative z interval (see kt_clip_halfline) ----------------------------------------
     int z0, z1;
     {
-        // camera coordinates (unscaled) at z index 0 and the per-index step
-        float ax = Ri[0] * v_g_x + Ri[1] * v_g_y + Ri[2] * v_g_z0;
-        float ay = Ri[3] * v_g_x + Ri[4] * v_g_y + Ri[5] * v_g_z0;
-        float az = Ri[6] * v_g_x + Ri[7] * v_g_y + Ri[8] * v_g_z0;
-        float bx = Ri[2] * a.cell_z, by = Ri[5] * a.cell_z, bz = Ri[8] * a.cell_z;
-        const float m = 8.0f;         // pixel margin
-        const float znear = 0.05f;    // below this depth the pixel bounds are not trusted
-        float lo = 0.0f, hi = (float)(N - 1);
-        // frustum part: p_z >= znear and the four image sides padded by m pixels
-        float flo = lo, fhi = hi;
+        const float ax = Ri[0] * v_g_x + Ri[1] * v_g_y + Ri[2] * v_g_z0;
+        const float ay = Ri[3] * v_g_x + Ri[4] * v_g_y + Ri[5] * v_g_z0;
+        const float az = Ri[6] * v_g_x + Ri[7] * v_g_y + Ri[8] * v_g_z0;
+        const float bx = Ri[2] * a.cell_z, by = Ri[5] * a.cell_z, bz = Ri[8] * a.cell_z;
+        const float m = 8.0f;       // pixel margin
+        const float znear = 0.05f;  // below this depth the pixel bounds are not trusted
+        const float lo = 0.0f, hi = (float)(N - 1);
+        float flo = lo, fhi = hi;   // frustum part: p_z >= znear and the four image sides padded by m pixels
         kt_clip_halfline(az - znear, bz, flo, fhi);
-        float ul = -0.5f - m - a.intr.cx, uh = (float)a.cols - 0.5f + m - a.intr.cx;
-        float vl = -0.5f - m - a.intr.cy, vh = (float)a.rows - 0.5f + m - a.intr.cy;
+        const float ul = -0.5f - m - a.intr.cx, uh = (float)a.cols - 0.5f + m - a.intr.cx;
+        const float vl = -0.5f - m - a.intr.cy, vh = (float)a.rows - 0.5f + m - a.intr.cy;
         kt_clip_halfline(a.intr.fx * ax - ul * az, a.intr.fx * bx - ul * bz, flo, fhi);
         kt_clip_halfline(uh * az - a.intr.fx * ax, uh * bz - a.intr.fx * bx, flo, fhi);
         kt_clip_halfline(a.intr.fy * ay - vl * az, a.intr.fy * by - vl * bz, flo, fhi);
         kt_clip_halfline(vh * az - a.intr.fy * ay, vh * bz - a.intr.fy * by, flo, fhi);
-        // near slab: -cell <= p_z <= znear, kept unconditionally (pixel coordinates ill-conditioned there)
-        float nlo = lo, nhi = hi;
+        float nlo = lo, nhi = hi;   // near slab: -cell <= p_z <= znear, kept unconditionally
         kt_clip_halfline(az + a.cell_z + a.cell_x + a.cell_y, bz, nlo, nhi);
         kt_clip_halfline(znear - az, -bz, nlo, nhi);
         float l = 1e30f, h = -1e30f;
         if (flo <= fhi) { l = fminf(l, flo); h = fmaxf(h, fhi); }
         if (nlo <= nhi) { l = fminf(l, nlo); h = fmaxf(h, nhi); }
-        if (l > h) return;
-        z0 = max(0, (int)floorf(l) - 2);
-        z1 = min(N, (int)ceilf(h) + 3);
-        if (z0 >= z1) return;
+        if (l > h || !col_ok) { z0 = N; z1 = 0; }
+        else {
+            z0 = max(0, (int)floorf(l) - 2);
+            z1 = min(N, (int)ceilf(h) + 3);
+        }
     }
+    z0 = max(z0, (int)blockIdx.z * KT_TSDF_ZCHUNK);
+    z1 = min(z1, (int)(blockIdx.z + 1) * KT_TSDF_ZCHUNK);
+    if (z0 >= z1) { z0 = N; z1 = 0; }  // this lane has nothing to do in this chunk
+    // All 64 lanes of the wave walk the SAME z sequence (their union interval) with a per-lane predicate, so that every
+    // volume access of the wave is one contiguous 128 B (tsdf) / 256 B (colour) line segment of a single z plane.
+    int wz0 = z0, wz1 = z1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        wz0 = min(wz0, __shfl_xor(wz0, off, 64));
+        wz1 = max(wz1, __shfl_xor(wz1, off, 64));
+    }
+    wz0 = __builtin_amdgcn_readfirstlane(wz0);
+    wz1 = __builtin_amdgcn_readfirstlane(wz1);
+    if (wz0 >= wz1) return;
 
-    // ---- replay the incremental walk up to z0 (quirk A.17: values are built by repeated +=) ----
-    for (int z = 0; z < z0; ++z) {
+    // ---- replay the incremental walk up to the wave's first z -----------------------------------
+    for (int z = 0; z < wz0; ++z) {
         v_x += Rcurr_inv_0_z_scaled;
         v_y += Rcurr_inv_1_z_scaled;
     }
 
     const size_t plane = (size_t)N * N;
     const size_t col_base = (size_t)sx + (size_t)sy * N;
-    int sz = z0 + a.wz; if (sz >= N) sz -= N;
     unsigned int n_upd = 0;
 
-    for (int z = z0; z < z1; ++z, v_x += Rcurr_inv_0_z_scaled, v_y += Rcurr_inv_1_z_scaled, sz = (sz + 1 == N) ? 0 : sz + 1) {
-        const float v_g_z = a.vgz[z];
-        const float z_scaled = a.zs[z];
-        float inv_z = 1.0f / __builtin_fmaf(Ri[8], z_scaled, v_z);
-        if (inv_z < 0) continue;
-        int coo_x = kt_f2i_rn(__builtin_fmaf(v_x, inv_z, a.intr.cx));
-        int coo_y = kt_f2i_rn(__builtin_fmaf(v_y, inv_z, a.intr.cy));
-        if (coo_x >= 0 && coo_y >= 0 && coo_x < a.cols && coo_y < a.rows) {
-            const kt_pixrec r = a.rec[coo_y * a.cols + coo_x];
-            float Dp_scaled = r.dp;
-            bool no_color = false;
-            if (Dp_scaled < 0.0f) { Dp_scaled = -Dp_scaled; no_color = true; }
-            float sdf = Dp_scaled - __builtin_sqrtf(__builtin_fmaf(v_g_z, v_g_z, v_g_part_norm));
-            if (Dp_scaled != 0 && sdf >= -a.tranc_dist) {
-                float tsdf = fminf(1.0f, sdf * tranc_dist_inv);
-                const size_t idx = col_base + (size_t)sz * plane;
-                float tsdf_prev = kt_unpack_tsdf(a.volume[idx]);
-                uchar4 c = a.color[idx];
-                float weight_prev = (float)c.w;
-                a.volume[idx] = kt_pack_tsdf(__builtin_fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
-                uchar4 o = c;
-                o.w = kt_f2u8_rz(fminf(weight_prev + 1.0f, KT_MAX_WEIGHT));
-                if (COUNT) ++n_upd;
-                const bool normal_nan = (r.rgbf >> 24) & 1u;
-                if ((!normal_nan && !no_color) || (c.x == 0 && c.y == 0 && c.z == 0)) {
-                    const float Wrkc = r.wrkc;
-                    const float den = weight_prev + Wrkc;
-                    float new_x = __builtin_fmaf((float)c.x, weight_prev, Wrkc * (float)(r.rgbf & 0xffu)) / den;
-                    float new_y = __builtin_fmaf((float)c.y, weight_prev, Wrkc * (float)((r.rgbf >> 8) & 0xffu)) / den;
-                    float new_z = __builtin_fmaf((float)c.z, weight_prev, Wrkc * (float)((r.rgbf >> 16) & 0xffu)) / den;
-                    o.x = (unsigned char)min(255, max(0, kt_f2i_rn(new_x)));
-                    o.y = (unsigned char)min(255, max(0, kt_f2i_rn(new_y)));
-                    o.z = (unsigned char)min(255, max(0, kt_f2i_rn(new_z)));
-                }
-                a.color[idx] = o;
+    for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
+        bool in_img[KT_TSDF_UNROLL];
+        int pix[KT_TSDF_UNROLL];
+        float vgz[KT_TSDF_UNROLL];
+        // phase 1: projection of the 4 voxels (walk advances on every step, also on skipped ones)
+#pragma unroll
+        for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
+            const int z = zb + u;
+            const bool live = z >= z0 && z < z1;
+            const int zz = min(z, N - 1);  // wave-uniform index: scalar loads
+            vgz[u] = a.vgz[zz];
+            const float z_scaled = a.zs[zz];
+            const float inv_z = 1.0f / __builtin_fmaf(Ri[8], z_scaled, v_z);
+            const int coo_x = kt_f2i_rn(__builtin_fmaf(v_x, inv_z, a.intr.cx));
+            const int coo_y = kt_f2i_rn(__builtin_fmaf(v_y, inv_z, a.intr.cy));
+            in_img[u] = live && !(inv_z < 0) && coo_x >= 0 && coo_y >= 0 && coo_x < a.cols && coo_y < a.rows;
+            pix[u] = in_img[u] ? coo_y * a.cols + coo_x : 0;
+            v_x += Rcurr_inv_0_z_scaled;
+            v_y += Rcurr_inv_1_z_scaled;
+        }
+        // phase 2: the per-pixel records (one 16-byte gather each)
+        kt_pixrec rec[KT_TSDF_UNROLL];
+#pragma unroll
+        for (int u = 0; u < KT_TSDF_UNROLL; ++u) rec[u] = a.rec[pix[u]];
+        // phase 3: sdf test, then the voxel loads
+        bool upd[KT_TSDF_UNROLL], no_color[KT_TSDF_UNROLL];
+        float sdf[KT_TSDF_UNROLL];
+        size_t idx[KT_TSDF_UNROLL];
+        short tsdf_raw[KT_TSDF_UNROLL];
+        uchar4 col[KT_TSDF_UNROLL];
+#pragma unroll
+        for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
+            float Dp_scaled = rec[u].dp;
+            no_color[u] = false;
+            if (Dp_scaled < 0.0f) { Dp_scaled = -Dp_scaled; no_color[u] = true; }
+            sdf[u] = Dp_scaled - __builtin_sqrtf(__builtin_fmaf(vgz[u], vgz[u], v_g_part_norm));
+            upd[u] = in_img[u] && Dp_scaled != 0 && sdf[u] >= -a.tranc_dist;
+            int sz = zb + u + a.wz; if (sz >= N) sz -= N;
+            idx[u] = col_base + (size_t)sz * plane;
+        }
+#pragma unroll
+        for (int u = 0; u < KT_TSDF_UNROLL; ++u)
+            if (upd[u]) { tsdf_raw[u] = a.volume[idx[u]]; col[u] = a.color[idx[u]]; }
+        // phase 4: update + store
+#pragma unroll
+        for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
+            if (!upd[u]) continue;
+            const float tsdf = fminf(1.0f, sdf[u] * tranc_dist_inv);
+            const float tsdf_prev = kt_unpack_tsdf(tsdf_raw[u]);
+            const uchar4 c = col[u];
+            const float weight_prev = (float)c.w;
+            a.volume[idx[u]] = kt_pack_tsdf(__builtin_fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
+            uchar4 o = c;
+            o.w = kt_f2u8_rz(fminf(weight_prev + 1.0f, KT_MAX_WEIGHT));
+            if (COUNT) ++n_upd;
+            const bool normal_nan = (rec[u].rgbf >> 24) & 1u;
+            if ((!normal_nan && !no_color[u]) || (c.x == 0 && c.y == 0 && c.z == 0)) {
+                const float Wrkc = rec[u].wrkc;
+                const float den = weight_prev + Wrkc;
+                const float new_x = __builtin_fmaf((float)c.x, weight_prev, Wrkc * (float)(rec[u].rgbf & 0xffu)) / den;
+                const float new_y = __builtin_fmaf((float)c.y, weight_prev, Wrkc * (float)((rec[u].rgbf >> 8) & 0xffu)) / den;
+                const float new_z = __builtin_fmaf((float)c.z, weight_prev, Wrkc * (float)((rec[u].rgbf >> 16) & 0xffu)) / den;
+                o.x = (unsigned char)min(255, max(0, kt_f2i_rn(new_x)));
+                o.y = (unsigned char)min(255, max(0, kt_f2i_rn(new_y)));
+                o.z = (unsigned char)min(255, max(0, kt_f2i_rn(new_z)));
             }
+            a.color[idx[u]] = o;
         }
     }
     if (COUNT) {
@@ -238,6 +277,8 @@ __global__ __launch_bounds__(256) void kt_tsdf23_kernel(const kt_tsdf23_args a)
 struct kt_integrate_scratch {
     kt_pixrec* rec = nullptr; size_t rec_px = 0;
     float* vgz = nullptr; float* zs = nullptr; int tabN = 0;
+    float* tab_host[2] = {nullptr, nullptr};  // pinned staging of {vgz[N], zs[N]}, double-buffered
+    int flip = 0;
 };
 static thread_local kt_integrate_scratch g_scratch;  // one GPU thread per context (SURVEY 8b threading)
 
@@ -251,11 +292,15 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
         s.rec_px = px;
     }
     if (s.tabN < N) {
+        KT_HIP(hipStreamSynchronize(c->stream));
         if (s.vgz) KT_HIP(hipFree(s.vgz));
-        if (s.zs) KT_HIP(hipFree(s.zs));
         s.vgz = s.zs = nullptr; s.tabN = 0;
-        KT_HIP(hipMalloc((void**)&s.vgz, sizeof(float) * N));
-        KT_HIP(hipMalloc((void**)&s.zs, sizeof(float) * N));
+        KT_HIP(hipMalloc((void**)&s.vgz, sizeof(float) * 2 * N));
+        s.zs = s.vgz + N;
+        for (int k = 0; k < 2; ++k) {
+            if (s.tab_host[k]) KT_HIP(hipHostFree(s.tab_host[k]));
+            KT_HIP(hipHostMalloc((void**)&s.tab_host[k], sizeof(float) * 2 * N, hipHostMallocDefault));
+        }
         s.tabN = N;
     }
     return KT_OK;
@@ -272,9 +317,26 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     int s = kt_integrate_scratch_reserve(c, (size_t)cols * rows, N);
     if (s != KT_OK) return s;
     const float cell_x = volume_size[0] / N, cell_y = volume_size[1] / N, cell_z = volume_size[2] / N;
+    // the incremental z walk of tsdf23 (quirk A.17) is the same float sequence for every column: build it once on the
+    // host (plain IEEE float adds, this file is compiled with -ffp-contract=off) and ship 2 * N floats with the frame
+    {
+        kt_integrate_scratch& sc = g_scratch;
+        float* th = sc.tab_host[sc.flip];
+        sc.flip ^= 1;
+        float v_g_z = fmaf(0 + 0.5f, cell_z, -tcurr[2]);
+        float z_scaled = 0;
+        for (int z = 0; z < N; ++z) {
+            th[z] = v_g_z;
+            th[sc.tabN + z] = z_scaled;
+            v_g_z += cell_z;
+            z_scaled += cell_z;
+        }
+        KT_HIP(hipMemcpyAsync(sc.vgz, th, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
+        KT_HIP(hipMemcpyAsync(sc.zs, th + sc.tabN, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
+    }
     dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8));
     hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, g_scratch.rec, colors, nmap_curr,
-                       cols, rows, *intr, angle_color, g_scratch.vgz, g_scratch.zs, N, cell_z, tcurr[2]);
+                       cols, rows, *intr, angle_color);
     KT_LAUNCH_CHECK();
     kt_tsdf23_args a;
     a.rec = g_scratch.rec;
@@ -291,10 +353,15 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     for (int k = 0; k < 3; ++k) KT_ARG(voxel_wrap[k] >= 0);  // vWrapCopy is always normalised (KintinuousTracker.cpp:1075-1085)
     a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
     a.cols = cols; a.rows = rows; a.N = N;
-    dim3 b(256), g(kt_div_up(N, 64), kt_div_up(N, 4));
+    dim3 b(256), g(kt_div_up(N, 64), kt_div_up(N, 4), kt_div_up(N, KT_TSDF_ZCHUNK));
+    if (kt_tsdf23_hook.on) KT_HIP(hipEventRecord(kt_tsdf23_hook.ev[0], c->stream));
     if (updated_dev) hipLaunchKernelGGL(kt_tsdf23_kernel<true>, g, b, 0, c->stream, a);
     else hipLaunchKernelGGL(kt_tsdf23_kernel<false>, g, b, 0, c->stream, a);
     KT_LAUNCH_CHECK();
+    if (kt_tsdf23_hook.on) {
+        kt_tsdf23_hook.on = false;  // one-shot: armed by the tracker per call
+        KT_HIP(hipEventRecord(kt_tsdf23_hook.ev[1], c->stream));
+    }
     return KT_OK;
 }
 
@@ -324,6 +391,8 @@ struct kt_raycast_args {
     int wx, wy, wz;
     uchar4* vmap_color;
     unsigned long long* steps;  // optional march-step counter (S of SURVEY 8d)
+    // optional fused resizeVMap / resizeNMap outputs for levels 1..3 (maps.cu:225-308), tracker path only
+    float* vpyr[3]; float* npyr[3];
 };
 
 struct kt_rc {
@@ -389,14 +458,49 @@ struct kt_rc {
     }
 };
 
-template <bool COUNT>
+// 2x2 box down-sampling of one map level held in LDS (resizeMapKernel<normalize>, maps.cu:225-277): x-plane NaN in any of
+// the four inputs -> NaN in the output x plane only.  src: [3][S][S] tile in LDS, dst written to LDS tile and to global.
+template <bool NORMALIZE, int S>
+__device__ __forceinline__ void kt_tile_resize(const float* __restrict__ src, float* __restrict__ dst, int lx, int ly, int gx, int gy, int dcols,
+                                               int drows, float* __restrict__ out)
+{
+    constexpr int D = S / 2;
+    const float x00 = src[(2 * ly) * S + 2 * lx], x01 = src[(2 * ly) * S + 2 * lx + 1];
+    const float x10 = src[(2 * ly + 1) * S + 2 * lx], x11 = src[(2 * ly + 1) * S + 2 * lx + 1];
+    const bool inside = gx < dcols && gy < drows;
+    if (kt_isnan(x00) || kt_isnan(x01) || kt_isnan(x10) || kt_isnan(x11)) {
+        dst[ly * D + lx] = kt_nan();
+        if (inside) out[gy * dcols + gx] = kt_nan();
+        return;
+    }
+    f3 n;
+    n.x = (x00 + x01 + x10 + x11) / 4;
+    const float* sy = src + S * S;
+    n.y = (sy[(2 * ly) * S + 2 * lx] + sy[(2 * ly) * S + 2 * lx + 1] + sy[(2 * ly + 1) * S + 2 * lx] + sy[(2 * ly + 1) * S + 2 * lx + 1]) / 4;
+    const float* sz = src + 2 * S * S;
+    n.z = (sz[(2 * ly) * S + 2 * lx] + sz[(2 * ly) * S + 2 * lx + 1] + sz[(2 * ly + 1) * S + 2 * lx] + sz[(2 * ly + 1) * S + 2 * lx + 1]) / 4;
+    if (NORMALIZE) n = kt_normalized(n);
+    dst[ly * D + lx] = n.x;
+    dst[D * D + ly * D + lx] = n.y;
+    dst[2 * D * D + ly * D + lx] = n.z;
+    if (inside) {
+        out[gy * dcols + gx] = n.x;
+        out[(gy + drows) * dcols + gx] = n.y;
+        out[(gy + 2 * drows) * dcols + gx] = n.z;
+    }
+}
+
+#define KT_RC_BATCH 8
+
+template <bool COUNT, bool PYR>
 __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a)
 {
     // a 256-thread block covers a 16x16 pixel tile; each wave an 8x8 sub-tile (coherent gathers)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (x >= a.cols || y >= a.rows) return;
+    const int tx = (wave & 1) * 8 + (lane & 7), ty = (wave >> 1) * 8 + (lane >> 3);
+    const int x = blockIdx.x * 16 + tx;
+    const int y = blockIdx.y * 16 + ty;
+    const bool in_image = x < a.cols && y < a.rows;
     const kt_rc rc{a};
     const int cols = a.cols, rows = a.rows, N = a.N;
     unsigned int steps = 0;
@@ -406,92 +510,155 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
     float vfx = 0, vfy = 0, vfz = 0, nx = 0, ny = 0, nz = 0;
     uchar4 colr = make_uchar4(0, 0, 0, 0);
 
-    const f3 rs = {a.tx, a.ty, a.tz};
-    f3 rnl = {((float)x - a.intr.cx) / a.intr.fx, ((float)y - a.intr.cy) / a.intr.fy, 1.0f};
-    f3 ray_next = kt_add(kt_mul(a.R, rnl), rs);
-    f3 rd = kt_normalized(kt_sub(ray_next, rs));
-    rd.x = (rd.x == 0.f) ? (float)1e-15 : rd.x;
-    rd.y = (rd.y == 0.f) ? (float)1e-15 : rd.y;
-    rd.z = (rd.z == 0.f) ? (float)1e-15 : rd.z;
-    // getMinTime / getMaxTime  ray_caster.cu:56-74
-    float txmin = ((rd.x > 0 ? 0.f : a.vsx) - rs.x) / rd.x;
-    float tymin = ((rd.y > 0 ? 0.f : a.vsy) - rs.y) / rd.y;
-    float tzmin = ((rd.z > 0 ? 0.f : a.vsz) - rs.z) / rd.z;
-    float txmax = ((rd.x > 0 ? a.vsx : 0.f) - rs.x) / rd.x;
-    float tymax = ((rd.y > 0 ? a.vsy : 0.f) - rs.y) / rd.y;
-    float tzmax = ((rd.z > 0 ? a.vsz : 0.f) - rs.z) / rd.z;
-    float time_start_volume = fmaxf(fmaxf(txmin, tymin), tzmin);
-    float time_exit_volume = fminf(fminf(txmax, tymax), tzmax);
-    time_start_volume = fmaxf(time_start_volume, 0.f);
-    if (time_start_volume < time_exit_volume) {
-        float time_curr = time_start_volume;
-        int gx, gy, gz;
-        rc.voxel(__builtin_fmaf(rd.x, time_curr, rs.x), __builtin_fmaf(rd.y, time_curr, rs.y), __builtin_fmaf(rd.z, time_curr, rs.z), gx, gy, gz);
-        gx = max(0, min(gx, N - 1)); gy = max(0, min(gy, N - 1)); gz = max(0, min(gz, N - 1));
-        // only the SIGN of the nearest-voxel tsdf steers the march: compare the packed shorts directly
-        int tsdf = a.volume[rc.index(gx, gy, gz)];
-        const float max_time = 3 * (a.vsx + a.vsy + a.vsz);
-        for (; time_curr < max_time; time_curr += a.time_step) {
-            const int tsdf_prev = tsdf;
-            const float tn = time_curr + a.time_step;
-            const float px = __builtin_fmaf(rd.x, tn, rs.x), py = __builtin_fmaf(rd.y, tn, rs.y), pz = __builtin_fmaf(rd.z, tn, rs.z);
-            rc.voxel(px, py, pz, gx, gy, gz);
-            if (!(gx >= 0 && gy >= 0 && gz >= 0 && gx < N && gy < N && gz < N)) break;  // checkInds
-            tsdf = a.volume[rc.index(gx, gy, gz)];
-            if (COUNT) ++steps;
-            if (tsdf_prev < 0 && tsdf > 0) break;
-            if (tsdf_prev > 0 && tsdf < 0) {  // zero crossing
-                float Ftdt = rc.tsdf_at(px, py, pz);
-                if (kt_isnan(Ftdt)) break;
-                const float qx = __builtin_fmaf(rd.x, time_curr, rs.x), qy = __builtin_fmaf(rd.y, time_curr, rs.y), qz = __builtin_fmaf(rd.z, time_curr, rs.z);
-                float Ft = rc.tsdf_at(qx, qy, qz);
-                if (kt_isnan(Ft)) break;
-                float Ts = time_curr - a.time_step * Ft / (Ftdt - Ft);
-                vfx = __builtin_fmaf(rd.x, Ts, rs.x); vfy = __builtin_fmaf(rd.y, Ts, rs.y); vfz = __builtin_fmaf(rd.z, Ts, rs.z);
-                hit = true;
-                out_vx = vfx;
-                int hx, hy, hz;
-                rc.voxel(qx, qy, qz, hx, hy, hz);
-                float col;
-                colr.x = rc.trilinear<0>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
-                colr.y = rc.trilinear<1>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
-                colr.z = rc.trilinear<2>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
-                colr.w = rc.trilinear<3>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
-                if (hx > 1 && hy > 1 && hz > 1 && hx < N - 2 && hy < N - 2 && hz < N - 2) {
-                    float Fx1 = rc.tsdf_at(vfx + a.cx_, vfy, vfz), Fx2 = rc.tsdf_at(vfx - a.cx_, vfy, vfz);
-                    float Fy1 = rc.tsdf_at(vfx, vfy + a.cy_, vfz), Fy2 = rc.tsdf_at(vfx, vfy - a.cy_, vfz);
-                    float Fz1 = rc.tsdf_at(vfx, vfy, vfz + a.cz_), Fz2 = rc.tsdf_at(vfx, vfy, vfz - a.cz_);
-                    f3 n = kt_normalized({Fx1 - Fx2, Fy1 - Fy2, Fz1 - Fz2});
-                    nx = n.x; ny = n.y; nz = n.z;
-                    has_normal = true;
-                    out_nx = nx;
+    if (in_image) {
+        const f3 rs = {a.tx, a.ty, a.tz};
+        f3 rnl = {((float)x - a.intr.cx) / a.intr.fx, ((float)y - a.intr.cy) / a.intr.fy, 1.0f};
+        f3 ray_next = kt_add(kt_mul(a.R, rnl), rs);
+        f3 rd = kt_normalized(kt_sub(ray_next, rs));
+        rd.x = (rd.x == 0.f) ? (float)1e-15 : rd.x;
+        rd.y = (rd.y == 0.f) ? (float)1e-15 : rd.y;
+        rd.z = (rd.z == 0.f) ? (float)1e-15 : rd.z;
+        // getMinTime / getMaxTime  ray_caster.cu:56-74
+        const float txmin = ((rd.x > 0 ? 0.f : a.vsx) - rs.x) / rd.x;
+        const float tymin = ((rd.y > 0 ? 0.f : a.vsy) - rs.y) / rd.y;
+        const float tzmin = ((rd.z > 0 ? 0.f : a.vsz) - rs.z) / rd.z;
+        const float txmax = ((rd.x > 0 ? a.vsx : 0.f) - rs.x) / rd.x;
+        const float tymax = ((rd.y > 0 ? a.vsy : 0.f) - rs.y) / rd.y;
+        const float tzmax = ((rd.z > 0 ? a.vsz : 0.f) - rs.z) / rd.z;
+        float time_start_volume = fmaxf(fmaxf(txmin, tymin), tzmin);
+        const float time_exit_volume = fminf(fminf(txmax, tymax), tzmax);
+        time_start_volume = fmaxf(time_start_volume, 0.f);
+        if (time_start_volume < time_exit_volume) {
+            float time_curr = time_start_volume;
+            int gx, gy, gz;
+            rc.voxel(__builtin_fmaf(rd.x, time_curr, rs.x), __builtin_fmaf(rd.y, time_curr, rs.y), __builtin_fmaf(rd.z, time_curr, rs.z), gx, gy, gz);
+            gx = max(0, min(gx, N - 1)); gy = max(0, min(gy, N - 1)); gz = max(0, min(gz, N - 1));
+            // only the SIGN of the nearest-voxel tsdf steers the march: compare the packed shorts directly
+            int tsdf = a.volume[rc.index(gx, gy, gz)];
+            const float max_time = 3 * (a.vsx + a.vsy + a.vsz);
+            // The march (ray_caster.cu:340-352) visits time_curr, time_curr + step, ... one dependent gather per step.
+            // The addresses do not depend on the loaded values, so KT_RC_BATCH steps are issued together and the exit
+            // tests are then replayed in order; loads past the exit point are speculative and always in bounds.
+            bool crossing = false, done = false;
+            float t_cross = 0.f;
+            while (!done) {
+                float tc[KT_RC_BATCH];
+                size_t gi[KT_RC_BATCH];
+                bool inb[KT_RC_BATCH];
+                float t = time_curr;
+#pragma unroll
+                for (int k = 0; k < KT_RC_BATCH; ++k) {
+                    tc[k] = t;
+                    const float tn = t + a.time_step;
+                    rc.voxel(__builtin_fmaf(rd.x, tn, rs.x), __builtin_fmaf(rd.y, tn, rs.y), __builtin_fmaf(rd.z, tn, rs.z), gx, gy, gz);
+                    inb[k] = (gx >= 0 && gy >= 0 && gz >= 0 && gx < N && gy < N && gz < N);  // checkInds
+                    gi[k] = inb[k] ? rc.index(gx, gy, gz) : 0;
+                    t += a.time_step;
                 }
-                break;
+                short v[KT_RC_BATCH];
+#pragma unroll
+                for (int k = 0; k < KT_RC_BATCH; ++k) v[k] = a.volume[gi[k]];
+#pragma unroll
+                for (int k = 0; k < KT_RC_BATCH; ++k) {
+                    if (done) break;
+                    if (!(tc[k] < max_time) || !inb[k]) { done = true; break; }
+                    const int tsdf_prev = tsdf;
+                    tsdf = v[k];
+                    if (COUNT) ++steps;
+                    if (tsdf_prev < 0 && tsdf > 0) { done = true; break; }
+                    if (tsdf_prev > 0 && tsdf < 0) { crossing = true; t_cross = tc[k]; done = true; break; }
+                }
+                time_curr = t;
+            }
+            if (crossing) {  // zero crossing, ray_caster.cu:354-422
+                time_curr = t_cross;
+                const float tn = time_curr + a.time_step;
+                const float px = __builtin_fmaf(rd.x, tn, rs.x), py = __builtin_fmaf(rd.y, tn, rs.y), pz = __builtin_fmaf(rd.z, tn, rs.z);
+                const float Ftdt = rc.tsdf_at(px, py, pz);
+                if (!kt_isnan(Ftdt)) {
+                    const float qx = __builtin_fmaf(rd.x, time_curr, rs.x), qy = __builtin_fmaf(rd.y, time_curr, rs.y), qz = __builtin_fmaf(rd.z, time_curr, rs.z);
+                    const float Ft = rc.tsdf_at(qx, qy, qz);
+                    if (!kt_isnan(Ft)) {
+                        const float Ts = time_curr - a.time_step * Ft / (Ftdt - Ft);
+                        vfx = __builtin_fmaf(rd.x, Ts, rs.x); vfy = __builtin_fmaf(rd.y, Ts, rs.y); vfz = __builtin_fmaf(rd.z, Ts, rs.z);
+                        hit = true;
+                        out_vx = vfx;
+                        int hx, hy, hz;
+                        rc.voxel(qx, qy, qz, hx, hy, hz);
+                        float col;
+                        colr.x = rc.trilinear<0>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
+                        colr.y = rc.trilinear<1>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
+                        colr.z = rc.trilinear<2>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
+                        colr.w = rc.trilinear<3>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
+                        if (hx > 1 && hy > 1 && hz > 1 && hx < N - 2 && hy < N - 2 && hz < N - 2) {
+                            const float Fx1 = rc.tsdf_at(vfx + a.cx_, vfy, vfz), Fx2 = rc.tsdf_at(vfx - a.cx_, vfy, vfz);
+                            const float Fy1 = rc.tsdf_at(vfx, vfy + a.cy_, vfz), Fy2 = rc.tsdf_at(vfx, vfy - a.cy_, vfz);
+                            const float Fz1 = rc.tsdf_at(vfx, vfy, vfz + a.cz_), Fz2 = rc.tsdf_at(vfx, vfy, vfz - a.cz_);
+                            const f3 n = kt_normalized({Fx1 - Fx2, Fy1 - Fy2, Fz1 - Fz2});
+                            nx = n.x; ny = n.y; nz = n.z;
+                            has_normal = true;
+                            out_nx = nx;
+                        }
+                    }
+                }
             }
         }
-    }
-    // unhit pixels: NaN in the x planes only, y/z planes and the colour map keep their previous content
-    a.vmap[y * cols + x] = out_vx;
-    a.nmap[y * cols + x] = out_nx;
-    if (hit) {
-        a.vmap[(y + rows) * cols + x] = vfy;
-        a.vmap[(y + 2 * rows) * cols + x] = vfz;
-        a.vmap_color[y * cols + x] = colr;
-        if (has_normal) {
-            a.nmap[(y + rows) * cols + x] = ny;
-            a.nmap[(y + 2 * rows) * cols + x] = nz;
+        // unhit pixels: NaN in the x planes only, y/z planes and the colour map keep their previous content
+        a.vmap[y * cols + x] = out_vx;
+        a.nmap[y * cols + x] = out_nx;
+        if (hit) {
+            a.vmap[(y + rows) * cols + x] = vfy;
+            a.vmap[(y + 2 * rows) * cols + x] = vfz;
+            a.vmap_color[y * cols + x] = colr;
+            if (has_normal) {
+                a.nmap[(y + rows) * cols + x] = ny;
+                a.nmap[(y + 2 * rows) * cols + x] = nz;
+            }
         }
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) steps += __shfl_down(steps, off, 64);
         if (lane == 0 && steps) atomicAdd(a.steps, (unsigned long long)steps);
     }
+    if (PYR) {
+        // fused resizeVMap / resizeNMap for levels 1..3 of this 16x16 tile (KintinuousTracker.cpp:892-899): 8x8, 4x4, 2x2
+        __shared__ float tv0[3 * 16 * 16], tn0[3 * 16 * 16];
+        __shared__ float tv1[3 * 8 * 8], tn1[3 * 8 * 8], tv2[3 * 4 * 4], tn2[3 * 4 * 4], tv3[3 * 2 * 2], tn3[3 * 2 * 2];
+        const int li = ty * 16 + tx;
+        tv0[li] = out_vx; tv0[256 + li] = vfy; tv0[512 + li] = vfz;
+        tn0[li] = out_nx; tn0[256 + li] = ny; tn0[512 + li] = nz;
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < 64) {
+            const int lx = t & 7, ly = t >> 3;
+            kt_tile_resize<false, 16>(tv0, tv1, lx, ly, blockIdx.x * 8 + lx, blockIdx.y * 8 + ly, cols / 2, rows / 2, a.vpyr[0]);
+        } else if (t < 128) {
+            const int lx = t & 7, ly = (t >> 3) & 7;
+            kt_tile_resize<true, 16>(tn0, tn1, lx, ly, blockIdx.x * 8 + lx, blockIdx.y * 8 + ly, cols / 2, rows / 2, a.npyr[0]);
+        }
+        __syncthreads();
+        if (t < 16) {
+            const int lx = t & 3, ly = t >> 2;
+            kt_tile_resize<false, 8>(tv1, tv2, lx, ly, blockIdx.x * 4 + lx, blockIdx.y * 4 + ly, cols / 4, rows / 4, a.vpyr[1]);
+        } else if (t >= 64 && t < 80) {
+            const int lx = t & 3, ly = (t >> 2) & 3;
+            kt_tile_resize<true, 8>(tn1, tn2, lx, ly, blockIdx.x * 4 + lx, blockIdx.y * 4 + ly, cols / 4, rows / 4, a.npyr[1]);
+        }
+        __syncthreads();
+        if (t < 4) {
+            const int lx = t & 1, ly = t >> 1;
+            kt_tile_resize<false, 4>(tv2, tv3, lx, ly, blockIdx.x * 2 + lx, blockIdx.y * 2 + ly, cols / 8, rows / 8, a.vpyr[2]);
+        } else if (t >= 64 && t < 68) {
+            const int lx = t & 1, ly = (t >> 1) & 1;
+            kt_tile_resize<true, 4>(tn2, tn3, lx, ly, blockIdx.x * 2 + lx, blockIdx.y * 2 + ly, cols / 8, rows / 8, a.npyr[2]);
+        }
+    }
 }
 
 int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const float tcurr[3], float tranc_dist,
                     const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
                     const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,
-                    unsigned long long* steps_dev)
+                    unsigned long long* steps_dev, float* const* vpyr, float* const* npyr)
 {
     KT_ARG(c && intr && Rcurr && tcurr && volume_size && volume && vmap && nmap && voxel_wrap && vmap_curr_color && color_volume);
     KT_ARG(N > 0 && cols > 0 && rows > 0);
@@ -510,9 +677,17 @@ int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const
     a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
     a.vmap_color = (uchar4*)vmap_curr_color;
     a.steps = steps_dev;
+    const bool pyr = vpyr && npyr;
+    for (int k = 0; k < 3; ++k) { a.vpyr[k] = pyr ? vpyr[k] : nullptr; a.npyr[k] = pyr ? npyr[k] : nullptr; }
+    if (pyr) KT_ARG((cols % 8) == 0 && (rows % 8) == 0);
     dim3 b(256), g(kt_div_up(cols, 16), kt_div_up(rows, 16));
-    if (steps_dev) hipLaunchKernelGGL(kt_raycast_kernel<true>, g, b, 0, c->stream, a);
-    else hipLaunchKernelGGL(kt_raycast_kernel<false>, g, b, 0, c->stream, a);
+    if (pyr) {
+        if (steps_dev) hipLaunchKernelGGL((kt_raycast_kernel<true, true>), g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((kt_raycast_kernel<false, true>), g, b, 0, c->stream, a);
+    } else {
+        if (steps_dev) hipLaunchKernelGGL((kt_raycast_kernel<true, false>), g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((kt_raycast_kernel<false, false>), g, b, 0, c->stream, a);
+    }
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
@@ -522,7 +697,7 @@ extern "C" int kt_raycast(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr,
                           const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N)
 {
     return kt_raycast_impl(c, intr, Rcurr, tcurr, tranc_dist, volume_size, volume, vmap, nmap, cols, rows, voxel_wrap,
-                           vmap_curr_color, color_volume, N, nullptr);
+                           vmap_curr_color, color_volume, N, nullptr, nullptr, nullptr);
 }
 
 // ================================================================================================

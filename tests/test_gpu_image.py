@@ -125,3 +125,35 @@ def test_rgbd_pyramids(ctx, oracle_mod, small_scene):
         gc = ctx.empty(cl.nbytes)
         ctx.project_to_cloud(ctx.upload(src), cc, rr, gc, cam.fx, cam.fy, cam.cx, cam.cy, level)
         assert np.array_equal(cl.view(np.uint32), ctx.download(gc, np.float32, cl.shape).view(np.uint32))
+
+
+@pytest.mark.parametrize("size", [(160, 120), (640, 480), (200, 72)])
+def test_build_pyramid_fused(ctx, oracle_mod, size):
+    """kt_build_pyramid (one launch) == pyrDown x3 + createVMap x4 + createNMap x4 of the oracle, bit for bit,
+    including the stale-plane semantics of invalid pixels."""
+    from kintinuous_amd import synth
+    from kintinuous_amd.abi import Intr
+    from oracle.oracle import OIntr
+    cols, rows = size
+    cam = synth.Camera.small(cols, rows)
+    d, _ = synth.render(synth.Scene("room"), cam, np.eye(3), np.zeros(3))
+    rng = np.random.default_rng(cols)
+    d = d.copy()
+    d[rng.uniform(size=d.shape) < 0.08] = 0
+    d0 = oracle_mod.bilateral_filter(d)
+    depths = [d0]
+    for l in range(3):
+        depths.append(oracle_mod.pyr_down(depths[-1]))
+    pre = [rng.uniform(-1, 1, (3 * (rows >> l), cols >> l)).astype(np.float32) for l in range(4)]
+    vref = [oracle_mod.create_vmap(OIntr(cam.fx, cam.fy, cam.cx, cam.cy).level(l), depths[l], out=pre[l].copy()) for l in range(4)]
+    nref = [oracle_mod.create_nmap(vref[l], out=pre[l].copy()) for l in range(4)]
+    gd = [ctx.zeros(depths[l].nbytes) for l in range(1, 4)]
+    gv = [ctx.upload(pre[l]) for l in range(4)]
+    gn = [ctx.upload(pre[l]) for l in range(4)]
+    ctx.build_pyramid(Intr(cam.fx, cam.fy, cam.cx, cam.cy), ctx.upload(d0), cols, rows, gd, gv, gn)
+    ctx.sync()
+    for l in range(1, 4):
+        assert np.array_equal(depths[l], ctx.download(gd[l - 1], np.uint16, depths[l].shape)), f"depth level {l}"
+    for l in range(4):
+        assert np.array_equal(vref[l].view(np.uint32), ctx.download(gv[l], np.float32, vref[l].shape).view(np.uint32)), f"vmap level {l}"
+        assert np.array_equal(nref[l].view(np.uint32), ctx.download(gn[l], np.float32, nref[l].shape).view(np.uint32)), f"nmap level {l}"

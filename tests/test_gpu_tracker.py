@@ -64,15 +64,15 @@ def test_icp_orbit(ctx, oracle_mod, small_scene):
     ts2, P2, loop2 = otr.dense_pose(0)
     assert (ts, loop) == (ts2, loop2) and np.array_equal(P, P2)
     _volume_close(trk, otr)
-    # predicted maps of the last frame (raycast + resize pyramid)
+    # predicted maps of the last frame (raycast with the fused resize pyramid): valid pixels bit-identical
     for lvl in range(4):
-        a, b = trk.vmap_g_prev(lvl), otr.vmap_g_prev(lvl)
-        rows = a.shape[0] // 3
-        va, vb = np.isfinite(a[:rows]), np.isfinite(b[:rows])
-        assert (va != vb).mean() < 2e-3
-        m = va & vb
-        for p in range(3):
-            assert np.abs(a[p * rows:(p + 1) * rows][m] - b[p * rows:(p + 1) * rows][m]).max() < 2e-3
+        for a, b in ((trk.vmap_g_prev(lvl), otr.vmap_g_prev(lvl)), (trk.nmap_g_prev(lvl), otr.nmap_g_prev(lvl))):
+            rows = a.shape[0] // 3
+            va, vb = np.isfinite(a[:rows]), np.isfinite(b[:rows])
+            assert np.array_equal(va, vb), f"level {lvl}: validity masks differ"
+            assert va.sum() > 0
+            for p in range(3):
+                assert np.array_equal(a[p * rows:(p + 1) * rows][va].view(np.uint32), b[p * rows:(p + 1) * rows][va].view(np.uint32)), (lvl, p)
     # tracking itself must be right: against ground truth (volume frame = scene + 3 m)
     R, t, _ = trk.pose()
     Rg, cg = traj[len(frames) - 1]
