@@ -41,11 +41,7 @@ WORKLOADS = {
 }
 
 
-def pingpong(i, n):
-    """0,1,..,n-1,n-2,..,1,0,1,.. : stays a continuous camera motion for any number of steps."""
-    period = 2 * (n - 1)
-    j = i % period
-    return j if j < n else period - j
+from kintinuous_amd.multistream import aggregate_fps, gather_poses, pingpong, stream_seed  # noqa: E402
 
 
 def main():
@@ -71,7 +67,7 @@ def main():
     cam = synth.Camera.scaled(scale)
     total_frames = args.steps + args.warmup
     nuniq = max(2, min(args.unique_frames, total_frames))
-    seed = 1234 + rank
+    seed = stream_seed(rank)
     _, frames, traj, kw2 = synth.sequence(cfg_name, nuniq, cam, seed)
     d = dict(volume_size=6.0, voxel_shift=14, overlap=2, static_mode=0, use_rgbd=0, use_rgbd_icp=0, fast_odometry=0, disable_color_angle=0)
     d.update(kw2)
@@ -103,10 +99,9 @@ def main():
     if dist is not None:
         import torch
         k = min(args.steps, trk.num_poses())
-        mine = torch.empty(k * 16, dtype=torch.float32, device=f"cuda:{local_rank}")
+        mine = torch.empty((k, 16), dtype=torch.float32, device=f"cuda:{local_rank}")
         trk.export_poses_device(k, mine.data_ptr())
-        allp = torch.empty(world * k * 16, dtype=torch.float32, device=f"cuda:{local_rank}")
-        dist.all_gather_into_tensor(allp, mine)  # the single RCCL gather of per-stream poses
+        allp = gather_poses(dist, mine, world)  # the single RCCL gather of per-stream poses
         pose_bytes = allp.numel() * 4
     ctx.sync()
     if dist is not None:
@@ -115,11 +110,8 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if dist is not None:
-        import torch
-        te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    fps = aggregate_fps(dist, args.steps, elapsed, world, device=(f"cuda:{local_rank}" if dist is not None else None))
+    elapsed = world * args.steps / fps
 
     stage = trk.stage_ms()
     tsdf23_ms, tsdf23_n = stage["tsdf23"]

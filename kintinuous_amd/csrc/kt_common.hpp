@@ -1,6 +1,6 @@
 // kt_common.hpp -- shared host/device helpers for libkt_hip.so (gfx950 only).
 //
-// Arithmetic contract (matches oracle/kt_oracle.h, restated independently here): IEEE binary32,
+// Arithmetic contract (DESIGN.md "Arithmetic"; the test oracle restates the same rules independently): IEEE binary32,
 // correctly rounded '/' and sqrtf (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), built with
 // -ffp-contract=off so a*b+c fuses ONLY where __builtin_fmaf is written; rsqrtf -> 1/sqrtf;
 // __expf -> kt_expf (explicit fmaf chain); CUDA __float2int_r{n,z,d} semantics (saturate, NaN -> 0)

@@ -1,0 +1,101 @@
+"""Host-side logic that needs no GPU: synthetic data, .klg I/O, the frame schedule, and the oracle's tracker state machine
+(shift decisions, slices, pose bookkeeping) on a small sequence."""
+import os
+
+import numpy as np
+import pytest
+
+
+def test_synth_is_deterministic_and_sane():
+    from kintinuous_amd import synth
+    cam = synth.Camera.small(160, 120)
+    R, c = synth.orbit_trajectory(4)[3]
+    a = synth.render(synth.Scene("room"), cam, R, c)
+    b = synth.render(synth.Scene("room"), cam, R, c)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    d, rgb = a
+    assert d.dtype == np.uint16 and rgb.dtype == np.uint8 and d.shape == (120, 160) and rgb.shape == (120, 160, 3)
+    assert (d > 0).all() and d.max() < 4000 and rgb.min() >= 1  # closed room: every ray hits; intensity never 0
+    other = synth.render(synth.Scene("room", seed=1235), cam, R, c)
+    assert not np.array_equal(other[0], d)  # per-stream seeds move the sphere / cube
+    # per-frame motion stays inside the projective-ICP basin
+    tr = synth.orbit_trajectory(300)
+    step = max(np.linalg.norm(tr[k + 1][1] - tr[k][1]) for k in range(299))
+    assert step < 0.02
+    cw = synth.crabwalk_trajectory(420)
+    assert abs(cw[200][1][0] - 3.0) < 1e-9 and abs(cw[400][1][0]) < 1e-9
+
+
+def test_klg_roundtrip(tmp_path):
+    from kintinuous_amd import klg, synth
+    cam = synth.Camera.small(64, 48)
+    tr = synth.orbit_trajectory(4)
+    frames = [synth.render(synth.Scene("room"), cam, R, c) for (R, c) in tr]
+    for comp in (False, True):
+        p = str(tmp_path / f"s{int(comp)}.klg")
+        klg.write_klg(p, frames, cols=64, rows=48, compress_depth=comp)
+        got = list(klg.read_klg(p, 64, 48))
+        assert len(got) == 3  # the reference reader never yields the last frame (RawLogReader.cpp:147-150)
+        for k, (ts, d, rgb) in enumerate(got):
+            assert ts == 33333 * k and np.array_equal(d, frames[k][0]) and np.array_equal(rgb, frames[k][1])
+        assert len(list(klg.read_klg(p, 64, 48, reference_quirk=False))) == 4
+
+
+def test_pingpong_schedule():
+    from kintinuous_amd.multistream import pingpong, stream_seed
+    assert [pingpong(i, 4) for i in range(10)] == [0, 1, 2, 3, 2, 1, 0, 1, 2, 3]
+    assert all(abs(pingpong(i + 1, 7) - pingpong(i, 7)) == 1 for i in range(50))
+    assert stream_seed(0) == 1234 and stream_seed(7) == 1241
+
+
+def test_oracle_tracker_shifts_and_bookkeeping(oracle_mod):
+    """KintinuousTracker state machine in the oracle: moving the camera +x past the shift threshold extracts a slab,
+    clears it, advances voxelWrap and pulls the translation back; the global camera position stays continuous."""
+    from kintinuous_amd import synth
+    from oracle.oracle import OTrackerConfig, OracleTracker
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("wall")
+    traj = synth.crabwalk_trajectory(420)
+    idx = list(range(0, 30, 2))
+    N, size, shift = 64, 7.0, 2
+    trk = OracleTracker(OTrackerConfig(cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, size, shift, 2, 0, 0, 0, 0, 0, 0))
+    prev_g = None
+    for k, i in enumerate(idx):
+        d, rgb = synth.render(scene, cam, *traj[i])
+        trk.process_frame(d, rgb, 1000 * k)
+        R, t, g = trk.pose()
+        if prev_g is not None:
+            assert np.linalg.norm(g - prev_g) < 0.08  # continuous although t is pulled back on every shift
+        prev_g = g
+        cell = size / N
+        assert np.all(np.abs(t - size / 2) < (shift + 1.5) * cell + 0.35)  # the camera stays near the volume centre
+    w = trk.voxel_wrap()
+    assert w[0] >= 2 and trk.num_slices() >= 1
+    pts, dim = trk.slice(0)
+    assert dim == 0  # XPlus (the first slabs leave the volume at its unobserved left edge, so they may be empty)
+    assert trk.num_poses() == len(idx)
+    ts, P, loop = trk.dense_pose(0)
+    assert ts == 0 and loop and np.allclose(P[:3, :3], np.eye(3)) and np.allclose(P[:3, 3], 0)
+    ts, P, loop = trk.dense_pose(len(idx) - 1)
+    Rg, cg = traj[idx[-1]]
+    assert not loop and np.abs(P[:3, 3] - cg).max() < 0.06  # global camera == scene coordinates (volume centred on camera 0)
+    trk.finalise()
+    pts, dim = trk.slice(trk.num_slices() - 1)
+    assert dim == 7 and len(pts) > 300  # FINAL: the whole remaining surface
+    assert pts["bgra"][:, 3].min() >= 1  # alpha carries the voxel weight (CloudSliceProcessor culls on it)
+    trk.close()
+
+
+def test_oracle_static_mode_never_shifts(oracle_mod):
+    from kintinuous_amd import synth
+    from oracle.oracle import OTrackerConfig, OracleTracker
+    cam = synth.Camera.small(160, 120)
+    trk = OracleTracker(OTrackerConfig(cam.cols, cam.rows, 48, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 1, 2, 1, 0, 0, 0, 0, 0))
+    R, t, g = trk.pose()
+    assert t[2] == pytest.approx(-0.45) and t[0] == pytest.approx(3.0)  # camera parked 0.45 m outside the near face (:101-110)
+    for k, (Rk, ck) in enumerate(synth.static_trajectory(3)):
+        d, rgb = synth.render(synth.Scene("farwall"), cam, Rk, ck)
+        trk.process_frame(d, rgb, k)
+    assert trk.num_slices() == 0 and not trk.voxel_wrap().any()
+    assert abs(trk.trunc_dist() - 2.1 * 6.0 / 48) < 1e-6  # clamped to >= 2.1 voxels (TSDFVolume.cpp:89-97)
+    trk.close()
