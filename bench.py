@@ -64,6 +64,7 @@ def main():
         dist.barrier()
 
     cfg_name, scale, N, kw = WORKLOADS[args.workload]
+    N = int(os.environ.get("KT_BENCH_N", N))  # experiments only
     cam = synth.Camera.scaled(scale)
     total_frames = args.steps + args.warmup
     nuniq = max(2, min(args.unique_frames, total_frames))
@@ -124,19 +125,21 @@ def main():
     w = trk.voxel_wrap().astype(np.float64) * (d["volume_size"] / N)
     pose_err = float(np.abs((t + w) - (cg + basis)).max())
 
-    # ---- untimed: per-stage breakdown and the U / S counters of a few frames ----------------------
+    # ---- untimed: per-stage breakdown (events around every stage), then the U / S counters of a few frames -----------
+    base = args.warmup + args.steps
     trk.enable_profiling(2)
+    for i in range(base, base + 8):
+        step(i)
+    stage_all = trk.stage_ms()
+    trk.enable_profiling(0)
     trk.enable_counts(True)
     Us, Ss = [], []
-    base = args.warmup + args.steps
-    for i in range(base, base + 8):
+    for i in range(base + 8, base + 12):
         step(i)
         U, S = trk.last_counts()
         Us.append(U)
         Ss.append(S)
     trk.enable_counts(False)
-    stage_all = trk.stage_ms()
-    trk.enable_profiling(0)
     U = float(np.mean(Us))
     P = cam.cols * cam.rows
     # algorithmic bytes of the tsdf23 launch (DESIGN.md "integrate"): 12 B per updated voxel (2 B tsdf + 4 B colour/weight,

@@ -199,6 +199,9 @@ int kt_tracker_stage_counts(kt_tracker* t, long long n_host[7]);
  * integrate update predicate, S = ray-march steps */
 int kt_tracker_enable_counts(kt_tracker* t, int on);
 int kt_tracker_last_counts(kt_tracker* t, unsigned long long* U, unsigned long long* S);
+/* diagnostics of the last counted integrate: {U, wave batches of 4 z-steps, active wave-chunks, sum and max of the active
+ * waves' durations, sum of their issue and consume phases (10 ns ticks), 0} */
+int kt_tracker_debug_counts(kt_tracker* t, unsigned int out8_host[8]);
 
 /* ---- multi-GPU: independent streams, one tracker per GPU; poses are gathered by the caller's
  * collective (bench.py / the CLI use RCCL all_gather on the buffer filled here) ---- */

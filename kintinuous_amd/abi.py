@@ -121,6 +121,7 @@ _PROTOS = {
     "kt_tracker_stage_counts": (_i, [_vp, C.POINTER(C.c_longlong)]),
     "kt_tracker_enable_counts": (_i, [_vp, _i]),
     "kt_tracker_last_counts": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "kt_tracker_debug_counts": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_export_poses_device": (_i, [_vp, _i, _vp]),
 }
 
@@ -418,6 +419,11 @@ class Tracker:
         U, S = C.c_ulonglong(0), C.c_ulonglong(0)
         _chk(lib().kt_tracker_last_counts(self.h, C.byref(U), C.byref(S)))
         return int(U.value), int(S.value)
+
+    def debug_counts(self):
+        o = (C.c_uint * 8)()
+        _chk(lib().kt_tracker_debug_counts(self.h, o))
+        return [int(v) for v in o]
 
     def export_poses_device(self, k: int, dst_ptr: int) -> None:
         _chk(lib().kt_tracker_export_poses_device(self.h, k, dst_ptr))

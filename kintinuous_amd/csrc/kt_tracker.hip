@@ -76,11 +76,14 @@ static kt_intr lvl_intr(kt_intr k, int l)  // Intr::operator() internal.h:255-25
 
 #define KT_TRY(expr) do { int _s = (expr); if (_s != KT_OK) return _s; } while (0)
 
+// zero-fill goes on the context's stream: the stream is non-blocking, so a null-stream hipMemset would not be ordered
+// against the kernels that later write these buffers
+static thread_local hipStream_t g_alloc_stream = nullptr;
 template <typename T>
 static int dev_alloc(T** p, size_t count, bool zero)
 {
     KT_HIP(hipMalloc((void**)p, (count ? count : 1) * sizeof(T)));
-    if (zero) KT_HIP(hipMemset(*p, 0, (count ? count : 1) * sizeof(T)));
+    if (zero) KT_HIP(hipMemsetAsync(*p, 0, (count ? count : 1) * sizeof(T), g_alloc_stream));
     return KT_OK;
 }
 
@@ -166,6 +169,7 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
     KT_HIP(hipSetDevice(ctx->device));
     kt_tracker* t = new kt_tracker();
     t->ctx = ctx;
+    g_alloc_stream = ctx->stream;
     t->cfg = *cfg;
     t->N = cfg->N;
     // KintinuousTracker ctor, KintinuousTracker.cpp:71-182
@@ -215,7 +219,7 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
     KT_TRY(dev_alloc(&t->rgb_stage, P * 3, true));
     KT_HIP(hipHostMalloc((void**)&t->depth_stage_host, P * sizeof(uint16_t), hipHostMallocDefault));
     KT_HIP(hipHostMalloc((void**)&t->rgb_stage_host, P * 3, hipHostMallocDefault));
-    KT_TRY(dev_alloc(&t->upd_dev, 4, true));
+    KT_TRY(dev_alloc(&t->upd_dev, 16, true));
     KT_TRY(dev_alloc(&t->steps_dev, 2, true));
     t->profiling = 0;
     t->counting = 0;
@@ -451,7 +455,7 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
         kt_mat33_inverse(Rcam.m, Rcam_inv.m);
         const int empty[3] = {0, 0, 0};
         if (rgbd) KT_TRY(populate_rgbd(t, depth_raw, colors, t->last_depth, t->last_image));  // firstRun
-        if (t->counting) KT_HIP(hipMemsetAsync(t->upd_dev, 0, sizeof(unsigned int), c->stream));
+        if (t->counting) KT_HIP(hipMemsetAsync(t->upd_dev, 0, 16 * sizeof(unsigned int), c->stream));
         KT_TRY(ev_begin(t, ST_INTEGRATE));
         tsdf23_hook_arm(t);
         KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rcam_inv, t->tlast, t->tranc_dist, t->tsdf,
@@ -532,7 +536,7 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
 
     // [H] integrate: raw depth, current-frame level-0 normals :864-876
     if (t->counting) {
-        KT_HIP(hipMemsetAsync(t->upd_dev, 0, sizeof(unsigned int), c->stream));
+        KT_HIP(hipMemsetAsync(t->upd_dev, 0, 16 * sizeof(unsigned int), c->stream));
         KT_HIP(hipMemsetAsync(t->steps_dev, 0, sizeof(unsigned long long), c->stream));
     }
     KT_TRY(ev_begin(t, ST_INTEGRATE));
@@ -659,6 +663,12 @@ int kt_tracker_enable_counts(kt_tracker* t, int on)
 {
     KT_ARG(t);
     t->counting = on;
+    return KT_OK;
+}
+int kt_tracker_debug_counts(kt_tracker* t, unsigned int* out4)
+{
+    KT_ARG(t && out4);
+    KT_HIP(hipMemcpy(out4, t->upd_dev, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost));
     return KT_OK;
 }
 int kt_tracker_last_counts(kt_tracker* t, unsigned long long* U, unsigned long long* S)

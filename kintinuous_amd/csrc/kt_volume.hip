@@ -9,6 +9,8 @@
 // wave own 64 consecutive STORAGE x of one (y, z) line: 128 B of tsdf + 256 B of colour per access.
 #include "kt_internal.hpp"
 
+#include <stdlib.h>
+
 thread_local kt_event_hook kt_tsdf23_hook = {{nullptr, nullptr}, false};
 
 // ================================================================================================
@@ -91,6 +93,8 @@ struct kt_tsdf23_args {
     uchar4* color;
     const float* vgz;
     const float* zs;
+    const unsigned int* interval;  // per storage column: z0 | z1 << 16 (kt_tsdf_interval_kernel)
+    const float2* walk;            // [chunk][sy][sx]: (v_x, v_y) of the reference walk at z = chunk * KT_TSDF_ZCHUNK
     unsigned int* updated;  // optional counter (U of SURVEY 8d)
     kt_mat33 Ri;            // Rcurr_inv
     float tx, ty, tz;
@@ -119,32 +123,23 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
 #define KT_TSDF_ZCHUNK 32
 #define KT_TSDF_UNROLL 4
 
-template <bool COUNT>
-__global__ __launch_bounds__(256) void kt_tsdf23_kernel(const kt_tsdf23_args a)
+// Pre-pass: the conservative z-interval of every voxel column (one thread per column, computed ONCE per frame instead
+// of once per z-chunk).  Stored as (z0 | z1 << 16) per storage column; empty = (N | 0 << 16).
+__global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_args a, unsigned int* __restrict__ interval, float2* __restrict__ walk)
 {
     const int N = a.N;
-    // storage coordinates of this column; logical = storage - wrap (mod N)
     const int sx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const bool col_ok = sx < N && sy < N;
+    if (sx >= N || sy >= N) return;
     int x = sx - a.wx; if (x < 0) x += N;
     int y = sy - a.wy; if (y < 0) y += N;
-
     const float* Ri = a.Ri.m;
     const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
     const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
     const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
-    const float v_g_part_norm = __builtin_fmaf(v_g_x, v_g_x, v_g_y * v_g_y);
-    float v_x = __builtin_fmaf(Ri[2], v_g_z0, __builtin_fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * a.intr.fx;
-    float v_y = __builtin_fmaf(Ri[5], v_g_z0, __builtin_fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * a.intr.fy;
-    const float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
-    const float Rcurr_inv_0_z_scaled = Ri[2] * a.cell_z * a.intr.fx;
-    const float Rcurr_inv_1_z_scaled = Ri[5] * a.cell_z * a.intr.fy;
-    const float tranc_dist_inv = 1.0f / a.tranc_dist;
-
-    // ---- conservative z interval (see kt_clip_halfline) ----------------------------------------
-    int z0, z1;
+    int z0 = N, z1 = 0;
     {
+        // camera coordinates (unscaled) at z index 0 and the per-index step: p(z) = A + z * B
         const float ax = Ri[0] * v_g_x + Ri[1] * v_g_y + Ri[2] * v_g_z0;
         const float ay = Ri[3] * v_g_x + Ri[4] * v_g_y + Ri[5] * v_g_z0;
         const float az = Ri[6] * v_g_x + Ri[7] * v_g_y + Ri[8] * v_g_z0;
@@ -160,23 +155,173 @@ __global__ __launch_bounds__(256) void kt_tsdf23_kernel(const kt_tsdf23_args a)
         kt_clip_halfline(uh * az - a.intr.fx * ax, uh * bz - a.intr.fx * bx, flo, fhi);
         kt_clip_halfline(a.intr.fy * ay - vl * az, a.intr.fy * by - vl * bz, flo, fhi);
         kt_clip_halfline(vh * az - a.intr.fy * ay, vh * bz - a.intr.fy * by, flo, fhi);
-        float nlo = lo, nhi = hi;   // near slab: -cell <= p_z <= znear, kept unconditionally
+        // near slab: -cell <= p_z <= znear.  There the pixel coordinates are ill-conditioned, so the slab is kept without
+        // testing them -- but a voxel that close to the camera plane can only project into the image when it is also within
+        // |p_x|, |p_y| <= znear * (image half-size / f) ~ 0.06 m of the optical axis; columns that stay 0.2 m away skip it.
+        float nlo = lo, nhi = hi;
         kt_clip_halfline(az + a.cell_z + a.cell_x + a.cell_y, bz, nlo, nhi);
         kt_clip_halfline(znear - az, -bz, nlo, nhi);
+        if (nlo <= nhi) {
+            const float pxa = ax + nlo * bx, pxb = ax + nhi * bx, pya = ay + nlo * by, pyb = ay + nhi * by;
+            const float rlim = 0.2f;
+            const bool far_x = (pxa > rlim && pxb > rlim) || (pxa < -rlim && pxb < -rlim);
+            const bool far_y = (pya > rlim && pyb > rlim) || (pya < -rlim && pyb < -rlim);
+            if (far_x || far_y) { nlo = 1e30f; nhi = -1e30f; }
+        }
         float l = 1e30f, h = -1e30f;
         if (flo <= fhi) { l = fminf(l, flo); h = fmaxf(h, fhi); }
         if (nlo <= nhi) { l = fminf(l, nlo); h = fmaxf(h, nhi); }
-        if (l > h || !col_ok) { z0 = N; z1 = 0; }
-        else {
+        if (l <= h) {
             z0 = max(0, (int)floorf(l) - 2);
             z1 = min(N, (int)ceilf(h) + 3);
+            if (z0 >= z1) { z0 = N; z1 = 0; }
         }
     }
-    z0 = max(z0, (int)blockIdx.z * KT_TSDF_ZCHUNK);
-    z1 = min(z1, (int)(blockIdx.z + 1) * KT_TSDF_ZCHUNK);
-    if (z0 >= z1) { z0 = N; z1 = 0; }  // this lane has nothing to do in this chunk
-    // All 64 lanes of the wave walk the SAME z sequence (their union interval) with a per-lane predicate, so that every
-    // volume access of the wave is one contiguous 128 B (tsdf) / 256 B (colour) line segment of a single z plane.
+    interval[(size_t)sy * N + sx] = (unsigned int)z0 | ((unsigned int)z1 << 16);
+    // Checkpoints of the incremental walk (quirk A.17: v_x, v_y are DEFINED by repeated float +=, so a wave that starts at
+    // z > 0 must know the value the reference would hold there).  One serial walk per column here, stored at every chunk
+    // boundary inside the interval, replaces a replay from z = 0 in every (column, chunk) wave of the voxel kernel.
+    if (z0 < z1) {
+        float v_x = __builtin_fmaf(Ri[2], v_g_z0, __builtin_fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * a.intr.fx;
+        float v_y = __builtin_fmaf(Ri[5], v_g_z0, __builtin_fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * a.intr.fy;
+        const float dvx = Ri[2] * a.cell_z * a.intr.fx, dvy = Ri[5] * a.cell_z * a.intr.fy;
+        const int cfirst = z0 / KT_TSDF_ZCHUNK, clast = (z1 - 1) / KT_TSDF_ZCHUNK;
+        int z = 0;
+        for (int c = cfirst; c <= clast; ++c) {
+            const int zt = c * KT_TSDF_ZCHUNK;
+            for (; z < zt; ++z) { v_x += dvx; v_y += dvy; }
+            walk[((size_t)c * N + sy) * N + sx] = make_float2(v_x, v_y);
+        }
+    }
+}
+
+// One in-flight batch of KT_TSDF_UNROLL consecutive z steps of a wave: everything phase A produces for phase B.
+struct kt_tsdf_batch {
+    bool in_img[KT_TSDF_UNROLL];
+    unsigned int off[KT_TSDF_UNROLL];   // storage element index of the voxel
+    float vgz[KT_TSDF_UNROLL];
+    kt_pixrec rec[KT_TSDF_UNROLL];
+    short tsdf_raw[KT_TSDF_UNROLL];
+    uchar4 col[KT_TSDF_UNROLL];
+};
+
+// The voxel kernel.  grid = (N/64, N/4, N/KT_TSDF_ZCHUNK); a wave owns 64 consecutive storage x of one y and one z chunk,
+// leaves at once when the pre-pass interval says none of its columns crosses the chunk, and otherwise
+//   - replays the incremental float walk of v_x / v_y from z = 0 (quirk A.17: values are defined by repeated +=),
+//   - then runs the reference loop body KT_TSDF_UNROLL z-steps at a time in two software-pipelined phases:
+//       A  projection of the voxels, then ALL their loads at once -- the 16-byte pixel record and, speculatively for every
+//          voxel that projects into the image, its tsdf and colour words (the update predicate needs the record, so
+//          waiting for it first would double the exposed latency);
+//       B  sdf test, running-average update, stores;
+//     phase A of batch i+1 is issued before phase B of batch i, so one memory latency is exposed per batch at most.
+// Every lane of the wave walks the same z sequence: each volume access is one contiguous 128 B / 256 B segment.
+template <bool COUNT>
+__device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, kt_tsdf_batch& b, int zb, int z0, int z1, unsigned int col_base,
+                                              unsigned int plane, float v_z, float& v_x, float& v_y, float dvx, float dvy, float tab_vgz,
+                                              float tab_zs, int tab_base)
+{
+    const int N = a.N;
+#pragma unroll
+    for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
+        const int z = zb + u;
+        const bool live = z >= z0 && z < z1;
+        const int zz = min(z, N - 1);  // wave-uniform
+        // wave-uniform table entries: broadcast from the lane that holds them (no memory access in the loop)
+        const int tl = zz - tab_base;
+        b.vgz[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tab_vgz), tl));
+        const float z_scaled = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tab_zs), tl));
+        const float inv_z = 1.0f / __builtin_fmaf(a.Ri.m[8], z_scaled, v_z);
+        const int coo_x = kt_f2i_rn(__builtin_fmaf(v_x, inv_z, a.intr.cx));
+        const int coo_y = kt_f2i_rn(__builtin_fmaf(v_y, inv_z, a.intr.cy));
+        b.in_img[u] = live && !(inv_z < 0) && coo_x >= 0 && coo_y >= 0 && coo_x < a.cols && coo_y < a.rows;
+        const int pix = b.in_img[u] ? coo_y * a.cols + coo_x : 0;
+        int sz = zz + a.wz; if (sz >= N) sz -= N;
+        b.off[u] = col_base + (unsigned int)sz * plane;
+        b.rec[u] = a.rec[pix];
+        v_x += dvx;  // the walk advances on every step, also on skipped ones
+        v_y += dvy;
+    }
+#pragma unroll
+    for (int u = 0; u < KT_TSDF_UNROLL; ++u)
+        if (b.in_img[u]) { b.tsdf_raw[u] = a.volume[b.off[u]]; b.col[u] = a.color[b.off[u]]; }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const kt_tsdf_batch& b, float v_g_part_norm, float tranc_dist_inv,
+                                                unsigned int& n_upd)
+{
+#pragma unroll
+    for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
+        if (!b.in_img[u]) continue;
+        float Dp_scaled = b.rec[u].dp;
+        bool no_color = false;
+        if (Dp_scaled < 0.0f) { Dp_scaled = -Dp_scaled; no_color = true; }
+        // Free-space shortcut: tsdf = min(1, sdf / trunc) is exactly 1 well in front of the surface whatever the last bit of
+        // the square root is.  v_sqrt_f32 (<= 1 ulp) decides with a 1e-3 guard band (the exact value differs from the
+        // approximation by < 2e-5 in tsdf units); only voxels inside the band or nearer take the correctly rounded sqrt.
+        const float r2 = __builtin_fmaf(b.vgz[u], b.vgz[u], v_g_part_norm);
+        float sdf = Dp_scaled - __builtin_amdgcn_sqrtf(r2);
+        const bool is_free = sdf * tranc_dist_inv > 1.001f;
+        if (!is_free) sdf = Dp_scaled - __builtin_sqrtf(r2);
+        if (!(Dp_scaled != 0 && (is_free || sdf >= -a.tranc_dist))) continue;
+        const uchar4 c = b.col[u];
+        const float weight_prev = (float)c.w;
+        // free voxel that already holds F = 1 (raw 32767): (1 * W + 1) / (W + 1) == 1 exactly, the stored value stays
+        if (!(is_free && b.tsdf_raw[u] == KT_DIVISOR)) {
+            const float tsdf = is_free ? 1.0f : fminf(1.0f, sdf * tranc_dist_inv);
+            const float tsdf_prev = kt_unpack_tsdf(b.tsdf_raw[u]);
+            a.volume[b.off[u]] = kt_pack_tsdf(__builtin_fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
+        }
+        uchar4 o = c;
+        o.w = kt_f2u8_rz(fminf(weight_prev + 1.0f, KT_MAX_WEIGHT));
+        if (COUNT) ++n_upd;
+        const unsigned int rgbf = b.rec[u].rgbf;
+        const bool normal_nan = (rgbf >> 24) & 1u;
+        if ((!normal_nan && !no_color) || (c.x == 0 && c.y == 0 && c.z == 0)) {
+            // c' = clamp(rint(RN(n / den))): only the INTEGER is stored, so the correctly rounded quotient matters only within
+            // a hair of a half-integer.  q' = n * v_rcp_f32(den) is within 2.4e-7 * q of RN(n / den) (1 ulp reciprocal, two
+            // roundings), i.e. < 7e-5 for q <= 256; if q' is farther than 2e-4 from every half-integer (or clearly above the
+            // clamp) rint(q') is the reference's value.  Otherwise (wave-uniform branch, ~7% of steps) the three IEEE divisions run.
+            const float Wrkc = b.rec[u].wrkc;
+            const float den = weight_prev + Wrkc;
+            const float nx = __builtin_fmaf((float)c.x, weight_prev, Wrkc * (float)(rgbf & 0xffu));
+            const float ny = __builtin_fmaf((float)c.y, weight_prev, Wrkc * (float)((rgbf >> 8) & 0xffu));
+            const float nz = __builtin_fmaf((float)c.z, weight_prev, Wrkc * (float)((rgbf >> 16) & 0xffu));
+            const float rden = __builtin_amdgcn_rcpf(den);
+            float qx = nx * rden, qy = ny * rden, qz = nz * rden;
+            const float tol = 2e-4f;
+            const bool sx_ = qx > 256.5f || fabsf((qx - __builtin_floorf(qx)) - 0.5f) > tol;
+            const bool sy_ = qy > 256.5f || fabsf((qy - __builtin_floorf(qy)) - 0.5f) > tol;
+            const bool sz_ = qz > 256.5f || fabsf((qz - __builtin_floorf(qz)) - 0.5f) > tol;
+            const bool safe = sx_ && sy_ && sz_;   // false for NaN (0 / 0)
+            if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
+                if (!safe) { qx = nx / den; qy = ny / den; qz = nz / den; }
+            }
+            o.x = (unsigned char)min(255, max(0, kt_f2i_rn(qx)));
+            o.y = (unsigned char)min(255, max(0, kt_f2i_rn(qy)));
+            o.z = (unsigned char)min(255, max(0, kt_f2i_rn(qz)));
+        }
+        a.color[b.off[u]] = o;
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args a)
+{
+    const int N = a.N;
+    const int lane = threadIdx.x & 63;
+    // grid = (N/4 y-groups, N/64 x-groups, chunks): workgroup b runs on XCD b % 8, so the fastest grid index is y -- the
+    // frustum covers only a few of the 64-wide x-groups and an x-fastest order would leave most XCDs idle
+    const int sx = blockIdx.y * 64 + lane;
+    const int sy = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int z0 = N, z1 = 0;
+    if (sx < N && sy < N) {
+        const unsigned int iv = a.interval[(size_t)sy * N + sx];
+        z0 = max((int)(iv & 0xffffu), (int)blockIdx.z * KT_TSDF_ZCHUNK);
+        z1 = min((int)(iv >> 16), (int)(blockIdx.z + 1) * KT_TSDF_ZCHUNK);
+        if (z0 >= z1) { z0 = N; z1 = 0; }
+    }
+    // the wave's union interval inside this chunk (wave-uniform)
     int wz0 = z0, wz1 = z1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -187,89 +332,52 @@ __global__ __launch_bounds__(256) void kt_tsdf23_kernel(const kt_tsdf23_args a)
     wz1 = __builtin_amdgcn_readfirstlane(wz1);
     if (wz0 >= wz1) return;
 
-    // ---- replay the incremental walk up to the wave's first z -----------------------------------
-    for (int z = 0; z < wz0; ++z) {
-        v_x += Rcurr_inv_0_z_scaled;
-        v_y += Rcurr_inv_1_z_scaled;
+    const float* Ri = a.Ri.m;
+    const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
+    const float dvx = Ri[2] * a.cell_z * a.intr.fx;   // Rcurr_inv_0_z_scaled
+    const float dvy = Ri[5] * a.cell_z * a.intr.fy;   // Rcurr_inv_1_z_scaled
+    const float tranc_dist_inv = 1.0f / a.tranc_dist;
+    const unsigned int plane = (unsigned int)N * (unsigned int)N;
+    unsigned int n_upd = 0, n_batches = 0;
+    int x = sx - a.wx; if (x < 0) x += N;
+    int y = sy - a.wy; if (y < 0) y += N;
+    const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
+    const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
+    const float v_g_part_norm = __builtin_fmaf(v_g_x, v_g_x, v_g_y * v_g_y);
+    const float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
+    // the walk resumes from the pre-pass checkpoint of this chunk (valid for every lane whose interval touches the chunk;
+    // the other lanes are never live) and advances to the wave's first z
+    float v_x = 0.f, v_y = 0.f;
+    if (z0 < z1) {
+        const float2 cp = a.walk[((size_t)blockIdx.z * N + sy) * N + sx];
+        v_x = cp.x; v_y = cp.y;
     }
-
-    const size_t plane = (size_t)N * N;
-    const size_t col_base = (size_t)sx + (size_t)sy * N;
-    unsigned int n_upd = 0;
-
+    for (int z = (int)blockIdx.z * KT_TSDF_ZCHUNK; z < wz0; ++z) {
+        v_x += dvx;
+        v_y += dvy;
+    }
+    const unsigned int col_base = (unsigned int)min(sx, N - 1) + (unsigned int)min(sy, N - 1) * (unsigned int)N;
+    // the chunk's slice of the z-walk tables, one entry per lane (KT_TSDF_ZCHUNK <= 64 == wave size)
+    const int tab_base = (int)blockIdx.z * KT_TSDF_ZCHUNK;
+    const float tab_vgz = a.vgz[min(tab_base + lane, N - 1)];
+    const float tab_zs = a.zs[min(tab_base + lane, N - 1)];
+    // Latency is hidden by occupancy (8 waves per SIMD, one z-chunk each) rather than by cross-iteration software
+    // pipelining: hipcc's s_waitcnt insertion cannot count loads that are still in flight across a loop back-edge and
+    // falls back to vmcnt(0), which serialises a hand-rotated pipeline anyway.
     for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
-        bool in_img[KT_TSDF_UNROLL];
-        int pix[KT_TSDF_UNROLL];
-        float vgz[KT_TSDF_UNROLL];
-        // phase 1: projection of the 4 voxels (walk advances on every step, also on skipped ones)
-#pragma unroll
-        for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
-            const int z = zb + u;
-            const bool live = z >= z0 && z < z1;
-            const int zz = min(z, N - 1);  // wave-uniform index: scalar loads
-            vgz[u] = a.vgz[zz];
-            const float z_scaled = a.zs[zz];
-            const float inv_z = 1.0f / __builtin_fmaf(Ri[8], z_scaled, v_z);
-            const int coo_x = kt_f2i_rn(__builtin_fmaf(v_x, inv_z, a.intr.cx));
-            const int coo_y = kt_f2i_rn(__builtin_fmaf(v_y, inv_z, a.intr.cy));
-            in_img[u] = live && !(inv_z < 0) && coo_x >= 0 && coo_y >= 0 && coo_x < a.cols && coo_y < a.rows;
-            pix[u] = in_img[u] ? coo_y * a.cols + coo_x : 0;
-            v_x += Rcurr_inv_0_z_scaled;
-            v_y += Rcurr_inv_1_z_scaled;
-        }
-        // phase 2: the per-pixel records (one 16-byte gather each)
-        kt_pixrec rec[KT_TSDF_UNROLL];
-#pragma unroll
-        for (int u = 0; u < KT_TSDF_UNROLL; ++u) rec[u] = a.rec[pix[u]];
-        // phase 3: sdf test, then the voxel loads
-        bool upd[KT_TSDF_UNROLL], no_color[KT_TSDF_UNROLL];
-        float sdf[KT_TSDF_UNROLL];
-        size_t idx[KT_TSDF_UNROLL];
-        short tsdf_raw[KT_TSDF_UNROLL];
-        uchar4 col[KT_TSDF_UNROLL];
-#pragma unroll
-        for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
-            float Dp_scaled = rec[u].dp;
-            no_color[u] = false;
-            if (Dp_scaled < 0.0f) { Dp_scaled = -Dp_scaled; no_color[u] = true; }
-            sdf[u] = Dp_scaled - __builtin_sqrtf(__builtin_fmaf(vgz[u], vgz[u], v_g_part_norm));
-            upd[u] = in_img[u] && Dp_scaled != 0 && sdf[u] >= -a.tranc_dist;
-            int sz = zb + u + a.wz; if (sz >= N) sz -= N;
-            idx[u] = col_base + (size_t)sz * plane;
-        }
-#pragma unroll
-        for (int u = 0; u < KT_TSDF_UNROLL; ++u)
-            if (upd[u]) { tsdf_raw[u] = a.volume[idx[u]]; col[u] = a.color[idx[u]]; }
-        // phase 4: update + store
-#pragma unroll
-        for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
-            if (!upd[u]) continue;
-            const float tsdf = fminf(1.0f, sdf[u] * tranc_dist_inv);
-            const float tsdf_prev = kt_unpack_tsdf(tsdf_raw[u]);
-            const uchar4 c = col[u];
-            const float weight_prev = (float)c.w;
-            a.volume[idx[u]] = kt_pack_tsdf(__builtin_fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
-            uchar4 o = c;
-            o.w = kt_f2u8_rz(fminf(weight_prev + 1.0f, KT_MAX_WEIGHT));
-            if (COUNT) ++n_upd;
-            const bool normal_nan = (rec[u].rgbf >> 24) & 1u;
-            if ((!normal_nan && !no_color[u]) || (c.x == 0 && c.y == 0 && c.z == 0)) {
-                const float Wrkc = rec[u].wrkc;
-                const float den = weight_prev + Wrkc;
-                const float new_x = __builtin_fmaf((float)c.x, weight_prev, Wrkc * (float)(rec[u].rgbf & 0xffu)) / den;
-                const float new_y = __builtin_fmaf((float)c.y, weight_prev, Wrkc * (float)((rec[u].rgbf >> 8) & 0xffu)) / den;
-                const float new_z = __builtin_fmaf((float)c.z, weight_prev, Wrkc * (float)((rec[u].rgbf >> 16) & 0xffu)) / den;
-                o.x = (unsigned char)min(255, max(0, kt_f2i_rn(new_x)));
-                o.y = (unsigned char)min(255, max(0, kt_f2i_rn(new_y)));
-                o.z = (unsigned char)min(255, max(0, kt_f2i_rn(new_z)));
-            }
-            a.color[idx[u]] = o;
-        }
+        kt_tsdf_batch cur;
+        kt_tsdf_issue<COUNT>(a, cur, zb, z0, z1, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base);
+        kt_tsdf_consume<COUNT>(a, cur, v_g_part_norm, tranc_dist_inv, n_upd);
+        if (COUNT) ++n_batches;
     }
     if (COUNT) {
-        // wave-level sum, one atomic per wave
+        // wave-level sum, one atomic per wave; [1] = wave batches, [2] = active wave-chunks (diagnostics)
         for (int off = 32; off > 0; off >>= 1) n_upd += __shfl_down(n_upd, off, 64);
-        if ((threadIdx.x & 63) == 0 && n_upd) atomicAdd(a.updated, n_upd);
+        if (lane == 0) {
+            if (n_upd) atomicAdd(a.updated, n_upd);
+            atomicAdd(a.updated + 1, n_batches);
+            atomicAdd(a.updated + 2, 1u);
+        }
     }
 }
 
@@ -278,6 +386,8 @@ struct kt_integrate_scratch {
     kt_pixrec* rec = nullptr; size_t rec_px = 0;
     float* vgz = nullptr; float* zs = nullptr; int tabN = 0;
     float* tab_host[2] = {nullptr, nullptr};  // pinned staging of {vgz[N], zs[N]}, double-buffered
+    unsigned int* interval = nullptr;          // N * N column intervals
+    float2* walk = nullptr;                    // chunk checkpoints of the z walk
     int flip = 0;
 };
 static thread_local kt_integrate_scratch g_scratch;  // one GPU thread per context (SURVEY 8b threading)
@@ -294,7 +404,13 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
     if (s.tabN < N) {
         KT_HIP(hipStreamSynchronize(c->stream));
         if (s.vgz) KT_HIP(hipFree(s.vgz));
-        s.vgz = s.zs = nullptr; s.tabN = 0;
+        if (s.interval) KT_HIP(hipFree(s.interval));
+        if (s.walk) KT_HIP(hipFree(s.walk));
+        s.walk = nullptr;
+        s.vgz = s.zs = nullptr; s.interval = nullptr; s.tabN = 0;
+        KT_HIP(hipMalloc((void**)&s.interval, sizeof(unsigned int) * (size_t)N * N));
+        KT_HIP(hipMalloc((void**)&s.walk, sizeof(float2) * (size_t)N * N * kt_div_up(N, KT_TSDF_ZCHUNK)));
+
         KT_HIP(hipMalloc((void**)&s.vgz, sizeof(float) * 2 * N));
         s.zs = s.vgz + N;
         for (int k = 0; k < 2; ++k) {
@@ -353,7 +469,12 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     for (int k = 0; k < 3; ++k) KT_ARG(voxel_wrap[k] >= 0);  // vWrapCopy is always normalised (KintinuousTracker.cpp:1075-1085)
     a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
     a.cols = cols; a.rows = rows; a.N = N;
-    dim3 b(256), g(kt_div_up(N, 64), kt_div_up(N, 4), kt_div_up(N, KT_TSDF_ZCHUNK));
+    KT_ARG(N <= 4096);
+    a.interval = g_scratch.interval;
+    a.walk = g_scratch.walk;
+    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(kt_div_up(N, 64), kt_div_up(N, 4)), dim3(256), 0, c->stream, a, g_scratch.interval, g_scratch.walk);
+    KT_LAUNCH_CHECK();
+    dim3 b(256), g(kt_div_up(N, 4), kt_div_up(N, 64), kt_div_up(N, KT_TSDF_ZCHUNK));
     if (kt_tsdf23_hook.on) KT_HIP(hipEventRecord(kt_tsdf23_hook.ev[0], c->stream));
     if (updated_dev) hipLaunchKernelGGL(kt_tsdf23_kernel<true>, g, b, 0, c->stream, a);
     else hipLaunchKernelGGL(kt_tsdf23_kernel<false>, g, b, 0, c->stream, a);
@@ -409,6 +530,22 @@ struct kt_rc {
         gx = kt_f2i_rd(px / a.cx_);
         gy = kt_f2i_rd(py / a.cy_);
         gz = kt_f2i_rd(pz / a.cz_);
+    }
+    // getVoxel for the march loop.  floor(RN(p / cell)) is needed bit-exactly, but the quotient itself only matters next
+    // to an integer: q' = p * RN(1 / cell) differs from RN(p / cell) by at most 3 * 2^-24 * |q| (< 1e-4 for |q| <= 512), so
+    // whenever q' is farther than 2e-4 from an integer (and |q'| < 1024) floor(q') is the reference's voxel.  Lanes that are
+    // not provably safe take the correctly rounded division; the branch is wave-uniform and rare (~7% of wave steps).
+    __device__ __forceinline__ void voxel_fast(float px, float py, float pz, float rcx, float rcy, float rcz, int& gx, int& gy, int& gz) const
+    {
+        float qx = px * rcx, qy = py * rcy, qz = pz * rcz;
+        const float fx = qx - __builtin_floorf(qx), fy = qy - __builtin_floorf(qy), fz = qz - __builtin_floorf(qz);
+        const float lo = 2e-4f, hi = 1.0f - 2e-4f;
+        const bool safe = fx > lo && fx < hi && fy > lo && fy < hi && fz > lo && fz < hi &&
+                          fabsf(qx) < 1024.f && fabsf(qy) < 1024.f && fabsf(qz) < 1024.f;
+        if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
+            if (!safe) { qx = px / a.cx_; qy = py / a.cy_; qz = pz / a.cz_; }
+        }
+        gx = kt_f2i_rd(qx); gy = kt_f2i_rd(qy); gz = kt_f2i_rd(qz);
     }
     // interpolateTrilineary / ...Color / ...Heat bodies, ray_caster.cu:160-296.  CH < 0: tsdf.
     template <int CH>
@@ -536,23 +673,45 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
             // only the SIGN of the nearest-voxel tsdf steers the march: compare the packed shorts directly
             int tsdf = a.volume[rc.index(gx, gy, gz)];
             const float max_time = 3 * (a.vsx + a.vsy + a.vsz);
+            const float rcx = 1.0f / a.cx_, rcy = 1.0f / a.cy_, rcz = 1.0f / a.cz_;
             // The march (ray_caster.cu:340-352) visits time_curr, time_curr + step, ... one dependent gather per step.
             // The addresses do not depend on the loaded values, so KT_RC_BATCH steps are issued together and the exit
             // tests are then replayed in order; loads past the exit point are speculative and always in bounds.
+            // The loop below is branch-free per step (selects instead of breaks) with 32-bit voxel offsets; the only
+            // branches are the wave-uniform slow path of the voxel index and the batch-level exit.
             bool crossing = false, done = false;
             float t_cross = 0.f;
-            while (!done) {
+            const unsigned int uN = (unsigned int)N;
+            while (true) {
                 float tc[KT_RC_BATCH];
-                size_t gi[KT_RC_BATCH];
+                unsigned int gi[KT_RC_BATCH];
                 bool inb[KT_RC_BATCH];
                 float t = time_curr;
 #pragma unroll
                 for (int k = 0; k < KT_RC_BATCH; ++k) {
                     tc[k] = t;
                     const float tn = t + a.time_step;
-                    rc.voxel(__builtin_fmaf(rd.x, tn, rs.x), __builtin_fmaf(rd.y, tn, rs.y), __builtin_fmaf(rd.z, tn, rs.z), gx, gy, gz);
-                    inb[k] = (gx >= 0 && gy >= 0 && gz >= 0 && gx < N && gy < N && gz < N);  // checkInds
-                    gi[k] = inb[k] ? rc.index(gx, gy, gz) : 0;
+                    const float px = __builtin_fmaf(rd.x, tn, rs.x), py = __builtin_fmaf(rd.y, tn, rs.y), pz = __builtin_fmaf(rd.z, tn, rs.z);
+                    // getVoxel: floor(RN(p / cell)), via p * RN(1 / cell) when provably identical (see kt_rc::voxel_fast)
+                    float qx = px * rcx, qy = py * rcy, qz = pz * rcz;
+                    float flx = __builtin_floorf(qx), fly = __builtin_floorf(qy), flz = __builtin_floorf(qz);
+                    const float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+                    const float lo = 2e-4f, hi = 1.0f - 2e-4f;
+                    const bool safe = fx > lo && fx < hi && fy > lo && fy < hi && fz > lo && fz < hi &&
+                                      fabsf(qx) < 1024.f && fabsf(qy) < 1024.f && fabsf(qz) < 1024.f;
+                    if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
+                        if (!safe) {
+                            flx = __builtin_floorf(px / a.cx_);
+                            fly = __builtin_floorf(py / a.cy_);
+                            flz = __builtin_floorf(pz / a.cz_);
+                        }
+                    }
+                    const unsigned int ux = (unsigned int)kt_cvt_i32(flx), uy = (unsigned int)kt_cvt_i32(fly), uz = (unsigned int)kt_cvt_i32(flz);
+                    inb[k] = ux < uN && uy < uN && uz < uN;  // checkInds (negative indices wrap to huge unsigned values)
+                    unsigned int X = ux + (unsigned int)a.wx; X -= (X >= uN) ? uN : 0u;
+                    unsigned int Y = uy + (unsigned int)a.wy; Y -= (Y >= uN) ? uN : 0u;
+                    unsigned int Z = uz + (unsigned int)a.wz; Z -= (Z >= uN) ? uN : 0u;
+                    gi[k] = inb[k] ? (Z * uN + Y) * uN + X : 0u;
                     t += a.time_step;
                 }
                 short v[KT_RC_BATCH];
@@ -560,15 +719,19 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
                 for (int k = 0; k < KT_RC_BATCH; ++k) v[k] = a.volume[gi[k]];
 #pragma unroll
                 for (int k = 0; k < KT_RC_BATCH; ++k) {
-                    if (done) break;
-                    if (!(tc[k] < max_time) || !inb[k]) { done = true; break; }
-                    const int tsdf_prev = tsdf;
-                    tsdf = v[k];
-                    if (COUNT) ++steps;
-                    if (tsdf_prev < 0 && tsdf > 0) { done = true; break; }
-                    if (tsdf_prev > 0 && tsdf < 0) { crossing = true; t_cross = tc[k]; done = true; break; }
+                    // for (; time_curr < max_time; ...) { if (!checkInds) break; ... }  replayed with selects
+                    const bool alive = !done && (tc[k] < max_time) && inb[k];
+                    const int cur = v[k];
+                    const bool mp = alive && tsdf < 0 && cur > 0;   // - -> + : leave without a hit
+                    const bool pm = alive && tsdf > 0 && cur < 0;   // + -> - : zero crossing
+                    if (COUNT) steps += alive ? 1u : 0u;
+                    t_cross = pm ? tc[k] : t_cross;
+                    crossing = crossing || pm;
+                    tsdf = alive ? cur : tsdf;
+                    done = done || !alive || mp || pm;
                 }
                 time_curr = t;
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
             }
             if (crossing) {  // zero crossing, ray_caster.cu:354-422
                 time_curr = t_cross;
