@@ -202,6 +202,8 @@ int kt_tracker_last_counts(kt_tracker* t, unsigned long long* U, unsigned long l
 /* diagnostics of the last counted integrate: {U, wave batches of 4 z-steps, active wave-chunks, sum and max of the active
  * waves' durations, sum of their issue and consume phases (10 ns ticks), 0} */
 int kt_tracker_debug_counts(kt_tracker* t, unsigned int out8_host[8]);
+/* diagnostics: the 29 ICP sums stashed by the last joint RGB-D + ICP iteration (or timing probes in instrumented builds) */
+int kt_tracker_debug_state(kt_tracker* t, float out29_host[29]);
 
 /* ---- multi-GPU: independent streams, one tracker per GPU; poses are gathered by the caller's
  * collective (bench.py / the CLI use RCCL all_gather on the buffer filled here) ---- */

@@ -122,6 +122,7 @@ _PROTOS = {
     "kt_tracker_enable_counts": (_i, [_vp, _i]),
     "kt_tracker_last_counts": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "kt_tracker_debug_counts": (_i, [_vp, C.POINTER(C.c_uint)]),
+    "kt_tracker_debug_state": (_i, [_vp, _pf]),
     "kt_tracker_export_poses_device": (_i, [_vp, _i, _vp]),
 }
 
@@ -419,6 +420,11 @@ class Tracker:
         U, S = C.c_ulonglong(0), C.c_ulonglong(0)
         _chk(lib().kt_tracker_last_counts(self.h, C.byref(U), C.byref(S)))
         return int(U.value), int(S.value)
+
+    def debug_state(self):
+        o = (C.c_float * 29)()
+        _chk(lib().kt_tracker_debug_state(self.h, o))
+        return [float(v) for v in o]
 
     def debug_counts(self):
         o = (C.c_uint * 8)()

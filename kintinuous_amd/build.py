@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src):
         obj = os.path.join(BUILD_DIR, os.path.splitext(src)[0] + ".o")
-        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc] + FLAGS + os.environ.get("KT_EXTRA_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

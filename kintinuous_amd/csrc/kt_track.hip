@@ -55,10 +55,17 @@ __device__ __constant__ unsigned char KT_PB[28] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3,
 
 // Phases 2..end of the reduction.  RowFn(i, row[7]) -> found computes one pixel.  Returns true (workgroup-uniformly) in
 // the workgroup that retired last; there total[0..28] (LDS) holds the grid sums.
+#ifdef KT_ICP_TIMING
+#define KT_TS(i) do { if (threadIdx.x == 0) kt_ts[i] = wall_clock64(); } while (0)
+__shared__ unsigned long long kt_ts[8];
+#else
+#define KT_TS(i) do {} while (0)
+#endif
 template <typename RowFn>
 __device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, float* __restrict__ partials, unsigned int* __restrict__ ticket,
                                             float (&total)[KT_RED_SLOTS])
 {
+    KT_TS(0);
     __shared__ float rows[KT_KBATCH][8][32];
     __shared__ bool is_last;
     const int tid = threadIdx.x;
@@ -94,6 +101,7 @@ __device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, float* __res
         }
         __syncthreads();
     }
+    KT_TS(1);
     // warp tree: the 32 lanes of a half-wave hold product `comp` of the 32 virtual threads of this CUDA warp
     const float wsum = kt_warp32_sum(acc);
     if (comp < 29 && vt == 0) {
@@ -101,12 +109,14 @@ __device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, float* __res
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    KT_TS(2);
     if (tid == 0) {
         const unsigned int t = atomicAdd(ticket, 1u);
         is_last = (t == gridDim.x - 1);
         if (is_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
     }
     __syncthreads();
+    KT_TS(3);
     if (!is_last) return false;
     // blockReduceSum second stage (reduce.cu:131-164) per CUDA block b: lanes 0..3 hold the warp sums, lanes 4..31 zero;
     // offsets 16, 8, 4 add zeros, offset 2 gives s0+s2 and s1+s3, offset 1 adds them.  Then reduceSum<<<1, 512>>>
@@ -132,6 +142,7 @@ __device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, float* __res
         }
     }
     __syncthreads();
+    KT_TS(4);
     return true;
 }
 
@@ -217,6 +228,9 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
             a.state->last_residual[0] = h[27];
             a.state->last_residual[1] = h[28];
             kt_solve_and_update(a.state, dA, db);
+#ifdef KT_ICP_TIMING
+            { const unsigned long long t5 = wall_clock64(); for (int q = 0; q < 5; ++q) a.state->icp29[q] = (float)(kt_ts[q + 0] - kt_ts[0]); a.state->icp29[5] = (float)(t5 - kt_ts[0]); }
+#endif
         } else {  // KT_MODE_ICP_STASH: joint RGB-D + ICP, the rgb kernel's epilogue combines and solves
             for (int k = 0; k < 29; ++k) a.state->icp29[k] = h[k];
         }

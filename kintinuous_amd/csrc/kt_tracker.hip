@@ -665,6 +665,12 @@ int kt_tracker_enable_counts(kt_tracker* t, int on)
     t->counting = on;
     return KT_OK;
 }
+int kt_tracker_debug_state(kt_tracker* t, float* out29)
+{
+    KT_ARG(t && out29);
+    memcpy(out29, t->state_host->icp29, 29 * sizeof(float));
+    return KT_OK;
+}
 int kt_tracker_debug_counts(kt_tracker* t, unsigned int* out4)
 {
     KT_ARG(t && out4);

@@ -1,0 +1,13 @@
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from kintinuous_amd import abi, synth
+cam = synth.Camera()
+_, frames, traj, kw = synth.sequence("orbit", 6, cam)
+ctx = abi.Ctx(0)
+cfg = abi.TrackerConfig(cam.cols, cam.rows, 512, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
+trk = abi.Tracker(ctx, cfg)
+for k, (d, rgb) in enumerate(frames):
+    trk.process_frame_host(d, rgb, k)
+# state_dev is private; read icp29 of the last iteration (level 0) through the pinned host mirror offset: use debug hook
+print("ticks(10ns) from kernel start of last block: after loop, after publish, after ticket, after fold, after solve:", trk.debug_state()[:6])
