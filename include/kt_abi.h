@@ -146,6 +146,18 @@ int kt_extract_cloud_slice(kt_ctx* ctx, const int16_t* volume, const float volum
                            int minX, int maxX, int minY, int maxY, int minZ, int maxZ, int subsample,
                            const int real_voxel_wrap[3], int N, size_t* count_host);
 
+/* ---- host math of one Gauss-Newton step (no GPU work), for callers that drive kt_icp_step / kt_rgb_step themselves ----
+ * dA.ldlt().solve(db)  ICPOdometry.cpp:130 (Eigen LDLT<6x6 double>: pivoted, pseudo-inverse of D); A row-major */
+int kt_host_ldlt_solve6(const double A[36], const double b[6], double x[6]);
+/* cv::Rodrigues(rvec, R)  OdometryProvider.h:63 */
+int kt_host_rodrigues(const double r[3], double R_out[9]);
+/* Eigen Matrix3f::inverse()  ICPOdometry.cpp:77 */
+int kt_host_mat33_inverse(const float m[9], float out[9]);
+/* resultRt = [Rodrigues(x[3..5]) | x[0..2]] * resultRt;  [Rcurr | tcurr] = [Rprev | tprev] * resultRt^-1 (float)
+ * ICPOdometry.cpp:133-178 */
+int kt_host_pose_update(const double x[6], double resultRt[16], const float Rprev[9], const float tprev[3],
+                        float Rcurr[9], float tcurr[3]);
+
 /* ---- frame-level tracker (KintinuousTracker::processFrame, KintinuousTracker.cpp:444-915) ----
  * Device-resident fast path: the whole per-frame pipeline is enqueued on the context stream, the ICP /
  * RGB-D Gauss-Newton iterations solve and update the pose on the device (no host round trip per
@@ -182,6 +194,10 @@ int kt_tracker_get_voxel_wrap(kt_tracker* t, int wrap_host[3]);
 int kt_tracker_num_slices(kt_tracker* t);
 int kt_tracker_slice_info(kt_tracker* t, int i, size_t* n_points, int* dimension);
 int kt_tracker_slice_points(kt_tracker* t, int i, kt_point_xyzrgb* out_host);
+/* the CloudSlice's cameraRotation (row-major), cameraTranslation (= currentGlobalCamera) and utime, CloudSlice.h:110-115 */
+int kt_tracker_slice_pose(kt_tracker* t, int i, float R_host[9], float cam_host[3], uint64_t* ts);
+/* setParked (KintinuousTracker.cpp:988-991): a parked tracker never shifts */
+int kt_tracker_set_parked(kt_tracker* t, int parked);
 /* device pointers of the tracker's volume / maps, for inspection and parity tests */
 int16_t* kt_tracker_volume(kt_tracker* t);
 uint8_t* kt_tracker_color_volume(kt_tracker* t);

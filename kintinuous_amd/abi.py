@@ -55,6 +55,7 @@ assert DATATERM_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 32
 
 _vp, _i, _f, _d, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint64
 _pf = C.POINTER(C.c_float)
+_pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int)
 _pI = C.POINTER(Intr)
 _pM = C.POINTER(Mat33)
@@ -123,6 +124,12 @@ _PROTOS = {
     "kt_tracker_last_counts": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "kt_tracker_debug_counts": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_debug_state": (_i, [_vp, _pf]),
+    "kt_tracker_slice_pose": (_i, [_vp, _i, _pf, _pf, C.POINTER(_u64)]),
+    "kt_tracker_set_parked": (_i, [_vp, _i]),
+    "kt_host_ldlt_solve6": (_i, [_pd, _pd, _pd]),
+    "kt_host_rodrigues": (_i, [_pd, _pd]),
+    "kt_host_mat33_inverse": (_i, [_pf, _pf]),
+    "kt_host_pose_update": (_i, [_pd, _pd, _pf, _pf, _pf, _pf]),
     "kt_tracker_export_poses_device": (_i, [_vp, _i, _vp]),
 }
 
@@ -433,3 +440,42 @@ class Tracker:
 
     def export_poses_device(self, k: int, dst_ptr: int) -> None:
         _chk(lib().kt_tracker_export_poses_device(self.h, k, dst_ptr))
+
+
+# ---- host math of the Gauss-Newton step (kt_host_*; no GPU needed) ------------------------------------------------
+def _dp(a):
+    return a.ctypes.data_as(_pd)
+
+
+def host_ldlt_solve6(A, b) -> np.ndarray:
+    A = np.ascontiguousarray(A, np.float64).reshape(36)
+    b = np.ascontiguousarray(b, np.float64).reshape(6)
+    x = np.zeros(6, np.float64)
+    _chk(lib().kt_host_ldlt_solve6(_dp(A), _dp(b), _dp(x)))
+    return x
+
+
+def host_rodrigues(r) -> np.ndarray:
+    r = np.ascontiguousarray(r, np.float64).reshape(3)
+    R = np.zeros(9, np.float64)
+    _chk(lib().kt_host_rodrigues(_dp(r), _dp(R)))
+    return R.reshape(3, 3)
+
+
+def host_mat33_inverse(m) -> np.ndarray:
+    m = np.ascontiguousarray(m, np.float32).reshape(9)
+    o = np.zeros(9, np.float32)
+    _chk(lib().kt_host_mat33_inverse(m.ctypes.data_as(_pf), o.ctypes.data_as(_pf)))
+    return o.reshape(3, 3)
+
+
+def host_pose_update(x, result_rt, Rprev, tprev):
+    """Returns (result_rt', Rcurr, tcurr) -- ICPOdometry.cpp:133-178."""
+    x = np.ascontiguousarray(x, np.float64).reshape(6)
+    rt = np.array(result_rt, np.float64).reshape(16).copy()
+    Rp = np.ascontiguousarray(Rprev, np.float32).reshape(9)
+    tp = np.ascontiguousarray(tprev, np.float32).reshape(3)
+    Rc, tc = np.zeros(9, np.float32), np.zeros(3, np.float32)
+    _chk(lib().kt_host_pose_update(_dp(x), _dp(rt), Rp.ctypes.data_as(_pf), tp.ctypes.data_as(_pf),
+                                   Rc.ctypes.data_as(_pf), tc.ctypes.data_as(_pf)))
+    return rt.reshape(4, 4), Rc.reshape(3, 3), tc

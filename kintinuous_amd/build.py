@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libkt_hip.so")
 BUILD_DIR = os.path.join(os.path.dirname(_HERE), "build")
-SOURCES = ["kt_context.hip", "kt_image.hip", "kt_volume.hip", "kt_track.hip", "kt_tracker.hip"]
+SOURCES = ["kt_context.hip", "kt_image.hip", "kt_volume.hip", "kt_track.hip", "kt_tracker.hip", "kt_hostmath.hip"]
 # -ffp-contract=off: a*b+c fuses only where __builtin_fmaf is written (bit-parity with the oracle);
 # IEEE division / sqrt are hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
@@ -65,5 +65,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+HOST_DIR = os.path.join(_HERE, "host")
+HOST_BIN = os.path.join(HOST_DIR, "bin", "kintinuous_hip")
+
+
+def build_host(force: bool = False) -> str:
+    """g++ build of the C++ host shell's headless driver (kintinuous_amd/host/main.cpp) against libkt_hip.so."""
+    deps = [os.path.join(dp, f) for dp, _, fs in os.walk(HOST_DIR) for f in fs if f.endswith((".h", ".hpp", ".cpp"))]
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "kt_abi.h"))
+    if not force and os.path.exists(HOST_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_BIN) for d in deps):
+        return HOST_BIN
+    os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.dirname(_HERE), os.path.join(HOST_DIR, "main.cpp"), "-o", HOST_BIN,
+           "-L", _HERE, "-lkt_hip", "-lz", "-Wl,-rpath,$ORIGIN/../..", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"host shell build failed:\n{r.stderr}")
+    return HOST_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv))

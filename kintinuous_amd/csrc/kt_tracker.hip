@@ -15,7 +15,7 @@
 namespace {
 
 struct DensePose { uint64_t ts; float pose[16]; int is_loop; };   // KintinuousTracker.h:151-169
-struct Slice { std::vector<kt_point_xyzrgb> pts; int dim; };      // CloudSlice.h:28-129 (cloud + dimension)
+struct Slice { std::vector<kt_point_xyzrgb> pts; int dim; float R[9], cam[3]; uint64_t ts; };      // CloudSlice.h:28-129 (cloud + dimension)
 
 enum { ST_PYRAMID = 0, ST_ODOMETRY, ST_SHIFT, ST_INTEGRATE, ST_RAYCAST, ST_RESIZE, ST_TSDF23, ST_COUNT };
 
@@ -32,6 +32,7 @@ struct kt_tracker {
     float initial_rotation[9];
     int voxel_wrap[3], v_wrap_copy[3];
     int global_time;
+    uint64_t current_ts = 0;
     bool parked;
     float Rlast[9], tlast[3];          // rmats_.back(), tvecs_.back()
     float current_global_camera[3];
@@ -421,6 +422,9 @@ static int fetch_slice(kt_tracker* t, const int lo[3], const int hi[3], int dim)
     t->slices.emplace_back();
     Slice& s = t->slices.back();
     s.dim = dim;
+    memcpy(s.R, t->Rlast, sizeof(s.R));                          // rmats_.back(), currentGlobalCamera, current_utime:
+    memcpy(s.cam, t->current_global_camera, sizeof(s.cam));      // KintinuousTracker.cpp:1186-1191
+    s.ts = t->current_ts;
     s.pts.resize(n);
     if (n) {
         KT_HIP(hipMemcpyAsync(s.pts.data(), t->cloud_device, n * sizeof(kt_point_xyzrgb), hipMemcpyDeviceToHost, c->stream));
@@ -435,6 +439,7 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
 {
     KT_ARG(t && depth_raw && colors);
     kt_ctx* c = t->ctx;
+    t->current_ts = timestamp;
     const int cols = t->cfg.cols, rows = t->cfg.rows, N = t->N;
     const bool icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
     const bool rgbd = !icp;
@@ -621,6 +626,20 @@ int kt_tracker_slice_info(kt_tracker* t, int i, size_t* n_points, int* dimension
     KT_ARG(t && i >= 0 && i < (int)t->slices.size() && n_points && dimension);
     *n_points = t->slices[i].pts.size();
     *dimension = t->slices[i].dim;
+    return KT_OK;
+}
+int kt_tracker_set_parked(kt_tracker* t, int parked)
+{
+    KT_ARG(t);
+    t->parked = parked != 0;
+    return KT_OK;
+}
+int kt_tracker_slice_pose(kt_tracker* t, int i, float* R, float* cam, uint64_t* ts)
+{
+    KT_ARG(t && i >= 0 && i < (int)t->slices.size());
+    if (R) memcpy(R, t->slices[i].R, 9 * sizeof(float));
+    if (cam) memcpy(cam, t->slices[i].cam, 3 * sizeof(float));
+    if (ts) *ts = t->slices[i].ts;
     return KT_OK;
 }
 int kt_tracker_slice_points(kt_tracker* t, int i, kt_point_xyzrgb* out)

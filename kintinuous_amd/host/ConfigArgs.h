@@ -1,0 +1,83 @@
+// ConfigArgs.h -- the command-line options of the reference that reach the tracking + fusion path
+// (utils/ConfigArgs.h:36-75, 111-200).  Options of the GUI / backend (-v, -m, -od, -il, ...) are accepted and ignored so
+// reference command lines keep working.  Additions: -n <N> volume resolution (the reference's compile-time VOL),
+// -w/-h image size, -o <prefix> output prefix (the reference derives saveFile from the log name).
+#pragma once
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+class ConfigArgs {
+  public:
+    static const ConfigArgs& get(int argc = 0, char** argv = 0)
+    {
+        static const ConfigArgs instance(argc, argv);
+        return instance;
+    }
+
+    static void usage(const std::string argv0)
+    {
+        std::fprintf(stderr,
+                     "Usage: %s [Options]\n"
+                     "  -l <log.klg>   log file (raw or zlib depth, raw rgb)\n"
+                     "  -c <calib>     calibration file: fx fy cx cy\n"
+                     "  -s <metres>    volume size (default 6)\n"
+                     "  -t <voxels>    voxel shift threshold (default 14)\n"
+                     "  -g <gpu>       device\n"
+                     "  -n <N>         volume resolution (default 512)\n"
+                     "  -r | -ri       RGB-D odometry | RGB-D + ICP odometry\n"
+                     "  -fod           fast odometry,  -sm static mode,  -dc no colour angle weight,  -no no overlap\n"
+                     "  -f             flip colours (RGB <-> BGR)\n"
+                     "  -tum           write poses with timestamps in seconds (TUM format; the .poses default)\n"
+                     "  -o <prefix>    output prefix (default: the log name)\n",
+                     argv0.c_str());
+    }
+
+    std::string calibrationFile, logFile, trajectoryFile, saveFile;
+    int gpu, voxelShift, volumeResolution, width, height, totalNumFrames;
+    float volumeSize;
+    bool staticMode, flipColors, extractOverlap, useRGBD, useRGBDICP, disableColorAngleWeight, fastOdometry, help;
+
+  private:
+    static bool flag(int argc, char** argv, const char* name)
+    {
+        for (int i = 1; i < argc; ++i)
+            if (std::strcmp(argv[i], name) == 0) return true;
+        return false;
+    }
+    static const char* value(int argc, char** argv, const char* name)
+    {
+        for (int i = 1; i + 1 < argc; ++i)
+            if (std::strcmp(argv[i], name) == 0) return argv[i + 1];
+        return 0;
+    }
+
+    ConfigArgs(int argc, char** argv)
+        : gpu(0), voxelShift(14), volumeResolution(512), width(640), height(480), totalNumFrames(0), volumeSize(6.0f)
+    {
+        const char* v;
+        if ((v = value(argc, argv, "-c"))) calibrationFile = v;
+        if ((v = value(argc, argv, "-l"))) logFile = v;
+        if ((v = value(argc, argv, "-p"))) trajectoryFile = v;
+        if ((v = value(argc, argv, "-g"))) gpu = std::atoi(v);
+        if ((v = value(argc, argv, "-t"))) voxelShift = std::atoi(v);
+        if ((v = value(argc, argv, "-n"))) volumeResolution = std::atoi(v);
+        if ((v = value(argc, argv, "-w"))) width = std::atoi(v);
+        if ((v = value(argc, argv, "-h"))) height = std::atoi(v);
+        if ((v = value(argc, argv, "-s"))) volumeSize = (float)std::atof(v);
+        if ((v = value(argc, argv, "-fl"))) totalNumFrames = std::atoi(v);
+        staticMode = flag(argc, argv, "-sm");
+        flipColors = flag(argc, argv, "-f");
+        extractOverlap = !flag(argc, argv, "-no");
+        useRGBD = flag(argc, argv, "-r");
+        useRGBDICP = flag(argc, argv, "-ri");
+        disableColorAngleWeight = flag(argc, argv, "-dc");
+        fastOdometry = flag(argc, argv, "-fod");
+        help = flag(argc, argv, "--help");
+        if (useRGBDICP) useRGBD = false;  // ConfigArgs.h: -ri wins over -r
+        if ((v = value(argc, argv, "-o"))) saveFile = v;
+        else saveFile = logFile;
+    }
+};

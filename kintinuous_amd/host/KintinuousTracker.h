@@ -1,0 +1,441 @@
+// KintinuousTracker.h -- the per-frame tracking + fusion front end with the reference's public surface
+// (frontend/KintinuousTracker.h:82-276, KintinuousTracker.cpp:71-1050).  Two execution paths with identical results:
+//   * device-resident (default): one kt_tracker_process_frame call; the Gauss-Newton iterations, shift clears and the
+//     predicted-map pyramid stay on the GPU, one host sync per frame;
+//   * operator path (operatorPath = true): the frame is composed on the host from the internal.h operators exactly as the
+//     reference composes it (bilateralFilter, pyrDown, createVMap, ..., ICPOdometry, integrateTsdfVolume, raycast,
+//     resizeVMap) -- the drop-in granularity of the reference, one sync per operator.  ICP odometry only.
+// Not carried over: GUI image generation (getImage / getModelDepth / liveTsdf), place-recognition buffering and the
+// ground-truth trajectory provider: they are outside the tracked path.
+#pragma once
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "CloudSlice.h"
+#include "ConfigArgs.h"
+#include "ICPOdometry.h"
+#include "Resolution.h"
+#include "TSDFVolume.h"
+#include "Volume.h"
+
+class KintinuousTracker {
+  public:
+    class DensePose {  // KintinuousTracker.h:151-169
+      public:
+        DensePose(uint64_t timestamp, const kt::Matrix4f& pose, bool isLoopPose) : timestamp(timestamp), pose(pose), isLoopPose(isLoopPose) {}
+        DensePose() : timestamp(0), isLoopPose(false) {}
+        uint64_t timestamp;
+        kt::Matrix4f pose;
+        bool isLoopPose;
+    };
+
+    std::vector<DensePose> densePoseGraph;
+    CloudSlice::Odometry lastOdometry;
+
+    // depthIntrinsics: fx, fy, cx, cy of the depth camera (the reference passes the 3x3 K as a cv::Mat)
+    explicit KintinuousTracker(const Intr& depthIntrinsics, bool operatorPath = false)
+        : lastOdometry(CloudSlice::ICP), intr(depthIntrinsics), operatorPath(operatorPath), fast(0), tsdf_volume_(0), color_volume_(0),
+          icp(0), overlap(0), parked(false), global_time_(0), current_utime(0), nextSlice(0)
+    {
+        const ConfigArgs& args = ConfigArgs::get();
+        N = Volume::get().getResolution();
+        if (!operatorPath) {
+            kt_tracker_config cfg = {};
+            cfg.cols = Resolution::get().cols();
+            cfg.rows = Resolution::get().rows();
+            cfg.N = N;
+            cfg.fx = intr.fx; cfg.fy = intr.fy; cfg.cx = intr.cx; cfg.cy = intr.cy;
+            cfg.volume_size = Volume::get().getVolumeSize();
+            cfg.voxel_shift = args.voxelShift;
+            cfg.overlap = 0;
+            cfg.static_mode = args.staticMode;
+            cfg.use_rgbd = args.useRGBD;
+            cfg.use_rgbd_icp = args.useRGBDICP;
+            cfg.fast_odometry = args.fastOdometry;
+            cfg.disable_color_angle = args.disableColorAngleWeight;
+            config = cfg;
+            lastOdometry = (args.useRGBD || args.useRGBDICP) ? CloudSlice::RGBD : CloudSlice::ICP;
+            return;
+        }
+        if (args.useRGBD || args.useRGBDICP) {
+            std::fprintf(stderr, "the operator path implements ICP odometry only; use the device-resident tracker for -r / -ri\n");
+            std::exit(1);
+        }
+        // KintinuousTracker.cpp:86-118
+        const float vs = Volume::get().getVolumeSize();
+        volumeBasis = kt::Vector3f(vs * 0.5f, vs * 0.5f, vs * 0.5f);
+        if (args.staticMode) volumeBasis(2) = vs * 0.5f - (float)(((double)vs * 0.5) + 0.45);
+        tsdf_volume_ = new TsdfVolume(N);
+        tsdf_volume_->setSize(kt::Vector3f(vs, vs, vs));
+        tsdf_volume_->setTsdfTruncDist(std::max(0.01f, vs / 100.0f));
+        color_volume_ = new ColorVolume(*tsdf_volume_);
+        cloud_device_.create((size_t)Resolution::get().numPixels() * 3);
+        allocateBuffers();
+        icp = new ICPOdometry(tvecs_, rmats_, vmaps_g_prev_, nmaps_g_prev_, vmaps_curr_, nmaps_curr_, intr, args.fastOdometry);
+        reset();
+    }
+
+    virtual ~KintinuousTracker()
+    {
+        for (size_t i = 0; i < sharedCloudSlices.size(); ++i) delete sharedCloudSlices[i];
+        if (fast) kt_tracker_destroy(fast);
+        delete icp;
+        delete color_volume_;
+        delete tsdf_volume_;
+    }
+
+    void processFrame(const DeviceArray2D<unsigned short>& depth, const DeviceArray2D<PixelRGB>& colors, unsigned char* rgbImage,
+                      unsigned short* depthData, uint64_t timestamp, bool /*compression*/ = false, uint8_t* /*lastCompressedDepth*/ = 0,
+                      int /*depthSize*/ = 0, uint8_t* /*lastCompressedImage*/ = 0, int /*imageSize*/ = 0)
+    {
+        lastRgbImage = rgbImage;
+        lastDepthData = depthData;
+        current_utime = timestamp;
+        if (!operatorPath) {
+            ensureFast();
+            ktSafeCall(kt_tracker_process_frame(fast, depth.ptr(), reinterpret_cast<const uint8_t*>(colors.ptr()), timestamp));
+            syncFromFast();
+        } else {
+            processFrameOperators(depth, colors, timestamp);
+        }
+        if (global_time_ > 1 && ConfigArgs::get().saveFile.size()) outputPose(timestamp, lastRotation);
+    }
+
+    kt::Vector3f getVolumeOffset() const { return volumeBasisValue(); }
+    void setParked(const bool park)
+    {
+        parked = park;
+        if (fast) ktSafeCall(kt_tracker_set_parked(fast, park));
+    }
+    // tvecs_.back() - volumeBasis (KintinuousTracker.cpp:993-996)
+    kt::Vector3f getLastTranslation() const
+    {
+        const kt::Vector3f b = volumeBasisValue();
+        return kt::Vector3f(lastTranslation(0) - b(0), lastTranslation(1) - b(1), lastTranslation(2) - b(2));
+    }
+    kt::Vector3f getVoxelSize() const
+    {
+        const float v = Volume::get().getVolumeSize() / (float)N;
+        return kt::Vector3f(v, v, v);
+    }
+    kt::Matrix3f getLastRotation() const { return lastRotation; }
+    kt::Vector3f getCurrentGlobalCamera() const { return currentGlobalCamera; }
+    std::vector<CloudSlice*>& getCloudSlices() { return sharedCloudSlices; }
+    void setOverlap(int o)
+    {
+        overlap = o;
+        config.overlap = o;
+        if (fast) { kt_tracker_destroy(fast); fast = 0; }
+    }
+
+    void finalise()
+    {
+        if (!operatorPath) {
+            ensureFast();
+            ktSafeCall(kt_tracker_finalise(fast));
+            syncFromFast();
+            return;
+        }
+        vWrapCopyUpdate();
+        DeviceArray<PointXYZRGB> cloud = tsdf_volume_->fetchCloud(cloud_device_, vWrapCopy, color_volume_->data(), 0, N, 0, N, 0, N, voxelWrap);
+        pushSlice(cloud, CloudSlice::FINAL, lastRgbImage, lastDepthData);
+    }
+
+    void reset()
+    {
+        global_time_ = 0;
+        densePoseGraph.clear();
+        for (size_t i = 0; i < sharedCloudSlices.size(); ++i) delete sharedCloudSlices[i];
+        sharedCloudSlices.clear();
+        nextSlice = 0;
+        if (!operatorPath) {
+            if (fast) ktSafeCall(kt_tracker_reset(fast));
+            return;
+        }
+        // KintinuousTracker.cpp:262-354
+        rmats_.clear();
+        tvecs_.clear();
+        rmats_.push_back(kt::Matrix3f());
+        tvecs_.push_back(volumeBasis);
+        voxelWrap = make_int3(0, 0, 0);
+        vWrapCopy = voxelWrap;
+        computeGlobalCamera(0);
+        lastRotation = rmats_.back();
+        lastTranslation = tvecs_.back();
+        parked = ConfigArgs::get().staticMode;
+        tsdf_volume_->reset();
+        color_volume_->reset();
+        if (ConfigArgs::get().saveFile.size()) {
+            FILE* f = std::fopen((ConfigArgs::get().saveFile + ".poses").c_str(), "w");
+            if (f) std::fclose(f);
+        }
+    }
+
+    kt_tracker* handle() { ensureFast(); return fast; }
+
+  private:
+    Intr intr;
+    bool operatorPath;
+    int N;
+    // device-resident path
+    kt_tracker* fast;
+    kt_tracker_config config;
+    // operator path state (KintinuousTracker.h:177-250)
+    TsdfVolume* tsdf_volume_;
+    ColorVolume* color_volume_;
+    ICPOdometry* icp;
+    kt::Vector3f volumeBasis;
+    std::vector<DeviceArray2D<unsigned short> > depths_curr_;
+    std::vector<DeviceArray2D<float> > vmaps_g_prev_, nmaps_g_prev_, vmaps_curr_, nmaps_curr_;
+    DeviceArray2D<uchar4> vmap_curr_color;
+    DeviceArray2D<float> depthRawScaled_;
+    std::vector<kt::Matrix3f> rmats_;
+    std::vector<kt::Vector3f> tvecs_;
+    int3 voxelWrap, vWrapCopy;
+    DeviceArray<PointXYZRGB> cloud_device_;
+    // shared
+    std::vector<CloudSlice*> sharedCloudSlices;
+    int overlap;
+    bool parked;
+    int global_time_;
+    uint64_t current_utime;
+    int nextSlice;
+    kt::Matrix3f lastRotation;
+    kt::Vector3f lastTranslation, currentGlobalCamera;
+    unsigned char* lastRgbImage = 0;
+    unsigned short* lastDepthData = 0;
+
+    kt::Vector3f volumeBasisValue() const
+    {
+        if (operatorPath) return volumeBasis;
+        const float vs = Volume::get().getVolumeSize();
+        kt::Vector3f b(vs * 0.5f, vs * 0.5f, vs * 0.5f);
+        if (ConfigArgs::get().staticMode) b(2) = vs * 0.5f - (float)(((double)vs * 0.5) + 0.45);
+        return b;
+    }
+
+    void ensureFast()
+    {
+        if (fast) return;
+        ktSafeCall(kt_tracker_create(kt::device::context(), &config, &fast));
+        if (parked) ktSafeCall(kt_tracker_set_parked(fast, 1));
+        if (ConfigArgs::get().saveFile.size()) {
+            FILE* f = std::fopen((ConfigArgs::get().saveFile + ".poses").c_str(), "w");
+            if (f) std::fclose(f);
+        }
+    }
+
+    // pull pose, dense pose graph and new slices out of the device-resident tracker
+    void syncFromFast()
+    {
+        ktSafeCall(kt_tracker_get_pose(fast, lastRotation.data(), lastTranslation.data(), currentGlobalCamera.data()));
+        global_time_ = kt_tracker_num_poses(fast);
+        for (int i = (int)densePoseGraph.size(); i < global_time_; ++i) {
+            uint64_t ts;
+            kt::Matrix4f pose;
+            int loop;
+            ktSafeCall(kt_tracker_get_dense_pose(fast, i, &ts, pose.m, &loop));
+            densePoseGraph.push_back(DensePose(ts, pose, loop != 0));
+        }
+        const int ns = kt_tracker_num_slices(fast);
+        for (; nextSlice < ns; ++nextSlice) {
+            size_t n;
+            int dim;
+            ktSafeCall(kt_tracker_slice_info(fast, nextSlice, &n, &dim));
+            CloudSlice::PointCloud* cloud = new CloudSlice::PointCloud(n);
+            if (n) ktSafeCall(kt_tracker_slice_points(fast, nextSlice, cloud->data()));
+            kt::Matrix3f R;
+            kt::Vector3f cam;
+            uint64_t ts;
+            ktSafeCall(kt_tracker_slice_pose(fast, nextSlice, R.data(), cam.data(), &ts));
+            const bool fin = dim == CloudSlice::FINAL;
+            sharedCloudSlices.push_back(new CloudSlice(cloud, (CloudSlice::Dimension)dim, lastOdometry, cam, R, ts, 0, fin ? lastRgbImage : 0,
+                                                       fin ? lastDepthData : 0));
+        }
+    }
+
+    // <saveFile>.poses, KintinuousTracker.cpp:199-218
+    void outputPose(uint64_t timestamp, const kt::Matrix3f& Rcurr)
+    {
+        FILE* f = std::fopen((ConfigArgs::get().saveFile + ".poses").c_str(), "a");
+        if (!f) return;
+        const kt::Quaternionf q(Rcurr);
+        std::fprintf(f, "%.6f %g %g %g %g %g %g %g\n", (double)timestamp / 1000000.0, currentGlobalCamera(0), currentGlobalCamera(1),
+                     currentGlobalCamera(2), q.x, q.y, q.z, q.w);
+        std::fclose(f);
+    }
+
+    // ---- operator path ------------------------------------------------------------------------------------------
+    void allocateBuffers()  // KintinuousTracker.cpp:356-382
+    {
+        depths_curr_.resize(ICPOdometry::LEVELS);
+        vmaps_g_prev_.resize(ICPOdometry::LEVELS);
+        nmaps_g_prev_.resize(ICPOdometry::LEVELS);
+        vmaps_curr_.resize(ICPOdometry::LEVELS);
+        nmaps_curr_.resize(ICPOdometry::LEVELS);
+        for (int i = 0; i < ICPOdometry::LEVELS; ++i) {
+            const int pyr_rows = Resolution::get().rows() >> i, pyr_cols = Resolution::get().cols() >> i;
+            depths_curr_[i].create(pyr_rows, pyr_cols);
+            vmaps_g_prev_[i].create(pyr_rows * 3, pyr_cols);
+            nmaps_g_prev_[i].create(pyr_rows * 3, pyr_cols);
+            vmaps_curr_[i].create(pyr_rows * 3, pyr_cols);
+            nmaps_curr_[i].create(pyr_rows * 3, pyr_cols);
+        }
+        vmap_curr_color.create(Resolution::get().rows(), Resolution::get().cols());
+        depthRawScaled_.create(Resolution::get().rows(), Resolution::get().cols());
+    }
+
+    void vWrapCopyUpdate()  // KintinuousTracker.cpp:1075-1085
+    {
+        int* w = &voxelWrap.x;
+        int* c = &vWrapCopy.x;
+        for (int k = 0; k < 3; ++k) {
+            c[k] = w[k];
+            if (c[k] < 0) c[k] = N - ((-c[k]) % N);
+        }
+    }
+
+    void computeGlobalCamera(const kt::Vector3f* tcurr)  // KintinuousTracker.cpp:581-595
+    {
+        const float vs = Volume::get().getVolumeSize();
+        const float voxel = vs / (float)N;
+        const int* w = &voxelWrap.x;
+        for (int k = 0; k < 3; ++k) {
+            currentGlobalCamera(k) = (float)((double)volumeBasis(k) - (double)vs * 0.5);
+            currentGlobalCamera(k) += (float)w[k] * voxel;
+            if (tcurr) currentGlobalCamera(k) += (*tcurr)(k) - volumeBasis(k);
+        }
+    }
+
+    void pushDensePose(uint64_t ts, const kt::Matrix3f& R, bool loop)
+    {
+        kt::Matrix4f pose;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) pose(i, j) = R(i, j);
+            pose(i, 3) = currentGlobalCamera(i);
+        }
+        densePoseGraph.push_back(DensePose(ts, pose, loop));
+    }
+
+    void pushSlice(const DeviceArray<PointXYZRGB>& cloud, CloudSlice::Dimension dim, unsigned char* rgb, unsigned short* depth)
+    {
+        CloudSlice::PointCloud* pts = new CloudSlice::PointCloud();
+        cloud.download(*pts);
+        sharedCloudSlices.push_back(new CloudSlice(pts, dim, lastOdometry, currentGlobalCamera, rmats_.back(), current_utime, 0, rgb, depth));
+    }
+
+    static int voxelTranslation(float translation, float voxel, int thresh)  // KintinuousTracker.cpp:640-667
+    {
+        const int f = (int)std::floor(translation / voxel);
+        if (f < 0) return (-thresh > f) ? -thresh : f;
+        return thresh < f ? thresh : f;
+    }
+
+    void processFrameOperators(const DeviceArray2D<unsigned short>& depth_raw, const DeviceArray2D<PixelRGB>& colors, uint64_t timestamp)
+    {
+        const bool angleColor = !ConfigArgs::get().disableColorAngleWeight;
+        const float3 device_volume_size = make_float3(tsdf_volume_->getSize()(0), tsdf_volume_->getSize()(1), tsdf_volume_->getSize()(2));
+        // pyramid, KintinuousTracker.cpp:465-479
+        bilateralFilter(depth_raw, depths_curr_[0]);
+        for (int i = 1; i < ICPOdometry::LEVELS; ++i) pyrDown(depths_curr_[i - 1], depths_curr_[i]);
+        for (int i = 0; i < ICPOdometry::LEVELS; ++i) {
+            createVMap(intr(i), depths_curr_[i], vmaps_curr_[i]);
+            createNMap(vmaps_curr_[i], nmaps_curr_[i]);
+        }
+
+        if (global_time_ == 0) {  // :481-557
+            kt::Matrix3f init_Rcam = rmats_.back(), init_Rcam_inv;
+            kt::Vector3f init_tcam = tvecs_.back();
+            ktSafeCall(kt_host_mat33_inverse(init_Rcam.data(), init_Rcam_inv.data()));
+            const int3 emptyVoxel = make_int3(0, 0, 0);
+            integrateTsdfVolume(depth_raw, intr, device_volume_size, kt::dev(init_Rcam_inv), kt::dev(init_tcam),
+                                tsdf_volume_->getTsdfTruncDist(), tsdf_volume_->data(), depthRawScaled_, emptyVoxel, color_volume_->data(),
+                                colors, nmaps_curr_[0], angleColor);
+            for (int i = 0; i < ICPOdometry::LEVELS; ++i)
+                tranformMaps(vmaps_curr_[i], nmaps_curr_[i], kt::dev(init_Rcam), kt::dev(init_tcam),
+                             vmaps_g_prev_[i], nmaps_g_prev_[i]);
+            ++global_time_;
+            pushDensePose(timestamp, init_Rcam, true);
+            return;
+        }
+
+        // odometry :564-572
+        kt::Matrix3f Rcurr;
+        kt::Vector3f tcurr;
+        lastOdometry = icp->getIncrementalTransformation(tcurr, Rcurr, depth_raw, colors, timestamp, lastRgbImage, lastDepthData);
+        rmats_.push_back(Rcurr);
+        tvecs_.push_back(tcurr);
+        computeGlobalCamera(&tcurr);
+        kt::Matrix3f Rcurr_inv;
+        ktSafeCall(kt_host_mat33_inverse(Rcurr.data(), Rcurr_inv.data()));
+
+        // shift decision and the three axis blocks :627-833
+        const kt::Vector3f voxel = tsdf_volume_->getVoxelSize();
+        const int thresh = parked ? INT_MAX : ConfigArgs::get().voxelShift;
+        int vt[3];
+        for (int k = 0; k < 3; ++k) vt[k] = voxelTranslation(tvecs_.back()(k) - volumeBasis(k), voxel(k), thresh);
+        for (int axis = 0; axis < 3; ++axis) {
+            vWrapCopyUpdate();
+            int lo[3] = {0, 0, 0}, hi[3] = {N, N, N};
+            int* w = &voxelWrap.x;
+            bool cycled = false;
+            CloudSlice::Dimension dim = CloudSlice::XPlus;
+            const bool back = vt[axis] <= -thresh;
+            if (vt[axis] >= thresh) {
+                hi[axis] = vt[axis] + 1 + overlap;
+                dim = (CloudSlice::Dimension)(axis * 2);
+                cycled = true;
+            } else if (back) {
+                if (axis == 2) { lo[2] = N + (vt[2] - overlap) - 1; hi[2] = N - 1; }  // the reference's z-minus bounds :805
+                else lo[axis] = N + (vt[axis] - overlap);
+                dim = (CloudSlice::Dimension)(axis * 2 + 1);
+                cycled = true;
+            }
+            if (!cycled) continue;
+            DeviceArray<PointXYZRGB> cloud = tsdf_volume_->fetchCloud(cloud_device_, vWrapCopy, color_volume_->data(), lo[0], hi[0], lo[1],
+                                                                      hi[1], lo[2], hi[2], voxelWrap);
+            clearAxis(axis, back, w[axis], w[axis] + vt[axis]);
+            // mutexOutCloudBuffer :1156-1208
+            pushSlice(cloud, dim, 0, 0);
+            const float shift = voxel(axis) * (float)vt[axis];
+            tvecs_.back()(axis) -= shift;
+            w[axis] += vt[axis];
+            tcurr(axis) -= shift;
+        }
+        vWrapCopyUpdate();
+
+        // integrate + raycast + predicted pyramid :864-899
+        integrateTsdfVolume(depth_raw, intr, device_volume_size, kt::dev(Rcurr_inv), kt::dev(tcurr),
+                            tsdf_volume_->getTsdfTruncDist(), tsdf_volume_->data(), depthRawScaled_, vWrapCopy, color_volume_->data(), colors,
+                            nmaps_curr_[0], angleColor);
+        raycast(intr, kt::dev(Rcurr), kt::dev(tcurr), tsdf_volume_->getTsdfTruncDist(), device_volume_size,
+                tsdf_volume_->data(), vmaps_g_prev_[0], nmaps_g_prev_[0], vWrapCopy, vmap_curr_color, color_volume_->data());
+        for (int i = 1; i < ICPOdometry::LEVELS; ++i) {
+            resizeVMap(vmaps_g_prev_[i - 1], vmaps_g_prev_[i]);
+            resizeNMap(nmaps_g_prev_[i - 1], nmaps_g_prev_[i]);
+        }
+        kt::device::sync();
+        ++global_time_;
+        lastRotation = Rcurr;
+        lastTranslation = tvecs_.back();
+        pushDensePose(timestamp, Rcurr, false);
+    }
+
+    void clearAxis(int axis, bool back, int cur, int next)
+    {
+        DeviceArray2D<short>& v = tsdf_volume_->data();
+        DeviceArray2D<uchar4>& c = color_volume_->data();
+        switch (axis * 2 + (back ? 1 : 0)) {
+            case 0: clearVolumeX(v, cur, next); clearVolumeXc(c, cur, next); break;
+            case 1: clearVolumeXBack(v, cur, next); clearVolumeXBackc(c, cur, next); break;
+            case 2: clearVolumeY(v, cur, next); clearVolumeYc(c, cur, next); break;
+            case 3: clearVolumeYBack(v, cur, next); clearVolumeYBackc(c, cur, next); break;
+            case 4: clearVolumeZ(v, cur, next); clearVolumeZc(c, cur, next); break;
+            default: clearVolumeZBack(v, cur, next); clearVolumeZBackc(c, cur, next); break;
+        }
+    }
+};

@@ -1,0 +1,87 @@
+// RawLogReader.h -- .klg reader (utils/LogReader.h, utils/RawLogReader.cpp:21-150): int32 numFrames, then per frame
+// int64 timestamp, int32 depthSize, int32 imageSize, depth bytes, image bytes.  Depth: raw u16 (depthSize == 2*W*H) or a
+// zlib stream; image: raw rgb24 (imageSize == 3*W*H), absent (imageSize == 0 -> zeros); JPEG payloads are rejected (no
+// decoder in this build).  hasMore() keeps the reference's off-by-one: the last frame of a log is never returned.
+#pragma once
+
+#include <stdint.h>
+#include <zlib.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ConfigArgs.h"
+#include "Resolution.h"
+
+class LogReader {
+  public:
+    LogReader() : decompressedDepth(0), decompressedImage(0), timestamp(0), isCompressed(false) {}
+    virtual ~LogReader() {}
+    virtual bool grabNext(bool& returnVal, int& currentFrame) = 0;
+    unsigned short* decompressedDepth;
+    unsigned char* decompressedImage;
+    int64_t timestamp;
+    bool isCompressed;
+};
+
+class RawLogReader : public LogReader {
+  public:
+    explicit RawLogReader(const std::string& file = ConfigArgs::get().logFile) : fp(0), numFrames(0), currentFrame(0)
+    {
+        fp = std::fopen(file.c_str(), "rb");
+        if (!fp) { std::fprintf(stderr, "cannot open log %s\n", file.c_str()); std::exit(1); }
+        const int n = Resolution::get().numPixels();
+        depthBuffer.resize(n);
+        imageBuffer.resize((size_t)n * 3);
+        decompressedDepth = depthBuffer.data();
+        decompressedImage = imageBuffer.data();
+        int32_t frames = 0;
+        if (std::fread(&frames, sizeof(int32_t), 1, fp) != 1) frames = 0;
+        numFrames = frames;
+    }
+    virtual ~RawLogReader() { if (fp) std::fclose(fp); }
+
+    bool hasMore() const { return currentFrame + 1 < numFrames; }  // RawLogReader.cpp:147-150
+    int getNumFrames() const { return numFrames; }
+
+    bool grabNext(bool& returnVal, int& /*frame*/)
+    {
+        if (!hasMore()) { returnVal = false; return false; }
+        const size_t n = (size_t)Resolution::get().numPixels();
+        int32_t depthSize = 0, imageSize = 0;
+        if (std::fread(&timestamp, sizeof(int64_t), 1, fp) != 1 || std::fread(&depthSize, sizeof(int32_t), 1, fp) != 1 ||
+            std::fread(&imageSize, sizeof(int32_t), 1, fp) != 1) { returnVal = false; return false; }
+        scratch.resize((size_t)(depthSize > imageSize ? depthSize : imageSize));
+        if (depthSize > 0 && std::fread(scratch.data(), (size_t)depthSize, 1, fp) != 1) { returnVal = false; return false; }
+        if ((size_t)depthSize == n * 2) {
+            std::memcpy(depthBuffer.data(), scratch.data(), n * 2);
+            isCompressed = false;
+        } else if (depthSize > 0) {
+            uLongf decomp = (uLongf)(n * 2);
+            if (uncompress((Bytef*)depthBuffer.data(), &decomp, (const Bytef*)scratch.data(), (uLong)depthSize) != Z_OK) {
+                std::fprintf(stderr, "corrupt zlib depth in frame %d\n", currentFrame);
+                std::exit(1);
+            }
+            isCompressed = true;
+        } else {
+            std::memset(depthBuffer.data(), 0, n * 2);
+        }
+        if (imageSize > 0 && std::fread(scratch.data(), (size_t)imageSize, 1, fp) != 1) { returnVal = false; return false; }
+        if ((size_t)imageSize == n * 3) std::memcpy(imageBuffer.data(), scratch.data(), n * 3);
+        else if (imageSize == 0) std::memset(imageBuffer.data(), 0, n * 3);
+        else { std::fprintf(stderr, "JPEG-compressed .klg images are not supported by this build\n"); std::exit(1); }
+        if (ConfigArgs::get().flipColors)  // RawLogReader.cpp:118-121 (cv::cvtColor RGB2BGR)
+            for (size_t i = 0; i < n; ++i) { unsigned char t = imageBuffer[i * 3]; imageBuffer[i * 3] = imageBuffer[i * 3 + 2]; imageBuffer[i * 3 + 2] = t; }
+        ++currentFrame;
+        returnVal = true;
+        return true;
+    }
+
+  private:
+    FILE* fp;
+    int numFrames, currentFrame;
+    std::vector<unsigned short> depthBuffer;
+    std::vector<unsigned char> imageBuffer, scratch;
+};

@@ -1,0 +1,51 @@
+// TrackerInterface.h -- the frame pump of the reference's tracker thread (backend/TrackerInterface.h:34-88,
+// TrackerInterface.cpp:20-137) without the threading shell: grab a frame, upload, processFrame; finalise at the end of
+// the log.  One instance per GPU.
+#pragma once
+
+#include "KintinuousTracker.h"
+#include "RawLogReader.h"
+
+class TrackerInterface {
+  public:
+    TrackerInterface(LogReader* logRead, const Intr& depthIntrinsics, bool operatorPath = false)
+        : logRead(logRead), currentFrame(0), firstRun(true)
+    {
+        kt::device::context(ConfigArgs::get().gpu);  // cudaSetDevice(ConfigArgs::get().gpu), TrackerInterface.cpp:48
+        frontend = new KintinuousTracker(depthIntrinsics, operatorPath);
+        reset();
+    }
+    virtual ~TrackerInterface() { delete frontend; }
+
+    void reset() { currentFrame = 0; frontend->reset(); }
+    KintinuousTracker* getFrontend() { return frontend; }
+    void finalise() { frontend->finalise(); }
+    void setPark(const bool park) { frontend->setParked(park); }
+    void enableOverlap() { frontend->setOverlap(2); }
+    int getCurrentFrame() const { return currentFrame; }
+
+    // one iteration of TrackerInterface::process(): false once the log is exhausted (after finalise())
+    bool process()
+    {
+        bool returnVal = true;
+        if (!logRead->grabNext(returnVal, currentFrame)) {
+            finalise();
+            return false;
+        }
+        ++currentFrame;
+        const int rows = Resolution::get().rows(), cols = Resolution::get().cols();
+        depth_device.upload(logRead->decompressedDepth, (size_t)cols * 2, rows, cols);
+        colors_device.upload(logRead->decompressedImage, (size_t)cols * 3, rows, cols);
+        frontend->processFrame(depth_device, colors_device, logRead->decompressedImage, logRead->decompressedDepth, (uint64_t)logRead->timestamp,
+                               logRead->isCompressed);
+        return true;
+    }
+
+  private:
+    LogReader* logRead;
+    KintinuousTracker* frontend;
+    DeviceArray2D<unsigned short> depth_device;
+    DeviceArray2D<PixelRGB> colors_device;
+    int currentFrame;
+    bool firstRun;
+};

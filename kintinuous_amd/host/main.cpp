@@ -1,0 +1,52 @@
+// kintinuous_hip -- headless driver of the tracking + fusion path over a .klg log: the part of the reference's
+// `Kintinuous -l log.klg [-c calib] [-s size] [-t shift] [-r|-ri] [-fod] [-sm] ...` run (src/Kintinuous.cpp,
+// MainController.cpp:73-170) that ends at the CloudSlices and the .poses file.  Extra options: -n <N>, -w/-h, -o <prefix>,
+// -ops (compose every frame from the internal.h operators instead of the device-resident tracker).
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <string>
+
+#include "TrackerInterface.h"
+
+static Intr loadCalibration(const std::string& file, int width, int height)
+{
+    // MainController.cpp:121-150: a calibration file holds "fx fy cx cy"; the default is 528 / 528 / 320 / 240 at VGA
+    Intr k(528.0f * width / 640.0f, 528.0f * height / 480.0f, 320.0f * width / 640.0f, 240.0f * height / 480.0f);
+    if (file.size()) {
+        std::ifstream f(file.c_str());
+        double fx, fy, cx, cy;
+        if (f >> fx >> fy >> cx >> cy) k = Intr((float)fx, (float)fy, (float)cx, (float)cy);
+        else { std::fprintf(stderr, "cannot read calibration %s\n", file.c_str()); std::exit(1); }
+    }
+    return k;
+}
+
+int main(int argc, char** argv)
+{
+    const ConfigArgs& args = ConfigArgs::get(argc, argv);
+    if (args.help || args.logFile.empty()) { ConfigArgs::usage(argv[0]); return args.help ? 0 : 1; }
+    bool ops = false;
+    for (int i = 1; i < argc; ++i) ops = ops || std::string(argv[i]) == "-ops";
+
+    Resolution::get(args.width, args.height);
+    Volume::get(args.volumeSize, args.volumeResolution);
+    const Intr intr = loadCalibration(args.calibrationFile, args.width, args.height);
+
+    RawLogReader log(args.logFile);
+    TrackerInterface tracker(&log, intr, ops);
+    if (args.extractOverlap) tracker.enableOverlap();  // MainController.cpp:187-190
+
+    const auto t0 = std::chrono::steady_clock::now();
+    int frames = 0;
+    while (tracker.process()) ++frames;
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    KintinuousTracker* fe = tracker.getFrontend();
+    size_t points = 0;
+    for (size_t i = 0; i < fe->getCloudSlices().size(); ++i) points += fe->getCloudSlices()[i]->cloud->size();
+    const kt::Vector3f cam = fe->getCurrentGlobalCamera();
+    std::printf("frames %d  slices %zu  points %zu  last camera %.6f %.6f %.6f  %.1f frames/s (incl. file I/O and uploads)  path %s\n", frames,
+                fe->getCloudSlices().size(), points, cam(0), cam(1), cam(2), frames / sec, ops ? "operators" : "device-resident");
+    return 0;
+}

@@ -99,3 +99,29 @@ def test_oracle_static_mode_never_shifts(oracle_mod):
     assert trk.num_slices() == 0 and not trk.voxel_wrap().any()
     assert abs(trk.trunc_dist() - 2.1 * 6.0 / 48) < 1e-6  # clamped to >= 2.1 voxels (TSDFVolume.cpp:89-97)
     trk.close()
+
+
+def test_host_math_abi_matches_oracle(oracle_mod):
+    """kt_host_* (the Gauss-Newton host math exported for per-operator callers) vs the oracle's restatement of
+    Eigen LDLT / cv::Rodrigues / Matrix3f::inverse: bit-identical (both are the same published algorithms in double)."""
+    import numpy as np
+    from kintinuous_amd import abi
+    rng = np.random.default_rng(7)
+    for trial in range(20):
+        J = rng.standard_normal((40, 6))
+        A = J.T @ J
+        if trial % 5 == 4:
+            A[:, 3] = A[:, 2]; A[3, :] = A[2, :]          # rank deficient: pseudo-inverse branch
+        b = rng.standard_normal(6)
+        x, xo = abi.host_ldlt_solve6(A, b), oracle_mod.ldlt_solve6(A, b)
+        assert np.array_equal(x.view(np.uint64), xo.view(np.uint64))
+        r = rng.standard_normal(3) * (1e-9 if trial == 0 else 0.3)
+        assert np.array_equal(abi.host_rodrigues(r).view(np.uint64), oracle_mod.rodrigues(r).view(np.uint64))
+        from tests.conftest import random_rotation
+        R = random_rotation(rng, 1.0)
+        assert np.array_equal(abi.host_mat33_inverse(R).view(np.uint32), oracle_mod.mat33_inverse(R).view(np.uint32))
+    # pose update: identity increment keeps the pose; a pure translation increment moves the camera by -R*t
+    rt, Rc, tc = abi.host_pose_update(np.zeros(6), np.eye(4), np.eye(3), [1, 2, 3])
+    assert np.array_equal(Rc, np.eye(3, dtype=np.float32)) and np.array_equal(tc, np.array([1, 2, 3], np.float32))
+    rt, Rc, tc = abi.host_pose_update([0.5, 0, 0, 0, 0, 0], np.eye(4), np.eye(3), [1, 2, 3])
+    assert np.allclose(tc, [0.5, 2, 3]) and rt[0, 3] == 0.5
