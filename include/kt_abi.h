@@ -182,6 +182,12 @@ int kt_tracker_destroy(kt_tracker* t);
 int kt_tracker_reset(kt_tracker* t);
 /* processFrame with device-resident inputs: depth u16 [rows][cols] (mm), rgb24 [rows][cols][3] */
 int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_dev, const uint8_t* rgb24_dev, uint64_t timestamp);
+/* Optional read-ahead for log playback: announce a frame that a LATER kt_tracker_process_frame call will receive (same two
+ * pointers, contents unchanged until then).  Its pose-independent stages (bilateral filter, depth / vertex / normal pyramids,
+ * scaleDepth) run on a second HIP stream, overlapped with the tracking of the frames before it.  At most two announced frames
+ * may be outstanding; they must be processed in the order announced (anything else is legal but discards the read-ahead).
+ * Results are identical with and without it. */
+int kt_tracker_prefetch_frame(kt_tracker* t, const uint16_t* depth_dev, const uint8_t* rgb24_dev);
 /* TrackerInterface::process upload path (TrackerInterface.cpp:90-91): host frame -> device -> processFrame */
 int kt_tracker_process_frame_host(kt_tracker* t, const uint16_t* depth_host, const uint8_t* rgb24_host, uint64_t timestamp);
 int kt_tracker_finalise(kt_tracker* t);

@@ -21,13 +21,14 @@ struct kt_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
-    // scratch for reductions: per-block partials (double[blocks][32]) + final (float[32]) + ticket counter
+    // scratch for reductions: hand-off granules (u64[32][256] {epoch, value}) + final (float[32])
     double* red_partials;
     float* red_out;        // device, 32 floats
     float* red_out_host;   // pinned host mirror
     unsigned int* counters;  // device: [0] ticket, [1] extract global count, [2..] spare
     int* int_out_host;       // pinned, small
     int red_max_blocks;
+    unsigned int red_epoch;  // tag of the last reduction launch (kt_track.hip hand-off granules)
 };
 
 void kt_set_error(const char* fmt, ...);

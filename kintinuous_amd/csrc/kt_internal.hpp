@@ -6,7 +6,11 @@
 int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
                            const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
                            int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
-                           const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev);
+                           const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev,
+                           const void* prepared_rec);
+size_t kt_integrate_rec_bytes(int cols, int rows);
+int kt_integrate_prepare(kt_ctx* c, const uint16_t* depth_raw, const uint8_t* colors, const float* nmap_curr, int cols, int rows,
+                         const kt_intr* intr, int angle_color, float* depth_raw_scaled, void* rec);
 int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const float tcurr[3], float tranc_dist,
                     const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
                     const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,

@@ -17,9 +17,11 @@
 //            chains, exactly the reference's per-thread sums;
 //   tree:    lanes are laid out c-major, so each 32-lane half-wave holds one product of the 32 vts = one CUDA warp:
 //            ds_swizzle(xor 16) + DPP row_shl 8/4/2/1 reproduces warpReduceSum;
-//   hand-off: the 29 warp sums are stored write-through (sc1), drained, and a device-scope ticket elects the last
-//            workgroup (cdna_hip_programming.md G16 form R1, no fences); it folds blocks and the final tree with sc1
-//            loads and, in the device-resident path, solves the 6x6 system and updates the pose.
+//   hand-off: the data is the flag (cdna_hip_programming.md G16 form R2): each warp sum goes out as ONE aligned 8-byte
+//            {epoch, value} granule, stored write-through at agent scope; the last workgroup of the grid sweeps the 29 x 256
+//            granules with agent-scope loads until every tag carries this launch's epoch, folds blocks and the final
+//            tree and, in the device-resident path, solves the 6x6 system and updates the pose.  No ticket, no fence,
+//            no zeroing between launches (epochs never repeat within a context; the buffer is zeroed at creation).
 #include "kt_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -55,19 +57,15 @@ __device__ __constant__ unsigned char KT_PB[28] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3,
 
 // Phases 2..end of the reduction.  RowFn(i, row[7]) -> found computes one pixel.  Returns true (workgroup-uniformly) in
 // the workgroup that retired last; there total[0..28] (LDS) holds the grid sums.
-#ifdef KT_ICP_TIMING
-#define KT_TS(i) do { if (threadIdx.x == 0) kt_ts[i] = wall_clock64(); } while (0)
-__shared__ unsigned long long kt_ts[8];
-#else
-#define KT_TS(i) do {} while (0)
-#endif
-template <typename RowFn>
-__device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, float* __restrict__ partials, unsigned int* __restrict__ ticket,
-                                            float (&total)[KT_RED_SLOTS])
+struct kt_no_prefetch { __device__ __forceinline__ void operator()() const {} };
+// `pre` runs in the sweeping workgroup between its publish and the sweep: the place to issue loads the epilogue will need
+// (their latency hides under the sweep).
+template <typename RowFn, typename PreFn = kt_no_prefetch>
+__device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, unsigned long long* __restrict__ granules, unsigned int epoch,
+                                            float (&total)[KT_RED_SLOTS], const PreFn& pre = PreFn())
 {
     KT_TS(0);
     __shared__ float rows[KT_KBATCH][8][32];
-    __shared__ bool is_last;
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * 32;           // first virtual thread of this CUDA warp
     const int comp = tid >> 5, vt = tid & 31;  // phase-2 role
@@ -104,43 +102,59 @@ __device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, float* __res
     KT_TS(1);
     // warp tree: the 32 lanes of a half-wave hold product `comp` of the 32 virtual threads of this CUDA warp
     const float wsum = kt_warp32_sum(acc);
-    if (comp < 29 && vt == 0) {
-        __hip_atomic_store(&partials[comp * KT_RED_BLOCKS + blockIdx.x], wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
+    if (comp < 29 && vt == 0)
+        __hip_atomic_store(&granules[comp * KT_RED_BLOCKS + blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     KT_TS(2);
-    if (tid == 0) {
-        const unsigned int t = atomicAdd(ticket, 1u);
-        is_last = (t == gridDim.x - 1);
-        if (is_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
-    }
-    __syncthreads();
+    if (blockIdx.x != gridDim.x - 1) return false;
     KT_TS(3);
-    if (!is_last) return false;
-    // blockReduceSum second stage (reduce.cu:131-164) per CUDA block b: lanes 0..3 hold the warp sums, lanes 4..31 zero;
-    // offsets 16, 8, 4 add zeros, offset 2 gives s0+s2 and s1+s3, offset 1 adds them.  Then reduceSum<<<1, 512>>>
-    // (reduce.cu:166-184): threads 0..63 hold 0 + in[b]; warps 0 and 1 fold with the 32-lane tree, the rest is zero; the
-    // final first-warp tree reduces to s0 + s1.  Wave w handles products w and w + 16; lane = CUDA block b.
+    pre();
+    __shared__ unsigned int timed_out;
+    if (tid == 0) timed_out = 0;
+    __syncthreads();
+    // The sweeping workgroup.  blockReduceSum second stage (reduce.cu:131-164) per CUDA block b: lanes 0..3 hold the warp sums,
+    // lanes 4..31 zero; offsets 16, 8, 4 add zeros, offset 2 gives s0+s2 and s1+s3, offset 1 adds them.  Then
+    // reduceSum<<<1, 512>>> (reduce.cu:166-184): threads 0..63 hold 0 + in[b]; warps 0 and 1 fold with the 32-lane tree, the rest
+    // is zero; the final first-warp tree reduces to s0 + s1.  Wave w handles products w and w + 16; lane = CUDA block b, whose 4
+    // warp sums are the granules 4b..4b+3.  Each wave re-reads its granules until all 256 carry this launch's epoch (bounded:
+    // a hand-off that never completes raises slot 31 of total[], which the callers report as an error).
     {
         const int w = tid >> 6, lane = tid & 63;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int c = w + 16 * r;
             if (c < 29) {
-                const float* pp = &partials[c * KT_RED_BLOCKS + 4 * lane];
-                const float s0 = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 0.0f;
-                const float s1 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 0.0f;
-                const float s2 = __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 0.0f;
-                const float s3 = __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 0.0f;
+                const unsigned long long* pp = &granules[c * KT_RED_BLOCKS + 4 * lane];
+                unsigned long long g0, g1, g2, g3;
+                bool ok;
+                unsigned int spins = 0;
+                for (;;) {
+                    g0 = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g1 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g2 = __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g3 = __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (unsigned int)(g0 >> 32) == epoch && (unsigned int)(g1 >> 32) == epoch && (unsigned int)(g2 >> 32) == epoch &&
+                         (unsigned int)(g3 >> 32) == epoch;
+                    if (__all(ok) || ++spins > (1u << 22)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const float s0 = __uint_as_float((unsigned int)g0) + 0.0f;
+                const float s1 = __uint_as_float((unsigned int)g1) + 0.0f;
+                const float s2 = __uint_as_float((unsigned int)g2) + 0.0f;
+                const float s3 = __uint_as_float((unsigned int)g3) + 0.0f;
                 const float blk = (s0 + s2) + (s1 + s3);
                 const float tr = kt_warp32_sum(0.0f + blk);
                 const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tr), 0));
                 const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tr), 32));
-                if (lane == 0) total[c] = (lo + 0.0f) + (hi + 0.0f);
+                if (lane == 0) {
+                    total[c] = (lo + 0.0f) + (hi + 0.0f);
+                    if (!__all(ok)) atomicOr(&timed_out, 1u);
+                }
             }
         }
     }
+    __syncthreads();
+    if (tid == 0) total[KT_RED_SLOTS - 1] = timed_out ? 1.0f : 0.0f;  // slot 31: the hand-off never completed (reported by the callers)
     __syncthreads();
     KT_TS(4);
     return true;
@@ -159,7 +173,7 @@ struct kt_icp_args {
     kt_mat33 Rcurr; float tcurr[3];
     kt_mat33 Rprev_inv; float tprev[3];
     kt_track_state* state;     // nullptr on the host path
-    float* partials; unsigned int* ticket;
+    unsigned long long* granules; unsigned int epoch;   // inter-workgroup hand-off (kt_reduce29)
     float* out29;              // host path: 29 floats
     int mode;                  // KT_MODE_*
 };
@@ -215,9 +229,12 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
         fn.tprev = {a.tprev[0], a.tprev[1], a.tprev[2]};
     }
     __shared__ float total[KT_RED_SLOTS];
-    if (!kt_reduce29(fn, a.cols * a.rows, a.partials, a.ticket, total)) return;
+    kt_pose_regs pr;
+    const bool solve_here = a.mode == KT_MODE_ICP_SOLVE;
+    auto pre = [&]() { if (solve_here && threadIdx.x == 0) pr.load(a.state); };
+    if (!kt_reduce29(fn, a.cols * a.rows, a.granules, a.epoch, total, pre)) return;
     if (a.mode == KT_MODE_HOST) {
-        if (threadIdx.x < 29) a.out29[threadIdx.x] = total[threadIdx.x];
+        if (threadIdx.x < KT_RED_SLOTS && (threadIdx.x < 29 || threadIdx.x == KT_RED_SLOTS - 1)) a.out29[threadIdx.x] = total[threadIdx.x];
     } else if (threadIdx.x == 0) {
         float h[29];
         for (int k = 0; k < 29; ++k) h[k] = total[k];
@@ -227,20 +244,32 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
             kt_unpack29_d(h, dA, db);
             a.state->last_residual[0] = h[27];
             a.state->last_residual[1] = h[28];
-            kt_solve_and_update(a.state, dA, db);
+            if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
+            kt_solve_and_update(a.state, pr, dA, db);
 #ifdef KT_ICP_TIMING
-            { const unsigned long long t5 = wall_clock64(); for (int q = 0; q < 5; ++q) a.state->icp29[q] = (float)(kt_ts[q + 0] - kt_ts[0]); a.state->icp29[5] = (float)(t5 - kt_ts[0]); }
+            { const unsigned long long t5 = wall_clock64(); for (int q = 0; q < 7; ++q) a.state->icp29[q] = (float)(kt_ts[q + 0] - kt_ts[0]); a.state->icp29[7] = (float)(t5 - kt_ts[0]); }
 #endif
         } else {  // KT_MODE_ICP_STASH: joint RGB-D + ICP, the rgb kernel's epilogue combines and solves
             for (int k = 0; k < 29; ++k) a.state->icp29[k] = h[k];
+            if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
         }
     }
 }
 
+// epoch of the next reduction launch on this context: never 0 (the zeroed buffer's tag), never repeated between two zeroings
+static unsigned int kt_next_epoch(kt_ctx* c)
+{
+    if (++c->red_epoch == 0) {
+        (void)hipMemsetAsync(c->red_partials, 0, sizeof(double) * 32 * c->red_max_blocks, c->stream);
+        c->red_epoch = 1;
+    }
+    return c->red_epoch;
+}
+
 int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
 {
-    a.partials = (float*)c->red_partials;
-    a.ticket = &c->counters[0];
+    a.granules = (unsigned long long*)c->red_partials;
+    a.epoch = kt_next_epoch(c);
     hipLaunchKernelGGL(kt_icp_kernel, dim3(KT_RED_BLOCKS), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
@@ -274,8 +303,9 @@ extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3
     a.state = nullptr; a.out29 = c->red_out; a.mode = KT_MODE_HOST;
     int s = kt_icp_launch(c, a);
     if (s != KT_OK) return s;
-    KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * 29, hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * KT_RED_SLOTS, hipMemcpyDeviceToHost, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
+    if (c->red_out_host[KT_RED_SLOTS - 1] != 0.0f) { kt_set_error("icpStep: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
     kt_unpack29_host(c->red_out_host, A_host, b_host, residual_host);
     return KT_OK;
 }
@@ -446,7 +476,7 @@ struct kt_rgb_args {
     float sobel_scale;
     int cols, rows;
     kt_track_state* state;
-    float* partials; unsigned int* ticket;
+    unsigned long long* granules; unsigned int epoch;
     float* out29;
     int mode;              // KT_MODE_HOST, KT_MODE_RGB_SOLVE, KT_MODE_JOINT_SOLVE
     kt_level_k next_k;     // intrinsics of the level the NEXT iteration runs at (for K R K^-1, K t)
@@ -487,14 +517,17 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_arg
 {
     const kt_rgb_row fn{a, a.state ? a.state->sigma_val : a.sigma};
     __shared__ float total[KT_RED_SLOTS];
-    if (!kt_reduce29(fn, a.cols * a.rows, a.partials, a.ticket, total)) return;
+    kt_pose_regs pr;
+    auto pre = [&]() { if (a.mode != KT_MODE_HOST && threadIdx.x == 0) pr.load(a.state); };
+    if (!kt_reduce29(fn, a.cols * a.rows, a.granules, a.epoch, total, pre)) return;
     if (a.mode == KT_MODE_HOST) {
-        if (threadIdx.x < 29) a.out29[threadIdx.x] = total[threadIdx.x];
+        if (threadIdx.x < KT_RED_SLOTS && (threadIdx.x < 29 || threadIdx.x == KT_RED_SLOTS - 1)) a.out29[threadIdx.x] = total[threadIdx.x];
     } else if (threadIdx.x == 0) {
         float h[29];
         for (int k = 0; k < 29; ++k) h[k] = total[k];
         double dA[36], db[6];
         kt_unpack29_d(h, dA, db);
+        if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
         if (a.mode == KT_MODE_JOINT_SOLVE) {
             // RGBDOdometry.cpp:316-321: A = A_rgbd + w*w*A_icp, b = b_rgbd + w*b_icp, w = 10
             double iA[36], ib[6];
@@ -503,7 +536,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_arg
             for (int k = 0; k < 36; ++k) dA[k] = dA[k] + w * w * iA[k];
             for (int k = 0; k < 6; ++k) db[k] = db[k] + w * ib[k];
         }
-        kt_solve_and_update(a.state, dA, db);
+        kt_solve_and_update(a.state, pr, dA, db);
         kt_update_krk(a.state, a.next_k);
     }
 }
@@ -516,11 +549,12 @@ extern "C" int kt_rgb_step(kt_ctx* c, const kt_dataterm* corres_img, float sigma
     kt_rgb_args a;
     a.corres = corres_img; a.sigma = sigma; a.cloud = cloud; a.fx = fx; a.fy = fy; a.dIdx = dIdx; a.dIdy = dIdy;
     a.sobel_scale = sobel_scale; a.cols = cols; a.rows = rows; a.state = nullptr;
-    a.partials = (float*)c->red_partials; a.ticket = &c->counters[0]; a.out29 = c->red_out; a.mode = KT_MODE_HOST;
+    a.granules = (unsigned long long*)c->red_partials; a.epoch = kt_next_epoch(c); a.out29 = c->red_out; a.mode = KT_MODE_HOST;
     hipLaunchKernelGGL(kt_rgb_kernel, dim3(KT_RED_BLOCKS), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
-    KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * 29, hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * KT_RED_SLOTS, hipMemcpyDeviceToHost, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
+    if (c->red_out_host[KT_RED_SLOTS - 1] != 0.0f) { kt_set_error("rgbStep: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
     kt_unpack29_host(c->red_out_host, A_host, b_host, nullptr);
     return KT_OK;
 }
@@ -532,7 +566,7 @@ int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corr
     kt_rgb_args a;
     a.corres = corres_img; a.sigma = 0.f; a.cloud = cloud; a.fx = fx; a.fy = fy; a.dIdx = dIdx; a.dIdy = dIdy;
     a.sobel_scale = sobel_scale; a.cols = cols; a.rows = rows; a.state = state;
-    a.partials = (float*)c->red_partials; a.ticket = &c->counters[0]; a.out29 = nullptr; a.mode = mode;
+    a.granules = (unsigned long long*)c->red_partials; a.epoch = kt_next_epoch(c); a.out29 = nullptr; a.mode = mode;
     a.next_k = *next_k;
     hipLaunchKernelGGL(kt_rgb_kernel, dim3(KT_RED_BLOCKS), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();

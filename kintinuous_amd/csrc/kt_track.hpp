@@ -24,7 +24,7 @@ struct kt_track_state {
     int rgb_count, rgb_sigma;
     float icp29[29];                          // ICP sums stashed for the joint solve
     float last_residual[2];
-    float pad;
+    int handoff_timeout;                      // set by a reduction epilogue whose hand-off sweep gave up
 };
 
 #ifdef __HIPCC__
@@ -196,6 +196,9 @@ __device__ __forceinline__ void kt_ldlt_step(double (&A)[36], int (&tr)[6])
         const double v = fabs(A[i * 6 + i]);
         if (v > big) { big = v; p = i; }
     }
+    // one lane runs the solve: make the pivot index wave-uniform so the swaps below are scalar branches around a few moves
+    // instead of 15 x 24 predicated selects
+    p = __builtin_amdgcn_readfirstlane(p);
     tr[K] = p;
 #pragma unroll
     for (int c = K + 1; c < 6; ++c)
@@ -253,23 +256,40 @@ __device__ __forceinline__ void kt_ldlt_solve6_reg(double (&A)[36], const double
             if (tr[k] == c) { const double t = x[k]; x[k] = x[c]; x[c] = t; }
 }
 
-// executed by ONE thread in the epilogue of the last block
-__device__ __forceinline__ void kt_solve_and_update(kt_track_state* st, double (&dA)[36], const double (&db)[6])
+// opt-in timing probes of the reduction tail (build with KT_EXTRA_FLAGS=-DKT_ICP_TIMING; scripts/icp_timing.py)
+#ifdef KT_ICP_TIMING
+#define KT_TS(i) do { if (threadIdx.x == 0) kt_ts[i] = wall_clock64(); } while (0)
+__shared__ unsigned long long kt_ts[8];
+#else
+#define KT_TS(i) do {} while (0)
+#endif
+
+// the part of the device state one Gauss-Newton step reads, held in registers (loaded early by the sweeping workgroup)
+struct kt_pose_regs {
+    double resultRt[16];
+    float Rprev[9], tprev[3];
+    __device__ __forceinline__ void load(const kt_track_state* st)
+    {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) resultRt[k] = st->resultRt[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rprev[k] = st->Rprev[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tprev[k] = st->tprev[k];
+    }
+};
+
+// executed by ONE thread in the epilogue of the sweeping workgroup
+__device__ __forceinline__ void kt_solve_and_update(kt_track_state* st, kt_pose_regs& pr, double (&dA)[36], const double (&db)[6])
 {
     double x[6];
     kt_ldlt_solve6_reg(dA, db, x);
-    // local copies keep the pose update in registers; the state is written once at the end
-    double resultRt[16];
-    float Rprev[9], tprev[3], Rcurr[9], tcurr[3];
+    KT_TS(5);
+    float Rcurr[9], tcurr[3];
+    kt_pose_update(x, pr.resultRt, pr.Rprev, pr.tprev, Rcurr, tcurr);
+    KT_TS(6);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) resultRt[k] = st->resultRt[k];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rprev[k] = st->Rprev[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tprev[k] = st->tprev[k];
-    kt_pose_update(x, resultRt, Rprev, tprev, Rcurr, tcurr);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) st->resultRt[k] = resultRt[k];
+    for (int k = 0; k < 16; ++k) st->resultRt[k] = pr.resultRt[k];
 #pragma unroll
     for (int k = 0; k < 9; ++k) st->Rcurr[k] = Rcurr[k];
 #pragma unroll

@@ -17,6 +17,19 @@ namespace {
 struct DensePose { uint64_t ts; float pose[16]; int is_loop; };   // KintinuousTracker.h:151-169
 struct Slice { std::vector<kt_point_xyzrgb> pts; int dim; float R[9], cam[3]; uint64_t ts; };      // CloudSlice.h:28-129 (cloud + dimension)
 
+// Everything computed from the input frame alone (bilateral + pyramids + scaleDepth records): two sets, so the set of frame
+// k + 1 can be filled on the prefetch stream while frame k is tracked and fused on the main stream.
+struct FrameSet {
+    uint16_t* depths[KT_LEVELS];
+    float *vmaps[KT_LEVELS], *nmaps[KT_LEVELS];
+    void* rec;            // per-pixel integrate records (kt_integrate_prepare)
+    float* scaled;        // depthRawScaled_
+    hipEvent_t ready;     // recorded on the prefetch stream when the set is complete
+    hipEvent_t released;  // recorded on the main stream after the last reader (integrate) of the frame that used the set
+    bool used;
+};
+struct Pending { const uint16_t* depth; const uint8_t* rgb; int set; };
+
 enum { ST_PYRAMID = 0, ST_ODOMETRY, ST_SHIFT, ST_INTEGRATE, ST_RAYCAST, ST_RESIZE, ST_TSDF23, ST_COUNT };
 
 }  // namespace
@@ -42,6 +55,13 @@ struct kt_tracker {
     float *vmaps_curr[KT_LEVELS], *nmaps_curr[KT_LEVELS], *vmaps_g_prev[KT_LEVELS], *nmaps_g_prev[KT_LEVELS];
     uint8_t* vmap_curr_color;
     float* depth_raw_scaled;
+    void* rec_curr;                    // integrate records of the current frame (set member, like the *_curr maps above)
+    // the *_curr pointers above alias sets[cur_set]
+    FrameSet sets[2];
+    int last_assigned;                 // set handed to the most recent frame (prefetched or inline)
+    std::vector<Pending> pending;      // prefetched frames not yet processed (at most 2)
+    hipStream_t pre_stream;
+    kt_ctx pre_ctx;                    // the context with pre_stream as its stream (image kernels only)
     kt_point_xyzrgb* cloud_device; size_t cloud_cap;
     // RGBDOdometry buffers (RGBDOdometry.h:96-111)
     float *last_depth[KT_LEVELS], *next_depth[KT_LEVELS];
@@ -86,6 +106,32 @@ static int dev_alloc(T** p, size_t count, bool zero)
     KT_HIP(hipMalloc((void**)p, (count ? count : 1) * sizeof(T)));
     if (zero) KT_HIP(hipMemsetAsync(*p, 0, (count ? count : 1) * sizeof(T), g_alloc_stream));
     return KT_OK;
+}
+
+// make sets[q] the current frame's set
+static void select_set(kt_tracker* t, int q)
+{
+    for (int l = 0; l < KT_LEVELS; ++l) {
+        t->depths_curr[l] = t->sets[q].depths[l];
+        t->vmaps_curr[l] = t->sets[q].vmaps[l];
+        t->nmaps_curr[l] = t->sets[q].nmaps[l];
+    }
+    t->depth_raw_scaled = t->sets[q].scaled;
+    t->rec_curr = t->sets[q].rec;
+}
+
+// [A] of processFrame (KintinuousTracker.cpp:465-479) plus the pose-independent half of integrate, into sets[q] on cx's stream
+static int build_frame_set(kt_tracker* t, kt_ctx* cx, int q, const uint16_t* depth_raw, const uint8_t* colors)
+{
+    const int cols = t->cfg.cols, rows = t->cfg.rows;
+    FrameSet& fs = t->sets[q];
+    const bool icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
+    if (icp || t->cfg.use_rgbd_icp || !t->cfg.disable_color_angle) {
+        KT_TRY(kt_bilateral_filter(cx, depth_raw, fs.depths[0], cols, rows));
+        uint16_t* dl[3] = {fs.depths[1], fs.depths[2], fs.depths[3]};
+        KT_TRY(kt_build_pyramid(cx, &t->intr, fs.depths[0], cols, rows, dl, fs.vmaps, fs.nmaps));
+    }
+    return kt_integrate_prepare(cx, depth_raw, colors, fs.nmaps[0], cols, rows, &t->intr, !t->cfg.disable_color_angle, fs.scaled, fs.rec);
 }
 
 static void compute_global_camera(kt_tracker* t, const float* tcurr)
@@ -194,9 +240,11 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
     KT_TRY(dev_alloc(&t->color, nvox * 4, false));
     for (int l = 0; l < KT_LEVELS; ++l) {  // allocateBuffers :356-382; zero-filled so "stale" planes are defined
         const size_t p = (size_t)lvl_cols(t, l) * lvl_rows(t, l);
-        KT_TRY(dev_alloc(&t->depths_curr[l], p, true));
-        KT_TRY(dev_alloc(&t->vmaps_curr[l], 3 * p, true));
-        KT_TRY(dev_alloc(&t->nmaps_curr[l], 3 * p, true));
+        for (int q = 0; q < 2; ++q) {
+            KT_TRY(dev_alloc(&t->sets[q].depths[l], p, true));
+            KT_TRY(dev_alloc(&t->sets[q].vmaps[l], 3 * p, true));
+            KT_TRY(dev_alloc(&t->sets[q].nmaps[l], 3 * p, true));
+        }
         KT_TRY(dev_alloc(&t->vmaps_g_prev[l], 3 * p, true));
         KT_TRY(dev_alloc(&t->nmaps_g_prev[l], 3 * p, true));
         const bool rgbd = cfg->use_rgbd || cfg->use_rgbd_icp;
@@ -211,7 +259,21 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
         KT_TRY(dev_alloc(&t->corres[l], q, true));
     }
     KT_TRY(dev_alloc(&t->vmap_curr_color, P * 4, true));
-    KT_TRY(dev_alloc(&t->depth_raw_scaled, P, true));
+    for (int q = 0; q < 2; ++q) {
+        KT_TRY(dev_alloc(&t->sets[q].scaled, P, true));
+        unsigned char* rec = nullptr;
+        KT_TRY(dev_alloc(&rec, kt_integrate_rec_bytes(cfg->cols, cfg->rows), true));
+        t->sets[q].rec = rec;
+        KT_HIP(hipEventCreateWithFlags(&t->sets[q].ready, hipEventDisableTiming));
+        KT_HIP(hipEventCreateWithFlags(&t->sets[q].released, hipEventDisableTiming));
+        t->sets[q].used = false;
+    }
+    KT_HIP(hipStreamCreateWithFlags(&t->pre_stream, hipStreamNonBlocking));
+    t->pre_ctx = *ctx;
+    t->pre_ctx.stream = t->pre_stream;
+    t->pre_ctx.own_stream = false;
+    t->last_assigned = 1;
+    select_set(t, 0);
     t->cloud_cap = cfg->max_slice_points > 0 ? (size_t)cfg->max_slice_points : P * 3;  // cloud_device_(numPixels * 3) :77
     KT_TRY(dev_alloc(&t->cloud_device, t->cloud_cap, false));
     KT_TRY(dev_alloc(&t->state_dev, 1, true));
@@ -240,12 +302,18 @@ int kt_tracker_destroy(kt_tracker* t)
     (void)hipStreamSynchronize(t->ctx->stream);
     (void)hipFree(t->tsdf); (void)hipFree(t->color);
     for (int l = 0; l < KT_LEVELS; ++l) {
-        (void)hipFree(t->depths_curr[l]); (void)hipFree(t->vmaps_curr[l]); (void)hipFree(t->nmaps_curr[l]);
+        for (int q = 0; q < 2; ++q) { (void)hipFree(t->sets[q].depths[l]); (void)hipFree(t->sets[q].vmaps[l]); (void)hipFree(t->sets[q].nmaps[l]); }
         (void)hipFree(t->vmaps_g_prev[l]); (void)hipFree(t->nmaps_g_prev[l]);
         (void)hipFree(t->last_depth[l]); (void)hipFree(t->next_depth[l]); (void)hipFree(t->last_image[l]); (void)hipFree(t->next_image[l]);
         (void)hipFree(t->next_dIdx[l]); (void)hipFree(t->next_dIdy[l]); (void)hipFree(t->point_clouds[l]); (void)hipFree(t->corres[l]);
     }
-    (void)hipFree(t->vmap_curr_color); (void)hipFree(t->depth_raw_scaled); (void)hipFree(t->cloud_device);
+    (void)hipStreamSynchronize(t->pre_stream);
+    for (int q = 0; q < 2; ++q) {
+        (void)hipFree(t->sets[q].scaled); (void)hipFree(t->sets[q].rec);
+        (void)hipEventDestroy(t->sets[q].ready); (void)hipEventDestroy(t->sets[q].released);
+    }
+    (void)hipStreamDestroy(t->pre_stream);
+    (void)hipFree(t->vmap_curr_color); (void)hipFree(t->cloud_device);
     (void)hipFree(t->state_dev); (void)hipHostFree(t->state_host);
     (void)hipFree(t->depth_stage); (void)hipFree(t->rgb_stage);
     (void)hipHostFree(t->depth_stage_host); (void)hipHostFree(t->rgb_stage_host);
@@ -266,6 +334,8 @@ int kt_tracker_reset(kt_tracker* t)
     t->voxel_wrap[0] = t->voxel_wrap[1] = t->voxel_wrap[2] = 0;
     t->poses.clear();
     t->slices.clear();
+    KT_HIP(hipStreamSynchronize(t->pre_stream));
+    t->pending.clear();
     t->parked = t->cfg.static_mode != 0;
     KT_TRY(kt_init_volume(t->ctx, t->tsdf, t->N));
     KT_TRY(kt_init_color_volume(t->ctx, t->color, t->N));
@@ -301,6 +371,7 @@ static int odometry_end(kt_tracker* t, float* Rcurr, float* tcurr)
     KT_HIP(hipMemcpyAsync(t->state_host, t->state_dev, sizeof(kt_track_state), hipMemcpyDeviceToHost, t->ctx->stream));
     KT_HIP(hipStreamSynchronize(t->ctx->stream));  // the ONE host sync of the frame
     ev_collect(t);
+    if (t->state_host->handoff_timeout) { kt_set_error("odometry: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
     memcpy(Rcurr, t->state_host->Rcurr, 9 * sizeof(float));
     memcpy(tcurr, t->state_host->tcurr, 3 * sizeof(float));
     return KT_OK;
@@ -445,14 +516,23 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
     const bool rgbd = !icp;
     const int angle_color = !t->cfg.disable_color_angle;
 
-    // [A] pyramid build, KintinuousTracker.cpp:465-479
-    KT_TRY(ev_begin(t, ST_PYRAMID));
-    if (icp || t->cfg.use_rgbd_icp || !t->cfg.disable_color_angle) {
-        KT_TRY(kt_bilateral_filter(c, depth_raw, t->depths_curr[0], cols, rows));
-        uint16_t* dl[3] = {t->depths_curr[1], t->depths_curr[2], t->depths_curr[3]};
-        KT_TRY(kt_build_pyramid(c, &t->intr, t->depths_curr[0], cols, rows, dl, t->vmaps_curr, t->nmaps_curr));
+    // [A] pyramid build, KintinuousTracker.cpp:465-479 (+ scaleDepth records): taken from the prefetch stream if this frame
+    // was announced with kt_tracker_prefetch_frame, otherwise computed here
+    int set;
+    if (!t->pending.empty() && t->pending.front().depth == depth_raw && t->pending.front().rgb == colors) {
+        set = t->pending.front().set;
+        t->pending.erase(t->pending.begin());
+        KT_HIP(hipStreamWaitEvent(c->stream, t->sets[set].ready, 0));
+    } else {
+        for (const Pending& p : t->pending) KT_HIP(hipStreamWaitEvent(c->stream, t->sets[p.set].ready, 0));  // abandoned prefetches
+        t->pending.clear();
+        set = t->last_assigned ^ 1;
+        t->last_assigned = set;
+        KT_TRY(ev_begin(t, ST_PYRAMID));
+        KT_TRY(build_frame_set(t, c, set, depth_raw, colors));
+        KT_TRY(ev_end(t, ST_PYRAMID));
     }
-    KT_TRY(ev_end(t, ST_PYRAMID));
+    select_set(t, set);
 
     if (t->global_time == 0) {  // [B] :481-557
         kt_mat33 Rcam, Rcam_inv;
@@ -465,11 +545,13 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
         tsdf23_hook_arm(t);
         KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rcam_inv, t->tlast, t->tranc_dist, t->tsdf,
                                       t->depth_raw_scaled, empty, t->color, colors, t->nmaps_curr[0], angle_color, N,
-                                      t->counting ? t->upd_dev : nullptr));
+                                      t->counting ? t->upd_dev : nullptr, t->rec_curr));
         KT_TRY(ev_end(t, ST_INTEGRATE));
         for (int l = 0; l < KT_LEVELS; ++l)
             KT_TRY(kt_transform_maps(c, t->vmaps_curr[l], t->nmaps_curr[l], lvl_cols(t, l), lvl_rows(t, l), &Rcam, t->tlast, t->vmaps_g_prev[l],
                                      t->nmaps_g_prev[l]));
+        KT_HIP(hipEventRecord(t->sets[set].released, c->stream));  // transform_maps was the last reader of this set
+        t->sets[set].used = true;
         ++t->global_time;
         push_pose(t, timestamp, t->Rlast, 1);
         if (t->counting) {
@@ -548,8 +630,10 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
     tsdf23_hook_arm(t);
     KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rc_inv, tcurr, t->tranc_dist, t->tsdf,
                                   t->depth_raw_scaled, t->v_wrap_copy, t->color, colors, t->nmaps_curr[0], angle_color, N,
-                                  t->counting ? t->upd_dev : nullptr));
+                                  t->counting ? t->upd_dev : nullptr, t->rec_curr));
     KT_TRY(ev_end(t, ST_INTEGRATE));
+    KT_HIP(hipEventRecord(t->sets[set].released, c->stream));  // integrate was the last reader of this frame's set
+    t->sets[set].used = true;
     v_wrap_copy_update(t);
     // [I] raycast :880-890
     KT_TRY(ev_begin(t, ST_RAYCAST));
@@ -572,6 +656,20 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
         t->last_U = u;
         t->last_S = s;
     }
+    return KT_OK;
+}
+
+int kt_tracker_prefetch_frame(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors)
+{
+    KT_ARG(t && depth_raw && colors);
+    if (t->pending.size() >= 2) { kt_set_error("kt_tracker_prefetch_frame: two frames are already outstanding"); return KT_ERR_STATE; }
+    const int set = t->last_assigned ^ 1;
+    t->last_assigned = set;
+    if (t->sets[set].used) KT_HIP(hipStreamWaitEvent(t->pre_stream, t->sets[set].released, 0));
+    t->pre_ctx.device = t->ctx->device;
+    KT_TRY(build_frame_set(t, &t->pre_ctx, set, depth_raw, colors));
+    KT_HIP(hipEventRecord(t->sets[set].ready, t->pre_stream));
+    t->pending.push_back(Pending{depth_raw, colors, set});
     return KT_OK;
 }
 

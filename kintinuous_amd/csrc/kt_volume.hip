@@ -426,7 +426,8 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
 int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
                            const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
                            int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
-                           const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev)
+                           const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev,
+                           const void* prepared_rec)
 {
     KT_ARG(c && depth_raw && intr && volume_size && Rcurr_inv && tcurr && volume && depth_raw_scaled && voxel_wrap &&
            color_volume && colors && nmap_curr && N > 0 && cols > 0 && rows > 0);
@@ -450,12 +451,14 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
         KT_HIP(hipMemcpyAsync(sc.vgz, th, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
         KT_HIP(hipMemcpyAsync(sc.zs, th + sc.tabN, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
     }
-    dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8));
-    hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, g_scratch.rec, colors, nmap_curr,
-                       cols, rows, *intr, angle_color);
-    KT_LAUNCH_CHECK();
+    if (!prepared_rec) {  // scaleDepth + per-pixel records (a caller that ran kt_integrate_prepare ahead of time passes them in)
+        dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8));
+        hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, g_scratch.rec, colors, nmap_curr,
+                           cols, rows, *intr, angle_color);
+        KT_LAUNCH_CHECK();
+    }
     kt_tsdf23_args a;
-    a.rec = g_scratch.rec;
+    a.rec = prepared_rec ? (const kt_pixrec*)prepared_rec : g_scratch.rec;
     a.volume = volume;
     a.color = (uchar4*)color_volume;
     a.vgz = g_scratch.vgz;
@@ -486,13 +489,26 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     return KT_OK;
 }
 
+// The pose-independent half of integrateTsdfVolume (scaleDepth, tsdf_volume.cu:493-511, plus the per-pixel records): the tracker
+// runs it for frame k + 1 on its prefetch stream while frame k is still being tracked.
+size_t kt_integrate_rec_bytes(int cols, int rows) { return (size_t)cols * rows * sizeof(kt_pixrec); }
+int kt_integrate_prepare(kt_ctx* c, const uint16_t* depth_raw, const uint8_t* colors, const float* nmap_curr, int cols, int rows,
+                         const kt_intr* intr, int angle_color, float* depth_raw_scaled, void* rec)
+{
+    dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8));
+    hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, (kt_pixrec*)rec, colors, nmap_curr, cols, rows,
+                       *intr, angle_color);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
 extern "C" int kt_integrate_tsdf(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
                                  const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
                                  int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
                                  const uint8_t* colors, const float* nmap_curr, int angle_color, int N)
 {
     return kt_integrate_tsdf_impl(c, depth_raw, cols, rows, intr, volume_size, Rcurr_inv, tcurr, tranc_dist, volume,
-                                  depth_raw_scaled, voxel_wrap, color_volume, colors, nmap_curr, angle_color, N, nullptr);
+                                  depth_raw_scaled, voxel_wrap, color_volume, colors, nmap_curr, angle_color, N, nullptr, nullptr);
 }
 
 // ================================================================================================

@@ -152,3 +152,45 @@ def test_device_frames_and_counts(ctx, oracle_mod, small_scene):
     ms = trk.stage_ms()
     assert ms["integrate"][1] >= 2 and ms["integrate"][0] > 0 and ms["tsdf23"][1] >= 0
     trk.close(); otr.close()
+
+
+def test_readahead_is_transparent(ctx, small_scene):
+    """kt_tracker_prefetch_frame (pose-independent stages of the next frame on a second stream) must not change anything:
+    same poses, same volumes, same predicted maps -- with in-order read-ahead, with an abandoned read-ahead, and mixed
+    with host-frame calls."""
+    from kintinuous_amd import abi
+    cam, frames, _ = small_scene
+    frames = frames[:8]
+    dev = [(ctx.upload(d), ctx.upload(rgb)) for d, rgb in frames]
+    g, _ = _cfgs(cam, 96)
+
+    def run(mode):
+        trk = abi.Tracker(ctx, g)
+        for k in range(len(dev)):
+            if mode == "ahead" and k + 1 < len(dev):
+                trk.prefetch_frame(*dev[k + 1])
+            if mode == "chaos":
+                if k == 2:
+                    trk.prefetch_frame(*dev[5])            # never processed next: must be discarded
+                elif k == 4:
+                    trk.prefetch_frame(*dev[5]); trk.prefetch_frame(*dev[6])   # two outstanding, consumed in order
+                    with pytest.raises(abi.KtError):
+                        trk.prefetch_frame(*dev[7])
+            if mode == "chaos" and k == 3:
+                trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
+            else:
+                trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+        poses = [trk.dense_pose(i)[1].copy() for i in range(trk.num_poses())]
+        out = (poses, trk.volume().copy(), trk.color_volume().copy(), [trk.vmap_g_prev(l).copy() for l in range(4)])
+        trk.close()
+        return out
+
+    ref = run("plain")
+    for mode in ("ahead", "chaos"):
+        got = run(mode)
+        assert len(got[0]) == len(ref[0])
+        for a, b in zip(got[0], ref[0]):
+            assert np.array_equal(a, b), mode
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), mode
+        for a, b in zip(got[3], ref[3]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mode
