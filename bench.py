@@ -103,6 +103,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     ctx.sync()
+    trk.host_times(reset=True)
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
@@ -124,6 +125,7 @@ def main():
     fps = aggregate_fps(dist, args.steps, elapsed, world, device=(f"cuda:{local_rank}" if dist is not None else None))
     elapsed = world * args.steps / fps
 
+    host_call_s, host_wait_s = trk.host_times()
     stage = trk.stage_ms()
     tsdf23_ms, tsdf23_n = stage["tsdf23"]
     # tracking must still be healthy at the end of the timed region (not a degenerate run)
@@ -180,6 +182,7 @@ def main():
                      "frac": achieved / peak, "traffic": None, "algorithmic_bytes_per_launch": bytes_tsdf23,
                      "avg_launch_ms": tsdf23_ms, "launches_timed": tsdf23_n, "U_voxels_updated": U, "S_raycast_steps": float(np.mean(Ss))},
         "stage_ms": {k: round(v[0], 4) for k, v in stage_all.items()},
+        "host_ms_per_frame": {"process_frame_call": round(1e3 * host_call_s, 4), "of_which_waiting_for_pose": round(1e3 * host_wait_s, 4)},
     }
 
     if rank == 0 and not args.no_cpu_baseline:

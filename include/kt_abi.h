@@ -217,6 +217,9 @@ float kt_tracker_trunc_dist(kt_tracker* t);
 int kt_tracker_enable_profiling(kt_tracker* t, int on);
 int kt_tracker_stage_ms(kt_tracker* t, float ms_host[7]);
 int kt_tracker_stage_counts(kt_tracker* t, long long n_host[7]);
+/* where the host thread spends a frame: mean seconds per kt_tracker_process_frame call {whole call, waiting for the previous
+ * frame's pose}; reset != 0 restarts the statistics */
+int kt_tracker_host_times(kt_tracker* t, double out2_host[2], int reset);
 /* counters of the last frame (costs two extra syncs per frame; off by default): U = voxels that passed the
  * integrate update predicate, S = ray-march steps */
 int kt_tracker_enable_counts(kt_tracker* t, int on);

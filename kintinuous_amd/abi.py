@@ -124,6 +124,7 @@ _PROTOS = {
     "kt_tracker_last_counts": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "kt_tracker_debug_counts": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_debug_state": (_i, [_vp, _pf]),
+    "kt_tracker_host_times": (_i, [_vp, _pd, _i]),
     "kt_tracker_prefetch_frame": (_i, [_vp, _vp, _vp]),
     "kt_tracker_slice_pose": (_i, [_vp, _i, _pf, _pf, C.POINTER(_u64)]),
     "kt_tracker_set_parked": (_i, [_vp, _i]),
@@ -354,6 +355,12 @@ class Tracker:
         d = depth_dev.ptr if isinstance(depth_dev, DevBuf) else int(depth_dev)
         r = rgb_dev.ptr if isinstance(rgb_dev, DevBuf) else int(rgb_dev)
         _chk(lib().kt_tracker_process_frame(self.h, d, r, timestamp))
+
+    def host_times(self, reset: bool = False):
+        """(mean seconds per process_frame call, of which waiting for the previous frame's pose)."""
+        o = (C.c_double * 2)()
+        _chk(lib().kt_tracker_host_times(self.h, o, 1 if reset else 0))
+        return float(o[0]), float(o[1])
 
     def prefetch_frame(self, depth_dev, rgb_dev) -> None:
         """Announce a frame a later process_frame call will receive: its pose-independent stages run on a second stream."""

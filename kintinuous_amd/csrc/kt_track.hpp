@@ -25,6 +25,8 @@ struct kt_track_state {
     float icp29[29];                          // ICP sums stashed for the joint solve
     float last_residual[2];
     int handoff_timeout;                      // set by a reduction epilogue whose hand-off sweep gave up
+    int fusion_skipped;                       // kt_frame_setup_kernel: the frame needs a volume shift, fusion kernels did nothing
+    int pad2;
 };
 
 #ifdef __HIPCC__

@@ -10,6 +10,7 @@
 #include <limits.h>
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -77,9 +78,16 @@ struct kt_tracker {
     // outputs
     std::vector<DensePose> poses;
     std::vector<Slice> slices;
-    // profiling / counters
-    int profiling;
-    hipEvent_t ev[ST_COUNT][2]; bool ev_rec[ST_COUNT];
+    // deferred completion: a frame's fusion kernels are enqueued before the host has seen its pose (complete_frame)
+    bool outstanding; uint64_t out_ts; int out_set;
+    const uint16_t* out_depth; const uint8_t* out_rgb; int out_thresh;
+    kt_frame_params* fp_dev;
+    float *vgz_dev, *zs_dev;           // z tables of integrate (kt_integrate_tables)
+    hipStream_t copy_stream; hipEvent_t ev_setup_done, ev_state;
+    // profiling / counters (events double-buffered by frame parity: a pair is read one frame after it was recorded)
+    double host_wait_s, host_call_s; long long host_calls;   // where the host thread spends a frame (kt_tracker_host_times)
+    int profiling; int ev_par;
+    hipEvent_t ev[2][ST_COUNT][2]; bool ev_rec[2][ST_COUNT];
     double stage_ms_sum[ST_COUNT]; long long stage_n[ST_COUNT]; float stage_ms_last[ST_COUNT];
     int counting;
     unsigned int* upd_dev; unsigned long long* steps_dev;
@@ -171,39 +179,40 @@ static void push_pose(kt_tracker* t, uint64_t ts, const float* R, int is_loop)
 static int ev_begin(kt_tracker* t, int st)
 {
     if (t->profiling >= 2 || (t->profiling == 1 && st == ST_TSDF23)) {
-        KT_HIP(hipEventRecord(t->ev[st][0], t->ctx->stream));
+        KT_HIP(hipEventRecord(t->ev[t->ev_par][st][0], t->ctx->stream));
     }
     return KT_OK;
 }
 static int ev_end(kt_tracker* t, int st)
 {
     if (t->profiling >= 2 || (t->profiling == 1 && st == ST_TSDF23)) {
-        KT_HIP(hipEventRecord(t->ev[st][1], t->ctx->stream));
-        t->ev_rec[st] = true;
+        KT_HIP(hipEventRecord(t->ev[t->ev_par][st][1], t->ctx->stream));
+        t->ev_rec[t->ev_par][st] = true;
     }
     return KT_OK;
 }
 static void tsdf23_hook_arm(kt_tracker* t)
 {
     kt_tsdf23_hook.on = t->profiling >= 1;
-    kt_tsdf23_hook.ev[0] = t->ev[ST_TSDF23][0];
-    kt_tsdf23_hook.ev[1] = t->ev[ST_TSDF23][1];
-    if (kt_tsdf23_hook.on) t->ev_rec[ST_TSDF23] = true;
+    kt_tsdf23_hook.ev[0] = t->ev[t->ev_par][ST_TSDF23][0];
+    kt_tsdf23_hook.ev[1] = t->ev[t->ev_par][ST_TSDF23][1];
+    if (kt_tsdf23_hook.on) t->ev_rec[t->ev_par][ST_TSDF23] = true;
 }
-// call only right after a stream synchronisation: every recorded pair is complete
+// harvest every recorded pair whose end event has completed (pairs still in flight stay armed)
 static void ev_collect(kt_tracker* t)
 {
     if (!t->profiling) return;
-    for (int st = 0; st < ST_COUNT; ++st)
-        if (t->ev_rec[st]) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, t->ev[st][0], t->ev[st][1]) == hipSuccess) {
-                t->stage_ms_sum[st] += ms;
-                t->stage_n[st] += 1;
-                t->stage_ms_last[st] = ms;
+    for (int par = 0; par < 2; ++par)
+        for (int st = 0; st < ST_COUNT; ++st)
+            if (t->ev_rec[par][st] && hipEventQuery(t->ev[par][st][1]) == hipSuccess) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, t->ev[par][st][0], t->ev[par][st][1]) == hipSuccess) {
+                    t->stage_ms_sum[st] += ms;
+                    t->stage_n[st] += 1;
+                    t->stage_ms_last[st] = ms;
+                }
+                t->ev_rec[par][st] = false;
             }
-            t->ev_rec[st] = false;
-        }
 }
 
 extern "C" {
@@ -286,11 +295,20 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
     KT_TRY(dev_alloc(&t->steps_dev, 2, true));
     t->profiling = 0;
     t->counting = 0;
-    for (int s = 0; s < ST_COUNT; ++s) {
-        KT_HIP(hipEventCreate(&t->ev[s][0]));
-        KT_HIP(hipEventCreate(&t->ev[s][1]));
-        t->ev_rec[s] = false;
-    }
+    for (int par = 0; par < 2; ++par)
+        for (int s = 0; s < ST_COUNT; ++s) {
+            KT_HIP(hipEventCreate(&t->ev[par][s][0]));
+            KT_HIP(hipEventCreate(&t->ev[par][s][1]));
+            t->ev_rec[par][s] = false;
+        }
+    t->ev_par = 0;
+    t->outstanding = false;
+    t->host_wait_s = t->host_call_s = 0.0; t->host_calls = 0;
+    KT_TRY(dev_alloc(&t->fp_dev, 1, true));
+    KT_TRY(kt_integrate_tables(ctx, cfg->cols, cfg->rows, cfg->N, &t->vgz_dev, &t->zs_dev));
+    KT_HIP(hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking));
+    KT_HIP(hipEventCreateWithFlags(&t->ev_setup_done, hipEventDisableTiming));
+    KT_HIP(hipEventCreateWithFlags(&t->ev_state, hipEventDisableTiming));
     KT_TRY(kt_tracker_reset(t));
     *out = t;
     return KT_OK;
@@ -299,6 +317,7 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
 int kt_tracker_destroy(kt_tracker* t)
 {
     if (!t) return KT_OK;
+    if (t->outstanding) (void)hipEventSynchronize(t->ev_state);
     (void)hipStreamSynchronize(t->ctx->stream);
     (void)hipFree(t->tsdf); (void)hipFree(t->color);
     for (int l = 0; l < KT_LEVELS; ++l) {
@@ -318,7 +337,12 @@ int kt_tracker_destroy(kt_tracker* t)
     (void)hipFree(t->depth_stage); (void)hipFree(t->rgb_stage);
     (void)hipHostFree(t->depth_stage_host); (void)hipHostFree(t->rgb_stage_host);
     (void)hipFree(t->upd_dev); (void)hipFree(t->steps_dev);
-    for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(t->ev[s][0]); (void)hipEventDestroy(t->ev[s][1]); }
+    for (int par = 0; par < 2; ++par)
+        for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(t->ev[par][s][0]); (void)hipEventDestroy(t->ev[par][s][1]); }
+    (void)hipStreamSynchronize(t->copy_stream);
+    (void)hipStreamDestroy(t->copy_stream);
+    (void)hipEventDestroy(t->ev_setup_done); (void)hipEventDestroy(t->ev_state);
+    (void)hipFree(t->fp_dev);
     delete t;
     return KT_OK;
 }
@@ -327,6 +351,8 @@ int kt_tracker_reset(kt_tracker* t)
 {
     // KintinuousTracker::reset :262-354
     KT_ARG(t);
+    if (t->outstanding) { (void)hipEventSynchronize(t->ev_state); t->outstanding = false; }
+    KT_HIP(hipStreamSynchronize(t->ctx->stream));
     t->global_time = 0;
     memcpy(t->Rlast, t->initial_rotation, sizeof(t->Rlast));
     memcpy(t->tlast, t->volume_basis, sizeof(t->tlast));
@@ -365,20 +391,13 @@ static int odometry_begin(kt_tracker* t, const kt_level_k* first_k)
     return KT_OK;
 }
 
-static int odometry_end(kt_tracker* t, float* Rcurr, float* tcurr)
+static int odometry_end(kt_tracker* t)
 {
-    KT_TRY(ev_end(t, ST_ODOMETRY));
-    KT_HIP(hipMemcpyAsync(t->state_host, t->state_dev, sizeof(kt_track_state), hipMemcpyDeviceToHost, t->ctx->stream));
-    KT_HIP(hipStreamSynchronize(t->ctx->stream));  // the ONE host sync of the frame
-    ev_collect(t);
-    if (t->state_host->handoff_timeout) { kt_set_error("odometry: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
-    memcpy(Rcurr, t->state_host->Rcurr, 9 * sizeof(float));
-    memcpy(tcurr, t->state_host->tcurr, 3 * sizeof(float));
-    return KT_OK;
+    return ev_end(t, ST_ODOMETRY);  // the pose stays on the device; complete_frame() reads it one frame later
 }
 
 // ICPOdometry::getIncrementalTransformation, ICPOdometry.cpp:68-186
-static int icp_odometry(kt_tracker* t, float* tcurr, float* Rcurr)
+static int icp_odometry(kt_tracker* t)
 {
     int iters[KT_LEVELS] = {10, 5, 4, 0};
     if (t->cfg.fast_odometry) { iters[0] = 0; iters[1] = 10; iters[2] = 5; iters[3] = 0; }
@@ -391,7 +410,7 @@ static int icp_odometry(kt_tracker* t, float* tcurr, float* Rcurr)
             KT_TRY(kt_icp_step_device(t->ctx, t->state_dev, t->vmaps_curr[l], t->nmaps_curr[l], &li, t->vmaps_g_prev[l],
                                       t->nmaps_g_prev[l], lvl_cols(t, l), lvl_rows(t, l), dist_thres, angle_thres, KT_MODE_ICP_SOLVE));
     }
-    return odometry_end(t, Rcurr, tcurr);
+    return odometry_end(t);
 }
 
 // RGBDOdometry::populateRGBDData, RGBDOdometry.cpp:140-158
@@ -405,7 +424,7 @@ static int populate_rgbd(kt_tracker* t, const uint16_t* depth, const uint8_t* rg
 }
 
 // RGBDOdometry::getIncrementalTransformation, RGBDOdometry.cpp:165-393
-static int rgbd_odometry(kt_tracker* t, const uint16_t* depth, const uint8_t* rgb, float* tcurr, float* Rcurr)
+static int rgbd_odometry(kt_tracker* t, const uint16_t* depth, const uint8_t* rgb)
 {
     int iters[KT_LEVELS];
     if (!t->cfg.use_rgbd_icp) {
@@ -419,9 +438,6 @@ static int rgbd_odometry(kt_tracker* t, const uint16_t* depth, const uint8_t* rg
     const double SOBEL_SCALE = 1.0 / pow(2.0, 3), MAX_DEPTH_DELTA = 0.07;
     const float dist_thres = 0.10f;
     const float angle_thres = (float)sin(20.f * 3.14159254f / 180.f);
-    const float tprev[3] = {t->tlast[0], t->tlast[1], t->tlast[2]};
-    float Rprev[9];
-    memcpy(Rprev, t->Rlast, sizeof(Rprev));
 
     KT_TRY(populate_rgbd(t, depth, rgb, t->next_depth, t->next_image));
     for (int l = 0; l < KT_LEVELS; ++l)
@@ -459,25 +475,127 @@ static int rgbd_odometry(kt_tracker* t, const uint16_t* depth, const uint8_t* rg
         KT_TRY(kt_rgb_step_device(t->ctx, t->state_dev, t->corres[l], t->point_clouds[l], li.fx, li.fy, t->next_dIdx[l], t->next_dIdy[l],
                                   (float)SOBEL_SCALE, cols, rows, t->cfg.use_rgbd_icp ? KT_MODE_JOINT_SOLVE : KT_MODE_RGB_SOLVE, nk));
     }
-    KT_TRY(odometry_end(t, Rcurr, tcurr));
+    KT_TRY(odometry_end(t));
     for (int l = 0; l < KT_LEVELS; ++l) {  // swap last/next :377-381
         float* fd = t->last_depth[l]; t->last_depth[l] = t->next_depth[l]; t->next_depth[l] = fd;
         uint8_t* ui = t->last_image[l]; t->last_image[l] = t->next_image[l]; t->next_image[l] = ui;
     }
-    const float d[3] = {tcurr[0] - tprev[0], tcurr[1] - tprev[1], tcurr[2] - tprev[2]};
-    if (sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) > 0.3) {  // :383-387
-        memcpy(Rcurr, Rprev, sizeof(Rprev));
-        memcpy(tcurr, tprev, sizeof(tprev));
-    }
-    return KT_OK;
+    return KT_OK;  // the > 0.3 m jump guard (:383-387) runs in kt_frame_setup_kernel
 }
 
-static int voxel_trans(float translation, float voxel, int thresh)
+__host__ __device__ static int voxel_trans(float translation, float voxel, int thresh)
 {
     // KintinuousTracker.cpp:640-667
     const int f = (int)floorf(translation / voxel);
     if (f < 0) return (-thresh > f) ? -thresh : f;
     return thresh < f ? thresh : f;
+}
+
+// ---- frame set-up on the device ---------------------------------------------------------------------------------------
+// Runs after the last odometry iteration.  Turns the device-resident Gauss-Newton result into what the fusion kernels need:
+// the final pose (RGB-D jump guard applied), its inverse, the z tables of tsdf23 (quirk A.17: a sequential float recurrence)
+// and the shift decision of KintinuousTracker.cpp:627-667 -- a frame that must shift the volume first is parked (skip = 1)
+// and redone by the host's shift path in complete_frame().  mode 1 = pose supplied by the host (that redo).
+struct kt_setup_args {
+    kt_track_state* st; kt_frame_params* fp;
+    float* vgz; float* zs; int N; float cell_z;
+    int mode, rgbd_guard;
+    float R[9], t[3];
+    float basis[3], voxel[3]; int thresh;
+};
+
+__global__ __launch_bounds__(64) void kt_frame_setup_kernel(const kt_setup_args a)
+{
+    float R[9], tv[3];
+    int skip = 0;
+    if (a.mode == 0) {
+        for (int k = 0; k < 9; ++k) R[k] = a.st->Rcurr[k];
+        for (int k = 0; k < 3; ++k) tv[k] = a.st->tcurr[k];
+        if (a.rgbd_guard) {  // RGBDOdometry.cpp:383-387: an increment of more than 0.3 m is discarded
+            const float d0 = tv[0] - a.st->tprev[0], d1 = tv[1] - a.st->tprev[1], d2 = tv[2] - a.st->tprev[2];
+            if ((double)__builtin_sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
+                for (int k = 0; k < 9; ++k) R[k] = a.st->Rprev[k];
+                for (int k = 0; k < 3; ++k) tv[k] = a.st->tprev[k];
+            }
+        }
+        for (int k = 0; k < 3; ++k) {
+            const int vt = voxel_trans(tv[k] - a.basis[k], a.voxel[k], a.thresh);
+            if (vt >= a.thresh || vt <= -a.thresh) skip = 1;
+        }
+    } else {
+        for (int k = 0; k < 9; ++k) R[k] = a.R[k];
+        for (int k = 0; k < 3; ++k) tv[k] = a.t[k];
+    }
+    float Rinv[9];
+    kt_mat33_inverse(R, Rinv);
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        for (int k = 0; k < 9; ++k) { a.fp->R[k] = R[k]; a.fp->Rinv[k] = Rinv[k]; }
+        for (int k = 0; k < 3; ++k) a.fp->t[k] = tv[k];
+        a.fp->skip = skip;
+        if (a.mode == 0) {  // what the host reads back: the final pose and whether the fusion kernels ran
+            for (int k = 0; k < 9; ++k) a.st->Rcurr[k] = R[k];
+            for (int k = 0; k < 3; ++k) a.st->tcurr[k] = tv[k];
+            a.st->fusion_skipped = skip;
+        }
+    }
+    // lane 0 walks v_g_z, lane 1 walks z_scaled: the same dependent float adds as tsdf23's z loop (tsdf_volume.cu:560-640)
+    if (lane < 2 && !skip) {
+        float acc = lane == 0 ? __builtin_fmaf(0 + 0.5f, a.cell_z, -tv[2]) : 0.0f;
+        float* tab = lane == 0 ? a.vgz : a.zs;
+        for (int z = 0; z < a.N; ++z) {
+            tab[z] = acc;
+            acc += a.cell_z;
+        }
+    }
+}
+
+static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv)
+{
+    kt_setup_args a;
+    a.st = t->state_dev; a.fp = t->fp_dev; a.vgz = t->vgz_dev; a.zs = t->zs_dev; a.N = t->N;
+    a.cell_z = t->volume_size[2] / t->N;
+    a.mode = mode;
+    a.rgbd_guard = (t->cfg.use_rgbd || t->cfg.use_rgbd_icp) ? 1 : 0;
+    for (int k = 0; k < 9; ++k) a.R[k] = R ? R[k] : 0.f;
+    for (int k = 0; k < 3; ++k) a.t[k] = tv ? tv[k] : 0.f;
+    for (int k = 0; k < 3; ++k) { a.basis[k] = t->volume_basis[k]; a.voxel[k] = t->voxel_size[k]; }
+    a.thresh = t->parked ? INT_MAX : t->cfg.voxel_shift;
+    hipLaunchKernelGGL(kt_frame_setup_kernel, dim3(1), dim3(64), 0, t->ctx->stream, a);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// [H] integrate (:864-876) + [I] raycast (:880-890) + [J] predicted-map pyramid (:892-899, fused into the raycast epilogue), with
+// the pose taken from fp_dev; wrap = the tracker's current v_wrap_copy
+static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, const uint8_t* colors)
+{
+    kt_ctx* c = t->ctx;
+    const int cols = t->cfg.cols, rows = t->cfg.rows, N = t->N;
+    const bool icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
+    const kt_mat33 dummy_R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    const float dummy_t[3] = {0, 0, 0};
+    if (t->counting) {
+        KT_HIP(hipMemsetAsync(t->upd_dev, 0, 16 * sizeof(unsigned int), c->stream));
+        KT_HIP(hipMemsetAsync(t->steps_dev, 0, sizeof(unsigned long long), c->stream));
+    }
+    KT_TRY(ev_begin(t, ST_INTEGRATE));
+    tsdf23_hook_arm(t);
+    KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &dummy_R, dummy_t, t->tranc_dist, t->tsdf,
+                                  t->sets[set].scaled, t->v_wrap_copy, t->color, colors, t->sets[set].nmaps[0], !t->cfg.disable_color_angle, N,
+                                  t->counting ? t->upd_dev : nullptr, t->sets[set].rec, t->fp_dev));
+    KT_TRY(ev_end(t, ST_INTEGRATE));
+    KT_HIP(hipEventRecord(t->sets[set].released, c->stream));  // integrate was the last reader of this frame's set
+    t->sets[set].used = true;
+    KT_TRY(ev_begin(t, ST_RAYCAST));
+    const bool pyr = icp || t->cfg.use_rgbd_icp;
+    float* vp[3] = {t->vmaps_g_prev[1], t->vmaps_g_prev[2], t->vmaps_g_prev[3]};
+    float* np_[3] = {t->nmaps_g_prev[1], t->nmaps_g_prev[2], t->nmaps_g_prev[3]};
+    KT_TRY(kt_raycast_impl(c, &t->intr, &dummy_R, dummy_t, t->tranc_dist, t->volume_size, t->tsdf, t->vmaps_g_prev[0], t->nmaps_g_prev[0], cols, rows,
+                           t->v_wrap_copy, t->vmap_curr_color, t->color, N, t->counting ? t->steps_dev : nullptr, pyr ? vp : nullptr,
+                           pyr ? np_ : nullptr, t->fp_dev));
+    KT_TRY(ev_end(t, ST_RAYCAST));
+    return KT_OK;
 }
 
 // fetchCloud + download (TSDFVolume.cpp:135-172, KintinuousTracker.cpp:1164-1166): returns the slice on the host
@@ -504,11 +622,132 @@ static int fetch_slice(kt_tracker* t, const int lo[3], const int hi[3], int dim)
     return KT_OK;
 }
 
+static int read_counts(kt_tracker* t)
+{
+    if (!t->counting) return KT_OK;
+    kt_ctx* c = t->ctx;
+    unsigned int u = 0;
+    unsigned long long sdev = 0;
+    KT_HIP(hipMemcpyAsync(&u, t->upd_dev, sizeof(u), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipMemcpyAsync(&sdev, t->steps_dev, sizeof(sdev), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    t->last_U = u;
+    t->last_S = sdev;
+    return KT_OK;
+}
+
+// Host half of the frame enqueued by the last kt_tracker_process_frame call: wait for its pose (the copy-stream event, NOT the
+// fusion kernels), do the pose bookkeeping of KintinuousTracker.cpp:574-595, 903-909 and, when the volume has to shift
+// (:627-833), run the shift and redo the fusion the device parked.  Called at the start of the next frame and by every getter.
+static int complete_frame(kt_tracker* t)
+{
+    if (!t->outstanding) return KT_OK;
+    t->outstanding = false;
+    kt_ctx* c = t->ctx;
+    const int N = t->N;
+    {
+        const auto w0 = std::chrono::steady_clock::now();
+        KT_HIP(hipEventSynchronize(t->ev_state));  // the ONE host wait of the frame; the GPU is busy with integrate / raycast meanwhile
+        t->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+    }
+    ev_collect(t);
+    if (t->state_host->handoff_timeout) { kt_set_error("odometry: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
+    float Rcurr[9], tcurr[3];
+    memcpy(Rcurr, t->state_host->Rcurr, sizeof(Rcurr));
+    memcpy(tcurr, t->state_host->tcurr, sizeof(tcurr));
+    t->current_ts = t->out_ts;
+
+    // [D] rmats_/tvecs_ push, currentGlobalCamera :574-595
+    memcpy(t->Rlast, Rcurr, sizeof(Rcurr));
+    memcpy(t->tlast, tcurr, sizeof(tcurr));
+    compute_global_camera(t, tcurr);
+
+    // [F] shift decision :627-667 and the three axis blocks :669-833
+    float current_translation[3];
+    for (int k = 0; k < 3; ++k) current_translation[k] = t->tlast[k] - t->volume_basis[k];
+    const int thresh = t->out_thresh;
+    int vt[3];
+    bool need_shift = false;
+    for (int k = 0; k < 3; ++k) {
+        vt[k] = voxel_trans(current_translation[k], t->voxel_size[k], thresh);
+        need_shift = need_shift || vt[k] >= thresh || vt[k] <= -thresh;
+    }
+    if (need_shift != (t->state_host->fusion_skipped != 0)) {
+        kt_set_error("tracker: host and device disagree on the shift decision");
+        return KT_ERR_STATE;
+    }
+    if (need_shift) {
+        const int ov = t->cfg.overlap;
+        KT_TRY(ev_begin(t, ST_SHIFT));
+        for (int axis = 0; axis < 3; ++axis) {
+            v_wrap_copy_update(t);
+            bool cycled = false;
+            int lo[3] = {0, 0, 0}, hi[3] = {N, N, N};
+            int dim = 0;
+            if (vt[axis] >= thresh) {
+                lo[axis] = 0; hi[axis] = vt[axis] + 1 + ov;
+                dim = axis * 2;  // XPlus / YPlus / ZPlus, CloudSlice.h:33-36
+                KT_TRY(fetch_slice(t, lo, hi, dim));
+                KT_TRY(kt_clear_volume(c, t->tsdf, 2, N, axis, 0, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
+                KT_TRY(kt_clear_volume(c, t->color, 4, N, axis, 0, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
+                cycled = true;
+            } else if (vt[axis] <= -thresh) {
+                if (axis == 2) { lo[2] = N + (vt[2] - ov) - 1; hi[2] = N - 1; }  // z-minus off by one :805
+                else { lo[axis] = N + (vt[axis] - ov); hi[axis] = N; }
+                dim = axis * 2 + 1;
+                KT_TRY(fetch_slice(t, lo, hi, dim));
+                KT_TRY(kt_clear_volume(c, t->tsdf, 2, N, axis, 1, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
+                KT_TRY(kt_clear_volume(c, t->color, 4, N, axis, 1, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
+                cycled = true;
+            }
+            if (cycled) {
+                // mutexOutCloudBuffer :1156-1208
+                const float shift = t->voxel_size[axis] * (float)vt[axis];
+                t->tlast[axis] -= shift;
+                t->voxel_wrap[axis] += vt[axis];
+                tcurr[axis] -= shift;
+            }
+        }
+        v_wrap_copy_update(t);
+        KT_TRY(ev_end(t, ST_SHIFT));
+        // the fusion the device parked, now with the shifted pose and wrap
+        KT_TRY(launch_setup(t, 1, Rcurr, tcurr));
+        KT_TRY(enqueue_fusion(t, t->out_set, t->out_depth, t->out_rgb));
+    }
+    v_wrap_copy_update(t);
+    ++t->global_time;
+    push_pose(t, t->out_ts, Rcurr, 0);  // [K] :903-909
+    return KT_OK;
+}
+
 extern "C" {
+
+static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors, uint64_t timestamp);
 
 int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors, uint64_t timestamp)
 {
     KT_ARG(t && depth_raw && colors);
+    const auto c0 = std::chrono::steady_clock::now();
+    const int r = process_frame_impl(t, depth_raw, colors, timestamp);
+    t->host_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+    t->host_calls += 1;
+    return r;
+}
+
+/* mean seconds per kt_tracker_process_frame call since the last reset of the statistics: {total in the call, of which waiting for
+ * the previous frame's pose}; the difference is enqueue work */
+int kt_tracker_host_times(kt_tracker* t, double out2[2], int reset)
+{
+    KT_ARG(t && out2);
+    out2[0] = t->host_calls ? t->host_call_s / (double)t->host_calls : 0.0;
+    out2[1] = t->host_calls ? t->host_wait_s / (double)t->host_calls : 0.0;
+    if (reset) { t->host_call_s = t->host_wait_s = 0.0; t->host_calls = 0; }
+    return KT_OK;
+}
+
+static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors, uint64_t timestamp)
+{
+    KT_TRY(complete_frame(t));
     kt_ctx* c = t->ctx;
     t->current_ts = timestamp;
     const int cols = t->cfg.cols, rows = t->cfg.rows, N = t->N;
@@ -553,6 +792,7 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
         KT_HIP(hipEventRecord(t->sets[set].released, c->stream));  // transform_maps was the last reader of this set
         t->sets[set].used = true;
         ++t->global_time;
+        t->ev_par ^= 1;
         push_pose(t, timestamp, t->Rlast, 1);
         if (t->counting) {
             unsigned int u = 0;
@@ -564,97 +804,29 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_raw, const uin
         return KT_OK;
     }
 
-    // [C] odometry :564-572
-    float Rcurr[9], tcurr[3];
+    // [C] odometry :564-572 -- every Gauss-Newton iteration is enqueued; the pose stays on the device
     KT_TRY(ev_begin(t, ST_ODOMETRY));
-    if (icp) KT_TRY(icp_odometry(t, tcurr, Rcurr));
-    else KT_TRY(rgbd_odometry(t, depth_raw, colors, tcurr, Rcurr));
-
-    // [D] rmats_/tvecs_ push, currentGlobalCamera :574-595
-    memcpy(t->Rlast, Rcurr, sizeof(Rcurr));
-    memcpy(t->tlast, tcurr, sizeof(tcurr));
-    compute_global_camera(t, tcurr);
-    kt_mat33 Rc, Rc_inv;
-    memcpy(Rc.m, Rcurr, sizeof(Rc.m));
-    kt_mat33_inverse(Rc.m, Rc_inv.m);
-
-    // [F] shift decision :627-667 and the three axis blocks :669-833
-    float current_translation[3];
-    for (int k = 0; k < 3; ++k) current_translation[k] = t->tlast[k] - t->volume_basis[k];
-    const int thresh = t->parked ? INT_MAX : t->cfg.voxel_shift;
-    int vt[3];
-    for (int k = 0; k < 3; ++k) vt[k] = voxel_trans(current_translation[k], t->voxel_size[k], thresh);
-    const int ov = t->cfg.overlap;
-    bool any_shift = false;
-    for (int axis = 0; axis < 3; ++axis) {
-        v_wrap_copy_update(t);
-        bool cycled = false;
-        int lo[3] = {0, 0, 0}, hi[3] = {N, N, N};
-        int dim = 0;
-        if (vt[axis] >= thresh) {
-            if (!any_shift) { KT_TRY(ev_begin(t, ST_SHIFT)); any_shift = true; }
-            lo[axis] = 0; hi[axis] = vt[axis] + 1 + ov;
-            dim = axis * 2;  // XPlus / YPlus / ZPlus, CloudSlice.h:33-36
-            KT_TRY(fetch_slice(t, lo, hi, dim));
-            KT_TRY(kt_clear_volume(c, t->tsdf, 2, N, axis, 0, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
-            KT_TRY(kt_clear_volume(c, t->color, 4, N, axis, 0, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
-            cycled = true;
-        } else if (vt[axis] <= -thresh) {
-            if (!any_shift) { KT_TRY(ev_begin(t, ST_SHIFT)); any_shift = true; }
-            if (axis == 2) { lo[2] = N + (vt[2] - ov) - 1; hi[2] = N - 1; }  // z-minus off by one :805
-            else { lo[axis] = N + (vt[axis] - ov); hi[axis] = N; }
-            dim = axis * 2 + 1;
-            KT_TRY(fetch_slice(t, lo, hi, dim));
-            KT_TRY(kt_clear_volume(c, t->tsdf, 2, N, axis, 1, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
-            KT_TRY(kt_clear_volume(c, t->color, 4, N, axis, 1, t->voxel_wrap[axis], t->voxel_wrap[axis] + vt[axis]));
-            cycled = true;
-        }
-        if (cycled) {
-            // mutexOutCloudBuffer :1156-1208
-            float voxel_trans_size[3] = {0, 0, 0};
-            voxel_trans_size[axis] = t->voxel_size[axis] * (float)vt[axis];
-            for (int k = 0; k < 3; ++k) t->tlast[k] -= voxel_trans_size[k];
-            t->voxel_wrap[axis] += vt[axis];
-            for (int k = 0; k < 3; ++k) tcurr[k] -= voxel_trans_size[k];
-        }
-    }
+    if (icp) KT_TRY(icp_odometry(t));
+    else KT_TRY(rgbd_odometry(t, depth_raw, colors));
+    // device-side frame set-up, then the pose travels to the host on the copy stream while the fusion kernels -- enqueued right
+    // here, speculatively, on the assumption that the volume does not shift -- already run
     v_wrap_copy_update(t);
-    if (any_shift) KT_TRY(ev_end(t, ST_SHIFT));
-
-    // [H] integrate: raw depth, current-frame level-0 normals :864-876
-    if (t->counting) {
-        KT_HIP(hipMemsetAsync(t->upd_dev, 0, 16 * sizeof(unsigned int), c->stream));
-        KT_HIP(hipMemsetAsync(t->steps_dev, 0, sizeof(unsigned long long), c->stream));
-    }
-    KT_TRY(ev_begin(t, ST_INTEGRATE));
-    tsdf23_hook_arm(t);
-    KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rc_inv, tcurr, t->tranc_dist, t->tsdf,
-                                  t->depth_raw_scaled, t->v_wrap_copy, t->color, colors, t->nmaps_curr[0], angle_color, N,
-                                  t->counting ? t->upd_dev : nullptr, t->rec_curr));
-    KT_TRY(ev_end(t, ST_INTEGRATE));
-    KT_HIP(hipEventRecord(t->sets[set].released, c->stream));  // integrate was the last reader of this frame's set
-    t->sets[set].used = true;
-    v_wrap_copy_update(t);
-    // [I] raycast :880-890
-    KT_TRY(ev_begin(t, ST_RAYCAST));
-    // [I] + [J]: raycast :880-890 with the predicted-map pyramid (resizeVMap / resizeNMap, :892-899) fused into its epilogue
-    const bool pyr = icp || t->cfg.use_rgbd_icp;
-    float* vp[3] = {t->vmaps_g_prev[1], t->vmaps_g_prev[2], t->vmaps_g_prev[3]};
-    float* np_[3] = {t->nmaps_g_prev[1], t->nmaps_g_prev[2], t->nmaps_g_prev[3]};
-    KT_TRY(kt_raycast_impl(c, &t->intr, &Rc, tcurr, t->tranc_dist, t->volume_size, t->tsdf, t->vmaps_g_prev[0], t->nmaps_g_prev[0], cols, rows,
-                           t->v_wrap_copy, t->vmap_curr_color, t->color, N, t->counting ? t->steps_dev : nullptr, pyr ? vp : nullptr,
-                           pyr ? np_ : nullptr));
-    KT_TRY(ev_end(t, ST_RAYCAST));
-    ++t->global_time;
-    push_pose(t, timestamp, Rcurr, 0);  // [K] :903-909
-    if (t->counting) {
-        unsigned int u = 0;
-        unsigned long long s = 0;
-        KT_HIP(hipMemcpyAsync(&u, t->upd_dev, sizeof(u), hipMemcpyDeviceToHost, c->stream));
-        KT_HIP(hipMemcpyAsync(&s, t->steps_dev, sizeof(s), hipMemcpyDeviceToHost, c->stream));
-        KT_HIP(hipStreamSynchronize(c->stream));
-        t->last_U = u;
-        t->last_S = s;
+    KT_TRY(launch_setup(t, 0, nullptr, nullptr));
+    KT_HIP(hipEventRecord(t->ev_setup_done, c->stream));
+    KT_HIP(hipStreamWaitEvent(t->copy_stream, t->ev_setup_done, 0));
+    KT_HIP(hipMemcpyAsync(t->state_host, t->state_dev, sizeof(kt_track_state), hipMemcpyDeviceToHost, t->copy_stream));
+    KT_HIP(hipEventRecord(t->ev_state, t->copy_stream));
+    KT_TRY(enqueue_fusion(t, set, depth_raw, colors));
+    t->outstanding = true;
+    t->out_ts = timestamp;
+    t->out_set = set;
+    t->out_depth = depth_raw;
+    t->out_rgb = colors;
+    t->out_thresh = t->parked ? INT_MAX : t->cfg.voxel_shift;
+    t->ev_par ^= 1;
+    if (t->counting) {  // the counters are read back per frame: finish it before returning
+        KT_TRY(complete_frame(t));
+        KT_TRY(read_counts(t));
     }
     return KT_OK;
 }
@@ -677,6 +849,7 @@ int kt_tracker_process_frame_host(kt_tracker* t, const uint16_t* depth_host, con
 {
     // TrackerInterface::process upload, TrackerInterface.cpp:90-91 (pinned staging + async copies instead of blocking cudaMemcpy2D)
     KT_ARG(t && depth_host && rgb_host);
+    KT_TRY(complete_frame(t));
     const size_t P = (size_t)t->cfg.cols * t->cfg.rows;
     KT_HIP(hipStreamSynchronize(t->ctx->stream));  // staging buffers are reused
     memcpy(t->depth_stage_host, depth_host, P * sizeof(uint16_t));
@@ -690,6 +863,7 @@ int kt_tracker_finalise(kt_tracker* t)
 {
     // finalise :1003-1048
     KT_ARG(t);
+    KT_TRY(complete_frame(t));
     v_wrap_copy_update(t);
     const int lo[3] = {0, 0, 0}, hi[3] = {t->N, t->N, t->N};
     return fetch_slice(t, lo, hi, 7 /* CloudSlice::FINAL */);
@@ -698,14 +872,17 @@ int kt_tracker_finalise(kt_tracker* t)
 int kt_tracker_get_pose(kt_tracker* t, float* R, float* tv, float* gc)
 {
     KT_ARG(t && R && tv && gc);
+    KT_TRY(complete_frame(t));
     memcpy(R, t->Rlast, sizeof(t->Rlast));
     memcpy(tv, t->tlast, sizeof(t->tlast));
     memcpy(gc, t->current_global_camera, sizeof(t->current_global_camera));
     return KT_OK;
 }
-int kt_tracker_num_poses(kt_tracker* t) { return t ? (int)t->poses.size() : 0; }
+int kt_tracker_num_poses(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? (int)t->poses.size() : 0; }
 int kt_tracker_get_dense_pose(kt_tracker* t, int i, uint64_t* ts, float* pose16, int* is_loop)
 {
+    KT_ARG(t);
+    KT_TRY(complete_frame(t));
     KT_ARG(t && i >= 0 && i < (int)t->poses.size() && ts && pose16 && is_loop);
     *ts = t->poses[i].ts;
     memcpy(pose16, t->poses[i].pose, sizeof(t->poses[i].pose));
@@ -715,12 +892,15 @@ int kt_tracker_get_dense_pose(kt_tracker* t, int i, uint64_t* ts, float* pose16,
 int kt_tracker_get_voxel_wrap(kt_tracker* t, int* wrap)
 {
     KT_ARG(t && wrap);
+    KT_TRY(complete_frame(t));
     memcpy(wrap, t->voxel_wrap, sizeof(t->voxel_wrap));
     return KT_OK;
 }
-int kt_tracker_num_slices(kt_tracker* t) { return t ? (int)t->slices.size() : 0; }
+int kt_tracker_num_slices(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? (int)t->slices.size() : 0; }
 int kt_tracker_slice_info(kt_tracker* t, int i, size_t* n_points, int* dimension)
 {
+    KT_ARG(t);
+    KT_TRY(complete_frame(t));
     KT_ARG(t && i >= 0 && i < (int)t->slices.size() && n_points && dimension);
     *n_points = t->slices[i].pts.size();
     *dimension = t->slices[i].dim;
@@ -729,11 +909,14 @@ int kt_tracker_slice_info(kt_tracker* t, int i, size_t* n_points, int* dimension
 int kt_tracker_set_parked(kt_tracker* t, int parked)
 {
     KT_ARG(t);
+    KT_TRY(complete_frame(t));
     t->parked = parked != 0;
     return KT_OK;
 }
 int kt_tracker_slice_pose(kt_tracker* t, int i, float* R, float* cam, uint64_t* ts)
 {
+    KT_ARG(t);
+    KT_TRY(complete_frame(t));
     KT_ARG(t && i >= 0 && i < (int)t->slices.size());
     if (R) memcpy(R, t->slices[i].R, 9 * sizeof(float));
     if (cam) memcpy(cam, t->slices[i].cam, 3 * sizeof(float));
@@ -742,19 +925,22 @@ int kt_tracker_slice_pose(kt_tracker* t, int i, float* R, float* cam, uint64_t* 
 }
 int kt_tracker_slice_points(kt_tracker* t, int i, kt_point_xyzrgb* out)
 {
+    KT_ARG(t);
+    KT_TRY(complete_frame(t));
     KT_ARG(t && i >= 0 && i < (int)t->slices.size() && out);
     if (!t->slices[i].pts.empty()) memcpy(out, t->slices[i].pts.data(), t->slices[i].pts.size() * sizeof(kt_point_xyzrgb));
     return KT_OK;
 }
-int16_t* kt_tracker_volume(kt_tracker* t) { return t ? t->tsdf : nullptr; }
-uint8_t* kt_tracker_color_volume(kt_tracker* t) { return t ? t->color : nullptr; }
-float* kt_tracker_vmap_g_prev(kt_tracker* t, int l) { return (t && l >= 0 && l < KT_LEVELS) ? t->vmaps_g_prev[l] : nullptr; }
-float* kt_tracker_nmap_g_prev(kt_tracker* t, int l) { return (t && l >= 0 && l < KT_LEVELS) ? t->nmaps_g_prev[l] : nullptr; }
+int16_t* kt_tracker_volume(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? t->tsdf : nullptr; }
+uint8_t* kt_tracker_color_volume(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? t->color : nullptr; }
+float* kt_tracker_vmap_g_prev(kt_tracker* t, int l) { return (t && l >= 0 && l < KT_LEVELS && complete_frame(t) == KT_OK) ? t->vmaps_g_prev[l] : nullptr; }
+float* kt_tracker_nmap_g_prev(kt_tracker* t, int l) { return (t && l >= 0 && l < KT_LEVELS && complete_frame(t) == KT_OK) ? t->nmaps_g_prev[l] : nullptr; }
 float kt_tracker_trunc_dist(kt_tracker* t) { return t ? t->tranc_dist : 0.f; }
 
 int kt_tracker_enable_profiling(kt_tracker* t, int on)
 {
     KT_ARG(t);
+    KT_TRY(complete_frame(t));
     KT_HIP(hipStreamSynchronize(t->ctx->stream));
     ev_collect(t);
     t->profiling = on;
@@ -765,6 +951,7 @@ int kt_tracker_enable_profiling(kt_tracker* t, int on)
 int kt_tracker_stage_ms(kt_tracker* t, float* ms)
 {
     KT_ARG(t && ms);
+    KT_TRY(complete_frame(t));
     KT_HIP(hipStreamSynchronize(t->ctx->stream));
     ev_collect(t);
     for (int s = 0; s < ST_COUNT; ++s) ms[s] = t->stage_n[s] ? (float)(t->stage_ms_sum[s] / (double)t->stage_n[s]) : 0.f;
@@ -804,7 +991,9 @@ int kt_tracker_last_counts(kt_tracker* t, unsigned long long* U, unsigned long l
 
 int kt_tracker_export_poses_device(kt_tracker* t, int k, float* dst_dev)
 {
-    KT_ARG(t && k > 0 && dst_dev && k <= (int)t->poses.size());
+    KT_ARG(t);
+    KT_TRY(complete_frame(t));
+    KT_ARG(k > 0 && dst_dev && k <= (int)t->poses.size());
     std::vector<float> tmp((size_t)k * 16);
     for (int i = 0; i < k; ++i) memcpy(&tmp[(size_t)i * 16], t->poses[t->poses.size() - k + i].pose, 16 * sizeof(float));
     KT_HIP(hipMemcpyAsync(dst_dev, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, t->ctx->stream));

@@ -103,7 +103,18 @@ struct kt_tsdf23_args {
     float tranc_dist;
     int wx, wy, wz;         // voxel wrap, normalised to [0, N)
     int cols, rows, N;
+    const kt_frame_params* fp;  // when set: Ri / t come from the device (kt_frame_params) instead of the fields above
 };
+
+// pose override shared by the two integrate kernels (wave-uniform scalar loads)
+__device__ __forceinline__ bool kt_tsdf_pose_from_device(kt_tsdf23_args& a)
+{
+    if (!a.fp) return false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.Ri.m[k] = a.fp->Rinv[k];
+    a.tx = a.fp->t[0]; a.ty = a.fp->t[1]; a.tz = a.fp->t[2];
+    return a.fp->skip != 0;
+}
 
 // Conservative z-interval of one voxel column inside the (margin-padded) view frustum.  Only used to
 // skip iterations whose in-image test must fail; every kept iteration runs the reference's exact test,
@@ -125,12 +136,18 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
 
 // Pre-pass: the conservative z-interval of every voxel column (one thread per column, computed ONCE per frame instead
 // of once per z-chunk).  Stored as (z0 | z1 << 16) per storage column; empty = (N | 0 << 16).
-__global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_args a, unsigned int* __restrict__ interval, float2* __restrict__ walk)
+__global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_args a_in, unsigned int* __restrict__ interval, float2* __restrict__ walk)
 {
+    kt_tsdf23_args a = a_in;
+    const bool skip = kt_tsdf_pose_from_device(a);
     const int N = a.N;
     const int sx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (sx >= N || sy >= N) return;
+    if (skip) {  // frame parked for the host's shift path: every column empty, so the voxel kernel retires at once
+        interval[(size_t)sy * N + sx] = (unsigned int)N;
+        return;
+    }
     int x = sx - a.wx; if (x < 0) x += N;
     int y = sy - a.wy; if (y < 0) y += N;
     const float* Ri = a.Ri.m;
@@ -306,8 +323,10 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args a)
+__global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args a_in)
 {
+    kt_tsdf23_args a = a_in;
+    (void)kt_tsdf_pose_from_device(a);   // a skipped frame has empty intervals: nothing to test here
     const int N = a.N;
     const int lane = threadIdx.x & 63;
     // grid = (N/4 y-groups, N/64 x-groups, chunks): workgroup b runs on XCD b % 8, so the fastest grid index is y -- the
@@ -427,7 +446,7 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
                            const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
                            int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
                            const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev,
-                           const void* prepared_rec)
+                           const void* prepared_rec, const kt_frame_params* fp)
 {
     KT_ARG(c && depth_raw && intr && volume_size && Rcurr_inv && tcurr && volume && depth_raw_scaled && voxel_wrap &&
            color_volume && colors && nmap_curr && N > 0 && cols > 0 && rows > 0);
@@ -436,7 +455,7 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     const float cell_x = volume_size[0] / N, cell_y = volume_size[1] / N, cell_z = volume_size[2] / N;
     // the incremental z walk of tsdf23 (quirk A.17) is the same float sequence for every column: build it once on the
     // host (plain IEEE float adds, this file is compiled with -ffp-contract=off) and ship 2 * N floats with the frame
-    {
+    if (!fp) {
         kt_integrate_scratch& sc = g_scratch;
         float* th = sc.tab_host[sc.flip];
         sc.flip ^= 1;
@@ -464,6 +483,7 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     a.vgz = g_scratch.vgz;
     a.zs = g_scratch.zs;
     a.updated = updated_dev;
+    a.fp = fp;
     a.Ri = *Rcurr_inv;
     a.tx = tcurr[0]; a.ty = tcurr[1]; a.tz = tcurr[2];
     a.intr = *intr;
@@ -486,6 +506,15 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
         kt_tsdf23_hook.on = false;  // one-shot: armed by the tracker per call
         KT_HIP(hipEventRecord(kt_tsdf23_hook.ev[1], c->stream));
     }
+    return KT_OK;
+}
+
+int kt_integrate_tables(kt_ctx* c, int cols, int rows, int N, float** vgz, float** zs)
+{
+    int s = kt_integrate_scratch_reserve(c, (size_t)cols * rows, N);
+    if (s != KT_OK) return s;
+    *vgz = g_scratch.vgz;
+    *zs = g_scratch.zs;
     return KT_OK;
 }
 
@@ -530,6 +559,7 @@ struct kt_raycast_args {
     unsigned long long* steps;  // optional march-step counter (S of SURVEY 8d)
     // optional fused resizeVMap / resizeNMap outputs for levels 1..3 (maps.cu:225-308), tracker path only
     float* vpyr[3]; float* npyr[3];
+    const kt_frame_params* fp;  // when set: R / t come from the device
 };
 
 struct kt_rc {
@@ -646,8 +676,15 @@ __device__ __forceinline__ void kt_tile_resize(const float* __restrict__ src, fl
 #define KT_RC_BATCH 8
 
 template <bool COUNT, bool PYR>
-__global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a)
+__global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a_in)
 {
+    kt_raycast_args a = a_in;
+    if (a.fp) {
+        if (a.fp->skip) return;  // parked for the host's shift path; the predicted maps are rebuilt there
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.R.m[k] = a.fp->R[k];
+        a.tx = a.fp->t[0]; a.ty = a.fp->t[1]; a.tz = a.fp->t[2];
+    }
     // a 256-thread block covers a 16x16 pixel tile; each wave an 8x8 sub-tile (coherent gathers)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = (wave & 1) * 8 + (lane & 7), ty = (wave >> 1) * 8 + (lane >> 3);
@@ -837,7 +874,7 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
 int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const float tcurr[3], float tranc_dist,
                     const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
                     const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,
-                    unsigned long long* steps_dev, float* const* vpyr, float* const* npyr)
+                    unsigned long long* steps_dev, float* const* vpyr, float* const* npyr, const kt_frame_params* fp)
 {
     KT_ARG(c && intr && Rcurr && tcurr && volume_size && volume && vmap && nmap && voxel_wrap && vmap_curr_color && color_volume);
     KT_ARG(N > 0 && cols > 0 && rows > 0);
@@ -856,6 +893,7 @@ int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const
     a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
     a.vmap_color = (uchar4*)vmap_curr_color;
     a.steps = steps_dev;
+    a.fp = fp;
     const bool pyr = vpyr && npyr;
     for (int k = 0; k < 3; ++k) { a.vpyr[k] = pyr ? vpyr[k] : nullptr; a.npyr[k] = pyr ? npyr[k] : nullptr; }
     if (pyr) KT_ARG((cols % 8) == 0 && (rows % 8) == 0);
