@@ -184,9 +184,9 @@ int kt_tracker_reset(kt_tracker* t);
 int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_dev, const uint8_t* rgb24_dev, uint64_t timestamp);
 /* Optional read-ahead for log playback: announce a frame that a LATER kt_tracker_process_frame call will receive (same two
  * pointers, contents unchanged until then).  Its pose-independent stages (bilateral filter, depth / vertex / normal pyramids,
- * scaleDepth) run on a second HIP stream, overlapped with the tracking of the frames before it.  At most two announced frames
- * may be outstanding; they must be processed in the order announced (anything else is legal but discards the read-ahead).
- * Results are identical with and without it. */
+ * scaleDepth) run on a second HIP stream, overlapped with the fusion of the frame before it.  One announced frame may be
+ * outstanding; handing a different frame to kt_tracker_process_frame first is legal but discards the read-ahead.  Best issued right
+ * after the kt_tracker_process_frame call of the preceding frame.  Results are identical with and without it. */
 int kt_tracker_prefetch_frame(kt_tracker* t, const uint16_t* depth_dev, const uint8_t* rgb24_dev);
 /* TrackerInterface::process upload path (TrackerInterface.cpp:90-91): host frame -> device -> processFrame */
 int kt_tracker_process_frame_host(kt_tracker* t, const uint16_t* depth_host, const uint8_t* rgb24_host, uint64_t timestamp);

@@ -32,7 +32,7 @@ int kt_extract_cloud_slice_async(kt_ctx* c, const int16_t* volume, const float v
                                  unsigned int* count_dev);
 int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
                        const float* vmap_g_prev, const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres,
-                       int mode);
+                       int mode, const kt_track_state* init = nullptr);
 int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
                            const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
                            int cols, int rows, kt_dataterm* corres_img, float max_depth_delta);

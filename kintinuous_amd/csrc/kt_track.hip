@@ -24,6 +24,8 @@
 //            no zeroing between launches (epochs never repeat within a context; the buffer is zeroed at creation).
 #include "kt_internal.hpp"
 
+#include <string.h>
+
 // ------------------------------------------------------------------------------------------------
 // block / grid reduction
 // ------------------------------------------------------------------------------------------------
@@ -173,6 +175,8 @@ struct kt_icp_args {
     kt_mat33 Rcurr; float tcurr[3];
     kt_mat33 Rprev_inv; float tprev[3];
     kt_track_state* state;     // nullptr on the host path
+    int first;                 // device path, first iteration of a frame: the pose comes from the fields above (== previous pose) and
+                               // the epilogue initialises *state (no host-to-device copy of the state per frame)
     unsigned long long* granules; unsigned int epoch;   // inter-workgroup hand-off (kt_reduce29)
     float* out29;              // host path: 29 floats
     int mode;                  // KT_MODE_*
@@ -218,7 +222,7 @@ struct kt_icp_row {
 __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_args a)
 {
     kt_icp_row fn{a};
-    if (a.state) {
+    if (a.state && !a.first) {
         // pose produced by the previous iteration's epilogue (kernel boundary orders the accesses)
         for (int k = 0; k < 9; ++k) { fn.Rcurr.m[k] = a.state->Rcurr[k]; fn.Rprev_inv.m[k] = a.state->Rprev_inv[k]; }
         fn.tcurr = {a.state->tcurr[0], a.state->tcurr[1], a.state->tcurr[2]};
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
     __shared__ float total[KT_RED_SLOTS];
     kt_pose_regs pr;
     const bool solve_here = a.mode == KT_MODE_ICP_SOLVE;
-    auto pre = [&]() { if (solve_here && threadIdx.x == 0) pr.load(a.state); };
+    auto pre = [&]() { if (solve_here && threadIdx.x == 0 && !a.first) pr.load(a.state); };
     if (!kt_reduce29(fn, a.cols * a.rows, a.granules, a.epoch, total, pre)) return;
     if (a.mode == KT_MODE_HOST) {
         if (threadIdx.x < KT_RED_SLOTS && (threadIdx.x < 29 || threadIdx.x == KT_RED_SLOTS - 1)) a.out29[threadIdx.x] = total[threadIdx.x];
@@ -244,6 +248,15 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
             kt_unpack29_d(h, dA, db);
             a.state->last_residual[0] = h[27];
             a.state->last_residual[1] = h[28];
+            if (a.first) {  // ICPOdometry.cpp:70-85: previous pose, its inverse, identity increment
+#pragma unroll
+                for (int k = 0; k < 16; ++k) pr.resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { pr.Rprev[k] = a.Rcurr.m[k]; a.state->Rprev[k] = a.Rcurr.m[k]; a.state->Rprev_inv[k] = a.Rprev_inv.m[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { pr.tprev[k] = a.tprev[k]; a.state->tprev[k] = a.tprev[k]; }
+                a.state->handoff_timeout = 0;
+            }
             if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
             kt_solve_and_update(a.state, pr, dA, db);
 #ifdef KT_ICP_TIMING
@@ -300,7 +313,7 @@ extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3
     a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
     a.Rcurr = *Rcurr; a.Rprev_inv = *Rprev_inv;
     for (int k = 0; k < 3; ++k) { a.tcurr[k] = tcurr[k]; a.tprev[k] = tprev[k]; }
-    a.state = nullptr; a.out29 = c->red_out; a.mode = KT_MODE_HOST;
+    a.state = nullptr; a.first = 0; a.out29 = c->red_out; a.mode = KT_MODE_HOST;
     int s = kt_icp_launch(c, a);
     if (s != KT_OK) return s;
     KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * KT_RED_SLOTS, hipMemcpyDeviceToHost, c->stream));
@@ -312,12 +325,20 @@ extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3
 
 int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
                        const float* vmap_g_prev, const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres,
-                       int mode)
+                       int mode, const kt_track_state* init)
 {
     kt_icp_args a;
     a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
     a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
     a.state = state; a.out29 = nullptr; a.mode = mode;
+    a.first = 0;
+    if (init) {  // first iteration of a frame (ICP-only path): the starting pose travels in the kernel arguments
+        if (mode != KT_MODE_ICP_SOLVE) { kt_set_error("kt_icp_step_device: init needs KT_MODE_ICP_SOLVE"); return KT_ERR_ARG; }
+        a.first = 1;
+        memcpy(a.Rcurr.m, init->Rcurr, sizeof(a.Rcurr.m));
+        memcpy(a.Rprev_inv.m, init->Rprev_inv, sizeof(a.Rprev_inv.m));
+        for (int k = 0; k < 3; ++k) { a.tcurr[k] = init->tcurr[k]; a.tprev[k] = init->tprev[k]; }
+    }
     return kt_icp_launch(c, a);
 }
 

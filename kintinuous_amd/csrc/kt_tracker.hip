@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -26,8 +27,19 @@ struct FrameSet {
     void* rec;            // per-pixel integrate records (kt_integrate_prepare)
     float* scaled;        // depthRawScaled_
     hipEvent_t ready;     // recorded on the prefetch stream when the set is complete
-    hipEvent_t released;  // recorded on the main stream after the last reader (integrate) of the frame that used the set
-    bool used;
+    long long user;       // ordinal of the process_frame call that last consumed the set (-1: none)
+};
+// Three sets rotate.  A read-ahead for frame i + 1 is only accepted once frame i has been handed to kt_tracker_process_frame, and
+// that call began by observing frame i - 1's pose: everything up to ICP(i - 1) has retired, in particular the fusion of frame
+// i - 2 -- the last reader of the set the read-ahead is about to overwrite.  No event is needed to recycle a set.
+#define KT_NSETS 3
+
+// the host's window on the frame in flight: written by kt_frame_setup_kernel straight into pinned, device-mapped host memory
+// (payload, system-scope fence, then seq), polled by complete_frame() -- no copy, no event, no driver call on the critical path
+struct PoseMirror {
+    float R[9], t[3];
+    int skip, handoff_timeout;
+    unsigned int seq;
 };
 struct Pending { const uint16_t* depth; const uint8_t* rgb; int set; };
 
@@ -58,9 +70,11 @@ struct kt_tracker {
     float* depth_raw_scaled;
     void* rec_curr;                    // integrate records of the current frame (set member, like the *_curr maps above)
     // the *_curr pointers above alias sets[cur_set]
-    FrameSet sets[2];
+    FrameSet sets[KT_NSETS];
     int last_assigned;                 // set handed to the most recent frame (prefetched or inline)
-    std::vector<Pending> pending;      // prefetched frames not yet processed (at most 2)
+    std::vector<Pending> pending;      // prefetched frame not yet processed (at most 1)
+    long long frames_started;          // process_frame calls so far
+    hipEvent_t guard_ev;               // only for out-of-pattern read-aheads (see kt_tracker_prefetch_frame)
     hipStream_t pre_stream;
     kt_ctx pre_ctx;                    // the context with pre_stream as its stream (image kernels only)
     kt_point_xyzrgb* cloud_device; size_t cloud_cap;
@@ -83,7 +97,9 @@ struct kt_tracker {
     const uint16_t* out_depth; const uint8_t* out_rgb; int out_thresh;
     kt_frame_params* fp_dev;
     float *vgz_dev, *zs_dev;           // z tables of integrate (kt_integrate_tables)
-    hipStream_t copy_stream; hipEvent_t ev_setup_done, ev_state;
+    PoseMirror* mirror;                // pinned + mapped host memory
+    unsigned int frame_seq;            // sequence number of the frame in flight (PoseMirror::seq)
+    long long prof_frames;             // frames seen with profiling == 1 (the tsdf23 event pair is recorded on every 8th)
     // profiling / counters (events double-buffered by frame parity: a pair is read one frame after it was recorded)
     double host_wait_s, host_call_s; long long host_calls;   // where the host thread spends a frame (kt_tracker_host_times)
     int profiling; int ev_par;
@@ -193,7 +209,8 @@ static int ev_end(kt_tracker* t, int st)
 }
 static void tsdf23_hook_arm(kt_tracker* t)
 {
-    kt_tsdf23_hook.on = t->profiling >= 1;
+    // profiling == 1 (bench timed region): one frame in 8 carries the event pair, so the timing itself stays off the other 7
+    kt_tsdf23_hook.on = t->profiling >= 2 || (t->profiling == 1 && (t->prof_frames++ % 8) == 0);
     kt_tsdf23_hook.ev[0] = t->ev[t->ev_par][ST_TSDF23][0];
     kt_tsdf23_hook.ev[1] = t->ev[t->ev_par][ST_TSDF23][1];
     if (kt_tsdf23_hook.on) t->ev_rec[t->ev_par][ST_TSDF23] = true;
@@ -249,7 +266,7 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
     KT_TRY(dev_alloc(&t->color, nvox * 4, false));
     for (int l = 0; l < KT_LEVELS; ++l) {  // allocateBuffers :356-382; zero-filled so "stale" planes are defined
         const size_t p = (size_t)lvl_cols(t, l) * lvl_rows(t, l);
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < KT_NSETS; ++q) {
             KT_TRY(dev_alloc(&t->sets[q].depths[l], p, true));
             KT_TRY(dev_alloc(&t->sets[q].vmaps[l], 3 * p, true));
             KT_TRY(dev_alloc(&t->sets[q].nmaps[l], 3 * p, true));
@@ -268,20 +285,21 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
         KT_TRY(dev_alloc(&t->corres[l], q, true));
     }
     KT_TRY(dev_alloc(&t->vmap_curr_color, P * 4, true));
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < KT_NSETS; ++q) {
         KT_TRY(dev_alloc(&t->sets[q].scaled, P, true));
         unsigned char* rec = nullptr;
         KT_TRY(dev_alloc(&rec, kt_integrate_rec_bytes(cfg->cols, cfg->rows), true));
         t->sets[q].rec = rec;
         KT_HIP(hipEventCreateWithFlags(&t->sets[q].ready, hipEventDisableTiming));
-        KT_HIP(hipEventCreateWithFlags(&t->sets[q].released, hipEventDisableTiming));
-        t->sets[q].used = false;
+        t->sets[q].user = -1;
     }
+    t->frames_started = 0;
+    KT_HIP(hipEventCreateWithFlags(&t->guard_ev, hipEventDisableTiming));
     KT_HIP(hipStreamCreateWithFlags(&t->pre_stream, hipStreamNonBlocking));
     t->pre_ctx = *ctx;
     t->pre_ctx.stream = t->pre_stream;
     t->pre_ctx.own_stream = false;
-    t->last_assigned = 1;
+    t->last_assigned = KT_NSETS - 1;
     select_set(t, 0);
     t->cloud_cap = cfg->max_slice_points > 0 ? (size_t)cfg->max_slice_points : P * 3;  // cloud_device_(numPixels * 3) :77
     KT_TRY(dev_alloc(&t->cloud_device, t->cloud_cap, false));
@@ -306,9 +324,10 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
     t->host_wait_s = t->host_call_s = 0.0; t->host_calls = 0;
     KT_TRY(dev_alloc(&t->fp_dev, 1, true));
     KT_TRY(kt_integrate_tables(ctx, cfg->cols, cfg->rows, cfg->N, &t->vgz_dev, &t->zs_dev));
-    KT_HIP(hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking));
-    KT_HIP(hipEventCreateWithFlags(&t->ev_setup_done, hipEventDisableTiming));
-    KT_HIP(hipEventCreateWithFlags(&t->ev_state, hipEventDisableTiming));
+    KT_HIP(hipHostMalloc((void**)&t->mirror, sizeof(PoseMirror), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(t->mirror, 0, sizeof(PoseMirror));
+    t->frame_seq = 0;
+    t->prof_frames = 0;
     KT_TRY(kt_tracker_reset(t));
     *out = t;
     return KT_OK;
@@ -317,20 +336,20 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
 int kt_tracker_destroy(kt_tracker* t)
 {
     if (!t) return KT_OK;
-    if (t->outstanding) (void)hipEventSynchronize(t->ev_state);
     (void)hipStreamSynchronize(t->ctx->stream);
     (void)hipFree(t->tsdf); (void)hipFree(t->color);
     for (int l = 0; l < KT_LEVELS; ++l) {
-        for (int q = 0; q < 2; ++q) { (void)hipFree(t->sets[q].depths[l]); (void)hipFree(t->sets[q].vmaps[l]); (void)hipFree(t->sets[q].nmaps[l]); }
+        for (int q = 0; q < KT_NSETS; ++q) { (void)hipFree(t->sets[q].depths[l]); (void)hipFree(t->sets[q].vmaps[l]); (void)hipFree(t->sets[q].nmaps[l]); }
         (void)hipFree(t->vmaps_g_prev[l]); (void)hipFree(t->nmaps_g_prev[l]);
         (void)hipFree(t->last_depth[l]); (void)hipFree(t->next_depth[l]); (void)hipFree(t->last_image[l]); (void)hipFree(t->next_image[l]);
         (void)hipFree(t->next_dIdx[l]); (void)hipFree(t->next_dIdy[l]); (void)hipFree(t->point_clouds[l]); (void)hipFree(t->corres[l]);
     }
     (void)hipStreamSynchronize(t->pre_stream);
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < KT_NSETS; ++q) {
         (void)hipFree(t->sets[q].scaled); (void)hipFree(t->sets[q].rec);
-        (void)hipEventDestroy(t->sets[q].ready); (void)hipEventDestroy(t->sets[q].released);
+        (void)hipEventDestroy(t->sets[q].ready);
     }
+    (void)hipEventDestroy(t->guard_ev);
     (void)hipStreamDestroy(t->pre_stream);
     (void)hipFree(t->vmap_curr_color); (void)hipFree(t->cloud_device);
     (void)hipFree(t->state_dev); (void)hipHostFree(t->state_host);
@@ -339,9 +358,7 @@ int kt_tracker_destroy(kt_tracker* t)
     (void)hipFree(t->upd_dev); (void)hipFree(t->steps_dev);
     for (int par = 0; par < 2; ++par)
         for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(t->ev[par][s][0]); (void)hipEventDestroy(t->ev[par][s][1]); }
-    (void)hipStreamSynchronize(t->copy_stream);
-    (void)hipStreamDestroy(t->copy_stream);
-    (void)hipEventDestroy(t->ev_setup_done); (void)hipEventDestroy(t->ev_state);
+    (void)hipHostFree(t->mirror);
     (void)hipFree(t->fp_dev);
     delete t;
     return KT_OK;
@@ -351,7 +368,7 @@ int kt_tracker_reset(kt_tracker* t)
 {
     // KintinuousTracker::reset :262-354
     KT_ARG(t);
-    if (t->outstanding) { (void)hipEventSynchronize(t->ev_state); t->outstanding = false; }
+    t->outstanding = false;
     KT_HIP(hipStreamSynchronize(t->ctx->stream));
     t->global_time = 0;
     memcpy(t->Rlast, t->initial_rotation, sizeof(t->Rlast));
@@ -403,12 +420,23 @@ static int icp_odometry(kt_tracker* t)
     if (t->cfg.fast_odometry) { iters[0] = 0; iters[1] = 10; iters[2] = 5; iters[3] = 0; }
     const float dist_thres = 0.10f;
     const float angle_thres = (float)sin(20.f * 3.14159254f / 180.f);  // ICPOdometry.h:35-36
-    KT_TRY(odometry_begin(t, nullptr));
+    // ICPOdometry.cpp:70-85: the starting state travels in the arguments of the first iteration (no per-frame upload)
+    kt_track_state init;
+    memset(&init, 0, sizeof(init));
+    memcpy(init.Rprev, t->Rlast, sizeof(init.Rprev));
+    memcpy(init.tprev, t->tlast, sizeof(init.tprev));
+    memcpy(init.Rcurr, t->Rlast, sizeof(init.Rcurr));
+    memcpy(init.tcurr, t->tlast, sizeof(init.tcurr));
+    kt_mat33_inverse(init.Rprev, init.Rprev_inv);  // ICPOdometry.cpp:81
+    bool first = true;
     for (int l = KT_LEVELS - 1; l >= 0; --l) {
         const kt_intr li = lvl_intr(t->intr, l);
-        for (int it = 0; it < iters[l]; ++it)
+        for (int it = 0; it < iters[l]; ++it) {
             KT_TRY(kt_icp_step_device(t->ctx, t->state_dev, t->vmaps_curr[l], t->nmaps_curr[l], &li, t->vmaps_g_prev[l],
-                                      t->nmaps_g_prev[l], lvl_cols(t, l), lvl_rows(t, l), dist_thres, angle_thres, KT_MODE_ICP_SOLVE));
+                                      t->nmaps_g_prev[l], lvl_cols(t, l), lvl_rows(t, l), dist_thres, angle_thres, KT_MODE_ICP_SOLVE,
+                                      first ? &init : nullptr));
+            first = false;
+        }
     }
     return odometry_end(t);
 }
@@ -498,6 +526,7 @@ __host__ __device__ static int voxel_trans(float translation, float voxel, int t
 // and redone by the host's shift path in complete_frame().  mode 1 = pose supplied by the host (that redo).
 struct kt_setup_args {
     kt_track_state* st; kt_frame_params* fp;
+    PoseMirror* mirror; unsigned int seq;
     float* vgz; float* zs; int N; float cell_z;
     int mode, rgbd_guard;
     float R[9], t[3];
@@ -533,20 +562,33 @@ __global__ __launch_bounds__(64) void kt_frame_setup_kernel(const kt_setup_args 
         for (int k = 0; k < 9; ++k) { a.fp->R[k] = R[k]; a.fp->Rinv[k] = Rinv[k]; }
         for (int k = 0; k < 3; ++k) a.fp->t[k] = tv[k];
         a.fp->skip = skip;
-        if (a.mode == 0) {  // what the host reads back: the final pose and whether the fusion kernels ran
+        if (a.mode == 0) {
+            // what the host needs: the final pose and whether the fusion kernels run -- straight into its memory
+            for (int k = 0; k < 9; ++k) a.mirror->R[k] = R[k];
+            for (int k = 0; k < 3; ++k) a.mirror->t[k] = tv[k];
+            a.mirror->skip = skip;
+            a.mirror->handoff_timeout = a.st->handoff_timeout;
+            __threadfence_system();
+            __hip_atomic_store(&a.mirror->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             for (int k = 0; k < 9; ++k) a.st->Rcurr[k] = R[k];
             for (int k = 0; k < 3; ++k) a.st->tcurr[k] = tv[k];
             a.st->fusion_skipped = skip;
         }
     }
-    // lane 0 walks v_g_z, lane 1 walks z_scaled: the same dependent float adds as tsdf23's z loop (tsdf_volume.cu:560-640)
+    // lane 0 walks v_g_z, lane 1 walks z_scaled: the same dependent float adds as tsdf23's z loop (tsdf_volume.cu:560-640),
+    // 16 at a time in registers so the chain runs at add latency
     if (lane < 2 && !skip) {
         float acc = lane == 0 ? __builtin_fmaf(0 + 0.5f, a.cell_z, -tv[2]) : 0.0f;
         float* tab = lane == 0 ? a.vgz : a.zs;
-        for (int z = 0; z < a.N; ++z) {
-            tab[z] = acc;
-            acc += a.cell_z;
+        int z = 0;
+        for (; z + 16 <= a.N; z += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { v[u] = acc; acc += a.cell_z; }
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) *(float4*)&tab[z + u] = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
         }
+        for (; z < a.N; ++z) { tab[z] = acc; acc += a.cell_z; }
     }
 }
 
@@ -554,6 +596,7 @@ static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv
 {
     kt_setup_args a;
     a.st = t->state_dev; a.fp = t->fp_dev; a.vgz = t->vgz_dev; a.zs = t->zs_dev; a.N = t->N;
+    a.mirror = t->mirror; a.seq = t->frame_seq;
     a.cell_z = t->volume_size[2] / t->N;
     a.mode = mode;
     a.rgbd_guard = (t->cfg.use_rgbd || t->cfg.use_rgbd_icp) ? 1 : 0;
@@ -585,8 +628,6 @@ static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, con
                                   t->sets[set].scaled, t->v_wrap_copy, t->color, colors, t->sets[set].nmaps[0], !t->cfg.disable_color_angle, N,
                                   t->counting ? t->upd_dev : nullptr, t->sets[set].rec, t->fp_dev));
     KT_TRY(ev_end(t, ST_INTEGRATE));
-    KT_HIP(hipEventRecord(t->sets[set].released, c->stream));  // integrate was the last reader of this frame's set
-    t->sets[set].used = true;
     KT_TRY(ev_begin(t, ST_RAYCAST));
     const bool pyr = icp || t->cfg.use_rgbd_icp;
     float* vp[3] = {t->vmaps_g_prev[1], t->vmaps_g_prev[2], t->vmaps_g_prev[3]};
@@ -646,15 +687,29 @@ static int complete_frame(kt_tracker* t)
     kt_ctx* c = t->ctx;
     const int N = t->N;
     {
+        // the ONE host wait of the frame: spin on the sequence word the set-up kernel posts after the odometry iterations (the GPU
+        // goes straight on to integrate / raycast meanwhile)
         const auto w0 = std::chrono::steady_clock::now();
-        KT_HIP(hipEventSynchronize(t->ev_state));  // the ONE host wait of the frame; the GPU is busy with integrate / raycast meanwhile
+        volatile unsigned int* seq = &t->mirror->seq;
+        long long spins = 0;
+        while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != t->frame_seq) {
+            if ((++spins & 0xfff) == 0) {
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+                if (waited > 30.0) {
+                    const hipError_t e = hipStreamQuery(c->stream);
+                    kt_set_error("tracker: no pose from the device after 30 s (stream status: %s)", hipGetErrorString(e));
+                    return KT_ERR_STATE;
+                }
+                if (waited > 0.002) std::this_thread::yield();
+            }
+        }
         t->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
     }
     ev_collect(t);
-    if (t->state_host->handoff_timeout) { kt_set_error("odometry: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
+    if (t->mirror->handoff_timeout) { kt_set_error("odometry: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
     float Rcurr[9], tcurr[3];
-    memcpy(Rcurr, t->state_host->Rcurr, sizeof(Rcurr));
-    memcpy(tcurr, t->state_host->tcurr, sizeof(tcurr));
+    memcpy(Rcurr, t->mirror->R, sizeof(Rcurr));
+    memcpy(tcurr, t->mirror->t, sizeof(tcurr));
     t->current_ts = t->out_ts;
 
     // [D] rmats_/tvecs_ push, currentGlobalCamera :574-595
@@ -672,7 +727,7 @@ static int complete_frame(kt_tracker* t)
         vt[k] = voxel_trans(current_translation[k], t->voxel_size[k], thresh);
         need_shift = need_shift || vt[k] >= thresh || vt[k] <= -thresh;
     }
-    if (need_shift != (t->state_host->fusion_skipped != 0)) {
+    if (need_shift != (t->mirror->skip != 0)) {
         kt_set_error("tracker: host and device disagree on the shift decision");
         return KT_ERR_STATE;
     }
@@ -765,13 +820,14 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     } else {
         for (const Pending& p : t->pending) KT_HIP(hipStreamWaitEvent(c->stream, t->sets[p.set].ready, 0));  // abandoned prefetches
         t->pending.clear();
-        set = t->last_assigned ^ 1;
+        set = (t->last_assigned + 1) % KT_NSETS;
         t->last_assigned = set;
         KT_TRY(ev_begin(t, ST_PYRAMID));
         KT_TRY(build_frame_set(t, c, set, depth_raw, colors));
         KT_TRY(ev_end(t, ST_PYRAMID));
     }
     select_set(t, set);
+    t->sets[set].user = t->frames_started++;
 
     if (t->global_time == 0) {  // [B] :481-557
         kt_mat33 Rcam, Rcam_inv;
@@ -789,8 +845,6 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         for (int l = 0; l < KT_LEVELS; ++l)
             KT_TRY(kt_transform_maps(c, t->vmaps_curr[l], t->nmaps_curr[l], lvl_cols(t, l), lvl_rows(t, l), &Rcam, t->tlast, t->vmaps_g_prev[l],
                                      t->nmaps_g_prev[l]));
-        KT_HIP(hipEventRecord(t->sets[set].released, c->stream));  // transform_maps was the last reader of this set
-        t->sets[set].used = true;
         ++t->global_time;
         t->ev_par ^= 1;
         push_pose(t, timestamp, t->Rlast, 1);
@@ -808,14 +862,11 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     KT_TRY(ev_begin(t, ST_ODOMETRY));
     if (icp) KT_TRY(icp_odometry(t));
     else KT_TRY(rgbd_odometry(t, depth_raw, colors));
-    // device-side frame set-up, then the pose travels to the host on the copy stream while the fusion kernels -- enqueued right
-    // here, speculatively, on the assumption that the volume does not shift -- already run
+    // device-side frame set-up (which also posts the pose into the host's PoseMirror), then the fusion kernels -- enqueued right
+    // here, speculatively, on the assumption that the volume does not shift
     v_wrap_copy_update(t);
+    if (++t->frame_seq == 0) t->frame_seq = 1;  // 0 is the mirror's initial value
     KT_TRY(launch_setup(t, 0, nullptr, nullptr));
-    KT_HIP(hipEventRecord(t->ev_setup_done, c->stream));
-    KT_HIP(hipStreamWaitEvent(t->copy_stream, t->ev_setup_done, 0));
-    KT_HIP(hipMemcpyAsync(t->state_host, t->state_dev, sizeof(kt_track_state), hipMemcpyDeviceToHost, t->copy_stream));
-    KT_HIP(hipEventRecord(t->ev_state, t->copy_stream));
     KT_TRY(enqueue_fusion(t, set, depth_raw, colors));
     t->outstanding = true;
     t->out_ts = timestamp;
@@ -834,10 +885,15 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
 int kt_tracker_prefetch_frame(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors)
 {
     KT_ARG(t && depth_raw && colors);
-    if (t->pending.size() >= 2) { kt_set_error("kt_tracker_prefetch_frame: two frames are already outstanding"); return KT_ERR_STATE; }
-    const int set = t->last_assigned ^ 1;
+    if (!t->pending.empty()) { kt_set_error("kt_tracker_prefetch_frame: a read-ahead frame is already outstanding"); return KT_ERR_STATE; }
+    const int set = (t->last_assigned + 1) % KT_NSETS;
     t->last_assigned = set;
-    if (t->sets[set].used) KT_HIP(hipStreamWaitEvent(t->pre_stream, t->sets[set].released, 0));
+    // In the playback pattern (process i, read-ahead i + 1, process i + 1, ...) the set was last consumed two frames before the
+    // one in flight and has retired (see KT_NSETS).  Anything else (abandoned read-aheads, resets) orders the streams explicitly.
+    if (t->sets[set].user >= 0 && t->sets[set].user > t->frames_started - 3) {
+        KT_HIP(hipEventRecord(t->guard_ev, t->ctx->stream));
+        KT_HIP(hipStreamWaitEvent(t->pre_stream, t->guard_ev, 0));
+    }
     t->pre_ctx.device = t->ctx->device;
     KT_TRY(build_frame_set(t, &t->pre_ctx, set, depth_raw, colors));
     KT_HIP(hipEventRecord(t->sets[set].ready, t->pre_stream));
@@ -972,6 +1028,9 @@ int kt_tracker_enable_counts(kt_tracker* t, int on)
 int kt_tracker_debug_state(kt_tracker* t, float* out29)
 {
     KT_ARG(t && out29);
+    KT_TRY(complete_frame(t));
+    KT_HIP(hipStreamSynchronize(t->ctx->stream));
+    KT_HIP(hipMemcpy(t->state_host, t->state_dev, sizeof(kt_track_state), hipMemcpyDeviceToHost));
     memcpy(out29, t->state_host->icp29, 29 * sizeof(float));
     return KT_OK;
 }

@@ -173,9 +173,9 @@ def test_readahead_is_transparent(ctx, small_scene):
                 if k == 2:
                     trk.prefetch_frame(*dev[5])            # never processed next: must be discarded
                 elif k == 4:
-                    trk.prefetch_frame(*dev[5]); trk.prefetch_frame(*dev[6])   # two outstanding, consumed in order
+                    trk.prefetch_frame(*dev[5])                                # issued BEFORE frame 4 is handed over
                     with pytest.raises(abi.KtError):
-                        trk.prefetch_frame(*dev[7])
+                        trk.prefetch_frame(*dev[6])                            # only one may be outstanding
             if mode == "chaos" and k == 3:
                 trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
             else:
