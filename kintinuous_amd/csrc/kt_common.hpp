@@ -17,6 +17,8 @@
 #define KT_MAX_WEIGHT 128.0f             // tsdf_volume.cu:481-488
 #define KT_LEVELS 4                      // ICPOdometry.h:52
 
+struct kt_integrate_scratch;  // kt_volume.hip
+
 struct kt_ctx {
     int device;
     hipStream_t stream;
@@ -28,10 +30,12 @@ struct kt_ctx {
     unsigned int* counters;  // device: [0] ticket, [1] extract global count, [2..] spare
     int* int_out_host;       // pinned, small
     int red_max_blocks;
+    kt_integrate_scratch* integ;   // integrate scratch (pixel records, z tables, intervals, task list), created on first use
     unsigned int red_epoch;  // tag of the last reduction launch (kt_track.hip hand-off granules)
 };
 
 void kt_set_error(const char* fmt, ...);
+void kt_integrate_scratch_free(kt_ctx* c);
 int kt_check(hipError_t e, const char* what, const char* file, int line);
 #define KT_HIP(expr)                                                        \
     do {                                                                    \

@@ -65,6 +65,7 @@ int kt_ctx_destroy(kt_ctx* c)
     if (!c) return KT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    kt_integrate_scratch_free(c);
     (void)hipFree(c->red_partials);
     (void)hipFree(c->red_out);
     (void)hipFree(c->counters);

@@ -594,6 +594,7 @@ __global__ __launch_bounds__(64) void kt_frame_setup_kernel(const kt_setup_args 
 
 static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv)
 {
+    KT_TRY(kt_integrate_tables(t->ctx, t->cfg.cols, t->cfg.rows, t->N, &t->vgz_dev, &t->zs_dev));  // may have been regrown by another user of the context
     kt_setup_args a;
     a.st = t->state_dev; a.fp = t->fp_dev; a.vgz = t->vgz_dev; a.zs = t->zs_dev; a.N = t->N;
     a.mirror = t->mirror; a.seq = t->frame_seq;

@@ -94,7 +94,8 @@ struct kt_tsdf23_args {
     const float* vgz;
     const float* zs;
     const unsigned int* interval;  // per storage column: z0 | z1 << 16 (kt_tsdf_interval_kernel)
-    const float2* walk;            // [chunk][sy][sx]: (v_x, v_y) of the reference walk at z = chunk * KT_TSDF_ZCHUNK
+    const unsigned int* tasks;     // compact list of (wave-column, z-chunk) units that contain work (kt_tsdf_tasks_kernel)
+    const unsigned int* task_count;
     unsigned int* updated;  // optional counter (U of SURVEY 8d)
     kt_mat33 Ri;            // Rcurr_inv
     float tx, ty, tz;
@@ -127,35 +128,50 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
     else if (alpha < 0) { lo = 1e30f; hi = -1e30f; }
 }
 
-// z-chunk per wave: the z range of a column is split over blockIdx.z so that enough waves are in flight to cover
-// HBM latency (only ~30% of the columns and ~40% of their z range lie inside the frustum).  Each chunk replays the
-// incremental float walk of v_x / v_y from z = 0 (quirk A.17: the values are defined by repeated +=), which is pure
-// ALU, then runs the reference loop body on its slice, 4 z-steps at a time with the loads of the 4 steps batched.
-#define KT_TSDF_ZCHUNK 32
+// Work decomposition of the voxel pass.  A unit of work ("task") is one wave-column -- 64 consecutive storage x of one y --
+// times one chunk of KT_TSDF_ZCHUNK z indices.  Only ~5% of the N^2/64 x N/16 units intersect the view frustum, so:
+//   1. kt_tsdf_interval_kernel   one thread per column: conservative z-interval inside the frustum; per wave-column the union;
+//   2. kt_tsdf_tasks_kernel      one workgroup: prefix sum over the wave-columns -> compact task list (no atomics);
+//   3. kt_tsdf23_kernel          a fixed grid of KT_TSDF_WAVES waves strides over the list, so every wave that is launched
+//                                has voxels to update and the SIMDs stay full of loads in flight.
+// A task replays the incremental float walk of v_x / v_y from z = 0 to its first z (quirk A.17: the values are DEFINED by
+// repeated +=; pure ALU, ~0.5 us), then runs the reference loop body 4 z-steps at a time with the loads of the 4 steps batched.
+#define KT_TSDF_ZCHUNK 16
 #define KT_TSDF_UNROLL 4
+#define KT_TSDF_WAVES 8192
 
-// Pre-pass: the conservative z-interval of every voxel column (one thread per column, computed ONCE per frame instead
-// of once per z-chunk).  Stored as (z0 | z1 << 16) per storage column; empty = (N | 0 << 16).
-__global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_args a_in, unsigned int* __restrict__ interval, float2* __restrict__ walk)
+__device__ __forceinline__ int kt_wave_min(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int kt_wave_max(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// Pre-pass 1: the conservative z-interval of every voxel column, stored as (z0 | z1 << 16) per storage column (empty = N | 0),
+// and per wave-column the union of its 64 intervals.  grid = (ceil(N / 64), ceil(N / 4)), 256 threads.
+__global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_args a_in, unsigned int* __restrict__ interval,
+                                                               unsigned int* __restrict__ wrange)
 {
     kt_tsdf23_args a = a_in;
     const bool skip = kt_tsdf_pose_from_device(a);
     const int N = a.N;
     const int sx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (sx >= N || sy >= N) return;
-    if (skip) {  // frame parked for the host's shift path: every column empty, so the voxel kernel retires at once
-        interval[(size_t)sy * N + sx] = (unsigned int)N;
-        return;
-    }
-    int x = sx - a.wx; if (x < 0) x += N;
-    int y = sy - a.wy; if (y < 0) y += N;
-    const float* Ri = a.Ri.m;
-    const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
-    const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
-    const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
+    const bool column = sx < N && sy < N;
     int z0 = N, z1 = 0;
-    {
+    if (column && !skip) {  // a frame parked for the host's shift path has no work
+        int x = sx - a.wx; if (x < 0) x += N;
+        int y = sy - a.wy; if (y < 0) y += N;
+        const float* Ri = a.Ri.m;
+        const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
+        const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
+        const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
         // camera coordinates (unscaled) at z index 0 and the per-index step: p(z) = A + z * B
         const float ax = Ri[0] * v_g_x + Ri[1] * v_g_y + Ri[2] * v_g_z0;
         const float ay = Ri[3] * v_g_x + Ri[4] * v_g_y + Ri[5] * v_g_z0;
@@ -194,22 +210,51 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
             if (z0 >= z1) { z0 = N; z1 = 0; }
         }
     }
-    interval[(size_t)sy * N + sx] = (unsigned int)z0 | ((unsigned int)z1 << 16);
-    // Checkpoints of the incremental walk (quirk A.17: v_x, v_y are DEFINED by repeated float +=, so a wave that starts at
-    // z > 0 must know the value the reference would hold there).  One serial walk per column here, stored at every chunk
-    // boundary inside the interval, replaces a replay from z = 0 in every (column, chunk) wave of the voxel kernel.
-    if (z0 < z1) {
-        float v_x = __builtin_fmaf(Ri[2], v_g_z0, __builtin_fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * a.intr.fx;
-        float v_y = __builtin_fmaf(Ri[5], v_g_z0, __builtin_fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * a.intr.fy;
-        const float dvx = Ri[2] * a.cell_z * a.intr.fx, dvy = Ri[5] * a.cell_z * a.intr.fy;
-        const int cfirst = z0 / KT_TSDF_ZCHUNK, clast = (z1 - 1) / KT_TSDF_ZCHUNK;
-        int z = 0;
-        for (int c = cfirst; c <= clast; ++c) {
-            const int zt = c * KT_TSDF_ZCHUNK;
-            for (; z < zt; ++z) { v_x += dvx; v_y += dvy; }
-            walk[((size_t)c * N + sy) * N + sx] = make_float2(v_x, v_y);
+    if (column) interval[(size_t)sy * N + sx] = (unsigned int)z0 | ((unsigned int)z1 << 16);
+    const int wz0 = kt_wave_min(z0), wz1 = kt_wave_max(z1);
+    if ((threadIdx.x & 63) == 0 && sy < N) wrange[(size_t)sy * gridDim.x + blockIdx.x] = (unsigned int)wz0 | ((unsigned int)wz1 << 16);
+}
+
+// Pre-pass 2: compact task list.  One workgroup; thread t owns a contiguous run of wave-columns, counts their chunks, a block-wide
+// exclusive scan places them.  task = sy | xg << 16 | chunk << 24.
+__global__ __launch_bounds__(1024) void kt_tsdf_tasks_kernel(const unsigned int* __restrict__ wrange, int M, int XG,
+                                                             unsigned int* __restrict__ tasks, unsigned int* __restrict__ task_count)
+{
+    __shared__ unsigned int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (M + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(M, i0 + per);
+    unsigned int mine = 0;
+    for (int i = i0; i < i1; ++i) {
+        const unsigned int r = wrange[i];
+        const int z0 = (int)(r & 0xffffu), z1 = (int)(r >> 16);
+        if (z0 < z1) mine += (unsigned int)((z1 - 1) / KT_TSDF_ZCHUNK - z0 / KT_TSDF_ZCHUNK + 1);
+    }
+    unsigned int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const unsigned int v = wave_tot[w];
+        if (w < wave) base += v;
+        total += v;
+    }
+    unsigned int pos = base + incl - mine;
+    for (int i = i0; i < i1; ++i) {
+        const unsigned int r = wrange[i];
+        const int z0 = (int)(r & 0xffffu), z1 = (int)(r >> 16);
+        if (z0 < z1) {
+            const unsigned int sy = (unsigned int)(i / XG), xg = (unsigned int)(i % XG);
+            for (int c = z0 / KT_TSDF_ZCHUNK; c <= (z1 - 1) / KT_TSDF_ZCHUNK; ++c) tasks[pos++] = sy | (xg << 16) | ((unsigned int)c << 24);
         }
     }
+    if (tid == 0) *task_count = total;
 }
 
 // One in-flight batch of KT_TSDF_UNROLL consecutive z steps of a wave: everything phase A produces for phase B.
@@ -222,15 +267,11 @@ struct kt_tsdf_batch {
     uchar4 col[KT_TSDF_UNROLL];
 };
 
-// The voxel kernel.  grid = (N/64, N/4, N/KT_TSDF_ZCHUNK); a wave owns 64 consecutive storage x of one y and one z chunk,
-// leaves at once when the pre-pass interval says none of its columns crosses the chunk, and otherwise
-//   - replays the incremental float walk of v_x / v_y from z = 0 (quirk A.17: values are defined by repeated +=),
-//   - then runs the reference loop body KT_TSDF_UNROLL z-steps at a time in two software-pipelined phases:
-//       A  projection of the voxels, then ALL their loads at once -- the 16-byte pixel record and, speculatively for every
-//          voxel that projects into the image, its tsdf and colour words (the update predicate needs the record, so
-//          waiting for it first would double the exposed latency);
-//       B  sdf test, running-average update, stores;
-//     phase A of batch i+1 is issued before phase B of batch i, so one memory latency is exposed per batch at most.
+// The voxel kernel runs the reference loop body KT_TSDF_UNROLL z-steps at a time in two phases:
+//   issue    projection of the 4 voxels, then ALL their loads at once -- the 16-byte pixel record and, speculatively for every
+//            voxel that projects into the image, its tsdf and colour words (the update predicate needs the record, so waiting
+//            for it first would double the exposed latency);
+//   consume  sdf test, running-average update, stores.
 // Every lane of the wave walks the same z sequence: each volume access is one contiguous 128 B / 256 B segment.
 template <bool COUNT>
 __device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, kt_tsdf_batch& b, int zb, int z0, int z1, unsigned int col_base,
@@ -326,95 +367,104 @@ template <bool COUNT>
 __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args a_in)
 {
     kt_tsdf23_args a = a_in;
-    (void)kt_tsdf_pose_from_device(a);   // a skipped frame has empty intervals: nothing to test here
+    (void)kt_tsdf_pose_from_device(a);   // a parked frame has an empty task list
     const int N = a.N;
     const int lane = threadIdx.x & 63;
-    // grid = (N/4 y-groups, N/64 x-groups, chunks): workgroup b runs on XCD b % 8, so the fastest grid index is y -- the
-    // frustum covers only a few of the 64-wide x-groups and an x-fastest order would leave most XCDs idle
-    const int sx = blockIdx.y * 64 + lane;
-    const int sy = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int z0 = N, z1 = 0;
-    if (sx < N && sy < N) {
-        const unsigned int iv = a.interval[(size_t)sy * N + sx];
-        z0 = max((int)(iv & 0xffffu), (int)blockIdx.z * KT_TSDF_ZCHUNK);
-        z1 = min((int)(iv >> 16), (int)(blockIdx.z + 1) * KT_TSDF_ZCHUNK);
-        if (z0 >= z1) { z0 = N; z1 = 0; }
-    }
-    // the wave's union interval inside this chunk (wave-uniform)
-    int wz0 = z0, wz1 = z1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        wz0 = min(wz0, __shfl_xor(wz0, off, 64));
-        wz1 = max(wz1, __shfl_xor(wz1, off, 64));
-    }
-    wz0 = __builtin_amdgcn_readfirstlane(wz0);
-    wz1 = __builtin_amdgcn_readfirstlane(wz1);
-    if (wz0 >= wz1) return;
-
+    const unsigned int n_tasks = *a.task_count;
+    const unsigned int n_waves = gridDim.x * 4u;
     const float* Ri = a.Ri.m;
     const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
     const float dvx = Ri[2] * a.cell_z * a.intr.fx;   // Rcurr_inv_0_z_scaled
     const float dvy = Ri[5] * a.cell_z * a.intr.fy;   // Rcurr_inv_1_z_scaled
     const float tranc_dist_inv = 1.0f / a.tranc_dist;
     const unsigned int plane = (unsigned int)N * (unsigned int)N;
-    unsigned int n_upd = 0, n_batches = 0;
-    int x = sx - a.wx; if (x < 0) x += N;
-    int y = sy - a.wy; if (y < 0) y += N;
-    const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
-    const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
-    const float v_g_part_norm = __builtin_fmaf(v_g_x, v_g_x, v_g_y * v_g_y);
-    const float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
-    // the walk resumes from the pre-pass checkpoint of this chunk (valid for every lane whose interval touches the chunk;
-    // the other lanes are never live) and advances to the wave's first z
-    float v_x = 0.f, v_y = 0.f;
-    if (z0 < z1) {
-        const float2 cp = a.walk[((size_t)blockIdx.z * N + sy) * N + sx];
-        v_x = cp.x; v_y = cp.y;
-    }
-    for (int z = (int)blockIdx.z * KT_TSDF_ZCHUNK; z < wz0; ++z) {
-        v_x += dvx;
-        v_y += dvy;
-    }
-    const unsigned int col_base = (unsigned int)min(sx, N - 1) + (unsigned int)min(sy, N - 1) * (unsigned int)N;
-    // the chunk's slice of the z-walk tables, one entry per lane (KT_TSDF_ZCHUNK <= 64 == wave size)
-    const int tab_base = (int)blockIdx.z * KT_TSDF_ZCHUNK;
-    const float tab_vgz = a.vgz[min(tab_base + lane, N - 1)];
-    const float tab_zs = a.zs[min(tab_base + lane, N - 1)];
-    // Latency is hidden by occupancy (8 waves per SIMD, one z-chunk each) rather than by cross-iteration software
-    // pipelining: hipcc's s_waitcnt insertion cannot count loads that are still in flight across a loop back-edge and
-    // falls back to vmcnt(0), which serialises a hand-rotated pipeline anyway.
-    for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
-        kt_tsdf_batch cur;
-        kt_tsdf_issue<COUNT>(a, cur, zb, z0, z1, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base);
-        kt_tsdf_consume<COUNT>(a, cur, v_g_part_norm, tranc_dist_inv, n_upd);
-        if (COUNT) ++n_batches;
+    unsigned int n_upd = 0, n_batches = 0, n_tasks_done = 0;
+    // consecutive tasks (neighbouring chunks of one wave-column) go to the 4 waves of one workgroup: they share pixel records
+    for (unsigned int t = blockIdx.x * 4u + (threadIdx.x >> 6); t < n_tasks; t += n_waves) {
+        const unsigned int task = __builtin_amdgcn_readfirstlane(a.tasks[t]);
+        const int sy = (int)(task & 0xffffu), chunk = (int)(task >> 24);
+        const int sx = (int)((task >> 16) & 0xffu) * 64 + lane;
+        int z0 = N, z1 = 0;
+        if (sx < N) {
+            const unsigned int iv = a.interval[(size_t)sy * N + sx];
+            z0 = max((int)(iv & 0xffffu), chunk * KT_TSDF_ZCHUNK);
+            z1 = min((int)(iv >> 16), (chunk + 1) * KT_TSDF_ZCHUNK);
+            if (z0 >= z1) { z0 = N; z1 = 0; }
+        }
+        const int wz0 = kt_wave_min(z0), wz1 = kt_wave_max(z1);  // the wave's union inside this chunk
+        if (wz0 >= wz1) continue;
+        int x = sx - a.wx; if (x < 0) x += N;
+        int y = sy - a.wy; if (y < 0) y += N;
+        const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
+        const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
+        const float v_g_part_norm = __builtin_fmaf(v_g_x, v_g_x, v_g_y * v_g_y);
+        const float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
+        // the reference's walk (tsdf_volume.cu:566-571, 634-640) from z = 0 up to the wave's first z
+        float v_x = __builtin_fmaf(Ri[2], v_g_z0, __builtin_fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * a.intr.fx;
+        float v_y = __builtin_fmaf(Ri[5], v_g_z0, __builtin_fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * a.intr.fy;
+        {
+            int z = 0;
+            for (; z + 16 <= wz0; z += 16) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { v_x += dvx; v_y += dvy; }
+            }
+            for (; z < wz0; ++z) { v_x += dvx; v_y += dvy; }
+        }
+        const unsigned int col_base = (unsigned int)min(sx, N - 1) + (unsigned int)sy * (unsigned int)N;
+        // the chunk's slice of the z-walk tables, one entry per lane (KT_TSDF_ZCHUNK + KT_TSDF_UNROLL <= 64 == wave size)
+        const int tab_base = chunk * KT_TSDF_ZCHUNK;
+        const float tab_vgz = a.vgz[min(tab_base + lane, N - 1)];
+        const float tab_zs = a.zs[min(tab_base + lane, N - 1)];
+        // Latency is hidden by occupancy (8 tasks per SIMD) rather than by cross-iteration software pipelining: hipcc's s_waitcnt
+        // insertion cannot count loads that are still in flight across a loop back-edge and falls back to vmcnt(0).
+        for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
+            kt_tsdf_batch cur;
+            kt_tsdf_issue<COUNT>(a, cur, zb, z0, z1, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base);
+            kt_tsdf_consume<COUNT>(a, cur, v_g_part_norm, tranc_dist_inv, n_upd);
+            if (COUNT) ++n_batches;
+        }
+        if (COUNT) ++n_tasks_done;
     }
     if (COUNT) {
-        // wave-level sum, one atomic per wave; [1] = wave batches, [2] = active wave-chunks (diagnostics)
+        // wave-level sum, one atomic per wave and counter; [1] = wave batches, [2] = tasks with work (diagnostics)
         for (int off = 32; off > 0; off >>= 1) n_upd += __shfl_down(n_upd, off, 64);
         if (lane == 0) {
             if (n_upd) atomicAdd(a.updated, n_upd);
-            atomicAdd(a.updated + 1, n_batches);
-            atomicAdd(a.updated + 2, 1u);
+            if (n_batches) atomicAdd(a.updated + 1, n_batches);
+            if (n_tasks_done) atomicAdd(a.updated + 2, n_tasks_done);
         }
     }
 }
 
-// scratch owned by the context for integrate (pixel records + z tables), grown on demand
+// scratch owned by the context for integrate (pixel records, z tables, intervals, task list), grown on demand
 struct kt_integrate_scratch {
     kt_pixrec* rec = nullptr; size_t rec_px = 0;
     float* vgz = nullptr; float* zs = nullptr; int tabN = 0;
     float* tab_host[2] = {nullptr, nullptr};  // pinned staging of {vgz[N], zs[N]}, double-buffered
     unsigned int* interval = nullptr;          // N * N column intervals
-    float2* walk = nullptr;                    // chunk checkpoints of the z walk
+    unsigned int* wrange = nullptr;            // N * ceil(N / 64) wave-column unions
+    unsigned int* tasks = nullptr;             // up to N * ceil(N / 64) * ceil(N / ZCHUNK) tasks
+    unsigned int* task_count = nullptr;
     int flip = 0;
 };
-static thread_local kt_integrate_scratch g_scratch;  // one GPU thread per context (SURVEY 8b threading)
+
+void kt_integrate_scratch_free(kt_ctx* c)
+{
+    kt_integrate_scratch* s = c->integ;
+    if (!s) return;
+    (void)hipFree(s->rec); (void)hipFree(s->vgz); (void)hipFree(s->interval); (void)hipFree(s->wrange); (void)hipFree(s->tasks);
+    (void)hipFree(s->task_count);
+    for (int k = 0; k < 2; ++k) (void)hipHostFree(s->tab_host[k]);
+    delete s;
+    c->integ = nullptr;
+}
 
 static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
 {
-    kt_integrate_scratch& s = g_scratch;
+    if (!c->integ) c->integ = new kt_integrate_scratch();
+    kt_integrate_scratch& s = *c->integ;
     if (s.rec_px < px) {
+        KT_HIP(hipStreamSynchronize(c->stream));
         if (s.rec) KT_HIP(hipFree(s.rec));
         s.rec = nullptr; s.rec_px = 0;
         KT_HIP(hipMalloc((void**)&s.rec, px * sizeof(kt_pixrec)));
@@ -422,14 +472,13 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
     }
     if (s.tabN < N) {
         KT_HIP(hipStreamSynchronize(c->stream));
-        if (s.vgz) KT_HIP(hipFree(s.vgz));
-        if (s.interval) KT_HIP(hipFree(s.interval));
-        if (s.walk) KT_HIP(hipFree(s.walk));
-        s.walk = nullptr;
-        s.vgz = s.zs = nullptr; s.interval = nullptr; s.tabN = 0;
+        (void)hipFree(s.vgz); (void)hipFree(s.interval); (void)hipFree(s.wrange); (void)hipFree(s.tasks); (void)hipFree(s.task_count);
+        s.vgz = s.zs = nullptr; s.interval = s.wrange = s.tasks = s.task_count = nullptr; s.tabN = 0;
+        const size_t wave_cols = (size_t)N * kt_div_up(N, 64);
         KT_HIP(hipMalloc((void**)&s.interval, sizeof(unsigned int) * (size_t)N * N));
-        KT_HIP(hipMalloc((void**)&s.walk, sizeof(float2) * (size_t)N * N * kt_div_up(N, KT_TSDF_ZCHUNK)));
-
+        KT_HIP(hipMalloc((void**)&s.wrange, sizeof(unsigned int) * wave_cols));
+        KT_HIP(hipMalloc((void**)&s.tasks, sizeof(unsigned int) * wave_cols * kt_div_up(N, KT_TSDF_ZCHUNK)));
+        KT_HIP(hipMalloc((void**)&s.task_count, sizeof(unsigned int)));
         KT_HIP(hipMalloc((void**)&s.vgz, sizeof(float) * 2 * N));
         s.zs = s.vgz + N;
         for (int k = 0; k < 2; ++k) {
@@ -456,7 +505,7 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     // the incremental z walk of tsdf23 (quirk A.17) is the same float sequence for every column: build it once on the
     // host (plain IEEE float adds, this file is compiled with -ffp-contract=off) and ship 2 * N floats with the frame
     if (!fp) {
-        kt_integrate_scratch& sc = g_scratch;
+        kt_integrate_scratch& sc = *c->integ;
         float* th = sc.tab_host[sc.flip];
         sc.flip ^= 1;
         float v_g_z = fmaf(0 + 0.5f, cell_z, -tcurr[2]);
@@ -472,16 +521,16 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     }
     if (!prepared_rec) {  // scaleDepth + per-pixel records (a caller that ran kt_integrate_prepare ahead of time passes them in)
         dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8));
-        hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, g_scratch.rec, colors, nmap_curr,
+        hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, c->integ->rec, colors, nmap_curr,
                            cols, rows, *intr, angle_color);
         KT_LAUNCH_CHECK();
     }
     kt_tsdf23_args a;
-    a.rec = prepared_rec ? (const kt_pixrec*)prepared_rec : g_scratch.rec;
+    a.rec = prepared_rec ? (const kt_pixrec*)prepared_rec : c->integ->rec;
     a.volume = volume;
     a.color = (uchar4*)color_volume;
-    a.vgz = g_scratch.vgz;
-    a.zs = g_scratch.zs;
+    a.vgz = c->integ->vgz;
+    a.zs = c->integ->zs;
     a.updated = updated_dev;
     a.fp = fp;
     a.Ri = *Rcurr_inv;
@@ -493,11 +542,15 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
     a.cols = cols; a.rows = rows; a.N = N;
     KT_ARG(N <= 4096);
-    a.interval = g_scratch.interval;
-    a.walk = g_scratch.walk;
-    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(kt_div_up(N, 64), kt_div_up(N, 4)), dim3(256), 0, c->stream, a, g_scratch.interval, g_scratch.walk);
+    a.interval = c->integ->interval;
+    a.tasks = c->integ->tasks;
+    a.task_count = c->integ->task_count;
+    const int XG = kt_div_up(N, 64);
+    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(XG, kt_div_up(N, 4)), dim3(256), 0, c->stream, a, c->integ->interval, c->integ->wrange);
     KT_LAUNCH_CHECK();
-    dim3 b(256), g(kt_div_up(N, 4), kt_div_up(N, 64), kt_div_up(N, KT_TSDF_ZCHUNK));
+    hipLaunchKernelGGL(kt_tsdf_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, c->integ->wrange, N * XG, XG, c->integ->tasks, c->integ->task_count);
+    KT_LAUNCH_CHECK();
+    dim3 b(256), g(KT_TSDF_WAVES / 4);
     if (kt_tsdf23_hook.on) KT_HIP(hipEventRecord(kt_tsdf23_hook.ev[0], c->stream));
     if (updated_dev) hipLaunchKernelGGL(kt_tsdf23_kernel<true>, g, b, 0, c->stream, a);
     else hipLaunchKernelGGL(kt_tsdf23_kernel<false>, g, b, 0, c->stream, a);
@@ -513,8 +566,8 @@ int kt_integrate_tables(kt_ctx* c, int cols, int rows, int N, float** vgz, float
 {
     int s = kt_integrate_scratch_reserve(c, (size_t)cols * rows, N);
     if (s != KT_OK) return s;
-    *vgz = g_scratch.vgz;
-    *zs = g_scratch.zs;
+    *vgz = c->integ->vgz;
+    *zs = c->integ->zs;
     return KT_OK;
 }
 
