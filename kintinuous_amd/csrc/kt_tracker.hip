@@ -96,6 +96,7 @@ struct kt_tracker {
     bool outstanding; uint64_t out_ts; int out_set;
     const uint16_t* out_depth; const uint8_t* out_rgb; int out_thresh;
     kt_frame_params* fp_dev;
+    unsigned char* bricks;             // negative-brick flags of the volume (tsdf23 raises, raycast skips; kt_volume.hip)
     float *vgz_dev, *zs_dev;           // z tables of integrate (kt_integrate_tables)
     PoseMirror* mirror;                // pinned + mapped host memory
     unsigned int frame_seq;            // sequence number of the frame in flight (PoseMirror::seq)
@@ -323,6 +324,7 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
     t->outstanding = false;
     t->host_wait_s = t->host_call_s = 0.0; t->host_calls = 0;
     KT_TRY(dev_alloc(&t->fp_dev, 1, true));
+    { const int nb = kt_div_up(cfg->N, 32); KT_TRY(dev_alloc(&t->bricks, (size_t)nb * nb * nb + 16, true)); }
     KT_TRY(kt_integrate_tables(ctx, cfg->cols, cfg->rows, cfg->N, &t->vgz_dev, &t->zs_dev));
     KT_HIP(hipHostMalloc((void**)&t->mirror, sizeof(PoseMirror), hipHostMallocMapped | hipHostMallocCoherent));
     memset(t->mirror, 0, sizeof(PoseMirror));
@@ -360,6 +362,7 @@ int kt_tracker_destroy(kt_tracker* t)
         for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(t->ev[par][s][0]); (void)hipEventDestroy(t->ev[par][s][1]); }
     (void)hipHostFree(t->mirror);
     (void)hipFree(t->fp_dev);
+    (void)hipFree(t->bricks);
     delete t;
     return KT_OK;
 }
@@ -382,6 +385,7 @@ int kt_tracker_reset(kt_tracker* t)
     t->parked = t->cfg.static_mode != 0;
     KT_TRY(kt_init_volume(t->ctx, t->tsdf, t->N));
     KT_TRY(kt_init_color_volume(t->ctx, t->color, t->N));
+    { const int nb = kt_div_up(t->N, 32); KT_HIP(hipMemsetAsync(t->bricks, 0, (size_t)nb * nb * nb, t->ctx->stream)); }
     memset(t->stage_ms_sum, 0, sizeof(t->stage_ms_sum));
     memset(t->stage_n, 0, sizeof(t->stage_n));
     memset(t->stage_ms_last, 0, sizeof(t->stage_ms_last));
@@ -621,13 +625,13 @@ static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, con
     const float dummy_t[3] = {0, 0, 0};
     if (t->counting) {
         KT_HIP(hipMemsetAsync(t->upd_dev, 0, 16 * sizeof(unsigned int), c->stream));
-        KT_HIP(hipMemsetAsync(t->steps_dev, 0, sizeof(unsigned long long), c->stream));
+        KT_HIP(hipMemsetAsync(t->steps_dev, 0, 2 * sizeof(unsigned long long), c->stream));
     }
     KT_TRY(ev_begin(t, ST_INTEGRATE));
     tsdf23_hook_arm(t);
     KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &dummy_R, dummy_t, t->tranc_dist, t->tsdf,
                                   t->sets[set].scaled, t->v_wrap_copy, t->color, colors, t->sets[set].nmaps[0], !t->cfg.disable_color_angle, N,
-                                  t->counting ? t->upd_dev : nullptr, t->sets[set].rec, t->fp_dev));
+                                  t->counting ? t->upd_dev : nullptr, t->sets[set].rec, t->fp_dev, t->bricks));
     KT_TRY(ev_end(t, ST_INTEGRATE));
     KT_TRY(ev_begin(t, ST_RAYCAST));
     const bool pyr = icp || t->cfg.use_rgbd_icp;
@@ -635,7 +639,7 @@ static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, con
     float* np_[3] = {t->nmaps_g_prev[1], t->nmaps_g_prev[2], t->nmaps_g_prev[3]};
     KT_TRY(kt_raycast_impl(c, &t->intr, &dummy_R, dummy_t, t->tranc_dist, t->volume_size, t->tsdf, t->vmaps_g_prev[0], t->nmaps_g_prev[0], cols, rows,
                            t->v_wrap_copy, t->vmap_curr_color, t->color, N, t->counting ? t->steps_dev : nullptr, pyr ? vp : nullptr,
-                           pyr ? np_ : nullptr, t->fp_dev));
+                           pyr ? np_ : nullptr, t->fp_dev, t->bricks));
     KT_TRY(ev_end(t, ST_RAYCAST));
     return KT_OK;
 }
@@ -841,7 +845,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         tsdf23_hook_arm(t);
         KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rcam_inv, t->tlast, t->tranc_dist, t->tsdf,
                                       t->depth_raw_scaled, empty, t->color, colors, t->nmaps_curr[0], angle_color, N,
-                                      t->counting ? t->upd_dev : nullptr, t->rec_curr));
+                                      t->counting ? t->upd_dev : nullptr, t->rec_curr, nullptr, t->bricks));
         KT_TRY(ev_end(t, ST_INTEGRATE));
         for (int l = 0; l < KT_LEVELS; ++l)
             KT_TRY(kt_transform_maps(c, t->vmaps_curr[l], t->nmaps_curr[l], lvl_cols(t, l), lvl_rows(t, l), &Rcam, t->tlast, t->vmaps_g_prev[l],
@@ -1039,6 +1043,7 @@ int kt_tracker_debug_counts(kt_tracker* t, unsigned int* out4)
 {
     KT_ARG(t && out4);
     KT_HIP(hipMemcpy(out4, t->upd_dev, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    { unsigned long long h = 0; KT_HIP(hipMemcpy(&h, t->steps_dev + 1, sizeof(h), hipMemcpyDeviceToHost)); out4[7] = (unsigned int)h; }
     return KT_OK;
 }
 int kt_tracker_last_counts(kt_tracker* t, unsigned long long* U, unsigned long long* S)
