@@ -230,6 +230,9 @@ int kt_tracker_debug_counts(kt_tracker* t, unsigned int out8_host[8]);
 /* diagnostics: the 29 ICP sums stashed by the last joint RGB-D + ICP iteration (or timing probes in instrumented builds) */
 int kt_tracker_debug_state(kt_tracker* t, float out29_host[29]);
 
+/* test hook: out[v + 32768] = the device's unpack_tsdf(v) for every short v (device.hpp:77-83 restated without a division) */
+int kt_debug_unpack_table(kt_ctx* ctx, float* out_host65536);
+
 /* ---- multi-GPU: independent streams, one tracker per GPU; poses are gathered by the caller's
  * collective (bench.py / the CLI use RCCL all_gather on the buffer filled here) ---- */
 /* copies the last k dense poses (k*16 floats, row-major 4x4) into a DEVICE buffer for the gather */

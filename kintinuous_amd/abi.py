@@ -124,6 +124,7 @@ _PROTOS = {
     "kt_tracker_last_counts": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "kt_tracker_debug_counts": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_debug_state": (_i, [_vp, _pf]),
+    "kt_debug_unpack_table": (_i, [_vp, _pf]),
     "kt_tracker_host_times": (_i, [_vp, _pd, _i]),
     "kt_tracker_prefetch_frame": (_i, [_vp, _vp, _vp]),
     "kt_tracker_slice_pose": (_i, [_vp, _i, _pf, _pf, C.POINTER(_u64)]),

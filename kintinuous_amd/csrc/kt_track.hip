@@ -78,15 +78,26 @@ __device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, unsigned lon
     float acc = 0.f;
     for (int kb = 0; kb < nk_blk; kb += KT_KBATCH) {
         const int kcount = min(KT_KBATCH, nk_blk - kb);
-        // phase 1: one pixel per thread, 32 consecutive pixels per k
-        for (int p = tid; p < kcount * 32; p += KT_RED_THREADS) {
-            const int kl = p >> 5, v = p & 31;
+        // phase 1: one pixel per thread and pass, 32 consecutive pixels per k.  Two passes are fused (pixels p and p + 1024 of the
+        // batch): RowFn is branch-free, so the loads of both pixels are in flight together.
+        for (int p = tid; p < kcount * 32; p += 2 * KT_RED_THREADS) {
+            const int p2 = p + KT_RED_THREADS;
+            const int kl = p >> 5, v = p & 31, kl2 = p2 >> 5;
             const int i = t0 + v + (kb + kl) * KT_VT_TOTAL;
-            float row[7] = {0, 0, 0, 0, 0, 0, 0};
-            bool found = false;
-            if (i < n) found = fn(i, row);
+            const int i2 = t0 + v + (kb + kl2) * KT_VT_TOTAL;       // (p2 & 31) == v
+            const bool has2 = p2 < kcount * 32;
+            float row[7], row2[7];
+            const bool found = fn(min(i, n - 1), row) && i < n;
+            if (__builtin_amdgcn_ballot_w64(has2) != 0) {            // wave-uniform: most waves have no second pixel
+                const bool found2 = fn(min(i2, n - 1), row2) && i2 < n && has2;
+                if (has2) {
 #pragma unroll
-            for (int q = 0; q < 7; ++q) rows[kl][q][v] = row[q];
+                    for (int q = 0; q < 7; ++q) rows[kl2][q][v] = found2 ? row2[q] : 0.0f;
+                    rows[kl2][7][v] = found2 ? 1.0f : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) rows[kl][q][v] = found ? row[q] : 0.0f;
             rows[kl][7][v] = found ? 1.0f : 0.0f;
         }
         __syncthreads();
@@ -186,36 +197,37 @@ struct kt_icp_row {
     const kt_icp_args& a;
     kt_mat33 Rcurr, Rprev_inv;
     f3 tcurr, tprev;
-    // search() + getProducts(), reduce.cu:213-277, for pixel i; fills row[7], returns found
+    // search() + getProducts(), reduce.cu:213-277, for pixel i; fills row[7] (zeros when no correspondence), returns found.
+    // Branch-free: the reference's early returns become predicates and the gather index of a rejected pixel is clamped to 0, so
+    // two calls inlined back to back have all their loads issued together (one exposed latency instead of two).
     __device__ __forceinline__ bool operator()(int i, float (&row)[7]) const
     {
         const int cols = a.cols, rows = a.rows;
         const int plane = cols * rows;
         const f3 vcurr = {a.vmap_curr[i], a.vmap_curr[i + plane], a.vmap_curr[i + 2 * plane]};  // y * cols + x == i
+        const f3 ncurr = {a.nmap_curr[i], a.nmap_curr[i + plane], a.nmap_curr[i + 2 * plane]};
         const f3 vcurr_g = kt_add(kt_mul(Rcurr, vcurr), tcurr);
         const f3 vcurr_cp = kt_mul(Rprev_inv, kt_sub(vcurr_g, tprev));
         const int ux = kt_f2i_rn(vcurr_cp.x * a.intr.fx / vcurr_cp.z + a.intr.cx);
         const int uy = kt_f2i_rn(vcurr_cp.y * a.intr.fy / vcurr_cp.z + a.intr.cy);
-        if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0) return false;
-        const int g = uy * cols + ux;
+        const bool inimg = !(ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0);
+        const int g = inimg ? uy * cols + ux : 0;
         const f3 vprev_g = {a.vmap_g_prev[g], a.vmap_g_prev[g + plane], a.vmap_g_prev[g + 2 * plane]};
-        const f3 ncurr = {a.nmap_curr[i], a.nmap_curr[i + plane], a.nmap_curr[i + 2 * plane]};
-        const f3 ncurr_g = kt_mul(Rcurr, ncurr);
         const f3 nprev_g = {a.nmap_g_prev[g], a.nmap_g_prev[g + plane], a.nmap_g_prev[g + 2 * plane]};
+        const f3 ncurr_g = kt_mul(Rcurr, ncurr);
         const f3 dv = kt_sub(vprev_g, vcurr_g);
         const float dist = __builtin_sqrtf(kt_dot(dv, dv));
         const f3 cr = kt_cross(ncurr_g, nprev_g);
         const float sine = __builtin_sqrtf(kt_dot(cr, cr));
-        const bool found = (sine < a.angle_thres && dist <= a.dist_thres && !kt_isnan(ncurr.x) && !kt_isnan(nprev_g.x));
-        if (!found) return false;
+        const bool found = inimg && (sine < a.angle_thres && dist <= a.dist_thres && !kt_isnan(ncurr.x) && !kt_isnan(nprev_g.x));
         const f3 s_cp = kt_mul(Rprev_inv, kt_sub(vcurr_g, tprev));
         const f3 d_cp = kt_mul(Rprev_inv, kt_sub(vprev_g, tprev));
         const f3 n_cp = kt_mul(Rprev_inv, nprev_g);
         const f3 sxn = kt_cross(s_cp, n_cp);
-        row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
-        row[3] = sxn.x; row[4] = sxn.y; row[5] = sxn.z;
-        row[6] = kt_dot(n_cp, kt_sub(s_cp, d_cp));
-        return true;
+        row[0] = found ? n_cp.x : 0.0f; row[1] = found ? n_cp.y : 0.0f; row[2] = found ? n_cp.z : 0.0f;
+        row[3] = found ? sxn.x : 0.0f; row[4] = found ? sxn.y : 0.0f; row[5] = found ? sxn.z : 0.0f;
+        row[6] = found ? kt_dot(n_cp, kt_sub(s_cp, d_cp)) : 0.0f;
+        return found;
     }
 };
 
@@ -530,6 +542,8 @@ struct kt_rgb_row {
     __device__ __forceinline__ bool operator()(int i, float (&row)[7]) const
     {
         const float flt_eps = 1.19209290E-07F;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) row[q] = 0.0f;
         const int4 raw = *(const int4*)&a.corres[i];
         const kt_dataterm c = *(const kt_dataterm*)&raw;
         if (c.valid == 0) return false;

@@ -337,11 +337,17 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
             if (a.bricks && packed < 0) a.bricks[b.bz[u] + brick_xy] = 1;  // idempotent byte store, no atomics
         }
         uchar4 o = c;
-        o.w = kt_f2u8_rz(fminf(weight_prev + 1.0f, KT_MAX_WEIGHT));
+        o.w = (unsigned char)min((int)c.w + 1, (int)KT_MAX_WEIGHT);  // == __float2uchar_rz(min(W + 1, 128)) for every 8-bit W
         if (COUNT) ++n_upd;
         const unsigned int rgbf = b.rec[u].rgbf;
         const bool normal_nan = (rgbf >> 24) & 1u;
-        if ((!normal_nan && !no_color) || (c.x == 0 && c.y == 0 && c.z == 0)) {
+        // A voxel whose stored colour already equals the pixel's keeps it: with c == rgb the blend is
+        // rint(RN(c (W + Wrkc(1 + e1))(1 + e2) / ((W + Wrkc)(1 + e3)))) = c for every weight (|error| <= 255 * 4 * 2^-24 << 0.5), and
+        // the degenerate 0 / 0 case (W = Wrkc = 0, or a NaN weight) can only meet c = 0 = rgb, where the reference stores 0 too.
+        // Skipped when the whole wave agrees (static camera: almost always).
+        const bool same_colour = ((((unsigned int)c.x | ((unsigned int)c.y << 8) | ((unsigned int)c.z << 16)) ^ rgbf) & 0xffffffu) == 0;
+        const bool blend = ((!normal_nan && !no_color) || (c.x == 0 && c.y == 0 && c.z == 0)) && !same_colour;
+        if (blend) {
             // c' = clamp(rint(RN(n / den))): only the INTEGER is stored, so the correctly rounded quotient matters only within
             // a hair of a half-integer.  q' = n * v_rcp_f32(den) is within 2.4e-7 * q of RN(n / den) (1 ulp reciprocal, two
             // roundings), i.e. < 7e-5 for q <= 256; if q' is farther than 2e-4 from every half-integer (or clearly above the
@@ -600,6 +606,24 @@ extern "C" int kt_integrate_tsdf(kt_ctx* c, const uint16_t* depth_raw, int cols,
 {
     return kt_integrate_tsdf_impl(c, depth_raw, cols, rows, intr, volume_size, Rcurr_inv, tcurr, tranc_dist, volume,
                                   depth_raw_scaled, voxel_wrap, color_volume, colors, nmap_curr, angle_color, N, nullptr, nullptr, nullptr, nullptr);
+}
+
+// exhaustive check hook for kt_unpack_tsdf (division by 32767 restated as a multiply and two FMAs): out[v + 32768] = unpack(v)
+__global__ void kt_unpack_table_kernel(float* out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 65536) out[i] = kt_unpack_tsdf((short)(i - 32768));
+}
+extern "C" int kt_debug_unpack_table(kt_ctx* c, float* out_host65536)
+{
+    KT_ARG(c && out_host65536);
+    float* d = nullptr;
+    KT_HIP(hipMalloc((void**)&d, 65536 * sizeof(float)));
+    hipLaunchKernelGGL(kt_unpack_table_kernel, dim3(256), dim3(256), 0, c->stream, d);
+    KT_HIP(hipMemcpyAsync(out_host65536, d, 65536 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    KT_HIP(hipFree(d));
+    return KT_OK;
 }
 
 // ================================================================================================

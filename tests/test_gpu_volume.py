@@ -218,3 +218,14 @@ def test_extract_capacity_clamp(ctx, oracle_mod, small_scene):
     out = ctx.empty(cap * 32)
     n = ctx.extract_cloud_slice(ctx.upload(vol), [size] * 3, out, cap, [0, 0, 0], ctx.upload(col), 0, N, 0, N, 0, N, 1, [0, 0, 0], N)
     assert n == cap
+
+
+def test_unpack_tsdf_all_shorts(ctx):
+    """The device restates (float)v / 32767 as a multiply plus two FMAs: must equal the IEEE division for all 65536 shorts."""
+    import ctypes as C
+    from kintinuous_amd import abi
+    out = np.zeros(65536, np.float32)
+    abi._chk(abi.lib().kt_debug_unpack_table(ctx.h, out.ctypes.data_as(C.POINTER(C.c_float))))
+    v = np.arange(-32768, 32768, dtype=np.float32)
+    ref = (v / np.float32(32767)).astype(np.float32)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
