@@ -270,26 +270,6 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
                 a.state->handoff_timeout = 0;
             }
             if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
-#ifdef KT_ICP_TIMING
-            {   // experiment: the same solve code executed twice in a row (cold vs warm instruction cache)
-                int passes = 2;
-                asm volatile("" : "+s"(passes));
-                unsigned long long tp[3];
-                tp[0] = wall_clock64();
-                double acc = 0;
-#pragma unroll 1
-                for (int pass = 0; pass < passes; ++pass) {
-                    double A2[36], x2[6];
-                    for (int k = 0; k < 36; ++k) A2[k] = dA[k] + acc;
-                    kt_ldlt_solve6_reg(A2, db, x2);
-                    acc += x2[0] * 1e-300;
-                    tp[pass + 1] = wall_clock64();
-                }
-                a.state->icp29[8] = (float)(tp[1] - tp[0]);
-                a.state->icp29[9] = (float)(tp[2] - tp[1]);
-                a.state->icp29[10] = (float)acc;
-            }
-#endif
             kt_solve_and_update(a.state, pr, dA, db);
 #ifdef KT_ICP_TIMING
             { const unsigned long long t5 = wall_clock64(); for (int q = 0; q < 7; ++q) a.state->icp29[q] = (float)(kt_ts[q + 0] - kt_ts[0]); a.state->icp29[7] = (float)(t5 - kt_ts[0]); }

@@ -185,6 +185,8 @@ KT_HD void kt_compute_krk(const double* resultRt, const kt_level_k k, float* krk
 }
 
 #ifdef __HIPCC__
+// (A one-row-per-lane variant with v_readlane / ds_bpermute exchange was measured at the same 2.5 us: the solve is bound by the
+// dependent chain of f64 operations -- pivot search, multiplier chain, one division per step -- not by the instruction count.)
 // Register-resident variant of kt_ldlt_solve6 for the kernel epilogues: identical operations in identical order, but
 // every array index is a compile-time constant (template-unrolled steps, pivot swaps as a chain of `if (p == c)`
 // with static indices), so the 6x6 system lives in VGPRs instead of scratch / LDS.
@@ -205,6 +207,7 @@ __device__ __forceinline__ void kt_ldlt_step(double (&A)[36], int (&tr)[6])
 #pragma unroll
     for (int c = K + 1; c < 6; ++c)
         if (p == c) {
+            asm volatile("; pivot swap " ::: "memory");  // keep this a real (scalar) branch: if-converted it is 24 selects per (K, c) pair
 #pragma unroll
             for (int j = 0; j < 6; ++j) { const double t = A[K * 6 + j]; A[K * 6 + j] = A[c * 6 + j]; A[c * 6 + j] = t; }
 #pragma unroll

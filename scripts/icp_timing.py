@@ -10,4 +10,4 @@ trk = abi.Tracker(ctx, cfg)
 for k, (d, rgb) in enumerate(frames):
     trk.process_frame_host(d, rgb, k)
 # state_dev is private; read icp29 of the last iteration (level 0) through the pinned host mirror offset: use debug hook
-print("ticks(10ns) from the start of the sweeping block: loop, publish, (same), sweep+fold, ldlt, pose update, state stored:", trk.debug_state()[:8]); print('ldlt twice in a loop (cold, warm) ticks:', trk.debug_state()[8:10])
+print("ticks(10ns) from the start of the sweeping block: loop, publish, (same), sweep+fold, ldlt, pose update, state stored:", trk.debug_state()[:8])
