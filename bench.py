@@ -159,6 +159,16 @@ def main():
     bytes_tsdf23 = 12.0 * U + 16.0 * P
     achieved = bytes_tsdf23 / (tsdf23_ms * 1e-3) / 1e9 if tsdf23_ms > 0 else 0.0
     peak = 8000.0
+    # HBM-side traffic of the same kernel: PMC counters cannot be read from inside the process, so this is the committed rocprofv3
+    # measurement of this workload (profiles/, collected and corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes,
+    # FETCH_SIZE x 2 after calibration on this access width, WRITE_SIZE x 1, KiB units); null for workloads without one
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_tsdf23_{args.workload}.json")
+    if N == WORKLOADS[args.workload][2] and os.path.exists(pmc_file):
+        try:
+            traffic = float(json.load(open(pmc_file))["traffic_bytes_per_launch"])
+        except Exception:
+            traffic = None
 
     out = {
         "metric": "RGB-D frames/sec @640x480, 512^3 TSDF" if args.workload == "orbit512" else f"RGB-D frames/sec ({args.workload})",
@@ -179,7 +189,7 @@ def main():
                    "volume": N, "cols": cam.cols, "rows": cam.rows, "unique_frames": nuniq, "pose_err_m_at_end": pose_err,
                    "pose_gather_bytes": pose_bytes},
         "roofline": {"kernel": "kt_tsdf23_kernel", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
-                     "frac": achieved / peak, "traffic": None, "algorithmic_bytes_per_launch": bytes_tsdf23,
+                     "frac": achieved / peak, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_tsdf23,
                      "avg_launch_ms": tsdf23_ms, "launches_timed": tsdf23_n, "U_voxels_updated": U, "S_raycast_steps": float(np.mean(Ss))},
         "stage_ms": {k: round(v[0], 4) for k, v in stage_all.items()},
         "host_ms_per_frame": {"process_frame_call": round(1e3 * host_call_s, 4), "of_which_waiting_for_pose": round(1e3 * host_wait_s, 4)},

@@ -230,6 +230,9 @@ int kt_tracker_debug_counts(kt_tracker* t, unsigned int out8_host[8]);
 /* diagnostics: the 29 ICP sums stashed by the last joint RGB-D + ICP iteration (or timing probes in instrumented builds) */
 int kt_tracker_debug_state(kt_tracker* t, float out29_host[29]);
 
+/* PMC calibration hook: stream `bytes` of a device buffer with 2- or 4-byte-per-lane coalesced accesses (the widths of the tsdf /
+ * colour volume accesses); rmw = 0 reads, 1 reads and writes back.  Used by scripts/pmc_calibrate.py to scale FETCH_SIZE / WRITE_SIZE. */
+int kt_debug_stream(kt_ctx* ctx, void* buf, size_t bytes, int elem_size, int rmw);
 /* test hook: out[v + 32768] = the device's unpack_tsdf(v) for every short v (device.hpp:77-83 restated without a division) */
 int kt_debug_unpack_table(kt_ctx* ctx, float* out_host65536);
 

@@ -124,6 +124,7 @@ _PROTOS = {
     "kt_tracker_last_counts": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "kt_tracker_debug_counts": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_debug_state": (_i, [_vp, _pf]),
+    "kt_debug_stream": (_i, [_vp, _vp, _sz, _i, _i]),
     "kt_debug_unpack_table": (_i, [_vp, _pf]),
     "kt_tracker_host_times": (_i, [_vp, _pd, _i]),
     "kt_tracker_prefetch_frame": (_i, [_vp, _vp, _vp]),

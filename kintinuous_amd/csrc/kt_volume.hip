@@ -391,8 +391,13 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
     const float tranc_dist_inv = 1.0f / a.tranc_dist;
     const unsigned int plane = (unsigned int)N * (unsigned int)N;
     unsigned int n_upd = 0, n_batches = 0, n_tasks_done = 0;
-    // consecutive tasks (neighbouring chunks of one wave-column) go to the 4 waves of one workgroup: they share pixel records
-    for (unsigned int t = blockIdx.x * 4u + (threadIdx.x >> 6); t < n_tasks; t += n_waves) {
+    // XCD-aware task order: workgroup b runs on XCD b % 8 (and each XCD has its own L2), so XCD k takes the k-th contiguous eighth of
+    // the list -- a band of y, i.e. a band of image rows whose 16-byte pixel records then stay in that one L2 -- and inside an XCD
+    // consecutive tasks (neighbouring chunks of one wave-column) go to the 4 waves of one workgroup.
+    const unsigned int per_xcd = (n_tasks + 7u) / 8u;
+    const unsigned int t_begin = (blockIdx.x & 7u) * per_xcd, t_end = min(t_begin + per_xcd, n_tasks);
+    (void)n_waves;
+    for (unsigned int t = t_begin + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); t < t_end; t += (gridDim.x >> 3) * 4u) {
         const unsigned int task = __builtin_amdgcn_readfirstlane(a.tasks[t]);
         const int sy = (int)(task & 0xffffu), chunk = (int)(task >> 24);
         const int sx = (int)((task >> 16) & 0xffu) * 64 + lane;
@@ -606,6 +611,29 @@ extern "C" int kt_integrate_tsdf(kt_ctx* c, const uint16_t* depth_raw, int cols,
 {
     return kt_integrate_tsdf_impl(c, depth_raw, cols, rows, intr, volume_size, Rcurr_inv, tcurr, tranc_dist, volume,
                                   depth_raw_scaled, voxel_wrap, color_volume, colors, nmap_curr, angle_color, N, nullptr, nullptr, nullptr, nullptr);
+}
+
+// PMC calibration hooks (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are uncalibrated for narrow accesses): stream a buffer
+// with exactly tsdf23's access widths -- 2 B per lane (tsdf) or 4 B per lane (colour), one contiguous segment per wave -- so the
+// counters can be scaled against a known byte count.  mode 0 = read, 1 = read-modify-write.
+template <typename T>
+__global__ __launch_bounds__(256) void kt_stream_kernel(T* __restrict__ p, size_t n, int rmw, unsigned int* __restrict__ sink)
+{
+    unsigned int acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        T v = p[i];
+        acc += (unsigned int)v;
+        if (rmw) p[i] = (T)(v + 1);
+    }
+    if (acc == 0x12345678u) *sink = acc;  // keeps the loads alive
+}
+extern "C" int kt_debug_stream(kt_ctx* c, void* buf, size_t bytes, int elem_size, int rmw)
+{
+    KT_ARG(c && buf && (elem_size == 2 || elem_size == 4));
+    if (elem_size == 2) hipLaunchKernelGGL(kt_stream_kernel<unsigned short>, dim3(8192), dim3(256), 0, c->stream, (unsigned short*)buf, bytes / 2, rmw, &c->counters[8]);
+    else hipLaunchKernelGGL(kt_stream_kernel<unsigned int>, dim3(8192), dim3(256), 0, c->stream, (unsigned int*)buf, bytes / 4, rmw, &c->counters[8]);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
 }
 
 // exhaustive check hook for kt_unpack_tsdf (division by 32767 restated as a multiply and two FMAs): out[v + 32768] = unpack(v)
