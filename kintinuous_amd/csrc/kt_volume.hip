@@ -96,6 +96,8 @@ struct kt_tsdf23_args {
     const unsigned int* interval;  // per storage column: z0 | z1 << 16 (kt_tsdf_interval_kernel)
     const unsigned int* tasks;     // compact list of (wave-column, z-chunk) units that contain work (kt_tsdf_tasks_kernel)
     const unsigned int* task_count;
+    const unsigned int* wrange;    // per wave-column: union of its 64 column intervals, z0 | z1 << 16
+    const float2* walk0;           // per column: (v_x, v_y) of the reference walk at z = the wave-column's first z
     unsigned int* updated;  // optional counter (U of SURVEY 8d)
     kt_mat33 Ri;            // Rcurr_inv
     float tx, ty, tz;
@@ -158,7 +160,7 @@ __device__ __forceinline__ int kt_wave_max(int v)
 // Pre-pass 1: the conservative z-interval of every voxel column, stored as (z0 | z1 << 16) per storage column (empty = N | 0),
 // and per wave-column the union of its 64 intervals.  grid = (ceil(N / 64), ceil(N / 4)), 256 threads.
 __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_args a_in, unsigned int* __restrict__ interval,
-                                                               unsigned int* __restrict__ wrange)
+                                                               unsigned int* __restrict__ wrange, float2* __restrict__ walk0)
 {
     kt_tsdf23_args a = a_in;
     const bool skip = kt_tsdf_pose_from_device(a);
@@ -215,6 +217,26 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
     if (column) interval[(size_t)sy * N + sx] = (unsigned int)z0 | ((unsigned int)z1 << 16);
     const int wz0 = kt_wave_min(z0), wz1 = kt_wave_max(z1);
     if ((threadIdx.x & 63) == 0 && sy < N) wrange[(size_t)sy * gridDim.x + blockIdx.x] = (unsigned int)wz0 | ((unsigned int)wz1 << 16);
+    // Checkpoint of the incremental walk (quirk A.17: v_x, v_y are DEFINED by repeated float +=) at the wave-column's first z:
+    // walked once per column here (wave-uniform trip count), so a voxel task only replays from there to its own chunk.
+    if (wz0 < wz1 && column) {
+        int x = sx - a.wx; if (x < 0) x += N;
+        int y = sy - a.wy; if (y < 0) y += N;
+        const float* Ri = a.Ri.m;
+        const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
+        const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
+        const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
+        float v_x = __builtin_fmaf(Ri[2], v_g_z0, __builtin_fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * a.intr.fx;
+        float v_y = __builtin_fmaf(Ri[5], v_g_z0, __builtin_fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * a.intr.fy;
+        const float dvx = Ri[2] * a.cell_z * a.intr.fx, dvy = Ri[5] * a.cell_z * a.intr.fy;
+        int z = 0;
+        for (; z + 16 <= wz0; z += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { v_x += dvx; v_y += dvy; }
+        }
+        for (; z < wz0; ++z) { v_x += dvx; v_y += dvy; }
+        walk0[(size_t)sy * N + sx] = make_float2(v_x, v_y);
+    }
 }
 
 // Pre-pass 2: compact task list.  One workgroup; thread t owns a contiguous run of wave-columns, counts their chunks, a block-wide
@@ -324,7 +346,10 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
         const float r2 = __builtin_fmaf(b.vgz[u], b.vgz[u], v_g_part_norm);
         float sdf = Dp_scaled - __builtin_amdgcn_sqrtf(r2);
         const bool is_free = sdf * tranc_dist_inv > 1.001f;
-        if (!is_free) sdf = Dp_scaled - __builtin_sqrtf(r2);
+        if (!is_free) {
+            asm volatile("; exact sqrt" ::: "memory");  // a real branch: if-converted, the 14-instruction correctly rounded sqrt runs for every voxel
+            sdf = Dp_scaled - __builtin_sqrtf(r2);
+        }
         if (!(Dp_scaled != 0 && (is_free || sdf >= -a.tranc_dist))) continue;
         const uchar4 c = b.col[u];
         const float weight_prev = (float)c.w;
@@ -416,11 +441,13 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
         const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
         const float v_g_part_norm = __builtin_fmaf(v_g_x, v_g_x, v_g_y * v_g_y);
         const float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
-        // the reference's walk (tsdf_volume.cu:566-571, 634-640) from z = 0 up to the wave's first z
-        float v_x = __builtin_fmaf(Ri[2], v_g_z0, __builtin_fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * a.intr.fx;
-        float v_y = __builtin_fmaf(Ri[5], v_g_z0, __builtin_fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * a.intr.fy;
+        // the reference's walk (tsdf_volume.cu:566-571, 634-640): resume from the wave-column's checkpoint (the value at its first z,
+        // kt_tsdf_interval_kernel) and advance to this task's first z
+        const int zc = (int)(__builtin_amdgcn_readfirstlane(a.wrange[(size_t)sy * ((N + 63) >> 6) + ((task >> 16) & 0xffu)]) & 0xffffu);
+        const float2 cp = a.walk0[(size_t)sy * N + min(sx, N - 1)];
+        float v_x = cp.x, v_y = cp.y;
         {
-            int z = 0;
+            int z = zc;
             for (; z + 16 <= wz0; z += 16) {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) { v_x += dvx; v_y += dvy; }
@@ -461,6 +488,7 @@ struct kt_integrate_scratch {
     float* tab_host[2] = {nullptr, nullptr};  // pinned staging of {vgz[N], zs[N]}, double-buffered
     unsigned int* interval = nullptr;          // N * N column intervals
     unsigned int* wrange = nullptr;            // N * ceil(N / 64) wave-column unions
+    float2* walk0 = nullptr;                   // N * N walk checkpoints at the wave-column's first z
     unsigned int* tasks = nullptr;             // up to N * ceil(N / 64) * ceil(N / ZCHUNK) tasks
     unsigned int* task_count = nullptr;
     int flip = 0;
@@ -470,7 +498,7 @@ void kt_integrate_scratch_free(kt_ctx* c)
 {
     kt_integrate_scratch* s = c->integ;
     if (!s) return;
-    (void)hipFree(s->rec); (void)hipFree(s->vgz); (void)hipFree(s->interval); (void)hipFree(s->wrange); (void)hipFree(s->tasks);
+    (void)hipFree(s->rec); (void)hipFree(s->vgz); (void)hipFree(s->interval); (void)hipFree(s->wrange); (void)hipFree(s->tasks); (void)hipFree(s->walk0);
     (void)hipFree(s->task_count);
     for (int k = 0; k < 2; ++k) (void)hipHostFree(s->tab_host[k]);
     delete s;
@@ -490,11 +518,12 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
     }
     if (s.tabN < N) {
         KT_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(s.vgz); (void)hipFree(s.interval); (void)hipFree(s.wrange); (void)hipFree(s.tasks); (void)hipFree(s.task_count);
-        s.vgz = s.zs = nullptr; s.interval = s.wrange = s.tasks = s.task_count = nullptr; s.tabN = 0;
+        (void)hipFree(s.vgz); (void)hipFree(s.interval); (void)hipFree(s.wrange); (void)hipFree(s.tasks); (void)hipFree(s.task_count); (void)hipFree(s.walk0);
+        s.vgz = s.zs = nullptr; s.interval = s.wrange = s.tasks = s.task_count = nullptr; s.walk0 = nullptr; s.tabN = 0;
         const size_t wave_cols = (size_t)N * kt_div_up(N, 64);
         KT_HIP(hipMalloc((void**)&s.interval, sizeof(unsigned int) * (size_t)N * N));
         KT_HIP(hipMalloc((void**)&s.wrange, sizeof(unsigned int) * wave_cols));
+        KT_HIP(hipMalloc((void**)&s.walk0, sizeof(float2) * (size_t)N * N));
         KT_HIP(hipMalloc((void**)&s.tasks, sizeof(unsigned int) * wave_cols * kt_div_up(N, KT_TSDF_ZCHUNK)));
         KT_HIP(hipMalloc((void**)&s.task_count, sizeof(unsigned int)));
         KT_HIP(hipMalloc((void**)&s.vgz, sizeof(float) * 2 * N));
@@ -565,8 +594,10 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     a.interval = c->integ->interval;
     a.tasks = c->integ->tasks;
     a.task_count = c->integ->task_count;
+    a.wrange = c->integ->wrange;
+    a.walk0 = c->integ->walk0;
     const int XG = kt_div_up(N, 64);
-    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(XG, kt_div_up(N, 4)), dim3(256), 0, c->stream, a, c->integ->interval, c->integ->wrange);
+    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(XG, kt_div_up(N, 4)), dim3(256), 0, c->stream, a, c->integ->interval, c->integ->wrange, c->integ->walk0);
     KT_LAUNCH_CHECK();
     hipLaunchKernelGGL(kt_tsdf_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, c->integ->wrange, N * XG, XG, c->integ->tasks, c->integ->task_count);
     KT_LAUNCH_CHECK();
