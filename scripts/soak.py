@@ -1,0 +1,32 @@
+"""Soak: long shifting sequence, HIP tracker (device frames + read-ahead) vs the oracle tracker, every pose compared."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+import numpy as np
+from kintinuous_amd import abi, synth
+from oracle import oracle
+cam = synth.Camera.small(160, 120)
+scene = synth.Scene("wall")
+traj = synth.crabwalk_trajectory(420)
+frames = [synth.render(scene, cam, *traj[i]) for i in range(0, 420, 1)]
+N = 96
+args = (cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, 7.0, 3, 2, 0, 0, 0, 0, 0, 0)
+ctx = abi.Ctx(0)
+trk, otr = abi.Tracker(ctx, abi.TrackerConfig(*args)), oracle.OracleTracker(oracle.OTrackerConfig(*args))
+dev = [(ctx.upload(d), ctx.upload(c)) for d, c in frames]
+worst = 0.0
+t0 = time.time()
+for k in range(len(frames)):
+    trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+    if k + 1 < len(frames):
+        trk.prefetch_frame(*dev[k + 1])
+    otr.process_frame(frames[k][0], frames[k][1], 33333 * k)
+    R, t, gc = trk.pose()
+    Ro, to, go = otr.pose()
+    worst = max(worst, float(np.abs(R - Ro).max()), float(np.abs(gc - go).max()))
+    assert np.array_equal(trk.voxel_wrap(), otr.voxel_wrap()), k
+assert trk.num_slices() == otr.num_slices()
+v, ov = trk.volume(), otr.volume()
+print("frames", len(frames), "slices", trk.num_slices(), "worst pose diff", worst, "tsdf mismatches", int((v != ov).sum()), "of", int((otr.color_volume()[..., 3] != 0).sum()),
+      "time %.1fs" % (time.time() - t0))
+assert worst < 1e-5
