@@ -173,6 +173,18 @@ __device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, unsigned lon
     return true;
 }
 
+// epoch of the next reduction launch on this context: never 0 (the zeroed buffer's tag), never repeated between two zeroings
+static unsigned int kt_next_epoch(kt_ctx* c)
+{
+    if (++c->red_epoch == 0) {
+        (void)hipMemsetAsync(c->red_partials, 0, sizeof(double) * 32 * c->red_max_blocks, c->stream);
+        c->red_epoch = 1;
+    }
+    return c->red_epoch;
+}
+// the residual kernel's granules live behind kt_reduce29's [32][256] block in the same buffer
+static unsigned long long* kt_residual_granules(kt_ctx* c) { return (unsigned long long*)c->red_partials + 32 * KT_RED_BLOCKS; }
+
 // ------------------------------------------------------------------------------------------------
 // a6  icpStep -> icpKernel + reduceSum                reduce.cu:186-419
 // ------------------------------------------------------------------------------------------------
@@ -281,16 +293,6 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
     }
 }
 
-// epoch of the next reduction launch on this context: never 0 (the zeroed buffer's tag), never repeated between two zeroings
-static unsigned int kt_next_epoch(kt_ctx* c)
-{
-    if (++c->red_epoch == 0) {
-        (void)hipMemsetAsync(c->red_partials, 0, sizeof(double) * 32 * c->red_max_blocks, c->stream);
-        c->red_epoch = 1;
-    }
-    return c->red_epoch;
-}
-
 int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
 {
     a.granules = (unsigned long long*)c->red_partials;
@@ -368,11 +370,13 @@ struct kt_residual_args {
     float kt_[3]; kt_mat33 krkinv;
     kt_track_state* state;   // device path: krkinv / kt read from the state, sigma written back
     int cols, rows;
-    int* out2;               // {count, sigma}; must be zero at launch
-    unsigned int* ticket;
+    int* out2;               // host path: {count, sigma} written by the sweeping workgroup
+    unsigned long long* granules; unsigned int epoch;   // [2][gridDim.x] {epoch, value} hand-off granules (as in kt_reduce29)
 };
 
-__global__ __launch_bounds__(256) void kt_residual_kernel(const kt_residual_args a)
+#define KT_RES_THREADS 256
+#define KT_RES_MAX_BLOCKS 1024
+__global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_residual_args a)
 {
     const int cols = a.cols, rows = a.rows, n = cols * rows;
     float K[9], kt[3];
@@ -426,32 +430,57 @@ __global__ __launch_bounds__(256) void kt_residual_kernel(const kt_residual_args
         // one 16-byte store per DataTerm (written for every pixel, quirk A.19)
         *(int4*)&a.corres[k] = *(const int4*)&corres;
     }
+    // {count, sum diff^2}: integer sums are order independent.  Wave shuffle -> workgroup -> ONE pair of {epoch, value} granules per
+    // workgroup (no atomics: thousands of device-scope atomics on two addresses cost more than the kernel); the last workgroup
+    // sweeps the granules (cdna_hip_programming.md G16 form R2) and, on the device path, turns them into sigmaVal for rgbStep.
     for (int off = 32; off > 0; off >>= 1) {
         cnt += __shfl_down(cnt, off, 64);
         sig += __shfl_down(sig, off, 64);
     }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        atomicAdd(&a.out2[0], cnt);
-        atomicAdd(&a.out2[1], (int)sig);
+    __shared__ unsigned int wsum[2][KT_RES_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { wsum[0][wave] = (unsigned int)cnt; wsum[1][wave] = sig; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned int t = 0;
+#pragma unroll
+        for (int w = 0; w < KT_RES_THREADS / 64; ++w) t += wsum[threadIdx.x][w];
+        __hip_atomic_store(&a.granules[threadIdx.x * gridDim.x + blockIdx.x], ((unsigned long long)a.epoch << 32) | t, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (a.state) {
-        // device path: the last block turns {count, sigma} into sigmaVal (RGBDOdometry.cpp:253 quirk) for rgbStep
-        __shared__ bool is_last;
-        __threadfence();   // this wave's atomics are performed before the block's ticket
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned int t = atomicAdd(a.ticket, 1u);
-            is_last = (t == gridDim.x - 1);
-            if (is_last) {
-                *a.ticket = 0;
-                const int count = atomicAdd(&a.out2[0], 0);   // device-scope RMW reads: coherent across XCDs
-                const int sigma = atomicAdd(&a.out2[1], 0);
-                a.state->sigma_val = __builtin_sqrtf(((float)sigma / (float)count == 0) ? 1.0f : (float)count);
-                a.state->rgb_count = count;
-                a.state->rgb_sigma = sigma;
-                atomicExch(&a.out2[0], 0);
-                atomicExch(&a.out2[1], 0);
-            }
+    if (blockIdx.x != gridDim.x - 1 || threadIdx.x >= 64) return;
+    // sweeping wave: lane l reads granules l, l + 64, ... of both sums until every tag carries this launch's epoch
+    unsigned int tot[2] = {0, 0};
+    bool ok = true;
+    for (int which = 0; which < 2; ++which)
+        for (unsigned int g = lane; g < gridDim.x; g += 64) {
+            unsigned long long v;
+            unsigned int spins = 0;
+            do {
+                v = __hip_atomic_load(&a.granules[which * gridDim.x + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)(v >> 32) == a.epoch) break;
+                __builtin_amdgcn_s_sleep(1);
+            } while (++spins < (1u << 22));
+            ok = ok && (unsigned int)(v >> 32) == a.epoch;
+            tot[which] += (unsigned int)v;
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        tot[0] += __shfl_down(tot[0], off, 64);
+        tot[1] += __shfl_down(tot[1], off, 64);
+    }
+    const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+    if (lane == 0) {
+        const int count = (int)tot[0], sigma = (int)tot[1];
+        if (a.state) {
+            // RGBDOdometry.cpp:253 (quirk): sigmaVal = sqrt(count) unless sigma / count == 0
+            a.state->sigma_val = __builtin_sqrtf(((float)sigma / (float)count == 0) ? 1.0f : (float)count);
+            a.state->rgb_count = count;
+            a.state->rgb_sigma = sigma;
+            if (!all_ok) a.state->handoff_timeout = 1;
+        } else {
+            a.out2[0] = count;
+            a.out2[1] = sigma;
+            a.out2[2] = all_ok ? 0 : 1;
         }
     }
 }
@@ -464,21 +493,21 @@ extern "C" int kt_rgb_residual(kt_ctx* c, float min_scale, const int16_t* dIdx, 
     KT_ARG(c && dIdx && dIdy && last_depth && next_depth && last_image && next_image && corres_img && kt && krkinv && sigma_sum_host && count_host);
     KT_ARG(cols > 0 && rows > 0);
     int* out2 = (int*)&c->counters[4];
-    KT_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(int), c->stream));
     kt_residual_args a;
     a.min_scale = min_scale; a.dIdx = dIdx; a.dIdy = dIdy; a.last_depth = last_depth; a.next_depth = next_depth;
     a.last_image = last_image; a.next_image = next_image; a.corres = corres_img; a.max_depth_delta = max_depth_delta;
     for (int k = 0; k < 3; ++k) a.kt_[k] = kt[k];
-    a.krkinv = *krkinv; a.state = nullptr; a.cols = cols; a.rows = rows; a.out2 = out2; a.ticket = &c->counters[6];
-    int g = kt_div_up(cols * rows, 256);
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(kt_residual_kernel, dim3(g), dim3(256), 0, c->stream, a);
+    a.krkinv = *krkinv; a.state = nullptr; a.cols = cols; a.rows = rows; a.out2 = out2;
+    a.granules = kt_residual_granules(c); a.epoch = kt_next_epoch(c);
+    int g = kt_div_up(cols * rows, KT_RES_THREADS);
+    if (g > KT_RES_MAX_BLOCKS) g = KT_RES_MAX_BLOCKS;
+    hipLaunchKernelGGL(kt_residual_kernel, dim3(g), dim3(KT_RES_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
-    KT_HIP(hipMemcpyAsync(c->int_out_host, out2, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipMemcpyAsync(c->int_out_host, out2, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
+    if (c->int_out_host[2]) { kt_set_error("computeRgbResidual: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
     *count_host = c->int_out_host[0];
     *sigma_sum_host = c->int_out_host[1];
-    KT_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(int), c->stream));  // invariant: {count, sigma} are zero at rest (device path relies on it)
     return KT_OK;
 }
 
@@ -489,10 +518,11 @@ int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, co
     kt_residual_args a;
     a.min_scale = min_scale; a.dIdx = dIdx; a.dIdy = dIdy; a.last_depth = last_depth; a.next_depth = next_depth;
     a.last_image = last_image; a.next_image = next_image; a.corres = corres_img; a.max_depth_delta = max_depth_delta;
-    a.state = state; a.cols = cols; a.rows = rows; a.out2 = (int*)&c->counters[4]; a.ticket = &c->counters[6];
-    int g = kt_div_up(cols * rows, 256);
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(kt_residual_kernel, dim3(g), dim3(256), 0, c->stream, a);
+    a.state = state; a.cols = cols; a.rows = rows; a.out2 = (int*)&c->counters[4];
+    a.granules = kt_residual_granules(c); a.epoch = kt_next_epoch(c);
+    int g = kt_div_up(cols * rows, KT_RES_THREADS);
+    if (g > KT_RES_MAX_BLOCKS) g = KT_RES_MAX_BLOCKS;
+    hipLaunchKernelGGL(kt_residual_kernel, dim3(g), dim3(KT_RES_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
