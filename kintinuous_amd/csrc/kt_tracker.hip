@@ -26,6 +26,12 @@ struct FrameSet {
     float *vmaps[KT_LEVELS], *nmaps[KT_LEVELS];
     void* rec;            // per-pixel integrate records (kt_integrate_prepare)
     float* scaled;        // depthRawScaled_
+    // RGB-D odometry inputs derived from the frame alone (RGBDOdometry.cpp:140-158, 186, 296-300); a frame is "next" while it is
+    // tracked and "last" for its successor, so the sets double as RGBDOdometry's lastDepth / nextDepth ... buffers
+    float* depth_m[KT_LEVELS];        // metric depth pyramid
+    uint8_t* image[KT_LEVELS];        // intensity pyramid
+    int16_t *dIdx[KT_LEVELS], *dIdy[KT_LEVELS];
+    float* cloud[KT_LEVELS];          // projectToPointCloud of depth_m (used when the frame is "last")
     hipEvent_t ready;     // recorded on the prefetch stream when the set is complete
     long long user;       // ordinal of the process_frame call that last consumed the set (-1: none)
 };
@@ -79,10 +85,7 @@ struct kt_tracker {
     kt_ctx pre_ctx;                    // the context with pre_stream as its stream (image kernels only)
     kt_point_xyzrgb* cloud_device; size_t cloud_cap;
     // RGBDOdometry buffers (RGBDOdometry.h:96-111)
-    float *last_depth[KT_LEVELS], *next_depth[KT_LEVELS];
-    uint8_t *last_image[KT_LEVELS], *next_image[KT_LEVELS];
-    int16_t *next_dIdx[KT_LEVELS], *next_dIdy[KT_LEVELS];
-    float* point_clouds[KT_LEVELS];
+    int prev_set;                      // set of the previous frame ("last" of RGBDOdometry), -1 before the first frame
     kt_dataterm* corres[KT_LEVELS];
     // device-resident Gauss-Newton state + pinned mirror
     kt_track_state* state_dev; kt_track_state* state_host;
@@ -156,7 +159,21 @@ static int build_frame_set(kt_tracker* t, kt_ctx* cx, int q, const uint16_t* dep
         uint16_t* dl[3] = {fs.depths[1], fs.depths[2], fs.depths[3]};
         KT_TRY(kt_build_pyramid(cx, &t->intr, fs.depths[0], cols, rows, dl, fs.vmaps, fs.nmaps));
     }
-    return kt_integrate_prepare(cx, depth_raw, colors, fs.nmaps[0], cols, rows, &t->intr, !t->cfg.disable_color_angle, fs.scaled, fs.rec);
+    KT_TRY(kt_integrate_prepare(cx, depth_raw, colors, fs.nmaps[0], cols, rows, &t->intr, !t->cfg.disable_color_angle, fs.scaled, fs.rec));
+    if (!icp) {
+        // RGBDOdometry::populateRGBDData (RGBDOdometry.cpp:140-158), the derivative images of the frame as "next" (:296-300) and its
+        // point clouds as "last" (:186): all functions of the frame alone
+        KT_TRY(kt_depth_to_metres(cx, depth_raw, fs.depth_m[0], cols, rows, (int)(6.0 * 1000)));
+        for (int l = 0; l + 1 < KT_LEVELS; ++l) KT_TRY(kt_pyr_down_gauss_f32(cx, fs.depth_m[l], lvl_cols(t, l), lvl_rows(t, l), fs.depth_m[l + 1]));
+        KT_TRY(kt_bgr_to_intensity(cx, colors, fs.image[0], cols, rows));
+        for (int l = 0; l + 1 < KT_LEVELS; ++l) KT_TRY(kt_pyr_down_gauss_u8(cx, fs.image[l], lvl_cols(t, l), lvl_rows(t, l), fs.image[l + 1]));
+        const double ifx = t->intr.fx, ify = t->intr.fy, icx = t->intr.cx, icy = t->intr.cy;  // RGBDOdometry.cpp:72-75
+        for (int l = 0; l < KT_LEVELS; ++l) {
+            KT_TRY(kt_derivative_images(cx, fs.image[l], lvl_cols(t, l), lvl_rows(t, l), fs.dIdx[l], fs.dIdy[l]));
+            KT_TRY(kt_project_to_cloud(cx, fs.depth_m[l], lvl_cols(t, l), lvl_rows(t, l), fs.cloud[l], ifx, ify, icx, icy, l));
+        }
+    }
+    return KT_OK;
 }
 
 static void compute_global_camera(kt_tracker* t, const float* tcurr)
@@ -276,13 +293,13 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
         KT_TRY(dev_alloc(&t->nmaps_g_prev[l], 3 * p, true));
         const bool rgbd = cfg->use_rgbd || cfg->use_rgbd_icp;
         const size_t q = rgbd ? p : 0;
-        KT_TRY(dev_alloc(&t->last_depth[l], q, true));
-        KT_TRY(dev_alloc(&t->next_depth[l], q, true));
-        KT_TRY(dev_alloc(&t->last_image[l], q, true));
-        KT_TRY(dev_alloc(&t->next_image[l], q, true));
-        KT_TRY(dev_alloc(&t->next_dIdx[l], q, true));
-        KT_TRY(dev_alloc(&t->next_dIdy[l], q, true));
-        KT_TRY(dev_alloc(&t->point_clouds[l], 3 * q, true));
+        for (int sidx = 0; sidx < KT_NSETS; ++sidx) {
+            KT_TRY(dev_alloc(&t->sets[sidx].depth_m[l], q, true));
+            KT_TRY(dev_alloc(&t->sets[sidx].image[l], q, true));
+            KT_TRY(dev_alloc(&t->sets[sidx].dIdx[l], q, true));
+            KT_TRY(dev_alloc(&t->sets[sidx].dIdy[l], q, true));
+            KT_TRY(dev_alloc(&t->sets[sidx].cloud[l], 3 * q, true));
+        }
         KT_TRY(dev_alloc(&t->corres[l], q, true));
     }
     KT_TRY(dev_alloc(&t->vmap_curr_color, P * 4, true));
@@ -343,8 +360,11 @@ int kt_tracker_destroy(kt_tracker* t)
     for (int l = 0; l < KT_LEVELS; ++l) {
         for (int q = 0; q < KT_NSETS; ++q) { (void)hipFree(t->sets[q].depths[l]); (void)hipFree(t->sets[q].vmaps[l]); (void)hipFree(t->sets[q].nmaps[l]); }
         (void)hipFree(t->vmaps_g_prev[l]); (void)hipFree(t->nmaps_g_prev[l]);
-        (void)hipFree(t->last_depth[l]); (void)hipFree(t->next_depth[l]); (void)hipFree(t->last_image[l]); (void)hipFree(t->next_image[l]);
-        (void)hipFree(t->next_dIdx[l]); (void)hipFree(t->next_dIdy[l]); (void)hipFree(t->point_clouds[l]); (void)hipFree(t->corres[l]);
+        for (int sidx = 0; sidx < KT_NSETS; ++sidx) {
+            (void)hipFree(t->sets[sidx].depth_m[l]); (void)hipFree(t->sets[sidx].image[l]); (void)hipFree(t->sets[sidx].dIdx[l]);
+            (void)hipFree(t->sets[sidx].dIdy[l]); (void)hipFree(t->sets[sidx].cloud[l]);
+        }
+        (void)hipFree(t->corres[l]);
     }
     (void)hipStreamSynchronize(t->pre_stream);
     for (int q = 0; q < KT_NSETS; ++q) {
@@ -382,6 +402,7 @@ int kt_tracker_reset(kt_tracker* t)
     t->slices.clear();
     KT_HIP(hipStreamSynchronize(t->pre_stream));
     t->pending.clear();
+    t->prev_set = -1;
     t->parked = t->cfg.static_mode != 0;
     KT_TRY(kt_init_volume(t->ctx, t->tsdf, t->N));
     KT_TRY(kt_init_color_volume(t->ctx, t->color, t->N));
@@ -445,18 +466,8 @@ static int icp_odometry(kt_tracker* t)
     return odometry_end(t);
 }
 
-// RGBDOdometry::populateRGBDData, RGBDOdometry.cpp:140-158
-static int populate_rgbd(kt_tracker* t, const uint16_t* depth, const uint8_t* rgb, float** dd, uint8_t** di)
-{
-    KT_TRY(kt_depth_to_metres(t->ctx, depth, dd[0], t->cfg.cols, t->cfg.rows, (int)(6.0 * 1000)));
-    for (int l = 0; l + 1 < KT_LEVELS; ++l) KT_TRY(kt_pyr_down_gauss_f32(t->ctx, dd[l], lvl_cols(t, l), lvl_rows(t, l), dd[l + 1]));
-    KT_TRY(kt_bgr_to_intensity(t->ctx, rgb, di[0], t->cfg.cols, t->cfg.rows));
-    for (int l = 0; l + 1 < KT_LEVELS; ++l) KT_TRY(kt_pyr_down_gauss_u8(t->ctx, di[l], lvl_cols(t, l), lvl_rows(t, l), di[l + 1]));
-    return KT_OK;
-}
-
 // RGBDOdometry::getIncrementalTransformation, RGBDOdometry.cpp:165-393
-static int rgbd_odometry(kt_tracker* t, const uint16_t* depth, const uint8_t* rgb)
+static int rgbd_odometry(kt_tracker* t, int set, int last_set)
 {
     int iters[KT_LEVELS];
     if (!t->cfg.use_rgbd_icp) {
@@ -470,10 +481,10 @@ static int rgbd_odometry(kt_tracker* t, const uint16_t* depth, const uint8_t* rg
     const double SOBEL_SCALE = 1.0 / pow(2.0, 3), MAX_DEPTH_DELTA = 0.07;
     const float dist_thres = 0.10f;
     const float angle_thres = (float)sin(20.f * 3.14159254f / 180.f);
-
-    KT_TRY(populate_rgbd(t, depth, rgb, t->next_depth, t->next_image));
-    for (int l = 0; l < KT_LEVELS; ++l)
-        KT_TRY(kt_derivative_images(t->ctx, t->next_image[l], lvl_cols(t, l), lvl_rows(t, l), t->next_dIdx[l], t->next_dIdy[l]));
+    // populateRGBDData, the derivative images and the point clouds were built with the frame sets (build_frame_set)
+    KT_ARG(last_set >= 0);
+    const FrameSet& next = t->sets[set];
+    const FrameSet& last = t->sets[last_set];
 
     const double ifx = t->intr.fx, ify = t->intr.fy, icx = t->intr.cx, icy = t->intr.cy;  // RGBDOdometry.cpp:72-75
     kt_level_k lk[KT_LEVELS];
@@ -486,33 +497,22 @@ static int rgbd_odometry(kt_tracker* t, const uint16_t* depth, const uint8_t* rg
     for (int l = KT_LEVELS - 1; l >= 0; --l)
         for (int j = 0; j < iters[l]; ++j) sched[ns++] = l;
     KT_TRY(odometry_begin(t, ns ? &lk[sched[0]] : nullptr));
-    int done_cloud[KT_LEVELS] = {0, 0, 0, 0};
-    for (int l = KT_LEVELS - 1; l >= 0; --l)  // projectToPointCloud is issued once per level (:186) even when it has 0 iterations
-        if (!done_cloud[l]) {
-            KT_TRY(kt_project_to_cloud(t->ctx, t->last_depth[l], lvl_cols(t, l), lvl_rows(t, l), t->point_clouds[l], ifx, ify, icx, icy, l));
-            done_cloud[l] = 1;
-        }
     for (int q = 0; q < ns; ++q) {
         const int l = sched[q];
         const int cols = lvl_cols(t, l), rows = lvl_rows(t, l);
         const float min_scale = (float)(pow(min_grad[l], 2.0) / pow(SOBEL_SCALE, 2.0));
-        KT_TRY(kt_rgb_residual_device(t->ctx, t->state_dev, min_scale, t->next_dIdx[l], t->next_dIdy[l], t->last_depth[l],
-                                      t->next_depth[l], t->last_image[l], t->next_image[l], cols, rows, t->corres[l],
-                                      (float)MAX_DEPTH_DELTA));
+        KT_TRY(kt_rgb_residual_device(t->ctx, t->state_dev, min_scale, next.dIdx[l], next.dIdy[l], last.depth_m[l], next.depth_m[l],
+                                      last.image[l], next.image[l], cols, rows, t->corres[l], (float)MAX_DEPTH_DELTA));
         const kt_intr li = lvl_intr(t->intr, l);
         if (t->cfg.use_rgbd_icp)
             KT_TRY(kt_icp_step_device(t->ctx, t->state_dev, t->vmaps_curr[l], t->nmaps_curr[l], &li, t->vmaps_g_prev[l],
                                       t->nmaps_g_prev[l], cols, rows, dist_thres, angle_thres, KT_MODE_ICP_STASH));
         const kt_level_k* nk = &lk[q + 1 < ns ? sched[q + 1] : l];
-        KT_TRY(kt_rgb_step_device(t->ctx, t->state_dev, t->corres[l], t->point_clouds[l], li.fx, li.fy, t->next_dIdx[l], t->next_dIdy[l],
+        KT_TRY(kt_rgb_step_device(t->ctx, t->state_dev, t->corres[l], last.cloud[l], li.fx, li.fy, next.dIdx[l], next.dIdy[l],
                                   (float)SOBEL_SCALE, cols, rows, t->cfg.use_rgbd_icp ? KT_MODE_JOINT_SOLVE : KT_MODE_RGB_SOLVE, nk));
     }
-    KT_TRY(odometry_end(t));
-    for (int l = 0; l < KT_LEVELS; ++l) {  // swap last/next :377-381
-        float* fd = t->last_depth[l]; t->last_depth[l] = t->next_depth[l]; t->next_depth[l] = fd;
-        uint8_t* ui = t->last_image[l]; t->last_image[l] = t->next_image[l]; t->next_image[l] = ui;
-    }
-    return KT_OK;  // the > 0.3 m jump guard (:383-387) runs in kt_frame_setup_kernel
+    // swap last/next (:377-381) = the frame sets rotate; the > 0.3 m jump guard (:383-387) runs in kt_frame_setup_kernel
+    return odometry_end(t);
 }
 
 __host__ __device__ static int voxel_trans(float translation, float voxel, int thresh)
@@ -812,7 +812,6 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     t->current_ts = timestamp;
     const int cols = t->cfg.cols, rows = t->cfg.rows, N = t->N;
     const bool icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
-    const bool rgbd = !icp;
     const int angle_color = !t->cfg.disable_color_angle;
 
     // [A] pyramid build, KintinuousTracker.cpp:465-479 (+ scaleDepth records): taken from the prefetch stream if this frame
@@ -833,13 +832,14 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     }
     select_set(t, set);
     t->sets[set].user = t->frames_started++;
+    const int last_set = t->prev_set;   // "last" of RGBDOdometry for this frame
+    t->prev_set = set;
 
     if (t->global_time == 0) {  // [B] :481-557
         kt_mat33 Rcam, Rcam_inv;
         memcpy(Rcam.m, t->Rlast, sizeof(Rcam.m));
         kt_mat33_inverse(Rcam.m, Rcam_inv.m);
         const int empty[3] = {0, 0, 0};
-        if (rgbd) KT_TRY(populate_rgbd(t, depth_raw, colors, t->last_depth, t->last_image));  // firstRun
         if (t->counting) KT_HIP(hipMemsetAsync(t->upd_dev, 0, 16 * sizeof(unsigned int), c->stream));
         KT_TRY(ev_begin(t, ST_INTEGRATE));
         tsdf23_hook_arm(t);
@@ -866,7 +866,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     // [C] odometry :564-572 -- every Gauss-Newton iteration is enqueued; the pose stays on the device
     KT_TRY(ev_begin(t, ST_ODOMETRY));
     if (icp) KT_TRY(icp_odometry(t));
-    else KT_TRY(rgbd_odometry(t, depth_raw, colors));
+    else KT_TRY(rgbd_odometry(t, set, last_set));
     // device-side frame set-up (which also posts the pose into the host's PoseMirror), then the fusion kernels -- enqueued right
     // here, speculatively, on the assumption that the volume does not shift
     v_wrap_copy_update(t);
