@@ -37,6 +37,10 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
 int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
                            const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
                            int cols, int rows, kt_dataterm* corres_img, float max_depth_delta);
+int kt_joint_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
+                         const float* vmap_g_prev, const float* nmap_g_prev, float dist_thres, float angle_thres,
+                         const kt_dataterm* corres_img, const float* cloud, const int16_t* dIdx, const int16_t* dIdy, float sobel_scale,
+                         int cols, int rows, const kt_level_k* next_k);
 int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corres_img, const float* cloud, float fx, float fy,
                        const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows, int mode,
                        const kt_level_k* next_k);

@@ -57,17 +57,17 @@ __device__ __forceinline__ float kt_warp32_sum(float v)
 __device__ __constant__ unsigned char KT_PA[28] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6};
 __device__ __constant__ unsigned char KT_PB[28] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 6, 2, 3, 4, 5, 6, 3, 4, 5, 6, 4, 5, 6, 5, 6, 6};
 
-// Phases 2..end of the reduction.  RowFn(i, row[7]) -> found computes one pixel.  Returns true (workgroup-uniformly) in
-// the workgroup that retired last; there total[0..28] (LDS) holds the grid sums.
+// The reduction in two parts.  kt_reduce29_publish: phases 1 and 2 and the warp tree of every workgroup, ending with its 29
+// granules stored; RowFn(i, row[7]) -> found computes one pixel.  kt_reduce29_sweep: the last workgroup gathers the grid sums into
+// total[0..28] (LDS).  kt_reduce29 = both, returning true (workgroup-uniformly) in the sweeping workgroup.
 struct kt_no_prefetch { __device__ __forceinline__ void operator()() const {} };
-// `pre` runs in the sweeping workgroup between its publish and the sweep: the place to issue loads the epilogue will need
-// (their latency hides under the sweep).
-template <typename RowFn, typename PreFn = kt_no_prefetch>
-__device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, unsigned long long* __restrict__ granules, unsigned int epoch,
-                                            float (&total)[KT_RED_SLOTS], const PreFn& pre = PreFn())
+typedef float kt_rows_t[8][32];   // LDS staging rows[k][component][vt], KT_KBATCH of them
+
+template <typename RowFn>
+__device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsigned long long* __restrict__ granules, unsigned int epoch,
+                                                    kt_rows_t* rows)
 {
     KT_TS(0);
-    __shared__ float rows[KT_KBATCH][8][32];
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * 32;           // first virtual thread of this CUDA warp
     const int comp = tid >> 5, vt = tid & 31;  // phase-2 role
@@ -119,11 +119,16 @@ __device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, unsigned lon
         __hip_atomic_store(&granules[comp * KT_RED_BLOCKS + blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     KT_TS(2);
-    if (blockIdx.x != gridDim.x - 1) return false;
+}
+
+// `sticky`: keep a time-out flag raised by an earlier sweep of the same kernel (joint reductions)
+__device__ __forceinline__ void kt_reduce29_sweep(const unsigned long long* __restrict__ granules, unsigned int epoch, float (&total)[KT_RED_SLOTS],
+                                                  bool sticky = false)
+{
+    const int tid = threadIdx.x;
     KT_TS(3);
-    pre();
     __shared__ unsigned int timed_out;
-    if (tid == 0) timed_out = 0;
+    if (tid == 0 && !sticky) timed_out = 0;
     __syncthreads();
     // The sweeping workgroup.  blockReduceSum second stage (reduce.cu:131-164) per CUDA block b: lanes 0..3 hold the warp sums,
     // lanes 4..31 zero; offsets 16, 8, 4 add zeros, offset 2 gives s0+s2 and s1+s3, offset 1 adds them.  Then
@@ -170,6 +175,19 @@ __device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, unsigned lon
     if (tid == 0) total[KT_RED_SLOTS - 1] = timed_out ? 1.0f : 0.0f;  // slot 31: the hand-off never completed (reported by the callers)
     __syncthreads();
     KT_TS(4);
+}
+
+// `pre` runs in the sweeping workgroup between its publish and the sweep: the place to issue loads the epilogue will need
+// (their latency hides under the sweep).
+template <typename RowFn, typename PreFn = kt_no_prefetch>
+__device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, unsigned long long* __restrict__ granules, unsigned int epoch,
+                                            float (&total)[KT_RED_SLOTS], const PreFn& pre = PreFn())
+{
+    __shared__ kt_rows_t rows[KT_KBATCH];
+    kt_reduce29_publish(fn, n, granules, epoch, rows);
+    if (blockIdx.x != gridDim.x - 1) return false;
+    pre();
+    kt_reduce29_sweep(granules, epoch, total);
     return true;
 }
 
@@ -182,8 +200,10 @@ static unsigned int kt_next_epoch(kt_ctx* c)
     }
     return c->red_epoch;
 }
-// the residual kernel's granules live behind kt_reduce29's [32][256] block in the same buffer
-static unsigned long long* kt_residual_granules(kt_ctx* c) { return (unsigned long long*)c->red_partials + 32 * KT_RED_BLOCKS; }
+// the residual kernel's granules live behind the two [32][256] kt_reduce29 blocks in the same buffer
+static unsigned long long* kt_residual_granules(kt_ctx* c) { return (unsigned long long*)c->red_partials + 64 * KT_RED_BLOCKS; }
+// second kt_reduce29 granule block, for kernels that run two reductions (kt_joint_kernel)
+static unsigned long long* kt_second_granules(kt_ctx* c) { return (unsigned long long*)c->red_partials + 32 * KT_RED_BLOCKS; }
 
 // ------------------------------------------------------------------------------------------------
 // a6  icpStep -> icpKernel + reduceSum                reduce.cu:186-419
@@ -604,6 +624,61 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_arg
         kt_solve_and_update(a.state, pr, dA, db);
         kt_update_krk(a.state, a.next_k);
     }
+}
+
+// Joint RGB-D + ICP iteration in ONE launch (RGBDOdometry.cpp:262-321): both 29-sum reductions are published by every workgroup, the
+// last one sweeps both, combines A = A_rgbd + w^2 A_icp, b = b_rgbd + w b_icp (w = 10), solves and updates the pose.  Replaces the
+// kt_icp_kernel(KT_MODE_ICP_STASH) + kt_rgb_kernel(KT_MODE_JOINT_SOLVE) pair: one kernel boundary and one sweep less per iteration.
+__global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_args ai, const kt_rgb_args ar)
+{
+    kt_icp_row fi{ai};
+    for (int k = 0; k < 9; ++k) { fi.Rcurr.m[k] = ai.state->Rcurr[k]; fi.Rprev_inv.m[k] = ai.state->Rprev_inv[k]; }
+    fi.tcurr = {ai.state->tcurr[0], ai.state->tcurr[1], ai.state->tcurr[2]};
+    fi.tprev = {ai.state->tprev[0], ai.state->tprev[1], ai.state->tprev[2]};
+    const kt_rgb_row fr{ar, ar.state->sigma_val};
+    __shared__ kt_rows_t rows[KT_KBATCH];
+    __shared__ float total_icp[KT_RED_SLOTS], total[KT_RED_SLOTS];
+    kt_reduce29_publish(fi, ai.cols * ai.rows, ai.granules, ai.epoch, rows);
+    kt_reduce29_publish(fr, ar.cols * ar.rows, ar.granules, ar.epoch, rows);
+    if (blockIdx.x != gridDim.x - 1) return;
+    kt_pose_regs pr;
+    if (threadIdx.x == 0) pr.load(ar.state);
+    kt_reduce29_sweep(ai.granules, ai.epoch, total_icp);
+    kt_reduce29_sweep(ar.granules, ar.epoch, total, true);
+    if (threadIdx.x == 0) {
+        float h[29], hi[29];
+        for (int k = 0; k < 29; ++k) { h[k] = total[k]; hi[k] = total_icp[k]; }
+        double dA[36], db[6], iA[36], ib[6];
+        kt_unpack29_d(h, dA, db);
+        kt_unpack29_d(hi, iA, ib);
+        if (total[KT_RED_SLOTS - 1] != 0.0f) ar.state->handoff_timeout = 1;
+        const double w = 10;
+        for (int k = 0; k < 36; ++k) dA[k] = dA[k] + w * w * iA[k];
+        for (int k = 0; k < 6; ++k) db[k] = db[k] + w * ib[k];
+        kt_solve_and_update(ar.state, pr, dA, db);
+        kt_update_krk(ar.state, ar.next_k);
+    }
+}
+
+int kt_joint_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
+                         const float* vmap_g_prev, const float* nmap_g_prev, float dist_thres, float angle_thres,
+                         const kt_dataterm* corres_img, const float* cloud, const int16_t* dIdx, const int16_t* dIdy, float sobel_scale,
+                         int cols, int rows, const kt_level_k* next_k)
+{
+    kt_icp_args a;
+    a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
+    a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
+    a.state = state; a.out29 = nullptr; a.mode = KT_MODE_ICP_STASH; a.first = 0;
+    a.granules = kt_second_granules(c);
+    a.epoch = kt_next_epoch(c);
+    kt_rgb_args r;
+    r.corres = corres_img; r.sigma = 0.f; r.cloud = cloud; r.fx = intr->fx; r.fy = intr->fy; r.dIdx = dIdx; r.dIdy = dIdy;
+    r.sobel_scale = sobel_scale; r.cols = cols; r.rows = rows; r.state = state;
+    r.granules = (unsigned long long*)c->red_partials; r.epoch = a.epoch; r.out29 = nullptr; r.mode = KT_MODE_JOINT_SOLVE;
+    r.next_k = *next_k;
+    hipLaunchKernelGGL(kt_joint_kernel, dim3(KT_RED_BLOCKS), dim3(KT_RED_THREADS), 0, c->stream, a, r);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
 }
 
 extern "C" int kt_rgb_step(kt_ctx* c, const kt_dataterm* corres_img, float sigma, const float* cloud, float fx, float fy,

@@ -504,12 +504,14 @@ static int rgbd_odometry(kt_tracker* t, int set, int last_set)
         KT_TRY(kt_rgb_residual_device(t->ctx, t->state_dev, min_scale, next.dIdx[l], next.dIdy[l], last.depth_m[l], next.depth_m[l],
                                       last.image[l], next.image[l], cols, rows, t->corres[l], (float)MAX_DEPTH_DELTA));
         const kt_intr li = lvl_intr(t->intr, l);
-        if (t->cfg.use_rgbd_icp)
-            KT_TRY(kt_icp_step_device(t->ctx, t->state_dev, t->vmaps_curr[l], t->nmaps_curr[l], &li, t->vmaps_g_prev[l],
-                                      t->nmaps_g_prev[l], cols, rows, dist_thres, angle_thres, KT_MODE_ICP_STASH));
         const kt_level_k* nk = &lk[q + 1 < ns ? sched[q + 1] : l];
-        KT_TRY(kt_rgb_step_device(t->ctx, t->state_dev, t->corres[l], last.cloud[l], li.fx, li.fy, next.dIdx[l], next.dIdy[l],
-                                  (float)SOBEL_SCALE, cols, rows, t->cfg.use_rgbd_icp ? KT_MODE_JOINT_SOLVE : KT_MODE_RGB_SOLVE, nk));
+        if (t->cfg.use_rgbd_icp)   // ICP sums + RGB-D sums + joint solve in one launch
+            KT_TRY(kt_joint_step_device(t->ctx, t->state_dev, t->vmaps_curr[l], t->nmaps_curr[l], &li, t->vmaps_g_prev[l], t->nmaps_g_prev[l],
+                                        dist_thres, angle_thres, t->corres[l], last.cloud[l], next.dIdx[l], next.dIdy[l], (float)SOBEL_SCALE,
+                                        cols, rows, nk));
+        else
+            KT_TRY(kt_rgb_step_device(t->ctx, t->state_dev, t->corres[l], last.cloud[l], li.fx, li.fy, next.dIdx[l], next.dIdy[l],
+                                      (float)SOBEL_SCALE, cols, rows, KT_MODE_RGB_SOLVE, nk));
     }
     // swap last/next (:377-381) = the frame sets rotate; the > 0.3 m jump guard (:383-387) runs in kt_frame_setup_kernel
     return odometry_end(t);
