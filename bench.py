@@ -81,18 +81,18 @@ def main():
     trk = abi.Tracker(ctx, cfg)
     dev_frames = [(ctx.upload(dep), ctx.upload(rgb)) for (dep, rgb) in frames]  # inputs resident in HBM before the timed region
 
-    # log playback with one frame of read-ahead: frame i + 1 is announced right after frame i has been enqueued, so its
-    # pose-independent stages (bilateral, pyramids, scaleDepth) run on the tracker's second stream under frame i's integrate
-    # and raycast.  Every stage of every frame still executes inside the timed region (the first timed frame's read-ahead
-    # is issued in the warm-up, the last timed frame issues one for a frame after the region: the counts balance).
+    # log playback with one frame of read-ahead: frame i + 1 is announced before frame i is handed over, so its pose-independent
+    # stages (bilateral, pyramids, scaleDepth) run on the tracker's second stream -- throttled to 2 workgroups per CU -- under
+    # frame i's latency-bound odometry chain.  Every stage of every frame still executes inside the timed region (the first timed
+    # frame's read-ahead is issued in the warm-up, the last timed frame issues one for a frame after the region: the counts balance).
     readahead = not args.no_readahead
 
     def step(i, announce_next=True):
-        dd, dr = dev_frames[pingpong(i, nuniq)]
-        trk.process_frame(dd, dr, 33333 * i)
-        if readahead and announce_next:   # enqueued behind frame i's integrate + raycast: overlaps those, not the ICP chain
+        if readahead and announce_next:   # frame i + 1's read-ahead gets the whole of frame i's odometry chain to hide under
             nd, nr = dev_frames[pingpong(i + 1, nuniq)]
             trk.prefetch_frame(nd, nr)
+        dd, dr = dev_frames[pingpong(i, nuniq)]
+        trk.process_frame(dd, dr, 33333 * i)
 
     for i in range(args.warmup):
         step(i)

@@ -8,6 +8,7 @@
 #include "kt_internal.hpp"
 
 #include <limits.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -35,9 +36,8 @@ struct FrameSet {
     hipEvent_t ready;     // recorded on the prefetch stream when the set is complete
     long long user;       // ordinal of the process_frame call that last consumed the set (-1: none)
 };
-// Three sets rotate.  A read-ahead for frame i + 1 is only accepted once frame i has been handed to kt_tracker_process_frame, and
-// that call began by observing frame i - 1's pose: everything up to ICP(i - 1) has retired, in particular the fusion of frame
-// i - 2 -- the last reader of the set the read-ahead is about to overwrite.  No event is needed to recycle a set.
+// Three sets rotate: the frame whose fusion is still running (also RGB-D "last" of its successor), the frame about to be tracked
+// and the frame being read ahead.  kt_tracker_prefetch_frame explains why no event is needed to recycle a set.
 #define KT_NSETS 3
 
 // the host's window on the frame in flight: written by kt_frame_setup_kernel straight into pinned, device-mapped host memory
@@ -78,7 +78,7 @@ struct kt_tracker {
     // the *_curr pointers above alias sets[cur_set]
     FrameSet sets[KT_NSETS];
     int last_assigned;                 // set handed to the most recent frame (prefetched or inline)
-    std::vector<Pending> pending;      // prefetched frame not yet processed (at most 1)
+    std::vector<Pending> pending;      // prefetched frames not yet processed (at most 2)
     long long frames_started;          // process_frame calls so far
     hipEvent_t guard_ev;               // only for out-of-pattern read-aheads (see kt_tracker_prefetch_frame)
     hipStream_t pre_stream;
@@ -146,6 +146,19 @@ static void select_set(kt_tracker* t, int q)
     }
     t->depth_raw_scaled = t->sets[q].scaled;
     t->rec_curr = t->sets[q].rec;
+}
+
+// next set in rotation that is neither the previous frame's (its fusion may still run; RGB-D "last" of the coming frame) nor owned
+// by an outstanding read-ahead; -1 if there is none
+static int pick_free_set(kt_tracker* t)
+{
+    for (int k = 1; k <= KT_NSETS; ++k) {
+        const int q = (t->last_assigned + k) % KT_NSETS;
+        bool taken = q == t->prev_set;
+        for (const Pending& p : t->pending) taken = taken || p.set == q;
+        if (!taken) return q;
+    }
+    return -1;
 }
 
 // [A] of processFrame (KintinuousTracker.cpp:465-479) plus the pose-independent half of integrate, into sets[q] on cx's stream
@@ -818,15 +831,24 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
 
     // [A] pyramid build, KintinuousTracker.cpp:465-479 (+ scaleDepth records): taken from the prefetch stream if this frame
     // was announced with kt_tracker_prefetch_frame, otherwise computed here
-    int set;
-    if (!t->pending.empty() && t->pending.front().depth == depth_raw && t->pending.front().rgb == colors) {
-        set = t->pending.front().set;
-        t->pending.erase(t->pending.begin());
-        KT_HIP(hipStreamWaitEvent(c->stream, t->sets[set].ready, 0));
-    } else {
-        for (const Pending& p : t->pending) KT_HIP(hipStreamWaitEvent(c->stream, t->sets[p.set].ready, 0));  // abandoned prefetches
-        t->pending.clear();
-        set = (t->last_assigned + 1) % KT_NSETS;
+    int set = -1;
+    for (size_t i = 0; i < t->pending.size(); ++i)
+        if (t->pending[i].depth == depth_raw && t->pending[i].rgb == colors) {
+            // read-aheads announced before this one were skipped by the caller: their sets return to the pool once written
+            for (size_t j = 0; j < i; ++j) KT_HIP(hipStreamWaitEvent(c->stream, t->sets[t->pending[j].set].ready, 0));
+            set = t->pending[i].set;
+            t->pending.erase(t->pending.begin(), t->pending.begin() + i + 1);
+            KT_HIP(hipStreamWaitEvent(c->stream, t->sets[set].ready, 0));
+            break;
+        }
+    if (set < 0) {
+        // not announced: build the set here (main-stream order protects the readers of whatever it overwrites)
+        set = pick_free_set(t);
+        if (set < 0) {  // both spare sets hold read-aheads the caller is not consuming: give up the older one
+            set = t->pending.front().set;
+            KT_HIP(hipStreamWaitEvent(c->stream, t->sets[set].ready, 0));
+            t->pending.erase(t->pending.begin());
+        }
         t->last_assigned = set;
         KT_TRY(ev_begin(t, ST_PYRAMID));
         KT_TRY(build_frame_set(t, c, set, depth_raw, colors));
@@ -892,12 +914,17 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
 int kt_tracker_prefetch_frame(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors)
 {
     KT_ARG(t && depth_raw && colors);
-    if (!t->pending.empty()) { kt_set_error("kt_tracker_prefetch_frame: a read-ahead frame is already outstanding"); return KT_ERR_STATE; }
-    const int set = (t->last_assigned + 1) % KT_NSETS;
+    if (t->pending.size() >= 2) { kt_set_error("kt_tracker_prefetch_frame: two read-ahead frames are already outstanding"); return KT_ERR_STATE; }
+    // Observe the pose of the frame in flight first (the next kt_tracker_process_frame call would wait for it anyway).  After that,
+    // with F = frames handed over so far, everything enqueued before the end of odometry(F - 1) has retired: fusion(F - 2) and the
+    // RGB-D "last" reads of odometry(F - 1).  So a set last consumed by frame <= F - 2 is free; the set of frame F - 1 (its fusion
+    // may still run, and it is RGB-D "last" for frame F) and the sets of outstanding read-aheads are not.
+    KT_TRY(complete_frame(t));
+    const int set = pick_free_set(t);   // exists: 3 sets, at most 1 other read-ahead outstanding here
+    if (set < 0) { kt_set_error("kt_tracker_prefetch_frame: no free frame set"); return KT_ERR_STATE; }
     t->last_assigned = set;
-    // In the playback pattern (process i, read-ahead i + 1, process i + 1, ...) the set was last consumed two frames before the
-    // one in flight and has retired (see KT_NSETS).  Anything else (abandoned read-aheads, resets) orders the streams explicitly.
-    if (t->sets[set].user >= 0 && t->sets[set].user > t->frames_started - 3) {
+    const bool busy = t->sets[set].user >= 0 && t->sets[set].user > t->frames_started - 2;
+    if (busy) {  // out-of-pattern use (abandoned read-aheads, ...): order the streams explicitly
         KT_HIP(hipEventRecord(t->guard_ev, t->ctx->stream));
         KT_HIP(hipStreamWaitEvent(t->pre_stream, t->guard_ev, 0));
     }

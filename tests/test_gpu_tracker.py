@@ -154,7 +154,8 @@ def test_device_frames_and_counts(ctx, oracle_mod, small_scene):
     trk.close(); otr.close()
 
 
-def test_readahead_is_transparent(ctx, small_scene):
+@pytest.mark.parametrize("rgbd_icp", [0, 1])
+def test_readahead_is_transparent(ctx, small_scene, rgbd_icp):
     """kt_tracker_prefetch_frame (pose-independent stages of the next frame on a second stream) must not change anything:
     same poses, same volumes, same predicted maps -- with in-order read-ahead, with an abandoned read-ahead, and mixed
     with host-frame calls."""
@@ -162,31 +163,35 @@ def test_readahead_is_transparent(ctx, small_scene):
     cam, frames, _ = small_scene
     frames = frames[:8]
     dev = [(ctx.upload(d), ctx.upload(rgb)) for d, rgb in frames]
-    g, _ = _cfgs(cam, 96)
+    g, _ = _cfgs(cam, 96, use_rgbd_icp=rgbd_icp)   # the RGB-D inputs ride in the frame sets too
 
     def run(mode):
         trk = abi.Tracker(ctx, g)
         for k in range(len(dev)):
-            if mode == "ahead" and k + 1 < len(dev):
-                trk.prefetch_frame(*dev[k + 1])
+            if mode == "ahead" and k + 1 < len(dev) and k > 0:
+                trk.prefetch_frame(*dev[k + 1])            # before frame k is handed over (frame 1 is built inline)
             if mode == "chaos":
                 if k == 2:
-                    trk.prefetch_frame(*dev[5])            # never processed next: must be discarded
+                    trk.prefetch_frame(*dev[5])            # announced three frames early: frames 2..4 are built inline meanwhile
                 elif k == 4:
-                    trk.prefetch_frame(*dev[5])                                # issued BEFORE frame 4 is handed over
+                    trk.prefetch_frame(*dev[6])            # two outstanding, consumed in order later
                     with pytest.raises(abi.KtError):
-                        trk.prefetch_frame(*dev[6])                            # only one may be outstanding
+                        trk.prefetch_frame(*dev[7])        # a third is refused
+                elif k == 7:
+                    trk.prefetch_frame(*dev[1])            # never consumed
             if mode == "chaos" and k == 3:
                 trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
             else:
                 trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+            if mode == "late" and k + 1 < len(dev):
+                trk.prefetch_frame(*dev[k + 1])            # after frame k has been handed over
         poses = [trk.dense_pose(i)[1].copy() for i in range(trk.num_poses())]
         out = (poses, trk.volume().copy(), trk.color_volume().copy(), [trk.vmap_g_prev(l).copy() for l in range(4)])
         trk.close()
         return out
 
     ref = run("plain")
-    for mode in ("ahead", "chaos"):
+    for mode in ("ahead", "late", "chaos"):
         got = run(mode)
         assert len(got[0]) == len(ref[0])
         for a, b in zip(got[0], ref[0]):
