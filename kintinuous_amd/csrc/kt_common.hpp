@@ -31,6 +31,7 @@ struct kt_ctx {
     int* int_out_host;       // pinned, small
     int red_max_blocks;
     kt_integrate_scratch* integ;   // integrate scratch (pixel records, z tables, intervals, task list), created on first use
+    float* bil_lut;                // bilateral tap weights [27][396] (kt_image.hip), built on first use
     unsigned int red_epoch;  // tag of the last reduction launch (kt_track.hip hand-off granules)
 };
 
@@ -43,6 +44,7 @@ int kt_check(hipError_t e, const char* what, const char* file, int line);
         if (_s != KT_OK) return _s;                                         \
     } while (0)
 #define KT_LAUNCH_CHECK() KT_HIP(hipGetLastError())
+#define KT_TRY(expr) do { int _s = (expr); if (_s != KT_OK) return _s; } while (0)
 #define KT_ARG(cond)                                                        \
     do {                                                                    \
         if (!(cond)) { kt_set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__); return KT_ERR_ARG; } \

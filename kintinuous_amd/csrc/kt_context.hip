@@ -66,6 +66,7 @@ int kt_ctx_destroy(kt_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     kt_integrate_scratch_free(c);
+    (void)hipFree(c->bil_lut);
     (void)hipFree(c->red_partials);
     (void)hipFree(c->red_out);
     (void)hipFree(c->counters);

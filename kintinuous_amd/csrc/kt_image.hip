@@ -2,7 +2,7 @@
 // vertex / normal maps (a3, a4), rigid map transform (a5), map down-sampling (a13) and the RGB-D
 // odometry image pyramids (a10 helpers).  Reference: src/frontend/cuda/bilateral_pyrdown.cu, maps.cu.
 // Results are bit-identical to the oracle's restatement (same operation order, explicit fmaf sites).
-#include "kt_common.hpp"
+#include "kt_internal.hpp"
 
 // ================================================================================================
 // a1  bilateralFilter -> bilateralKernel              bilateral_pyrdown.cu:59-99, 332-342
@@ -13,16 +13,52 @@
 #define KT_BIL_R 6
 #define KT_BIL_T 16
 #define KT_BIL_W (KT_BIL_T + 2 * KT_BIL_R)
+// The tap weight is ONE exponential of a sum, exp(-(space2 * A + color2 * B)) (bilateral_pyrdown.cu:89) -- not separable in floating
+// point -- but its argument takes few values: space2 = dx^2 + dy^2 has 27 distinct values in the 13x13 window and color2 = d^2 with
+// d = |centre - tap| an integer.  For d >= 395 the argument is below -125 * ln 2 and the restated __expf returns exactly 0 whatever
+// space2 is; for d >= 46341 the reference's int d * d wraps negative (quirk) and the weight is computed directly.  So the weights
+// come from a 27 x 396 table built once per context WITH THE SAME FUNCTION AND INPUTS (bit-identical by construction), staged in
+// LDS (42 KB) by every workgroup: ~8 vector instructions per tap instead of ~20.
+#define KT_BIL_ROWS 27
+#define KT_BIL_D 396
+__device__ __constant__ unsigned char KT_BIL_S2ROW[73] = {
+    0, 1, 2, 255, 3, 4, 255, 255, 5, 6, 7, 255, 255, 8, 255, 255, 9, 10, 11, 255, 12, 255, 255, 255, 255, 13, 14, 255, 255, 15, 255, 255, 16, 255, 17, 255,
+    18, 19, 255, 255, 20, 21, 255, 255, 255, 22, 255, 255, 255, 255, 23, 255, 24, 255, 255, 255, 255, 255, 255, 255, 255, 25, 255, 255, 255, 255, 255, 255,
+    255, 255, 255, 255, 26};
+__device__ __constant__ unsigned char KT_BIL_ROWS2[KT_BIL_ROWS] = {0, 1, 2, 4, 5, 8, 9, 10, 13, 16, 17, 18, 20, 25, 26, 29, 32, 34, 36, 37, 40, 41, 45, 50, 52, 61, 72};
+
+__device__ __forceinline__ float kt_bil_weight(int space2_i, int diff, float sigma_space2_inv_half, float sigma_color2_inv_half)
+{
+    const float space2 = (float)space2_i;
+    const float color2 = (float)(int)((unsigned)diff * (unsigned)diff);   // the reference's int product, wrap included
+    return kt_expf(-__builtin_fmaf(space2, sigma_space2_inv_half, color2 * sigma_color2_inv_half));
+}
+
+__global__ __launch_bounds__(256) void kt_bilateral_lut_kernel(float* __restrict__ lut, float sigma_space2_inv_half, float sigma_color2_inv_half)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= KT_BIL_ROWS * KT_BIL_D) return;
+    const int r = i / KT_BIL_D, d = i - r * KT_BIL_D;
+    lut[i] = kt_bil_weight(KT_BIL_ROWS2[r], d, sigma_space2_inv_half, sigma_color2_inv_half);
+}
 
 __global__ __launch_bounds__(256) void kt_bilateral_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int cols,
-                                                           int rows, float sigma_space2_inv_half, float sigma_color2_inv_half)
+                                                           int rows, float sigma_space2_inv_half, float sigma_color2_inv_half,
+                                                           const float* __restrict__ lut)
 {
     __shared__ int tile[KT_BIL_W][KT_BIL_W + 1];
+    __shared__ __attribute__((aligned(16))) float s_lut[KT_BIL_ROWS * KT_BIL_D];
+    __shared__ __attribute__((aligned(16))) unsigned short s_rowoff[2 * KT_BIL_R + 1][16];   // (dy + 6, dx + 6) -> row * KT_BIL_D
     const int bx = blockIdx.x * KT_BIL_T, by = blockIdx.y * KT_BIL_T;
     for (int i = threadIdx.x; i < KT_BIL_W * KT_BIL_W; i += 256) {
         const int ty = i / KT_BIL_W, tx = i - ty * KT_BIL_W;
         const int gx = bx + tx - KT_BIL_R, gy = by + ty - KT_BIL_R;
         tile[ty][tx] = (gx >= 0 && gy >= 0 && gx < cols && gy < rows) ? (int)src[gy * cols + gx] : 0;
+    }
+    for (int i = threadIdx.x; i < KT_BIL_ROWS * KT_BIL_D / 4; i += 256) ((float4*)s_lut)[i] = ((const float4*)lut)[i];
+    if (threadIdx.x < 169) {
+        const int dy = threadIdx.x / 13 - KT_BIL_R, dx = threadIdx.x % 13 - KT_BIL_R;
+        s_rowoff[dy + KT_BIL_R][dx + KT_BIL_R] = (unsigned short)(KT_BIL_S2ROW[dx * dx + dy * dy] * KT_BIL_D);
     }
     __syncthreads();
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
@@ -33,14 +69,47 @@ __global__ __launch_bounds__(256) void kt_bilateral_kernel(const uint16_t* __res
     const int tx = min(x - D / 2 + D, cols - 1);
     const int ty = min(y - D / 2 + D, rows - 1);
     float sum1 = 0, sum2 = 0;
+    // Workgroups whose every pixel has the full 13 x 13 window (all but the image border): the tap loop is unrolled in the reference's
+    // order with the table row of each (dy, dx) as a compile-time offset -- one LDS read per tap, 13 independent ones per row.
+    const bool interior = bx >= KT_BIL_R && by >= KT_BIL_R && bx + KT_BIL_T - 1 + D / 2 + 1 <= cols - 1 && by + KT_BIL_T - 1 + D / 2 + 1 <= rows - 1;
+    if (interior) {
+        bool wrap = false;
+#pragma unroll 1
+        for (int dy = -KT_BIL_R; dy <= KT_BIL_R; ++dy) {
+            // the 13 table-row offsets of this dy (16 ushorts = two 16-byte LDS reads) and the 13 taps of the tile row
+            const uint4 o0 = *(const uint4*)&s_rowoff[dy + KT_BIL_R][0], o1 = *(const uint4*)&s_rowoff[dy + KT_BIL_R][8];
+            const unsigned int ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            int t[2 * KT_BIL_R + 1];
+#pragma unroll
+            for (int k = 0; k <= 2 * KT_BIL_R; ++k) t[k] = tile[ly + KT_BIL_R + dy][lx + k];
+#pragma unroll
+            for (int k = 0; k <= 2 * KT_BIL_R; ++k) {
+                const int tmp = t[k];
+                const int d = abs(value - tmp);
+                const int roff = (int)((ow[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
+                const float weight = s_lut[roff + min(d, KT_BIL_D - 1)];
+                wrap = wrap || d >= 46341;
+                sum1 = __builtin_fmaf((float)tmp, weight, sum1);
+                sum2 += weight;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(wrap) == 0) {
+            const int res = kt_f2i_rn(sum1 / sum2);
+            dst[y * cols + x] = (uint16_t)max(0, min(res, 32767));
+            return;
+        }
+        sum1 = 0; sum2 = 0;   // a tap with a wrapping d * d (quirk): redo this wave on the general path
+    }
     for (int cy = max(y - D / 2, 0); cy < ty; ++cy) {
         const int* row = tile[cy - by + KT_BIL_R];
-        const int dy2 = (y - cy) * (y - cy);
+        const unsigned short* roff = s_rowoff[cy - y + KT_BIL_R];
         for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
             const int tmp = row[cx - bx + KT_BIL_R];
-            const float space2 = (float)((x - cx) * (x - cx) + dy2);
-            const float color2 = (float)(int)((unsigned)(value - tmp) * (unsigned)(value - tmp));
-            const float weight = kt_expf(-__builtin_fmaf(space2, sigma_space2_inv_half, color2 * sigma_color2_inv_half));
+            const int d = abs(value - tmp);
+            float weight = s_lut[roff[cx - x + KT_BIL_R] + min(d, KT_BIL_D - 1)];
+            if (__builtin_amdgcn_ballot_w64(d >= 46341) != 0) {   // d * d wraps in the reference's int arithmetic: no table for that
+                if (d >= 46341) weight = kt_bil_weight((x - cx) * (x - cx) + (y - cy) * (y - cy), value - tmp, sigma_space2_inv_half, sigma_color2_inv_half);
+            }
             sum1 = __builtin_fmaf((float)tmp, weight, sum1);
             sum2 += weight;
         }
@@ -49,12 +118,28 @@ __global__ __launch_bounds__(256) void kt_bilateral_kernel(const uint16_t* __res
     dst[y * cols + x] = (uint16_t)max(0, min(res, 32767));
 }
 
+// builds the tap-weight table of the context on first use (kt_tracker_create calls it before it clones the context for its
+// read-ahead stream, so both streams share one table)
+int kt_bilateral_lut_ensure(kt_ctx* c)
+{
+    if (c->bil_lut) return KT_OK;
+    const float sigma_color = 30.0f, sigma_space = 4.5f;  // bilateral_pyrdown.cu:56-57
+    const float A = 0.5f / (sigma_space * sigma_space), B = 0.5f / (sigma_color * sigma_color);
+    KT_HIP(hipMalloc((void**)&c->bil_lut, sizeof(float) * KT_BIL_ROWS * KT_BIL_D));
+    hipLaunchKernelGGL(kt_bilateral_lut_kernel, dim3(kt_div_up(KT_BIL_ROWS * KT_BIL_D, 256)), dim3(256), 0, c->stream, c->bil_lut, A, B);
+    KT_LAUNCH_CHECK();
+    KT_HIP(hipStreamSynchronize(c->stream));
+    return KT_OK;
+}
+
 extern "C" int kt_bilateral_filter(kt_ctx* c, const uint16_t* src, uint16_t* dst, int cols, int rows)
 {
     KT_ARG(c && src && dst && cols > 0 && rows > 0);
     const float sigma_color = 30.0f, sigma_space = 4.5f;  // bilateral_pyrdown.cu:56-57
+    const float A = 0.5f / (sigma_space * sigma_space), B = 0.5f / (sigma_color * sigma_color);
+    KT_TRY(kt_bilateral_lut_ensure(c));
     hipLaunchKernelGGL(kt_bilateral_kernel, dim3(kt_div_up(cols, KT_BIL_T), kt_div_up(rows, KT_BIL_T)), dim3(256), 0, c->stream, src,
-                       dst, cols, rows, 0.5f / (sigma_space * sigma_space), 0.5f / (sigma_color * sigma_color));
+                       dst, cols, rows, A, B, c->bil_lut);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }

@@ -12,6 +12,8 @@ struct kt_frame_params {
     int skip;           // 1: the frame needs a volume shift first -- the speculatively enqueued fusion kernels do nothing
 };
 
+int kt_bilateral_lut_ensure(kt_ctx* c);
+
 int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
                            const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
                            int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,

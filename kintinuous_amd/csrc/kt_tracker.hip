@@ -123,7 +123,6 @@ static kt_intr lvl_intr(kt_intr k, int l)  // Intr::operator() internal.h:255-25
     return r;
 }
 
-#define KT_TRY(expr) do { int _s = (expr); if (_s != KT_OK) return _s; } while (0)
 
 // zero-fill goes on the context's stream: the stream is non-blocking, so a null-stream hipMemset would not be ordered
 // against the kernels that later write these buffers
@@ -327,6 +326,7 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
     t->frames_started = 0;
     KT_HIP(hipEventCreateWithFlags(&t->guard_ev, hipEventDisableTiming));
     KT_HIP(hipStreamCreateWithFlags(&t->pre_stream, hipStreamNonBlocking));
+    KT_TRY(kt_bilateral_lut_ensure(ctx));   // before the context is cloned: both streams share the table
     t->pre_ctx = *ctx;
     t->pre_ctx.stream = t->pre_stream;
     t->pre_ctx.own_stream = false;
