@@ -190,7 +190,11 @@ def main():
                    "pose_gather_bytes": pose_bytes},
         "roofline": {"kernel": "kt_tsdf23_kernel", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                      "frac": achieved / peak, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_tsdf23,
-                     "avg_launch_ms": tsdf23_ms, "launches_timed": tsdf23_n, "U_voxels_updated": U, "S_raycast_steps": float(np.mean(Ss))},
+                     "avg_launch_ms": tsdf23_ms, "launches_timed": tsdf23_n, "U_voxels_updated": U, "S_raycast_steps": float(np.mean(Ss)),
+                     # in the timed region the kernel shares the GPU with the read-ahead stream (next frame's bilateral / pyramid);
+                     # the same launch with nothing else running (untimed stage pass below):
+                     "avg_launch_ms_alone": stage_all["tsdf23"][0],
+                     "frac_alone": (bytes_tsdf23 / (stage_all["tsdf23"][0] * 1e-3) / 1e9 / peak) if stage_all["tsdf23"][0] > 0 else None},
         "stage_ms": {k: round(v[0], 4) for k, v in stage_all.items()},
         "host_ms_per_frame": {"process_frame_call": round(1e3 * host_call_s, 4), "of_which_waiting_for_pose": round(1e3 * host_wait_s, 4)},
     }
