@@ -1000,9 +1000,6 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
                 time_curr = t;
                 if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
             }
-#if defined(KT_RC_EXPERIMENT) && KT_RC_EXPERIMENT == 1
-            if (crossing) { hit = true; out_vx = t_cross; vfx = t_cross; crossing = false; }  // timing experiment: no hit processing
-#endif
             if (crossing) {  // zero crossing, ray_caster.cu:354-422
                 time_curr = t_cross;
                 const float tn = time_curr + a.time_step;
