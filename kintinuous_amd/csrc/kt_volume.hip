@@ -590,7 +590,7 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     for (int k = 0; k < 3; ++k) KT_ARG(voxel_wrap[k] >= 0);  // vWrapCopy is always normalised (KintinuousTracker.cpp:1075-1085)
     a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
     a.cols = cols; a.rows = rows; a.N = N;
-    KT_ARG(N <= 4096);
+    KT_ARG(N <= 1536);  // 32-bit voxel offsets (N^3 < 2^32) and 16-bit z bounds
     a.interval = c->integ->interval;
     a.tasks = c->integ->tasks;
     a.task_count = c->integ->task_count;
@@ -710,6 +710,7 @@ struct kt_raycast_args {
 
 struct kt_rc {
     const kt_raycast_args& a;
+    float rcx, rcy, rcz;   // RN(1 / cell) per axis, for voxel_fast
     __device__ __forceinline__ size_t index(int x, int y, int z) const
     {
         int X = x + a.wx; if (X >= a.N) X -= a.N;
@@ -727,7 +728,7 @@ struct kt_rc {
     // to an integer: q' = p * RN(1 / cell) differs from RN(p / cell) by at most 3 * 2^-24 * |q| (< 1e-4 for |q| <= 512), so
     // whenever q' is farther than 2e-4 from an integer (and |q'| < 1024) floor(q') is the reference's voxel.  Lanes that are
     // not provably safe take the correctly rounded division; the branch is wave-uniform and rare (~7% of wave steps).
-    __device__ __forceinline__ void voxel_fast(float px, float py, float pz, float rcx, float rcy, float rcz, int& gx, int& gy, int& gz) const
+    __device__ __forceinline__ void voxel_fast(float px, float py, float pz, int& gx, int& gy, int& gz) const
     {
         float qx = px * rcx, qy = py * rcy, qz = pz * rcz;
         const float fx = qx - __builtin_floorf(qx), fy = qy - __builtin_floorf(qy), fz = qz - __builtin_floorf(qz);
@@ -744,7 +745,7 @@ struct kt_rc {
     __device__ __forceinline__ bool trilinear(float px, float py, float pz, float& out) const
     {
         int gx, gy, gz;
-        voxel(px, py, pz, gx, gy, gz);
+        voxel_fast(px, py, pz, gx, gy, gz);   // == voxel(): only floor(p / cell) is used
         const int N = a.N;
         if (gx <= 0 || gx >= N - 1) return false;
         if (gy <= 0 || gy >= N - 1) return false;
@@ -759,10 +760,19 @@ struct kt_rc {
         float fb = __builtin_fmaf(-((float)gy + 0.5f), a.cy_, py) / a.cy_;
         float fc = __builtin_fmaf(-((float)gz + 0.5f), a.cz_, pz) / a.cz_;
         float r[8];
+        // the 8 taps share 2 wrapped coordinates per axis (32-bit partial offsets: kt_raycast_impl requires N <= 1536)
+        unsigned int X[2], Y[2], Z[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            int xx = gx + d + a.wx; if (xx >= N) xx -= N;
+            int yy = gy + d + a.wy; if (yy >= N) yy -= N;
+            int zz = gz + d + a.wz; if (zz >= N) zz -= N;
+            X[d] = (unsigned int)xx; Y[d] = (unsigned int)yy * (unsigned int)N; Z[d] = (unsigned int)zz * (unsigned int)N * (unsigned int)N;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int dx = (k >> 2) & 1, dy = (k >> 1) & 1, dz = k & 1;
-            const size_t i = index(gx + dx, gy + dy, gz + dz);
+            const size_t i = (size_t)Z[dz] + Y[dy] + X[dx];
             if (CH < 0) r[k] = kt_unpack_tsdf(a.volume[i]);
             else {
                 const uchar4 c = a.color[i];
@@ -852,7 +862,7 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
     const int x = blockIdx.x * 16 + tx;
     const int y = blockIdx.y * 16 + ty;
     const bool in_image = x < a.cols && y < a.rows;
-    const kt_rc rc{a};
+    const kt_rc rc{a, 1.0f / a.cx_, 1.0f / a.cy_, 1.0f / a.cz_};
     const int cols = a.cols, rows = a.rows, N = a.N;
     unsigned int steps = 0, hopped = 0;
 
@@ -887,7 +897,7 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
             // only the SIGN of the nearest-voxel tsdf steers the march: compare the packed shorts directly
             int tsdf = a.volume[rc.index(gx, gy, gz)];
             const float max_time = 3 * (a.vsx + a.vsy + a.vsz);
-            const float rcx = 1.0f / a.cx_, rcy = 1.0f / a.cy_, rcz = 1.0f / a.cz_;
+            const float rcx = rc.rcx, rcy = rc.rcy, rcz = rc.rcz;
             // The march (ray_caster.cu:340-352) visits time_curr, time_curr + step, ... one dependent gather per step.
             // The addresses do not depend on the loaded values, so KT_RC_BATCH steps are issued together and the exit
             // tests are then replayed in order; loads past the exit point are speculative and always in bounds.
@@ -1094,6 +1104,7 @@ int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const
 {
     KT_ARG(c && intr && Rcurr && tcurr && volume_size && volume && vmap && nmap && voxel_wrap && vmap_curr_color && color_volume);
     KT_ARG(N > 0 && cols > 0 && rows > 0);
+    KT_ARG(N <= 1536);  // 32-bit voxel offsets (N^3 < 2^32)
     kt_raycast_args a;
     a.R = *Rcurr;
     a.tx = tcurr[0]; a.ty = tcurr[1]; a.tz = tcurr[2];
