@@ -144,13 +144,17 @@ def main():
         step(i, announce_next=False)  # serial frames: every stage on the main stream so that each has a duration
     stage_all = trk.stage_ms()
     trk.enable_profiling(0)
+    # U (voxels updated) and S (ray-march samples) of exactly the timed frames: the run is deterministic (and identical with and
+    # without read-ahead), so the same frames are replayed from a reset tracker with the counting kernel variants
+    trk.reset()
     trk.enable_counts(True)
     Us, Ss = [], []
-    for i in range(base + 8, base + 12):
+    for i in range(args.warmup + args.steps):
         step(i, announce_next=False)
-        U, S = trk.last_counts()
-        Us.append(U)
-        Ss.append(S)
+        if i >= args.warmup:
+            U, S = trk.last_counts()
+            Us.append(U)
+            Ss.append(S)
     trk.enable_counts(False)
     U = float(np.mean(Us))
     P = cam.cols * cam.rows
