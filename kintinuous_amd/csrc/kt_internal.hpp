@@ -18,12 +18,14 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
                            const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
                            int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
                            const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev,
-                           const void* prepared_rec, const kt_frame_params* fp = nullptr, unsigned char* bricks = nullptr);
+                           const void* prepared_rec, const kt_frame_params* fp = nullptr, unsigned char* bricks = nullptr,
+                           const float* prepared_dpmax = nullptr);
 // device z tables {v_g_z[N], z_scaled[N]} of the next integrate call with a non-null fp (filled by the caller's set-up kernel)
 int kt_integrate_tables(kt_ctx* c, int cols, int rows, int N, float** vgz, float** zs);
 size_t kt_integrate_rec_bytes(int cols, int rows);
 int kt_integrate_prepare(kt_ctx* c, const uint16_t* depth_raw, const uint8_t* colors, const float* nmap_curr, int cols, int rows,
-                         const kt_intr* intr, int angle_color, float* depth_raw_scaled, void* rec);
+                         const kt_intr* intr, int angle_color, float* depth_raw_scaled, void* rec, float* dpmax);
+size_t kt_integrate_dpmax_bytes(void);
 int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const float tcurr[3], float tranc_dist,
                     const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
                     const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,

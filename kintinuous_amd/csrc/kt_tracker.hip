@@ -26,6 +26,7 @@ struct FrameSet {
     uint16_t* depths[KT_LEVELS];
     float *vmaps[KT_LEVELS], *nmaps[KT_LEVELS];
     void* rec;            // per-pixel integrate records (kt_integrate_prepare)
+    float* dpmax;         // per 32 x 32 pixel tile: largest |scaled depth| (interval pre-pass prune)
     float* scaled;        // depthRawScaled_
     // RGB-D odometry inputs derived from the frame alone (RGBDOdometry.cpp:140-158, 186, 296-300); a frame is "next" while it is
     // tracked and "last" for its successor, so the sets double as RGBDOdometry's lastDepth / nextDepth ... buffers
@@ -171,7 +172,7 @@ static int build_frame_set(kt_tracker* t, kt_ctx* cx, int q, const uint16_t* dep
         uint16_t* dl[3] = {fs.depths[1], fs.depths[2], fs.depths[3]};
         KT_TRY(kt_build_pyramid(cx, &t->intr, fs.depths[0], cols, rows, dl, fs.vmaps, fs.nmaps));
     }
-    KT_TRY(kt_integrate_prepare(cx, depth_raw, colors, fs.nmaps[0], cols, rows, &t->intr, !t->cfg.disable_color_angle, fs.scaled, fs.rec));
+    KT_TRY(kt_integrate_prepare(cx, depth_raw, colors, fs.nmaps[0], cols, rows, &t->intr, !t->cfg.disable_color_angle, fs.scaled, fs.rec, fs.dpmax));
     if (!icp) {
         // RGBDOdometry::populateRGBDData (RGBDOdometry.cpp:140-158), the derivative images of the frame as "next" (:296-300) and its
         // point clouds as "last" (:186): all functions of the frame alone
@@ -320,6 +321,9 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
         unsigned char* rec = nullptr;
         KT_TRY(dev_alloc(&rec, kt_integrate_rec_bytes(cfg->cols, cfg->rows), true));
         t->sets[q].rec = rec;
+        unsigned char* dpm = nullptr;
+        KT_TRY(dev_alloc(&dpm, kt_integrate_dpmax_bytes(), true));
+        t->sets[q].dpmax = (float*)dpm;
         KT_HIP(hipEventCreateWithFlags(&t->sets[q].ready, hipEventDisableTiming));
         t->sets[q].user = -1;
     }
@@ -381,7 +385,7 @@ int kt_tracker_destroy(kt_tracker* t)
     }
     (void)hipStreamSynchronize(t->pre_stream);
     for (int q = 0; q < KT_NSETS; ++q) {
-        (void)hipFree(t->sets[q].scaled); (void)hipFree(t->sets[q].rec);
+        (void)hipFree(t->sets[q].scaled); (void)hipFree(t->sets[q].rec); (void)hipFree(t->sets[q].dpmax);
         (void)hipEventDestroy(t->sets[q].ready);
     }
     (void)hipEventDestroy(t->guard_ev);
@@ -646,7 +650,7 @@ static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, con
     tsdf23_hook_arm(t);
     KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &dummy_R, dummy_t, t->tranc_dist, t->tsdf,
                                   t->sets[set].scaled, t->v_wrap_copy, t->color, colors, t->sets[set].nmaps[0], !t->cfg.disable_color_angle, N,
-                                  t->counting ? t->upd_dev : nullptr, t->sets[set].rec, t->fp_dev, t->bricks));
+                                  t->counting ? t->upd_dev : nullptr, t->sets[set].rec, t->fp_dev, t->bricks, t->sets[set].dpmax));
     KT_TRY(ev_end(t, ST_INTEGRATE));
     KT_TRY(ev_begin(t, ST_RAYCAST));
     const bool pyr = icp || t->cfg.use_rgbd_icp;
@@ -869,7 +873,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         tsdf23_hook_arm(t);
         KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rcam_inv, t->tlast, t->tranc_dist, t->tsdf,
                                       t->depth_raw_scaled, empty, t->color, colors, t->nmaps_curr[0], angle_color, N,
-                                      t->counting ? t->upd_dev : nullptr, t->rec_curr, nullptr, t->bricks));
+                                      t->counting ? t->upd_dev : nullptr, t->rec_curr, nullptr, t->bricks, t->sets[set].dpmax));
         KT_TRY(ev_end(t, ST_INTEGRATE));
         for (int l = 0; l < KT_LEVELS; ++l)
             KT_TRY(kt_transform_maps(c, t->vmaps_curr[l], t->nmaps_curr[l], lvl_cols(t, l), lvl_rows(t, l), &Rcam, t->tlast, t->vmaps_g_prev[l],

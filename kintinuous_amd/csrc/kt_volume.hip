@@ -87,6 +87,26 @@ __global__ __launch_bounds__(256) void kt_scale_depth_kernel(const uint16_t* __r
     }
 }
 
+// Coarse map of the largest |scaled depth| per KT_DPT x KT_DPT pixel tile: lets the interval pre-pass bound, per voxel column, how far
+// from the camera an update is still possible (sdf >= -trunc needs |v| <= Dp + trunc).  One workgroup per tile.
+#define KT_DPT 32
+#define KT_DPT_MAX_TILES 2048
+__global__ __launch_bounds__(256) void kt_tile_max_kernel(const kt_pixrec* __restrict__ rec, int cols, int rows, float* __restrict__ dpmax)
+{
+    __shared__ float wmax[4];
+    const int x0 = blockIdx.x * KT_DPT, y0 = blockIdx.y * KT_DPT;
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < KT_DPT * KT_DPT; i += 256) {
+        const int x = x0 + (i & (KT_DPT - 1)), y = y0 + i / KT_DPT;
+        if (x < cols && y < rows) m = fmaxf(m, fabsf(rec[y * cols + x].dp));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) dpmax[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+}
+
 struct kt_tsdf23_args {
     const kt_pixrec* rec;
     int16_t* volume;
@@ -98,6 +118,7 @@ struct kt_tsdf23_args {
     const unsigned int* task_count;
     const unsigned int* wrange;    // per wave-column: union of its 64 column intervals, z0 | z1 << 16
     const float2* walk0;           // per column: (v_x, v_y) of the reference walk at z = the wave-column's first z
+    const float* dpmax;            // [ceil(rows / 32)][ceil(cols / 32)] largest |scaled depth| per pixel tile (kt_tile_max_kernel), or null
     unsigned int* updated;  // optional counter (U of SURVEY 8d)
     kt_mat33 Ri;            // Rcurr_inv
     float tx, ty, tz;
@@ -168,6 +189,13 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
     const int sx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const bool column = sx < N && sy < N;
+    __shared__ float s_dpmax[KT_DPT_MAX_TILES];
+    const int tcols = (a.cols + KT_DPT - 1) / KT_DPT, trows = (a.rows + KT_DPT - 1) / KT_DPT;
+    const bool prune = a.dpmax != nullptr && tcols * trows <= KT_DPT_MAX_TILES;
+    if (prune) {
+        for (int i = threadIdx.x; i < tcols * trows; i += 256) s_dpmax[i] = a.dpmax[i];
+        __syncthreads();
+    }
     int z0 = N, z1 = 0;
     if (column && !skip) {  // a frame parked for the host's shift path has no work
         int x = sx - a.wx; if (x < 0) x += N;
@@ -204,6 +232,38 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
             const bool far_x = (pxa > rlim && pxb > rlim) || (pxa < -rlim && pxb < -rlim);
             const bool far_y = (pya > rlim && pyb > rlim) || (pya < -rlim && pyb < -rlim);
             if (far_x || far_y) { nlo = 1e30f; nhi = -1e30f; }
+        }
+        // Depth-range prune of the frustum part.  The voxels of the column project onto a straight image segment; with D the largest
+        // |scaled depth| in the tiles that segment touches, a voxel farther than D + trunc from the camera has sdf < -trunc
+        // whatever pixel it meets, and one whose pixel has no depth is never updated: only z with
+        // |v|^2 = v_g_x^2 + v_g_y^2 + ((z + 0.5) cell_z - t_z)^2 <= (D + trunc)^2 can be updated.  (Skipped when the near slab is
+        // kept: the segment's end is ill-defined there.)
+        if (prune && flo <= fhi && !(nlo <= nhi)) {
+            const float pza = az + flo * bz, pzb = az + fhi * bz;   // >= znear by the clip above
+            const float ua = a.intr.fx * (ax + flo * bx) / pza + a.intr.cx, va = a.intr.fy * (ay + flo * by) / pza + a.intr.cy;
+            const float ub = a.intr.fx * (ax + fhi * bx) / pzb + a.intr.cx, vb = a.intr.fy * (ay + fhi * by) / pzb + a.intr.cy;
+            const float len = fmaxf(fabsf(ub - ua), fabsf(vb - va));
+            const int n = min(256, (int)(len * (2.0f / KT_DPT)) + 1);   // samples every <= 16 pixels
+            const float du = (ub - ua) / (float)n, dv = (vb - va) / (float)n;
+            float D = 0.0f;
+            for (int i = 0; i <= n; ++i) {
+                const float u = ua + du * (float)i, v = va + dv * (float)i;
+                // the tiles covering the 32 x 32 pixel square around the sample (clamped: outside the image nothing is updated)
+                const int tx0 = min(tcols - 1, max(0, (int)floorf((u - 0.5f * KT_DPT) * (1.0f / KT_DPT))));
+                const int tx1 = min(tcols - 1, max(0, (int)floorf((u + 0.5f * KT_DPT) * (1.0f / KT_DPT))));
+                const int ty0 = min(trows - 1, max(0, (int)floorf((v - 0.5f * KT_DPT) * (1.0f / KT_DPT))));
+                const int ty1 = min(trows - 1, max(0, (int)floorf((v + 0.5f * KT_DPT) * (1.0f / KT_DPT))));
+                D = fmaxf(D, fmaxf(fmaxf(s_dpmax[ty0 * tcols + tx0], s_dpmax[ty0 * tcols + tx1]),
+                                   fmaxf(s_dpmax[ty1 * tcols + tx0], s_dpmax[ty1 * tcols + tx1])));
+            }
+            const float R = (D + a.tranc_dist) * 1.001f + 1e-4f;
+            const float s2 = R * R - (v_g_x * v_g_x + v_g_y * v_g_y);
+            if (s2 < 0.0f) { flo = 1e30f; fhi = -1e30f; }
+            else {
+                const float sroot = __builtin_sqrtf(s2);
+                flo = fmaxf(flo, (a.tz - sroot) / a.cell_z - 0.5f - 1.5f);
+                fhi = fminf(fhi, (a.tz + sroot) / a.cell_z - 0.5f + 1.5f);
+            }
         }
         float l = 1e30f, h = -1e30f;
         if (flo <= fhi) { l = fminf(l, flo); h = fmaxf(h, fhi); }
@@ -489,6 +549,7 @@ struct kt_integrate_scratch {
     unsigned int* interval = nullptr;          // N * N column intervals
     unsigned int* wrange = nullptr;            // N * ceil(N / 64) wave-column unions
     float2* walk0 = nullptr;                   // N * N walk checkpoints at the wave-column's first z
+    float* dpmax = nullptr;                    // KT_DPT_MAX_TILES tile maxima of |scaled depth| (non-prepared path)
     unsigned int* tasks = nullptr;             // up to N * ceil(N / 64) * ceil(N / ZCHUNK) tasks
     unsigned int* task_count = nullptr;
     int flip = 0;
@@ -498,7 +559,7 @@ void kt_integrate_scratch_free(kt_ctx* c)
 {
     kt_integrate_scratch* s = c->integ;
     if (!s) return;
-    (void)hipFree(s->rec); (void)hipFree(s->vgz); (void)hipFree(s->interval); (void)hipFree(s->wrange); (void)hipFree(s->tasks); (void)hipFree(s->walk0);
+    (void)hipFree(s->rec); (void)hipFree(s->vgz); (void)hipFree(s->interval); (void)hipFree(s->wrange); (void)hipFree(s->tasks); (void)hipFree(s->walk0); (void)hipFree(s->dpmax);
     (void)hipFree(s->task_count);
     for (int k = 0; k < 2; ++k) (void)hipHostFree(s->tab_host[k]);
     delete s;
@@ -509,6 +570,7 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
 {
     if (!c->integ) c->integ = new kt_integrate_scratch();
     kt_integrate_scratch& s = *c->integ;
+    if (!s.dpmax) KT_HIP(hipMalloc((void**)&s.dpmax, sizeof(float) * KT_DPT_MAX_TILES));
     if (s.rec_px < px) {
         KT_HIP(hipStreamSynchronize(c->stream));
         if (s.rec) KT_HIP(hipFree(s.rec));
@@ -542,7 +604,7 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
                            const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
                            int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
                            const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev,
-                           const void* prepared_rec, const kt_frame_params* fp, unsigned char* bricks)
+                           const void* prepared_rec, const kt_frame_params* fp, unsigned char* bricks, const float* prepared_dpmax)
 {
     KT_ARG(c && depth_raw && intr && volume_size && Rcurr_inv && tcurr && volume && depth_raw_scaled && voxel_wrap &&
            color_volume && colors && nmap_curr && N > 0 && cols > 0 && rows > 0);
@@ -571,6 +633,13 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
         hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, c->integ->rec, colors, nmap_curr,
                            cols, rows, *intr, angle_color);
         KT_LAUNCH_CHECK();
+        prepared_dpmax = nullptr;
+        if (kt_div_up(cols, KT_DPT) * kt_div_up(rows, KT_DPT) <= KT_DPT_MAX_TILES) {
+            hipLaunchKernelGGL(kt_tile_max_kernel, dim3(kt_div_up(cols, KT_DPT), kt_div_up(rows, KT_DPT)), dim3(256), 0, c->stream, c->integ->rec, cols,
+                               rows, c->integ->dpmax);
+            KT_LAUNCH_CHECK();
+            prepared_dpmax = c->integ->dpmax;
+        }
     }
     kt_tsdf23_args a;
     a.rec = prepared_rec ? (const kt_pixrec*)prepared_rec : c->integ->rec;
@@ -596,6 +665,7 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     a.task_count = c->integ->task_count;
     a.wrange = c->integ->wrange;
     a.walk0 = c->integ->walk0;
+    a.dpmax = prepared_dpmax;
     const int XG = kt_div_up(N, 64);
     hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(XG, kt_div_up(N, 4)), dim3(256), 0, c->stream, a, c->integ->interval, c->integ->wrange, c->integ->walk0);
     KT_LAUNCH_CHECK();
@@ -625,13 +695,19 @@ int kt_integrate_tables(kt_ctx* c, int cols, int rows, int N, float** vgz, float
 // The pose-independent half of integrateTsdfVolume (scaleDepth, tsdf_volume.cu:493-511, plus the per-pixel records): the tracker
 // runs it for frame k + 1 on its prefetch stream while frame k is still being tracked.
 size_t kt_integrate_rec_bytes(int cols, int rows) { return (size_t)cols * rows * sizeof(kt_pixrec); }
+size_t kt_integrate_dpmax_bytes(void) { return sizeof(float) * KT_DPT_MAX_TILES; }
 int kt_integrate_prepare(kt_ctx* c, const uint16_t* depth_raw, const uint8_t* colors, const float* nmap_curr, int cols, int rows,
-                         const kt_intr* intr, int angle_color, float* depth_raw_scaled, void* rec)
+                         const kt_intr* intr, int angle_color, float* depth_raw_scaled, void* rec, float* dpmax)
 {
     dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8));
     hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, (kt_pixrec*)rec, colors, nmap_curr, cols, rows,
                        *intr, angle_color);
     KT_LAUNCH_CHECK();
+    if (dpmax && kt_div_up(cols, KT_DPT) * kt_div_up(rows, KT_DPT) <= KT_DPT_MAX_TILES) {
+        hipLaunchKernelGGL(kt_tile_max_kernel, dim3(kt_div_up(cols, KT_DPT), kt_div_up(rows, KT_DPT)), dim3(256), 0, c->stream, (const kt_pixrec*)rec,
+                           cols, rows, dpmax);
+        KT_LAUNCH_CHECK();
+    }
     return KT_OK;
 }
 
@@ -641,7 +717,7 @@ extern "C" int kt_integrate_tsdf(kt_ctx* c, const uint16_t* depth_raw, int cols,
                                  const uint8_t* colors, const float* nmap_curr, int angle_color, int N)
 {
     return kt_integrate_tsdf_impl(c, depth_raw, cols, rows, intr, volume_size, Rcurr_inv, tcurr, tranc_dist, volume,
-                                  depth_raw_scaled, voxel_wrap, color_volume, colors, nmap_curr, angle_color, N, nullptr, nullptr, nullptr, nullptr);
+                                  depth_raw_scaled, voxel_wrap, color_volume, colors, nmap_curr, angle_color, N, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 // PMC calibration hooks (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are uncalibrated for narrow accesses): stream a buffer
