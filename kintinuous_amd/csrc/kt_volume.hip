@@ -164,6 +164,10 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
 #define KT_TSDF_ZCHUNK 16
 #define KT_TSDF_UNROLL 4
 #define KT_TSDF_WAVES 8192
+// shape of a wave-column: 32 consecutive storage x of 2 consecutive y.  (64 x 1 wastes a third of the lanes at the left / right
+// frustum faces; 32 x 2 halves that and still moves 64 B of tsdf + 128 B of colour per row and access.)
+#define KT_WX 32
+#define KT_WY 2
 
 __device__ __forceinline__ int kt_wave_min(int v)
 {
@@ -179,15 +183,18 @@ __device__ __forceinline__ int kt_wave_max(int v)
 }
 
 // Pre-pass 1: the conservative z-interval of every voxel column, stored as (z0 | z1 << 16) per storage column (empty = N | 0),
-// and per wave-column the union of its 64 intervals.  grid = (ceil(N / 64), ceil(N / 4)), 256 threads.
+// and per wave-column the union of its 64 intervals.  grid = (ceil(N / 64), ceil(N / 4)), 256 threads = 2 x 2 wave-columns.
 __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_args a_in, unsigned int* __restrict__ interval,
                                                                unsigned int* __restrict__ wrange, float2* __restrict__ walk0)
 {
     kt_tsdf23_args a = a_in;
     const bool skip = kt_tsdf_pose_from_device(a);
     const int N = a.N;
-    const int sx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    // a workgroup covers 64 x 4 columns as 2 x 2 wave-columns
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    const int xg = blockIdx.x * 2 + (wave_ & 1), yg = blockIdx.y * 2 + (wave_ >> 1);
+    const int sx = xg * KT_WX + (lane_ & (KT_WX - 1));
+    const int sy = yg * KT_WY + (lane_ >> 5);
     const bool column = sx < N && sy < N;
     __shared__ float s_dpmax[KT_DPT_MAX_TILES];
     const int tcols = (a.cols + KT_DPT - 1) / KT_DPT, trows = (a.rows + KT_DPT - 1) / KT_DPT;
@@ -276,7 +283,8 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
     }
     if (column) interval[(size_t)sy * N + sx] = (unsigned int)z0 | ((unsigned int)z1 << 16);
     const int wz0 = kt_wave_min(z0), wz1 = kt_wave_max(z1);
-    if ((threadIdx.x & 63) == 0 && sy < N) wrange[(size_t)sy * gridDim.x + blockIdx.x] = (unsigned int)wz0 | ((unsigned int)wz1 << 16);
+    const int XG = (N + KT_WX - 1) / KT_WX, YG = (N + KT_WY - 1) / KT_WY;
+    if (lane_ == 0 && xg < XG && yg < YG) wrange[(size_t)yg * XG + xg] = (unsigned int)wz0 | ((unsigned int)wz1 << 16);
     // Checkpoint of the incremental walk (quirk A.17: v_x, v_y are DEFINED by repeated float +=) at the wave-column's first z:
     // walked once per column here (wave-uniform trip count), so a voxel task only replays from there to its own chunk.
     if (wz0 < wz1 && column) {
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
 }
 
 // Pre-pass 2: compact task list.  One workgroup; thread t owns a contiguous run of wave-columns, counts their chunks, a block-wide
-// exclusive scan places them.  task = sy | xg << 16 | chunk << 24.
+// exclusive scan places them.  task = yg | xg << 16 | chunk << 24 (wave-column (xg, yg), kt_tsdf_interval_kernel).
 __global__ __launch_bounds__(1024) void kt_tsdf_tasks_kernel(const unsigned int* __restrict__ wrange, int M, int XG,
                                                              unsigned int* __restrict__ tasks, unsigned int* __restrict__ task_count)
 {
@@ -392,11 +400,12 @@ __device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, kt_tsdf_b
 
 template <bool COUNT>
 __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const kt_tsdf_batch& b, float v_g_part_norm, float tranc_dist_inv,
-                                                unsigned int& n_upd, int brick_xy)
+                                                unsigned int& n_upd, int brick_xy, unsigned int& n_img)
 {
 #pragma unroll
     for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
         if (!b.in_img[u]) continue;
+        if (COUNT) ++n_img;   // diagnostics: voxel steps that project into the image
         float Dp_scaled = b.rec[u].dp;
         bool no_color = false;
         if (Dp_scaled < 0.0f) { Dp_scaled = -Dp_scaled; no_color = true; }
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
     const float dvy = Ri[5] * a.cell_z * a.intr.fy;   // Rcurr_inv_1_z_scaled
     const float tranc_dist_inv = 1.0f / a.tranc_dist;
     const unsigned int plane = (unsigned int)N * (unsigned int)N;
-    unsigned int n_upd = 0, n_batches = 0, n_tasks_done = 0;
+    unsigned int n_upd = 0, n_batches = 0, n_tasks_done = 0, n_img = 0;
     // XCD-aware task order: workgroup b runs on XCD b % 8 (and each XCD has its own L2), so XCD k takes the k-th contiguous eighth of
     // the list -- a band of y, i.e. a band of image rows whose 16-byte pixel records then stay in that one L2 -- and inside an XCD
     // consecutive tasks (neighbouring chunks of one wave-column) go to the 4 waves of one workgroup.
@@ -484,10 +493,11 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
     (void)n_waves;
     for (unsigned int t = t_begin + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); t < t_end; t += (gridDim.x >> 3) * 4u) {
         const unsigned int task = __builtin_amdgcn_readfirstlane(a.tasks[t]);
-        const int sy = (int)(task & 0xffffu), chunk = (int)(task >> 24);
-        const int sx = (int)((task >> 16) & 0xffu) * 64 + lane;
+        const int yg = (int)(task & 0xffffu), xg = (int)((task >> 16) & 0xffu), chunk = (int)(task >> 24);
+        const int sx = xg * KT_WX + (lane & (KT_WX - 1));
+        const int sy = min(yg * KT_WY + (lane >> 5), N - 1);   // a row past the volume (odd N) only repeats the last one, never live
         int z0 = N, z1 = 0;
-        if (sx < N) {
+        if (sx < N && yg * KT_WY + (lane >> 5) < N) {
             const unsigned int iv = a.interval[(size_t)sy * N + sx];
             z0 = max((int)(iv & 0xffffu), chunk * KT_TSDF_ZCHUNK);
             z1 = min((int)(iv >> 16), (chunk + 1) * KT_TSDF_ZCHUNK);
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
         const float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
         // the reference's walk (tsdf_volume.cu:566-571, 634-640): resume from the wave-column's checkpoint (the value at its first z,
         // kt_tsdf_interval_kernel) and advance to this task's first z
-        const int zc = (int)(__builtin_amdgcn_readfirstlane(a.wrange[(size_t)sy * ((N + 63) >> 6) + ((task >> 16) & 0xffu)]) & 0xffffu);
+        const int zc = (int)(__builtin_amdgcn_readfirstlane(a.wrange[(size_t)yg * ((N + KT_WX - 1) / KT_WX) + xg]) & 0xffffu);
         const float2 cp = a.walk0[(size_t)sy * N + min(sx, N - 1)];
         float v_x = cp.x, v_y = cp.y;
         {
@@ -525,18 +535,19 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
         for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
             kt_tsdf_batch cur;
             kt_tsdf_issue<COUNT>(a, cur, zb, z0, z1, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base);
-            kt_tsdf_consume<COUNT>(a, cur, v_g_part_norm, tranc_dist_inv, n_upd, brick_xy);
+            kt_tsdf_consume<COUNT>(a, cur, v_g_part_norm, tranc_dist_inv, n_upd, brick_xy, n_img);
             if (COUNT) ++n_batches;
         }
         if (COUNT) ++n_tasks_done;
     }
     if (COUNT) {
         // wave-level sum, one atomic per wave and counter; [1] = wave batches, [2] = tasks with work (diagnostics)
-        for (int off = 32; off > 0; off >>= 1) n_upd += __shfl_down(n_upd, off, 64);
+        for (int off = 32; off > 0; off >>= 1) { n_upd += __shfl_down(n_upd, off, 64); n_img += __shfl_down(n_img, off, 64); }
         if (lane == 0) {
             if (n_upd) atomicAdd(a.updated, n_upd);
             if (n_batches) atomicAdd(a.updated + 1, n_batches);
             if (n_tasks_done) atomicAdd(a.updated + 2, n_tasks_done);
+            if (n_img) atomicAdd(a.updated + 3, n_img);
         }
     }
 }
@@ -582,7 +593,7 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
         KT_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(s.vgz); (void)hipFree(s.interval); (void)hipFree(s.wrange); (void)hipFree(s.tasks); (void)hipFree(s.task_count); (void)hipFree(s.walk0);
         s.vgz = s.zs = nullptr; s.interval = s.wrange = s.tasks = s.task_count = nullptr; s.walk0 = nullptr; s.tabN = 0;
-        const size_t wave_cols = (size_t)N * kt_div_up(N, 64);
+        const size_t wave_cols = (size_t)kt_div_up(N, KT_WX) * kt_div_up(N, KT_WY);
         KT_HIP(hipMalloc((void**)&s.interval, sizeof(unsigned int) * (size_t)N * N));
         KT_HIP(hipMalloc((void**)&s.wrange, sizeof(unsigned int) * wave_cols));
         KT_HIP(hipMalloc((void**)&s.walk0, sizeof(float2) * (size_t)N * N));
@@ -666,10 +677,10 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     a.wrange = c->integ->wrange;
     a.walk0 = c->integ->walk0;
     a.dpmax = prepared_dpmax;
-    const int XG = kt_div_up(N, 64);
-    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(XG, kt_div_up(N, 4)), dim3(256), 0, c->stream, a, c->integ->interval, c->integ->wrange, c->integ->walk0);
+    const int XG = kt_div_up(N, KT_WX), YG = kt_div_up(N, KT_WY);
+    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(kt_div_up(N, 64), kt_div_up(N, 4)), dim3(256), 0, c->stream, a, c->integ->interval, c->integ->wrange, c->integ->walk0);
     KT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(kt_tsdf_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, c->integ->wrange, N * XG, XG, c->integ->tasks, c->integ->task_count);
+    hipLaunchKernelGGL(kt_tsdf_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, c->integ->wrange, XG * YG, XG, c->integ->tasks, c->integ->task_count);
     KT_LAUNCH_CHECK();
     dim3 b(256), g(KT_TSDF_WAVES / 4);
     if (kt_tsdf23_hook.on) KT_HIP(hipEventRecord(kt_tsdf23_hook.ev[0], c->stream));
