@@ -185,59 +185,67 @@ KT_HD void kt_compute_krk(const double* resultRt, const kt_level_k k, float* krk
 }
 
 #ifdef __HIPCC__
-// (A one-row-per-lane variant with v_readlane / ds_bpermute exchange was measured at the same 2.5 us: the solve is bound by the
-// dependent chain of f64 operations -- pivot search, multiplier chain, one division per step -- not by the instruction count.)
-// Register-resident variant of kt_ldlt_solve6 for the kernel epilogues: identical operations in identical order, but
-// every array index is a compile-time constant (template-unrolled steps, pivot swaps as a chain of `if (p == c)`
-// with static indices), so the 6x6 system lives in VGPRs instead of scratch / LDS.
-template <int K>
-__device__ __forceinline__ void kt_ldlt_step(double (&A)[36], int (&tr)[6])
+// Device-side 6x6 solve for the kernel epilogues.  (A register-resident version with in-loop pivoting (if-converted swaps, ~1300
+// instructions) and a one-row-per-lane version with v_readlane / ds_bpermute exchange were both measured at 2.4-2.6 us; the hoisted
+// form below takes 2.2 us and is the simplest of the three.)
+// Pivot-hoisted variant.  Eigen's unblocked LDLT is left-looking: step k only touches column k, so the diagonal entries it pivots on
+// at step k (rows >= k) are still the ORIGINAL ones -- the whole pivot sequence is a selection sort of the original diagonal (first
+// maximum wins, swaps included) and can be decided before any elimination arithmetic.  So: (1) simulate the swaps on the 6
+// diagonal values, (2) gather the symmetrically permuted system from an LDS copy with dynamic addresses, (3) factorise and solve
+// with compile-time indices and no swaps at all, (4) scatter x back through the permutation.  Every element sees exactly the
+// operations of kt_ldlt_solve6 in the same order; the code is ~40% shorter than with in-loop swaps.  `scratch`: 48 doubles of LDS owned by the calling thread.
+__device__ __forceinline__ void kt_ldlt_solve6_hoisted(const double (&Ain)[36], const double (&bin)[6], double (&x)[6], double* scratch)
 {
-    int p = K;
-    double big = fabs(A[K * 6 + K]);
+    // (1) pivot order
+    double dg[6];
+    int idx[6];
 #pragma unroll
-    for (int i = K + 1; i < 6; ++i) {
-        const double v = fabs(A[i * 6 + i]);
-        if (v > big) { big = v; p = i; }
-    }
-    // one lane runs the solve: make the pivot index wave-uniform so the swaps below are scalar branches around a few moves
-    // instead of 15 x 24 predicated selects
-    p = __builtin_amdgcn_readfirstlane(p);
-    tr[K] = p;
+    for (int i = 0; i < 6; ++i) { dg[i] = Ain[i * 6 + i]; idx[i] = i; }
 #pragma unroll
-    for (int c = K + 1; c < 6; ++c)
-        if (p == c) {
-            asm volatile("; pivot swap " ::: "memory");  // keep this a real (scalar) branch: if-converted it is 24 selects per (K, c) pair
+    for (int K = 0; K < 5; ++K) {
+        int p = K;
+        double big = fabs(dg[K]);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { const double t = A[K * 6 + j]; A[K * 6 + j] = A[c * 6 + j]; A[c * 6 + j] = t; }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) { const double t = A[i * 6 + K]; A[i * 6 + K] = A[i * 6 + c]; A[i * 6 + c] = t; }
+        for (int i = K + 1; i < 6; ++i) {
+            const double v = fabs(dg[i]);
+            if (v > big) { big = v; p = i; }
         }
-    double d = A[K * 6 + K];
+        p = __builtin_amdgcn_readfirstlane(p);
 #pragma unroll
-    for (int j = 0; j < K; ++j) d -= A[K * 6 + j] * A[K * 6 + j] * A[j * 6 + j];
-    A[K * 6 + K] = d;
-#pragma unroll
-    for (int i = K + 1; i < 6; ++i) {
-        double s = A[i * 6 + K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) s -= A[i * 6 + j] * A[K * 6 + j] * A[j * 6 + j];
-        A[i * 6 + K] = (d != 0.0) ? s / d : s;
+        for (int c = K + 1; c < 6; ++c)
+            if (p == c) {
+                asm volatile("; pivot swap" ::: "memory");
+                const double t = dg[K]; dg[K] = dg[c]; dg[c] = t;
+                const int ti = idx[K]; idx[K] = idx[c]; idx[c] = ti;
+            }
     }
-}
-
-__device__ __forceinline__ void kt_ldlt_solve6_reg(double (&A)[36], const double (&bin)[6], double (&x)[6])
-{
-    int tr[6];
-    kt_ldlt_step<0>(A, tr); kt_ldlt_step<1>(A, tr); kt_ldlt_step<2>(A, tr);
-    kt_ldlt_step<3>(A, tr); kt_ldlt_step<4>(A, tr); kt_ldlt_step<5>(A, tr);
+    // (2) permuted system A' = P A P^T (lower triangle), b' = P b
 #pragma unroll
-    for (int i = 0; i < 6; ++i) x[i] = bin[i];
+    for (int i = 0; i < 36; ++i) scratch[i] = Ain[i];
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
+    for (int i = 0; i < 6; ++i) scratch[36 + i] = bin[i];
+    double A[36];
 #pragma unroll
-        for (int c = k + 1; c < 6; ++c)
-            if (tr[k] == c) { const double t = x[k]; x[k] = x[c]; x[c] = t; }
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) A[i * 6 + j] = scratch[idx[i] * 6 + idx[j]];
+        x[i] = scratch[36 + idx[i]];
+    }
+    // (3) LDL^T without pivoting, forward / diagonal / backward substitution
+#pragma unroll
+    for (int K = 0; K < 6; ++K) {
+        double d = A[K * 6 + K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) d -= A[K * 6 + j] * A[K * 6 + j] * A[j * 6 + j];
+        A[K * 6 + K] = d;
+#pragma unroll
+        for (int i = K + 1; i < 6; ++i) {
+            double sacc = A[i * 6 + K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) sacc -= A[i * 6 + j] * A[K * 6 + j] * A[j * 6 + j];
+            A[i * 6 + K] = (d != 0.0) ? sacc / d : sacc;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -254,11 +262,11 @@ __device__ __forceinline__ void kt_ldlt_solve6_reg(double (&A)[36], const double
     for (int i = 5; i >= 0; --i)
 #pragma unroll
         for (int j = i + 1; j < 6; ++j) x[i] -= A[j * 6 + i] * x[j];
+    // (4) x = P^T x'
 #pragma unroll
-    for (int k = 5; k >= 0; --k)
+    for (int i = 0; i < 6; ++i) scratch[idx[i]] = x[i];
 #pragma unroll
-        for (int c = k + 1; c < 6; ++c)
-            if (tr[k] == c) { const double t = x[k]; x[k] = x[c]; x[c] = t; }
+    for (int i = 0; i < 6; ++i) x[i] = scratch[i];
 }
 
 // opt-in timing probes of the reduction tail (build with KT_EXTRA_FLAGS=-DKT_ICP_TIMING; scripts/icp_timing.py)
@@ -287,8 +295,9 @@ struct kt_pose_regs {
 // executed by ONE thread in the epilogue of the sweeping workgroup
 __device__ __forceinline__ void kt_solve_and_update(kt_track_state* st, kt_pose_regs& pr, double (&dA)[36], const double (&db)[6])
 {
+    __shared__ double solve_scratch[48];
     double x[6];
-    kt_ldlt_solve6_reg(dA, db, x);
+    kt_ldlt_solve6_hoisted(dA, db, x, solve_scratch);
     KT_TS(5);
     float Rcurr[9], tcurr[3];
     kt_pose_update(x, pr.resultRt, pr.Rprev, pr.tprev, Rcurr, tcurr);
