@@ -29,6 +29,8 @@ def parse():
     ap.add_argument("--unique-frames", type=int, default=120, help="frames rendered; the trajectory is played ping-pong beyond that")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-readahead", action="store_true", help="process frames strictly one at a time (no kt_tracker_prefetch_frame)")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="frames start in host memory (pinned staging copy + PCIe upload inside the timed region): the PCIe-inclusive rate, not the headline")
     ap.add_argument("--cpu-frames", type=int, default=6)
     return ap.parse_args()
 
@@ -87,7 +89,14 @@ def main():
     # frame's read-ahead is issued in the warm-up, the last timed frame issues one for a frame after the region: the counts balance).
     readahead = not args.no_readahead
 
+    host_frames = [(np.ascontiguousarray(dep, np.uint16), np.ascontiguousarray(rgb, np.uint8)) for (dep, rgb) in frames]
+
     def step(i, announce_next=True):
+        if args.host_frames:
+            if readahead and announce_next:
+                trk.prefetch_frame_host(*host_frames[pingpong(i + 1, nuniq)])
+            trk.process_frame_host(*host_frames[pingpong(i, nuniq)], 33333 * i)
+            return
         if readahead and announce_next:   # frame i + 1's read-ahead gets the whole of frame i's odometry chain to hide under
             nd, nr = dev_frames[pingpong(i + 1, nuniq)]
             trk.prefetch_frame(nd, nr)
@@ -188,7 +197,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {cam.cols}x{cam.rows} synthetic {cfg_name} sequence, {'ICP+RGB-D' if d['use_rgbd_icp'] else 'ICP-only'} tracking, "
-                               f"{N}^3 TSDF, inputs resident in HBM, 1 stream per GPU (BASELINE.json configs[1])"
+                               f"{N}^3 TSDF, " + ("inputs in HOST memory (PCIe-inclusive)" if args.host_frames else "inputs resident in HBM") + ", 1 stream per GPU (BASELINE.json configs[1])"
                                + (", log playback with 1 frame of read-ahead" if readahead else ", no read-ahead"),
                    "volume": N, "cols": cam.cols, "rows": cam.rows, "unique_frames": nuniq, "pose_err_m_at_end": pose_err,
                    "pose_gather_bytes": pose_bytes},

@@ -188,6 +188,10 @@ int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_dev, const uin
  * outstanding; handing a different frame to kt_tracker_process_frame first is legal but discards the read-ahead.  Best issued right
  * after the kt_tracker_process_frame call of the preceding frame.  Results are identical with and without it. */
 int kt_tracker_prefetch_frame(kt_tracker* t, const uint16_t* depth_dev, const uint8_t* rgb24_dev);
+/* the same for host-resident frames: pinned staging copy + upload + the pose-independent stages, all on the read-ahead stream.  A
+ * later kt_tracker_process_frame_host call with the SAME two host pointers consumes it, so outstanding frames need distinct host
+ * buffers (the contents are copied here and may change afterwards). */
+int kt_tracker_prefetch_frame_host(kt_tracker* t, const uint16_t* depth_host, const uint8_t* rgb24_host);
 /* TrackerInterface::process upload path (TrackerInterface.cpp:90-91): host frame -> device -> processFrame */
 int kt_tracker_process_frame_host(kt_tracker* t, const uint16_t* depth_host, const uint8_t* rgb24_host, uint64_t timestamp);
 int kt_tracker_finalise(kt_tracker* t);

@@ -128,6 +128,7 @@ _PROTOS = {
     "kt_debug_unpack_table": (_i, [_vp, _pf]),
     "kt_tracker_host_times": (_i, [_vp, _pd, _i]),
     "kt_tracker_prefetch_frame": (_i, [_vp, _vp, _vp]),
+    "kt_tracker_prefetch_frame_host": (_i, [_vp, _vp, _vp]),
     "kt_tracker_slice_pose": (_i, [_vp, _i, _pf, _pf, C.POINTER(_u64)]),
     "kt_tracker_set_parked": (_i, [_vp, _i]),
     "kt_host_ldlt_solve6": (_i, [_pd, _pd, _pd]),
@@ -369,6 +370,12 @@ class Tracker:
         d = depth_dev.ptr if isinstance(depth_dev, DevBuf) else int(depth_dev)
         r = rgb_dev.ptr if isinstance(rgb_dev, DevBuf) else int(rgb_dev)
         _chk(lib().kt_tracker_prefetch_frame(self.h, d, r))
+
+    def prefetch_frame_host(self, depth: np.ndarray, rgb: np.ndarray) -> None:
+        """Host-frame read-ahead: depth / rgb must be C-contiguous uint16 / uint8 arrays; pass the SAME array objects to
+        process_frame_host later (they are matched by address)."""
+        assert depth.dtype == np.uint16 and rgb.dtype == np.uint8 and depth.flags.c_contiguous and rgb.flags.c_contiguous
+        _chk(lib().kt_tracker_prefetch_frame_host(self.h, depth.ctypes.data, rgb.ctypes.data))
 
     def process_frame_host(self, depth: np.ndarray, rgb: np.ndarray, timestamp: int) -> None:
         depth = np.ascontiguousarray(depth, dtype=np.uint16)

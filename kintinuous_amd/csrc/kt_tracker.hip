@@ -48,7 +48,8 @@ struct PoseMirror {
     int skip, handoff_timeout;
     unsigned int seq;
 };
-struct Pending { const uint16_t* depth; const uint8_t* rgb; int set; };
+struct Pending { const uint16_t* depth; const uint8_t* rgb; int set; const uint16_t* depth_host; const uint8_t* rgb_host; };
+#define KT_NSLOTS 4   // host-frame staging: frame in flight + two read-aheads + the one being filled
 
 enum { ST_PYRAMID = 0, ST_ODOMETRY, ST_SHIFT, ST_INTEGRATE, ST_RAYCAST, ST_RESIZE, ST_TSDF23, ST_COUNT };
 
@@ -91,8 +92,11 @@ struct kt_tracker {
     // device-resident Gauss-Newton state + pinned mirror
     kt_track_state* state_dev; kt_track_state* state_host;
     // staging for the host-frame entry point
-    uint16_t* depth_stage; uint8_t* rgb_stage;
-    uint16_t* depth_stage_host; uint8_t* rgb_stage_host;  // pinned
+    // KT_NSLOTS rotating slots: pinned host copy + device copy of one frame, an event recorded after its upload
+    uint16_t* depth_stage[KT_NSLOTS]; uint8_t* rgb_stage[KT_NSLOTS];
+    uint16_t* depth_stage_host[KT_NSLOTS]; uint8_t* rgb_stage_host[KT_NSLOTS];  // pinned
+    hipEvent_t slot_uploaded[KT_NSLOTS];
+    int next_slot;
     // outputs
     std::vector<DensePose> poses;
     std::vector<Slice> slices;
@@ -340,10 +344,14 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
     KT_TRY(dev_alloc(&t->cloud_device, t->cloud_cap, false));
     KT_TRY(dev_alloc(&t->state_dev, 1, true));
     KT_HIP(hipHostMalloc((void**)&t->state_host, sizeof(kt_track_state), hipHostMallocDefault));
-    KT_TRY(dev_alloc(&t->depth_stage, P, true));
-    KT_TRY(dev_alloc(&t->rgb_stage, P * 3, true));
-    KT_HIP(hipHostMalloc((void**)&t->depth_stage_host, P * sizeof(uint16_t), hipHostMallocDefault));
-    KT_HIP(hipHostMalloc((void**)&t->rgb_stage_host, P * 3, hipHostMallocDefault));
+    for (int k = 0; k < KT_NSLOTS; ++k) {
+        KT_TRY(dev_alloc(&t->depth_stage[k], P, true));
+        KT_TRY(dev_alloc(&t->rgb_stage[k], P * 3, true));
+        KT_HIP(hipHostMalloc((void**)&t->depth_stage_host[k], P * sizeof(uint16_t), hipHostMallocDefault));
+        KT_HIP(hipHostMalloc((void**)&t->rgb_stage_host[k], P * 3, hipHostMallocDefault));
+        KT_HIP(hipEventCreateWithFlags(&t->slot_uploaded[k], hipEventDisableTiming));
+    }
+    t->next_slot = 0;
     KT_TRY(dev_alloc(&t->upd_dev, 16, true));
     KT_TRY(dev_alloc(&t->steps_dev, 2, true));
     t->profiling = 0;
@@ -392,8 +400,11 @@ int kt_tracker_destroy(kt_tracker* t)
     (void)hipStreamDestroy(t->pre_stream);
     (void)hipFree(t->vmap_curr_color); (void)hipFree(t->cloud_device);
     (void)hipFree(t->state_dev); (void)hipHostFree(t->state_host);
-    (void)hipFree(t->depth_stage); (void)hipFree(t->rgb_stage);
-    (void)hipHostFree(t->depth_stage_host); (void)hipHostFree(t->rgb_stage_host);
+    for (int k = 0; k < KT_NSLOTS; ++k) {
+        (void)hipFree(t->depth_stage[k]); (void)hipFree(t->rgb_stage[k]);
+        (void)hipHostFree(t->depth_stage_host[k]); (void)hipHostFree(t->rgb_stage_host[k]);
+        (void)hipEventDestroy(t->slot_uploaded[k]);
+    }
     (void)hipFree(t->upd_dev); (void)hipFree(t->steps_dev);
     for (int par = 0; par < 2; ++par)
         for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(t->ev[par][s][0]); (void)hipEventDestroy(t->ev[par][s][1]); }
@@ -915,9 +926,42 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     return KT_OK;
 }
 
+static int prefetch_impl(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors, const uint16_t* depth_host, const uint8_t* rgb_host);
+
 int kt_tracker_prefetch_frame(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors)
 {
     KT_ARG(t && depth_raw && colors);
+    return prefetch_impl(t, depth_raw, colors, nullptr, nullptr);
+}
+
+// stage a host frame into the next slot: pinned copy, then the upload on `stream`
+static int stage_host_frame(kt_tracker* t, hipStream_t stream, const uint16_t* depth_host, const uint8_t* rgb_host, int* slot_out)
+{
+    const size_t P = (size_t)t->cfg.cols * t->cfg.rows;
+    const int slot = t->next_slot;
+    t->next_slot = (t->next_slot + 1) % KT_NSLOTS;
+    KT_HIP(hipEventSynchronize(t->slot_uploaded[slot]));   // the pinned copy of the frame that used this slot 4 frames ago has left
+    memcpy(t->depth_stage_host[slot], depth_host, P * sizeof(uint16_t));
+    memcpy(t->rgb_stage_host[slot], rgb_host, P * 3);
+    KT_HIP(hipMemcpyAsync(t->depth_stage[slot], t->depth_stage_host[slot], P * sizeof(uint16_t), hipMemcpyHostToDevice, stream));
+    KT_HIP(hipMemcpyAsync(t->rgb_stage[slot], t->rgb_stage_host[slot], P * 3, hipMemcpyHostToDevice, stream));
+    KT_HIP(hipEventRecord(t->slot_uploaded[slot], stream));
+    *slot_out = slot;
+    return KT_OK;
+}
+
+int kt_tracker_prefetch_frame_host(kt_tracker* t, const uint16_t* depth_host, const uint8_t* rgb_host)
+{
+    KT_ARG(t && depth_host && rgb_host);
+    if (t->pending.size() >= 2) { kt_set_error("kt_tracker_prefetch_frame_host: two read-ahead frames are already outstanding"); return KT_ERR_STATE; }
+    KT_TRY(complete_frame(t));
+    int slot;
+    KT_TRY(stage_host_frame(t, t->pre_stream, depth_host, rgb_host, &slot));   // the upload rides the read-ahead stream too
+    return prefetch_impl(t, t->depth_stage[slot], t->rgb_stage[slot], depth_host, rgb_host);
+}
+
+static int prefetch_impl(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors, const uint16_t* depth_host, const uint8_t* rgb_host)
+{
     if (t->pending.size() >= 2) { kt_set_error("kt_tracker_prefetch_frame: two read-ahead frames are already outstanding"); return KT_ERR_STATE; }
     // Observe the pose of the frame in flight first (the next kt_tracker_process_frame call would wait for it anyway).  After that,
     // with F = frames handed over so far, everything enqueued before the end of odometry(F - 1) has retired: fusion(F - 2) and the
@@ -935,7 +979,7 @@ int kt_tracker_prefetch_frame(kt_tracker* t, const uint16_t* depth_raw, const ui
     t->pre_ctx.device = t->ctx->device;
     KT_TRY(build_frame_set(t, &t->pre_ctx, set, depth_raw, colors));
     KT_HIP(hipEventRecord(t->sets[set].ready, t->pre_stream));
-    t->pending.push_back(Pending{depth_raw, colors, set});
+    t->pending.push_back(Pending{depth_raw, colors, set, depth_host, rgb_host});
     return KT_OK;
 }
 
@@ -943,14 +987,12 @@ int kt_tracker_process_frame_host(kt_tracker* t, const uint16_t* depth_host, con
 {
     // TrackerInterface::process upload, TrackerInterface.cpp:90-91 (pinned staging + async copies instead of blocking cudaMemcpy2D)
     KT_ARG(t && depth_host && rgb_host);
+    for (const Pending& p : t->pending)   // announced with kt_tracker_prefetch_frame_host: already on the device
+        if (p.depth_host == depth_host && p.rgb_host == rgb_host) return kt_tracker_process_frame(t, p.depth, p.rgb, timestamp);
     KT_TRY(complete_frame(t));
-    const size_t P = (size_t)t->cfg.cols * t->cfg.rows;
-    KT_HIP(hipStreamSynchronize(t->ctx->stream));  // staging buffers are reused
-    memcpy(t->depth_stage_host, depth_host, P * sizeof(uint16_t));
-    memcpy(t->rgb_stage_host, rgb_host, P * 3);
-    KT_HIP(hipMemcpyAsync(t->depth_stage, t->depth_stage_host, P * sizeof(uint16_t), hipMemcpyHostToDevice, t->ctx->stream));
-    KT_HIP(hipMemcpyAsync(t->rgb_stage, t->rgb_stage_host, P * 3, hipMemcpyHostToDevice, t->ctx->stream));
-    return kt_tracker_process_frame(t, t->depth_stage, t->rgb_stage, timestamp);
+    int slot;
+    KT_TRY(stage_host_frame(t, t->ctx->stream, depth_host, rgb_host, &slot));
+    return kt_tracker_process_frame(t, t->depth_stage[slot], t->rgb_stage[slot], timestamp);
 }
 
 int kt_tracker_finalise(kt_tracker* t)

@@ -105,6 +105,25 @@ class KintinuousTracker {
         if (global_time_ > 1 && ConfigArgs::get().saveFile.size()) outputPose(timestamp, lastRotation);
     }
 
+    // Host-resident frames with read-ahead (device-resident path only): announceFrame() stages a frame that a LATER processFrameHost()
+    // call with the same two pointers will consume -- its upload and pose-independent stages overlap the frames before it.
+    void announceFrame(const unsigned short* depthData, const unsigned char* rgbImage)
+    {
+        if (operatorPath) return;
+        ensureFast();
+        ktSafeCall(kt_tracker_prefetch_frame_host(fast, depthData, rgbImage));
+    }
+    void processFrameHost(unsigned short* depthData, unsigned char* rgbImage, uint64_t timestamp)
+    {
+        lastRgbImage = rgbImage;
+        lastDepthData = depthData;
+        current_utime = timestamp;
+        ensureFast();
+        ktSafeCall(kt_tracker_process_frame_host(fast, depthData, rgbImage, timestamp));
+        syncFromFast();
+        if (global_time_ > 1 && ConfigArgs::get().saveFile.size()) outputPose(timestamp, lastRotation);
+    }
+
     kt::Vector3f getVolumeOffset() const { return volumeBasisValue(); }
     void setParked(const bool park)
     {

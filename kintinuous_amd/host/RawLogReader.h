@@ -33,10 +33,13 @@ class RawLogReader : public LogReader {
         fp = std::fopen(file.c_str(), "rb");
         if (!fp) { std::fprintf(stderr, "cannot open log %s\n", file.c_str()); std::exit(1); }
         const int n = Resolution::get().numPixels();
-        depthBuffer.resize(n);
-        imageBuffer.resize((size_t)n * 3);
-        decompressedDepth = depthBuffer.data();
-        decompressedImage = imageBuffer.data();
+        for (int k = 0; k < kBuffers; ++k) {
+            depthBuffers[k].resize(n);
+            imageBuffers[k].resize((size_t)n * 3);
+        }
+        flip = 0;
+        decompressedDepth = depthBuffers[0].data();
+        decompressedImage = imageBuffers[0].data();
         int32_t frames = 0;
         if (std::fread(&frames, sizeof(int32_t), 1, fp) != 1) frames = 0;
         numFrames = frames;
@@ -50,6 +53,12 @@ class RawLogReader : public LogReader {
     {
         if (!hasMore()) { returnVal = false; return false; }
         const size_t n = (size_t)Resolution::get().numPixels();
+        // rotating frame buffers: the tracker's read-ahead keeps up to two earlier frames alive by address
+        flip = (flip + 1) % kBuffers;
+        std::vector<unsigned short>& depthBuffer = depthBuffers[flip];
+        std::vector<unsigned char>& imageBuffer = imageBuffers[flip];
+        decompressedDepth = depthBuffer.data();
+        decompressedImage = imageBuffer.data();
         int32_t depthSize = 0, imageSize = 0;
         if (std::fread(&timestamp, sizeof(int64_t), 1, fp) != 1 || std::fread(&depthSize, sizeof(int32_t), 1, fp) != 1 ||
             std::fread(&imageSize, sizeof(int32_t), 1, fp) != 1) { returnVal = false; return false; }
@@ -82,6 +91,8 @@ class RawLogReader : public LogReader {
   private:
     FILE* fp;
     int numFrames, currentFrame;
-    std::vector<unsigned short> depthBuffer;
-    std::vector<unsigned char> imageBuffer, scratch;
+    static const int kBuffers = 4;
+    int flip;
+    std::vector<unsigned short> depthBuffers[kBuffers];
+    std::vector<unsigned char> imageBuffers[kBuffers], scratch;
 };

@@ -9,7 +9,8 @@
 class TrackerInterface {
   public:
     TrackerInterface(LogReader* logRead, const Intr& depthIntrinsics, bool operatorPath = false)
-        : logRead(logRead), currentFrame(0), firstRun(true)
+        : logRead(logRead), currentFrame(0), firstRun(true), operatorPath(operatorPath), primed(false), haveNext(false), nextDepth(0),
+          nextImage(0), nextTime(0)
     {
         kt::device::context(ConfigArgs::get().gpu);  // cudaSetDevice(ConfigArgs::get().gpu), TrackerInterface.cpp:48
         frontend = new KintinuousTracker(depthIntrinsics, operatorPath);
@@ -17,27 +18,45 @@ class TrackerInterface {
     }
     virtual ~TrackerInterface() { delete frontend; }
 
-    void reset() { currentFrame = 0; frontend->reset(); }
+    void reset() { currentFrame = 0; primed = false; haveNext = false; frontend->reset(); }
     KintinuousTracker* getFrontend() { return frontend; }
     void finalise() { frontend->finalise(); }
     void setPark(const bool park) { frontend->setParked(park); }
     void enableOverlap() { frontend->setOverlap(2); }
     int getCurrentFrame() const { return currentFrame; }
 
-    // one iteration of TrackerInterface::process(): false once the log is exhausted (after finalise())
+    // one iteration of TrackerInterface::process(): false once the log is exhausted (after finalise()).  On the device-resident
+    // path the log is read one frame ahead: frame k + 1 is announced (pinned copy, upload, pose-independent stages on the tracker's
+    // second stream) before frame k is tracked.
     bool process()
     {
         bool returnVal = true;
-        if (!logRead->grabNext(returnVal, currentFrame)) {
-            finalise();
-            return false;
+        if (operatorPath) {
+            if (!logRead->grabNext(returnVal, currentFrame)) { finalise(); return false; }
+            ++currentFrame;
+            const int rows = Resolution::get().rows(), cols = Resolution::get().cols();
+            depth_device.upload(logRead->decompressedDepth, (size_t)cols * 2, rows, cols);
+            colors_device.upload(logRead->decompressedImage, (size_t)cols * 3, rows, cols);
+            frontend->processFrame(depth_device, colors_device, logRead->decompressedImage, logRead->decompressedDepth,
+                                   (uint64_t)logRead->timestamp, logRead->isCompressed);
+            return true;
+        }
+        if (!primed) {
+            primed = true;
+            haveNext = logRead->grabNext(returnVal, currentFrame);
+            if (haveNext) { nextDepth = logRead->decompressedDepth; nextImage = logRead->decompressedImage; nextTime = (uint64_t)logRead->timestamp; }
+        }
+        if (!haveNext) { finalise(); return false; }
+        unsigned short* depth = nextDepth;
+        unsigned char* image = nextImage;
+        const uint64_t time = nextTime;
+        haveNext = logRead->grabNext(returnVal, currentFrame);   // the reader rotates its frame buffers: `depth` / `image` stay valid
+        if (haveNext) {
+            nextDepth = logRead->decompressedDepth; nextImage = logRead->decompressedImage; nextTime = (uint64_t)logRead->timestamp;
+            frontend->announceFrame(nextDepth, nextImage);
         }
         ++currentFrame;
-        const int rows = Resolution::get().rows(), cols = Resolution::get().cols();
-        depth_device.upload(logRead->decompressedDepth, (size_t)cols * 2, rows, cols);
-        colors_device.upload(logRead->decompressedImage, (size_t)cols * 3, rows, cols);
-        frontend->processFrame(depth_device, colors_device, logRead->decompressedImage, logRead->decompressedDepth, (uint64_t)logRead->timestamp,
-                               logRead->isCompressed);
+        frontend->processFrameHost(depth, image, time);
         return true;
     }
 
@@ -47,5 +66,8 @@ class TrackerInterface {
     DeviceArray2D<unsigned short> depth_device;
     DeviceArray2D<PixelRGB> colors_device;
     int currentFrame;
-    bool firstRun;
+    bool firstRun, operatorPath, primed, haveNext;
+    unsigned short* nextDepth;
+    unsigned char* nextImage;
+    uint64_t nextTime;
 };

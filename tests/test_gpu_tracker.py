@@ -161,7 +161,7 @@ def test_readahead_is_transparent(ctx, small_scene, rgbd_icp):
     with host-frame calls."""
     from kintinuous_amd import abi
     cam, frames, _ = small_scene
-    frames = frames[:8]
+    frames = [(np.ascontiguousarray(d, np.uint16), np.ascontiguousarray(rgb, np.uint8)) for d, rgb in frames[:8]]
     dev = [(ctx.upload(d), ctx.upload(rgb)) for d, rgb in frames]
     g, _ = _cfgs(cam, 96, use_rgbd_icp=rgbd_icp)   # the RGB-D inputs ride in the frame sets too
 
@@ -179,7 +179,13 @@ def test_readahead_is_transparent(ctx, small_scene, rgbd_icp):
                         trk.prefetch_frame(*dev[7])        # a third is refused
                 elif k == 7:
                     trk.prefetch_frame(*dev[1])            # never consumed
-            if mode == "chaos" and k == 3:
+            if mode == "host_ahead":
+                if k + 1 < len(frames):
+                    trk.prefetch_frame_host(frames[k + 1][0], frames[k + 1][1])   # upload + pose-independent stages on the read-ahead stream
+                trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
+            elif mode == "host":
+                trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
+            elif mode == "chaos" and k == 3:
                 trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
             else:
                 trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
@@ -191,7 +197,7 @@ def test_readahead_is_transparent(ctx, small_scene, rgbd_icp):
         return out
 
     ref = run("plain")
-    for mode in ("ahead", "late", "chaos"):
+    for mode in ("ahead", "late", "chaos", "host", "host_ahead"):
         got = run(mode)
         assert len(got[0]) == len(ref[0])
         for a, b in zip(got[0], ref[0]):
