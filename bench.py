@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--no-readahead", action="store_true", help="process frames strictly one at a time (no kt_tracker_prefetch_frame)")
     ap.add_argument("--host-frames", action="store_true",
                     help="frames start in host memory (pinned staging copy + PCIe upload inside the timed region): the PCIe-inclusive rate, not the headline")
-    ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--cpu-frames", type=int, default=31, help="frames of the CPU baseline sample (about 3 s wall = 100 core-seconds on 32 threads)")
     return ap.parse_args()
 
 
