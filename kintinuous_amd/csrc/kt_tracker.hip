@@ -269,13 +269,28 @@ static void ev_collect(kt_tracker* t)
 
 extern "C" {
 
+static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_config* cfg);
+
 int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** out)
 {
     KT_ARG(ctx && cfg && out);
     KT_ARG(cfg->cols > 0 && cfg->rows > 0 && cfg->N > 0 && cfg->volume_size > 0);
     KT_ARG((cfg->cols % 8) == 0 && (cfg->rows % 8) == 0);  // 4 pyramid levels
+    KT_ARG(cfg->N <= 1536);                                 // 32-bit voxel offsets (kt_volume.hip)
     KT_HIP(hipSetDevice(ctx->device));
-    kt_tracker* t = new kt_tracker();
+    kt_tracker* t = new kt_tracker();   // value-initialised: every pointer starts null, so a failed create can be destroyed
+    const int s = tracker_create_impl(t, ctx, cfg);
+    if (s != KT_OK) {
+        t->ctx = ctx;
+        (void)kt_tracker_destroy(t);   // kt_last_error() keeps the message of the failure
+        return s;
+    }
+    *out = t;
+    return KT_OK;
+}
+
+static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_config* cfg)
+{
     t->ctx = ctx;
     g_alloc_stream = ctx->stream;
     t->cfg = *cfg;
@@ -372,9 +387,7 @@ int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** ou
     memset(t->mirror, 0, sizeof(PoseMirror));
     t->frame_seq = 0;
     t->prof_frames = 0;
-    KT_TRY(kt_tracker_reset(t));
-    *out = t;
-    return KT_OK;
+    return kt_tracker_reset(t);
 }
 
 int kt_tracker_destroy(kt_tracker* t)
@@ -391,23 +404,26 @@ int kt_tracker_destroy(kt_tracker* t)
         }
         (void)hipFree(t->corres[l]);
     }
-    (void)hipStreamSynchronize(t->pre_stream);
+    if (t->pre_stream) (void)hipStreamSynchronize(t->pre_stream);
     for (int q = 0; q < KT_NSETS; ++q) {
         (void)hipFree(t->sets[q].scaled); (void)hipFree(t->sets[q].rec); (void)hipFree(t->sets[q].dpmax);
-        (void)hipEventDestroy(t->sets[q].ready);
+        if (t->sets[q].ready) (void)hipEventDestroy(t->sets[q].ready);
     }
-    (void)hipEventDestroy(t->guard_ev);
-    (void)hipStreamDestroy(t->pre_stream);
+    if (t->guard_ev) (void)hipEventDestroy(t->guard_ev);
+    if (t->pre_stream) (void)hipStreamDestroy(t->pre_stream);
     (void)hipFree(t->vmap_curr_color); (void)hipFree(t->cloud_device);
     (void)hipFree(t->state_dev); (void)hipHostFree(t->state_host);
     for (int k = 0; k < KT_NSLOTS; ++k) {
         (void)hipFree(t->depth_stage[k]); (void)hipFree(t->rgb_stage[k]);
         (void)hipHostFree(t->depth_stage_host[k]); (void)hipHostFree(t->rgb_stage_host[k]);
-        (void)hipEventDestroy(t->slot_uploaded[k]);
+        if (t->slot_uploaded[k]) (void)hipEventDestroy(t->slot_uploaded[k]);
     }
     (void)hipFree(t->upd_dev); (void)hipFree(t->steps_dev);
     for (int par = 0; par < 2; ++par)
-        for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(t->ev[par][s][0]); (void)hipEventDestroy(t->ev[par][s][1]); }
+        for (int s = 0; s < ST_COUNT; ++s) {
+            if (t->ev[par][s][0]) (void)hipEventDestroy(t->ev[par][s][0]);
+            if (t->ev[par][s][1]) (void)hipEventDestroy(t->ev[par][s][1]);
+        }
     (void)hipHostFree(t->mirror);
     (void)hipFree(t->fp_dev);
     (void)hipFree(t->bricks);

@@ -205,3 +205,23 @@ def test_readahead_is_transparent(ctx, small_scene, rgbd_icp):
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), mode
         for a, b in zip(got[3], ref[3]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mode
+
+
+def test_errors_are_reported_not_swallowed(ctx, small_scene):
+    """The C-ABI fails loudly: bad configurations and bad calls return a status with a message (the ctypes binding raises)."""
+    from kintinuous_amd import abi
+    cam, frames, _ = small_scene
+    d = dict(volume_size=6.0, voxel_shift=14, overlap=2, static_mode=0, use_rgbd=0, use_rgbd_icp=0, fast_odometry=0, disable_color_angle=0)
+    mk = lambda cols, rows, N, size: abi.TrackerConfig(cols, rows, N, cam.fx, cam.fy, cam.cx, cam.cy, size, 14, 2, 0, 0, 0, 0, 0, 0)
+    for bad in (mk(100, 120, 64, 6.0), mk(160, 120, 0, 6.0), mk(160, 120, 64, -1.0), mk(160, 120, 4096, 6.0)):
+        with pytest.raises(abi.KtError) as e:
+            abi.Tracker(ctx, bad)
+        assert "bad argument" in str(e.value)
+    trk = abi.Tracker(ctx, mk(cam.cols, cam.rows, 64, 6.0))
+    with pytest.raises(abi.KtError):
+        trk.process_frame(0, 0, 0)                      # null device pointers
+    with pytest.raises(abi.KtError):
+        trk.dense_pose(5)                               # no such pose yet
+    trk.process_frame_host(frames[0][0], frames[0][1], 0)
+    assert trk.num_poses() == 1
+    trk.close()
