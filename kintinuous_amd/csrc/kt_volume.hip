@@ -917,7 +917,7 @@ __device__ __forceinline__ void kt_tile_resize(const float* __restrict__ src, fl
     }
 }
 
-#define KT_RC_BATCH 8
+#define KT_RC_BATCH 4
 #define KT_RC_MAX_BRICKS 32768   // brick flags staged in LDS (N <= 1024)
 
 // Empty-space skipping (SKIP).  The march only ever reacts to a sign change between two consecutive samples (+ -> - is the hit,
