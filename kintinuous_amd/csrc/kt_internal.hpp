@@ -13,6 +13,7 @@ struct kt_frame_params {
 };
 
 int kt_bilateral_lut_ensure(kt_ctx* c);
+size_t kt_brick_count(int N);   // flags of the raycast's empty-space bricks for an N^3 volume
 
 int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
                            const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,

@@ -381,7 +381,7 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     t->outstanding = false;
     t->host_wait_s = t->host_call_s = 0.0; t->host_calls = 0;
     KT_TRY(dev_alloc(&t->fp_dev, 1, true));
-    { const int nb = kt_div_up(cfg->N, 32); KT_TRY(dev_alloc(&t->bricks, (size_t)nb * nb * nb + 16, true)); }
+    KT_TRY(dev_alloc(&t->bricks, kt_brick_count(cfg->N) + 16, true));
     KT_TRY(kt_integrate_tables(ctx, cfg->cols, cfg->rows, cfg->N, &t->vgz_dev, &t->zs_dev));
     KT_HIP(hipHostMalloc((void**)&t->mirror, sizeof(PoseMirror), hipHostMallocMapped | hipHostMallocCoherent));
     memset(t->mirror, 0, sizeof(PoseMirror));
@@ -450,7 +450,7 @@ int kt_tracker_reset(kt_tracker* t)
     t->parked = t->cfg.static_mode != 0;
     KT_TRY(kt_init_volume(t->ctx, t->tsdf, t->N));
     KT_TRY(kt_init_color_volume(t->ctx, t->color, t->N));
-    { const int nb = kt_div_up(t->N, 32); KT_HIP(hipMemsetAsync(t->bricks, 0, (size_t)nb * nb * nb, t->ctx->stream)); }
+    KT_HIP(hipMemsetAsync(t->bricks, 0, kt_brick_count(t->N), t->ctx->stream));
     memset(t->stage_ms_sum, 0, sizeof(t->stage_ms_sum));
     memset(t->stage_n, 0, sizeof(t->stage_n));
     memset(t->stage_ms_last, 0, sizeof(t->stage_ms_last));

@@ -36,6 +36,11 @@ extern "C" int kt_init_color_volume(kt_ctx* c, uint8_t* cv, int N)
 // (scaled depth with the no-colour sign flag, the colour weight derived from |n_z|, rgb, normal-valid)
 // packed into ONE 16-byte gather instead of 8 scalar gathers.  All fields are computed with exactly
 // the reference's expressions, only earlier.
+// edge of the bricks whose "holds a negative tsdf" flags steer the raycast's empty-space hops (kt_raycast_kernel)
+#define KT_BRICK_LOG2 5   // 32^3: 16^3 costs 32 KB of LDS staging and twice the hops (97 us), 64^3 leaves a thicker flagged shell (68 us vs 66)
+#define KT_BRICK (1 << KT_BRICK_LOG2)
+size_t kt_brick_count(int N) { const size_t nb = (size_t)(N + KT_BRICK - 1) / KT_BRICK; return nb * nb * nb; }
+
 struct __attribute__((aligned(16))) kt_pixrec {
     float dp;        // scaleDepth output (negative = "no colour", tsdf_volume.cu:520-527)
     float wrkc;      // (angleColor ? min(1, |n_z| / 0.75) : 1) * 2       tsdf_volume.cu:625
@@ -389,7 +394,7 @@ __device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, kt_tsdf_b
         const int pix = b.in_img[u] ? coo_y * a.cols + coo_x : 0;
         int sz = zz + a.wz; if (sz >= N) sz -= N;
         b.off[u] = col_base + (unsigned int)sz * plane;
-        b.bz[u] = (sz >> 5) * a.nb * a.nb;
+        b.bz[u] = (sz >> KT_BRICK_LOG2) * a.nb * a.nb;
         b.rec[u] = a.rec[pix];
         v_x += dvx;  // the walk advances on every step, also on skipped ones
         v_y += dvy;
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
             for (; z < wz0; ++z) { v_x += dvx; v_y += dvy; }
         }
         const unsigned int col_base = (unsigned int)min(sx, N - 1) + (unsigned int)sy * (unsigned int)N;
-        const int brick_xy = (sy >> 5) * a.nb + (min(sx, N - 1) >> 5);
+        const int brick_xy = (sy >> KT_BRICK_LOG2) * a.nb + (min(sx, N - 1) >> KT_BRICK_LOG2);
         // the chunk's slice of the z-walk tables, one entry per lane (KT_TSDF_ZCHUNK + KT_TSDF_UNROLL <= 64 == wave size)
         const int tab_base = chunk * KT_TSDF_ZCHUNK;
         const float tab_vgz = a.vgz[min(tab_base + lane, N - 1)];
@@ -661,8 +666,8 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     a.zs = c->integ->zs;
     a.updated = updated_dev;
     a.fp = fp;
-    a.nb = N / 32;
-    a.bricks = (bricks && (N % 32) == 0) ? bricks : nullptr;
+    a.nb = N / KT_BRICK;
+    a.bricks = (bricks && (N % KT_BRICK) == 0) ? bricks : nullptr;
     a.Ri = *Rcurr_inv;
     a.tx = tcurr[0]; a.ty = tcurr[1]; a.tz = tcurr[2];
     a.intr = *intr;
@@ -997,8 +1002,9 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
             // SKIP state: tsdf_known == false means "the previous sample was skipped: its value is >= 0 but not loaded"
             bool tsdf_known = true;
             const float fN = (float)N, eps_v = 0.01f;
-            const float rwx = (float)(a.wx & 31), rwy = (float)(a.wy & 31), rwz = (float)(a.wz & 31);
-            const int awx = a.wx >> 5, awy = a.wy >> 5, awz = a.wz >> 5;
+            const float rwx = (float)(a.wx & (KT_BRICK - 1)), rwy = (float)(a.wy & (KT_BRICK - 1)), rwz = (float)(a.wz & (KT_BRICK - 1));
+            const int awx = a.wx >> KT_BRICK_LOG2, awy = a.wy >> KT_BRICK_LOG2, awz = a.wz >> KT_BRICK_LOG2;
+            const float fB = (float)KT_BRICK, rB = 1.0f / (float)KT_BRICK;
             // voxels per unit of ray time along each axis, and its inverse (geometry only: the margins absorb their rounding)
             const float vdx = rd.x * rcx, vdy = rd.y * rcy, vdz = rd.z * rcz;
             const float ivx = __builtin_amdgcn_rcpf(vdx), ivy = __builtin_amdgcn_rcpf(vdy), ivz = __builtin_amdgcn_rcpf(vdz);
@@ -1009,11 +1015,11 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
                     const float qx = __builtin_fmaf(rd.x, tn, rs.x) * rcx, qy = __builtin_fmaf(rd.y, tn, rs.y) * rcy,
                                 qz = __builtin_fmaf(rd.z, tn, rs.z) * rcz;
                     // cell of the storage-brick grid seen from logical coordinates: faces at 32 c - (wrap & 31)
-                    const float cx = __builtin_floorf((qx + rwx) * 0.03125f), cy = __builtin_floorf((qy + rwy) * 0.03125f),
-                                cz = __builtin_floorf((qz + rwz) * 0.03125f);
-                    const float lox = fmaxf(__builtin_fmaf(cx, 32.0f, -rwx), 0.0f) + eps_v, hix = fminf(__builtin_fmaf(cx, 32.0f, 32.0f - rwx), fN) - eps_v;
-                    const float loy = fmaxf(__builtin_fmaf(cy, 32.0f, -rwy), 0.0f) + eps_v, hiy = fminf(__builtin_fmaf(cy, 32.0f, 32.0f - rwy), fN) - eps_v;
-                    const float loz = fmaxf(__builtin_fmaf(cz, 32.0f, -rwz), 0.0f) + eps_v, hiz = fminf(__builtin_fmaf(cz, 32.0f, 32.0f - rwz), fN) - eps_v;
+                    const float cx = __builtin_floorf((qx + rwx) * rB), cy = __builtin_floorf((qy + rwy) * rB),
+                                cz = __builtin_floorf((qz + rwz) * rB);
+                    const float lox = fmaxf(__builtin_fmaf(cx, fB, -rwx), 0.0f) + eps_v, hix = fminf(__builtin_fmaf(cx, fB, fB - rwx), fN) - eps_v;
+                    const float loy = fmaxf(__builtin_fmaf(cy, fB, -rwy), 0.0f) + eps_v, hiy = fminf(__builtin_fmaf(cy, fB, fB - rwy), fN) - eps_v;
+                    const float loz = fmaxf(__builtin_fmaf(cz, fB, -rwz), 0.0f) + eps_v, hiz = fminf(__builtin_fmaf(cz, fB, fB - rwz), fN) - eps_v;
                     const bool inside = qx > lox && qx < hix && qy > loy && qy < hiy && qz > loz && qz < hiz;
                     bool canhop = false;
                     float dt = 0.f;
@@ -1213,8 +1219,8 @@ int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const
     for (int k = 0; k < 3; ++k) { a.vpyr[k] = pyr ? vpyr[k] : nullptr; a.npyr[k] = pyr ? npyr[k] : nullptr; }
     if (pyr) KT_ARG((cols % 8) == 0 && (rows % 8) == 0);
     dim3 b(256), g(kt_div_up(cols, 16), kt_div_up(rows, 16));
-    a.nb = N / 32;
-    const bool skip = bricks && (N % 32) == 0 && a.nb * a.nb * a.nb <= KT_RC_MAX_BRICKS;
+    a.nb = N / KT_BRICK;
+    const bool skip = bricks && (N % KT_BRICK) == 0 && a.nb * a.nb * a.nb <= KT_RC_MAX_BRICKS;
     a.bricks = skip ? bricks : nullptr;
     const size_t lds = skip ? (size_t)((a.nb * a.nb * a.nb + 15) & ~15) : 0;
 #define KT_RC_LAUNCH(C, P, S) hipLaunchKernelGGL((kt_raycast_kernel<C, P, S>), g, b, lds, c->stream, a)
