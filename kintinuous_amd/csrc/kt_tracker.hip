@@ -368,7 +368,7 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     }
     t->next_slot = 0;
     KT_TRY(dev_alloc(&t->upd_dev, 16, true));
-    KT_TRY(dev_alloc(&t->steps_dev, 2, true));
+    KT_TRY(dev_alloc(&t->steps_dev, 4, true));
     t->profiling = 0;
     t->counting = 0;
     for (int par = 0; par < 2; ++par)
@@ -671,7 +671,7 @@ static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, con
     const float dummy_t[3] = {0, 0, 0};
     if (t->counting) {
         KT_HIP(hipMemsetAsync(t->upd_dev, 0, 16 * sizeof(unsigned int), c->stream));
-        KT_HIP(hipMemsetAsync(t->steps_dev, 0, 2 * sizeof(unsigned long long), c->stream));
+        KT_HIP(hipMemsetAsync(t->steps_dev, 0, 4 * sizeof(unsigned long long), c->stream));
     }
     KT_TRY(ev_begin(t, ST_INTEGRATE));
     tsdf23_hook_arm(t);
@@ -1134,7 +1134,7 @@ int kt_tracker_debug_counts(kt_tracker* t, unsigned int* out4)
 {
     KT_ARG(t && out4);
     KT_HIP(hipMemcpy(out4, t->upd_dev, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost));
-    { unsigned long long h = 0; KT_HIP(hipMemcpy(&h, t->steps_dev + 1, sizeof(h), hipMemcpyDeviceToHost)); out4[7] = (unsigned int)h; }
+    { unsigned long long h[3] = {0, 0, 0}; KT_HIP(hipMemcpy(h, t->steps_dev + 1, sizeof(h), hipMemcpyDeviceToHost)); out4[7] = (unsigned int)h[0]; out4[5] = (unsigned int)h[1]; out4[6] = (unsigned int)h[2]; }
     return KT_OK;
 }
 int kt_tracker_last_counts(kt_tracker* t, unsigned long long* U, unsigned long long* S)

@@ -957,7 +957,7 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
     const bool in_image = x < a.cols && y < a.rows;
     const kt_rc rc{a, 1.0f / a.cx_, 1.0f / a.cy_, 1.0f / a.cz_};
     const int cols = a.cols, rows = a.rows, N = a.N;
-    unsigned int steps = 0, hopped = 0;
+    unsigned int steps = 0, hopped = 0, n_hop_iters = 0, n_batch_iters = 0;
 
     float out_vx = kt_nan(), out_nx = kt_nan();
     bool hit = false, has_normal = false;
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
                         K = min(K, 64);   // a 32^3 brick holds at most ~14 samples; the bound keeps the replayed adds' drift << the margin
                         const int kmax = kt_wave_max(K);
                         for (int i = 0; i < kmax; ++i) time_curr = (i < K) ? time_curr + a.time_step : time_curr;
-                        if (COUNT) { steps += (unsigned int)K; hopped += (unsigned int)K; }
+                        if (COUNT) { steps += (unsigned int)K; hopped += (unsigned int)K; if (lane == 0) ++n_hop_iters; }
                         tsdf_known = tsdf_known && K == 0;
                         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
                         continue;
@@ -1054,6 +1054,7 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
                     }
                     tsdf_known = true;
                 }
+                if (COUNT && lane == 0) ++n_batch_iters;
                 float tc[KT_RC_BATCH];
                 unsigned int gi[KT_RC_BATCH];
                 bool inb[KT_RC_BATCH];
@@ -1154,6 +1155,7 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
         for (int off = 32; off > 0; off >>= 1) { steps += __shfl_down(steps, off, 64); hopped += __shfl_down(hopped, off, 64); }
         if (lane == 0 && steps) atomicAdd(a.steps, (unsigned long long)steps);
         if (lane == 0 && hopped) atomicAdd(a.steps + 1, (unsigned long long)hopped);  // diagnostics: samples replaced by brick hops
+        if (lane == 0) { atomicAdd(a.steps + 2, (unsigned long long)n_hop_iters); atomicAdd(a.steps + 3, (unsigned long long)n_batch_iters); }
     }
     if (PYR) {
         // fused resizeVMap / resizeNMap for levels 1..3 of this 16x16 tile (KintinuousTracker.cpp:892-899): 8x8, 4x4, 2x2

@@ -12,4 +12,4 @@ for k, (d, rgb) in enumerate(frames):
     trk.process_frame_host(d, rgb, k)
     U, S = trk.last_counts()
     dc = trk.debug_counts()
-    print(k, "U", U, "S", S, "hopped", dc[7], "tasks", dc[2], "batches", dc[1], "in-image voxel steps", dc[3], "lane slots", dc[1] * 256)
+    print(k, "U", U, "S", S, "hopped", dc[7], "tasks", dc[2], "batches", dc[1], "in-image voxel steps", dc[3], "lane slots", dc[1] * 256, "raycast wave hop iterations", dc[5], "wave batch iterations", dc[6])
