@@ -194,6 +194,11 @@ int kt_tracker_prefetch_frame(kt_tracker* t, const uint16_t* depth_dev, const ui
 int kt_tracker_prefetch_frame_host(kt_tracker* t, const uint16_t* depth_host, const uint8_t* rgb24_host);
 /* TrackerInterface::process upload path (TrackerInterface.cpp:90-91): host frame -> device -> processFrame */
 int kt_tracker_process_frame_host(kt_tracker* t, const uint16_t* depth_host, const uint8_t* rgb24_host, uint64_t timestamp);
+/* -p ground-truth odometry.  KintinuousTracker::loadTrajectory (KintinuousTracker.cpp:216-260) without the text parsing:
+ * pose7 = n x {x y z qx qy qz qw}, one row per line "utime,x,y,z,qx,qy,qz,qw" of the trajectory file.  From then on the pose of
+ * every frame comes from GroundTruthOdometry (GroundTruthOdometry.cpp:42-74) instead of ICP / RGB-D, and a frame whose timestamp
+ * has no entry is dropped (preRun, :89-111).  Call before the first frame; repeated calls add entries. */
+int kt_tracker_load_trajectory(kt_tracker* t, int n, const uint64_t* utimes_host, const float* pose7_host);
 int kt_tracker_finalise(kt_tracker* t);
 /* rmats_.back() (row-major 3x3), tvecs_.back(), currentGlobalCamera */
 int kt_tracker_get_pose(kt_tracker* t, float R_host[9], float t_host[3], float global_cam_host[3]);

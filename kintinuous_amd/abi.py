@@ -104,6 +104,7 @@ _PROTOS = {
     "kt_tracker_reset": (_i, [_vp]),
     "kt_tracker_process_frame": (_i, [_vp, _vp, _vp, _u64]),
     "kt_tracker_process_frame_host": (_i, [_vp, _vp, _vp, _u64]),
+    "kt_tracker_load_trajectory": (_i, [_vp, _i, _vp, _vp]),
     "kt_tracker_finalise": (_i, [_vp]),
     "kt_tracker_get_pose": (_i, [_vp, _pf, _pf, _pf]),
     "kt_tracker_num_poses": (_i, [_vp]),
@@ -381,6 +382,13 @@ class Tracker:
         depth = np.ascontiguousarray(depth, dtype=np.uint16)
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         _chk(lib().kt_tracker_process_frame_host(self.h, depth.ctypes.data, rgb.ctypes.data, timestamp))
+
+    def load_trajectory(self, utimes, pose7) -> None:
+        """-p ground truth: utimes[n] uint64, pose7[n, 7] = x y z qx qy qz qw (KintinuousTracker::loadTrajectory)."""
+        utimes = np.ascontiguousarray(utimes, dtype=np.uint64)
+        pose7 = np.ascontiguousarray(pose7, dtype=np.float32).reshape(-1, 7)
+        assert len(utimes) == len(pose7)
+        _chk(lib().kt_tracker_load_trajectory(self.h, len(utimes), utimes.ctypes.data, pose7.ctypes.data))
 
     def finalise(self) -> None:
         _chk(lib().kt_tracker_finalise(self.h))

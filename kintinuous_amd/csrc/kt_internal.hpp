@@ -12,6 +12,21 @@ struct kt_frame_params {
     int skip;           // 1: the frame needs a volume shift first -- the speculatively enqueued fusion kernels do nothing
 };
 
+// Per-pixel record of integrate, built once per frame by kt_integrate_prepare: everything tsdf23 gathers per voxel from the frame
+// (scaled depth with the no-colour sign flag, the colour weight derived from |n_z|, rgb, normal-valid) in ONE 16-byte gather.
+struct __attribute__((aligned(16))) kt_pixrec {
+    float dp;        // scaleDepth output (negative = "no colour", tsdf_volume.cu:520-527)
+    float wrkc;      // (angleColor ? min(1, |n_z| / 0.75) : 1) * 2       tsdf_volume.cu:625
+    uint32_t rgbf;   // r | g<<8 | b<<16 | KT_REC_* flags
+    uint32_t pad;
+};
+#define KT_REC_NORMAL_NAN (1u << 24)   // isnan(n_x)
+// computeNmapKernel (maps.cu:96-133) writes only n_x = NaN for an invalid normal: n_z keeps whatever the buffer held, and tsdf23
+// still reads it for the colour weight of a voxel whose colour is (0, 0, 0).  With ONE nmaps_curr_ buffer, as in the reference,
+// that is the n_z of the last frame in which the pixel had a valid normal.  The flag marks such pixels; the tracker, whose
+// frame sets rotate, replaces their wrkc from a per-pixel carry kept in processing order (kt_frame_setup_kernel).
+#define KT_REC_STALE_NZ (1u << 25)
+
 int kt_bilateral_lut_ensure(kt_ctx* c);
 size_t kt_brick_count(int N);   // flags of the raycast's empty-space bricks for an N^3 volume
 

@@ -11,7 +11,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <array>
 #include <chrono>
+#include <map>
 #include <thread>
 #include <vector>
 
@@ -67,6 +69,11 @@ struct kt_tracker {
     int voxel_wrap[3], v_wrap_copy[3];
     int global_time;
     uint64_t current_ts = 0;
+    // -p ground-truth odometry: camera_trajectory (KintinuousTracker.h:237; its comparator is std::less<int>, so the keys are the
+    // timestamps narrowed to int) and current_utime as GroundTruthOdometry sees it (the previous tracked frame's timestamp)
+    bool has_trajectory = false;
+    std::map<int, std::array<float, 12>> trajectory;   // R row-major [0..8], t [9..11]
+    uint64_t gt_utime = 0;
     bool parked;
     float Rlast[9], tlast[3];          // rmats_.back(), tvecs_.back()
     float current_global_camera[3];
@@ -104,6 +111,9 @@ struct kt_tracker {
     bool outstanding; uint64_t out_ts; int out_set;
     const uint16_t* out_depth; const uint8_t* out_rgb; int out_thresh;
     kt_frame_params* fp_dev;
+    // colour weight carried across frames for pixels without a valid normal (KT_REC_STALE_NZ): [carry_sel] = state before the frame
+    // in flight, [carry_sel ^ 1] = state after it
+    float* wrkc_carry[2]; int carry_sel;
     unsigned char* bricks;             // negative-brick flags of the volume (tsdf23 raises, raycast skips; kt_volume.hip)
     float *vgz_dev, *zs_dev;           // z tables of integrate (kt_integrate_tables)
     PoseMirror* mirror;                // pinned + mapped host memory
@@ -170,14 +180,16 @@ static int build_frame_set(kt_tracker* t, kt_ctx* cx, int q, const uint16_t* dep
 {
     const int cols = t->cfg.cols, rows = t->cfg.rows;
     FrameSet& fs = t->sets[q];
-    const bool icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
+    // the odometry provider objects of the ctor (KintinuousTracker.cpp:128-178): ground truth wins over the RGB-D flags
+    const bool icp = !t->has_trajectory && !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
+    const bool rgbd = !t->has_trajectory && !icp;
     if (icp || t->cfg.use_rgbd_icp || !t->cfg.disable_color_angle) {
         KT_TRY(kt_bilateral_filter(cx, depth_raw, fs.depths[0], cols, rows));
         uint16_t* dl[3] = {fs.depths[1], fs.depths[2], fs.depths[3]};
         KT_TRY(kt_build_pyramid(cx, &t->intr, fs.depths[0], cols, rows, dl, fs.vmaps, fs.nmaps));
     }
     KT_TRY(kt_integrate_prepare(cx, depth_raw, colors, fs.nmaps[0], cols, rows, &t->intr, !t->cfg.disable_color_angle, fs.scaled, fs.rec, fs.dpmax));
-    if (!icp) {
+    if (rgbd) {
         // RGBDOdometry::populateRGBDData (RGBDOdometry.cpp:140-158), the derivative images of the frame as "next" (:296-300) and its
         // point clouds as "last" (:186): all functions of the frame alone
         KT_TRY(kt_depth_to_metres(cx, depth_raw, fs.depth_m[0], cols, rows, (int)(6.0 * 1000)));
@@ -382,6 +394,8 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     t->host_wait_s = t->host_call_s = 0.0; t->host_calls = 0;
     KT_TRY(dev_alloc(&t->fp_dev, 1, true));
     KT_TRY(dev_alloc(&t->bricks, kt_brick_count(cfg->N) + 16, true));
+    for (int k = 0; k < 2; ++k) KT_TRY(dev_alloc(&t->wrkc_carry[k], (size_t)cfg->cols * cfg->rows, true));  // zero: the oracle's calloc'ed normal map
+    t->carry_sel = 0;
     KT_TRY(kt_integrate_tables(ctx, cfg->cols, cfg->rows, cfg->N, &t->vgz_dev, &t->zs_dev));
     KT_HIP(hipHostMalloc((void**)&t->mirror, sizeof(PoseMirror), hipHostMallocMapped | hipHostMallocCoherent));
     memset(t->mirror, 0, sizeof(PoseMirror));
@@ -427,6 +441,7 @@ int kt_tracker_destroy(kt_tracker* t)
     (void)hipHostFree(t->mirror);
     (void)hipFree(t->fp_dev);
     (void)hipFree(t->bricks);
+    for (int k = 0; k < 2; ++k) (void)hipFree(t->wrkc_carry[k]);
     delete t;
     return KT_OK;
 }
@@ -581,10 +596,30 @@ struct kt_setup_args {
     int mode, rgbd_guard;
     float R[9], t[3];
     float basis[3], voxel[3]; int thresh;
+    kt_pixrec* rec; const float* carry_cur; float* carry_next; int npix;
 };
 
-__global__ __launch_bounds__(64) void kt_frame_setup_kernel(const kt_setup_args a)
+// Workgroup 0 (one wave) is the set-up proper; workgroups 1.. maintain the colour-weight carry of KT_REC_STALE_NZ pixels, 1024 pixels
+// each: a pixel without a valid normal takes the weight the carry holds (and passes it on), every other pixel deposits its own.
+// A pure function of (rec flags, rec.wrkc of valid pixels, carry_cur): running it twice for a frame (mode 0, then the mode 1 redo
+// after a shift) changes nothing.  mode 2 = carry only (first frame).
+__global__ __launch_bounds__(256) void kt_frame_setup_kernel(const kt_setup_args a)
 {
+    if (blockIdx.x > 0) {
+        const int base = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = base + k * 256;
+            if (p < a.npix) {
+                const bool stale = (a.rec[p].rgbf & KT_REC_STALE_NZ) != 0;
+                const float w = stale ? a.carry_cur[p] : a.rec[p].wrkc;
+                a.carry_next[p] = w;
+                if (stale) a.rec[p].wrkc = w;
+            }
+        }
+        return;
+    }
+    if (threadIdx.x >= 64 || a.mode == 2) return;
     float R[9], tv[3];
     int skip = 0;
     if (a.mode == 0) {
@@ -655,7 +690,12 @@ static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv
     for (int k = 0; k < 3; ++k) a.t[k] = tv ? tv[k] : 0.f;
     for (int k = 0; k < 3; ++k) { a.basis[k] = t->volume_basis[k]; a.voxel[k] = t->voxel_size[k]; }
     a.thresh = t->parked ? INT_MAX : t->cfg.voxel_shift;
-    hipLaunchKernelGGL(kt_frame_setup_kernel, dim3(1), dim3(64), 0, t->ctx->stream, a);
+    a.rec = (kt_pixrec*)t->sets[t->out_set].rec;
+    a.carry_cur = t->wrkc_carry[t->carry_sel];
+    a.carry_next = t->wrkc_carry[t->carry_sel ^ 1];
+    a.npix = t->cfg.cols * t->cfg.rows;
+    const int carry_groups = t->cfg.disable_color_angle ? 0 : (a.npix + 1023) / 1024;   // without the angle weight wrkc is 2 everywhere
+    hipLaunchKernelGGL(kt_frame_setup_kernel, dim3(1 + carry_groups), dim3(256), 0, t->ctx->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
@@ -666,7 +706,7 @@ static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, con
 {
     kt_ctx* c = t->ctx;
     const int cols = t->cfg.cols, rows = t->cfg.rows, N = t->N;
-    const bool icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
+    const bool icp = !t->has_trajectory && !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
     const kt_mat33 dummy_R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
     const float dummy_t[3] = {0, 0, 0};
     if (t->counting) {
@@ -728,44 +768,54 @@ static int read_counts(kt_tracker* t)
     return KT_OK;
 }
 
-// Host half of the frame enqueued by the last kt_tracker_process_frame call: wait for its pose (the copy-stream event, NOT the
-// fusion kernels), do the pose bookkeeping of KintinuousTracker.cpp:574-595, 903-909 and, when the volume has to shift
-// (:627-833), run the shift and redo the fusion the device parked.  Called at the start of the next frame and by every getter.
-static int complete_frame(kt_tracker* t)
+// GroundTruthOdometry::getIncrementalTransformation (GroundTruthOdometry.cpp:42-74): the pose of the frame stamped `timestamp` from
+// the loaded trajectory, composed in the volume's frame.  Every product is float, in Eigen's evaluation order: delta =
+// Ta^-1 * Tb as Isometry3f (3x3 products, translation = linear * t + t), then currentTsdf * M^-1 * delta * M left to right as
+// 4x4 products.  M permutes and negates axes, so the first and last product are exact column moves; the middle one rounds, with
+// its sums running over the moved columns.
+static void ground_truth_pose(kt_tracker* t, uint64_t timestamp, float Rcurr[9], float tcurr[3])
 {
-    if (!t->outstanding) return KT_OK;
-    t->outstanding = false;
+    memcpy(Rcurr, t->Rlast, 9 * sizeof(float));
+    memcpy(tcurr, t->tlast, 3 * sizeof(float));
+    if (t->gt_utime == 0 || t->trajectory.empty()) return;   // :50 -- a previous stamp of 0 reads as "no previous frame"
+    const std::array<float, 12>& A = t->trajectory[(int)(uint32_t)t->gt_utime];   // operator[], as the reference
+    const std::array<float, 12>& B = t->trajectory[(int)(uint32_t)timestamp];
+    float Ainv[9], ainv[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Ainv[i * 3 + j] = A[j * 3 + i];
+    for (int i = 0; i < 3; ++i) ainv[i] = ((-Ainv[i * 3]) * A[9] + (-Ainv[i * 3 + 1]) * A[10]) + (-Ainv[i * 3 + 2]) * A[11];
+    float delta[4][4];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) delta[i][j] = (Ainv[i * 3] * B[j] + Ainv[i * 3 + 1] * B[3 + j]) + Ainv[i * 3 + 2] * B[6 + j];
+        delta[i][3] = ((Ainv[i * 3] * B[9] + Ainv[i * 3 + 1] * B[10]) + Ainv[i * 3 + 2] * B[11]) + ainv[i];
+    }
+    delta[3][0] = delta[3][1] = delta[3][2] = 0.f;
+    delta[3][3] = 1.f;
+    for (int i = 0; i < 3; ++i) {
+        // row i of currentTsdf * M^-1: (z column, -x column, -y column, translation)
+        const float moved[4] = {t->Rlast[i * 3 + 2], -t->Rlast[i * 3], -t->Rlast[i * 3 + 1], t->tlast[i]};
+        float q[4];
+        for (int j = 0; j < 4; ++j) q[j] = ((moved[0] * delta[0][j] + moved[1] * delta[1][j]) + moved[2] * delta[2][j]) + moved[3] * delta[3][j];
+        // ... * M: columns (-q1, -q2, q0, q3)
+        Rcurr[i * 3] = -q[1];
+        Rcurr[i * 3 + 1] = -q[2];
+        Rcurr[i * 3 + 2] = q[0];
+        tcurr[i] = q[3];
+    }
+}
+
+// Host half of a frame once its pose is known: the pose bookkeeping of KintinuousTracker.cpp:574-595, 903-909 and, when the volume
+// has to shift (:627-833), the shift.  speculated = the fusion kernels were already enqueued against the device-side shift decision
+// (they ran unless the device parked them); otherwise (pose supplied by the host) they are enqueued here, after any shift.
+static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool speculated)
+{
     kt_ctx* c = t->ctx;
     const int N = t->N;
-    {
-        // the ONE host wait of the frame: spin on the sequence word the set-up kernel posts after the odometry iterations (the GPU
-        // goes straight on to integrate / raycast meanwhile)
-        const auto w0 = std::chrono::steady_clock::now();
-        volatile unsigned int* seq = &t->mirror->seq;
-        long long spins = 0;
-        while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != t->frame_seq) {
-            if ((++spins & 0xfff) == 0) {
-                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-                if (waited > 30.0) {
-                    const hipError_t e = hipStreamQuery(c->stream);
-                    kt_set_error("tracker: no pose from the device after 30 s (stream status: %s)", hipGetErrorString(e));
-                    return KT_ERR_STATE;
-                }
-                if (waited > 0.002) std::this_thread::yield();
-            }
-        }
-        t->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-    }
-    ev_collect(t);
-    if (t->mirror->handoff_timeout) { kt_set_error("odometry: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
-    float Rcurr[9], tcurr[3];
-    memcpy(Rcurr, t->mirror->R, sizeof(Rcurr));
-    memcpy(tcurr, t->mirror->t, sizeof(tcurr));
     t->current_ts = t->out_ts;
 
     // [D] rmats_/tvecs_ push, currentGlobalCamera :574-595
-    memcpy(t->Rlast, Rcurr, sizeof(Rcurr));
-    memcpy(t->tlast, tcurr, sizeof(tcurr));
+    memcpy(t->Rlast, Rcurr, 9 * sizeof(float));
+    memcpy(t->tlast, tcurr, 3 * sizeof(float));
     compute_global_camera(t, tcurr);
 
     // [F] shift decision :627-667 and the three axis blocks :669-833
@@ -778,7 +828,7 @@ static int complete_frame(kt_tracker* t)
         vt[k] = voxel_trans(current_translation[k], t->voxel_size[k], thresh);
         need_shift = need_shift || vt[k] >= thresh || vt[k] <= -thresh;
     }
-    if (need_shift != (t->mirror->skip != 0)) {
+    if (speculated && need_shift != (t->mirror->skip != 0)) {
         kt_set_error("tracker: host and device disagree on the shift decision");
         return KT_ERR_STATE;
     }
@@ -816,7 +866,10 @@ static int complete_frame(kt_tracker* t)
         }
         v_wrap_copy_update(t);
         KT_TRY(ev_end(t, ST_SHIFT));
-        // the fusion the device parked, now with the shifted pose and wrap
+    }
+    if (need_shift || !speculated) {
+        // the fusion the device parked (or that was never enqueued), with the final pose and wrap
+        v_wrap_copy_update(t);
         KT_TRY(launch_setup(t, 1, Rcurr, tcurr));
         KT_TRY(enqueue_fusion(t, t->out_set, t->out_depth, t->out_rgb));
     }
@@ -824,6 +877,41 @@ static int complete_frame(kt_tracker* t)
     ++t->global_time;
     push_pose(t, t->out_ts, Rcurr, 0);  // [K] :903-909
     return KT_OK;
+}
+
+// Host half of the frame enqueued by the last kt_tracker_process_frame call: wait for its pose (the copy-stream event, NOT the
+// fusion kernels), do the pose bookkeeping of KintinuousTracker.cpp:574-595, 903-909 and, when the volume has to shift
+// (:627-833), run the shift and redo the fusion the device parked.  Called at the start of the next frame and by every getter.
+static int complete_frame(kt_tracker* t)
+{
+    if (!t->outstanding) return KT_OK;
+    t->outstanding = false;
+    kt_ctx* c = t->ctx;
+    {
+        // the ONE host wait of the frame: spin on the sequence word the set-up kernel posts after the odometry iterations (the GPU
+        // goes straight on to integrate / raycast meanwhile)
+        const auto w0 = std::chrono::steady_clock::now();
+        volatile unsigned int* seq = &t->mirror->seq;
+        long long spins = 0;
+        while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != t->frame_seq) {
+            if ((++spins & 0xfff) == 0) {
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+                if (waited > 30.0) {
+                    const hipError_t e = hipStreamQuery(c->stream);
+                    kt_set_error("tracker: no pose from the device after 30 s (stream status: %s)", hipGetErrorString(e));
+                    return KT_ERR_STATE;
+                }
+                if (waited > 0.002) std::this_thread::yield();
+            }
+        }
+        t->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+    }
+    ev_collect(t);
+    if (t->mirror->handoff_timeout) { kt_set_error("odometry: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
+    float Rcurr[9], tcurr[3];
+    memcpy(Rcurr, t->mirror->R, sizeof(Rcurr));
+    memcpy(tcurr, t->mirror->t, sizeof(tcurr));
+    return finish_pose(t, Rcurr, tcurr, true);
 }
 
 extern "C" {
@@ -855,9 +943,21 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
 {
     KT_TRY(complete_frame(t));
     kt_ctx* c = t->ctx;
+    const bool gt = t->has_trajectory;
+    if (gt && !t->trajectory.count((int)(uint32_t)timestamp)) {
+        // GroundTruthOdometry::preRun :89-111, KintinuousTracker.cpp:460-463: a frame without a trajectory entry is not tracked at
+        // all.  If it was read ahead, its set goes back to the pool once written.
+        for (size_t i = 0; i < t->pending.size(); ++i)
+            if (t->pending[i].depth == depth_raw && t->pending[i].rgb == colors) {
+                KT_HIP(hipStreamWaitEvent(c->stream, t->sets[t->pending[i].set].ready, 0));
+                t->pending.erase(t->pending.begin() + i);
+                break;
+            }
+        return KT_OK;
+    }
     t->current_ts = timestamp;
     const int cols = t->cfg.cols, rows = t->cfg.rows, N = t->N;
-    const bool icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
+    const bool icp = !gt && !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
     const int angle_color = !t->cfg.disable_color_angle;
 
     // [A] pyramid build, KintinuousTracker.cpp:465-479 (+ scaleDepth records): taken from the prefetch stream if this frame
@@ -889,6 +989,8 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     t->sets[set].user = t->frames_started++;
     const int last_set = t->prev_set;   // "last" of RGBDOdometry for this frame
     t->prev_set = set;
+    t->out_set = set;
+    t->carry_sel ^= 1;                  // the state the previous tracked frame left becomes "before this frame"
 
     if (t->global_time == 0) {  // [B] :481-557
         kt_mat33 Rcam, Rcam_inv;
@@ -896,6 +998,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         kt_mat33_inverse(Rcam.m, Rcam_inv.m);
         const int empty[3] = {0, 0, 0};
         if (t->counting) KT_HIP(hipMemsetAsync(t->upd_dev, 0, 16 * sizeof(unsigned int), c->stream));
+        KT_TRY(launch_setup(t, 2, nullptr, nullptr));   // colour-weight carry only
         KT_TRY(ev_begin(t, ST_INTEGRATE));
         tsdf23_hook_arm(t);
         KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &Rcam_inv, t->tlast, t->tranc_dist, t->tsdf,
@@ -907,6 +1010,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
                                      t->nmaps_g_prev[l]));
         ++t->global_time;
         t->ev_par ^= 1;
+        t->gt_utime = timestamp;   // :527-528
         push_pose(t, timestamp, t->Rlast, 1);
         if (t->counting) {
             unsigned int u = 0;
@@ -915,6 +1019,23 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
             t->last_U = u;
             t->last_S = 0;
         }
+        return KT_OK;
+    }
+
+    t->out_ts = timestamp;
+    t->out_set = set;
+    t->out_depth = depth_raw;
+    t->out_rgb = colors;
+    t->out_thresh = t->parked ? INT_MAX : t->cfg.voxel_shift;
+    if (gt) {
+        // the pose comes from the trajectory, on the host: nothing to defer, nothing to speculate on
+        float Rcurr[9], tcurr[3];
+        ev_collect(t);
+        ground_truth_pose(t, timestamp, Rcurr, tcurr);
+        t->gt_utime = timestamp;   // :574-575
+        KT_TRY(finish_pose(t, Rcurr, tcurr, false));
+        t->ev_par ^= 1;
+        if (t->counting) KT_TRY(read_counts(t));
         return KT_OK;
     }
 
@@ -929,11 +1050,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     KT_TRY(launch_setup(t, 0, nullptr, nullptr));
     KT_TRY(enqueue_fusion(t, set, depth_raw, colors));
     t->outstanding = true;
-    t->out_ts = timestamp;
-    t->out_set = set;
-    t->out_depth = depth_raw;
-    t->out_rgb = colors;
-    t->out_thresh = t->parked ? INT_MAX : t->cfg.voxel_shift;
+    t->gt_utime = timestamp;
     t->ev_par ^= 1;
     if (t->counting) {  // the counters are read back per frame: finish it before returning
         KT_TRY(complete_frame(t));
@@ -1009,6 +1126,30 @@ int kt_tracker_process_frame_host(kt_tracker* t, const uint16_t* depth_host, con
     int slot;
     KT_TRY(stage_host_frame(t, t->ctx->stream, depth_host, rgb_host, &slot));
     return kt_tracker_process_frame(t, t->depth_stage[slot], t->rgb_stage[slot], timestamp);
+}
+
+// KintinuousTracker::loadTrajectory (KintinuousTracker.cpp:216-260) minus the text parsing: pose7 = n x {x y z qx qy qz qw}.
+// T.setIdentity(); T.pretranslate(t).rotate(q): linear = Quaternionf::toRotationMatrix() (no normalisation), translation = t.
+int kt_tracker_load_trajectory(kt_tracker* t, int n, const uint64_t* utimes, const float* pose7)
+{
+    KT_ARG(t && n >= 0 && (n == 0 || (utimes && pose7)));
+    KT_TRY(complete_frame(t));
+    t->has_trajectory = true;
+    for (int i = 0; i < n; ++i) {
+        const float* p = pose7 + (size_t)i * 7;
+        const float qx = p[3], qy = p[4], qz = p[5], qw = p[6];
+        const float x2 = 2.f * qx, y2 = 2.f * qy, z2 = 2.f * qz;
+        const float wx = x2 * qw, wy = y2 * qw, wz = z2 * qw;
+        const float xx = x2 * qx, xy = y2 * qx, xz = z2 * qx;
+        const float yy = y2 * qy, yz = z2 * qy, zz = z2 * qz;
+        std::array<float, 12> T = {1.f - (yy + zz), xy - wz, xz + wy,
+                                   xy + wz, 1.f - (xx + zz), yz - wx,
+                                   xz - wy, yz + wx, 1.f - (xx + yy),
+                                   p[0], p[1], p[2]};
+        t->trajectory[(int)(uint32_t)utimes[i]] = T;
+    }
+    t->gt_utime = 0;   // :259
+    return KT_OK;
 }
 
 int kt_tracker_finalise(kt_tracker* t)

@@ -41,13 +41,6 @@ extern "C" int kt_init_color_volume(kt_ctx* c, uint8_t* cv, int N)
 #define KT_BRICK (1 << KT_BRICK_LOG2)
 size_t kt_brick_count(int N) { const size_t nb = (size_t)(N + KT_BRICK - 1) / KT_BRICK; return nb * nb * nb; }
 
-struct __attribute__((aligned(16))) kt_pixrec {
-    float dp;        // scaleDepth output (negative = "no colour", tsdf_volume.cu:520-527)
-    float wrkc;      // (angleColor ? min(1, |n_z| / 0.75) : 1) * 2       tsdf_volume.cu:625
-    uint32_t rgbf;   // r | g<<8 | b<<16 | (isnan(n_x) ? 1<<24 : 0)
-    uint32_t pad;
-};
-
 struct kt_integrate_tables {  // incremental z walk of tsdf23 (quirk A.17), identical for every column
     float* vgz;      // v_g_z after z increments
     float* zs;       // z_scaled after z increments
@@ -86,7 +79,8 @@ __global__ __launch_bounds__(256) void kt_scale_depth_kernel(const uint16_t* __r
         r.dp = out;
         r.wrkc = (angle_color ? fminf(1.0f, nz / KT_RGB_VIEW_ANGLE_WEIGHT) : 1.0f) * 2.0f;
         const uint8_t* c = &colors[3 * (y * cols + x)];
-        r.rgbf = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | (kt_isnan(nx) ? (1u << 24) : 0u);
+        r.rgbf = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | (kt_isnan(nx) ? KT_REC_NORMAL_NAN : 0u) |
+                 ((angle_color && kt_isnan(nx)) ? KT_REC_STALE_NZ : 0u);
         r.pad = 0;
         rec[y * cols + x] = r;
     }

@@ -28,6 +28,7 @@ class ConfigArgs {
                      "  -g <gpu>       device\n"
                      "  -n <N>         volume resolution (default 512)\n"
                      "  -r | -ri       RGB-D odometry | RGB-D + ICP odometry\n"
+                     "  -p <file>      ground-truth odometry from a trajectory file (lines utime,x,y,z,qx,qy,qz,qw)\n"
                      "  -fod           fast odometry,  -sm static mode,  -dc no colour angle weight,  -no no overlap\n"
                      "  -f             flip colours (RGB <-> BGR)\n"
                      "  -tum           write poses with timestamps in seconds (TUM format; the .poses default)\n"

@@ -59,7 +59,15 @@ class KintinuousTracker {
             cfg.disable_color_angle = args.disableColorAngleWeight;
             config = cfg;
             lastOdometry = (args.useRGBD || args.useRGBDICP) ? CloudSlice::RGBD : CloudSlice::ICP;
+            if (args.trajectoryFile.size()) {  // KintinuousTracker.cpp:128-138: ground truth wins over the odometry flags
+                loadTrajectory(args.trajectoryFile);
+                lastOdometry = CloudSlice::GROUNDTRUTH;
+            }
             return;
+        }
+        if (args.trajectoryFile.size()) {
+            std::fprintf(stderr, "the operator path implements ICP odometry only; use the device-resident tracker for -p\n");
+            std::exit(1);
         }
         if (args.useRGBD || args.useRGBDICP) {
             std::fprintf(stderr, "the operator path implements ICP odometry only; use the device-resident tracker for -r / -ri\n");
@@ -97,8 +105,10 @@ class KintinuousTracker {
         current_utime = timestamp;
         if (!operatorPath) {
             ensureFast();
+            const int before = global_time_;
             ktSafeCall(kt_tracker_process_frame(fast, depth.ptr(), reinterpret_cast<const uint8_t*>(colors.ptr()), timestamp));
             syncFromFast();
+            if (global_time_ == before) return;  // no trajectory entry for this timestamp: the frame was dropped (:460-463)
         } else {
             processFrameOperators(depth, colors, timestamp);
         }
@@ -119,8 +129,10 @@ class KintinuousTracker {
         lastDepthData = depthData;
         current_utime = timestamp;
         ensureFast();
+        const int before = global_time_;
         ktSafeCall(kt_tracker_process_frame_host(fast, depthData, rgbImage, timestamp));
         syncFromFast();
+        if (global_time_ == before) return;  // dropped by the ground-truth trajectory lookup (:460-463)
         if (global_time_ > 1 && ConfigArgs::get().saveFile.size()) outputPose(timestamp, lastRotation);
     }
 
@@ -223,6 +235,9 @@ class KintinuousTracker {
     int global_time_;
     uint64_t current_utime;
     int nextSlice;
+    bool haveTrajectory = false;
+    std::vector<uint64_t> trajectoryTimes;   // -p file, flattened for kt_tracker_load_trajectory
+    std::vector<float> trajectoryPoses;
     kt::Matrix3f lastRotation;
     kt::Vector3f lastTranslation, currentGlobalCamera;
     unsigned char* lastRgbImage = 0;
@@ -242,6 +257,8 @@ class KintinuousTracker {
         if (fast) return;
         ktSafeCall(kt_tracker_create(kt::device::context(), &config, &fast));
         if (parked) ktSafeCall(kt_tracker_set_parked(fast, 1));
+        if (haveTrajectory)
+            ktSafeCall(kt_tracker_load_trajectory(fast, (int)trajectoryTimes.size(), trajectoryTimes.data(), trajectoryPoses.data()));
         if (ConfigArgs::get().saveFile.size()) {
             FILE* f = std::fopen((ConfigArgs::get().saveFile + ".poses").c_str(), "w");
             if (f) std::fclose(f);
@@ -275,6 +292,37 @@ class KintinuousTracker {
             sharedCloudSlices.push_back(new CloudSlice(cloud, (CloudSlice::Dimension)dim, lastOdometry, cam, R, ts, 0, fin ? lastRgbImage : 0,
                                                        fin ? lastDepthData : 0));
         }
+    }
+
+    // KintinuousTracker::loadTrajectory (KintinuousTracker.cpp:216-260): lines "utime,x,y,z,qx,qy,qz,qw"; the poses themselves are
+    // built inside the library (kt_tracker_load_trajectory)
+    void loadTrajectory(const std::string& filename)
+    {
+        FILE* f = std::fopen(filename.c_str(), "r");
+        if (!f) {
+            std::fprintf(stderr, "cannot open trajectory file %s\n", filename.c_str());
+            std::exit(1);
+        }
+        haveTrajectory = true;
+        char line[512];
+        double trajSum = 0.0;
+        bool first = true;
+        float lastT[3] = {0, 0, 0};
+        while (std::fgets(line, sizeof(line), f)) {
+            unsigned long long utime;
+            float v[7];
+            if (std::sscanf(line, "%llu,%f,%f,%f,%f,%f,%f,%f", &utime, &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) != 8) continue;
+            if (!first) {
+                const float d[3] = {v[0] - lastT[0], v[1] - lastT[1], v[2] - lastT[2]};
+                trajSum += std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            }
+            first = false;
+            for (int k = 0; k < 3; ++k) lastT[k] = v[k];
+            trajectoryTimes.push_back(utime);
+            trajectoryPoses.insert(trajectoryPoses.end(), v, v + 7);
+        }
+        std::fclose(f);
+        std::printf("Done loading ground truth, length: %g\n", trajSum);
     }
 
     // <saveFile>.poses, KintinuousTracker.cpp:199-218

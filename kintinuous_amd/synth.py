@@ -188,3 +188,25 @@ def sequence(config: str, n: int, cam: Camera = None, seed: int = 1234):
         raise ValueError(config)
     frames = [render(scene, cam, R, c) for (R, c) in traj[:n]]
     return cam, frames, traj[:n], kw
+
+
+def ground_truth_rows(poses) -> np.ndarray:
+    """Camera-to-world poses (R, c) in the tracker's camera convention (x right, y down, z forward) -> the rows
+    x y z qx qy qz qw of a -p trajectory file (x forward, y left, z up): T = M C M^-1, so that the tracker's
+    M^-1 (Ta^-1 Tb) M is Ca^-1 Cb (GroundTruthOdometry.cpp:52-68).  float32 [n, 7]."""
+    from scipy.spatial.transform import Rotation
+    M = np.array([[0, 0, 1, 0], [-1, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float64)
+    rows = []
+    for R, c in poses:
+        C4 = np.eye(4)
+        C4[:3, :3], C4[:3, 3] = R, c
+        T = M @ C4 @ M.T
+        rows.append(np.concatenate([T[:3, 3], Rotation.from_matrix(T[:3, :3]).as_quat()]))
+    return np.array(rows, np.float32)
+
+
+def write_trajectory_file(path: str, stamps, rows) -> None:
+    """-p file format of KintinuousTracker::loadTrajectory: utime,x,y,z,qx,qy,qz,qw per line."""
+    with open(path, "w") as f:
+        for ts, r in zip(stamps, rows):
+            f.write(str(int(ts)) + "," + ",".join(repr(float(np.float32(v))) for v in r) + "\n")

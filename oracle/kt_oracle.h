@@ -131,6 +131,8 @@ void kto_tracker_destroy(kto_tracker* t);
 void kto_tracker_reset(kto_tracker* t);
 /* processFrame: depth u16 [rows][cols] mm, rgb24 [rows][cols][3]. */
 void kto_tracker_process_frame(kto_tracker* t, const uint16_t* depth, const uint8_t* rgb24, uint64_t timestamp);
+/* -p ground-truth odometry (KintinuousTracker::loadTrajectory, GroundTruthOdometry.cpp): pose7 = n x {x y z qx qy qz qw} */
+void kto_tracker_load_trajectory(kto_tracker* t, int n, const uint64_t* utimes, const float* pose7);
 void kto_tracker_finalise(kto_tracker* t);
 /* outputs */
 void kto_tracker_get_pose(const kto_tracker* t, float R[9], float tvec[3], float global_cam[3]);

@@ -247,6 +247,11 @@ struct kto_tracker {
     slice_rec* slices; int n_slices, cap_slices;
     double stage_s[6];
     long long last_U, last_S;
+    /* ground-truth odometry (-p): camera_trajectory + current_utime, KintinuousTracker.h:237, KintinuousTracker.cpp:216-260 */
+    int has_trajectory, n_traj, cap_traj;
+    int* traj_key;          /* the map's comparator is std::less<int>: keys are the timestamps narrowed to int */
+    float (*traj_T)[12];    /* Isometry3f: R row-major [0..8], t [9..11] */
+    uint64_t current_utime;
 };
 
 static int lvl_cols(const kto_tracker* t, int l) { return t->cfg.cols >> l; }
@@ -317,6 +322,7 @@ void kto_tracker_destroy(kto_tracker* t)
     free(t->vmap_curr_color); free(t->depth_raw_scaled); free(t->cloud_device);
     for (int i = 0; i < t->n_slices; ++i) free(t->slices[i].pts);
     free(t->slices); free(t->poses);
+    free(t->traj_key); free(t->traj_T);
     free(t);
 }
 
@@ -533,6 +539,99 @@ static void rgbd_odometry(kto_tracker* t, const uint16_t* depth, const uint8_t* 
     }
 }
 
+/* KintinuousTracker::loadTrajectory KintinuousTracker.cpp:216-260 (the text parsing stays with the caller).
+ * pose7 = n x {x y z qx qy qz qw}.  T.setIdentity(); T.pretranslate(t).rotate(q): linear = Quaternionf::toRotationMatrix(),
+ * translation = t; a repeated key (as the int comparator sees it) overwrites the earlier entry. */
+void kto_tracker_load_trajectory(kto_tracker* t, int n, const uint64_t* utimes, const float* pose7)
+{
+    t->has_trajectory = 1;
+    for (int i = 0; i < n; ++i) {
+        const float* p = pose7 + (size_t)i * 7;
+        const float x = p[3], y = p[4], z = p[5], w = p[6];
+        /* Eigen QuaternionBase::toRotationMatrix */
+        const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+        const float twx = tx * w, twy = ty * w, twz = tz * w;
+        const float txx = tx * x, txy = ty * x, txz = tz * x;
+        const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+        float T[12];
+        T[0] = 1.f - (tyy + tzz); T[1] = txy - twz; T[2] = txz + twy;
+        T[3] = txy + twz; T[4] = 1.f - (txx + tzz); T[5] = tyz - twx;
+        T[6] = txz - twy; T[7] = tyz + twx; T[8] = 1.f - (txx + tyy);
+        T[9] = p[0]; T[10] = p[1]; T[11] = p[2];
+        const int key = (int)(uint32_t)utimes[i];
+        int at = -1;
+        for (int k = 0; k < t->n_traj; ++k)
+            if (t->traj_key[k] == key) { at = k; break; }
+        if (at < 0) {
+            if (t->n_traj == t->cap_traj) {
+                t->cap_traj = t->cap_traj ? 2 * t->cap_traj : 256;
+                t->traj_key = realloc(t->traj_key, (size_t)t->cap_traj * sizeof(int));
+                t->traj_T = realloc(t->traj_T, (size_t)t->cap_traj * sizeof(*t->traj_T));
+            }
+            at = t->n_traj++;
+            t->traj_key[at] = key;
+        }
+        memcpy(t->traj_T[at], T, sizeof(T));
+    }
+    t->current_utime = 0; /* :259 */
+}
+
+static const float* traj_find(const kto_tracker* t, uint64_t utime)
+{
+    const int key = (int)(uint32_t)utime;
+    for (int k = 0; k < t->n_traj; ++k)
+        if (t->traj_key[k] == key) return t->traj_T[k];
+    return NULL;
+}
+
+/* GroundTruthOdometry::getIncrementalTransformation GroundTruthOdometry.cpp:42-74.  last_utime there is a reference to the
+ * tracker's current_utime, i.e. the previous frame's timestamp; a previous timestamp of 0 means "no motion" (:50).
+ * currentTsdf * M.inverse() * delta * M is evaluated left to right as 4x4 float products; M is a signed permutation, so the
+ * outer two products only move and negate columns and the one rounding product is (currentTsdf*M^-1) * delta, whose sums run
+ * over the PERMUTED columns in order k = 0..3. */
+static void ground_truth_odometry(kto_tracker* t, uint64_t timestamp, float tcurr[3], float Rcurr[9])
+{
+    memcpy(Rcurr, t->Rlast, 9 * sizeof(float));
+    memcpy(tcurr, t->tlast, 3 * sizeof(float));
+    if (t->current_utime == 0 || t->n_traj == 0) return;
+    const float* Ta = traj_find(t, t->current_utime);
+    const float* Tb = traj_find(t, timestamp);
+    float ident[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    if (!Ta) Ta = ident; /* operator[] default-constructs; cannot happen: the previous frame passed preRun */
+    if (!Tb) Tb = ident;
+    /* delta = Ta.inverse() * Tb.  Isometry inverse: linear^T, -(linear^T) * translation */
+    float Ai[9], ai[3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Ai[r * 3 + c] = Ta[c * 3 + r];
+    for (int r = 0; r < 3; ++r) ai[r] = ((-Ai[r * 3 + 0]) * Ta[9] + (-Ai[r * 3 + 1]) * Ta[10]) + (-Ai[r * 3 + 2]) * Ta[11];
+    float D[16]; /* delta as a 4x4, row-major */
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) D[r * 4 + c] = (Ai[r * 3 + 0] * Tb[0 * 3 + c] + Ai[r * 3 + 1] * Tb[1 * 3 + c]) + Ai[r * 3 + 2] * Tb[2 * 3 + c];
+        D[r * 4 + 3] = ((Ai[r * 3 + 0] * Tb[9] + Ai[r * 3 + 1] * Tb[10]) + Ai[r * 3 + 2] * Tb[11]) + ai[r];
+    }
+    D[12] = 0.f; D[13] = 0.f; D[14] = 0.f; D[15] = 1.f;
+    /* P = currentTsdf * M^-1 (M^-1 = M^T): columns (T2, -T0, -T1, T3) of [Rprev | tprev; 0 0 0 1] */
+    float P[16];
+    for (int r = 0; r < 3; ++r) {
+        P[r * 4 + 0] = t->Rlast[r * 3 + 2];
+        P[r * 4 + 1] = -t->Rlast[r * 3 + 0];
+        P[r * 4 + 2] = -t->Rlast[r * 3 + 1];
+        P[r * 4 + 3] = t->tlast[r];
+    }
+    P[12] = 0.f; P[13] = 0.f; P[14] = 0.f; P[15] = 1.f;
+    float Q[12];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c)
+            Q[r * 4 + c] = ((P[r * 4 + 0] * D[0 * 4 + c] + P[r * 4 + 1] * D[1 * 4 + c]) + P[r * 4 + 2] * D[2 * 4 + c]) + P[r * 4 + 3] * D[3 * 4 + c];
+    /* X = Q * M: columns (-Q1, -Q2, Q0, Q3); rot = linear part (Isometry::rotation()), trans = translation */
+    for (int r = 0; r < 3; ++r) {
+        Rcurr[r * 3 + 0] = -Q[r * 4 + 1];
+        Rcurr[r * 3 + 1] = -Q[r * 4 + 2];
+        Rcurr[r * 3 + 2] = Q[r * 4 + 0];
+        tcurr[r] = Q[r * 4 + 3];
+    }
+}
+
 static int voxel_trans(float translation, float voxel, int thresh)
 {
     /* KintinuousTracker.cpp:640-667 */
@@ -544,10 +643,14 @@ static int voxel_trans(float translation, float voxel, int thresh)
 void kto_tracker_process_frame(kto_tracker* t, const uint16_t* depth_raw, const uint8_t* colors, uint64_t timestamp)
 {
     const int cols = t->cfg.cols, rows = t->cfg.rows, N = t->N;
-    const int icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
-    const int rgbd = !icp;
+    /* the odometry provider objects of the ctor :128-178: ground truth wins over the RGB-D flags */
+    const int gt = t->has_trajectory;
+    const int icp = !gt && !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
+    const int rgbd = !gt && !icp;
     const int angle_color = !t->cfg.disable_color_angle;
     double t0 = omp_get_wtime(), t1;
+
+    if (gt && !traj_find(t, timestamp)) return; /* GroundTruthOdometry::preRun :89-111, KintinuousTracker.cpp:460-463 */
 
     if (icp || t->cfg.use_rgbd_icp || !t->cfg.disable_color_angle) { /* [A] :465-479 */
         kto_bilateral_filter(depth_raw, t->depths_curr[0], cols, rows);
@@ -571,13 +674,16 @@ void kto_tracker_process_frame(kto_tracker* t, const uint16_t* depth_raw, const 
         for (int l = 0; l < LEVELS; ++l)
             kto_transform_maps(t->vmaps_curr[l], t->nmaps_curr[l], lvl_cols(t, l), lvl_rows(t, l), &Rcam, t->tlast, t->vmaps_g_prev[l], t->nmaps_g_prev[l]);
         ++t->global_time;
+        t->current_utime = timestamp; /* :527-528 */
         push_pose(t, timestamp, t->Rlast, 1);
         return;
     }
 
     float Rcurr[9], tcurr[3];
-    if (icp) icp_odometry(t, tcurr, Rcurr); /* [C] :564-572 */
+    if (gt) ground_truth_odometry(t, timestamp, tcurr, Rcurr);
+    else if (icp) icp_odometry(t, tcurr, Rcurr); /* [C] :564-572 */
     else rgbd_odometry(t, depth_raw, colors, tcurr, Rcurr);
+    t->current_utime = timestamp; /* :574-575 */
     t1 = omp_get_wtime(); t->stage_s[1] += t1 - t0; t0 = t1;
 
     memcpy(t->Rlast, Rcurr, sizeof(Rcurr)); /* [D] rmats_/tvecs_ push */

@@ -325,6 +325,11 @@ class OracleTracker:
         depth, rgb = _c(depth, np.uint16), _c(rgb, np.uint8)
         lib().kto_tracker_process_frame(self.h, _p(depth), _p(rgb), C.c_uint64(ts))
 
+    def load_trajectory(self, utimes, pose7) -> None:
+        """-p ground truth: utimes[n] (uint64), pose7[n,7] = x y z qx qy qz qw (float32)."""
+        utimes, pose7 = _c(utimes, np.uint64), _c(pose7, np.float32)
+        lib().kto_tracker_load_trajectory(self.h, C.c_int(len(utimes)), _p(utimes), _p(pose7))
+
     def finalise(self) -> None:
         lib().kto_tracker_finalise(self.h)
 

@@ -29,4 +29,6 @@ assert trk.num_slices() == otr.num_slices()
 v, ov = trk.volume(), otr.volume()
 print("frames", len(frames), "slices", trk.num_slices(), "worst pose diff", worst, "tsdf mismatches", int((v != ov).sum()), "of", int((otr.color_volume()[..., 3] != 0).sum()),
       "time %.1fs" % (time.time() - t0))
-assert worst < 1e-5
+c, oc = trk.color_volume(), otr.color_volume()
+print("colour mismatches per channel", [int((c[..., ch] != oc[..., ch]).sum()) for ch in range(4)])
+assert worst < 1e-5 and np.array_equal(v, ov) and np.array_equal(c, oc)

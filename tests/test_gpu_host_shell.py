@@ -23,7 +23,7 @@ def _run(args, cwd):
 
 
 def _summary(out):
-    tok = out.split()
+    tok = [l for l in out.splitlines() if l.startswith("frames ")][-1].split()
     return {"frames": int(tok[1]), "slices": int(tok[3]), "points": int(tok[5])}
 
 
@@ -85,3 +85,44 @@ def test_shifting_log_slices(tmp_path):
     assert a == b
     assert a["slices"] >= 5 and a["points"] > 0      # X+ / X- shifts + FINAL
     assert open(tmp_path / "dev.poses").read() == open(tmp_path / "ops.poses").read()
+
+
+def test_ground_truth_trajectory_cli(ctx, tmp_path):
+    """-p <trajectory>: the driver parses the reference's trajectory format, tracks with ground-truth poses, drops frames that have no
+    entry, and writes the same poses as the Python binding of the same tracker."""
+    from kintinuous_amd import abi, klg, synth
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("room")
+    poses = synth.orbit_trajectory(8)
+    frames = [synth.render(scene, cam, R, c) for (R, c) in poses]
+    stamps = [33333 * (k + 1) for k in range(len(frames))]
+    rows = synth.ground_truth_rows(poses)
+    keep = [k for k in range(len(frames)) if k != 4]
+    log = str(tmp_path / "gt.klg")
+    klg.write_klg(log, list(frames) + [frames[-1]], timestamps=stamps + [stamps[-1] + 33333], cols=cam.cols, rows=cam.rows)
+    calib = str(tmp_path / "calib.txt")
+    with open(calib, "w") as f:
+        f.write(f"{cam.fx!r} {cam.fy!r} {cam.cx!r} {cam.cy!r}\n")
+    tfile = str(tmp_path / "traj.csv")
+    synth.write_trajectory_file(tfile, [stamps[k] for k in keep], rows[keep])
+    out = _summary(_run(["-l", log, "-c", calib, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "6", "-p", tfile, "-o",
+                         str(tmp_path / "gt")], str(tmp_path)))
+    assert out["slices"] == 1
+    P = _poses(tmp_path / "gt.poses")
+    assert len(P) == len(keep) - 1                     # the first frame writes no line, the dropped frame none either
+
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
+    trk = abi.Tracker(ctx, cfg)
+    trk.load_trajectory(np.array([stamps[k] for k in keep], np.uint64), rows[keep])
+    line = 0
+    for k, (d, rgb) in enumerate(frames):
+        trk.process_frame_host(d, rgb, stamps[k])
+        if k in keep and k > 0:
+            _, _, gc = trk.pose()
+            assert np.allclose(P[line, 1:4], gc, rtol=2e-6, atol=1e-6)
+            assert abs(P[line, 0] - stamps[k] / 1e6) < 1e-6
+            line += 1
+    # ground truth keeps the camera on the rendered orbit
+    R, t, _ = trk.pose()
+    assert np.abs(t - (poses[-1][1] - poses[0][1] + 3.0)).max() < 1e-4
+    trk.close()

@@ -229,3 +229,59 @@ def test_rgbd_image_kernels(oracle_mod):
     f[3, 3] = np.nan
     p = oracle_mod.pyr_down_gauss_f32(f)
     assert np.allclose(p, 2.0)  # NaN taps are skipped and the weights renormalised
+
+
+# ---- -p ground-truth odometry (GroundTruthOdometry.cpp, KintinuousTracker::loadTrajectory) ---------------------------------------
+def test_ground_truth_odometry(oracle_mod):
+    from kintinuous_amd import synth
+    cam = synth.Camera.small(80, 60)
+    scene = synth.Scene("room")
+    traj = synth.orbit_trajectory(6)
+    frames = [synth.render(scene, cam, R, c) for (R, c) in traj]
+    pose7 = synth.ground_truth_rows(traj)
+    stamps = np.array([1000 * (k + 1) for k in range(len(traj))], np.uint64)
+    cfg = oracle_mod.OTrackerConfig(cam.cols, cam.rows, 32, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
+    trk = oracle_mod.OracleTracker(cfg)
+    keep = [0, 1, 2, 4, 5]                       # entry 3 is missing from the trajectory: that frame must be dropped (preRun)
+    trk.load_trajectory(stamps[keep], pose7[keep])
+    C = []
+    for R, c in traj:
+        C4 = np.eye(4)
+        C4[:3, :3], C4[:3, 3] = R, c
+        C.append(C4)
+    tracked = []
+    for k, (d, rgb) in enumerate(frames):
+        trk.process_frame(d, rgb, int(stamps[k]))
+        if k == 3:
+            assert trk.num_poses() == len(tracked), "a frame without a trajectory entry must not be tracked"
+            continue
+        tracked.append(k)
+        assert trk.num_poses() == len(tracked)
+        R, t, _ = trk.pose()
+        # expected: [I | basis] * C0^-1 Ck, chained through float32 products -> a few ulp
+        E = np.eye(4)
+        E[:3, 3] = 3.0
+        E = E @ np.linalg.inv(C[0]) @ C[k]
+        assert np.abs(R - E[:3, :3]).max() < 5e-6 and np.abs(t - E[:3, 3]).max() < 5e-6, k
+    # fusion and raycast ran with those poses (a 32^3 volume is coarse: a third of the pixels hit a surface)
+    assert np.isfinite(trk.vmap_g_prev(0)[: cam.rows]).mean() > 0.2
+    trk.close()
+
+    # quirks: (a) a previous timestamp of 0 reads as "no previous frame" (GroundTruthOdometry.cpp:50) -> frame 1 keeps frame 0's pose;
+    # (b) the map's comparator is std::less<int>: timestamps equal modulo 2^32 are the same key
+    trk = oracle_mod.OracleTracker(cfg)
+    stamps0 = np.array([0, 1000, 2000 + (1 << 32)], np.uint64)
+    trk.load_trajectory(stamps0, pose7[:3])
+    trk.process_frame(*frames[0], 0)
+    R0, t0, _ = trk.pose()
+    trk.process_frame(*frames[1], 1000)
+    R1, t1, _ = trk.pose()
+    assert np.array_equal(R0, R1) and np.array_equal(t0, t1)
+    trk.process_frame(*frames[2], 2000)          # found under the narrowed key
+    assert trk.num_poses() == 3
+    R2, t2, _ = trk.pose()
+    E = np.eye(4)
+    E[:3, 3] = 3.0
+    E = E @ np.linalg.inv(C[1]) @ C[2]           # the motion 0 -> 1 was lost, 1 -> 2 applied
+    assert np.abs(R2 - E[:3, :3]).max() < 5e-6 and np.abs(t2 - E[:3, 3]).max() < 5e-6
+    trk.close()
