@@ -47,6 +47,9 @@ WORKLOADS = {
 from kintinuous_amd.multistream import aggregate_fps, gather_poses, pingpong, stream_seed  # noqa: E402
 
 
+SLICE_NAMES = {0: "X+", 1: "X-", 2: "Y+", 3: "Y-", 4: "Z+", 5: "Z-", 7: "FINAL"}   # CloudSlice::Dimension
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -114,8 +117,10 @@ def main():
     ctx.sync()
     trk.host_times(reset=True)
     t0 = time.perf_counter()
+    marks = [t0]
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+        marks.append(time.perf_counter())   # a call returns once the PREVIOUS frame's pose (and any volume shift) is done
     pose_bytes = 0
     if dist is not None:
         import torch
@@ -134,6 +139,12 @@ def main():
     fps = aggregate_fps(dist, args.steps, elapsed, world, device=(f"cuda:{local_rank}" if dist is not None else None))
     elapsed = world * args.steps / fps
 
+    # per-frame period seen by the caller (shift frames show up as the tail: slab extraction + download + clears on the host path)
+    periods = np.diff(np.array(marks)) * 1e3
+    slices_by_dim = {}
+    for si in range(trk.num_slices()):
+        _, sdim = trk.slice_info(si)
+        slices_by_dim[SLICE_NAMES.get(sdim, str(sdim))] = slices_by_dim.get(SLICE_NAMES.get(sdim, str(sdim)), 0) + 1
     host_call_s, host_wait_s = trk.host_times()
     stage = trk.stage_ms()
     tsdf23_ms, tsdf23_n = stage["tsdf23"]
@@ -200,7 +211,10 @@ def main():
                                f"{N}^3 TSDF, " + ("inputs in HOST memory (PCIe-inclusive)" if args.host_frames else "inputs resident in HBM") + ", 1 stream per GPU (BASELINE.json configs[1])"
                                + (", log playback with 1 frame of read-ahead" if readahead else ", no read-ahead"),
                    "volume": N, "cols": cam.cols, "rows": cam.rows, "unique_frames": nuniq, "pose_err_m_at_end": pose_err,
-                   "pose_gather_bytes": pose_bytes},
+                   "pose_gather_bytes": pose_bytes,
+                   "frame_ms": {"p50": round(float(np.percentile(periods, 50)), 4), "p99": round(float(np.percentile(periods, 99)), 4),
+                                "max": round(float(periods.max()), 4)},
+                   "slices_by_direction": slices_by_dim},
         "roofline": {"kernel": "kt_tsdf23_kernel", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                      "frac": achieved / peak, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_tsdf23,
                      "avg_launch_ms": tsdf23_ms, "launches_timed": tsdf23_n, "U_voxels_updated": U, "S_raycast_steps": float(np.mean(Ss)),

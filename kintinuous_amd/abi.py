@@ -414,6 +414,12 @@ class Tracker:
     def num_slices(self) -> int:
         return lib().kt_tracker_num_slices(self.h)
 
+    def slice_info(self, i: int) -> Tuple[int, int]:
+        """(number of points, CloudSlice::Dimension) without downloading the points."""
+        n, dim = _sz(0), C.c_int(0)
+        _chk(lib().kt_tracker_slice_info(self.h, i, C.byref(n), C.byref(dim)))
+        return n.value, dim.value
+
     def slice(self, i: int) -> Tuple[np.ndarray, int]:
         n, dim = _sz(0), C.c_int(0)
         _chk(lib().kt_tracker_slice_info(self.h, i, C.byref(n), C.byref(dim)))
