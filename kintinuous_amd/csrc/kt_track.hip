@@ -121,60 +121,77 @@ __device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsi
     KT_TS(2);
 }
 
-// `sticky`: keep a time-out flag raised by an earlier sweep of the same kernel (joint reductions)
-__device__ __forceinline__ void kt_reduce29_sweep(const unsigned long long* __restrict__ granules, unsigned int epoch, float (&total)[KT_RED_SLOTS],
-                                                  bool sticky = false)
+// NS reductions published by the same launch (same epoch) are swept together: every wave issues the loads of all its granules --
+// 2 products x 4 warp sums x NS sets -- before it looks at any of them, so the sweep costs one memory round trip, not one per set.
+template <int NS>
+__device__ __forceinline__ void kt_reduce29_sweep_n(const unsigned long long* const (&granules)[NS], unsigned int epoch,
+                                                    float* const (&total)[NS])
 {
     const int tid = threadIdx.x;
     KT_TS(3);
     __shared__ unsigned int timed_out;
-    if (tid == 0 && !sticky) timed_out = 0;
+    if (tid == 0) timed_out = 0;
     __syncthreads();
     // The sweeping workgroup.  blockReduceSum second stage (reduce.cu:131-164) per CUDA block b: lanes 0..3 hold the warp sums,
     // lanes 4..31 zero; offsets 16, 8, 4 add zeros, offset 2 gives s0+s2 and s1+s3, offset 1 adds them.  Then
     // reduceSum<<<1, 512>>> (reduce.cu:166-184): threads 0..63 hold 0 + in[b]; warps 0 and 1 fold with the 32-lane tree, the rest
     // is zero; the final first-warp tree reduces to s0 + s1.  Wave w handles products w and w + 16; lane = CUDA block b, whose 4
-    // warp sums are the granules 4b..4b+3.  Each wave re-reads its granules until all 256 carry this launch's epoch (bounded:
+    // warp sums are the granules 4b..4b+3.  Each wave re-reads its granules until all of them carry this launch's epoch (bounded:
     // a hand-off that never completes raises slot 31 of total[], which the callers report as an error).
     {
         const int w = tid >> 6, lane = tid & 63;
+        unsigned long long g[NS][2][4];
+        bool ok;
+        unsigned int spins = 0;
+        for (;;) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int c = w + 16 * r;
-            if (c < 29) {
-                const unsigned long long* pp = &granules[c * KT_RED_BLOCKS + 4 * lane];
-                unsigned long long g0, g1, g2, g3;
-                bool ok;
-                unsigned int spins = 0;
-                for (;;) {
-                    g0 = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    g1 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    g2 = __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    g3 = __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (unsigned int)(g0 >> 32) == epoch && (unsigned int)(g1 >> 32) == epoch && (unsigned int)(g2 >> 32) == epoch &&
-                         (unsigned int)(g3 >> 32) == epoch;
-                    if (__all(ok) || ++spins > (1u << 22)) break;
-                    __builtin_amdgcn_s_sleep(1);
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int c = min(w + 16 * r, 28);   // waves 13..15 re-read product 28 in their second slot (result unused)
+                    const unsigned long long* pp = &granules[s][c * KT_RED_BLOCKS + 4 * lane];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[s][r][q] = __hip_atomic_load(pp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                const float s0 = __uint_as_float((unsigned int)g0) + 0.0f;
-                const float s1 = __uint_as_float((unsigned int)g1) + 0.0f;
-                const float s2 = __uint_as_float((unsigned int)g2) + 0.0f;
-                const float s3 = __uint_as_float((unsigned int)g3) + 0.0f;
+            ok = true;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ok = ok && (unsigned int)(g[s][r][q] >> 32) == epoch;
+            if (__all(ok) || ++spins > (1u << 22)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int c = w + 16 * r;
+                const float s0 = __uint_as_float((unsigned int)g[s][r][0]) + 0.0f;
+                const float s1 = __uint_as_float((unsigned int)g[s][r][1]) + 0.0f;
+                const float s2 = __uint_as_float((unsigned int)g[s][r][2]) + 0.0f;
+                const float s3 = __uint_as_float((unsigned int)g[s][r][3]) + 0.0f;
                 const float blk = (s0 + s2) + (s1 + s3);
                 const float tr = kt_warp32_sum(0.0f + blk);
                 const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tr), 0));
                 const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tr), 32));
-                if (lane == 0) {
-                    total[c] = (lo + 0.0f) + (hi + 0.0f);
-                    if (!__all(ok)) atomicOr(&timed_out, 1u);
-                }
+                if (lane == 0 && c < 29) total[s][c] = (lo + 0.0f) + (hi + 0.0f);
             }
-        }
+        const bool all_ok = __all(ok);
+        if (lane == 0 && !all_ok) atomicOr(&timed_out, 1u);
     }
     __syncthreads();
-    if (tid == 0) total[KT_RED_SLOTS - 1] = timed_out ? 1.0f : 0.0f;  // slot 31: the hand-off never completed (reported by the callers)
+    if (tid == 0) total[NS - 1][KT_RED_SLOTS - 1] = timed_out ? 1.0f : 0.0f;  // slot 31: the hand-off never completed (reported by the callers)
     __syncthreads();
     KT_TS(4);
+}
+
+__device__ __forceinline__ void kt_reduce29_sweep(const unsigned long long* __restrict__ granules, unsigned int epoch, float (&total)[KT_RED_SLOTS])
+{
+    const unsigned long long* const gs[1] = {granules};
+    float* const ts[1] = {total};
+    kt_reduce29_sweep_n<1>(gs, epoch, ts);
 }
 
 // `pre` runs in the sweeping workgroup between its publish and the sweep: the place to issue loads the epilogue will need
@@ -394,8 +411,8 @@ struct kt_residual_args {
     unsigned long long* granules; unsigned int epoch;   // [2][gridDim.x] {epoch, value} hand-off granules (as in kt_reduce29)
 };
 
-#define KT_RES_THREADS 256
-#define KT_RES_MAX_BLOCKS 1024
+#define KT_RES_THREADS 1024
+#define KT_RES_MAX_BLOCKS 256   // <= 4 granules per sweeping lane and sum
 __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_residual_args a)
 {
     const int cols = a.cols, rows = a.rows, n = cols * rows;
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_re
     }
     int cnt = 0;
     unsigned int sig = 0;  // wraps modulo 2^32 like the reference's int sum
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+    for (int k = blockIdx.x * KT_RES_THREADS + threadIdx.x; k < n; k += gridDim.x * KT_RES_THREADS) {
         const int i = k / cols, j0 = k - i * cols;
         kt_dataterm corres;
         corres.zero_x = corres.zero_y = corres.one_x = corres.one_y = 0;
@@ -469,21 +486,36 @@ __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_re
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     if (blockIdx.x != gridDim.x - 1 || threadIdx.x >= 64) return;
-    // sweeping wave: lane l reads granules l, l + 64, ... of both sums until every tag carries this launch's epoch
+    // sweeping wave: lane l reads granules l, l + 64, l + 128, l + 192 of both sums -- all eight loads in flight together -- until
+    // every tag carries this launch's epoch
     unsigned int tot[2] = {0, 0};
-    bool ok = true;
-    for (int which = 0; which < 2; ++which)
-        for (unsigned int g = lane; g < gridDim.x; g += 64) {
-            unsigned long long v;
-            unsigned int spins = 0;
-            do {
-                v = __hip_atomic_load(&a.granules[which * gridDim.x + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned int)(v >> 32) == a.epoch) break;
-                __builtin_amdgcn_s_sleep(1);
-            } while (++spins < (1u << 22));
-            ok = ok && (unsigned int)(v >> 32) == a.epoch;
-            tot[which] += (unsigned int)v;
+    bool ok;
+    {
+        const unsigned int G = gridDim.x;
+        unsigned long long v[2][4];
+        unsigned int spins = 0;
+        for (;;) {
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned int g = min((unsigned int)lane + 64u * q, G - 1);
+                    v[which][q] = __hip_atomic_load(&a.granules[which * G + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            ok = true;
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ok = ok && (unsigned int)(v[which][q] >> 32) == a.epoch;
+            if (__all(ok) || ++spins > (1u << 22)) break;
+            __builtin_amdgcn_s_sleep(1);
         }
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((unsigned int)lane + 64u * q < G) tot[which] += (unsigned int)v[which][q];
+    }
     for (int off = 32; off > 0; off >>= 1) {
         tot[0] += __shfl_down(tot[0], off, 64);
         tot[1] += __shfl_down(tot[1], off, 64);
@@ -643,8 +675,11 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
     if (blockIdx.x != gridDim.x - 1) return;
     kt_pose_regs pr;
     if (threadIdx.x == 0) pr.load(ar.state);
-    kt_reduce29_sweep(ai.granules, ai.epoch, total_icp);
-    kt_reduce29_sweep(ar.granules, ar.epoch, total, true);
+    {
+        const unsigned long long* const gs[2] = {ai.granules, ar.granules};
+        float* const ts[2] = {total_icp, total};   // the time-out flag lands in total[31]
+        kt_reduce29_sweep_n<2>(gs, ar.epoch, ts);
+    }
     if (threadIdx.x == 0) {
         float h[29], hi[29];
         for (int k = 0; k < 29; ++k) { h[k] = total[k]; hi[k] = total_icp[k]; }
