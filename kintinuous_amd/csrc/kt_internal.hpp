@@ -56,7 +56,11 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
                        int mode, const kt_track_state* init = nullptr);
 int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
                            const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
-                           int cols, int rows, kt_dataterm* corres_img, float max_depth_delta);
+                           int cols, int rows, kt_dataterm* corres_img, float max_depth_delta, const uint8_t* cand = nullptr,
+                           int write_all = 1);
+// the pose-independent half of the residual test, once per frame and level (cand[k] = 1: pixel k can yield a correspondence)
+int kt_rgb_residual_candidates(kt_ctx* c, float min_scale, const int16_t* dIdx, const int16_t* dIdy, const float* next_depth,
+                               const uint8_t* next_image, int cols, int rows, uint8_t* cand);
 int kt_joint_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
                          const float* vmap_g_prev, const float* nmap_g_prev, float dist_thres, float angle_thres,
                          const kt_dataterm* corres_img, const float* cloud, const int16_t* dIdx, const int16_t* dIdy, float sobel_scale,

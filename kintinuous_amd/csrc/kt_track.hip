@@ -121,6 +121,65 @@ __device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsi
     KT_TS(2);
 }
 
+// Two reductions over the same pixel range in ONE pass (the joint RGB-D + ICP iteration): phase 1 computes both rows of a pixel with
+// the loads of both in flight together, phase 2 walks both products of (comp, vt).  Every sum is formed exactly as by two
+// kt_reduce29_publish calls; only the waiting is shared.
+template <typename RowFnA, typename RowFnB>
+__device__ __forceinline__ void kt_reduce29_publish2(const RowFnA& fa, const RowFnB& fb, int n, unsigned long long* __restrict__ granules_a,
+                                                     unsigned long long* __restrict__ granules_b, unsigned int epoch, kt_rows_t* rows_a,
+                                                     kt_rows_t* rows_b)
+{
+    KT_TS(0);
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * 32;
+    const int comp = tid >> 5, vt = tid & 31;
+    const int my_a = comp < 28 ? KT_PA[comp] : 7, my_b = comp < 28 ? KT_PB[comp] : 7;
+    const int nk_vt = (n - (t0 + vt) + KT_VT_TOTAL - 1) / KT_VT_TOTAL;
+    const int nk_blk = (n - t0 + KT_VT_TOTAL - 1) / KT_VT_TOTAL;
+    float acc_a = 0.f, acc_b = 0.f;
+    for (int kb = 0; kb < nk_blk; kb += KT_KBATCH) {
+        const int kcount = min(KT_KBATCH, nk_blk - kb);
+        for (int p = tid; p < kcount * 32; p += KT_RED_THREADS) {
+            const int kl = p >> 5, v = p & 31;
+            const int i = t0 + v + (kb + kl) * KT_VT_TOTAL;
+            {
+                float rb[7];   // the short one first: its row is parked in LDS before the long one starts
+                const bool found_b = fb(min(i, n - 1), rb) && i < n;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) rows_b[kl][q][v] = found_b ? rb[q] : 0.0f;
+                rows_b[kl][7][v] = found_b ? 1.0f : 0.0f;
+            }
+            float ra[7];
+            const bool found_a = fa(min(i, n - 1), ra) && i < n;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) rows_a[kl][q][v] = found_a ? ra[q] : 0.0f;
+            rows_a[kl][7][v] = found_a ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        if (comp < 29) {
+            const int kend = min(kcount, nk_vt - kb);
+            if (comp < 28) {
+                for (int kl = 0; kl < kend; ++kl) {
+                    acc_a += rows_a[kl][my_a][vt] * rows_a[kl][my_b][vt];
+                    acc_b += rows_b[kl][my_a][vt] * rows_b[kl][my_b][vt];
+                }
+            } else {
+                for (int kl = 0; kl < kend; ++kl) { acc_a += rows_a[kl][7][vt]; acc_b += rows_b[kl][7][vt]; }
+            }
+        }
+        __syncthreads();
+    }
+    KT_TS(1);
+    const float wsum_a = kt_warp32_sum(acc_a), wsum_b = kt_warp32_sum(acc_b);
+    if (comp < 29 && vt == 0) {
+        __hip_atomic_store(&granules_a[comp * KT_RED_BLOCKS + blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum_a),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&granules_b[comp * KT_RED_BLOCKS + blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum_b),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    KT_TS(2);
+}
+
 // NS reductions published by the same launch (same epoch) are swept together: every wave issues the loads of all its granules --
 // 2 products x 4 warp sums x NS sets -- before it looks at any of them, so the sweep costs one memory round trip, not one per set.
 template <int NS>
@@ -409,10 +468,49 @@ struct kt_residual_args {
     int cols, rows;
     int* out2;               // host path: {count, sigma} written by the sweeping workgroup
     unsigned long long* granules; unsigned int epoch;   // [2][gridDim.x] {epoch, value} hand-off granules (as in kt_reduce29)
+    const uint8_t* cand;     // tracker path: the pose-independent half of the per-pixel test, precomputed per frame (kt_residual_candidates_kernel)
+    int write_all;           // with cand: 0 = only candidates are stored (the other DataTerms were zeroed by an earlier iteration of this frame)
 };
+
+// The part of residualKernel's per-pixel test that does not depend on the pose (reduce.cu:686-716): image border, the 4x4 window of
+// non-zero intensities, the gradient threshold and a valid depth.
+__device__ __forceinline__ bool kt_residual_candidate(const uint8_t* __restrict__ next_image, const int16_t* __restrict__ dIdx,
+                                                      const int16_t* __restrict__ dIdy, const float* __restrict__ next_depth, int cols, int rows,
+                                                      float min_scale, int i, int j0)
+{
+    if (!(j0 < cols - 5 && i < rows - 1)) return false;
+    bool valid = true;
+    for (int u = max(i - 2, 0); u < min(i + 2, rows); u++)
+        for (int v = max(j0 - 2, 0); v < min(j0 + 2, cols); v++) valid = valid && (next_image[u * cols + v] > 0);
+    if (!valid) return false;
+    const int valx = dIdx[i * cols + j0], valy = dIdy[i * cols + j0];
+    const float mTwo = (float)((valx * valx) + (valy * valy));
+    if (!(mTwo >= min_scale)) return false;
+    return !kt_isnan(next_depth[i * cols + j0]);
+}
+
+__global__ __launch_bounds__(256) void kt_residual_candidates_kernel(const uint8_t* __restrict__ next_image, const int16_t* __restrict__ dIdx,
+                                                                     const int16_t* __restrict__ dIdy, const float* __restrict__ next_depth,
+                                                                     int cols, int rows, float min_scale, uint8_t* __restrict__ cand)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cols * rows) return;
+    const int i = k / cols, j0 = k - i * cols;
+    cand[k] = kt_residual_candidate(next_image, dIdx, dIdy, next_depth, cols, rows, min_scale, i, j0) ? 1 : 0;
+}
+
+int kt_rgb_residual_candidates(kt_ctx* c, float min_scale, const int16_t* dIdx, const int16_t* dIdy, const float* next_depth,
+                               const uint8_t* next_image, int cols, int rows, uint8_t* cand)
+{
+    hipLaunchKernelGGL(kt_residual_candidates_kernel, dim3(kt_div_up(cols * rows, 256)), dim3(256), 0, c->stream, next_image, dIdx, dIdy,
+                       next_depth, cols, rows, min_scale, cand);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
 
 #define KT_RES_THREADS 1024
 #define KT_RES_MAX_BLOCKS 256   // <= 4 granules per sweeping lane and sum
+template <bool PRE>
 __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_residual_args a)
 {
     const int cols = a.cols, rows = a.rows, n = cols * rows;
@@ -433,37 +531,29 @@ __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_re
         corres.diff = 0.f;
         corres.valid = 0;
         corres.pad[0] = corres.pad[1] = corres.pad[2] = 0;
-        if (j0 < cols - 5 && i < rows - 1) {
-            bool valid = true;
-            for (int u = max(i - 2, 0); u < min(i + 2, rows); u++)
-                for (int v = max(j0 - 2, 0); v < min(j0 + 2, cols); v++) valid = valid && (a.next_image[u * cols + v] > 0);
-            if (valid) {
-                const int valx = a.dIdx[i * cols + j0], valy = a.dIdy[i * cols + j0];
-                const float mTwo = (float)((valx * valx) + (valy * valy));
-                if (mTwo >= a.min_scale) {
-                    const int y = i, x = j0;
-                    const float d1 = a.next_depth[y * cols + x];
-                    if (!kt_isnan(d1)) {
-                        const float xf = (float)x, yf = (float)y;
-                        const float transformed_d1 = __builtin_fmaf(d1, __builtin_fmaf(K[6], xf, K[7] * yf) + K[8], kt[2]);
-                        const int u0 = kt_f2i_rn(__builtin_fmaf(d1, __builtin_fmaf(K[0], xf, K[1] * yf) + K[2], kt[0]) / transformed_d1);
-                        const int v0 = kt_f2i_rn(__builtin_fmaf(d1, __builtin_fmaf(K[3], xf, K[4] * yf) + K[5], kt[1]) / transformed_d1);
-                        if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
-                            const float d0 = a.last_depth[v0 * cols + u0];
-                            const uint8_t li = a.last_image[v0 * cols + u0];
-                            if (d0 > 0 && fabsf(transformed_d1 - d0) <= a.max_depth_delta && li != 0) {
-                                corres.zero_x = (int16_t)u0; corres.zero_y = (int16_t)v0;
-                                corres.one_x = (int16_t)x; corres.one_y = (int16_t)y;
-                                corres.diff = (float)a.next_image[y * cols + x] - (float)li;
-                                corres.valid = 1;
-                                cnt += 1;
-                                sig += (unsigned int)kt_f2i_rz(corres.diff * corres.diff);
-                            }
-                        }
-                    }
+        const bool candidate = PRE ? a.cand[k] != 0
+                                   : kt_residual_candidate(a.next_image, a.dIdx, a.dIdy, a.next_depth, cols, rows, a.min_scale, i, j0);
+        if (candidate) {
+            const int y = i, x = j0;
+            const float d1 = a.next_depth[y * cols + x];
+            const float xf = (float)x, yf = (float)y;
+            const float transformed_d1 = __builtin_fmaf(d1, __builtin_fmaf(K[6], xf, K[7] * yf) + K[8], kt[2]);
+            const int u0 = kt_f2i_rn(__builtin_fmaf(d1, __builtin_fmaf(K[0], xf, K[1] * yf) + K[2], kt[0]) / transformed_d1);
+            const int v0 = kt_f2i_rn(__builtin_fmaf(d1, __builtin_fmaf(K[3], xf, K[4] * yf) + K[5], kt[1]) / transformed_d1);
+            if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+                const float d0 = a.last_depth[v0 * cols + u0];
+                const uint8_t li = a.last_image[v0 * cols + u0];
+                if (d0 > 0 && fabsf(transformed_d1 - d0) <= a.max_depth_delta && li != 0) {
+                    corres.zero_x = (int16_t)u0; corres.zero_y = (int16_t)v0;
+                    corres.one_x = (int16_t)x; corres.one_y = (int16_t)y;
+                    corres.diff = (float)a.next_image[y * cols + x] - (float)li;
+                    corres.valid = 1;
+                    cnt += 1;
+                    sig += (unsigned int)kt_f2i_rz(corres.diff * corres.diff);
                 }
             }
         }
+        if (PRE && !a.write_all && !candidate) continue;   // still zero from the first iteration of this level in this frame
         // one 16-byte store per DataTerm (written for every pixel, quirk A.19)
         *(int4*)&a.corres[k] = *(const int4*)&corres;
     }
@@ -551,9 +641,10 @@ extern "C" int kt_rgb_residual(kt_ctx* c, float min_scale, const int16_t* dIdx, 
     for (int k = 0; k < 3; ++k) a.kt_[k] = kt[k];
     a.krkinv = *krkinv; a.state = nullptr; a.cols = cols; a.rows = rows; a.out2 = out2;
     a.granules = kt_residual_granules(c); a.epoch = kt_next_epoch(c);
+    a.cand = nullptr; a.write_all = 1;
     int g = kt_div_up(cols * rows, KT_RES_THREADS);
     if (g > KT_RES_MAX_BLOCKS) g = KT_RES_MAX_BLOCKS;
-    hipLaunchKernelGGL(kt_residual_kernel, dim3(g), dim3(KT_RES_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(kt_residual_kernel<false>, dim3(g), dim3(KT_RES_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     KT_HIP(hipMemcpyAsync(c->int_out_host, out2, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
@@ -565,16 +656,18 @@ extern "C" int kt_rgb_residual(kt_ctx* c, float min_scale, const int16_t* dIdx, 
 
 int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
                            const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
-                           int cols, int rows, kt_dataterm* corres_img, float max_depth_delta)
+                           int cols, int rows, kt_dataterm* corres_img, float max_depth_delta, const uint8_t* cand, int write_all)
 {
     kt_residual_args a;
     a.min_scale = min_scale; a.dIdx = dIdx; a.dIdy = dIdy; a.last_depth = last_depth; a.next_depth = next_depth;
     a.last_image = last_image; a.next_image = next_image; a.corres = corres_img; a.max_depth_delta = max_depth_delta;
     a.state = state; a.cols = cols; a.rows = rows; a.out2 = (int*)&c->counters[4];
     a.granules = kt_residual_granules(c); a.epoch = kt_next_epoch(c);
+    a.cand = cand; a.write_all = write_all;
     int g = kt_div_up(cols * rows, KT_RES_THREADS);
     if (g > KT_RES_MAX_BLOCKS) g = KT_RES_MAX_BLOCKS;
-    hipLaunchKernelGGL(kt_residual_kernel, dim3(g), dim3(KT_RES_THREADS), 0, c->stream, a);
+    if (cand) hipLaunchKernelGGL(kt_residual_kernel<true>, dim3(g), dim3(KT_RES_THREADS), 0, c->stream, a);
+    else hipLaunchKernelGGL(kt_residual_kernel<false>, dim3(g), dim3(KT_RES_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
@@ -668,10 +761,9 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
     fi.tcurr = {ai.state->tcurr[0], ai.state->tcurr[1], ai.state->tcurr[2]};
     fi.tprev = {ai.state->tprev[0], ai.state->tprev[1], ai.state->tprev[2]};
     const kt_rgb_row fr{ar, ar.state->sigma_val};
-    __shared__ kt_rows_t rows[KT_KBATCH];
+    __shared__ kt_rows_t rows_icp[KT_KBATCH], rows_rgb[KT_KBATCH];   // 2 x 40 KB
     __shared__ float total_icp[KT_RED_SLOTS], total[KT_RED_SLOTS];
-    kt_reduce29_publish(fi, ai.cols * ai.rows, ai.granules, ai.epoch, rows);
-    kt_reduce29_publish(fr, ar.cols * ar.rows, ar.granules, ar.epoch, rows);
+    kt_reduce29_publish2(fi, fr, ai.cols * ai.rows, ai.granules, ar.granules, ar.epoch, rows_icp, rows_rgb);
     if (blockIdx.x != gridDim.x - 1) return;
     kt_pose_regs pr;
     if (threadIdx.x == 0) pr.load(ar.state);

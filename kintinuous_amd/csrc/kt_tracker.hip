@@ -35,6 +35,7 @@ struct FrameSet {
     float* depth_m[KT_LEVELS];        // metric depth pyramid
     uint8_t* image[KT_LEVELS];        // intensity pyramid
     int16_t *dIdx[KT_LEVELS], *dIdy[KT_LEVELS];
+    uint8_t* cand[KT_LEVELS];         // pixels that can yield a photometric correspondence when the frame is "next" (pose-independent tests)
     float* cloud[KT_LEVELS];          // projectToPointCloud of depth_m (used when the frame is "last")
     hipEvent_t ready;     // recorded on the prefetch stream when the set is complete
     long long user;       // ordinal of the process_frame call that last consumed the set (-1: none)
@@ -175,6 +176,14 @@ static int pick_free_set(kt_tracker* t)
     return -1;
 }
 
+// minimumGradientMagnitudes / sobelScale of RGBDOdometry (RGBDOdometry.cpp:64-70, 236): the squared-gradient threshold of level l
+static float rgbd_min_scale(int l)
+{
+    const float min_grad[KT_LEVELS] = {12, 5, 3, 1};
+    const double SOBEL_SCALE = 1.0 / pow(2.0, 3);
+    return (float)(pow(min_grad[l], 2.0) / pow(SOBEL_SCALE, 2.0));
+}
+
 // [A] of processFrame (KintinuousTracker.cpp:465-479) plus the pose-independent half of integrate, into sets[q] on cx's stream
 static int build_frame_set(kt_tracker* t, kt_ctx* cx, int q, const uint16_t* depth_raw, const uint8_t* colors)
 {
@@ -199,6 +208,8 @@ static int build_frame_set(kt_tracker* t, kt_ctx* cx, int q, const uint16_t* dep
         const double ifx = t->intr.fx, ify = t->intr.fy, icx = t->intr.cx, icy = t->intr.cy;  // RGBDOdometry.cpp:72-75
         for (int l = 0; l < KT_LEVELS; ++l) {
             KT_TRY(kt_derivative_images(cx, fs.image[l], lvl_cols(t, l), lvl_rows(t, l), fs.dIdx[l], fs.dIdy[l]));
+            KT_TRY(kt_rgb_residual_candidates(cx, rgbd_min_scale(l), fs.dIdx[l], fs.dIdy[l], fs.depth_m[l], fs.image[l], lvl_cols(t, l),
+                                              lvl_rows(t, l), fs.cand[l]));
             KT_TRY(kt_project_to_cloud(cx, fs.depth_m[l], lvl_cols(t, l), lvl_rows(t, l), fs.cloud[l], ifx, ify, icx, icy, l));
         }
     }
@@ -342,6 +353,7 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
             KT_TRY(dev_alloc(&t->sets[sidx].image[l], q, true));
             KT_TRY(dev_alloc(&t->sets[sidx].dIdx[l], q, true));
             KT_TRY(dev_alloc(&t->sets[sidx].dIdy[l], q, true));
+            KT_TRY(dev_alloc(&t->sets[sidx].cand[l], q, true));
             KT_TRY(dev_alloc(&t->sets[sidx].cloud[l], 3 * q, true));
         }
         KT_TRY(dev_alloc(&t->corres[l], q, true));
@@ -414,7 +426,7 @@ int kt_tracker_destroy(kt_tracker* t)
         (void)hipFree(t->vmaps_g_prev[l]); (void)hipFree(t->nmaps_g_prev[l]);
         for (int sidx = 0; sidx < KT_NSETS; ++sidx) {
             (void)hipFree(t->sets[sidx].depth_m[l]); (void)hipFree(t->sets[sidx].image[l]); (void)hipFree(t->sets[sidx].dIdx[l]);
-            (void)hipFree(t->sets[sidx].dIdy[l]); (void)hipFree(t->sets[sidx].cloud[l]);
+            (void)hipFree(t->sets[sidx].dIdy[l]); (void)hipFree(t->sets[sidx].cloud[l]); (void)hipFree(t->sets[sidx].cand[l]);
         }
         (void)hipFree(t->corres[l]);
     }
@@ -536,7 +548,6 @@ static int rgbd_odometry(kt_tracker* t, int set, int last_set)
         iters[0] = 10; iters[1] = 5; iters[2] = 4; iters[3] = 0;
         if (t->cfg.fast_odometry) { iters[0] = 0; iters[1] = 10; iters[2] = 7; iters[3] = 0; }
     }
-    const float min_grad[KT_LEVELS] = {12, 5, 3, 1};
     const double SOBEL_SCALE = 1.0 / pow(2.0, 3), MAX_DEPTH_DELTA = 0.07;
     const float dist_thres = 0.10f;
     const float angle_thres = (float)sin(20.f * 3.14159254f / 180.f);
@@ -559,9 +570,10 @@ static int rgbd_odometry(kt_tracker* t, int set, int last_set)
     for (int q = 0; q < ns; ++q) {
         const int l = sched[q];
         const int cols = lvl_cols(t, l), rows = lvl_rows(t, l);
-        const float min_scale = (float)(pow(min_grad[l], 2.0) / pow(SOBEL_SCALE, 2.0));
-        KT_TRY(kt_rgb_residual_device(t->ctx, t->state_dev, min_scale, next.dIdx[l], next.dIdy[l], last.depth_m[l], next.depth_m[l],
-                                      last.image[l], next.image[l], cols, rows, t->corres[l], (float)MAX_DEPTH_DELTA));
+        const int first_at_level = q == 0 || sched[q - 1] != l;   // writes every DataTerm; later iterations only the candidates
+        KT_TRY(kt_rgb_residual_device(t->ctx, t->state_dev, rgbd_min_scale(l), next.dIdx[l], next.dIdy[l], last.depth_m[l], next.depth_m[l],
+                                      last.image[l], next.image[l], cols, rows, t->corres[l], (float)MAX_DEPTH_DELTA, next.cand[l],
+                                      first_at_level));
         const kt_intr li = lvl_intr(t->intr, l);
         const kt_level_k* nk = &lk[q + 1 < ns ? sched[q + 1] : l];
         if (t->cfg.use_rgbd_icp)   // ICP sums + RGB-D sums + joint solve in one launch
