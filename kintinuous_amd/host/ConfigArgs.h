@@ -32,7 +32,8 @@ class ConfigArgs {
                      "  -fod           fast odometry,  -sm static mode,  -dc no colour angle weight,  -no no overlap\n"
                      "  -f             flip colours (RGB <-> BGR)\n"
                      "  -tum           write poses with timestamps in seconds (TUM format; the .poses default)\n"
-                     "  -o <prefix>    output prefix (default: the log name)\n",
+                     "  -o <prefix>    output prefix (default: the log name)\n"
+                     "  -pcd           write every extracted slice into <prefix>.pcd (binary, x y z rgb)\n",
                      argv0.c_str());
     }
 

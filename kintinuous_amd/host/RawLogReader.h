@@ -1,7 +1,7 @@
 // RawLogReader.h -- .klg reader (utils/LogReader.h, utils/RawLogReader.cpp:21-150): int32 numFrames, then per frame
 // int64 timestamp, int32 depthSize, int32 imageSize, depth bytes, image bytes.  Depth: raw u16 (depthSize == 2*W*H) or a
-// zlib stream; image: raw rgb24 (imageSize == 3*W*H), absent (imageSize == 0 -> zeros); JPEG payloads are rejected (no
-// decoder in this build).  hasMore() keeps the reference's off-by-one: the last frame of a log is never returned.
+// zlib stream; image: raw rgb24 (imageSize == 3*W*H), absent (imageSize == 0 -> zeros) or a JPEG stream (cvDecodeImage in the
+// reference, JpegDecoder.h here).  hasMore() keeps the reference's off-by-one: the last frame of a log is never returned.
 #pragma once
 
 #include <stdint.h>
@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "ConfigArgs.h"
+#include "JpegDecoder.h"
 #include "Resolution.h"
 
 class LogReader {
@@ -80,7 +81,14 @@ class RawLogReader : public LogReader {
         if (imageSize > 0 && std::fread(scratch.data(), (size_t)imageSize, 1, fp) != 1) { returnVal = false; return false; }
         if ((size_t)imageSize == n * 3) std::memcpy(imageBuffer.data(), scratch.data(), n * 3);
         else if (imageSize == 0) std::memset(imageBuffer.data(), 0, n * 3);
-        else { std::fprintf(stderr, "JPEG-compressed .klg images are not supported by this build\n"); std::exit(1); }
+        else {  // RawLogReader.cpp:81-86: anything else is handed to cvDecodeImage -> B G R bytes
+            std::string err;
+            if (!kt::jpeg::decodeBGR(scratch.data(), (size_t)imageSize, Resolution::get().width(), Resolution::get().height(), imageBuffer.data(), &err)) {
+                std::fprintf(stderr, "cannot decode the colour image of frame %d: %s\n", currentFrame, err.c_str());
+                std::exit(1);
+            }
+            isCompressed = true;
+        }
         if (ConfigArgs::get().flipColors)  // RawLogReader.cpp:118-121 (cv::cvtColor RGB2BGR)
             for (size_t i = 0; i < n; ++i) { unsigned char t = imageBuffer[i * 3]; imageBuffer[i * 3] = imageBuffer[i * 3 + 2]; imageBuffer[i * 3 + 2] = t; }
         ++currentFrame;

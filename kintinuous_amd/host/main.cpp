@@ -1,7 +1,7 @@
 // kintinuous_hip -- headless driver of the tracking + fusion path over a .klg log: the part of the reference's
 // `Kintinuous -l log.klg [-c calib] [-s size] [-t shift] [-r|-ri] [-fod] [-sm] ...` run (src/Kintinuous.cpp,
 // MainController.cpp:73-170) that ends at the CloudSlices and the .poses file.  Extra options: -n <N>, -w/-h, -o <prefix>,
-// -ops (compose every frame from the internal.h operators instead of the device-resident tracker).
+// -ops (compose every frame from the internal.h operators instead of the device-resident tracker), -pcd (write <prefix>.pcd).
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -22,12 +22,35 @@ static Intr loadCalibration(const std::string& file, int width, int height)
     return k;
 }
 
+// <prefix>.pcd: every extracted slice appended into one binary PCD in pcl::PointXYZRGB field order (x y z rgb; rgb = the packed
+// b, g, r, a bytes viewed as a float, as pcl::io::savePCDFile(..., true) writes it).  The reference saves the backend's
+// processed cloud (normals + voxel grid, CloudSliceProcessor.cpp:180-231); this is the tracker's raw output in the same container.
+static bool writePcd(const std::string& file, const std::vector<CloudSlice*>& slices)
+{
+    size_t n = 0;
+    for (size_t i = 0; i < slices.size(); ++i) n += slices[i]->cloud->size();
+    FILE* f = std::fopen(file.c_str(), "wb");
+    if (!f) return false;
+    std::fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+                    "WIDTH %zu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA binary\n", n, n);
+    for (size_t i = 0; i < slices.size(); ++i)
+        for (size_t k = 0; k < slices[i]->cloud->size(); ++k) {
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(&(*slices[i]->cloud)[k]);
+            std::fwrite(p, 1, 12, f);        // x y z
+            std::fwrite(p + 16, 1, 4, f);    // b g r a
+        }
+    return std::fclose(f) == 0;
+}
+
 int main(int argc, char** argv)
 {
     const ConfigArgs& args = ConfigArgs::get(argc, argv);
     if (args.help || args.logFile.empty()) { ConfigArgs::usage(argv[0]); return args.help ? 0 : 1; }
-    bool ops = false;
-    for (int i = 1; i < argc; ++i) ops = ops || std::string(argv[i]) == "-ops";
+    bool ops = false, pcd = false;
+    for (int i = 1; i < argc; ++i) {
+        ops = ops || std::string(argv[i]) == "-ops";
+        pcd = pcd || std::string(argv[i]) == "-pcd";
+    }
 
     Resolution::get(args.width, args.height);
     Volume::get(args.volumeSize, args.volumeResolution);
@@ -45,6 +68,7 @@ int main(int argc, char** argv)
     KintinuousTracker* fe = tracker.getFrontend();
     size_t points = 0;
     for (size_t i = 0; i < fe->getCloudSlices().size(); ++i) points += fe->getCloudSlices()[i]->cloud->size();
+    if (pcd && !writePcd(args.saveFile + ".pcd", fe->getCloudSlices())) std::fprintf(stderr, "cannot write %s.pcd\n", args.saveFile.c_str());
     const kt::Vector3f cam = fe->getCurrentGlobalCamera();
     std::printf("frames %d  slices %zu  points %zu  last camera %.6f %.6f %.6f  %.1f frames/s (incl. file I/O and uploads)  path %s\n", frames,
                 fe->getCloudSlices().size(), points, cam(0), cam(1), cam(2), frames / sec, ops ? "operators" : "device-resident");

@@ -15,7 +15,11 @@ from typing import Iterator, Tuple
 import numpy as np
 
 
-def write_klg(path: str, frames, timestamps=None, cols: int = 640, rows: int = 480, compress_depth: bool = False) -> None:
+def write_klg(path: str, frames, timestamps=None, cols: int = 640, rows: int = 480, compress_depth: bool = False,
+              jpeg_quality: int = 0) -> None:
+    """jpeg_quality > 0: the colour image is stored as a baseline JPEG (what the reference's Logger2 records; needs zlib depth,
+    RawLogReader.cpp:99-108), encoded by kintinuous_amd/jpeg_ref.py."""
+    assert not jpeg_quality or compress_depth
     with open(path, "wb") as f:
         f.write(struct.pack("<i", len(frames)))
         for k, (depth, rgb) in enumerate(frames):
@@ -25,6 +29,9 @@ def write_klg(path: str, frames, timestamps=None, cols: int = 640, rows: int = 4
             assert len(d) == 2 * cols * rows and len(img) == 3 * cols * rows
             if compress_depth:
                 d = zlib.compress(d)
+            if jpeg_quality:
+                from . import jpeg_ref
+                img = jpeg_ref.encode(np.ascontiguousarray(rgb, dtype=np.uint8).reshape(rows, cols, 3), quality=jpeg_quality)
             f.write(struct.pack("<qii", ts, len(d), len(img)))
             f.write(d)
             f.write(img)
@@ -53,8 +60,10 @@ def read_klg(path: str, cols: int = 640, rows: int = 480, reference_quirk: bool 
                 rgb = np.frombuffer(img, dtype=np.uint8).reshape(rows, cols, 3)
             elif isz == 0:
                 rgb = np.zeros((rows, cols, 3), np.uint8)
-            else:
-                raise NotImplementedError("JPEG-compressed .klg images need a JPEG decoder (not available here)")
+            else:  # cvDecodeImage in the reference: B G R bytes of the JPEG stream
+                from . import jpeg_ref
+                rgb = jpeg_ref.decode(img)
+                assert rgb.shape == (rows, cols, 3)
             yield ts, depth.copy(), rgb.copy()
 
 
@@ -65,3 +74,19 @@ def write_poses(path: str, poses) -> None:
         for ts, t, q in poses:
             f.write("%.6f " % (ts / 1000000.0))
             f.write(" ".join("%g" % v for v in list(t) + list(q)) + "\n")
+
+
+def read_pcd(path: str) -> np.ndarray:
+    """Binary x y z rgb PCD (what `kintinuous_hip -pcd` writes) -> structured array {xyz float32[3], bgra uint8[4]}."""
+    with open(path, "rb") as f:
+        n = None
+        while True:
+            line = f.readline().decode("ascii").strip()
+            if line.startswith("FIELDS"):
+                assert line.split()[1:] == ["x", "y", "z", "rgb"], line
+            if line.startswith("POINTS"):
+                n = int(line.split()[1])
+            if line.startswith("DATA"):
+                assert line.split()[1] == "binary", line
+                break
+        return np.frombuffer(f.read(16 * n), dtype=np.dtype([("xyz", np.float32, 3), ("bgra", np.uint8, 4)]), count=n)

@@ -80,11 +80,18 @@ def test_shifting_log_slices(tmp_path):
     frames = [synth.render(scene, cam, *traj[i]) for i in idx]
     log, calib = _make_log(tmp_path, cam, frames)
     common = ["-l", log, "-c", calib, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "7", "-t", "3"]
-    a = _summary(_run(common + ["-o", str(tmp_path / "dev")], str(tmp_path)))
-    b = _summary(_run(common + ["-o", str(tmp_path / "ops"), "-ops"], str(tmp_path)))
+    a = _summary(_run(common + ["-o", str(tmp_path / "dev"), "-pcd"], str(tmp_path)))
+    b = _summary(_run(common + ["-o", str(tmp_path / "ops"), "-ops", "-pcd"], str(tmp_path)))
     assert a == b
     assert a["slices"] >= 5 and a["points"] > 0      # X+ / X- shifts + FINAL
     assert open(tmp_path / "dev.poses").read() == open(tmp_path / "ops.poses").read()
+    # -pcd: every slice point, x y z rgb; both paths extract the same point set (the order inside a slice is free)
+    from kintinuous_amd import klg
+    pa, pb = klg.read_pcd(str(tmp_path / "dev.pcd")), klg.read_pcd(str(tmp_path / "ops.pcd"))
+    assert len(pa) == a["points"] == len(pb)
+    key = lambda p: np.sort(np.ascontiguousarray(p).view(np.dtype((np.void, p.dtype.itemsize))).ravel())
+    assert np.array_equal(key(pa), key(pb))
+    assert np.isfinite(pa["xyz"]).all() and pa["bgra"][:, :3].any()
 
 
 def test_ground_truth_trajectory_cli(ctx, tmp_path):
@@ -125,4 +132,34 @@ def test_ground_truth_trajectory_cli(ctx, tmp_path):
     # ground truth keeps the camera on the rendered orbit
     R, t, _ = trk.pose()
     assert np.abs(t - (poses[-1][1] - poses[0][1] + 3.0)).max() < 1e-4
+    trk.close()
+
+
+def test_logger2_style_log_with_jpeg_colour(ctx, tmp_path):
+    """zlib depth + JPEG colour (what the reference's logger records): the C++ reader decodes the colour with JpegDecoder.h; the
+    RGB-D + ICP odometry then sees the same bytes as a Python run on frames decoded by the numpy reference decoder."""
+    from kintinuous_amd import abi, klg, synth
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("room")
+    frames = [synth.render(scene, cam, R, c) for (R, c) in synth.orbit_trajectory(6)]
+    log = str(tmp_path / "jpeg.klg")
+    klg.write_klg(log, list(frames) + [frames[-1]], cols=cam.cols, rows=cam.rows, compress_depth=True, jpeg_quality=92)
+    calib = str(tmp_path / "calib.txt")
+    with open(calib, "w") as f:
+        f.write(f"{cam.fx!r} {cam.fy!r} {cam.cx!r} {cam.cy!r}\n")
+    out = _summary(_run(["-l", log, "-c", calib, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "6", "-ri", "-o", str(tmp_path / "j")],
+                        str(tmp_path)))
+    assert out["frames"] == len(frames)
+    P = _poses(tmp_path / "j.poses")
+    decoded = list(klg.read_klg(log, cols=cam.cols, rows=cam.rows))
+    assert len(decoded) == len(frames)
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 1, 0, 0, 0)
+    trk = abi.Tracker(ctx, cfg)
+    for k, (ts, d, rgb) in enumerate(decoded):
+        assert np.array_equal(d, frames[k][0])
+        assert not np.array_equal(rgb, frames[k][1]) and np.abs(rgb.astype(int) - frames[k][1].astype(int)).mean() < 4   # lossy, but close
+        trk.process_frame_host(d, rgb, ts)
+        if k >= 1:
+            _, _, gc = trk.pose()
+            assert np.allclose(P[k - 1, 1:4], gc, rtol=2e-6, atol=1e-6)
     trk.close()

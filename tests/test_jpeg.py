@@ -1,0 +1,107 @@
+"""CPU: the .klg colour decoder (kintinuous_amd/host/JpegDecoder.h, the stand-in for cvDecodeImage in RawLogReader) against an
+independent numpy restatement of libjpeg's default decode path (kintinuous_amd/jpeg_ref.py): byte-identical output for every
+stream layout the encoder can produce; the integer IDCT path within 2 grey levels of a double-precision decode; decent PSNR
+against the source image.  No libjpeg in this image: parity with the real library is unpinned (both sides restate the same
+published algorithms)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tool():
+    from kintinuous_amd import build
+    build.build_host()
+    assert os.path.exists(build.JPEG_TOOL)
+    return build.JPEG_TOOL
+
+
+def _cxx_decode(tool, data, w, h, tmp_path, name="x"):
+    src, dst = tmp_path / f"{name}.jpg", tmp_path / f"{name}.bgr"
+    src.write_bytes(data)
+    r = subprocess.run([tool, str(src), str(w), str(h), str(dst)], capture_output=True, text=True, timeout=60)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return np.frombuffer(dst.read_bytes(), np.uint8).reshape(h, w, 3)
+
+
+def _images():
+    from kintinuous_amd import synth
+    cam = synth.Camera.small(160, 120)
+    _, rgb = synth.render(synth.Scene("room"), cam, *synth.orbit_trajectory(2)[0])
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (23, 37, 3), dtype=np.uint8)            # ragged size, worst-case content
+    yy, xx = np.mgrid[0:50, 0:67]
+    ramp = np.stack([(xx * 3) % 256, (yy * 5) % 256, (xx + yy) % 256], -1).astype(np.uint8)
+    return {"render": np.ascontiguousarray(rgb), "noise": noise, "ramp": ramp}
+
+
+@pytest.mark.parametrize("sub", ["420", "422", "444"])
+@pytest.mark.parametrize("name", ["render", "noise", "ramp"])
+def test_decoder_matches_reference_restatement(tool, tmp_path, name, sub):
+    from kintinuous_amd import jpeg_ref
+    img = _images()[name]
+    h, w = img.shape[:2]
+    data = jpeg_ref.encode(img, quality=90, subsampling=sub)
+    got = _cxx_decode(tool, data, w, h, tmp_path)
+    ref = jpeg_ref.decode(data)
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} bytes differ"
+    flt = jpeg_ref.decode(data, float_idct=True)
+    d = np.abs(ref.astype(int) - flt.astype(int))
+    assert d.max() <= 3 and (d > 1).mean() < 0.01
+    if name != "noise":
+        mse = np.mean((ref.astype(float) - img.astype(float)) ** 2)
+        assert 10 * np.log10(255 ** 2 / mse) > 30
+
+
+@pytest.mark.parametrize("kw", [dict(restart_interval=3), dict(ac_table="skewed"), dict(interleaved=False), dict(quality=35),
+                                dict(restart_interval=1, subsampling="422", ac_table="skewed")])
+def test_stream_layouts(tool, tmp_path, kw):
+    from kintinuous_amd import jpeg_ref
+    img = _images()["ramp"]
+    h, w = img.shape[:2]
+    data = jpeg_ref.encode(img, **kw)
+    assert np.array_equal(_cxx_decode(tool, data, w, h, tmp_path), jpeg_ref.decode(data))
+
+
+def test_grey_and_errors(tool, tmp_path):
+    from kintinuous_amd import jpeg_ref
+    img = _images()["ramp"]
+    h, w = img.shape[:2]
+    data = jpeg_ref.encode(img[..., 1].copy())
+    got = _cxx_decode(tool, data, w, h, tmp_path)
+    assert np.array_equal(got, jpeg_ref.decode(data)) and np.array_equal(got[..., 0], got[..., 2])
+    good = jpeg_ref.encode(img)
+    with pytest.raises(RuntimeError, match="size differs"):
+        _cxx_decode(tool, good, w + 1, h, tmp_path)
+    with pytest.raises(RuntimeError, match="SOI"):
+        _cxx_decode(tool, b"not a jpeg at all", w, h, tmp_path)
+    # truncated and bit-flipped streams must fail cleanly or decode to something -- never crash
+    rng = np.random.default_rng(0)
+    for k in range(40):
+        bad = bytearray(good if k % 2 else good[: rng.integers(20, len(good))])
+        for _ in range(3):
+            bad[rng.integers(2, len(bad))] = rng.integers(0, 256)
+        src, dst = tmp_path / "bad.jpg", tmp_path / "bad.bgr"
+        src.write_bytes(bytes(bad))
+        r = subprocess.run([tool, str(src), str(w), str(h), str(dst)], capture_output=True, text=True, timeout=60)
+        assert r.returncode in (0, 1), (k, r.returncode, r.stderr)
+
+
+def test_klg_with_jpeg_colour_round_trip(tool, tmp_path):
+    """write_klg(jpeg_quality=...) produces Logger2-style frames (zlib depth + JPEG colour) and read_klg decodes them with the same
+    reference decoder the C++ reader is tested against."""
+    from kintinuous_amd import jpeg_ref, klg, synth
+    cam = synth.Camera.small(160, 120)
+    frames = [synth.render(synth.Scene("room"), cam, *p) for p in synth.orbit_trajectory(3)]
+    path = str(tmp_path / "j.klg")
+    klg.write_klg(path, frames, cols=cam.cols, rows=cam.rows, compress_depth=True, jpeg_quality=90)
+    back = list(klg.read_klg(path, cols=cam.cols, rows=cam.rows, reference_quirk=False))
+    assert len(back) == len(frames)
+    for (ts, d, rgb), (d0, rgb0) in zip(back, frames):
+        assert np.array_equal(d, d0)
+        assert np.array_equal(rgb, jpeg_ref.decode(jpeg_ref.encode(np.ascontiguousarray(rgb0), quality=90)))
