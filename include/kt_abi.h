@@ -87,6 +87,13 @@ int kt_transform_maps(kt_ctx* ctx, const float* vmap_src, const float* nmap_src,
 /* resizeVMap / resizeNMap  internal.h:453,460 / maps.cu:279-308; out is (in_cols/2) x (in_rows/2) */
 int kt_resize_vmap(kt_ctx* ctx, const float* in, int in_cols, int in_rows, float* out);
 int kt_resize_nmap(kt_ctx* ctx, const float* in, int in_cols, int in_rows, float* out);
+/* generateImage  internal.h:435 / image_generator.cu:56-179: shaded + colour views of a predicted map (vmap_curr_color = the uchar4
+ * raycast colour output); dst / dst_color are rgb24 [rows][cols][3].  light_number <= 1 (LightSource holds one position). */
+int kt_generate_image(kt_ctx* ctx, const float* vmap, const float* nmap, const uint8_t* vmap_curr_color, int cols, int rows,
+                      const float light_pos[3], int light_number, uint8_t* dst_rgb24, uint8_t* dst_color_rgb24);
+/* generateDepth  internal.h:442 / image_generator.cu:181-219: depth image (mm) of a predicted map seen from pose (R_inv, t) */
+int kt_generate_depth(kt_ctx* ctx, const kt_mat33* R_inv, const float t[3], const float* vmap, const float* nmap, int cols, int rows,
+                      uint16_t* dst);
 /* shortDepthToMetres  internal.h:313 / bilateral_pyrdown.cu:404-411 */
 int kt_depth_to_metres(kt_ctx* ctx, const uint16_t* src, float* dst, int cols, int rows, int cutoff);
 /* imageBGRToIntensity  internal.h:315 / bilateral_pyrdown.cu:413-420; src = rgb24 */
@@ -218,6 +225,8 @@ int16_t* kt_tracker_volume(kt_tracker* t);
 uint8_t* kt_tracker_color_volume(kt_tracker* t);
 float* kt_tracker_vmap_g_prev(kt_tracker* t, int level);
 float* kt_tracker_nmap_g_prev(kt_tracker* t, int level);
+/* vmap_curr_color: the raycast's uchar4 colour + weight image of the last frame (input of kt_generate_image) */
+uint8_t* kt_tracker_vmap_curr_color(kt_tracker* t);
 float kt_tracker_trunc_dist(kt_tracker* t);
 /* profiling: on = 0 off, 1 = time only the tsdf23 voxel kernel (2 event records per frame), 2 = all stages.
  * kt_tracker_stage_ms returns the MEAN milliseconds per frame since profiling was enabled (hipEvent pairs on

@@ -83,6 +83,8 @@ _PROTOS = {
     "kt_transform_maps": (_i, [_vp, _vp, _vp, _i, _i, _pM, _pf, _vp, _vp]),
     "kt_resize_vmap": (_i, [_vp, _vp, _i, _i, _vp]),
     "kt_resize_nmap": (_i, [_vp, _vp, _i, _i, _vp]),
+    "kt_generate_image": (_i, [_vp, _vp, _vp, _vp, _i, _i, _pf, _i, _vp, _vp]),
+    "kt_generate_depth": (_i, [_vp, _pM, _pf, _vp, _vp, _i, _i, _vp]),
     "kt_depth_to_metres": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "kt_bgr_to_intensity": (_i, [_vp, _vp, _vp, _i, _i]),
     "kt_pyr_down_gauss_f32": (_i, [_vp, _vp, _i, _i, _vp]),
@@ -116,6 +118,7 @@ _PROTOS = {
     "kt_tracker_volume": (_vp, [_vp]),
     "kt_tracker_color_volume": (_vp, [_vp]),
     "kt_tracker_vmap_g_prev": (_vp, [_vp, _i]),
+    "kt_tracker_vmap_curr_color": (_vp, [_vp]),
     "kt_tracker_nmap_g_prev": (_vp, [_vp, _i]),
     "kt_tracker_trunc_dist": (_f, [_vp]),
     "kt_tracker_enable_profiling": (_i, [_vp, _i]),
@@ -257,6 +260,12 @@ class Ctx:
 
     def resize_nmap(self, src, in_cols, in_rows, dst) -> None:
         _chk(lib().kt_resize_nmap(self.h, src.ptr, in_cols, in_rows, dst.ptr))
+
+    def generate_image(self, vmap, nmap, vmap_color, cols, rows, light_pos, light_number, dst, dst_color) -> None:
+        _chk(lib().kt_generate_image(self.h, vmap.ptr, nmap.ptr, vmap_color.ptr, cols, rows, _fp(light_pos), light_number, dst.ptr, dst_color.ptr))
+
+    def generate_depth(self, R_inv, t, vmap, nmap, cols, rows, dst) -> None:
+        _chk(lib().kt_generate_depth(self.h, C.byref(Mat33.from_np(R_inv)), _fp(t), vmap.ptr, nmap.ptr, cols, rows, dst.ptr))
 
     def depth_to_metres(self, src, dst, cols, rows, cutoff) -> None:
         _chk(lib().kt_depth_to_metres(self.h, src.ptr, dst.ptr, cols, rows, cutoff))

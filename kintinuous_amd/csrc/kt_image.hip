@@ -492,6 +492,96 @@ extern "C" int kt_project_to_cloud(kt_ctx* c, const float* depth, int cols, int 
 }
 
 // ================================================================================================
+// view products: generateImage -> generateImageKernel (image_generator.cu:56-179), generateDepth -> generateDepthKernel
+// (image_generator.cu:181-219).  Off the tracked path; they complete the internal.h surface (getImage / getModelDepth).
+// ================================================================================================
+__device__ __forceinline__ void kt_heat_map_color(float value, int& red, int& green, int& blue)
+{
+    const float color[4][3] = {{0, 0, 1}, {0, 1, 0}, {1, 1, 0}, {1, 0, 0}};
+    int idx1, idx2;
+    float fract = 0;
+    if (value <= 0) idx1 = idx2 = 0;
+    else if (value >= 1) idx1 = idx2 = 3;
+    else {
+        value = value * 3;
+        idx1 = (int)__builtin_floorf(value);
+        idx2 = idx1 + 1;
+        fract = value - (float)idx1;
+    }
+    red = kt_f2i_rz(__builtin_fmaf(color[idx2][0] - color[idx1][0], fract, color[idx1][0]) * 235.0f);
+    green = kt_f2i_rz(__builtin_fmaf(color[idx2][1] - color[idx1][1], fract, color[idx1][1]) * 235.0f);
+    blue = kt_f2i_rz(__builtin_fmaf(color[idx2][2] - color[idx1][2], fract, color[idx1][2]) * 235.0f);
+}
+
+__global__ __launch_bounds__(256) void kt_generate_image_kernel(const float* __restrict__ vmap, const float* __restrict__ nmap,
+                                                                const uchar4* __restrict__ vcol, int cols, int rows, f3 light, int nlights,
+                                                                uint8_t* __restrict__ dst, uint8_t* __restrict__ dst_color)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const float vx = vmap[y * cols + x], nx = nmap[y * cols + x];
+    const uchar4 cc = vcol[y * cols + x];
+    const bool ok = !kt_isnan(vx) && !kt_isnan(nx);
+    uint8_t* oc = &dst_color[3 * (y * cols + x)];
+    oc[0] = ok ? cc.x : 0; oc[1] = ok ? cc.y : 0; oc[2] = ok ? cc.z : 0;
+    uint8_t s0 = 0, s1 = 0, s2 = 0;
+    if (ok) {
+        const f3 v = {vx, vmap[(y + rows) * cols + x], vmap[(y + 2 * rows) * cols + x]};
+        const f3 n = {nx, nmap[(y + rows) * cols + x], nmap[(y + 2 * rows) * cols + x]};
+        float weight = 1.f;
+        for (int i = 0; i < nlights; ++i) weight *= fabsf(kt_dot(kt_normalized(kt_sub(light, v)), n));
+        int r, g, b;
+        kt_heat_map_color((float)cc.w / 128.0f, r, g, b);
+        s0 = (uint8_t)kt_f2i_rz(__builtin_fmaf((float)b, weight, 20.f));
+        s1 = (uint8_t)kt_f2i_rz(__builtin_fmaf((float)g, weight, 20.f));
+        s2 = (uint8_t)kt_f2i_rz(__builtin_fmaf((float)r, weight, 20.f));
+    }
+    uint8_t* o = &dst[3 * (y * cols + x)];
+    o[0] = s0; o[1] = s1; o[2] = s2;
+}
+
+extern "C" int kt_generate_image(kt_ctx* c, const float* vmap, const float* nmap, const uint8_t* vmap_curr_color, int cols, int rows,
+                                 const float light_pos[3], int light_number, uint8_t* dst_rgb24, uint8_t* dst_color_rgb24)
+{
+    KT_ARG(c && vmap && nmap && vmap_curr_color && light_pos && dst_rgb24 && dst_color_rgb24 && cols > 0 && rows > 0);
+    KT_ARG(light_number >= 0 && light_number <= 1);   // LightSource holds one position (internal.h:289-293)
+    const f3 light = {light_pos[0], light_pos[1], light_pos[2]};
+    hipLaunchKernelGGL(kt_generate_image_kernel, dim3(kt_div_up(cols, 64), kt_div_up(rows, 4)), dim3(256), 0, c->stream, vmap, nmap,
+                       (const uchar4*)vmap_curr_color, cols, rows, light, light_number, dst_rgb24, dst_color_rgb24);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+__global__ __launch_bounds__(256) void kt_generate_depth_kernel(f3 rinv_row3, f3 t, const float* __restrict__ vmap, const float* __restrict__ nmap,
+                                                                int cols, int rows, uint16_t* __restrict__ depth)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    uint16_t result = 0;
+    const float vx = vmap[y * cols + x], nx = nmap[y * cols + x];
+    if (!kt_isnan(vx) && !kt_isnan(nx)) {
+        const f3 vg = {vx, vmap[(y + rows) * cols + x], vmap[(y + 2 * rows) * cols + x]};
+        const float m = kt_dot(rinv_row3, kt_sub(vg, t)) * 1000;
+        // static_cast<unsigned short>(float) as cvt.rzi.u16.f32: truncate, clamp to [0, 65535], NaN -> 0
+        result = (m != m || m <= 0.0f) ? 0 : (m >= 65535.0f ? 65535 : (uint16_t)kt_f2i_rz(m));
+    }
+    depth[y * cols + x] = result;
+}
+
+extern "C" int kt_generate_depth(kt_ctx* c, const kt_mat33* R_inv, const float t[3], const float* vmap, const float* nmap, int cols, int rows,
+                                 uint16_t* dst)
+{
+    KT_ARG(c && R_inv && t && vmap && nmap && dst && cols > 0 && rows > 0);
+    const f3 row3 = {R_inv->m[6], R_inv->m[7], R_inv->m[8]}, tt = {t[0], t[1], t[2]};
+    hipLaunchKernelGGL(kt_generate_depth_kernel, dim3(kt_div_up(cols, 64), kt_div_up(rows, 4)), dim3(256), 0, c->stream, row3, tt, vmap, nmap,
+                       cols, rows, dst);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// ================================================================================================
 // Fused pyramid build: pyrDown x3 + createVMap x4 + createNMap x4 in ONE launch
 // (KintinuousTracker.cpp:469-478 issues 11 kernels for this; each is launch-latency bound at VGA).
 // One workgroup owns a 4x4 tile of level 3 (= 8x8 / 16x16 / 32x32 at levels 2 / 1 / 0).  The level-0 depth it needs,

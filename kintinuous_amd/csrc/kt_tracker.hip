@@ -1240,6 +1240,7 @@ int16_t* kt_tracker_volume(kt_tracker* t) { return (t && complete_frame(t) == KT
 uint8_t* kt_tracker_color_volume(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? t->color : nullptr; }
 float* kt_tracker_vmap_g_prev(kt_tracker* t, int l) { return (t && l >= 0 && l < KT_LEVELS && complete_frame(t) == KT_OK) ? t->vmaps_g_prev[l] : nullptr; }
 float* kt_tracker_nmap_g_prev(kt_tracker* t, int l) { return (t && l >= 0 && l < KT_LEVELS && complete_frame(t) == KT_OK) ? t->nmaps_g_prev[l] : nullptr; }
+uint8_t* kt_tracker_vmap_curr_color(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? t->vmap_curr_color : nullptr; }
 float kt_tracker_trunc_dist(kt_tracker* t) { return t ? t->tranc_dist : 0.f; }
 
 int kt_tracker_enable_profiling(kt_tracker* t, int on)

@@ -33,7 +33,8 @@ class ConfigArgs {
                      "  -f             flip colours (RGB <-> BGR)\n"
                      "  -tum           write poses with timestamps in seconds (TUM format; the .poses default)\n"
                      "  -o <prefix>    output prefix (default: the log name)\n"
-                     "  -pcd           write every extracted slice into <prefix>.pcd (binary, x y z rgb)\n",
+                     "  -pcd           write every extracted slice into <prefix>.pcd (binary, x y z rgb)\n"
+                     "  -ppm           write the final model views: <prefix>_model.ppm, _color.ppm, _depth.pgm\n",
                      argv0.c_str());
     }
 

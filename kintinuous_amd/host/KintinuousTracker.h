@@ -5,8 +5,8 @@
 //   * operator path (operatorPath = true): the frame is composed on the host from the internal.h operators exactly as the
 //     reference composes it (bilateralFilter, pyrDown, createVMap, ..., ICPOdometry, integrateTsdfVolume, raycast,
 //     resizeVMap) -- the drop-in granularity of the reference, one sync per operator.  ICP odometry only.
-// Not carried over: GUI image generation (getImage / getModelDepth / liveTsdf), place-recognition buffering and the
-// ground-truth trajectory provider: they are outside the tracked path.
+// getImage / getModelDepth (KintinuousTracker.cpp:960-981) render the predicted maps without OpenGL; -p ground truth is handled by
+// the device-resident path.  Not carried over: liveTsdf and place-recognition buffering (outside the tracked path).
 #pragma once
 
 #include <climits>
@@ -135,6 +135,40 @@ class KintinuousTracker {
         if (global_time_ == before) return;  // dropped by the ground-truth trajectory lookup (:460-463)
         if (global_time_ > 1 && ConfigArgs::get().saveFile.size()) outputPose(timestamp, lastRotation);
     }
+
+    // KintinuousTracker.cpp:960-969: shaded + colour view of the current predicted map into modelSurface / modelColor
+    void getImage()
+    {
+        LightSource light;
+        light.number = 1;
+        const float vs = Volume::get().getVolumeSize();
+        light.pos[0].x = vs * (-3.f); light.pos[0].y = vs * (-3.f); light.pos[0].z = vs * (-3.f);
+        if (operatorPath) { generateImage(vmaps_g_prev_[0], nmaps_g_prev_[0], vmap_curr_color, light, modelSurface, modelColor); return; }
+        ensureFast();
+        const int rows = Resolution::get().rows(), cols = Resolution::get().cols();
+        modelSurface.create(rows, cols);
+        modelColor.create(rows, cols);
+        ktSafeCall(kt_generate_image(kt::device::context(), kt_tracker_vmap_g_prev(fast, 0), kt_tracker_nmap_g_prev(fast, 0),
+                                     kt_tracker_vmap_curr_color(fast), cols, rows, kt::abi(light.pos[0]), light.number, &modelSurface.ptr()->r,
+                                     &modelColor.ptr()->r));
+    }
+    // KintinuousTracker.cpp:971-981: depth (mm) of the predicted map from the current pose, into modelDepth / modelDepthHost
+    void getModelDepth()
+    {
+        kt::Matrix3f Rinv;
+        kt_host_mat33_inverse(lastRotation.data(), Rinv.data());
+        const int rows = Resolution::get().rows(), cols = Resolution::get().cols();
+        modelDepth.create(rows, cols);
+        const float* v = operatorPath ? vmaps_g_prev_[0].ptr() : (ensureFast(), kt_tracker_vmap_g_prev(fast, 0));
+        const float* n = operatorPath ? nmaps_g_prev_[0].ptr() : kt_tracker_nmap_g_prev(fast, 0);
+        ktSafeCall(kt_generate_depth(kt::device::context(), reinterpret_cast<const kt_mat33*>(Rinv.data()), lastTranslation.data(), v, n, cols, rows,
+                                     modelDepth.ptr()));
+        int c;
+        modelDepth.download(modelDepthHost, c);
+    }
+    DeviceArray2D<PixelRGB> modelSurface, modelColor;   // KintinuousTracker.h:231-235
+    DeviceArray2D<unsigned short> modelDepth;
+    std::vector<unsigned short> modelDepthHost;
 
     kt::Vector3f getVolumeOffset() const { return volumeBasisValue(); }
     void setParked(const bool park)

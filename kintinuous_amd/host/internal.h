@@ -169,6 +169,26 @@ inline void raycast(const Intr& intr, const Mat33& Rcurr, const float3& tcurr, f
                           vmap.ptr(), nmap.ptr(), cols, rows, kt::abi(voxelWrap), &vmap_curr_color.ptr()->x,
                           &color_volume.ptr()->x, kt::volN(volume)));
 }
+// internal.h:284-293, 435-442: view products (KintinuousTracker::getImage / getModelDepth)
+struct LightSource { float3 pos[1]; int number; };
+inline void generateImage(const DeviceArray2D<float>& vmap, const DeviceArray2D<float>& nmap, const DeviceArray2D<uchar4>& vmap_curr_color,
+                          const LightSource& light, DeviceArray2D<PixelRGB>& dst, DeviceArray2D<PixelRGB>& dstColor)
+{
+    const int cols = vmap.cols(), rows = vmap.rows() / 3;
+    dst.create(rows, cols);
+    dstColor.create(rows, cols);
+    ktSafeCall(kt_generate_image(KT_CTX, vmap.ptr(), nmap.ptr(), &vmap_curr_color.ptr()->x, cols, rows, kt::abi(light.pos[0]), light.number,
+                                 &dst.ptr()->r, &dstColor.ptr()->r));
+}
+inline void generateDepth(const Mat33& R_inv, const float3& t, const DeviceArray2D<float>& vmap, const DeviceArray2D<float>& nmap,
+                          DeviceArray2D<unsigned short>& dst, float /*maxDepth*/)
+{
+    const int cols = vmap.cols(), rows = vmap.rows() / 3;
+    dst.create(rows, cols);
+    ktSafeCall(kt_generate_depth(KT_CTX, kt::abi(R_inv), kt::abi(t), vmap.ptr(), nmap.ptr(), cols, rows, dst.ptr()));
+}
+inline int GetGridDim(int D, int B) { return (D + B - 1) / B; }  // internal.h:458 (launch arithmetic; nothing here needs it)
+
 inline size_t extractCloudSlice(const DeviceArray2D<short>& volume, const float3& volume_size, DeviceArray<PointXYZRGB>& output,
                                 int3 voxelWrap, DeviceArray2D<uchar4>& color_volume, int minX, int maxX, int minY, int maxY,
                                 int minZ, int maxZ, int subsample, int3 realVoxelWrap)

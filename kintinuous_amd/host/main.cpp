@@ -1,7 +1,7 @@
 // kintinuous_hip -- headless driver of the tracking + fusion path over a .klg log: the part of the reference's
 // `Kintinuous -l log.klg [-c calib] [-s size] [-t shift] [-r|-ri] [-fod] [-sm] ...` run (src/Kintinuous.cpp,
 // MainController.cpp:73-170) that ends at the CloudSlices and the .poses file.  Extra options: -n <N>, -w/-h, -o <prefix>,
-// -ops (compose every frame from the internal.h operators instead of the device-resident tracker), -pcd (write <prefix>.pcd).
+// -ops (compose every frame from the internal.h operators instead of the device-resident tracker), -pcd (write <prefix>.pcd), -ppm (write the model views).
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -42,14 +42,43 @@ static bool writePcd(const std::string& file, const std::vector<CloudSlice*>& sl
     return std::fclose(f) == 0;
 }
 
+// -ppm: the reference's live views of the final model, without a window: <prefix>_model.ppm (shaded), <prefix>_color.ppm (fused
+// colour), <prefix>_depth.pgm (16-bit millimetres)
+static void writeViews(KintinuousTracker* fe, const std::string& prefix)
+{
+    fe->getImage();
+    fe->getModelDepth();
+    const int rows = Resolution::get().rows(), cols = Resolution::get().cols();
+    std::vector<PixelRGB> img;
+    int c;
+    const char* names[2] = {"_model.ppm", "_color.ppm"};
+    for (int k = 0; k < 2; ++k) {
+        (k == 0 ? fe->modelSurface : fe->modelColor).download(img, c);
+        FILE* f = std::fopen((prefix + names[k]).c_str(), "wb");
+        if (!f) continue;
+        std::fprintf(f, "P6\n%d %d\n255\n", cols, rows);
+        std::fwrite(img.data(), 3, img.size(), f);
+        std::fclose(f);
+    }
+    FILE* f = std::fopen((prefix + "_depth.pgm").c_str(), "wb");
+    if (!f) return;
+    std::fprintf(f, "P5\n%d %d\n65535\n", cols, rows);
+    for (size_t i = 0; i < fe->modelDepthHost.size(); ++i) {
+        const unsigned char be[2] = {(unsigned char)(fe->modelDepthHost[i] >> 8), (unsigned char)(fe->modelDepthHost[i] & 255)};
+        std::fwrite(be, 1, 2, f);
+    }
+    std::fclose(f);
+}
+
 int main(int argc, char** argv)
 {
     const ConfigArgs& args = ConfigArgs::get(argc, argv);
     if (args.help || args.logFile.empty()) { ConfigArgs::usage(argv[0]); return args.help ? 0 : 1; }
-    bool ops = false, pcd = false;
+    bool ops = false, pcd = false, ppm = false;
     for (int i = 1; i < argc; ++i) {
         ops = ops || std::string(argv[i]) == "-ops";
         pcd = pcd || std::string(argv[i]) == "-pcd";
+        ppm = ppm || std::string(argv[i]) == "-ppm";
     }
 
     Resolution::get(args.width, args.height);
@@ -69,6 +98,7 @@ int main(int argc, char** argv)
     size_t points = 0;
     for (size_t i = 0; i < fe->getCloudSlices().size(); ++i) points += fe->getCloudSlices()[i]->cloud->size();
     if (pcd && !writePcd(args.saveFile + ".pcd", fe->getCloudSlices())) std::fprintf(stderr, "cannot write %s.pcd\n", args.saveFile.c_str());
+    if (ppm) writeViews(fe, args.saveFile);
     const kt::Vector3f cam = fe->getCurrentGlobalCamera();
     std::printf("frames %d  slices %zu  points %zu  last camera %.6f %.6f %.6f  %.1f frames/s (incl. file I/O and uploads)  path %s\n", frames,
                 fe->getCloudSlices().size(), points, cam(0), cam(1), cam(2), frames / sec, ops ? "operators" : "device-resident");

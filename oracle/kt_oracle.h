@@ -58,6 +58,10 @@ void kto_transform_maps(const float* vmap_src, const float* nmap_src, int cols, 
                         const kto_mat33* R, const float t[3], float* vmap_dst, float* nmap_dst);
 void kto_resize_vmap(const float* in, int in_cols, int in_rows, float* out);
 void kto_resize_nmap(const float* in, int in_cols, int in_rows, float* out);
+/* generateImage / generateDepth (image_generator.cu): dst, dst_color = rgb24 [rows][cols][3]; vmap_curr_color = uchar4 per pixel */
+void kto_generate_image(const float* vmap, const float* nmap, const uint8_t* vmap_curr_color, int cols, int rows,
+                        const float light_pos[3], int light_number, uint8_t* dst, uint8_t* dst_color);
+void kto_generate_depth(const kto_mat33* R_inv, const float t[3], const float* vmap, const float* nmap, int cols, int rows, uint16_t* dst);
 
 /* ---- a10 helpers: RGB-D image pyramids ---- */
 void kto_depth_to_metres(const uint16_t* src, float* dst, int cols, int rows, int cutoff);

@@ -222,6 +222,79 @@ void kto_create_nmap(const float* vmap, int cols, int rows, float* nmap)
 }
 
 /* ================================================================================================
+ * view products (internal.h:435-442): generateImage -> generateImageKernel (image_generator.cu:56-179),
+ * generateDepth -> generateDepthKernel (image_generator.cu:181-219).  Not on the tracked path: they complete the internal.h surface
+ * (KintinuousTracker::getImage / getModelDepth, KintinuousTracker.cpp:960-981).
+ * ============================================================================================== */
+static void heat_map_color(float value, int* red, int* green, int* blue)
+{
+    static const float color[4][3] = {{0, 0, 1}, {0, 1, 0}, {1, 1, 0}, {1, 0, 0}};
+    int idx1, idx2;
+    float fract = 0;
+    if (value <= 0) idx1 = idx2 = 0;
+    else if (value >= 1) idx1 = idx2 = 3;
+    else {
+        value = value * 3;
+        idx1 = (int)floorf(value);
+        idx2 = idx1 + 1;
+        fract = value - (float)idx1;
+    }
+    *red = kto_f2i_rz(fmaf(color[idx2][0] - color[idx1][0], fract, color[idx1][0]) * 235.0f);
+    *green = kto_f2i_rz(fmaf(color[idx2][1] - color[idx1][1], fract, color[idx1][1]) * 235.0f);
+    *blue = kto_f2i_rz(fmaf(color[idx2][2] - color[idx1][2], fract, color[idx1][2]) * 235.0f);
+}
+
+void kto_generate_image(const float* vmap, const float* nmap, const uint8_t* vmap_curr_color, int cols, int rows,
+                        const float light_pos[3], int light_number, uint8_t* dst, uint8_t* dst_color)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const float vx = vmap[y * cols + x], nx = nmap[y * cols + x];
+            const uint8_t* cc = &vmap_curr_color[4 * (y * cols + x)];
+            const int ok = !kto_isnan(vx) && !kto_isnan(nx);
+            uint8_t c3[3] = {0, 0, 0};
+            if (ok) { c3[0] = cc[0]; c3[1] = cc[1]; c3[2] = cc[2]; }
+            memcpy(&dst_color[3 * (y * cols + x)], c3, 3);
+            uint8_t s3[3] = {0, 0, 0};
+            if (ok) {
+                const float v[3] = {vx, vmap[(y + rows) * cols + x], vmap[(y + 2 * rows) * cols + x]};
+                const float n[3] = {nx, nmap[(y + rows) * cols + x], nmap[(y + 2 * rows) * cols + x]};
+                float weight = 1.f;
+                for (int i = 0; i < light_number; ++i) { /* LightSource holds one position (internal.h:289-293) */
+                    float vec[3] = {light_pos[0] - v[0], light_pos[1] - v[1], light_pos[2] - v[2]};
+                    normalize3(vec);
+                    weight *= fabsf(dot3(vec, n));
+                }
+                int r, g, b;
+                heat_map_color((float)cc[3] / 128.0f, &r, &g, &b);
+                s3[0] = (uint8_t)kto_f2i_rz(fmaf((float)b, weight, 20.f));
+                s3[1] = (uint8_t)kto_f2i_rz(fmaf((float)g, weight, 20.f));
+                s3[2] = (uint8_t)kto_f2i_rz(fmaf((float)r, weight, 20.f));
+            }
+            memcpy(&dst[3 * (y * cols + x)], s3, 3);
+        }
+}
+
+void kto_generate_depth(const kto_mat33* R_inv, const float t[3], const float* vmap, const float* nmap, int cols, int rows, uint16_t* dst)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            uint16_t result = 0;
+            const float vx = vmap[y * cols + x], nx = nmap[y * cols + x];
+            if (!kto_isnan(vx) && !kto_isnan(nx)) {
+                const float d[3] = {vx - t[0], vmap[(y + rows) * cols + x] - t[1], vmap[(y + 2 * rows) * cols + x] - t[2]};
+                const float v_z = dot3(&R_inv->m[6], d);
+                /* static_cast<unsigned short>(float): cvt.rzi.u16.f32 -- truncate, clamp to [0, 65535], NaN -> 0 */
+                const float m = v_z * 1000;
+                result = (m != m || m <= 0.0f) ? 0 : (m >= 65535.0f ? 65535 : (uint16_t)(int)m);
+            }
+            dst[y * cols + x] = result;
+        }
+}
+
+/* ================================================================================================
  * a5  tranformMaps -> tranformMapsKernel            maps.cu:156-223
  * ============================================================================================== */
 void kto_transform_maps(const float* vmap_src, const float* nmap_src, int cols, int rows,

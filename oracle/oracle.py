@@ -151,6 +151,22 @@ def resize_map(inp: np.ndarray, normalize: bool, out: np.ndarray = None) -> np.n
     return o
 
 
+def generate_image(vmap, nmap, vmap_color, light_pos, light_number: int = 1):
+    vmap, nmap, vmap_color = _c(vmap, np.float32), _c(nmap, np.float32), _c(vmap_color, np.uint8)
+    rows, cols = vmap.shape[0] // 3, vmap.shape[1]
+    dst, dst_color = np.zeros((rows, cols, 3), np.uint8), np.zeros((rows, cols, 3), np.uint8)
+    lib().kto_generate_image(_p(vmap), _p(nmap), _p(vmap_color), cols, rows, _f3(light_pos), light_number, _p(dst), _p(dst_color))
+    return dst, dst_color
+
+
+def generate_depth(R_inv, t, vmap, nmap) -> np.ndarray:
+    vmap, nmap = _c(vmap, np.float32), _c(nmap, np.float32)
+    rows, cols = vmap.shape[0] // 3, vmap.shape[1]
+    dst = np.zeros((rows, cols), np.uint16)
+    lib().kto_generate_depth(C.byref(OMat33.from_np(R_inv)), _f3(t), _p(vmap), _p(nmap), cols, rows, _p(dst))
+    return dst
+
+
 def depth_to_metres(src, cutoff: int) -> np.ndarray:
     src = _c(src, np.uint16)
     rows, cols = src.shape

@@ -52,9 +52,16 @@ def test_operator_path_equals_device_path(ctx, oracle_mod, small_scene, tmp_path
     frames = frames[:6]
     log, calib = _make_log(tmp_path, cam, frames, zlib_depth=True)
     common = ["-l", log, "-c", calib, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "6"]
-    a = _summary(_run(common + ["-o", str(tmp_path / "dev")], str(tmp_path)))
-    b = _summary(_run(common + ["-o", str(tmp_path / "ops"), "-ops"], str(tmp_path)))
+    a = _summary(_run(common + ["-o", str(tmp_path / "dev"), "-ppm"], str(tmp_path)))
+    b = _summary(_run(common + ["-o", str(tmp_path / "ops"), "-ops", "-ppm"], str(tmp_path)))
     assert a == b and a["frames"] == len(frames) and a["slices"] == 1  # FINAL slice only
+    # -ppm: getImage / getModelDepth views of the final model, identical on both paths and not blank
+    for name in ("_model.ppm", "_color.ppm", "_depth.pgm"):
+        va, vb = open(str(tmp_path / "dev") + name, "rb").read(), open(str(tmp_path / "ops") + name, "rb").read()
+        assert va == vb and len(va) > cam.cols * cam.rows
+    header = f"P6\n{cam.cols} {cam.rows}\n255\n".encode()
+    model = np.frombuffer(open(str(tmp_path / "dev_model.ppm"), "rb").read()[len(header):], np.uint8).reshape(cam.rows, cam.cols, 3)
+    assert (model.max(axis=2) >= 20).mean() > 0.5       # shaded pixels carry the +20 ambient term
     ta, tb = open(tmp_path / "dev.poses").read(), open(tmp_path / "ops.poses").read()
     assert ta == tb and len(ta.splitlines()) == len(frames) - 1
 

@@ -157,3 +157,44 @@ def test_build_pyramid_fused(ctx, oracle_mod, size):
     for l in range(4):
         assert np.array_equal(vref[l].view(np.uint32), ctx.download(gv[l], np.float32, vref[l].shape).view(np.uint32)), f"vmap level {l}"
         assert np.array_equal(nref[l].view(np.uint32), ctx.download(gn[l], np.float32, nref[l].shape).view(np.uint32)), f"nmap level {l}"
+
+
+def test_generate_image_and_depth(ctx, oracle_mod, small_scene):
+    """generateImage / generateDepth (image_generator.cu): the view products of KintinuousTracker::getImage / getModelDepth on the
+    predicted maps of a tracked sequence, plus synthetic maps that hit every branch (NaN vertex, NaN normal, every heat-map band)."""
+    from kintinuous_amd import abi
+    cam, frames, _ = small_scene
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
+    trk = abi.Tracker(ctx, cfg)
+    for k, (d, rgb) in enumerate(frames[:4]):
+        trk.process_frame_host(d, rgb, 33333 * k)
+    vmap, nmap = trk.vmap_g_prev(0), trk.nmap_g_prev(0)
+    R, t, _ = trk.pose()
+    trk.close()
+    rows, cols = cam.rows, cam.cols
+    rng = np.random.default_rng(2)
+    cases = [(vmap, nmap, rng.integers(0, 256, (rows, cols, 4), dtype=np.uint8))]
+    v2 = rng.uniform(-3, 9, (3 * rows, cols)).astype(np.float32)
+    n2 = rng.normal(size=(3 * rows, cols)).astype(np.float32)
+    v2[:rows][rng.uniform(size=(rows, cols)) < 0.1] = np.nan
+    n2[:rows][rng.uniform(size=(rows, cols)) < 0.1] = np.nan
+    c2 = rng.integers(0, 256, (rows, cols, 4), dtype=np.uint8)
+    c2[..., 3] = np.arange(rows * cols).reshape(rows, cols) % 160          # heat value from 0 to beyond 1 (weight / 128)
+    cases.append((v2, n2, c2))
+    light = np.array([-18.0, -18.0, -18.0], np.float32)                    # getImage: volume size * -3
+    Rinv = oracle_mod.mat33_inverse(R)
+    for i, (v, n, c) in enumerate(cases):
+        ref_img, ref_col = oracle_mod.generate_image(v, n, c, light)
+        ref_dep = oracle_mod.generate_depth(Rinv, t, v, n)
+        dv, dn, dc = ctx.upload(v), ctx.upload(n), ctx.upload(c)
+        di, dcol, dd = ctx.empty(rows * cols * 3), ctx.empty(rows * cols * 3), ctx.empty(rows * cols * 2)
+        ctx.generate_image(dv, dn, dc, cols, rows, light, 1, di, dcol)
+        ctx.generate_depth(Rinv, t, dv, dn, cols, rows, dd)
+        assert np.array_equal(ref_img, ctx.download(di, np.uint8, (rows, cols, 3))), i
+        assert np.array_equal(ref_col, ctx.download(dcol, np.uint8, (rows, cols, 3))), i
+        assert np.array_equal(ref_dep, ctx.download(dd, np.uint16, (rows, cols))), i
+    # on the tracked maps the rendered depth is the input depth seen again (the model of frame 3, within the volume's resolution)
+    hit = np.isfinite(vmap[:rows]) & np.isfinite(nmap[:rows]) & (frames[3][0] > 0)
+    assert hit.mean() > 0.5
+    err = np.abs(oracle_mod.generate_depth(Rinv, t, vmap, nmap).astype(int) - frames[3][0].astype(int))[hit]
+    assert np.median(err) < 30

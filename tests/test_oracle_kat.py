@@ -285,3 +285,28 @@ def test_ground_truth_odometry(oracle_mod):
     E = E @ np.linalg.inv(C[1]) @ C[2]           # the motion 0 -> 1 was lost, 1 -> 2 applied
     assert np.abs(R2 - E[:3, :3]).max() < 5e-6 and np.abs(t2 - E[:3, 3]).max() < 5e-6
     trk.close()
+
+
+def test_view_products(oracle_mod):
+    """generateImage / generateDepth on a hand-made map: a plane z = 2 facing the camera, lit from the camera centre."""
+    rows, cols = 6, 8
+    v = np.zeros((3 * rows, cols), np.float32)
+    n = np.zeros((3 * rows, cols), np.float32)
+    v[2 * rows:] = 2.0
+    n[2 * rows:] = -1.0
+    v[0, 0] = np.nan                       # no vertex
+    n[1, 1] = np.nan                       # no normal
+    col = np.zeros((rows, cols, 4), np.uint8)
+    col[..., :3] = (10, 20, 30)
+    col[..., 3] = 128                      # heat 1.0 -> pure red (r = 235)
+    col[2, 2, 3] = 0                       # heat 0 -> pure blue
+    col[3, 3, 3] = 64                      # 0.5 -> value 1.5: between green and yellow -> r = 117 (117.5 truncated), g = 235
+    img, dcol = oracle_mod.generate_image(v, n, col, [0.0, 0.0, 0.0])
+    assert tuple(img[0, 0]) == (0, 0, 0) and tuple(img[1, 1]) == (0, 0, 0) and tuple(dcol[0, 0]) == (0, 0, 0)
+    assert tuple(dcol[4, 4]) == (10, 20, 30)
+    # light at the origin, point (0, 0, 2), normal (0, 0, -1): |cos| = 1 -> colour = heat * 1 + 20, stored as (b, g, r)
+    assert tuple(img[4, 4]) == (20, 20, 255)
+    assert tuple(img[2, 2]) == (255, 20, 20)
+    assert tuple(img[3, 3]) == (20, 255, 137)
+    d = oracle_mod.generate_depth(np.eye(3, dtype=np.float32), [0.0, 0.0, 0.5], v, n)
+    assert d[0, 0] == 0 and d[1, 1] == 0 and d[4, 4] == 1500
