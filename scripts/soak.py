@@ -10,7 +10,10 @@ scene = synth.Scene("wall")
 traj = synth.crabwalk_trajectory(420)
 frames = [synth.render(scene, cam, *traj[i]) for i in range(0, 420, 1)]
 N = 96
-args = (cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, 7.0, 3, 2, 0, 0, 0, 0, 0, 0)
+MODE = sys.argv[1] if len(sys.argv) > 1 else "icp"          # icp | rgbd_icp | rgbd
+if MODE != "icp":
+    frames = frames[:160]                                   # the RGB-D oracle is slower; 160 frames still shift the volume 10 times
+args = (cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, 7.0, 3, 2, 0, int(MODE == "rgbd"), int(MODE == "rgbd_icp"), 0, 0, 0)
 ctx = abi.Ctx(0)
 trk, otr = abi.Tracker(ctx, abi.TrackerConfig(*args)), oracle.OracleTracker(oracle.OTrackerConfig(*args))
 dev = [(ctx.upload(d), ctx.upload(c)) for d, c in frames]
@@ -27,7 +30,7 @@ for k in range(len(frames)):
     assert np.array_equal(trk.voxel_wrap(), otr.voxel_wrap()), k
 assert trk.num_slices() == otr.num_slices()
 v, ov = trk.volume(), otr.volume()
-print("frames", len(frames), "slices", trk.num_slices(), "worst pose diff", worst, "tsdf mismatches", int((v != ov).sum()), "of", int((otr.color_volume()[..., 3] != 0).sum()),
+print(MODE, "frames", len(frames), "slices", trk.num_slices(), "worst pose diff", worst, "tsdf mismatches", int((v != ov).sum()), "of", int((otr.color_volume()[..., 3] != 0).sum()),
       "time %.1fs" % (time.time() - t0))
 c, oc = trk.color_volume(), otr.color_volume()
 print("colour mismatches per channel", [int((c[..., ch] != oc[..., ch]).sum()) for ch in range(4)])

@@ -145,3 +145,33 @@ def test_shift_round_trip(ctx):
     p, dim = trk.slice(trk.num_slices() - 1)
     assert dim == 7 and len(p) > 10000                                            # the wall is still in the volume after the shifts
     trk.close()
+
+
+@pytest.mark.parametrize("mode", ["icp", "rgbd_icp"])
+def test_vga_frames_against_the_oracle(ctx, oracle_mod, orbit_vga, mode):
+    """Full-resolution frames (640x480) through the oracle too -- at 256^3 and for 4 frames, which it finishes in seconds: poses,
+    TSDF, colour volume and the predicted maps of every pyramid level must be identical (the small-size tracker tests, at VGA)."""
+    from kintinuous_amd import abi
+    from oracle import oracle
+    cam, frames, _ = orbit_vga
+    n = 256
+    ri = int(mode == "rgbd_icp")
+    args = (cam.cols, cam.rows, n, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, ri, 0, 0, 0)
+    trk, otr = abi.Tracker(ctx, abi.TrackerConfig(*args)), oracle.OracleTracker(oracle.OTrackerConfig(*args))
+    for k in range(4):
+        d, rgb = frames[k]
+        trk.process_frame_host(d, rgb, 33333 * k)
+        otr.process_frame(d, rgb, 33333 * k)
+        R, t, gc = trk.pose()
+        Ro, to, go = otr.pose()
+        assert np.array_equal(R, Ro) and np.array_equal(t, to) and np.array_equal(gc, go), k
+    assert np.array_equal(trk.volume(), otr.volume())
+    assert np.array_equal(trk.color_volume(), otr.color_volume())
+    for lvl in range(4):
+        for a, b in ((trk.vmap_g_prev(lvl), otr.vmap_g_prev(lvl)), (trk.nmap_g_prev(lvl), otr.nmap_g_prev(lvl))):
+            rows = a.shape[0] // 3
+            va = np.isfinite(a[:rows])
+            assert np.array_equal(va, np.isfinite(b[:rows])) and va.sum() > 0
+            for p in range(3):
+                assert np.array_equal(a[p * rows:(p + 1) * rows][va].view(np.uint32), b[p * rows:(p + 1) * rows][va].view(np.uint32)), (lvl, p)
+    trk.close(); otr.close()
