@@ -213,7 +213,9 @@ def main():
                    "volume": N, "cols": cam.cols, "rows": cam.rows, "unique_frames": nuniq, "pose_err_m_at_end": pose_err,
                    "pose_gather_bytes": pose_bytes,
                    "frame_ms": {"p50": round(float(np.percentile(periods, 50)), 4), "p99": round(float(np.percentile(periods, 99)), 4),
-                                "max": round(float(periods.max()), 4)},
+                                "max": round(float(periods.max()), 4),
+                                # the slowest calls (index in the timed region, ms): shift frames and whatever else stalls the caller
+                                "slowest": [[int(i), round(float(periods[i]), 3)] for i in np.argsort(periods)[::-1][:4]]},
                    "slices_by_direction": slices_by_dim},
         "roofline": {"kernel": "kt_tsdf23_kernel", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                      "frac": achieved / peak, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_tsdf23,
