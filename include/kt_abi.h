@@ -182,6 +182,8 @@ typedef struct {
     int fast_odometry;   /* -fod */
     int disable_color_angle; /* -dc */
     int max_slice_points;    /* 0 = 3 * cols * rows (KintinuousTracker.cpp:77) */
+    int dynamic_cube;        /* -d: the cube swings around the camera with its heading (repositionCube, KintinuousTracker.cpp:384-442);
+                                the pose is then observed on the host before the frame is fused (no speculative fusion) */
 } kt_tracker_config;
 
 int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** out);
@@ -207,6 +209,10 @@ int kt_tracker_process_frame_host(kt_tracker* t, const uint16_t* depth_host, con
  * has no entry is dropped (preRun, :89-111).  Call before the first frame; repeated calls add entries. */
 int kt_tracker_load_trajectory(kt_tracker* t, int n, const uint64_t* utimes_host, const float* pose7_host);
 int kt_tracker_finalise(kt_tracker* t);
+/* volumeBasis (KintinuousTracker::getVolumeOffset); constant unless dynamic_cube is set */
+int kt_tracker_get_volume_basis(kt_tracker* t, float basis_host[3]);
+/* KintinuousTracker::repositionCube on explicit state (host code): may move basis[0] and basis[2] */
+void kt_host_reposition_cube(const float R[9], const float tlast[3], float volume_size, const float voxel_size[3], int thresh, float basis[3]);
 /* rmats_.back() (row-major 3x3), tvecs_.back(), currentGlobalCamera */
 int kt_tracker_get_pose(kt_tracker* t, float R_host[9], float t_host[3], float global_cam_host[3]);
 int kt_tracker_num_poses(kt_tracker* t);

@@ -45,7 +45,7 @@ class TrackerConfig(C.Structure):  # kt_tracker_config
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
         ("volume_size", C.c_float), ("voxel_shift", C.c_int), ("overlap", C.c_int), ("static_mode", C.c_int),
         ("use_rgbd", C.c_int), ("use_rgbd_icp", C.c_int), ("fast_odometry", C.c_int), ("disable_color_angle", C.c_int),
-        ("max_slice_points", C.c_int),
+        ("max_slice_points", C.c_int), ("dynamic_cube", C.c_int),
     ]
 
 
@@ -108,6 +108,8 @@ _PROTOS = {
     "kt_tracker_process_frame_host": (_i, [_vp, _vp, _vp, _u64]),
     "kt_tracker_load_trajectory": (_i, [_vp, _i, _vp, _vp]),
     "kt_tracker_finalise": (_i, [_vp]),
+    "kt_tracker_get_volume_basis": (_i, [_vp, _pf]),
+    "kt_host_reposition_cube": (None, [_pf, _pf, _f, _pf, _i, _pf]),
     "kt_tracker_get_pose": (_i, [_vp, _pf, _pf, _pf]),
     "kt_tracker_num_poses": (_i, [_vp]),
     "kt_tracker_get_dense_pose": (_i, [_vp, _i, C.POINTER(_u64), _pf, _pi]),
@@ -401,6 +403,11 @@ class Tracker:
 
     def finalise(self) -> None:
         _chk(lib().kt_tracker_finalise(self.h))
+
+    def volume_basis(self) -> np.ndarray:
+        b = (C.c_float * 3)()
+        _chk(lib().kt_tracker_get_volume_basis(self.h, b))
+        return np.array(b, dtype=np.float32)
 
     def pose(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         R, t, g = (C.c_float * 9)(), (C.c_float * 3)(), (C.c_float * 3)()

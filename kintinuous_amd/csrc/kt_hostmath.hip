@@ -3,6 +3,8 @@
 // in the epilogue of the reduction kernels (kt_track.hpp).  Replaces the Eigen / OpenCV calls of ICPOdometry.cpp:127-178.
 #include "kt_track.hpp"
 
+#include <math.h>
+
 extern "C" {
 
 int kt_host_ldlt_solve6(const double A[36], const double b[6], double x[6])
@@ -36,3 +38,57 @@ int kt_host_pose_update(const double x[6], double resultRt[16], const float Rpre
 }
 
 }  // extern "C"
+
+// KintinuousTracker::rodrigues2 (KintinuousTracker.cpp:1210-1255), the axis-angle of a rotation matrix in double as cv::Rodrigues'
+// matrix branch computes it.  The reference's JacobiSVD re-orthonormalisation (R = U V^T) is not restated: on a rotation matrix the
+// polar factor is the matrix up to float rounding.
+static void axis_angle_of(const float R[9], float out[3])
+{
+    double ax = (double)(R[7] - R[5]), ay = (double)(R[2] - R[6]), az = (double)(R[3] - R[1]);
+    const double sine = sqrt((ax * ax + ay * ay + az * az) * 0.25);
+    double cosine = (double)((R[0] + R[4] + R[8]) - 1) * 0.5;
+    cosine = cosine > 1. ? 1. : cosine < -1. ? -1. : cosine;
+    double angle = acos(cosine);
+    if (sine < 1e-5) {
+        if (cosine > 0) ax = ay = az = 0;
+        else {  // angle near pi: the axis comes from the diagonal
+            double h = (R[0] + 1) * 0.5;
+            ax = sqrt(h > 0.0 ? h : 0.0);
+            h = (R[4] + 1) * 0.5;
+            ay = sqrt(h > 0.0 ? h : 0.0) * (R[1] < 0 ? -1.0 : 1.0);
+            h = (R[8] + 1) * 0.5;
+            az = sqrt(h > 0.0 ? h : 0.0) * (R[2] < 0 ? -1.0 : 1.0);
+            if (fabs(ax) < fabs(ay) && fabs(ax) < fabs(az) && (R[5] > 0) != (ay * az > 0)) az = -az;
+            angle /= sqrt(ax * ax + ay * ay + az * az);
+            ax *= angle; ay *= angle; az *= angle;
+        }
+    } else {
+        double k = 1 / (2 * sine);
+        k *= angle;
+        ax *= k; ay *= k; az *= k;
+    }
+    out[0] = (float)ax; out[1] = (float)ay; out[2] = (float)az;
+}
+
+extern "C" void kt_host_reposition_cube(const float R[9], const float tlast[3], float volume_size, const float voxel_size[3], int thresh,
+                                        float basis[3])
+{
+    // KintinuousTracker::repositionCube :384-442: the cube's corner swings on a circle of half the cube size around the camera,
+    // following the heading (rotation about y); it only moves when the camera would otherwise trip the shift threshold
+    float aa[3];
+    axis_angle_of(R, aa);
+    const float heading = aa[1];
+    const float PI = 3.14159265359f;
+    const float radius = (float)(volume_size * 0.5);
+    // global ::cos / ::sin on a float argument: the C library's double functions (the float sum is widened), then float * double
+    const float moved[3] = {(float)(radius * (::cos((double)(heading + (PI / 2))) + 1.0f)), basis[1],
+                            (float)(radius * (::sin((double)(heading - (PI / 2))) + 1.0f))};
+    bool trips = false;
+    for (int k = 0; k < 3; ++k) {
+        // the clamped floor of :409-433
+        const int f = (int)floorf((tlast[k] - moved[k]) / voxel_size[k]);
+        const int v = f < 0 ? (-thresh > f ? -thresh : f) : (thresh < f ? thresh : f);
+        trips = trips || v >= thresh || v <= -thresh;
+    }
+    if (trips) { basis[0] = moved[0]; basis[2] = moved[2]; }
+}

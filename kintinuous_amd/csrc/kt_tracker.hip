@@ -111,6 +111,7 @@ struct kt_tracker {
     // deferred completion: a frame's fusion kernels are enqueued before the host has seen its pose (complete_frame)
     bool outstanding; uint64_t out_ts; int out_set;
     const uint16_t* out_depth; const uint8_t* out_rgb; int out_thresh;
+    bool out_speculated;               // the fusion kernels of the frame in flight were enqueued against the device's shift decision
     kt_frame_params* fp_dev;
     // colour weight carried across frames for pixels without a valid normal (KT_REC_STALE_NZ): [carry_sel] = state before the frame
     // in flight, [carry_sel ^ 1] = state after it
@@ -326,8 +327,8 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     }
     for (int k = 0; k < 9; ++k) t->initial_rotation[k] = (k % 4 == 0) ? 1.f : 0.f;
     for (int k = 0; k < 3; ++k) t->volume_basis[k] = t->volume_size[k] * 0.5f;
-    if (cfg->static_mode)  // :101-110
-        t->volume_basis[2] = t->volume_size[2] * 0.5f - (float)(((double)t->volume_size[2] * 0.5) + 0.45);
+    if (cfg->static_mode || cfg->dynamic_cube)  // :101-110
+        t->volume_basis[2] = t->volume_size[2] * 0.5f - (float)(((double)t->volume_size[2] * 0.5) + (cfg->static_mode ? 0.45 : 0));
     const float default_tranc = fmaxf(0.01f, t->volume_size[0] / 100.0f);               // :112
     const float mc = fmaxf(t->voxel_size[0], fmaxf(t->voxel_size[1], t->voxel_size[2]));
     t->tranc_dist = fmaxf(default_tranc, 2.1f * mc);                                    // TSDFVolume.cpp:89-97
@@ -829,6 +830,9 @@ static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool specu
     memcpy(t->Rlast, Rcurr, 9 * sizeof(float));
     memcpy(t->tlast, tcurr, 3 * sizeof(float));
     compute_global_camera(t, tcurr);
+    if (t->cfg.dynamic_cube)  // :597-600; while parked its threshold is VOLUME_X (x 3 with -sm), :403
+        kt_host_reposition_cube(Rcurr, t->tlast, t->cfg.volume_size, t->voxel_size,
+                                t->parked ? (t->cfg.static_mode ? t->N * 3 : t->N) : t->cfg.voxel_shift, t->volume_basis);
 
     // [F] shift decision :627-667 and the three axis blocks :669-833
     float current_translation[3];
@@ -923,7 +927,7 @@ static int complete_frame(kt_tracker* t)
     float Rcurr[9], tcurr[3];
     memcpy(Rcurr, t->mirror->R, sizeof(Rcurr));
     memcpy(tcurr, t->mirror->t, sizeof(tcurr));
-    return finish_pose(t, Rcurr, tcurr, true);
+    return finish_pose(t, Rcurr, tcurr, t->out_speculated);
 }
 
 extern "C" {
@@ -1060,9 +1064,12 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     v_wrap_copy_update(t);
     if (++t->frame_seq == 0) t->frame_seq = 1;  // 0 is the mirror's initial value
     KT_TRY(launch_setup(t, 0, nullptr, nullptr));
-    KT_TRY(enqueue_fusion(t, set, depth_raw, colors));
+    // -d: the cube may be repositioned once the pose is known, which changes the shift decision -- nothing to speculate on
+    t->out_speculated = !t->cfg.dynamic_cube;
+    if (t->out_speculated) KT_TRY(enqueue_fusion(t, set, depth_raw, colors));
     t->outstanding = true;
     t->gt_utime = timestamp;
+    if (!t->out_speculated) KT_TRY(complete_frame(t));   // observe the pose, reposition, shift if needed, enqueue the fusion
     t->ev_par ^= 1;
     if (t->counting) {  // the counters are read back per frame: finish it before returning
         KT_TRY(complete_frame(t));
@@ -1161,6 +1168,14 @@ int kt_tracker_load_trajectory(kt_tracker* t, int n, const uint64_t* utimes, con
         t->trajectory[(int)(uint32_t)utimes[i]] = T;
     }
     t->gt_utime = 0;   // :259
+    return KT_OK;
+}
+
+int kt_tracker_get_volume_basis(kt_tracker* t, float* basis)
+{
+    KT_ARG(t && basis);
+    KT_TRY(complete_frame(t));
+    memcpy(basis, t->volume_basis, sizeof(t->volume_basis));
     return KT_OK;
 }
 

@@ -29,7 +29,7 @@ class ConfigArgs {
                      "  -n <N>         volume resolution (default 512)\n"
                      "  -r | -ri       RGB-D odometry | RGB-D + ICP odometry\n"
                      "  -p <file>      ground-truth odometry from a trajectory file (lines utime,x,y,z,qx,qy,qz,qw)\n"
-                     "  -fod           fast odometry,  -sm static mode,  -dc no colour angle weight,  -no no overlap\n"
+                     "  -fod           fast odometry,  -sm static mode,  -d dynamic cube,  -dc no colour angle weight,  -no no overlap\n"
                      "  -f             flip colours (RGB <-> BGR)\n"
                      "  -tum           write poses with timestamps in seconds (TUM format; the .poses default)\n"
                      "  -o <prefix>    output prefix (default: the log name)\n"
@@ -41,7 +41,7 @@ class ConfigArgs {
     std::string calibrationFile, logFile, trajectoryFile, saveFile;
     int gpu, voxelShift, volumeResolution, width, height, totalNumFrames;
     float volumeSize;
-    bool staticMode, flipColors, extractOverlap, useRGBD, useRGBDICP, disableColorAngleWeight, fastOdometry, help;
+    bool staticMode, dynamicCube, flipColors, extractOverlap, useRGBD, useRGBDICP, disableColorAngleWeight, fastOdometry, help;
 
   private:
     static bool flag(int argc, char** argv, const char* name)
@@ -72,6 +72,7 @@ class ConfigArgs {
         if ((v = value(argc, argv, "-s"))) volumeSize = (float)std::atof(v);
         if ((v = value(argc, argv, "-fl"))) totalNumFrames = std::atoi(v);
         staticMode = flag(argc, argv, "-sm");
+        dynamicCube = flag(argc, argv, "-d");
         flipColors = flag(argc, argv, "-f");
         extractOverlap = !flag(argc, argv, "-no");
         useRGBD = flag(argc, argv, "-r");

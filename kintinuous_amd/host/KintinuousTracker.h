@@ -53,6 +53,7 @@ class KintinuousTracker {
             cfg.voxel_shift = args.voxelShift;
             cfg.overlap = 0;
             cfg.static_mode = args.staticMode;
+            cfg.dynamic_cube = args.dynamicCube;
             cfg.use_rgbd = args.useRGBD;
             cfg.use_rgbd_icp = args.useRGBDICP;
             cfg.fast_odometry = args.fastOdometry;
@@ -76,7 +77,7 @@ class KintinuousTracker {
         // KintinuousTracker.cpp:86-118
         const float vs = Volume::get().getVolumeSize();
         volumeBasis = kt::Vector3f(vs * 0.5f, vs * 0.5f, vs * 0.5f);
-        if (args.staticMode) volumeBasis(2) = vs * 0.5f - (float)(((double)vs * 0.5) + 0.45);
+        if (args.staticMode || args.dynamicCube) volumeBasis(2) = vs * 0.5f - (float)(((double)vs * 0.5) + (args.staticMode ? 0.45 : 0));
         tsdf_volume_ = new TsdfVolume(N);
         tsdf_volume_->setSize(kt::Vector3f(vs, vs, vs));
         tsdf_volume_->setTsdfTruncDist(std::max(0.01f, vs / 100.0f));
@@ -280,9 +281,12 @@ class KintinuousTracker {
     kt::Vector3f volumeBasisValue() const
     {
         if (operatorPath) return volumeBasis;
+        kt::Vector3f b;
+        if (fast) { ktSafeCall(kt_tracker_get_volume_basis(fast, b.data())); return b; }
         const float vs = Volume::get().getVolumeSize();
-        kt::Vector3f b(vs * 0.5f, vs * 0.5f, vs * 0.5f);
-        if (ConfigArgs::get().staticMode) b(2) = vs * 0.5f - (float)(((double)vs * 0.5) + 0.45);
+        b = kt::Vector3f(vs * 0.5f, vs * 0.5f, vs * 0.5f);
+        if (ConfigArgs::get().staticMode || ConfigArgs::get().dynamicCube)
+            b(2) = vs * 0.5f - (float)(((double)vs * 0.5) + (ConfigArgs::get().staticMode ? 0.45 : 0));
         return b;
     }
 
@@ -471,6 +475,11 @@ class KintinuousTracker {
         rmats_.push_back(Rcurr);
         tvecs_.push_back(tcurr);
         computeGlobalCamera(&tcurr);
+        if (ConfigArgs::get().dynamicCube) {  // repositionCube :597-600, 384-442
+            const kt::Vector3f vx = tsdf_volume_->getVoxelSize();
+            kt_host_reposition_cube(Rcurr.data(), tvecs_.back().data(), Volume::get().getVolumeSize(), vx.data(),
+                                    parked ? (ConfigArgs::get().staticMode ? N * 3 : N) : ConfigArgs::get().voxelShift, volumeBasis.data());
+        }
         kt::Matrix3f Rcurr_inv;
         ktSafeCall(kt_host_mat33_inverse(Rcurr.data(), Rcurr_inv.data()));
 

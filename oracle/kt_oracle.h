@@ -128,11 +128,15 @@ typedef struct {
     int fast_odometry;          /* -fod */
     int disable_color_angle;    /* -dc */
     int reduce_order;           /* 0 reference float tree, 1 double */
+    int dynamic_cube;           /* -d */
 } kto_tracker_config;
 
 kto_tracker* kto_tracker_create(const kto_tracker_config* cfg);
 void kto_tracker_destroy(kto_tracker* t);
 void kto_tracker_reset(kto_tracker* t);
+/* KintinuousTracker::repositionCube (KintinuousTracker.cpp:384-442) on explicit state: may move basis[0], basis[2] */
+void kto_reposition_cube(const float R[9], const float tlast[3], float volume_size, const float voxel_size[3], int thresh, float basis[3]);
+void kto_tracker_get_volume_basis(const kto_tracker* t, float basis[3]);
 /* processFrame: depth u16 [rows][cols] mm, rgb24 [rows][cols][3]. */
 void kto_tracker_process_frame(kto_tracker* t, const uint16_t* depth, const uint8_t* rgb24, uint64_t timestamp);
 /* -p ground-truth odometry (KintinuousTracker::loadTrajectory, GroundTruthOdometry.cpp): pose7 = n x {x y z qx qy qz qw} */

@@ -279,8 +279,8 @@ kto_tracker* kto_tracker_create(const kto_tracker_config* cfg)
     t->color = malloc(nvox * 4);
     for (int k = 0; k < 9; ++k) t->initial_rotation[k] = (k % 4 == 0) ? 1.f : 0.f;
     for (int k = 0; k < 3; ++k) t->volume_basis[k] = t->volume_size[k] * 0.5f;
-    if (cfg->static_mode) /* :101-110; the double z offset is narrowed to float by the Vector3f ctor, then subtracted */
-        t->volume_basis[2] = t->volume_size[2] * 0.5f - (float)(((double)t->volume_size[2] * 0.5) + 0.45);
+    if (cfg->static_mode || cfg->dynamic_cube) /* :101-110; the double z offset is narrowed to float by the Vector3f ctor, then subtracted */
+        t->volume_basis[2] = t->volume_size[2] * 0.5f - (float)(((double)t->volume_size[2] * 0.5) + (cfg->static_mode ? 0.45 : 0));
     /* :112-113 and TSDFVolume.cpp:89-97 */
     float default_tranc = fmaxf(0.01f, t->volume_size[0] / 100.0f);
     float mc = fmaxf(t->voxel_size[0], fmaxf(t->voxel_size[1], t->voxel_size[2]));
@@ -632,6 +632,58 @@ static void ground_truth_odometry(kto_tracker* t, uint64_t timestamp, float tcur
     }
 }
 
+static int voxel_trans(float translation, float voxel, int thresh);
+
+/* KintinuousTracker::rodrigues2 (KintinuousTracker.cpp:1210-1255): rotation matrix -> axis-angle, cv::Rodrigues' inverse branch in
+ * double.  The reference first re-orthonormalises the matrix (JacobiSVD, R = U V^T); for the rotation matrices this is called on,
+ * that polar factor differs from the input by float rounding only and the SVD is not restated: R is used as is. */
+static void rodrigues2(const float R[9], float out[3])
+{
+    double rx = (double)(R[7] - R[5]), ry = (double)(R[2] - R[6]), rz = (double)(R[3] - R[1]); /* float differences, widened */
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (double)((R[0] + R[4] + R[8]) - 1) * 0.5; /* R.trace() is a float */
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) rx = ry = rz = 0;
+        else {
+            double tt = (R[0] + 1) * 0.5;
+            rx = sqrt(tt > 0.0 ? tt : 0.0);
+            tt = (R[4] + 1) * 0.5;
+            ry = sqrt(tt > 0.0 ? tt : 0.0) * (R[1] < 0 ? -1.0 : 1.0);
+            tt = (R[8] + 1) * 0.5;
+            rz = sqrt(tt > 0.0 ? tt : 0.0) * (R[2] < 0 ? -1.0 : 1.0);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        double vth = 1 / (2 * s);
+        vth *= theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    out[0] = (float)rx; out[1] = (float)ry; out[2] = (float)rz;
+}
+
+/* KintinuousTracker::repositionCube :384-442.  cos / sin are the C library's double versions (global ::cos on a float argument). */
+void kto_reposition_cube(const float R[9], const float tlast[3], float volume_size, const float voxel_size[3], int thresh, float basis[3])
+{
+    float rot[3];
+    rodrigues2(R, rot);
+    const float yRot = rot[1];
+    const float PI = 3.14159265359f;
+    const float radius = (float)(volume_size * 0.5);
+    float np_[3] = {basis[0], basis[1], basis[2]};
+    np_[0] = (float)(radius * (cos(yRot + (PI / 2)) + 1.0f));
+    np_[2] = (float)(radius * (sin(yRot - (PI / 2)) + 1.0f));
+    int moved = 0;
+    for (int k = 0; k < 3; ++k) {
+        const int v = voxel_trans(tlast[k] - np_[k], voxel_size[k], thresh);
+        moved = moved || v >= thresh || v <= -thresh;
+    }
+    if (moved) { basis[0] = np_[0]; basis[1] = np_[1]; basis[2] = np_[2]; }
+}
+
 static int voxel_trans(float translation, float voxel, int thresh)
 {
     /* KintinuousTracker.cpp:640-667 */
@@ -689,6 +741,9 @@ void kto_tracker_process_frame(kto_tracker* t, const uint16_t* depth_raw, const 
     memcpy(t->Rlast, Rcurr, sizeof(Rcurr)); /* [D] rmats_/tvecs_ push */
     memcpy(t->tlast, tcurr, sizeof(tcurr));
     compute_global_camera(t, tcurr);
+    if (t->cfg.dynamic_cube) /* :597-600; its threshold while parked is VOLUME_X (x 3 with -sm), :403 */
+        kto_reposition_cube(Rcurr, t->tlast, t->cfg.volume_size, t->voxel_size,
+                            t->parked ? (t->cfg.static_mode ? t->N * 3 : t->N) : t->cfg.voxel_shift, t->volume_basis);
 
     kto_mat33 Rc, Rc_inv;
     memcpy(Rc.m, Rcurr, sizeof(Rc.m));
@@ -772,6 +827,7 @@ void kto_tracker_get_dense_pose(const kto_tracker* t, int i, uint64_t* ts, float
     memcpy(pose16, t->poses[i].pose, sizeof(t->poses[i].pose));
     *is_loop = t->poses[i].is_loop;
 }
+void kto_tracker_get_volume_basis(const kto_tracker* t, float basis[3]) { memcpy(basis, t->volume_basis, 3 * sizeof(float)); }
 void kto_tracker_get_voxel_wrap(const kto_tracker* t, int wrap[3]) { memcpy(wrap, t->voxel_wrap, sizeof(t->voxel_wrap)); }
 int kto_tracker_num_slices(const kto_tracker* t) { return t->n_slices; }
 size_t kto_tracker_slice_size(const kto_tracker* t, int i) { return t->slices[i].n; }

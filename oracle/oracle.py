@@ -39,7 +39,7 @@ class OTrackerConfig(C.Structure):
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
         ("volume_size", C.c_float), ("voxel_shift", C.c_int), ("overlap", C.c_int), ("static_mode", C.c_int),
         ("use_rgbd", C.c_int), ("use_rgbd_icp", C.c_int), ("fast_odometry", C.c_int), ("disable_color_angle", C.c_int),
-        ("reduce_order", C.c_int),
+        ("reduce_order", C.c_int), ("dynamic_cube", C.c_int),
     ]
 
 
@@ -348,6 +348,11 @@ class OracleTracker:
 
     def finalise(self) -> None:
         lib().kto_tracker_finalise(self.h)
+
+    def volume_basis(self) -> np.ndarray:
+        b = (C.c_float * 3)()
+        lib().kto_tracker_get_volume_basis(self.h, b)
+        return np.array(b, np.float32)
 
     def pose(self):
         R, t, g = (C.c_float * 9)(), (C.c_float * 3)(), (C.c_float * 3)()

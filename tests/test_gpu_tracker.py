@@ -12,12 +12,13 @@ pytestmark = pytest.mark.gpu
 def _cfgs(cam, N, **kw):
     from kintinuous_amd import abi
     from oracle import oracle
-    d = dict(volume_size=6.0, voxel_shift=14, overlap=2, static_mode=0, use_rgbd=0, use_rgbd_icp=0, fast_odometry=0, disable_color_angle=0)
+    d = dict(volume_size=6.0, voxel_shift=14, overlap=2, static_mode=0, use_rgbd=0, use_rgbd_icp=0, fast_odometry=0, disable_color_angle=0,
+             dynamic_cube=0)
     d.update(kw)
     g = abi.TrackerConfig(cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, d["volume_size"], d["voxel_shift"], d["overlap"], d["static_mode"],
-                          d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0)
+                          d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0, d["dynamic_cube"])
     o = oracle.OTrackerConfig(cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, d["volume_size"], d["voxel_shift"], d["overlap"], d["static_mode"],
-                              d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0)
+                              d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0, d["dynamic_cube"])
     return g, o
 
 
@@ -258,6 +259,33 @@ def test_ground_truth_odometry(ctx, oracle_mod, readahead):
     a, b = trk.vmap_g_prev(0), otr.vmap_g_prev(0)
     va = np.isfinite(a)
     assert np.array_equal(va, np.isfinite(b)) and va.sum() > 0 and np.array_equal(a[va].view(np.uint32), b[va].view(np.uint32))
+    trk.close(); otr.close()
+
+
+@pytest.mark.parametrize("mode", ["icp", "rgbd_icp", "static"])
+def test_dynamic_cube(ctx, oracle_mod, mode):
+    """-d: the camera turns on the spot; the cube's corner follows the heading (repositionCube), which trips volume shifts.  The pose
+    is observed on the host before the frame is fused, so nothing is speculated -- results must still equal the oracle's exactly."""
+    from kintinuous_amd import synth
+    from scipy.spatial.transform import Rotation
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("room")
+    yaws = [0.015 * k for k in range(14)] + [0.015 * (13 - k) for k in range(1, 8)]
+    frames = [synth.render(scene, cam, Rotation.from_euler("y", a).as_matrix(), np.zeros(3)) for a in yaws]
+    kw = dict(use_rgbd_icp=1) if mode == "rgbd_icp" else dict(static_mode=1) if mode == "static" else {}
+    trk, otr, max_t, max_r = _run_pair(ctx, cam, frames, 96, volume_size=6.0, voxel_shift=3, dynamic_cube=1, **kw)
+    assert max_t == 0.0 and max_r == 0.0
+    assert np.array_equal(trk.volume_basis(), otr.volume_basis())
+    if mode == "static":   # parked: the reposition threshold is 3 N voxels, the cube never moves (KintinuousTracker.cpp:403)
+        assert np.allclose(trk.volume_basis(), [3.0, 3.0, -0.45], atol=1e-6) and trk.num_slices() == 0
+    else:
+        assert not np.array_equal(trk.volume_basis(), np.array([3.0, 3.0, 0.0], np.float32))
+        assert trk.num_slices() == otr.num_slices() and trk.num_slices() >= 2
+        for i in range(trk.num_slices()):
+            p, dim = trk.slice(i)
+            q, dim2 = otr.slice(i)
+            assert dim == dim2 and _same_points(p, q)
+    _volume_close(trk, otr)
     trk.close(); otr.close()
 
 

@@ -310,3 +310,33 @@ def test_view_products(oracle_mod):
     assert tuple(img[3, 3]) == (20, 255, 137)
     d = oracle_mod.generate_depth(np.eye(3, dtype=np.float32), [0.0, 0.0, 0.5], v, n)
     assert d[0, 0] == 0 and d[1, 1] == 0 and d[4, 4] == 1500
+
+
+def test_dynamic_cube_repositioning(oracle_mod):
+    """-d (repositionCube): the cube's corner follows the heading on a circle of half the cube size; it only moves when the camera
+    would trip the shift threshold with the new position."""
+    from kintinuous_amd import synth
+    from scipy.spatial.transform import Rotation
+    cam = synth.Camera.small(80, 60)
+    scene = synth.Scene("room")
+    cfg = oracle_mod.OTrackerConfig(cam.cols, cam.rows, 64, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 3, 2, 0, 0, 0, 0, 0, 0, 1)
+    trk = oracle_mod.OracleTracker(cfg)
+    assert np.allclose(trk.volume_basis(), [3.0, 3.0, 0.0])          # KintinuousTracker.cpp:103-106 without the -sm offset
+    yaws = [0.02 * k for k in range(10)]
+    moved_at = None
+    for k, a in enumerate(yaws):
+        R = Rotation.from_euler("y", a).as_matrix()
+        d, rgb = synth.render(scene, cam, R, np.zeros(3))
+        trk.process_frame(d, rgb, 33333 * k)
+        b = trk.volume_basis()
+        Rt, t, _ = trk.pose()
+        if moved_at is None and not np.allclose(b, [3.0, 3.0, 0.0]):
+            moved_at = k
+            heading = Rotation.from_matrix(Rt.astype(np.float64)).as_rotvec()[1]
+            # the new corner: radius * (cos(heading + pi / 2) + 1), radius * (sin(heading - pi / 2) + 1)
+            assert abs(b[0] - 3.0 * (1 - np.sin(heading))) < 1e-4 and abs(b[2] - 3.0 * (1 - np.cos(heading))) < 1e-4 and b[1] == 3.0
+            # it moved because the camera was then >= 3 voxels from it, which also shifted the volume in the same frame
+            assert np.abs(trk.voxel_wrap()).max() >= 3
+    assert moved_at is not None and moved_at >= 2                    # not before the heading has swung the corner 3 voxels away
+    assert trk.num_poses() == len(yaws)
+    trk.close()
