@@ -63,6 +63,12 @@ class RawLogReader : public LogReader {
         int32_t depthSize = 0, imageSize = 0;
         if (std::fread(&timestamp, sizeof(int64_t), 1, fp) != 1 || std::fread(&depthSize, sizeof(int32_t), 1, fp) != 1 ||
             std::fread(&imageSize, sizeof(int32_t), 1, fp) != 1) { returnVal = false; return false; }
+        // a log is untrusted input: payload sizes beyond any frame this resolution could produce mean a corrupt header
+        const int32_t limit = (int32_t)(n * 16 + 65536);
+        if (depthSize < 0 || imageSize < 0 || depthSize > limit || imageSize > limit) {
+            std::fprintf(stderr, "corrupt frame header in frame %d (payload sizes %d / %d)\n", currentFrame, depthSize, imageSize);
+            std::exit(1);
+        }
         scratch.resize((size_t)(depthSize > imageSize ? depthSize : imageSize));
         if (depthSize > 0 && std::fread(scratch.data(), (size_t)depthSize, 1, fp) != 1) { returnVal = false; return false; }
         if ((size_t)depthSize == n * 2) {
