@@ -1,0 +1,22 @@
+# HBM-side traffic of the tsdf23 kernel for one workload: FETCH_SIZE and WRITE_SIZE in separate passes (kernel-trace only), written
+# as profiles-style JSON to gpurun_out/pmc_traffic_<workload>.json.   usage: pmc_traffic.sh <workload> <steps>
+cd /tmp && export TMPDIR=/tmp
+W=${1:-farwall768}; S=${2:-6}
+R=$GRAFT_REPO_ROOT
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmct_$c -- python $R/bench.py --workload $W --steps $S --warmup 2 --no-cpu-baseline --no-readahead > $R/gpurun_out/pmct_$c.log 2>&1 || tail -3 $R/gpurun_out/pmct_$c.log
+done
+python - <<PY
+import csv, glob, json, os
+out = {"workload": "$W ($S timed frames, no read-ahead)", "kernel": "kt_tsdf23_kernel<false>",
+       "collected": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, one pass each (scripts/pmc_traffic.sh), mean over the launches of the run",
+       "calibration": "scripts/pmc_calibrate.sh: corrected traffic = 2 * FETCH_SIZE + WRITE_SIZE (KiB)"}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = sorted(glob.glob("$R/gpurun_out/pmct_%s/*/*counter_collection.csv" % c), key=os.path.getmtime)
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(fs[-1])) if "tsdf23_kernel<false" in r["Kernel_Name"] and r["Counter_Name"] == c]
+    out[c] = sum(vals) / len(vals)
+    out["launches_" + c] = len(vals)
+out["traffic_bytes_per_launch"] = (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024
+json.dump(out, open("$R/gpurun_out/pmc_traffic_$W.json", "w"), indent=1)
+print(json.dumps(out))
+PY
