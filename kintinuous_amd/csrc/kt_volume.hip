@@ -309,13 +309,15 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
 
 // Pre-pass 2: compact task list.  One workgroup; thread t owns a contiguous run of wave-columns, counts their chunks, a block-wide
 // exclusive scan places them.  task = yg | xg << 16 | chunk << 24 (wave-column (xg, yg), kt_tsdf_interval_kernel).
+// Inside a run the tasks of two x-neighbouring wave-columns alternate chunk by chunk: the 4 waves of a workgroup then work on
+// (a, c), (b, c), (a, c + 1), (b, c + 1), i.e. on both 64-byte halves of the same 128-byte tsdf lines at the same time.
 __global__ __launch_bounds__(1024) void kt_tsdf_tasks_kernel(const unsigned int* __restrict__ wrange, int M, int XG,
                                                              unsigned int* __restrict__ tasks, unsigned int* __restrict__ task_count)
 {
     __shared__ unsigned int wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (M + 1023) / 1024;
-    const int i0 = tid * per, i1 = min(M, i0 + per);
+    const int per = (((M + 1023) / 1024) + 1) & ~1;   // even: runs start on an even wave-column
+    const int i0 = min(M, tid * per), i1 = min(M, i0 + per);
     unsigned int mine = 0;
     for (int i = i0; i < i1; ++i) {
         const unsigned int r = wrange[i];
@@ -338,13 +340,21 @@ __global__ __launch_bounds__(1024) void kt_tsdf_tasks_kernel(const unsigned int*
         total += v;
     }
     unsigned int pos = base + incl - mine;
-    for (int i = i0; i < i1; ++i) {
-        const unsigned int r = wrange[i];
-        const int z0 = (int)(r & 0xffffu), z1 = (int)(r >> 16);
-        if (z0 < z1) {
-            const unsigned int sy = (unsigned int)(i / XG), xg = (unsigned int)(i % XG);
-            for (int c = z0 / KT_TSDF_ZCHUNK; c <= (z1 - 1) / KT_TSDF_ZCHUNK; ++c) tasks[pos++] = sy | (xg << 16) | ((unsigned int)c << 24);
+    for (int i = i0; i < i1; i += 2) {
+        int c0[2] = {1, 1}, c1[2] = {0, 0};   // chunk range of the pair's two columns (empty: c0 > c1)
+        unsigned int key[2] = {0, 0};
+        for (int k = 0; k < 2; ++k) {
+            if (i + k >= i1) continue;
+            const unsigned int r = wrange[i + k];
+            const int z0 = (int)(r & 0xffffu), z1 = (int)(r >> 16);
+            if (z0 < z1) { c0[k] = z0 / KT_TSDF_ZCHUNK; c1[k] = (z1 - 1) / KT_TSDF_ZCHUNK; }
+            key[k] = (unsigned int)((i + k) / XG) | ((unsigned int)((i + k) % XG) << 16);
         }
+        const int lo = min(c0[0] <= c1[0] ? c0[0] : INT_MAX, c0[1] <= c1[1] ? c0[1] : INT_MAX);
+        const int hi = max(c0[0] <= c1[0] ? c1[0] : -1, c0[1] <= c1[1] ? c1[1] : -1);
+        for (int c = lo; c <= hi; ++c)
+            for (int k = 0; k < 2; ++k)
+                if (c >= c0[k] && c <= c1[k]) tasks[pos++] = key[k] | ((unsigned int)c << 24);
     }
     if (tid == 0) *task_count = total;
 }
