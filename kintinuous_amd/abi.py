@@ -13,7 +13,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkt_hip.so")
+LIB_PATH = os.environ.get("KT_HIP_LIB") or os.path.join(_HERE, "libkt_hip.so")   # KT_HIP_LIB: an alternative build (A/B experiments)
 
 KT_OK = 0
 
