@@ -160,9 +160,14 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
 //                                has voxels to update and the SIMDs stay full of loads in flight.
 // A task replays the incremental float walk of v_x / v_y from z = 0 to its first z (quirk A.17: the values are DEFINED by
 // repeated +=; pure ALU, ~0.5 us), then runs the reference loop body 4 z-steps at a time with the loads of the 4 steps batched.
+// (measured, 512^3 orbit / 768^3 static: ZCHUNK 8 -> -1% / -17%, 32 -> -4% / -2%; 4096 waves -> -4% / -10%, 16384 -> 0% / +2%)
+#ifndef KT_TSDF_ZCHUNK
 #define KT_TSDF_ZCHUNK 16
+#endif
 #define KT_TSDF_UNROLL 4
+#ifndef KT_TSDF_WAVES
 #define KT_TSDF_WAVES 8192
+#endif
 // shape of a wave-column: 32 consecutive storage x of 2 consecutive y.  (64 x 1 wastes a third of the lanes at the left / right
 // frustum faces; 32 x 2 halves that and still moves 64 B of tsdf + 128 B of colour per row and access; 16 x 4 is another 5%
 // better on the sparse 512^3 orbit but 10% worse on the dense 1280x960 @ 768^3 case, where the 32-byte rows cost more than the lanes.)
