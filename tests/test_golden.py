@@ -96,3 +96,101 @@ def test_hip_reproduces_golden(ctx, g):
             assert np.abs(trk.dense_pose(k)[1] - g[f"trk_{name}_poses"][k]).max() < 1e-6, (name, k)
         assert _eq(trk.volume(), g[f"trk_{name}_vol"]) and _eq(trk.color_volume()[..., 3], g[f"trk_{name}_colw"])
         trk.close()
+
+
+# ---- golden_v2: full colour volumes, -p ground truth, -d dynamic cube, view products, JPEG colour -------------------------------------
+G2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v2.npz")
+
+
+@pytest.fixture(scope="module")
+def g2():
+    return dict(np.load(G2))
+
+
+def _cfg_args(g, **kw):
+    d = dict(voxel_shift=14, dynamic_cube=0)
+    d.update(kw)
+    return (int(g["cols"]), int(g["rows"]), 64, *[float(x) for x in g["intr"]], 6.0, d["voxel_shift"], 2, 0, 0, 0, 0, 0, 0, d["dynamic_cube"])
+
+
+def _run_v2(g2, make, finish):
+    """The three tracker scenarios of golden_v2 on a tracker factory `make(args)`; `finish(trk)` closes it."""
+    out = {}
+    trk = make(_cfg_args(g2))
+    for k in range(4):
+        trk.process_frame(g2[f"depth{k}"], g2[f"rgb{k}"], 33333 * k)
+    out["icp_vol"], out["icp_color"] = trk.volume().copy(), trk.color_volume().copy()
+    finish(trk)
+    trk = make(_cfg_args(g2))
+    trk.load_trajectory(g2["gt_stamps"], g2["gt_rows"])
+    for k in range(6):
+        trk.process_frame(g2[f"depth{k}"], g2[f"rgb{k}"], int(g2["gt_all_stamps"][k]))
+    out["gt_poses"] = np.stack([trk.dense_pose(i)[1] for i in range(trk.num_poses())])
+    out["gt_vol"], out["gt_color"] = trk.volume().copy(), trk.color_volume().copy()
+    finish(trk)
+    trk = make(_cfg_args(g2, dynamic_cube=1, voxel_shift=2))
+    basis, wraps = [], []
+    for k in range(8):
+        trk.process_frame(g2[f"dyn_depth{k}"], g2[f"dyn_rgb{k}"], 33333 * k)
+        basis.append(trk.volume_basis())
+        wraps.append(np.array(trk.voxel_wrap()))
+    out["dyn_basis"], out["dyn_wrap"] = np.stack(basis), np.stack(wraps)
+    out["dyn_poses"] = np.stack([trk.dense_pose(i)[1] for i in range(trk.num_poses())])
+    out["dyn_vol"], out["dyn_color"] = trk.volume().copy(), trk.color_volume().copy()
+    finish(trk)
+    return out
+
+
+def test_oracle_reproduces_golden_v2(oracle_mod, g2):
+    from oracle.oracle import OTrackerConfig, OracleTracker
+    got = _run_v2(g2, lambda a: OracleTracker(OTrackerConfig(*a)), lambda t: t.close())
+    for key, val in got.items():
+        assert _eq(val, g2[key]), key
+    img, col = oracle_mod.generate_image(g2["view_vmap"], g2["view_nmap"], g2["view_vcol"], [-18.0, -18.0, -18.0])
+    assert _eq(img, g2["view_img"]) and _eq(col, g2["view_color"])
+    assert _eq(oracle_mod.generate_depth(oracle_mod.mat33_inverse(g2["view_R"]), g2["view_t"], g2["view_vmap"], g2["view_nmap"]), g2["view_depth"])
+
+
+def test_jpeg_decoders_reproduce_golden_v2(g2, tmp_path):
+    """Both the numpy reference decoder and the C++ decoder of the .klg reader give the committed bytes for the committed streams."""
+    import subprocess
+    from kintinuous_amd import build, jpeg_ref
+    build.build_host()
+    cols, rows = int(g2["cols"]), int(g2["rows"])
+    for name in ("420", "422r", "444n"):
+        data = g2[f"jpeg_{name}"].tobytes()
+        assert _eq(jpeg_ref.decode(data), g2[f"jpeg_{name}_bgr"]), name
+        src, dst = tmp_path / f"{name}.jpg", tmp_path / f"{name}.bgr"
+        src.write_bytes(data)
+        r = subprocess.run([build.JPEG_TOOL, str(src), str(cols), str(rows), str(dst)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        assert _eq(np.frombuffer(dst.read_bytes(), np.uint8).reshape(rows, cols, 3), g2[f"jpeg_{name}_bgr"]), name
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_v2(ctx, g2):
+    from kintinuous_amd import abi
+
+    class Host:   # the tracker fed with host frames, with the oracle tracker's method names
+        def __init__(self, args):
+            self.t = abi.Tracker(ctx, abi.TrackerConfig(*args))
+
+        def process_frame(self, d, rgb, ts):
+            self.t.process_frame_host(d, rgb, ts)
+
+        def __getattr__(self, name):
+            return getattr(self.t, name)
+
+    got = _run_v2(g2, Host, lambda t: t.t.close())
+    for key, val in got.items():
+        if key.endswith("_poses") and key != "gt_poses":
+            assert np.abs(val - g2[key]).max() < 1e-6, key      # device libm in Rodrigues: see test_gpu_tracker.py
+        else:
+            assert _eq(val, g2[key]), key
+    rows, cols = int(g2["rows"]), int(g2["cols"])
+    dv, dn, dc = ctx.upload(g2["view_vmap"]), ctx.upload(g2["view_nmap"]), ctx.upload(g2["view_vcol"])
+    di, dcol, dd = ctx.empty(rows * cols * 3), ctx.empty(rows * cols * 3), ctx.empty(rows * cols * 2)
+    ctx.generate_image(dv, dn, dc, cols, rows, [-18.0, -18.0, -18.0], 1, di, dcol)
+    ctx.generate_depth(abi.host_mat33_inverse(g2["view_R"]), g2["view_t"], dv, dn, cols, rows, dd)
+    assert _eq(ctx.download(di, np.uint8, (rows, cols, 3)), g2["view_img"]) and _eq(ctx.download(dcol, np.uint8, (rows, cols, 3)), g2["view_color"])
+    assert _eq(ctx.download(dd, np.uint16, (rows, cols)), g2["view_depth"])
