@@ -193,9 +193,10 @@ int kt_tracker_reset(kt_tracker* t);
 int kt_tracker_process_frame(kt_tracker* t, const uint16_t* depth_dev, const uint8_t* rgb24_dev, uint64_t timestamp);
 /* Optional read-ahead for log playback: announce a frame that a LATER kt_tracker_process_frame call will receive (same two
  * pointers, contents unchanged until then).  Its pose-independent stages (bilateral filter, depth / vertex / normal pyramids,
- * scaleDepth) run on a second HIP stream, overlapped with the fusion of the frame before it.  One announced frame may be
- * outstanding; handing a different frame to kt_tracker_process_frame first is legal but discards the read-ahead.  Best issued right
- * after the kt_tracker_process_frame call of the preceding frame.  Results are identical with and without it. */
+ * scaleDepth) run on a second HIP stream, overlapped with the fusion of the frame before it.  Up to two announced frames
+ * may be outstanding (a third is refused with KT_ERR_STATE); frames may be handed to kt_tracker_process_frame in any order -- an
+ * announced frame is found by its pointers, one that is skipped gives its buffers back.  Best issued right before the
+ * kt_tracker_process_frame call of the preceding frame.  Results are identical with and without it. */
 int kt_tracker_prefetch_frame(kt_tracker* t, const uint16_t* depth_dev, const uint8_t* rgb24_dev);
 /* the same for host-resident frames: pinned staging copy + upload + the pose-independent stages, all on the read-ahead stream.  A
  * later kt_tracker_process_frame_host call with the SAME two host pointers consumes it, so outstanding frames need distinct host
