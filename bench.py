@@ -257,6 +257,22 @@ def cpu_baseline(cam, N, d, frames, nframes):
         otr.process_frame(frames[k][0], frames[k][1], 33333 * k)
     dt = time.perf_counter() - t0
     stages = otr.stage_seconds()
+    # the same tracker on ONE thread, two more frames (SURVEY 8d asks for both ends of the host's range)
+    single = None
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        t1 = time.perf_counter()
+        m = 0
+        for k in range(n, min(n + 2, len(frames))):
+            otr.process_frame(frames[k][0], frames[k][1], 33333 * k)
+            m += 1
+        if m:
+            single = m / (time.perf_counter() - t1)
+        gomp.omp_set_num_threads(cores)
+    except OSError:
+        pass
     otr.close()
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -264,7 +280,8 @@ def cpu_baseline(cam, N, d, frames, nframes):
         model = "unknown"
     return {"value": (n - 1) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"frames 1..{n - 1} of the same sequence through oracle/ (OpenMP, {cores} threads) on {model}",
-            "stage_s_total": {k: round(v, 3) for k, v in stages.items()}}
+            "stage_s_total": {k: round(v, 3) for k, v in stages.items()},
+            "single_thread_value": single}
 
 
 if __name__ == "__main__":
