@@ -367,13 +367,22 @@ __global__ __launch_bounds__(1024) void kt_tsdf_tasks_kernel(const unsigned int*
 // One in-flight batch of KT_TSDF_UNROLL consecutive z steps of a wave: everything phase A produces for phase B.
 struct kt_tsdf_batch {
     bool in_img[KT_TSDF_UNROLL];
-    unsigned int off[KT_TSDF_UNROLL];   // storage element index of the voxel
+    unsigned int off[KT_TSDF_UNROLL];   // storage element index of the voxel (pointer path)
+    int sz[KT_TSDF_UNROLL];             // storage z (wave-uniform; buffer path)
     int bz[KT_TSDF_UNROLL];             // (storage z >> 5) * nb * nb (wave-uniform)
     float vgz[KT_TSDF_UNROLL];
     kt_pixrec rec[KT_TSDF_UNROLL];
     short tsdf_raw[KT_TSDF_UNROLL];
     uchar4 col[KT_TSDF_UNROLL];
 };
+
+// Buffer path (BUF, every N < 1024): the two volumes are addressed through buffer descriptors (descriptors for the pixel records
+// and the brick flags as well cost more SGPRs than the kernel has: 50 spills, more VALU than before).
+// A voxel access is then `buffer_load v, v_column_offset, s[descriptor], s_plane_offset`: the z-plane's byte offset lives in an SGPR
+// (z is wave-uniform), the lane's offset inside the plane is loop-invariant, and no per-step VALU address arithmetic is left
+// (the pointer path spends 2-5 VALU per access on 64-bit adds, a quarter-rate multiply for the pixel index included).
+// Needs 32-bit byte offsets: N^3 * 4 < 2^32.
+struct kt_tsdf_bufs { __amdgpu_buffer_rsrc_t vol, col; };
 
 // The voxel kernel runs the reference loop body KT_TSDF_UNROLL z-steps at a time in two phases:
 //   issue    projection of the 4 voxels, then ALL their loads at once -- the 16-byte pixel record and, speculatively for every
@@ -383,10 +392,10 @@ struct kt_tsdf_batch {
 // Every lane of the wave walks the same z sequence: each volume access is one contiguous 128 B / 256 B segment.
 // (Non-temporal volume loads / stores, meant to keep the streamed volume from evicting the pixel records in L2, measured 17% slower
 // on the 512^3 orbit and neutral on the dense 768^3 case.)
-template <bool COUNT>
-__device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, kt_tsdf_batch& b, int zb, int z0, int z1, unsigned int col_base,
-                                              unsigned int plane, float v_z, float& v_x, float& v_y, float dvx, float dvy, float tab_vgz,
-                                              float tab_zs, int tab_base)
+template <bool COUNT, bool BUF>
+__device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, const kt_tsdf_bufs& m, kt_tsdf_batch& b, int zb, int z0, int z1,
+                                              unsigned int col_base, unsigned int plane, float v_z, float& v_x, float& v_y, float dvx,
+                                              float dvy, float tab_vgz, float tab_zs, int tab_base)
 {
     const int N = a.N;
 #pragma unroll
@@ -402,22 +411,35 @@ __device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, kt_tsdf_b
         const int coo_x = kt_f2i_rn(__builtin_fmaf(v_x, inv_z, a.intr.cx));
         const int coo_y = kt_f2i_rn(__builtin_fmaf(v_y, inv_z, a.intr.cy));
         b.in_img[u] = live && !(inv_z < 0) && coo_x >= 0 && coo_y >= 0 && coo_x < a.cols && coo_y < a.rows;
-        const int pix = b.in_img[u] ? coo_y * a.cols + coo_x : 0;
         int sz = zz + a.wz; if (sz >= N) sz -= N;
-        b.off[u] = col_base + (unsigned int)sz * plane;
         b.bz[u] = (sz >> KT_BRICK_LOG2) * a.nb * a.nb;
+        // coo_x, coo_y < 2^24 inside the image: the 24-bit multiply is exact there (and full rate, unlike v_mul_lo_u32)
+        const unsigned int pix = b.in_img[u] ? __umul24((unsigned int)coo_y, (unsigned int)a.cols) + (unsigned int)coo_x : 0u;
         b.rec[u] = a.rec[pix];
+        if constexpr (BUF) b.sz[u] = sz;
+        else b.off[u] = col_base + (unsigned int)sz * plane;
         v_x += dvx;  // the walk advances on every step, also on skipped ones
         v_y += dvy;
     }
 #pragma unroll
     for (int u = 0; u < KT_TSDF_UNROLL; ++u)
-        if (b.in_img[u]) { b.tsdf_raw[u] = a.volume[b.off[u]]; b.col[u] = a.color[b.off[u]]; }
+        if (b.in_img[u]) {
+            if constexpr (BUF) {
+                const unsigned int zoff = (unsigned int)b.sz[u] * plane;   // elements; wave-uniform
+                b.tsdf_raw[u] = __builtin_amdgcn_raw_buffer_load_b16(m.vol, col_base * 2u, zoff * 2u, 0);
+                const unsigned int cw = __builtin_amdgcn_raw_buffer_load_b32(m.col, col_base * 4u, zoff * 4u, 0);
+                b.col[u] = *(const uchar4*)&cw;
+            } else {
+                b.tsdf_raw[u] = a.volume[b.off[u]];
+                b.col[u] = a.color[b.off[u]];
+            }
+        }
 }
 
-template <bool COUNT>
-__device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const kt_tsdf_batch& b, float v_g_part_norm, float tranc_dist_inv,
-                                                unsigned int& n_upd, int brick_xy, unsigned int& n_img)
+template <bool COUNT, bool BUF>
+__device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const kt_tsdf_bufs& m, const kt_tsdf_batch& b, float v_g_part_norm,
+                                                float tranc_dist_inv, unsigned int& n_upd, int brick_xy, unsigned int& n_img,
+                                                unsigned int col_base, unsigned int plane)
 {
 #pragma unroll
     for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
@@ -444,8 +466,13 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
             const float tsdf = is_free ? 1.0f : fminf(1.0f, sdf * tranc_dist_inv);
             const float tsdf_prev = kt_unpack_tsdf(b.tsdf_raw[u]);
             const short packed = kt_pack_tsdf(__builtin_fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
-            a.volume[b.off[u]] = packed;
-            if (a.bricks && packed < 0) a.bricks[b.bz[u] + brick_xy] = 1;  // idempotent byte store, no atomics
+            if constexpr (BUF) {
+                __builtin_amdgcn_raw_buffer_store_b16(packed, m.vol, col_base * 2u, (unsigned int)b.sz[u] * plane * 2u, 0);
+                if (a.bricks && packed < 0) a.bricks[b.bz[u] + brick_xy] = 1;  // idempotent byte store, no atomics
+            } else {
+                a.volume[b.off[u]] = packed;
+                if (a.bricks && packed < 0) a.bricks[b.bz[u] + brick_xy] = 1;  // idempotent byte store, no atomics
+            }
         }
         uchar4 o = c;
         o.w = (unsigned char)min((int)c.w + 1, (int)KT_MAX_WEIGHT);  // == __float2uchar_rz(min(W + 1, 128)) for every 8-bit W
@@ -482,14 +509,21 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
             o.y = (unsigned char)min(255, max(0, kt_f2i_rn(qy)));
             o.z = (unsigned char)min(255, max(0, kt_f2i_rn(qz)));
         }
-        a.color[b.off[u]] = o;
+        if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b32(*(const unsigned int*)&o, m.col, col_base * 4u, (unsigned int)b.sz[u] * plane * 4u, 0);
+        else a.color[b.off[u]] = o;
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool BUF>
 __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args a_in)
 {
     kt_tsdf23_args a = a_in;
+    kt_tsdf_bufs m = {};
+    if constexpr (BUF) {   // descriptors from kernel arguments only: they stay in SGPRs
+        const unsigned int nvox = (unsigned int)a_in.N * (unsigned int)a_in.N * (unsigned int)a_in.N;
+        m.vol = __builtin_amdgcn_make_buffer_rsrc((void*)a_in.volume, 0, nvox * 2u, 0x00020000);
+        m.col = __builtin_amdgcn_make_buffer_rsrc((void*)a_in.color, 0, nvox * 4u, 0x00020000);
+    }
     (void)kt_tsdf_pose_from_device(a);   // a parked frame has an empty task list
     const int N = a.N;
     const int lane = threadIdx.x & 63;
@@ -552,8 +586,8 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
         // 4-batch version with two batches in flight needs 96 VGPRs = 5 waves per SIMD and measured 15% / 40% slower at 512^3 / 768^3.)
         for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
             kt_tsdf_batch cur;
-            kt_tsdf_issue<COUNT>(a, cur, zb, z0, z1, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base);
-            kt_tsdf_consume<COUNT>(a, cur, v_g_part_norm, tranc_dist_inv, n_upd, brick_xy, n_img);
+            kt_tsdf_issue<COUNT, BUF>(a, m, cur, zb, z0, z1, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base);
+            kt_tsdf_consume<COUNT, BUF>(a, m, cur, v_g_part_norm, tranc_dist_inv, n_upd, brick_xy, n_img, col_base, plane);
             if (COUNT) ++n_batches;
         }
         if (COUNT) ++n_tasks_done;
@@ -702,8 +736,14 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     KT_LAUNCH_CHECK();
     dim3 b(256), g(KT_TSDF_WAVES / 4);
     if (kt_tsdf23_hook.on) KT_HIP(hipEventRecord(kt_tsdf23_hook.ev[0], c->stream));
-    if (updated_dev) hipLaunchKernelGGL(kt_tsdf23_kernel<true>, g, b, 0, c->stream, a);
-    else hipLaunchKernelGGL(kt_tsdf23_kernel<false>, g, b, 0, c->stream, a);
+    const bool buf = N < 1024 && !getenv("KT_TSDF_POINTERS");   // 32-bit byte offsets into the colour volume (N^3 * 4 < 2^32)
+    if (updated_dev) {
+        if (buf) hipLaunchKernelGGL((kt_tsdf23_kernel<true, true>), g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((kt_tsdf23_kernel<true, false>), g, b, 0, c->stream, a);
+    } else {
+        if (buf) hipLaunchKernelGGL((kt_tsdf23_kernel<false, true>), g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((kt_tsdf23_kernel<false, false>), g, b, 0, c->stream, a);
+    }
     KT_LAUNCH_CHECK();
     if (kt_tsdf23_hook.on) {
         kt_tsdf23_hook.on = false;  // one-shot: armed by the tracker per call
