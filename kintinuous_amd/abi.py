@@ -522,6 +522,15 @@ def host_mat33_inverse(m) -> np.ndarray:
     return o.reshape(3, 3)
 
 
+def host_reposition_cube(R, tlast, volume_size, voxel_size, thresh, basis) -> np.ndarray:
+    R = np.ascontiguousarray(R, np.float32).reshape(9)
+    t = np.ascontiguousarray(tlast, np.float32)
+    v = np.ascontiguousarray(voxel_size, np.float32)
+    b = np.ascontiguousarray(basis, np.float32).copy()
+    lib().kt_host_reposition_cube(R.ctypes.data_as(_pf), t.ctypes.data_as(_pf), float(volume_size), v.ctypes.data_as(_pf), int(thresh), b.ctypes.data_as(_pf))
+    return b
+
+
 def host_pose_update(x, result_rt, Rprev, tprev):
     """Returns (result_rt', Rcurr, tcurr) -- ICPOdometry.cpp:133-178."""
     x = np.ascontiguousarray(x, np.float64).reshape(6)

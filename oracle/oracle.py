@@ -320,6 +320,13 @@ def rodrigues(r) -> np.ndarray:
     return R.reshape(3, 3)
 
 
+def reposition_cube(R, tlast, volume_size, voxel_size, thresh, basis) -> np.ndarray:
+    """KintinuousTracker::repositionCube on explicit state; returns the (possibly moved) basis."""
+    b = (C.c_float * 3)(*[float(v) for v in basis])
+    lib().kto_reposition_cube(_f3(np.asarray(R, np.float32).reshape(-1)), _f3(tlast), C.c_float(volume_size), _f3(voxel_size), int(thresh), b)
+    return np.array(b, np.float32)
+
+
 def quat_from_mat33(R) -> np.ndarray:
     q = (C.c_float * 4)()
     lib().kto_quat_from_mat33(C.byref(OMat33.from_np(R)), q)

@@ -125,3 +125,31 @@ def test_host_math_abi_matches_oracle(oracle_mod):
     assert np.array_equal(Rc, np.eye(3, dtype=np.float32)) and np.array_equal(tc, np.array([1, 2, 3], np.float32))
     rt, Rc, tc = abi.host_pose_update([0.5, 0, 0, 0, 0, 0], np.eye(4), np.eye(3), [1, 2, 3])
     assert np.allclose(tc, [0.5, 2, 3]) and rt[0, 3] == 0.5
+
+
+def test_reposition_cube_abi_matches_oracle(oracle_mod):
+    """kt_host_reposition_cube vs the oracle over random rotations -- the general branch, the small-angle branch (identity and
+    nearly identity), rotations by almost pi (axis from the diagonal) and not-quite-orthonormal matrices: bit-identical bases."""
+    from kintinuous_amd import abi
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(11)
+    cases = [np.eye(3)]
+    for k in range(200):
+        axis = rng.standard_normal(3)
+        axis /= np.linalg.norm(axis)
+        angle = [rng.uniform(0, np.pi), 1e-7 * rng.uniform(), np.pi - 1e-6 * rng.uniform(), np.pi][k % 4]
+        R = Rotation.from_rotvec(axis * angle).as_matrix()
+        if k % 7 == 0:
+            R = R + rng.standard_normal((3, 3)) * 1e-4          # tracked rotations drift off SO(3) a little
+        cases.append(R)
+    moved = 0
+    for R in cases:
+        R = R.astype(np.float32)
+        t = (np.array([3.0, 3.0, 0.0]) + rng.uniform(-0.6, 0.6, 3)).astype(np.float32)
+        basis = np.array([3.0, 3.0, 0.0], np.float32)
+        for thresh in (2, 14):
+            a = abi.host_reposition_cube(R, t, 6.0, [6.0 / 96] * 3, thresh, basis)
+            b = oracle_mod.reposition_cube(R, t, 6.0, [6.0 / 96] * 3, thresh, basis)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (R, t, thresh, a, b)
+            moved += int(not np.array_equal(a, basis))
+    assert moved > 50      # both outcomes are exercised
