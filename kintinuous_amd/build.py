@@ -68,20 +68,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
 HOST_DIR = os.path.join(_HERE, "host")
 HOST_BIN = os.path.join(HOST_DIR, "bin", "kintinuous_hip")
 JPEG_TOOL = os.path.join(HOST_DIR, "bin", "jpeg_tool")
+KLG_TOOL = os.path.join(HOST_DIR, "bin", "klg_tool")
 
 
 def build_host(force: bool = False) -> str:
     """g++ build of the C++ host shell's headless driver (kintinuous_amd/host/main.cpp) against libkt_hip.so."""
     deps = [os.path.join(dp, f) for dp, _, fs in os.walk(HOST_DIR) for f in fs if f.endswith((".h", ".hpp", ".cpp"))]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "kt_abi.h"))
-    if not force and os.path.exists(HOST_BIN) and os.path.exists(JPEG_TOOL) and all(
-            os.path.getmtime(d) <= min(os.path.getmtime(HOST_BIN), os.path.getmtime(JPEG_TOOL)) for d in deps):
+    outs = (HOST_BIN, JPEG_TOOL, KLG_TOOL)
+    if not force and all(os.path.exists(o) for o in outs) and all(os.path.getmtime(d) <= min(os.path.getmtime(o) for o in outs) for d in deps):
         return HOST_BIN
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
     # the .klg colour decoder on its own (no HIP dependency): used by the CPU tests
-    r = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", os.path.join(HOST_DIR, "jpeg_tool.cpp"), "-o", JPEG_TOOL], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"jpeg_tool build failed:\n{r.stderr}")
+    for src, out, libs in (("jpeg_tool.cpp", JPEG_TOOL, []), ("klg_tool.cpp", KLG_TOOL, ["-lz"])):
+        r = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", os.path.join(HOST_DIR, src), "-o", out] + libs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{src} build failed:\n{r.stderr}")
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.dirname(_HERE), os.path.join(HOST_DIR, "main.cpp"), "-o", HOST_BIN,
            "-L", _HERE, "-lkt_hip", "-lz", "-Wl,-rpath,$ORIGIN/../..", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)

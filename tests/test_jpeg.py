@@ -105,3 +105,29 @@ def test_klg_with_jpeg_colour_round_trip(tool, tmp_path):
     for (ts, d, rgb), (d0, rgb0) in zip(back, frames):
         assert np.array_equal(d, d0)
         assert np.array_equal(rgb, jpeg_ref.decode(jpeg_ref.encode(np.ascontiguousarray(rgb0), quality=90)))
+
+
+@pytest.mark.parametrize("layout", ["raw", "zlib", "jpeg", "jpeg_flip"])
+def test_cxx_log_reader(tool, tmp_path, layout):
+    """The C++ RawLogReader (host/klg_tool) against the Python reader on the same log: timestamps, depth and colour bytes of every
+    frame it returns (raw, zlib depth, JPEG colour, -f colour flip), and the reference's quirk that the last frame never comes out."""
+    import zlib
+    from kintinuous_amd import build, klg, synth
+    cam = synth.Camera.small(160, 120)
+    frames = [synth.render(synth.Scene("room"), cam, *p) for p in synth.orbit_trajectory(4)]
+    path = str(tmp_path / "t.klg")
+    klg.write_klg(path, frames, timestamps=[7 + 33333 * k for k in range(4)], cols=cam.cols, rows=cam.rows, compress_depth=layout != "raw",
+                  jpeg_quality=90 if layout.startswith("jpeg") else 0)
+    args = [build.KLG_TOOL, "-l", path, "-w", str(cam.cols), "-h", str(cam.rows)] + (["-f"] if layout == "jpeg_flip" else [])
+    r = subprocess.run(args, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split() for l in r.stdout.splitlines()]
+    want = list(klg.read_klg(path, cols=cam.cols, rows=cam.rows))          # reference_quirk=True: 3 of the 4 frames
+    assert len(lines) == len(want) == 3
+    for (ts, cd, ci, comp), (wts, wd, wrgb) in zip(lines, want):
+        if layout == "jpeg_flip":
+            wrgb = wrgb[..., ::-1]
+        assert int(ts) == wts
+        assert int(cd, 16) == zlib.crc32(np.ascontiguousarray(wd, "<u2").tobytes())
+        assert int(ci, 16) == zlib.crc32(np.ascontiguousarray(wrgb).tobytes())
+        assert int(comp) == int(layout != "raw")
