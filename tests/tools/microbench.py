@@ -1,7 +1,7 @@
 """Runs individual C-ABI kernels at VGA size repeatedly (meant to run under rocprofv3 --kernel-trace --stats)."""
 import os, sys
 os.environ.setdefault("OMP_NUM_THREADS", "8")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from kintinuous_amd import abi, synth
 from oracle import oracle

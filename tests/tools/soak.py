@@ -1,6 +1,6 @@
 """Soak: long shifting sequence, HIP tracker (device frames + read-ahead) vs the oracle tracker, every pose compared."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("OMP_NUM_THREADS", "16")
 import numpy as np
 from kintinuous_amd import abi, synth
