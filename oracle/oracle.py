@@ -13,7 +13,7 @@ from typing import Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkt_oracle.so")
+LIB_PATH = os.environ.get("KT_ORACLE_LIB") or os.path.join(_HERE, "libkt_oracle.so")   # KT_ORACLE_LIB: e.g. a sanitizer build
 
 
 class OIntr(C.Structure):
