@@ -181,6 +181,8 @@ def main():
     # algorithmic bytes of the tsdf23 launch (DESIGN.md "integrate"): 12 B per updated voxel (2 B tsdf + 4 B colour/weight,
     # read and written) + the per-pixel record gathered by the voxels (16 B, counted once per pixel)
     bytes_tsdf23 = 12.0 * U + 16.0 * P
+    if tsdf23_n == 0 or tsdf23_ms <= 0:   # very short runs: no timed frame carried the event pair -> the untimed stage pass's launches
+        tsdf23_ms, tsdf23_n = stage_all["tsdf23"][0], 0
     achieved = bytes_tsdf23 / (tsdf23_ms * 1e-3) / 1e9 if tsdf23_ms > 0 else 0.0
     peak = 8000.0
     # HBM-side traffic of the same kernel: PMC counters cannot be read from inside the process, so this is the committed rocprofv3
