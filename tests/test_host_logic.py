@@ -107,14 +107,22 @@ def test_host_math_abi_matches_oracle(oracle_mod):
     import numpy as np
     from kintinuous_amd import abi
     rng = np.random.default_rng(7)
-    for trial in range(20):
-        J = rng.standard_normal((40, 6))
+    # well conditioned, rank deficient, badly scaled and ICP-like (float sums widened) systems
+    for trial in range(3000):
+        J = rng.standard_normal((40, 6)) * rng.uniform(0.1, 10.0, 6)
         A = J.T @ J
         if trial % 5 == 4:
             A[:, 3] = A[:, 2]; A[3, :] = A[2, :]          # rank deficient: pseudo-inverse branch
-        b = rng.standard_normal(6)
+        if trial % 7 == 3:
+            A *= 10.0 ** rng.integers(-200, 200)
+        if trial % 11 == 5 and trial % 7 != 3:
+            A = A.astype(np.float32).astype(np.float64)   # float sums widened, as the trackers feed it
+        b = rng.standard_normal(6) * 10.0 ** rng.integers(-3, 4)
+        if trial % 13 == 0:
+            b[rng.integers(0, 6)] = 0.0
         x, xo = abi.host_ldlt_solve6(A, b), oracle_mod.ldlt_solve6(A, b)
-        assert np.array_equal(x.view(np.uint64), xo.view(np.uint64))
+        assert np.array_equal(x.view(np.uint64), xo.view(np.uint64)), trial
+    for trial in range(20):
         r = rng.standard_normal(3) * (1e-9 if trial == 0 else 0.3)
         assert np.array_equal(abi.host_rodrigues(r).view(np.uint64), oracle_mod.rodrigues(r).view(np.uint64))
         from tests.conftest import random_rotation
