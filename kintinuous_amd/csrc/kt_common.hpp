@@ -88,6 +88,7 @@ __device__ __forceinline__ float kt_expf(float x)
 {
     float t = x * 1.44269504088896341f;
     if (!(t >= -125.0f)) return 0.0f;
+    if (t >= 128.0f) return __builtin_inff();   // ex2.approx overflows to +inf (reached when bilateralKernel's int product wraps)
     float n = __builtin_rintf(t);
     float r = __builtin_fmaf(n, -0.693359375f, x);
     r = __builtin_fmaf(n, 2.12194440e-4f, r);

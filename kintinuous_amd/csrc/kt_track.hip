@@ -13,8 +13,10 @@
 // is not.  So one 1024-thread workgroup per CUDA WARP (256 workgroups = every CU of the MI355X):
 //   phase 1: its 32 vts' pixels are processed one per thread, fully parallel and coalesced (32 consecutive pixels per
 //            k-step); the 7-vector row + inlier flag of every pixel goes to LDS as rows[k][component][vt] (bank-conflict free);
-//   phase 2: thread (c, vt) owns product c of vt and walks k in order: acc += row[a_c] * row[b_c] -- 29 x 32 independent
-//            chains, exactly the reference's per-thread sums;
+//   phase 2: thread (c, vt) owns product c of vt and walks k in order: acc = fma(row[a_c], row[b_c], acc) -- 29 x 32
+//            independent chains, exactly the reference's per-thread sums (`sum.add(getProducts(i))`, reduce.cu:322-327: the
+//            product's only user is the accumulation, so nvcc's -fmad=true contracts it; oracle/_ref, the reference source
+//            compiled by clang with -ffp-contract=fast, pins that);
 //   tree:    lanes are laid out c-major, so each 32-lane half-wave holds one product of the 32 vts = one CUDA warp:
 //            ds_swizzle(xor 16) + DPP row_shl 8/4/2/1 reproduces warpReduceSum;
 //   hand-off: the data is the flag (cdna_hip_programming.md G16 form R2): each warp sum goes out as ONE aligned 8-byte
@@ -105,7 +107,7 @@ __device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsi
         if (comp < 29) {
             const int kend = min(kcount, nk_vt - kb);
             if (comp < 28) {
-                for (int kl = 0; kl < kend; ++kl) acc += rows[kl][my_a][vt] * rows[kl][my_b][vt];
+                for (int kl = 0; kl < kend; ++kl) acc = __builtin_fmaf(rows[kl][my_a][vt], rows[kl][my_b][vt], acc);
             } else {
                 for (int kl = 0; kl < kend; ++kl) acc += rows[kl][7][vt];
             }
@@ -160,8 +162,8 @@ __device__ __forceinline__ void kt_reduce29_publish2(const RowFnA& fa, const Row
             const int kend = min(kcount, nk_vt - kb);
             if (comp < 28) {
                 for (int kl = 0; kl < kend; ++kl) {
-                    acc_a += rows_a[kl][my_a][vt] * rows_a[kl][my_b][vt];
-                    acc_b += rows_b[kl][my_a][vt] * rows_b[kl][my_b][vt];
+                    acc_a = __builtin_fmaf(rows_a[kl][my_a][vt], rows_a[kl][my_b][vt], acc_a);
+                    acc_b = __builtin_fmaf(rows_b[kl][my_a][vt], rows_b[kl][my_b][vt], acc_b);
                 }
             } else {
                 for (int kl = 0; kl < kend; ++kl) { acc_a += rows_a[kl][7][vt]; acc_b += rows_b[kl][7][vt]; }
@@ -716,9 +718,9 @@ struct kt_rgb_row {
         const float v1 = dI_dy_val * a.fy * invz;
         const float v2 = -__builtin_fmaf(v0, X, v1 * Y) * invz;
         row[0] = v0; row[1] = v1; row[2] = v2;
-        row[3] = __builtin_fmaf(-Z, v1, Y * v2);
+        row[3] = __builtin_fmaf(Y, v2, -(Z * v1));   // -Z*v1 + Y*v2 is canonicalised to Y*v2 - Z*v1 before contraction (oracle/_ref)
         row[4] = __builtin_fmaf(Z, v0, -(X * v2));
-        row[5] = __builtin_fmaf(-Y, v0, X * v1);
+        row[5] = __builtin_fmaf(X, v1, -(Y * v0));   // likewise: X*v1 - Y*v0
         return true;
     }
 };

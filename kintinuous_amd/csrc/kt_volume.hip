@@ -1442,7 +1442,8 @@ __global__ __launch_bounds__(256) void kt_extract_kernel(const kt_extract_args a
                     float p[3] = {V[0], V[1], V[2]};
                     const float Vn = V[axis] + cell[axis];
                     const float d_inv = 1.f / (fabsf(F) + fabsf(Fn));
-                    p[axis] = __builtin_fmaf(V[axis], fabsf(Fn), Vn * fabsf(F)) * d_inv;
+                    // dz: the other product is the contracted one (LLVM operand order on extract.cu:224, pinned by oracle/_ref)
+                    p[axis] = (axis == 2 ? __builtin_fmaf(Vn, fabsf(F), V[axis] * fabsf(Fn)) : __builtin_fmaf(V[axis], fabsf(Fn), Vn * fabsf(F))) * d_inv;
                     pts[local] = make_float4(p[0], p[1], p[2], 0.f);
                     // colour of the NEIGHBOUR voxel, alpha = weight of the base voxel; the point's byte order is
                     // b,g,r,a with ptr->b = colour.x and ptr->r = colour.z (store_point_type, quirk A.14)

@@ -64,11 +64,13 @@ static inline int16_t f2s16_rz(float x)
 /* Restatement of __expf (bilateral_pyrdown.cu:89): exp(x) = 2^n * e^r, n = rint(x*log2e),
  * r = x - n*ln2 (two-step Cody-Waite), e^r by the cephes degree-6 polynomial, every step an explicit
  * fmaf so that the HIP kernel can repeat it bit for bit.  Results below 2^-125 flush to 0 (the reference
- * is built with --ftz=true). Only called with x <= 0. */
+ * is built with --ftz=true) and from 2^128 up the result is +inf, like ex2.approx: the argument is positive when the
+ * int product (value - tmp)^2 of bilateralKernel wraps (depth differences > 46340 mm; found by oracle/_ref). */
 float kto_expf(float x)
 {
     float t = x * 1.44269504088896341f;
     if (!(t >= -125.0f)) return 0.0f; /* also catches NaN */
+    if (t >= 128.0f) return INFINITY;
     float n = rintf(t);
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);
@@ -499,13 +501,22 @@ static void block_reduce(float (*thr)[29], int nthreads, float out[29])
     warp_tree(shared, 0);
     memcpy(out, shared[0], sizeof(float) * 29);
 }
-static void reduce29(const float* vals, int n, int threads, int blocks, int order, float out[29])
+/* `rows` = per-element 8-vectors {row[0..6], found}, n elements.  The per-thread accumulation is
+ * `sum.add(getProducts(i))` (reduce.cu:322-327 / :531-536): after inlining every one of the 28 products row[i] * row[j]
+ * has the accumulator as its only user, so `acc += row[i] * row[j]` contracts to fma(row[i], row[j], acc) under nvcc's
+ * default -fmad=true (and under clang -ffp-contract=fast, which is how oracle/_ref pins it); inliers is a plain add. */
+static void reduce29(const float* rows, int n, int threads, int blocks, int order, float out[29])
 {
     if (order == 1) {
         double acc[29];
         for (int k = 0; k < 29; ++k) acc[k] = 0;
-        for (int i = 0; i < n; ++i)
-            for (int k = 0; k < 29; ++k) acc[k] += (double)vals[(size_t)i * 29 + k];
+        for (int i = 0; i < n; ++i) {
+            const float* r = &rows[(size_t)i * 8];
+            int s = 0;
+            for (int a = 0; a < 7; ++a)
+                for (int b = a; b < 7; ++b) acc[s++] += (double)r[a] * (double)r[b];
+            acc[28] += (double)r[7];
+        }
         for (int k = 0; k < 29; ++k) out[k] = (float)acc[k];
         return;
     }
@@ -513,8 +524,13 @@ static void reduce29(const float* vals, int n, int threads, int blocks, int orde
     float(*thr)[29] = calloc((size_t)T, sizeof(*thr));
 #pragma omp parallel for schedule(static)
     for (int t = 0; t < T; ++t)
-        for (int i = t; i < n; i += T)
-            for (int k = 0; k < 29; ++k) thr[t][k] += vals[(size_t)i * 29 + k];
+        for (int i = t; i < n; i += T) {
+            const float* r = &rows[(size_t)i * 8];
+            int s = 0;
+            for (int a = 0; a < 7; ++a)
+                for (int b = a; b < 7; ++b, ++s) thr[t][s] = fmaf(r[a], r[b], thr[t][s]);
+            thr[t][28] += r[7];
+        }
     float(*part)[29] = calloc(512, sizeof(*part)); /* reduceSum<<<1, 512>>>: thread i<blocks loads in[i] */
     for (int b = 0; b < blocks; ++b) block_reduce(&thr[b * threads], threads, part[b]);
     block_reduce(part, 512, out);
@@ -533,13 +549,10 @@ static void unpack29(const float h[29], float A[36], float b[6], float residual[
         }
     if (residual) { residual[0] = h[27]; residual[1] = h[28]; }
 }
-static inline void outer29(const float row[7], float found, float* v)
+static inline void store_row8(const float row[7], float found, float* v)
 {
-    int s = 0;
-    for (int i = 0; i < 7; ++i)
-        for (int j = i; j < 7; ++j) v[s++] = row[i] * row[j];
-    /* s == 28: aa..fg (27) + residual gg */
-    v[28] = found;
+    for (int i = 0; i < 7; ++i) v[i] = row[i];
+    v[7] = found;
 }
 
 /* ================================================================================================
@@ -551,7 +564,7 @@ void kto_icp_step(const kto_mat33* Rcurr, const float tcurr[3], const float* vma
                   float A[36], float b[6], float residual[2])
 {
     const int n = cols * rows;
-    float* vals = malloc((size_t)n * 29 * sizeof(float));
+    float* vals = malloc((size_t)n * 8 * sizeof(float));
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
         int y = i / cols, x = i - y * cols;
@@ -592,7 +605,7 @@ void kto_icp_step(const kto_mat33* Rcurr, const float tcurr[3], const float* vma
                 row[6] = dot3(n_cp, sd);
             }
         }
-        outer29(row, (float)found, &vals[(size_t)i * 29]);
+        store_row8(row, (float)found, &vals[(size_t)i * 8]);
     }
     float h[29];
     reduce29(vals, n, 128, 64, order, h); /* ICPOdometry.cpp:123-124: threads 128, blocks 64 */
@@ -662,7 +675,7 @@ void kto_rgb_step(const kto_dataterm* corres_img, float sigma, const float* clou
 {
     const int n = cols * rows;
     const float flt_eps = 1.19209290E-07F;
-    float* vals = malloc((size_t)n * 29 * sizeof(float));
+    float* vals = malloc((size_t)n * 8 * sizeof(float));
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
         const kto_dataterm* c = &corres_img[i];
@@ -682,11 +695,13 @@ void kto_rgb_step(const kto_dataterm* corres_img, float sigma, const float* clou
             float v1 = dI_dy_val * fy * invz;
             float v2 = -fmaf(v0, X, v1 * Y) * invz;
             row[0] = v0; row[1] = v1; row[2] = v2;
-            row[3] = fmaf(-Z, v1, Y * v2);
+            /* reduce.cu:478-480.  `-a*b + c*d` is canonicalised to `c*d - a*b` before contraction (LLVM InstCombine), so the
+             * fused product of rows 3 and 5 is the second one of the source expression (pinned by oracle/_ref) */
+            row[3] = fmaf(Y, v2, -(Z * v1));
             row[4] = fmaf(Z, v0, -(X * v2));
-            row[5] = fmaf(-Y, v0, X * v1);
+            row[5] = fmaf(X, v1, -(Y * v0));
         }
-        outer29(row, (float)found, &vals[(size_t)i * 29]);
+        store_row8(row, (float)found, &vals[(size_t)i * 8]);
     }
     float h[29];
     reduce29(vals, n, 128, 64, order, h); /* RGBDOdometry.cpp:306-307 */
@@ -1060,7 +1075,10 @@ size_t kto_extract_cloud_slice(const int16_t* volume, const float volume_size[3]
                     float p[3] = {V[0], V[1], V[2]};
                     float Vn = V[axis] + cell[axis];
                     float d_inv = 1.f / (fabsf(F) + fabsf(Fn));
-                    p[axis] = fmaf(V[axis], fabsf(Fn), Vn * fabsf(F)) * d_inv;
+                    /* (V * |Fn| + Vn * |F|) * d_inv, extract.cu:166, :195, :224.  For dx and dy the left product is the one
+                     * contracted; in the dz block V.z and Vnz are defined inside the z loop and LLVM's canonical operand
+                     * order puts Vnz * |F| first, so there the other product is fused (pinned by oracle/_ref). */
+                    p[axis] = (axis == 2 ? fmaf(Vn, fabsf(F), V[axis] * fabsf(Fn)) : fmaf(V[axis], fabsf(Fn), Vn * fabsf(F))) * d_inv;
                     size_t ni = wrap_index(nx, ny, nz, voxel_wrap, N);
                     if (count < out_cap) {
                         kto_point* o = &out[count];

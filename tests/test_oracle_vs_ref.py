@@ -1,0 +1,368 @@
+"""Pins the oracle to the reference: every kernel of oracle/kt_oracle_kernels.c against oracle/_ref/libkt_ref.so, which is
+the reference's OWN source files (frontend/cuda/*.cu + containers/device_memory.cpp) compiled for the CPU by oracle/Makefile
+against the CUDA emulation in oracle/ref_shim/ (fibers for threads, rendez-vous for __syncthreads / __shfl_down / __ballot).
+
+Bar: bit-exact -- integers, bytes, indices AND floats (the oracle's hand-placed fmaf() sites must be the contractions
+clang -ffp-contract=fast makes on the reference source; both sides use IEEE division / sqrt, rsqrtf = 1/sqrtf, denormals
+flushed inside kernels as --ftz=true does).  The two documented exceptions are asserted as such, not tolerated silently:
+  * __expf: _ref uses libm expf, the oracle its own kto_expf -- the bilateral filter output is identical except where the
+    last bit of a weight flips a tie of rn(sum1/sum2) (bounded: <= 2e-5 of the pixels, 1 mm);
+  * (unsigned char)NaN is undefined in C++ (CUDA gives 0): the raycast "heat" byte of pixels whose vertex lies within one
+    voxel of a volume face is excluded.
+What _ref cannot pin: nvcc's --prec-div=false / --prec-sqrt=false / ex2.approx (hardware approximations) and the
+host-side code of the path (Eigen / OpenCV), see DESIGN.md section 5.
+"""
+import numpy as np
+import pytest
+
+from conftest import random_rotation
+
+pytestmark = pytest.mark.skipif(not __import__("oracle.ref", fromlist=["available"]).available(), reason="oracle/_ref not built and /root/reference absent")
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import ref
+    ref.build()
+    ref.lib()
+    return ref
+
+
+def same(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    return np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def nmism(a, b):
+    return int((np.ascontiguousarray(a).view(np.uint8) != np.ascontiguousarray(b).view(np.uint8)).sum())
+
+
+def _frames(cols, rows, n, scene="room"):
+    from kintinuous_amd import synth
+    cam = synth.Camera.small(cols, rows) if (cols, rows) != (640, 480) else synth.Camera()
+    sc = synth.Scene(scene)
+    traj = synth.orbit_trajectory(n)
+    return cam, [synth.render(sc, cam, Rm, c) for (Rm, c) in traj], traj
+
+
+def _holes(depth, rng, frac=0.03):
+    d = depth.copy()
+    d[rng.random(d.shape) < frac] = 0
+    return d
+
+
+@pytest.mark.parametrize("cols,rows", [(160, 120), (96, 70), (640, 480)])
+def test_image_kernels(oracle_mod, R, cols, rows):
+    """a1-a5, a13 + the RGB-D pyramids (bilateral_pyrdown.cu, maps.cu) on ragged, VGA and hole-ridden inputs."""
+    O = oracle_mod
+    from oracle.oracle import OIntr
+    rng = np.random.default_rng(cols)
+    cam, frames, _ = _frames(cols, rows, 1)
+    depth, rgb = frames[0]
+    depth = _holes(depth, rng)
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    bo = O.bilateral_filter(depth)
+    br = R.bilateral_filter(depth)
+    # __expf model (libm expf in _ref, kto_expf in the oracle, ex2.approx in CUDA): the last bit of a weight can flip a tie of
+    # rn(sum1 / sum2) -- at most 2e-5 of the pixels, by 1 mm
+    bad = bo != br
+    assert int(bad.sum()) <= max(1, bo.size // 50000) and (np.abs(bo.astype(int) - br.astype(int)) <= 1).all()
+    noisy = rng.integers(0, 65536, depth.shape).astype(np.uint16)      # full u16 range: the int product (value - tmp)^2 wraps
+    if cols < 640:
+        assert same(O.bilateral_filter(noisy), R.bilateral_filter(noisy))
+        # white noise makes every off-centre weight tiny, so the last bit of exp() decides rn(sum1 / sum2) now and then: this
+        # is the __expf model (libm expf in _ref, kto_expf in the oracle, ex2.approx in CUDA), bounded here, exact on scenes
+        noisy2 = rng.integers(0, 40000, depth.shape).astype(np.uint16)
+        assert int((O.bilateral_filter(noisy2) != R.bilateral_filter(noisy2)).sum()) <= max(2, noisy2.size // 2000)
+    assert same(O.pyr_down(bo), R.pyr_down(bo))
+    assert same(O.pyr_down(noisy), R.pyr_down(noisy))
+    vo = O.create_vmap(intr, bo)
+    assert same(vo, R.create_vmap(intr, bo))
+    no = O.create_nmap(vo)
+    assert same(no, R.create_nmap(vo))
+    Rm = O.rodrigues(np.array([0.1, 0.2, -0.05])).astype(np.float32)
+    a, b = O.transform_maps(vo, no, Rm, [0.1, -0.2, 0.3])
+    c, d = R.transform_maps(vo, no, Rm, [0.1, -0.2, 0.3])
+    assert same(a, c) and same(b, d)
+    assert same(O.resize_map(vo, False), R.resize_map(vo, False))
+    assert same(O.resize_map(no, True), R.resize_map(no, True))
+    dm = O.depth_to_metres(depth, 6000)
+    assert same(dm, R.depth_to_metres(depth, 6000))
+    io = O.bgr_to_intensity(rgb)
+    assert same(io, R.bgr_to_intensity(rgb))
+    assert same(O.pyr_down_gauss_f32(dm), R.pyr_down_gauss_f32(dm))
+    assert same(O.pyr_down_gauss_u8(io), R.pyr_down_gauss_u8(io))
+    rnd8 = rng.integers(0, 256, io.shape).astype(np.uint8)
+    assert same(O.pyr_down_gauss_u8(rnd8), R.pyr_down_gauss_u8(rnd8))
+    for img in (io, rnd8):
+        dxo, dyo = O.derivative_images(img)
+        dxr, dyr = R.derivative_images(img)
+        assert same(dxo, dxr) and same(dyo, dyr)
+    for level in (0, 2):
+        assert same(O.project_to_cloud(dm, cam.fx, cam.fy, cam.cx, cam.cy, level), R.project_to_cloud(dm, cam.fx, cam.fy, cam.cx, cam.cy, level))
+
+
+def test_generate_image_and_depth(oracle_mod, R):
+    """image_generator.cu (live-view products)."""
+    O = oracle_mod
+    from oracle.oracle import OIntr
+    cam, frames, _ = _frames(160, 120, 1)
+    depth, rgb = frames[0]
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    v = O.create_vmap(intr, O.bilateral_filter(depth))
+    n = O.create_nmap(v)
+    col = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 7, np.uint8)], axis=2)
+    a, b = O.generate_image(v, n, col, [0.5, -1.0, -2.0])
+    c, d = R.generate_image(v, n, col, [0.5, -1.0, -2.0])
+    assert same(a, c) and same(b, d)
+    Rinv = O.mat33_inverse(O.rodrigues(np.array([0.02, -0.03, 0.01])).astype(np.float32))
+    assert same(O.generate_depth(Rinv, [0.1, 0.0, -0.2], v, n), R.generate_depth(Rinv, [0.1, 0.0, -0.2], v, n, 6.0))
+
+
+def _volume_after(O, cam, frames, traj, N, size, nframes, wrap, angle=True, rng=None):
+    from oracle.oracle import OIntr
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    trunc = max(0.06 if size == 6.0 else max(0.01, size / 100), 2.1 * size / N)
+    vol = np.zeros((N, N, N), np.int16)
+    col = np.zeros((N, N, N, 4), np.uint8)
+    poses = []
+    for k in range(nframes):
+        d, c = frames[k]
+        v = O.create_vmap(intr, O.bilateral_filter(d))
+        n = O.create_nmap(v)
+        Rk = np.asarray(traj[k][0], np.float32)
+        tk = (np.asarray(traj[k][1], np.float32) + np.float32(size / 2)).astype(np.float32)
+        if rng is not None:
+            Rk = (random_rotation(rng, 0.3) @ Rk).astype(np.float32)
+            tk = (tk + rng.uniform(-0.3, 0.3, 3)).astype(np.float32)
+        O.integrate_tsdf(d, intr, [size] * 3, O.mat33_inverse(Rk), tk, trunc, vol, wrap, col, c, n, angle)
+        poses.append((Rk, tk))
+    return intr, trunc, vol, col, poses
+
+
+@pytest.mark.parametrize("N,wrap,angle", [(64, [0, 0, 0], True), (96, [5, 90, 41], True), (80, [79, 1, 33], False)])
+def test_integrate(oracle_mod, R, N, wrap, angle):
+    """a11: scaleDepth + tsdf23 over several frames into the same volume (accumulated weights and colours), random poses,
+    wrapped storage, non-power-of-two N."""
+    O = oracle_mod
+    from oracle.oracle import OIntr
+    rng = np.random.default_rng(N)
+    cam, frames, traj = _frames(160, 120, 4)
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    size = 6.0
+    trunc = max(0.06, 2.1 * size / N)
+    vo, co = np.zeros((N, N, N), np.int16), np.zeros((N, N, N, 4), np.uint8)
+    vr, cr = vo.copy(), co.copy()
+    for k in range(4):
+        d, c = frames[k]
+        d = _holes(d, rng, 0.01)
+        v = O.create_vmap(intr, O.bilateral_filter(d))
+        n = O.create_nmap(v)
+        Rk = (random_rotation(rng, 0.4) @ np.asarray(traj[k][0], np.float32)).astype(np.float32) if k else np.eye(3, dtype=np.float32)
+        tk = (np.array([3, 3, 3]) + (rng.uniform(-0.4, 0.4, 3) if k else 0)).astype(np.float32)
+        Rinv = O.mat33_inverse(Rk)
+        U, so = O.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vo, wrap, co, c, n, angle)
+        sr = R.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vr, wrap, cr, c, n, angle)
+        assert U > 100
+        assert same(so, sr), f"frame {k}: scaleDepth differs at {nmism(so, sr)} bytes"
+        assert same(vo, vr), f"frame {k}: {int((vo != vr).sum())} tsdf mismatches"
+        assert same(co, cr), f"frame {k}: {int((co != cr).any(axis=-1).sum())} colour / weight mismatches"
+
+
+def test_integrate_camera_outside(oracle_mod, R):
+    O = oracle_mod
+    from oracle.oracle import OIntr
+    cam, frames, _ = _frames(160, 120, 1)
+    d, c = frames[0]
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    n = O.create_nmap(O.create_vmap(intr, O.bilateral_filter(d)))
+    N = 64
+    vo, co = np.zeros((N, N, N), np.int16), np.zeros((N, N, N, 4), np.uint8)
+    vr, cr = vo.copy(), co.copy()
+    U, _ = O.integrate_tsdf(d, intr, [6.0] * 3, np.eye(3), [3, 3, -0.45], 0.2, vo, [0, 0, 0], co, c, n, True)   # static mode pose
+    R.integrate_tsdf(d, intr, [6.0] * 3, np.eye(3), [3, 3, -0.45], 0.2, vr, [0, 0, 0], cr, c, n, True)
+    assert U > 100 and same(vo, vr) and same(co, cr)
+
+
+def test_init_volumes(oracle_mod, R):
+    O = oracle_mod
+    N = 32
+    vo, co = np.full((N, N, N), 0x5A5A, np.int16), np.full((N, N, N, 4), 0x5A, np.uint8)
+    O.lib().kto_init_volume(vo.ctypes.data_as(__import__('ctypes').c_void_p), N)
+    O.lib().kto_init_color_volume(co.ctypes.data_as(__import__('ctypes').c_void_p), N)
+    assert same(vo, R.init_volume(N)) and same(co, R.init_color_volume(N))
+
+
+@pytest.mark.parametrize("N,wrap", [(64, [0, 0, 0]), (96, [5, 90, 41])])
+def test_raycast(oracle_mod, R, N, wrap):
+    """a12: vertex / normal maps bit-exact, colour bytes exact; the heat byte is excluded where the reference converts NaN
+    to unsigned char (undefined behaviour on the CPU, 0 in CUDA): vertices within one voxel of a face."""
+    O = oracle_mod
+    rng = np.random.default_rng(N + 1)
+    cam, frames, traj = _frames(160, 120, 4)
+    size = 6.0
+    intr, trunc, vol, col, poses = _volume_after(O, cam, frames, traj, N, size, 3, wrap)
+    cell = np.float32(size / N)
+    for trial in range(3):
+        Rk, tk = poses[trial]
+        if trial == 2:
+            Rk = (random_rotation(rng, 0.2) @ Rk).astype(np.float32)
+            tk = (tk + rng.uniform(-0.2, 0.2, 3)).astype(np.float32)
+        outs = []
+        for M in (O, R):
+            vm = np.full((3 * cam.rows, cam.cols), 7.0, np.float32)   # pre-filled: untouched planes must stay untouched
+            nm = np.full_like(vm, -3.0)
+            cm = np.full((cam.rows, cam.cols, 4), 9, np.uint8)
+            M.raycast(intr, Rk, tk, trunc, [size] * 3, vol, vm, nm, wrap, cm, col)
+            outs.append((vm, nm, cm))
+        (vo, no, co), (vr, nr, cr) = outs
+        assert np.isfinite(vo[: cam.rows]).sum() > 1000
+        assert same(vo, vr), f"vmap: {nmism(vo, vr)} bytes"
+        assert same(no, nr), f"nmap: {nmism(no, nr)} bytes"
+        assert same(co[..., :3], cr[..., :3])
+        hit = np.isfinite(vo[: cam.rows])
+        g = np.floor(np.stack([vo[: cam.rows], vo[cam.rows: 2 * cam.rows], vo[2 * cam.rows:]], -1) / cell)
+        border = hit & ((g <= 0) | (g >= N - 1)).any(axis=-1)
+        assert same(co[..., 3][~border], cr[..., 3][~border])
+        assert border.sum() < 0.02 * hit.sum()
+
+
+def test_raycast_camera_outside(oracle_mod, R):
+    O = oracle_mod
+    from oracle.oracle import OIntr
+    cam, frames, _ = _frames(160, 120, 1)
+    d, c = frames[0]
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    n = O.create_nmap(O.create_vmap(intr, O.bilateral_filter(d)))
+    N = 64
+    vol, col = np.zeros((N, N, N), np.int16), np.zeros((N, N, N, 4), np.uint8)
+    O.integrate_tsdf(d, intr, [6.0] * 3, np.eye(3), [3, 3, -0.45], 0.2, vol, [0, 0, 0], col, c, n, True)
+    outs = []
+    for M in (O, R):
+        vm = np.zeros((3 * cam.rows, cam.cols), np.float32)
+        nm = np.zeros_like(vm)
+        cm = np.zeros((cam.rows, cam.cols, 4), np.uint8)
+        M.raycast(intr, np.eye(3), [3, 3, -0.45], 0.2, [6.0] * 3, vol, vm, nm, [0, 0, 0], cm, col)
+        outs.append((vm, nm, cm))
+    assert np.isfinite(outs[0][0][: cam.rows]).sum() > 1000
+    assert same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1]) and same(outs[0][2][..., :3], outs[1][2][..., :3])
+
+
+@pytest.mark.parametrize("elem", [np.int16, np.uint32])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+@pytest.mark.parametrize("back", [False, True])
+def test_clear_volume(oracle_mod, R, elem, axis, back):
+    """a14 incl. the X launch-geometry quirk (delta 16 -> 17-plane slab, one plane left) and wraps across the seam."""
+    O = oracle_mod
+    N = 48
+    rng = np.random.default_rng(axis * 2 + back)
+    cases = [(0, 14), (40, 54), (-3, 11), (100, 116), (47, 61), (-20, -6)] if not back else [(0, -14), (10, -4), (-40, -54), (100, 84), (3, -13)]
+    for cur, delta in cases:
+        a = rng.integers(1, 100, (N, N, N)).astype(elem)
+        if elem == np.uint32:
+            a = a.view(np.uint8).reshape(N, N, N, 4).copy()
+        b = a.copy()
+        O.clear_volume(a, axis, back, cur, delta)
+        R.clear_volume(b, axis, back, cur, delta)
+        assert same(a, b), (axis, back, cur, delta, nmism(a, b))
+        assert (a == 0).any()
+
+
+def _point_set(p):
+    """slices are compared as sets of (xyz bits, bgra): the reference's output order depends on atomicAdd timing"""
+    raw = np.ascontiguousarray(p).view(np.uint8).reshape(len(p), 32)
+    key = np.concatenate([raw[:, :12], raw[:, 16:20]], axis=1)
+    return sorted(map(bytes, key))
+
+
+@pytest.mark.parametrize("box", ["xplus", "xminus", "yplus", "zminus", "full", "sub2"])
+def test_extract_cloud_slice(oracle_mod, R, box):
+    """a15: warp-compacted zero-crossing extraction (ballot / popc / scan_warp / atomicAdd in the reference)."""
+    O = oracle_mod
+    N, size = 64, 6.0
+    wrap = [7, 60, 13]
+    cam, frames, traj = _frames(160, 120, 3)
+    _, _, vol, col, _ = _volume_after(O, cam, frames, traj, N, size, 3, wrap)
+    real = [3, -2, 70]
+    sub = 1
+    if box == "xplus":
+        b = (0, 17, 0, N, 0, N)
+    elif box == "xminus":
+        b = (N - 12, N, 0, N, 0, N)
+    elif box == "yplus":
+        b = (0, N, 0, 17, 0, N)
+    elif box == "zminus":
+        b = (0, N, 0, N, N - 13, N)      # KintinuousTracker.cpp:805 off-by-one slab
+    elif box == "full":
+        b = (0, N, 0, N, 0, N)
+    else:
+        b, sub = (0, N, 0, N, 0, N), 2
+    po = O.extract_cloud_slice(vol, [size] * 3, 400000, wrap, col, *b, sub, real)
+    pr = R.extract_cloud_slice(vol, [size] * 3, 400000, wrap, col, *b, sub, real)
+    assert len(po) == len(pr)
+    if box in ("full", "zminus"):
+        assert len(po) > 500
+    assert _point_set(po) == _point_set(pr)
+
+
+@pytest.mark.parametrize("cols,rows", [(160, 120), (640, 480)])
+def test_icp_step(oracle_mod, R, cols, rows):
+    """a6: correspondence search + 29-float reduction through the reference's own icpKernel<<<64,128>>> + reduceSum<<<1,512>>>
+    (the __shfl_down trees run on the fiber emulation): A, b, residual bit-identical to the oracle's reference-order mode."""
+    O = oracle_mod
+    N, size = 96, 6.0
+    cam, frames, traj = _frames(cols, rows, 4)
+    intr, trunc, vol, col, poses = _volume_after(O, cam, frames, traj, N, size, 2, [0, 0, 0])
+    Rp, tp = poses[1]
+    vprev = np.zeros((3 * rows, cols), np.float32)
+    nprev = np.zeros_like(vprev)
+    O.raycast(intr, Rp, tp, trunc, [size] * 3, vol, vprev, nprev, [0, 0, 0], np.zeros((rows, cols, 4), np.uint8), col)
+    d, _ = frames[3]
+    v = O.create_vmap(intr, O.bilateral_filter(d))
+    n = O.create_nmap(v)
+    Rp_inv = O.mat33_inverse(Rp)
+    rng = np.random.default_rng(5)
+    for trial in range(2):
+        Rc = Rp if trial == 0 else (random_rotation(rng, 0.02) @ Rp).astype(np.float32)
+        tc = tp if trial == 0 else (tp + rng.uniform(-0.01, 0.01, 3)).astype(np.float32)
+        Ao, bo, ro = O.icp_step(Rc, tc, v, n, Rp_inv, tp, intr, vprev, nprev, 0.10, float(np.sin(np.float32(20.0 * 3.14159265 / 180.0))), 0)
+        Ar, br, rr = R.icp_step(Rc, tc, v, n, Rp_inv, tp, intr, vprev, nprev, 0.10, float(np.sin(np.float32(20.0 * 3.14159265 / 180.0))))
+        assert ro[1] > 0.3 * cols * rows
+        assert same(Ao, Ar) and same(bo, br) and same(ro, rr), (Ao - Ar, bo - br, ro, rr)
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_rgb_residual_and_step(oracle_mod, R, level):
+    """a8, a9: residualKernel<<<256,128>>> + int2 reduceSum, rgbKernel + reduceSum: DataTerm of every valid pixel, count, sigma,
+    A, b bit-identical."""
+    O = oracle_mod
+    cols, rows = 160 >> level, 120 >> level
+    cam, frames, _ = _frames(160, 120, 8)
+    pyr = []
+    for d, rgb in (frames[0], frames[1]):
+        dm, it = O.depth_to_metres(d, 6000), O.bgr_to_intensity(rgb)
+        for _ in range(level):
+            dm, it = O.pyr_down_gauss_f32(dm), O.pyr_down_gauss_u8(it)
+        pyr.append((dm, it))
+    (ld, li), (nd, ni) = pyr
+    dx, dy = O.derivative_images(ni)
+    f = 1.0 / (1 << level)
+    fx, fy, cx, cy = cam.fx * f, cam.fy * f, cam.cx * f, cam.cy * f
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
+    Rm = O.rodrigues(np.array([0.002, -0.003, 0.001]))
+    krkinv = (K @ Rm @ np.linalg.inv(K)).astype(np.float32)
+    kt = (K @ np.array([0.004, -0.002, 0.003])).astype(np.float32)
+    min_scale = (np.float32([12, 5, 3, 1][level]) / np.float32(0.125)) ** 2
+    co, so, no = O.rgb_residual(min_scale, dx, dy, ld, nd, li, ni, 0.07, kt, krkinv)
+    cr, sr, nr = R.rgb_residual(min_scale, dx, dy, ld, nd, li, ni, 0.07, kt, krkinv)
+    assert no > 50 and (so, no) == (sr, nr)
+    assert np.array_equal(co["valid"], cr["valid"] != 0)
+    m = co["valid"] != 0
+    for f_ in ("zero", "one", "diff"):
+        assert same(co[f_][m], cr[f_][m])
+    cloud = O.project_to_cloud(ld, fx, fy, cx, cy, 0)
+    sigma = float(np.sqrt(np.float32(no)))   # RGBDOdometry.cpp:253 quirk
+    Ao, bo = O.rgb_step(co, sigma, cloud, fx, fy, dx, dy, 0.125, 0)
+    Ar, br = R.rgb_step(cr, sigma, cloud, fx, fy, dx, dy, 0.125)
+    assert same(Ao, Ar) and same(bo, br), (Ao - Ar, bo - br)
