@@ -41,7 +41,7 @@ struct FrameSet {
     long long user;       // ordinal of the process_frame call that last consumed the set (-1: none)
 };
 // Three sets rotate: the frame whose fusion is still running (also RGB-D "last" of its successor), the frame about to be tracked
-// and the frame being read ahead.  kt_tracker_prefetch_frame explains why no event is needed to recycle a set.
+// and the frame being read ahead.  A set is recycled behind odo_ev (wait_frame_consumed).
 #define KT_NSETS 3
 
 // the host's window on the frame in flight: written by kt_frame_setup_kernel straight into pinned, device-mapped host memory
@@ -53,6 +53,7 @@ struct PoseMirror {
 };
 struct Pending { const uint16_t* depth; const uint8_t* rgb; int set; const uint16_t* depth_host; const uint8_t* rgb_host; };
 #define KT_NSLOTS 4   // host-frame staging: frame in flight + two read-aheads + the one being filled
+#define KT_NODO 8     // ring of "odometry of frame f enqueued" events
 
 enum { ST_PYRAMID = 0, ST_ODOMETRY, ST_SHIFT, ST_INTEGRATE, ST_RAYCAST, ST_RESIZE, ST_TSDF23, ST_COUNT };
 
@@ -91,6 +92,13 @@ struct kt_tracker {
     std::vector<Pending> pending;      // prefetched frames not yet processed (at most 2)
     long long frames_started;          // process_frame calls so far
     hipEvent_t guard_ev;               // only for out-of-pattern read-aheads (see kt_tracker_prefetch_frame)
+    // odo_ev[f % KT_NODO]: recorded on the main stream once everything of frame f up to the end of its odometry is enqueued, i.e.
+    // AFTER fusion(f - 1) and the RGB-D "last" reads of frame f - 1's set.  The read-ahead stream waits on odo_ev[u + 1] before it
+    // overwrites the set (or the staging slot) frame u consumed: explicit ordering in every mode -- with the pose mirror the host has
+    // already observed that point and the wait is free; under -p (no device odometry, the host never waits) it is what keeps a
+    // lagging GPU's fusion from reading a recycled set.
+    hipEvent_t odo_ev[8];
+    long long slot_frame[4];           // ordinal of the frame that consumed staging slot k (-1: none)
     hipStream_t pre_stream;
     kt_ctx pre_ctx;                    // the context with pre_stream as its stream (image kernels only)
     kt_point_xyzrgb* cloud_device; size_t cloud_cap;
@@ -175,6 +183,21 @@ static int pick_free_set(kt_tracker* t)
         if (!taken) return q;
     }
     return -1;
+}
+
+// `stream` may overwrite what frame `u` consumed (its frame set, its staging slot) only after fusion(u) and the RGB-D "last" reads of
+// odometry(u + 1): both precede odo_ev[u + 1] on the main stream.  If frame u + 1 has not been started, order against "now".
+static int wait_frame_consumed(kt_tracker* t, hipStream_t stream, long long u)
+{
+    if (u < 0 || stream == t->ctx->stream) return KT_OK;   // the main stream is ordered by itself
+    if (u + 1 < t->frames_started) {
+        // a slot of the ring that has since been re-recorded by frame u + 1 + k * KT_NODO only waits longer, never less
+        KT_HIP(hipStreamWaitEvent(stream, t->odo_ev[(u + 1) % KT_NODO], 0));
+    } else {
+        KT_HIP(hipEventRecord(t->guard_ev, t->ctx->stream));
+        KT_HIP(hipStreamWaitEvent(stream, t->guard_ev, 0));
+    }
+    return KT_OK;
 }
 
 // minimumGradientMagnitudes / sobelScale of RGBDOdometry (RGBDOdometry.cpp:64-70, 236): the squared-gradient threshold of level l
@@ -373,6 +396,8 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     }
     t->frames_started = 0;
     KT_HIP(hipEventCreateWithFlags(&t->guard_ev, hipEventDisableTiming));
+    for (int k = 0; k < KT_NODO; ++k) KT_HIP(hipEventCreateWithFlags(&t->odo_ev[k], hipEventDisableTiming));
+    for (int k = 0; k < KT_NSLOTS; ++k) t->slot_frame[k] = -1;
     KT_HIP(hipStreamCreateWithFlags(&t->pre_stream, hipStreamNonBlocking));
     KT_TRY(kt_bilateral_lut_ensure(ctx));   // before the context is cloned: both streams share the table
     t->pre_ctx = *ctx;
@@ -437,6 +462,8 @@ int kt_tracker_destroy(kt_tracker* t)
         if (t->sets[q].ready) (void)hipEventDestroy(t->sets[q].ready);
     }
     if (t->guard_ev) (void)hipEventDestroy(t->guard_ev);
+    for (int k = 0; k < KT_NODO; ++k)
+        if (t->odo_ev[k]) (void)hipEventDestroy(t->odo_ev[k]);
     if (t->pre_stream) (void)hipStreamDestroy(t->pre_stream);
     (void)hipFree(t->vmap_curr_color); (void)hipFree(t->cloud_device);
     (void)hipFree(t->state_dev); (void)hipHostFree(t->state_host);
@@ -1002,7 +1029,10 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         KT_TRY(ev_end(t, ST_PYRAMID));
     }
     select_set(t, set);
+    const long long ordinal = t->frames_started;
     t->sets[set].user = t->frames_started++;
+    for (int k = 0; k < KT_NSLOTS; ++k)
+        if (depth_raw == t->depth_stage[k]) t->slot_frame[k] = ordinal;
     const int last_set = t->prev_set;   // "last" of RGBDOdometry for this frame
     t->prev_set = set;
     t->out_set = set;
@@ -1027,6 +1057,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         ++t->global_time;
         t->ev_par ^= 1;
         t->gt_utime = timestamp;   // :527-528
+        KT_HIP(hipEventRecord(t->odo_ev[ordinal % KT_NODO], c->stream));
         push_pose(t, timestamp, t->Rlast, 1);
         if (t->counting) {
             unsigned int u = 0;
@@ -1049,6 +1080,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         ev_collect(t);
         ground_truth_pose(t, timestamp, Rcurr, tcurr);
         t->gt_utime = timestamp;   // :574-575
+        KT_HIP(hipEventRecord(t->odo_ev[ordinal % KT_NODO], c->stream));   // before this frame's fusion, after the previous one's
         KT_TRY(finish_pose(t, Rcurr, tcurr, false));
         t->ev_par ^= 1;
         if (t->counting) KT_TRY(read_counts(t));
@@ -1064,6 +1096,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     v_wrap_copy_update(t);
     if (++t->frame_seq == 0) t->frame_seq = 1;  // 0 is the mirror's initial value
     KT_TRY(launch_setup(t, 0, nullptr, nullptr));
+    KT_HIP(hipEventRecord(t->odo_ev[ordinal % KT_NODO], c->stream));
     // -d: the cube may be repositioned once the pose is known, which changes the shift decision -- nothing to speculate on
     t->out_speculated = !t->cfg.dynamic_cube;
     if (t->out_speculated) KT_TRY(enqueue_fusion(t, set, depth_raw, colors));
@@ -1093,6 +1126,8 @@ static int stage_host_frame(kt_tracker* t, hipStream_t stream, const uint16_t* d
     const int slot = t->next_slot;
     t->next_slot = (t->next_slot + 1) % KT_NSLOTS;
     KT_HIP(hipEventSynchronize(t->slot_uploaded[slot]));   // the pinned copy of the frame that used this slot 4 frames ago has left
+    KT_TRY(wait_frame_consumed(t, stream, t->slot_frame[slot]));   // ... and its fusion has read the device copy
+    t->slot_frame[slot] = -1;
     memcpy(t->depth_stage_host[slot], depth_host, P * sizeof(uint16_t));
     memcpy(t->rgb_stage_host[slot], rgb_host, P * 3);
     KT_HIP(hipMemcpyAsync(t->depth_stage[slot], t->depth_stage_host[slot], P * sizeof(uint16_t), hipMemcpyHostToDevice, stream));
@@ -1123,11 +1158,7 @@ static int prefetch_impl(kt_tracker* t, const uint16_t* depth_raw, const uint8_t
     const int set = pick_free_set(t);   // exists: 3 sets, at most 1 other read-ahead outstanding here
     if (set < 0) { kt_set_error("kt_tracker_prefetch_frame: no free frame set"); return KT_ERR_STATE; }
     t->last_assigned = set;
-    const bool busy = t->sets[set].user >= 0 && t->sets[set].user > t->frames_started - 2;
-    if (busy) {  // out-of-pattern use (abandoned read-aheads, ...): order the streams explicitly
-        KT_HIP(hipEventRecord(t->guard_ev, t->ctx->stream));
-        KT_HIP(hipStreamWaitEvent(t->pre_stream, t->guard_ev, 0));
-    }
+    KT_TRY(wait_frame_consumed(t, t->pre_stream, t->sets[set].user));
     t->pre_ctx.device = t->ctx->device;
     KT_TRY(build_frame_set(t, &t->pre_ctx, set, depth_raw, colors));
     KT_HIP(hipEventRecord(t->sets[set].ready, t->pre_stream));
