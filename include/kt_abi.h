@@ -260,6 +260,8 @@ int kt_tracker_debug_state(kt_tracker* t, float out29_host[29]);
 int kt_debug_stream(kt_ctx* ctx, void* buf, size_t bytes, int elem_size, int rmw);
 /* test hook: out[v + 32768] = the device's unpack_tsdf(v) for every short v (device.hpp:77-83 restated without a division) */
 int kt_debug_unpack_table(kt_ctx* ctx, float* out_host65536);
+/* test hook: number of floats d, 2^-20 <= |d| <= 2^20, for which the voxel kernel's unwrapped reciprocal chain differs from 1.0f / d */
+int kt_debug_rcp_check(kt_ctx* ctx, unsigned int* mismatches_host);
 
 /* ---- multi-GPU: independent streams, one tracker per GPU; poses are gathered by the caller's
  * collective (bench.py / the CLI use RCCL all_gather on the buffer filled here) ---- */

@@ -132,6 +132,7 @@ _PROTOS = {
     "kt_tracker_debug_state": (_i, [_vp, _pf]),
     "kt_debug_stream": (_i, [_vp, _vp, _sz, _i, _i]),
     "kt_debug_unpack_table": (_i, [_vp, _pf]),
+    "kt_debug_rcp_check": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_host_times": (_i, [_vp, _pd, _i]),
     "kt_tracker_prefetch_frame": (_i, [_vp, _vp, _vp]),
     "kt_tracker_prefetch_frame_host": (_i, [_vp, _vp, _vp]),

@@ -164,7 +164,9 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
 #ifndef KT_TSDF_ZCHUNK
 #define KT_TSDF_ZCHUNK 16
 #endif
+#ifndef KT_TSDF_UNROLL
 #define KT_TSDF_UNROLL 4
+#endif
 #ifndef KT_TSDF_WAVES
 #define KT_TSDF_WAVES 8192
 #endif
@@ -373,7 +375,7 @@ struct kt_tsdf_batch {
     float vgz[KT_TSDF_UNROLL];
     kt_pixrec rec[KT_TSDF_UNROLL];
     short tsdf_raw[KT_TSDF_UNROLL];
-    uchar4 col[KT_TSDF_UNROLL];
+    unsigned int col[KT_TSDF_UNROLL];   // the uchar4 {r, g, b, weight} as one word
 };
 
 // Buffer path (BUF, every N < 1024): the two volumes are addressed through buffer descriptors (descriptors for the pixel records
@@ -384,33 +386,49 @@ struct kt_tsdf_batch {
 // Needs 32-bit byte offsets: N^3 * 4 < 2^32.
 struct kt_tsdf_bufs { __amdgpu_buffer_rsrc_t vol, col; };
 
+// 1 / d, correctly rounded, without the scaling wrapper of the IEEE expansion (v_div_scale x2, v_div_fixup): the refinement chain
+// hipcc emits for 1.0f / d, which is exact as it stands whenever nothing in it can overflow or go denormal.  The caller guarantees
+// 2^-20 <= |d| <= 2^20 (checked once per task at the ends of the z chunk: d is monotone in z); kt_debug_exact_ops compares it
+// with the division on every float of that range.
+__device__ __forceinline__ float kt_rcp_exact(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
+}
+
 // The voxel kernel runs the reference loop body KT_TSDF_UNROLL z-steps at a time in two phases:
 //   issue    projection of the 4 voxels, then ALL their loads at once -- the 16-byte pixel record and, speculatively for every
 //            voxel that projects into the image, its tsdf and colour words (the update predicate needs the record, so waiting
 //            for it first would double the exposed latency);
-//   consume  sdf test, running-average update, stores.
+//   consume  sdf test, running-average update, stores (only of words that changed).
 // Every lane of the wave walks the same z sequence: each volume access is one contiguous 128 B / 256 B segment.
+// The column intervals only select the tasks: inside a task every lane runs the reference's in-image test on every step (a voxel
+// outside its conservative interval fails it by construction), which is cheaper than two more compares per step.
 // (Non-temporal volume loads / stores, meant to keep the streamed volume from evicting the pixel records in L2, measured 17% slower
 // on the 512^3 orbit and neutral on the dense 768^3 case.)
-template <bool COUNT, bool BUF>
-__device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, const kt_tsdf_bufs& m, kt_tsdf_batch& b, int zb, int z0, int z1,
+template <bool COUNT, bool BUF, bool FAST>
+__device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, const kt_tsdf_bufs& m, kt_tsdf_batch& b, int zb, int z_end, bool lane_ok,
                                               unsigned int col_base, unsigned int plane, float v_z, float& v_x, float& v_y, float dvx,
-                                              float dvy, float tab_vgz, float tab_zs, int tab_base)
+                                              float dvy, float tab_vgz, float tab_zs, int tab_base, float r8)
 {
     const int N = a.N;
 #pragma unroll
     for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
         const int z = zb + u;
-        const bool live = z >= z0 && z < z1;
         const int zz = min(z, N - 1);  // wave-uniform
         // wave-uniform table entries: broadcast from the lane that holds them (no memory access in the loop)
         const int tl = zz - tab_base;
         b.vgz[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tab_vgz), tl));
         const float z_scaled = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tab_zs), tl));
-        const float inv_z = 1.0f / __builtin_fmaf(a.Ri.m[8], z_scaled, v_z);
+        const float d = __builtin_fmaf(r8, z_scaled, v_z);
+        const float inv_z = FAST ? kt_rcp_exact(d) : 1.0f / d;
         const int coo_x = kt_f2i_rn(__builtin_fmaf(v_x, inv_z, a.intr.cx));
         const int coo_y = kt_f2i_rn(__builtin_fmaf(v_y, inv_z, a.intr.cy));
-        b.in_img[u] = live && !(inv_z < 0) && coo_x >= 0 && coo_y >= 0 && coo_x < a.cols && coo_y < a.rows;
+        // 0 <= coo < size as ONE unsigned compare per axis
+        // z_end (wave-uniform): the last batch of a task may reach past the chunk, whose next z belong to another task
+        b.in_img[u] = lane_ok && z < z_end && !(inv_z < 0) && (unsigned int)coo_x < (unsigned int)a.cols && (unsigned int)coo_y < (unsigned int)a.rows;
         int sz = zz + a.wz; if (sz >= N) sz -= N;
         b.bz[u] = (sz >> KT_BRICK_LOG2) * a.nb * a.nb;
         // coo_x, coo_y < 2^24 inside the image: the 24-bit multiply is exact there (and full rate, unlike v_mul_lo_u32)
@@ -427,11 +445,10 @@ __device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, const kt_
             if constexpr (BUF) {
                 const unsigned int zoff = (unsigned int)b.sz[u] * plane;   // elements; wave-uniform
                 b.tsdf_raw[u] = __builtin_amdgcn_raw_buffer_load_b16(m.vol, col_base * 2u, zoff * 2u, 0);
-                const unsigned int cw = __builtin_amdgcn_raw_buffer_load_b32(m.col, col_base * 4u, zoff * 4u, 0);
-                b.col[u] = *(const uchar4*)&cw;
+                b.col[u] = __builtin_amdgcn_raw_buffer_load_b32(m.col, col_base * 4u, zoff * 4u, 0);
             } else {
                 b.tsdf_raw[u] = a.volume[b.off[u]];
-                b.col[u] = a.color[b.off[u]];
+                b.col[u] = *(const unsigned int*)&a.color[b.off[u]];
             }
         }
 }
@@ -445,77 +462,88 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
     for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
         if (!b.in_img[u]) continue;
         if (COUNT) ++n_img;   // diagnostics: voxel steps that project into the image
-        float Dp_scaled = b.rec[u].dp;
-        bool no_color = false;
-        if (Dp_scaled < 0.0f) { Dp_scaled = -Dp_scaled; no_color = true; }
-        // Free-space shortcut: tsdf = min(1, sdf / trunc) is exactly 1 well in front of the surface whatever the last bit of
-        // the square root is.  v_sqrt_f32 (<= 1 ulp) decides with a 1e-3 guard band (the exact value differs from the
-        // approximation by < 2e-5 in tsdf units); only voxels inside the band or nearer take the correctly rounded sqrt.
+        const float dp = b.rec[u].dp;
+        const float Dp_scaled = fabsf(dp);          // a negative scaled depth flags "no colour" (tsdf_volume.cu:520-527, :590-594)
+        const bool no_color = dp < 0.0f;
+        // Classification with v_sqrt_f32 (<= 1 ulp): t = sdf / trunc to within 2e-5.  t > 1.001: free space, tsdf = min(1, t) is
+        // exactly 1 whatever the last bit of the square root is.  t < -1.001: sdf < -trunc, no update.  Only voxels in between (the
+        // truncation band and a hair around its two edges) take the correctly rounded sqrt, behind a wave-uniform branch.
         const float r2 = __builtin_fmaf(b.vgz[u], b.vgz[u], v_g_part_norm);
         float sdf = Dp_scaled - __builtin_amdgcn_sqrtf(r2);
-        const bool is_free = sdf * tranc_dist_inv > 1.001f;
-        if (!is_free) {
-            asm volatile("; exact sqrt" ::: "memory");  // a real branch: if-converted, the 14-instruction correctly rounded sqrt runs for every voxel
-            sdf = Dp_scaled - __builtin_sqrtf(r2);
+        const float t = sdf * tranc_dist_inv;
+        const bool is_free = t > 1.001f;
+        const bool band = !is_free && t >= -1.001f;   // NaN (never: r2 >= 0) would fall out of both
+        if (__builtin_amdgcn_ballot_w64(band) != 0) {
+            asm volatile("; exact sqrt" ::: "memory");  // a real branch: if-converted, the 16-instruction correctly rounded sqrt runs for every voxel
+            if (band) sdf = Dp_scaled - __builtin_sqrtf(r2);
         }
-        if (!(Dp_scaled != 0 && (is_free || sdf >= -a.tranc_dist))) continue;
-        const uchar4 c = b.col[u];
-        const float weight_prev = (float)c.w;
+        if (!(dp != 0 && (is_free || (band && sdf >= -a.tranc_dist)))) continue;
+        if (COUNT) ++n_upd;
+        const unsigned int c = b.col[u];
+        const float weight_prev = (float)(c >> 24);
         // free voxel that already holds F = 1 (raw 32767): (1 * W + 1) / (W + 1) == 1 exactly, the stored value stays
-        if (!(is_free && b.tsdf_raw[u] == KT_DIVISOR)) {
-            const float tsdf = is_free ? 1.0f : fminf(1.0f, sdf * tranc_dist_inv);
-            const float tsdf_prev = kt_unpack_tsdf(b.tsdf_raw[u]);
-            const short packed = kt_pack_tsdf(__builtin_fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
-            if constexpr (BUF) {
-                __builtin_amdgcn_raw_buffer_store_b16(packed, m.vol, col_base * 2u, (unsigned int)b.sz[u] * plane * 2u, 0);
-                if (a.bricks && packed < 0) a.bricks[b.bz[u] + brick_xy] = 1;  // idempotent byte store, no atomics
-            } else {
-                a.volume[b.off[u]] = packed;
-                if (a.bricks && packed < 0) a.bricks[b.bz[u] + brick_xy] = 1;  // idempotent byte store, no atomics
+        const bool touch = !(is_free && b.tsdf_raw[u] == KT_DIVISOR);
+        if (__builtin_amdgcn_ballot_w64(touch) != 0) {
+            if (touch) {
+                const float tsdf = is_free ? 1.0f : fminf(1.0f, sdf * tranc_dist_inv);
+                const float tsdf_prev = kt_unpack_tsdf(b.tsdf_raw[u]);
+                const short packed = kt_pack_tsdf(__builtin_fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
+                if (packed != b.tsdf_raw[u]) {   // an unchanged word is not written back
+                    if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b16(packed, m.vol, col_base * 2u, (unsigned int)b.sz[u] * plane * 2u, 0);
+                    else a.volume[b.off[u]] = packed;
+                    if (a.bricks && packed < 0) a.bricks[b.bz[u] + brick_xy] = 1;  // idempotent byte store, no atomics (a negative value
+                }                                                                  // that stays was flagged when it was first stored)
             }
         }
-        uchar4 o = c;
-        o.w = (unsigned char)min((int)c.w + 1, (int)KT_MAX_WEIGHT);  // == __float2uchar_rz(min(W + 1, 128)) for every 8-bit W
-        if (COUNT) ++n_upd;
+        // weight: min(W + 1, 128) in the top byte, on the whole word: W <= 128 always, so only 128 + 1 has to be undone
+        unsigned int o = min(c + 0x01000000u, c | 0x80000000u);
         const unsigned int rgbf = b.rec[u].rgbf;
-        const bool normal_nan = (rgbf >> 24) & 1u;
+        // colour update iff (normal valid and not flagged "no colour") or the stored colour is (0, 0, 0)  (tsdf_volume.cu:623).
         // A voxel whose stored colour already equals the pixel's keeps it: with c == rgb the blend is
         // rint(RN(c (W + Wrkc(1 + e1))(1 + e2) / ((W + Wrkc)(1 + e3)))) = c for every weight (|error| <= 255 * 4 * 2^-24 << 0.5), and
         // the degenerate 0 / 0 case (W = Wrkc = 0, or a NaN weight) can only meet c = 0 = rgb, where the reference stores 0 too.
-        // Skipped when the whole wave agrees (static camera: almost always).
-        const bool same_colour = ((((unsigned int)c.x | ((unsigned int)c.y << 8) | ((unsigned int)c.z << 16)) ^ rgbf) & 0xffffffu) == 0;
-        const bool blend = ((!normal_nan && !no_color) || (c.x == 0 && c.y == 0 && c.z == 0)) && !same_colour;
-        if (blend) {
-            // c' = clamp(rint(RN(n / den))): only the INTEGER is stored, so the correctly rounded quotient matters only within
-            // a hair of a half-integer.  q' = n * v_rcp_f32(den) is within 2.4e-7 * q of RN(n / den) (1 ulp reciprocal, two
-            // roundings), i.e. < 7e-5 for q <= 256; if q' is farther than 2e-4 from every half-integer (or clearly above the
-            // clamp) rint(q') is the reference's value.  Otherwise (wave-uniform branch, ~7% of steps) the three IEEE divisions run.
-            const float Wrkc = b.rec[u].wrkc;
-            const float den = weight_prev + Wrkc;
-            const float nx = __builtin_fmaf((float)c.x, weight_prev, Wrkc * (float)(rgbf & 0xffu));
-            const float ny = __builtin_fmaf((float)c.y, weight_prev, Wrkc * (float)((rgbf >> 8) & 0xffu));
-            const float nz = __builtin_fmaf((float)c.z, weight_prev, Wrkc * (float)((rgbf >> 16) & 0xffu));
-            const float rden = __builtin_amdgcn_rcpf(den);
-            float qx = nx * rden, qy = ny * rden, qz = nz * rden;
-            const float tol = 2e-4f;
-            const bool sx_ = qx > 256.5f || fabsf((qx - __builtin_floorf(qx)) - 0.5f) > tol;
-            const bool sy_ = qy > 256.5f || fabsf((qy - __builtin_floorf(qy)) - 0.5f) > tol;
-            const bool sz_ = qz > 256.5f || fabsf((qz - __builtin_floorf(qz)) - 0.5f) > tol;
-            const bool safe = sx_ && sy_ && sz_;   // false for NaN (0 / 0)
-            if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
-                if (!safe) { qx = nx / den; qy = ny / den; qz = nz / den; }
+        const bool same_colour = ((c ^ rgbf) & 0xffffffu) == 0;
+        const bool blend = ((!(rgbf & KT_REC_NORMAL_NAN) && !no_color) || (c & 0xffffffu) == 0) && !same_colour;
+        if (__builtin_amdgcn_ballot_w64(blend) != 0) {
+            if (blend) {
+                // c' = clamp(rint(RN(n / den))) per channel: only the INTEGER is stored.  k = rint(n * v_rcp_f32(den)) is a candidate; it
+                // is the reference's value whenever |n - k * den| < 0.4999 * den: the residual comes out of one FMA (relative error
+                // 2^-24), so the true quotient is then within 0.49991 of k and its float rounding (|error| <= 2^-16 below 256) still
+                // rounds to k.  n / den is a weighted mean of values in [0, 255], so k needs no clamp.  Otherwise -- a tie to within
+                // 1e-4, 0 / 0, a NaN weight -- the IEEE divisions run (wave-uniform branch, rare).
+                const float Wrkc = b.rec[u].wrkc;
+                const float den = weight_prev + Wrkc;
+                const float nx = __builtin_fmaf((float)(c & 0xffu), weight_prev, Wrkc * (float)(rgbf & 0xffu));
+                const float ny = __builtin_fmaf((float)((c >> 8) & 0xffu), weight_prev, Wrkc * (float)((rgbf >> 8) & 0xffu));
+                const float nz = __builtin_fmaf((float)((c >> 16) & 0xffu), weight_prev, Wrkc * (float)((rgbf >> 16) & 0xffu));
+                const float rden = __builtin_amdgcn_rcpf(den);
+                float kx = __builtin_rintf(nx * rden), ky = __builtin_rintf(ny * rden), kz = __builtin_rintf(nz * rden);
+                const float lim = 0.4999f * den;
+                const bool safe = fabsf(__builtin_fmaf(-kx, den, nx)) < lim && fabsf(__builtin_fmaf(-ky, den, ny)) < lim &&
+                                  fabsf(__builtin_fmaf(-kz, den, nz)) < lim;   // false for NaN
+                if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
+                    if (!safe) {
+                        kx = (float)min(255, max(0, kt_f2i_rn(nx / den)));
+                        ky = (float)min(255, max(0, kt_f2i_rn(ny / den)));
+                        kz = (float)min(255, max(0, kt_f2i_rn(nz / den)));
+                    }
+                }
+                o = (o & 0xff000000u) | (unsigned int)kx | ((unsigned int)ky << 8) | ((unsigned int)kz << 16);
             }
-            o.x = (unsigned char)min(255, max(0, kt_f2i_rn(qx)));
-            o.y = (unsigned char)min(255, max(0, kt_f2i_rn(qy)));
-            o.z = (unsigned char)min(255, max(0, kt_f2i_rn(qz)));
         }
-        if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b32(*(const unsigned int*)&o, m.col, col_base * 4u, (unsigned int)b.sz[u] * plane * 4u, 0);
-        else a.color[b.off[u]] = o;
+        if (o != c) {   // a saturated free-space voxel in front of an unchanged pixel costs reads only
+            if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b32(o, m.col, col_base * 4u, (unsigned int)b.sz[u] * plane * 4u, 0);
+            else *(unsigned int*)&a.color[b.off[u]] = o;
+        }
     }
 }
 
+
+#ifndef KT_TSDF_OCC
+#define KT_TSDF_OCC 8   // waves per SIMD the register budget is cut for
+#endif
 template <bool COUNT, bool BUF>
-__global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args a_in)
+__global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_tsdf23_args a_in)
 {
     kt_tsdf23_args a = a_in;
     kt_tsdf_bufs m = {};
@@ -528,33 +556,30 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
     const int N = a.N;
     const int lane = threadIdx.x & 63;
     const unsigned int n_tasks = *a.task_count;
-    const unsigned int n_waves = gridDim.x * 4u;
     const float* Ri = a.Ri.m;
     const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
     const float dvx = Ri[2] * a.cell_z * a.intr.fx;   // Rcurr_inv_0_z_scaled
     const float dvy = Ri[5] * a.cell_z * a.intr.fy;   // Rcurr_inv_1_z_scaled
     const float tranc_dist_inv = 1.0f / a.tranc_dist;
     const unsigned int plane = (unsigned int)N * (unsigned int)N;
+    float r8 = Ri[8];
+    asm volatile("" : "+v"(r8));   // keep it in a VGPR: fma(r8, z_scaled, v_z) then takes the broadcast z_scaled straight from its SGPR
     unsigned int n_upd = 0, n_batches = 0, n_tasks_done = 0, n_img = 0;
     // XCD-aware task order: workgroup b runs on XCD b % 8 (and each XCD has its own L2), so XCD k takes the k-th contiguous eighth of
     // the list -- a band of y, i.e. a band of image rows whose 16-byte pixel records then stay in that one L2 -- and inside an XCD
     // consecutive tasks (neighbouring chunks of one wave-column) go to the 4 waves of one workgroup.
     const unsigned int per_xcd = (n_tasks + 7u) / 8u;
     const unsigned int t_begin = (blockIdx.x & 7u) * per_xcd, t_end = min(t_begin + per_xcd, n_tasks);
-    (void)n_waves;
     for (unsigned int t = t_begin + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); t < t_end; t += (gridDim.x >> 3) * 4u) {
         const unsigned int task = __builtin_amdgcn_readfirstlane(a.tasks[t]);
         const int yg = (int)(task & 0xffffu), xg = (int)((task >> 16) & 0xffu), chunk = (int)(task >> 24);
         const int sx = xg * KT_WX + (lane & (KT_WX - 1));
         const int sy = min(yg * KT_WY + (lane / KT_WX), N - 1);   // a row past the volume (odd N) only repeats the last one, never live
-        int z0 = N, z1 = 0;
-        if (sx < N && yg * KT_WY + (lane / KT_WX) < N) {
-            const unsigned int iv = a.interval[(size_t)sy * N + sx];
-            z0 = max((int)(iv & 0xffffu), chunk * KT_TSDF_ZCHUNK);
-            z1 = min((int)(iv >> 16), (chunk + 1) * KT_TSDF_ZCHUNK);
-            if (z0 >= z1) { z0 = N; z1 = 0; }
-        }
-        const int wz0 = kt_wave_min(z0), wz1 = kt_wave_max(z1);  // the wave's union inside this chunk
+        const bool lane_ok = sx < N && yg * KT_WY + (lane / KT_WX) < N;
+        // the wave-column's union of column intervals, cut to this chunk (wave-uniform)
+        const unsigned int wr = __builtin_amdgcn_readfirstlane(a.wrange[(size_t)yg * ((N + KT_WX - 1) / KT_WX) + xg]);
+        const int zc = (int)(wr & 0xffffu);
+        const int wz0 = max(zc, chunk * KT_TSDF_ZCHUNK), wz1 = min((int)(wr >> 16), (chunk + 1) * KT_TSDF_ZCHUNK);
         if (wz0 >= wz1) continue;
         int x = sx - a.wx; if (x < 0) x += N;
         int y = sy - a.wy; if (y < 0) y += N;
@@ -564,7 +589,6 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
         const float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
         // the reference's walk (tsdf_volume.cu:566-571, 634-640): resume from the wave-column's checkpoint (the value at its first z,
         // kt_tsdf_interval_kernel) and advance to this task's first z
-        const int zc = (int)(__builtin_amdgcn_readfirstlane(a.wrange[(size_t)yg * ((N + KT_WX - 1) / KT_WX) + xg]) & 0xffffu);
         const float2 cp = a.walk0[(size_t)sy * N + min(sx, N - 1)];
         float v_x = cp.x, v_y = cp.y;
         {
@@ -581,12 +605,21 @@ __global__ __launch_bounds__(256, 8) void kt_tsdf23_kernel(const kt_tsdf23_args 
         const int tab_base = chunk * KT_TSDF_ZCHUNK;
         const float tab_vgz = a.vgz[min(tab_base + lane, N - 1)];
         const float tab_zs = a.zs[min(tab_base + lane, N - 1)];
+        // The camera-frame depth d(z) = fma(R8, z_scaled(z), v_z) of a column is monotone in z, so its values inside the chunk lie between
+        // those at the chunk's ends: when both are in [2^-20, 2^20] in magnitude and of one sign, every reciprocal of the task can use
+        // the unwrapped refinement chain (kt_rcp_exact); a column that crosses the camera plane inside the chunk takes the division.
+        const float zs_a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tab_zs), 0));
+        const float zs_b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tab_zs), min(KT_TSDF_ZCHUNK + KT_TSDF_UNROLL - 1, N - 1 - tab_base)));
+        const float d_a = __builtin_fmaf(r8, zs_a, v_z), d_b = __builtin_fmaf(r8, zs_b, v_z);
+        const bool d_ok = fminf(fabsf(d_a), fabsf(d_b)) >= 0x1p-20f && fmaxf(fabsf(d_a), fabsf(d_b)) <= 0x1p20f && (d_a < 0) == (d_b < 0);
+        const bool fast = __builtin_amdgcn_ballot_w64(!d_ok) == 0;
         // Latency is hidden by occupancy (8 tasks per SIMD) rather than by cross-iteration software pipelining: hipcc's s_waitcnt
         // insertion cannot count loads that are still in flight across a loop back-edge and falls back to vmcnt(0).  (A straight-line
         // 4-batch version with two batches in flight needs 96 VGPRs = 5 waves per SIMD and measured 15% / 40% slower at 512^3 / 768^3.)
         for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
             kt_tsdf_batch cur;
-            kt_tsdf_issue<COUNT, BUF>(a, m, cur, zb, z0, z1, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base);
+            if (fast) kt_tsdf_issue<COUNT, BUF, true>(a, m, cur, zb, wz1, lane_ok, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base, r8);
+            else kt_tsdf_issue<COUNT, BUF, false>(a, m, cur, zb, wz1, lane_ok, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base, r8);
             kt_tsdf_consume<COUNT, BUF>(a, m, cur, v_g_part_norm, tranc_dist_inv, n_upd, brick_xy, n_img, col_base, plane);
             if (COUNT) ++n_batches;
         }
@@ -809,6 +842,35 @@ extern "C" int kt_debug_stream(kt_ctx* c, void* buf, size_t bytes, int elem_size
     if (elem_size == 2) hipLaunchKernelGGL(kt_stream_kernel<unsigned short>, dim3(8192), dim3(256), 0, c->stream, (unsigned short*)buf, bytes / 2, rmw, &c->counters[8]);
     else hipLaunchKernelGGL(kt_stream_kernel<unsigned int>, dim3(8192), dim3(256), 0, c->stream, (unsigned int*)buf, bytes / 4, rmw, &c->counters[8]);
     KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// exhaustive check hook for kt_rcp_exact: every float d with 2^-20 <= |d| <= 2^20 (both signs) against the IEEE division
+__global__ __launch_bounds__(256) void kt_rcp_check_kernel(unsigned int* __restrict__ mismatches)
+{
+    const unsigned int lo = 0x35800000u, hi = 0x49800000u;   // 2^-20 .. 2^20
+    unsigned int bad = 0;
+    for (unsigned int bits = lo + blockIdx.x * 256u + threadIdx.x; bits <= hi; bits += gridDim.x * 256u) {
+        const float d = __uint_as_float(bits);
+        float q = 1.0f / d;
+        asm volatile("" : "+v"(q));
+        if (__float_as_uint(kt_rcp_exact(d)) != __float_as_uint(q)) ++bad;
+        float qn = 1.0f / -d;
+        asm volatile("" : "+v"(qn));
+        if (__float_as_uint(kt_rcp_exact(-d)) != __float_as_uint(qn)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+extern "C" int kt_debug_rcp_check(kt_ctx* c, unsigned int* mismatches_host)
+{
+    KT_ARG(c && mismatches_host);
+    unsigned int* d = nullptr;
+    KT_HIP(hipMalloc((void**)&d, sizeof(unsigned int)));
+    KT_HIP(hipMemsetAsync(d, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(kt_rcp_check_kernel, dim3(4096), dim3(256), 0, c->stream, d);
+    KT_HIP(hipMemcpyAsync(mismatches_host, d, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    KT_HIP(hipFree(d));
     return KT_OK;
 }
 

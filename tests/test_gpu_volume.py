@@ -229,3 +229,13 @@ def test_unpack_tsdf_all_shorts(ctx):
     v = np.arange(-32768, 32768, dtype=np.float32)
     ref = (v / np.float32(32767)).astype(np.float32)
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+def test_exact_reciprocal_all_floats(ctx):
+    """tsdf23's 1 / d is the IEEE refinement chain without its scaling wrapper (kt_rcp_exact): equal to the division for every float
+    in the range the kernel uses it on, 2^-20 <= |d| <= 2^20 (2 x 3.4e8 values)."""
+    import ctypes as C
+    from kintinuous_amd import abi
+    bad = C.c_uint(12345)
+    abi._chk(abi.lib().kt_debug_rcp_check(ctx.h, C.byref(bad)))
+    assert bad.value == 0
