@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--host-frames", action="store_true",
                     help="frames start in host memory (pinned staging copy + PCIe upload inside the timed region): the PCIe-inclusive rate, not the headline")
     ap.add_argument("--cpu-frames", type=int, default=31, help="frames of the CPU baseline sample (about 3 s wall = 100 core-seconds on 32 threads)")
+    ap.add_argument("--no-stress", action="store_true", help="skip the roofline_stress block (BASELINE.json configs[4]: 1280x960 @ 768^3, 3 frames)")
     return ap.parse_args()
 
 
@@ -109,7 +110,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     ctx.sync()
-    trk.enable_profiling(1)  # HIP events around the tsdf23 kernel only, on the stream it is launched on
+    # HIP events around the tsdf23 kernel only, on the stream it is launched on: every timed frame when the region is short,
+    # one frame in 8 otherwise (the timing itself then stays off the other 7)
+    trk.enable_profiling(4 if args.steps <= 50 else 1)
     if dist is not None:
         import torch
         dist.barrier()
@@ -188,13 +191,7 @@ def main():
     # HBM-side traffic of the same kernel: PMC counters cannot be read from inside the process, so this is the committed rocprofv3
     # measurement of this workload (profiles/, collected and corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes,
     # FETCH_SIZE x 2 after calibration on this access width, WRITE_SIZE x 1, KiB units); null for workloads without one
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_tsdf23_{args.workload}.json")
-    if N == WORKLOADS[args.workload][2] and os.path.exists(pmc_file):
-        try:
-            traffic = float(json.load(open(pmc_file))["traffic_bytes_per_launch"])
-        except Exception:
-            traffic = None
+    traffic = committed_traffic(args.workload) if N == WORKLOADS[args.workload][2] else None
 
     out = {
         "metric": "RGB-D frames/sec @640x480, 512^3 TSDF" if args.workload == "orbit512" else f"RGB-D frames/sec ({args.workload})",
@@ -230,8 +227,14 @@ def main():
         "host_ms_per_frame": {"process_frame_call": round(1e3 * host_call_s, 4), "of_which_waiting_for_pose": round(1e3 * host_wait_s, 4)},
     }
 
+    if rank == 0 and world == 1 and args.workload == "orbit512" and not args.no_stress and not args.host_frames:
+        out["roofline_stress"] = roofline_stress(ctx, abi, synth)
+
     if rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cam, N, d, frames, args.cpu_frames)
+        # the oracle needs cpu_frames + 2 frames of the same sequence whatever --steps / --warmup are
+        cframes = frames if len(frames) >= args.cpu_frames + 2 else synth.sequence(cfg_name, args.cpu_frames + 2, cam, seed)[1]
+        gpu_poses = [trk.dense_pose(k)[1] for k in range(min(trk.num_poses(), args.cpu_frames))]   # the counting replay above: frames 0..
+        out["cpu_baseline"] = cpu_baseline(cam, N, d, cframes, args.cpu_frames, gpu_poses)
 
     if rank == 0:
         print(json.dumps(out))
@@ -241,7 +244,63 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(cam, N, d, frames, nframes):
+def kt_volume_sha():
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "kintinuous_amd", "csrc", "kt_volume.hip"), "rb").read()).hexdigest()[:16]
+
+
+def committed_traffic(workload):
+    """HBM-side traffic of the tsdf23 launch: PMC counters cannot be read from inside the process, so this is the committed rocprofv3
+    measurement of this workload (profiles/r02_pmc_tsdf23_<workload>.json, written by scripts/pmc_traffic.sh: separate --pmc passes,
+    FETCH_SIZE x 2 after calibration on this access width, WRITE_SIZE x 1, as MI355X_MICROARCH.md prescribes).  It is only quoted for
+    the kernel it was measured on: the file records the sha256 of kt_volume.hip, and a stale measurement prints null."""
+    f = os.path.join(ROOT, "profiles", f"r02_pmc_tsdf23_{workload}.json")
+    try:
+        j = json.load(open(f))
+        return float(j["traffic_bytes_per_launch"]) if j.get("kt_volume_hip_sha16") == kt_volume_sha() else None
+    except Exception:
+        return None
+
+
+def roofline_stress(ctx, abi, synth):
+    """BASELINE.json configs[4] / SURVEY 8(d) config 5, the roofline showcase: 1280x960 depth into a 768^3 volume in static mode (the
+    camera 0.45 m outside the near face, far wall at 6.2 m), 3 timed frames, HIP events around every tsdf23 launch."""
+    N, cam = 768, synth.Camera.scaled(2)
+    _, frames, _, kw = synth.sequence("farwall", 5, cam)
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 1, 0, 0, 0, 0, 0)
+    trk = abi.Tracker(ctx, cfg)
+    dev = [(ctx.upload(a), ctx.upload(b)) for a, b in frames]
+    for k in range(2):
+        trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+    ctx.sync()
+    trk.enable_profiling(4)
+    t0 = time.perf_counter()
+    for k in range(2, 5):
+        trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+    trk.pose()
+    ctx.sync()
+    frame_ms = 1e3 * (time.perf_counter() - t0) / 3
+    trk.process_frame(dev[0][0], dev[0][1], 33333 * 5)   # harvest the last event pair
+    ctx.sync()
+    ms, n = trk.stage_ms()["tsdf23"]
+    trk.enable_profiling(0)
+    trk.reset()
+    trk.enable_counts(True)
+    Us = []
+    for k in range(5):
+        trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+        if k >= 2:
+            Us.append(trk.last_counts()[0])
+    trk.close()
+    U, P = float(np.mean(Us)), cam.cols * cam.rows
+    b = 12.0 * U + 16.0 * P
+    achieved = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"workload": "farwall768: 1280x960 synthetic far-wall sequence, static mode, 768^3 TSDF (BASELINE.json configs[4])", "kernel": "kt_tsdf23_kernel",
+            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": committed_traffic("farwall768"),
+            "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n, "U_voxels_updated": U, "frame_ms": round(frame_ms, 3)}
+
+
+def cpu_baseline(cam, N, d, frames, nframes, gpu_poses=()):
     """The oracle (CPU restatement of the reference -- the reference has no CPU path) timed on this host's cores on the
     first `nframes` frames of the same workload.  A reported baseline, not the target."""
     cores = min(32, len(os.sched_getaffinity(0)))
@@ -258,6 +317,9 @@ def cpu_baseline(cam, N, d, frames, nframes):
     for k in range(1, n):
         otr.process_frame(frames[k][0], frames[k][1], 33333 * k)
     dt = time.perf_counter() - t0
+    # the run is paid for: also compare its poses with the GPU's on the same frames (the parity tests proper are tests/test_gpu_configs.py)
+    m = min(n, len(gpu_poses))
+    pose_diff = max((float(np.abs(otr.dense_pose(k)[1] - gpu_poses[k]).max()) for k in range(m)), default=None)
     stages = otr.stage_seconds()
     # the same tracker on ONE thread, two more frames (SURVEY 8d asks for both ends of the host's range)
     single = None
@@ -283,7 +345,7 @@ def cpu_baseline(cam, N, d, frames, nframes):
     return {"value": (n - 1) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"frames 1..{n - 1} of the same sequence through oracle/ (OpenMP, {cores} threads) on {model}",
             "stage_s_total": {k: round(v, 3) for k, v in stages.items()},
-            "single_thread_value": single}
+            "single_thread_value": single, "pose_max_abs_diff_vs_gpu": pose_diff, "poses_compared": m}
 
 
 if __name__ == "__main__":

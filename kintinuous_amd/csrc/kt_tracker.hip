@@ -274,16 +274,20 @@ static void push_pose(kt_tracker* t, uint64_t ts, const float* R, int is_loop)
 }
 
 // ---- profiling helpers ---------------------------------------------------------------------------
+// profiling modes: 0 off; 1 the tsdf23 event pair on every 8th frame (long timed regions: the timing stays off the other 7);
+// 2 every stage of every frame (serial breakdown pass); 4 the tsdf23 pair on EVERY frame (short timed regions)
+static bool prof_all(const kt_tracker* t) { return t->profiling == 2 || t->profiling == 3; }
+static bool prof_tsdf(const kt_tracker* t) { return t->profiling == 1 || t->profiling == 4; }
 static int ev_begin(kt_tracker* t, int st)
 {
-    if (t->profiling >= 2 || (t->profiling == 1 && st == ST_TSDF23)) {
+    if (prof_all(t) || (prof_tsdf(t) && st == ST_TSDF23)) {
         KT_HIP(hipEventRecord(t->ev[t->ev_par][st][0], t->ctx->stream));
     }
     return KT_OK;
 }
 static int ev_end(kt_tracker* t, int st)
 {
-    if (t->profiling >= 2 || (t->profiling == 1 && st == ST_TSDF23)) {
+    if (prof_all(t) || (prof_tsdf(t) && st == ST_TSDF23)) {
         KT_HIP(hipEventRecord(t->ev[t->ev_par][st][1], t->ctx->stream));
         t->ev_rec[t->ev_par][st] = true;
     }
@@ -291,8 +295,7 @@ static int ev_end(kt_tracker* t, int st)
 }
 static void tsdf23_hook_arm(kt_tracker* t)
 {
-    // profiling == 1 (bench timed region): one frame in 8 carries the event pair, so the timing itself stays off the other 7
-    kt_tsdf23_hook.on = t->profiling >= 2 || (t->profiling == 1 && (t->prof_frames++ % 8) == 0);
+    kt_tsdf23_hook.on = prof_all(t) || t->profiling == 4 || (t->profiling == 1 && (t->prof_frames++ % 8) == 0);
     kt_tsdf23_hook.ev[0] = t->ev[t->ev_par][ST_TSDF23][0];
     kt_tsdf23_hook.ev[1] = t->ev[t->ev_par][ST_TSDF23][1];
     if (kt_tsdf23_hook.on) t->ev_rec[t->ev_par][ST_TSDF23] = true;

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() { n=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmcm_$n -- python $R/bench.py --workload orbit512 --steps 30 --warmup 2 --no-cpu-baseline --no-readahead > $R/gpurun_out/pmcm_$n.log 2>&1 || tail -3 $R/gpurun_out/pmcm_$n.log
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmcm_$n -- python $R/bench.py --workload orbit512 --steps 30 --warmup 2 --no-cpu-baseline --no-readahead --no-stress > $R/gpurun_out/pmcm_$n.log 2>&1 || tail -3 $R/gpurun_out/pmcm_$n.log
 }
 run a TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr
 run b TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum

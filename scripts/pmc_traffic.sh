@@ -1,14 +1,16 @@
 # HBM-side traffic of the tsdf23 kernel for one workload: FETCH_SIZE and WRITE_SIZE in separate passes (kernel-trace only), written
-# as profiles-style JSON to gpurun_out/pmc_traffic_<workload>.json.   usage: pmc_traffic.sh <workload> <steps>
+# as profiles-style JSON to gpurun_out/r02_pmc_tsdf23_<workload>.json (copy it to profiles/: bench.py quotes it as roofline.traffic
+# as long as kt_volume.hip still has the recorded hash).   usage: pmc_traffic.sh <workload> <steps>
 cd /tmp && export TMPDIR=/tmp
 W=${1:-farwall768}; S=${2:-6}
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmct_$c -- python $R/bench.py --workload $W --steps $S --warmup 2 --no-cpu-baseline --no-readahead > $R/gpurun_out/pmct_$c.log 2>&1 || tail -3 $R/gpurun_out/pmct_$c.log
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmct_$c -- python $R/bench.py --workload $W --steps $S --warmup 2 --no-cpu-baseline --no-readahead --no-stress > $R/gpurun_out/pmct_$c.log 2>&1 || tail -3 $R/gpurun_out/pmct_$c.log
 done
 python - <<PY
-import csv, glob, json, os
-out = {"workload": "$W ($S timed frames, no read-ahead)", "kernel": "kt_tsdf23_kernel<false>",
+import csv, glob, hashlib, json, os
+out = {"kt_volume_hip_sha16": hashlib.sha256(open("$R/kintinuous_amd/csrc/kt_volume.hip", "rb").read()).hexdigest()[:16],
+       "workload": "$W ($S timed frames, no read-ahead)", "kernel": "kt_tsdf23_kernel<false>",
        "collected": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, one pass each (scripts/pmc_traffic.sh), mean over the launches of the run",
        "calibration": "scripts/pmc_calibrate.sh: corrected traffic = 2 * FETCH_SIZE + WRITE_SIZE (KiB)"}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -17,6 +19,6 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     out[c] = sum(vals) / len(vals)
     out["launches_" + c] = len(vals)
 out["traffic_bytes_per_launch"] = (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024
-json.dump(out, open("$R/gpurun_out/pmc_traffic_$W.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/r02_pmc_tsdf23_$W.json", "w"), indent=1)
 print(json.dumps(out))
 PY

@@ -4,7 +4,7 @@ W=${1:-farwall768}; S=${2:-6}
 R=$GRAFT_REPO_ROOT
 run() { # name, counters...
   n=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$n -- python $R/bench.py --workload $W --steps $S --warmup 2 --no-cpu-baseline --no-readahead > $R/gpurun_out/pmc_$n.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$n -- python $R/bench.py --workload $W --steps $S --warmup 2 --no-cpu-baseline --no-readahead --no-stress > $R/gpurun_out/pmc_$n.log 2>&1
 }
 run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU
 run sq2 SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS

@@ -1,8 +1,8 @@
 """CPU: the .klg colour decoder (kintinuous_amd/host/JpegDecoder.h, the stand-in for cvDecodeImage in RawLogReader) against an
 independent numpy restatement of libjpeg's default decode path (kintinuous_amd/jpeg_ref.py): byte-identical output for every
 stream layout the encoder can produce; the integer IDCT path within 2 grey levels of a double-precision decode; decent PSNR
-against the source image.  No libjpeg in this image: parity with the real library is unpinned (both sides restate the same
-published algorithms)."""
+against the source image.  Pinned against the real library as well: Pillow (libjpeg-turbo, the decoder OpenCV's cvDecodeImage
+wraps too) decodes our encoder's streams AND its own to exactly the bytes the C++ decoder produces."""
 import os
 import subprocess
 
@@ -131,3 +131,30 @@ def test_cxx_log_reader(tool, tmp_path, layout):
         assert int(cd, 16) == zlib.crc32(np.ascontiguousarray(wd, "<u2").tobytes())
         assert int(ci, 16) == zlib.crc32(np.ascontiguousarray(wrgb).tobytes())
         assert int(comp) == int(layout != "raw")
+
+
+def _pillow():
+    PIL = pytest.importorskip("PIL.Image")
+    return PIL
+
+
+@pytest.mark.parametrize("sub", ["420", "422", "444"])
+@pytest.mark.parametrize("name", ["render", "noise", "ramp"])
+def test_decoder_matches_libjpeg(tool, tmp_path, name, sub):
+    """The C++ decoder against libjpeg-turbo itself (through Pillow): streams written by our encoder and streams written by
+    libjpeg's own encoder (different Huffman tables, sampling factors 4:2:0 / 4:2:2 / 4:4:4, qualities 60 and 92), byte for byte.
+    RawLogReader keeps OpenCV's BGR order; Pillow returns RGB."""
+    import io
+    Image = _pillow()
+    from kintinuous_amd import jpeg_ref
+    img = _images()[name]
+    h, w = img.shape[:2]
+    streams = [jpeg_ref.encode(img, quality=90, subsampling=sub)]
+    for q in (60, 92):
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, format="JPEG", quality=q, subsampling={"444": 0, "422": 1, "420": 2}[sub])
+        streams.append(buf.getvalue())
+    for k, data in enumerate(streams):
+        pil = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        got = _cxx_decode(tool, data, w, h, tmp_path, name=f"s{k}")
+        assert np.array_equal(got, pil[..., ::-1]), (k, int((got != pil[..., ::-1]).sum()))
