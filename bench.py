@@ -45,7 +45,7 @@ WORKLOADS = {
 }
 
 
-from kintinuous_amd.multistream import aggregate_fps, gather_poses, pingpong, stream_seed  # noqa: E402
+from kintinuous_amd.multistream import aggregate_fps, make_comm, pingpong, stream_seed  # noqa: E402
 
 
 SLICE_NAMES = {0: "X+", 1: "X-", 2: "Y+", 3: "Y-", 4: "Z+", 5: "Z-", 7: "FINAL"}   # CloudSlice::Dimension
@@ -107,6 +107,16 @@ def main():
         dd, dr = dev_frames[pingpong(i, nuniq)]
         trk.process_frame(dd, dr, 33333 * i)
 
+    # the one collective of the path: an RCCL all-gather of the ranks' dense poses through the C-ABI (kt_comm_*), also with a single
+    # rank (a one-rank communicator: the same call path, so the default run exercises it); KT_BENCH_NO_COMM=1 switches it off
+    comm = None
+    if not os.environ.get("KT_BENCH_NO_COMM"):
+        try:
+            comm = make_comm(dist, ctx, rank, world)
+        except Exception as e:   # no librccl on this host: the single-GPU measurement does not depend on it
+            if world > 1:
+                raise
+            sys.stderr.write(f"bench: pose gather disabled ({e})\n")
     for i in range(args.warmup):
         step(i)
     ctx.sync()
@@ -125,13 +135,10 @@ def main():
         step(i)
         marks.append(time.perf_counter())   # a call returns once the PREVIOUS frame's pose (and any volume shift) is done
     pose_bytes = 0
-    if dist is not None:
-        import torch
+    if comm is not None:
         k = min(args.steps, trk.num_poses())
-        mine = torch.empty((k, 16), dtype=torch.float32, device=f"cuda:{local_rank}")
-        trk.export_poses_device(k, mine.data_ptr())
-        allp = gather_poses(dist, mine, world)  # the single RCCL gather of per-stream poses
-        pose_bytes = allp.numel() * 4
+        allp = comm.gather_poses(trk, k)  # the single RCCL gather of per-stream poses, inside the timed region
+        pose_bytes = int(allp.size * 4)
     ctx.sync()
     if dist is not None:
         import torch
@@ -142,6 +149,7 @@ def main():
     fps = aggregate_fps(dist, args.steps, elapsed, world, device=(f"cuda:{local_rank}" if dist is not None else None))
     elapsed = world * args.steps / fps
 
+    timed_poses = [trk.dense_pose(trk.num_poses() - k + i)[1] for i in range(k)] if comm is not None else []
     # per-frame period seen by the caller (shift frames show up as the tail: slab extraction + download + clears on the host path)
     periods = np.diff(np.array(marks)) * 1e3
     slices_by_dim = {}
@@ -238,6 +246,9 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
+    if comm is not None:
+        assert np.array_equal(allp[rank], np.stack([p.reshape(16) for p in timed_poses])), "the gathered poses are not this rank's"
+        comm.close()
     trk.close()
     ctx.close()
     if dist is not None:

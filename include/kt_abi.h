@@ -268,6 +268,18 @@ int kt_debug_rcp_check(kt_ctx* ctx, unsigned int* mismatches_host);
 /* copies the last k dense poses (k*16 floats, row-major 4x4) into a DEVICE buffer for the gather */
 int kt_tracker_export_poses_device(kt_tracker* t, int k, float* dst_dev);
 
+/* The single collective of the path (north star: "a single RCCL gather of per-stream poses over xGMI"; SURVEY 8(b) export list, 8(e)):
+ * one process per GPU, rank r owns stream r.  Rank 0 makes the 128-byte RCCL id and hands it to the other ranks out of band
+ * (a file for the C++ driver, torch.distributed's store for bench.py); every rank then joins with kt_comm_init.
+ * kt_pose_gather: ONE ncclAllGather of k x 16 floats per rank (row-major [R | currentGlobalCamera], the DensePose payload of
+ * KintinuousTracker.h:151-169) on the communicator's own stream; all_poses_host receives nranks * k * 16 floats, rank-major. */
+#define KT_COMM_ID_BYTES 128
+typedef struct kt_comm kt_comm;
+int kt_comm_unique_id(unsigned char id[KT_COMM_ID_BYTES]);
+int kt_comm_init(kt_ctx* ctx, int rank, int nranks, const unsigned char id[KT_COMM_ID_BYTES], kt_comm** out);
+int kt_pose_gather(kt_comm* comm, kt_tracker* t, int k, float* all_poses_host);
+int kt_comm_destroy(kt_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,10 @@ _PROTOS = {
     "kt_debug_stream": (_i, [_vp, _vp, _sz, _i, _i]),
     "kt_debug_unpack_table": (_i, [_vp, _pf]),
     "kt_debug_rcp_check": (_i, [_vp, C.POINTER(C.c_uint)]),
+    "kt_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
+    "kt_comm_init": (_i, [_vp, _i, _i, C.POINTER(C.c_ubyte), C.POINTER(_vp)]),
+    "kt_pose_gather": (_i, [_vp, _vp, _i, _pf]),
+    "kt_comm_destroy": (_i, [_vp]),
     "kt_tracker_host_times": (_i, [_vp, _pd, _i]),
     "kt_tracker_prefetch_frame": (_i, [_vp, _vp, _vp]),
     "kt_tracker_prefetch_frame_host": (_i, [_vp, _vp, _vp]),
@@ -542,3 +546,29 @@ def host_pose_update(x, result_rt, Rprev, tprev):
     _chk(lib().kt_host_pose_update(_dp(x), _dp(rt), Rp.ctypes.data_as(_pf), tp.ctypes.data_as(_pf),
                                    Rc.ctypes.data_as(_pf), tc.ctypes.data_as(_pf)))
     return rt.reshape(4, 4), Rc.reshape(3, 3), tc
+
+
+class Comm:
+    """The path's single collective through the C-ABI (kt_comm_*: RCCL all-gather of dense poses).  Rank 0 makes the id, `share` hands
+    it to the other ranks (bytes -> bytes; identity for one rank)."""
+
+    def __init__(self, ctx: Ctx, rank: int, nranks: int, share=None):
+        ident = (C.c_ubyte * 128)()
+        if rank == 0:
+            _chk(lib().kt_comm_unique_id(ident))
+        if share is not None:
+            data = share(bytes(ident))
+            ident = (C.c_ubyte * 128)(*data)
+        self.h = C.c_void_p()
+        self.nranks = nranks
+        _chk(lib().kt_comm_init(ctx.h, rank, nranks, ident, C.byref(self.h)))
+
+    def gather_poses(self, trk: "Tracker", k: int) -> np.ndarray:
+        out = np.zeros((self.nranks, k, 16), np.float32)
+        _chk(lib().kt_pose_gather(self.h, trk.h, k, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def close(self) -> None:
+        if self.h:
+            lib().kt_comm_destroy(self.h)
+            self.h = None

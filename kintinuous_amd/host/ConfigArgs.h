@@ -34,7 +34,8 @@ class ConfigArgs {
                      "  -tum           write poses with timestamps in seconds (TUM format; the .poses default)\n"
                      "  -o <prefix>    output prefix (default: the log name)\n"
                      "  -pcd           write every extracted slice into <prefix>.pcd (binary, x y z rgb)\n"
-                     "  -ppm           write the final model views: <prefix>_model.ppm, _color.ppm, _depth.pgm\n",
+                     "  -ppm           write the final model views: <prefix>_model.ppm, _color.ppm, _depth.pgm\n"
+                     "  -rank R -world W -comm <file>   one process per GPU (-g): gather the ranks' dense poses at the end (RCCL)\n",
                      argv0.c_str());
     }
 

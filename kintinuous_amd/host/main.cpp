@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <fstream>
 #include <string>
+#include <thread>
 
 #include "TrackerInterface.h"
 
@@ -70,15 +71,57 @@ static void writeViews(KintinuousTracker* fe, const std::string& prefix)
     std::fclose(f);
 }
 
+// -rank R -world W -comm <file>: one process per GPU, each on its own log; after the last frame the ranks exchange their most recent
+// dense poses with the path's single collective (kt_pose_gather: one RCCL all-gather over xGMI).  Rank 0 writes the 128-byte RCCL id
+// to <file> (atomically, via rename); the other ranks wait for it.
+static bool gatherPoses(KintinuousTracker* fe, int rank, int world, const std::string& idFile)
+{
+    unsigned char id[KT_COMM_ID_BYTES];
+    if (rank == 0) {
+        ktSafeCall(kt_comm_unique_id(id));
+        FILE* f = std::fopen((idFile + ".tmp").c_str(), "wb");
+        if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0) return false;
+        if (std::rename((idFile + ".tmp").c_str(), idFile.c_str()) != 0) return false;
+    } else {
+        for (int tries = 0;; ++tries) {
+            FILE* f = std::fopen(idFile.c_str(), "rb");
+            if (f) {
+                const size_t got = std::fread(id, 1, sizeof(id), f);
+                std::fclose(f);
+                if (got == sizeof(id)) break;
+            }
+            if (tries > 6000) return false;   // 60 s
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+    }
+    kt_comm* comm = 0;
+    ktSafeCall(kt_comm_init(kt::device::context(), rank, world, id, &comm));
+    const int k = std::min(32, kt_tracker_num_poses(fe->handle()));
+    std::vector<float> all((size_t)world * k * 16);
+    ktSafeCall(kt_pose_gather(comm, fe->handle(), k, all.data()));
+    ktSafeCall(kt_comm_destroy(comm));
+    for (int r = 0; r < world; ++r) {
+        const float* p = &all[((size_t)r * k + (k - 1)) * 16];
+        std::printf("rank %d sees stream %d: last camera %.6f %.6f %.6f (%d poses gathered, %zu bytes)\n", rank, r, p[3], p[7], p[11], k,
+                    all.size() * sizeof(float));
+    }
+    return true;
+}
+
 int main(int argc, char** argv)
 {
     const ConfigArgs& args = ConfigArgs::get(argc, argv);
     if (args.help || args.logFile.empty()) { ConfigArgs::usage(argv[0]); return args.help ? 0 : 1; }
     bool ops = false, pcd = false, ppm = false;
+    int rank = 0, world = 0;
+    std::string commFile;
     for (int i = 1; i < argc; ++i) {
         ops = ops || std::string(argv[i]) == "-ops";
         pcd = pcd || std::string(argv[i]) == "-pcd";
         ppm = ppm || std::string(argv[i]) == "-ppm";
+        if (i + 1 < argc && std::string(argv[i]) == "-rank") rank = std::atoi(argv[i + 1]);
+        if (i + 1 < argc && std::string(argv[i]) == "-world") world = std::atoi(argv[i + 1]);
+        if (i + 1 < argc && std::string(argv[i]) == "-comm") commFile = argv[i + 1];
     }
 
     Resolution::get(args.width, args.height);
@@ -102,5 +145,8 @@ int main(int argc, char** argv)
     const kt::Vector3f cam = fe->getCurrentGlobalCamera();
     std::printf("frames %d  slices %zu  points %zu  last camera %.6f %.6f %.6f  %.1f frames/s (incl. file I/O and uploads)  path %s\n", frames,
                 fe->getCloudSlices().size(), points, cam(0), cam(1), cam(2), frames / sec, ops ? "operators" : "device-resident");
+    if (world > 0 && !ops) {
+        if (commFile.empty() || !gatherPoses(fe, rank, world, commFile)) { std::fprintf(stderr, "pose gather failed (-comm <file> shared by all ranks)\n"); return 1; }
+    }
     return 0;
 }

@@ -28,6 +28,21 @@ def gather_poses(dist, local_poses, world: int):
     return out
 
 
+def make_comm(dist, ctx, rank: int, world: int):
+    """The C-ABI communicator of the pose gather (kt_comm_init over RCCL): rank 0's id travels through torch.distributed's object
+    broadcast when there is more than one rank."""
+    from . import abi
+
+    def share(ident: bytes) -> bytes:
+        if dist is None or world <= 1:
+            return ident
+        box = [ident]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    return abi.Comm(ctx, rank, world, share)
+
+
 def aggregate_fps(dist, steps: int, elapsed_s: float, world: int, device=None) -> float:
     """Whole-job frames/s: all ranks' frames over the slowest rank's time (max over ranks)."""
     if dist is None or world <= 1:
