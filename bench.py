@@ -112,7 +112,14 @@ def main():
     comm = None
     if not os.environ.get("KT_BENCH_NO_COMM"):
         try:
-            comm = make_comm(dist, ctx, rank, world)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)            # librccl prints a version banner on stdout at init: the driver reads ONE JSON line from it
+            try:
+                comm = make_comm(dist, ctx, rank, world)
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
         except Exception as e:   # no librccl on this host: the single-GPU measurement does not depend on it
             if world > 1:
                 raise
@@ -150,6 +157,7 @@ def main():
     elapsed = world * args.steps / fps
 
     timed_poses = [trk.dense_pose(trk.num_poses() - k + i)[1] for i in range(k)] if comm is not None else []
+    first_poses = [trk.dense_pose(i)[1] for i in range(min(trk.num_poses(), args.cpu_frames))]   # frames 0.. of the sequence (warm-up first)
     # per-frame period seen by the caller (shift frames show up as the tail: slab extraction + download + clears on the host path)
     periods = np.diff(np.array(marks)) * 1e3
     slices_by_dim = {}
@@ -187,6 +195,8 @@ def main():
             Us.append(U)
             Ss.append(S)
     trk.enable_counts(False)
+    if trk.num_poses() != args.warmup + args.steps:
+        sys.stderr.write(f"bench: the counting replay produced {trk.num_poses()} poses for {args.warmup + args.steps} frames\n")
     U = float(np.mean(Us))
     P = cam.cols * cam.rows
     # algorithmic bytes of the tsdf23 launch (DESIGN.md "integrate"): 12 B per updated voxel (2 B tsdf + 4 B colour/weight,
@@ -241,8 +251,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         # the oracle needs cpu_frames + 2 frames of the same sequence whatever --steps / --warmup are
         cframes = frames if len(frames) >= args.cpu_frames + 2 else synth.sequence(cfg_name, args.cpu_frames + 2, cam, seed)[1]
-        gpu_poses = [trk.dense_pose(k)[1] for k in range(min(trk.num_poses(), args.cpu_frames))]   # the counting replay above: frames 0..
-        out["cpu_baseline"] = cpu_baseline(cam, N, d, cframes, args.cpu_frames, gpu_poses)
+        out["cpu_baseline"] = cpu_baseline(cam, N, d, cframes, args.cpu_frames, first_poses)
 
     if rank == 0:
         print(json.dumps(out))

@@ -506,6 +506,11 @@ int kt_tracker_reset(kt_tracker* t)
     t->pending.clear();
     t->prev_set = -1;
     t->parked = t->cfg.static_mode != 0;
+    t->v_wrap_copy[0] = t->v_wrap_copy[1] = t->v_wrap_copy[2] = 0;
+    t->gt_utime = 0;
+    t->current_ts = 0;
+    // the colour-weight carry of pixels without a normal starts from zero, like the freshly allocated nmaps_curr_ it stands for
+    for (int k = 0; k < 2; ++k) KT_HIP(hipMemsetAsync(t->wrkc_carry[k], 0, sizeof(float) * (size_t)t->cfg.cols * t->cfg.rows, t->ctx->stream));
     KT_TRY(kt_init_volume(t->ctx, t->tsdf, t->N));
     KT_TRY(kt_init_color_volume(t->ctx, t->color, t->N));
     KT_HIP(hipMemsetAsync(t->bricks, 0, kt_brick_count(t->N), t->ctx->stream));

@@ -307,3 +307,26 @@ def test_errors_are_reported_not_swallowed(ctx, small_scene):
     trk.process_frame_host(frames[0][0], frames[0][1], 0)
     assert trk.num_poses() == 1
     trk.close()
+
+
+def test_reset_replays_identically(ctx, small_scene):
+    """KintinuousTracker::reset (KintinuousTracker.cpp:262-354): after a reset the same frames give the same poses, volumes and colour
+    weights as on a fresh tracker (the colour-weight carry and the wrap copy start over too)."""
+    from kintinuous_amd import abi
+    cam, frames, _ = small_scene
+    g, _ = _cfgs(cam, 64)
+    trk = abi.Tracker(ctx, g)
+
+    def run():
+        for k, (d, rgb) in enumerate(frames[:6]):
+            trk.process_frame_host(d, rgb, 33333 * k)
+        return (np.stack([trk.dense_pose(i)[1] for i in range(trk.num_poses())]), trk.volume().copy(), trk.color_volume().copy())
+
+    a = run()
+    trk.reset()
+    assert trk.num_poses() == 0 and trk.num_slices() == 0
+    b = run()
+    assert len(a[0]) == len(b[0]) == 6
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    trk.close()
