@@ -184,6 +184,9 @@ typedef struct {
     int max_slice_points;    /* 0 = 3 * cols * rows (KintinuousTracker.cpp:77) */
     int dynamic_cube;        /* -d: the cube swings around the camera with its heading (repositionCube, KintinuousTracker.cpp:384-442);
                                 the pose is then observed on the host before the frame is fused (no speculative fusion) */
+    int place_recognition;   /* a vocabulary file is configured (-v, ConfigArgs::vocabFile): sample frames for the loop-closure
+                                backend whenever the camera has moved (rotation + translation) / 2 >= 0.15 since the last sample, or at
+                                the next volume shift (KintinuousTracker.cpp:605-624, 706-717), and mark those poses isLoopPose */
 } kt_tracker_config;
 
 int kt_tracker_create(kt_ctx* ctx, const kt_tracker_config* cfg, kt_tracker** out);
@@ -213,6 +216,8 @@ int kt_tracker_finalise(kt_tracker* t);
 /* volumeBasis (KintinuousTracker::getVolumeOffset); constant unless dynamic_cube is set */
 int kt_tracker_get_volume_basis(kt_tracker* t, float basis_host[3]);
 /* KintinuousTracker::repositionCube on explicit state (host code): may move basis[0] and basis[2] */
+/* (|rodrigues2(Rcurr^-1 Rlast)| + |cam - camLast|) / 2, KintinuousTracker.cpp:607-611 */
+float kt_host_place_recognition_movement(const float Rcurr[9], const float cam[3], const float Rlast[9], const float camLast[3]);
 void kt_host_reposition_cube(const float R[9], const float tlast[3], float volume_size, const float voxel_size[3], int thresh, float basis[3]);
 /* rmats_.back() (row-major 3x3), tvecs_.back(), currentGlobalCamera */
 int kt_tracker_get_pose(kt_tracker* t, float R_host[9], float t_host[3], float global_cam_host[3]);
@@ -262,6 +267,15 @@ int kt_debug_stream(kt_ctx* ctx, void* buf, size_t bytes, int elem_size, int rmw
 int kt_debug_unpack_table(kt_ctx* ctx, float* out_host65536);
 /* test hook: number of floats d, 2^-20 <= |d| <= 2^20, for which the voxel kernel's unwrapped reciprocal chain differs from 1.0f / d */
 int kt_debug_rcp_check(kt_ctx* ctx, unsigned int* mismatches_host);
+
+/* Place-recognition tap (KintinuousTracker::addToPlaceRecognition, KintinuousTracker.cpp:917-958): the frames sampled for the
+ * loop-closure backend, in order.  The library keeps the sample's metadata (PlaceRecognitionInput::utime / trans / rotation and the
+ * index of the dense pose it belongs to); the caller, who owns the frame buffers, copies the image and depth of that frame
+ * (host/KintinuousTracker.h fills placeRecognitionBuffer from them).  slice_pr_id: the sample attached to slice i as its
+ * placeRecognitionFrame (mutexOutCloudBuffer's last argument, finalise :1038-1045), or -1. */
+int kt_tracker_num_pr_samples(kt_tracker* t);
+int kt_tracker_pr_sample(kt_tracker* t, int i, uint64_t* utime, float trans[3], float rotation[9], int* pose_index);
+int kt_tracker_slice_pr_id(kt_tracker* t, int i, int* pr_id);
 
 /* ---- multi-GPU: independent streams, one tracker per GPU; poses are gathered by the caller's
  * collective (bench.py / the CLI use RCCL all_gather on the buffer filled here) ---- */

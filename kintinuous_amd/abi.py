@@ -45,7 +45,7 @@ class TrackerConfig(C.Structure):  # kt_tracker_config
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
         ("volume_size", C.c_float), ("voxel_shift", C.c_int), ("overlap", C.c_int), ("static_mode", C.c_int),
         ("use_rgbd", C.c_int), ("use_rgbd_icp", C.c_int), ("fast_odometry", C.c_int), ("disable_color_angle", C.c_int),
-        ("max_slice_points", C.c_int), ("dynamic_cube", C.c_int),
+        ("max_slice_points", C.c_int), ("dynamic_cube", C.c_int), ("place_recognition", C.c_int),
     ]
 
 
@@ -133,6 +133,10 @@ _PROTOS = {
     "kt_debug_stream": (_i, [_vp, _vp, _sz, _i, _i]),
     "kt_debug_unpack_table": (_i, [_vp, _pf]),
     "kt_debug_rcp_check": (_i, [_vp, C.POINTER(C.c_uint)]),
+    "kt_tracker_num_pr_samples": (_i, [_vp]),
+    "kt_tracker_pr_sample": (_i, [_vp, _i, C.POINTER(_u64), _pf, _pf, C.POINTER(C.c_int)]),
+    "kt_tracker_slice_pr_id": (_i, [_vp, _i, C.POINTER(C.c_int)]),
+    "kt_host_place_recognition_movement": (_f, [_pf, _pf, _pf, _pf]),
     "kt_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
     "kt_comm_init": (_i, [_vp, _i, _i, C.POINTER(C.c_ubyte), C.POINTER(_vp)]),
     "kt_pose_gather": (_i, [_vp, _vp, _i, _pf]),
@@ -448,6 +452,20 @@ class Tracker:
         if n.value:
             _chk(lib().kt_tracker_slice_points(self.h, i, out.ctypes.data))
         return out, dim.value
+
+    def pr_samples(self):
+        """[(utime, trans[3], rot[3,3], pose_index)] of the frames sampled for place recognition, in order."""
+        out = []
+        for i in range(lib().kt_tracker_num_pr_samples(self.h)):
+            ut, tr, ro, pi = _u64(0), (C.c_float * 3)(), (C.c_float * 9)(), C.c_int(0)
+            _chk(lib().kt_tracker_pr_sample(self.h, i, C.byref(ut), tr, ro, C.byref(pi)))
+            out.append((ut.value, np.array(tr, np.float32), np.array(ro, np.float32).reshape(3, 3), pi.value))
+        return out
+
+    def slice_pr_id(self, i: int) -> int:
+        v = C.c_int(0)
+        _chk(lib().kt_tracker_slice_pr_id(self.h, i, C.byref(v)))
+        return v.value
 
     def volume(self) -> np.ndarray:
         N = self.cfg.N

@@ -92,3 +92,19 @@ extern "C" void kt_host_reposition_cube(const float R[9], const float tlast[3], 
     }
     if (trips) { basis[0] = moved[0]; basis[2] = moved[2]; }
 }
+
+// The movement measure of the place-recognition tap (KintinuousTracker.cpp:607-611): (|rodrigues2(Rcurr^-1 * Rlast)| + |c - clast|) / 2,
+// every step in float as Eigen evaluates it (cofactor inverse, 3x3 product summed left to right, norms as sqrt of x^2 + y^2 + z^2).
+extern "C" float kt_host_place_recognition_movement(const float Rcurr[9], const float cam[3], const float Rlast[9], const float camLast[3])
+{
+    float inv[9], rel[9], aa[3];
+    kt_mat33_inverse(Rcurr, inv);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) rel[i * 3 + j] = (inv[i * 3] * Rlast[j] + inv[i * 3 + 1] * Rlast[3 + j]) + inv[i * 3 + 2] * Rlast[6 + j];
+    axis_angle_of(rel, aa);
+    const float rnorm = sqrtf((aa[0] * aa[0] + aa[1] * aa[1]) + aa[2] * aa[2]);
+    const float d[3] = {cam[0] - camLast[0], cam[1] - camLast[1], cam[2] - camLast[2]};
+    const float tnorm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float alpha = 1.f;
+    return (rnorm + alpha * tnorm) / 2;
+}

@@ -20,7 +20,8 @@
 namespace {
 
 struct DensePose { uint64_t ts; float pose[16]; int is_loop; };   // KintinuousTracker.h:151-169
-struct Slice { std::vector<kt_point_xyzrgb> pts; int dim; float R[9], cam[3]; uint64_t ts; };      // CloudSlice.h:28-129 (cloud + dimension)
+struct Slice { std::vector<kt_point_xyzrgb> pts; int dim; float R[9], cam[3]; uint64_t ts; int pr_id; };      // CloudSlice.h:28-129 (cloud + dimension)
+struct PrSample { uint64_t utime; float trans[3], rot[9]; int pose_index; };   // PlaceRecognitionInput.h:30-56, minus the frame bytes
 
 // Everything computed from the input frame alone (bilateral + pyramids + scaleDepth records): two sets, so the set of frame
 // k + 1 can be filled on the prefetch stream while frame k is tracked and fused on the main stream.
@@ -116,6 +117,9 @@ struct kt_tracker {
     // outputs
     std::vector<DensePose> poses;
     std::vector<Slice> slices;
+    // place-recognition tap (KintinuousTracker.h:216, 248-249): pose of the last sampled frame, the samples
+    float pr_rot[9], pr_trans[3];
+    std::vector<PrSample> pr_samples;
     // deferred completion: a frame's fusion kernels are enqueued before the host has seen its pose (complete_frame)
     bool outstanding; uint64_t out_ts; int out_set;
     const uint16_t* out_depth; const uint8_t* out_rgb; int out_thresh;
@@ -502,6 +506,9 @@ int kt_tracker_reset(kt_tracker* t)
     t->voxel_wrap[0] = t->voxel_wrap[1] = t->voxel_wrap[2] = 0;
     t->poses.clear();
     t->slices.clear();
+    t->pr_samples.clear();
+    memcpy(t->pr_trans, t->current_global_camera, sizeof(t->pr_trans));   // :290-291
+    memcpy(t->pr_rot, t->initial_rotation, sizeof(t->pr_rot));
     KT_HIP(hipStreamSynchronize(t->pre_stream));
     t->pending.clear();
     t->prev_set = -1;
@@ -791,6 +798,7 @@ static int fetch_slice(kt_tracker* t, const int lo[3], const int hi[3], int dim)
     t->slices.emplace_back();
     Slice& s = t->slices.back();
     s.dim = dim;
+    s.pr_id = -1;
     memcpy(s.R, t->Rlast, sizeof(s.R));                          // rmats_.back(), currentGlobalCamera, current_utime:
     memcpy(s.cam, t->current_global_camera, sizeof(s.cam));      // KintinuousTracker.cpp:1186-1191
     s.ts = t->current_ts;
@@ -852,6 +860,18 @@ static void ground_truth_pose(kt_tracker* t, uint64_t timestamp, float Rcurr[9],
     }
 }
 
+// KintinuousTracker::addToPlaceRecognition :917-958: the sample carries lastPlaceRecognitionTrans / Rot (set by the caller just before)
+static int add_pr_sample(kt_tracker* t)
+{
+    PrSample ps;
+    ps.utime = t->current_ts;
+    memcpy(ps.trans, t->pr_trans, sizeof(ps.trans));
+    memcpy(ps.rot, t->pr_rot, sizeof(ps.rot));
+    ps.pose_index = (int)t->poses.size();   // the dense pose of the frame being processed is pushed after this
+    t->pr_samples.push_back(ps);
+    return (int)t->pr_samples.size() - 1;
+}
+
 // Host half of a frame once its pose is known: the pose bookkeeping of KintinuousTracker.cpp:574-595, 903-909 and, when the volume
 // has to shift (:627-833), the shift.  speculated = the fusion kernels were already enqueued against the device-side shift decision
 // (they ran unless the device parked them); otherwise (pose supplied by the host) they are enqueued here, after any shift.
@@ -868,6 +888,21 @@ static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool specu
     if (t->cfg.dynamic_cube)  // :597-600; while parked its threshold is VOLUME_X (x 3 with -sm), :403
         kt_host_reposition_cube(Rcurr, t->tlast, t->cfg.volume_size, t->voxel_size,
                                 t->parked ? (t->cfg.static_mode ? t->N * 3 : t->N) : t->cfg.voxel_shift, t->volume_basis);
+
+    // place-recognition tap :601-624: sample now if the camera has moved enough since the last sample, else at the next shift
+    bool shift_send = false;
+    int is_loop = 0;
+    if (t->cfg.place_recognition) {
+        const float place_recognition_movement = 0.15f;   // KintinuousTracker.cpp:76
+        if (kt_host_place_recognition_movement(Rcurr, t->current_global_camera, t->pr_rot, t->pr_trans) >= place_recognition_movement) {
+            memcpy(t->pr_rot, Rcurr, sizeof(t->pr_rot));
+            memcpy(t->pr_trans, t->current_global_camera, sizeof(t->pr_trans));
+            add_pr_sample(t);
+            is_loop = 1;
+        } else {
+            shift_send = true;
+        }
+    }
 
     // [F] shift decision :627-667 and the three axis blocks :669-833
     float current_translation[3];
@@ -908,6 +943,13 @@ static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool specu
                 cycled = true;
             }
             if (cycled) {
+                if (shift_send) {   // :706-717, :762-771, :816-825: the slab leaving the volume takes a sample with it
+                    memcpy(t->pr_rot, Rcurr, sizeof(t->pr_rot));
+                    memcpy(t->pr_trans, t->current_global_camera, sizeof(t->pr_trans));
+                    t->slices.back().pr_id = add_pr_sample(t);
+                    is_loop = 1;
+                    shift_send = false;
+                }
                 // mutexOutCloudBuffer :1156-1208
                 const float shift = t->voxel_size[axis] * (float)vt[axis];
                 t->tlast[axis] -= shift;
@@ -926,7 +968,7 @@ static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool specu
     }
     v_wrap_copy_update(t);
     ++t->global_time;
-    push_pose(t, t->out_ts, Rcurr, 0);  // [K] :903-909
+    push_pose(t, t->out_ts, Rcurr, is_loop);  // [K] :903-909
     return KT_OK;
 }
 
@@ -1066,6 +1108,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         t->ev_par ^= 1;
         t->gt_utime = timestamp;   // :527-528
         KT_HIP(hipEventRecord(t->odo_ev[ordinal % KT_NODO], c->stream));
+        if (t->cfg.place_recognition) add_pr_sample(t);   // :546-549: the first frame is always sampled (pose index 0)
         push_pose(t, timestamp, t->Rlast, 1);
         if (t->counting) {
             unsigned int u = 0;
@@ -1225,7 +1268,36 @@ int kt_tracker_finalise(kt_tracker* t)
     KT_TRY(complete_frame(t));
     v_wrap_copy_update(t);
     const int lo[3] = {0, 0, 0}, hi[3] = {t->N, t->N, t->N};
-    return fetch_slice(t, lo, hi, 7 /* CloudSlice::FINAL */);
+    KT_TRY(fetch_slice(t, lo, hi, 7 /* CloudSlice::FINAL */));
+    if (t->cfg.place_recognition) {   // :1035-1045: the final slice carries one more sample, taken at the last pose
+        memcpy(t->pr_rot, t->Rlast, sizeof(t->pr_rot));
+        memcpy(t->pr_trans, t->current_global_camera, sizeof(t->pr_trans));
+        t->slices.back().pr_id = add_pr_sample(t);
+        t->pr_samples.back().pose_index = (int)t->poses.size() - 1;   // no new pose follows: it belongs to the last one
+    }
+    return KT_OK;
+}
+
+int kt_tracker_num_pr_samples(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? (int)t->pr_samples.size() : 0; }
+int kt_tracker_pr_sample(kt_tracker* t, int i, uint64_t* utime, float* trans, float* rotation, int* pose_index)
+{
+    KT_ARG(t && utime && trans && rotation && pose_index);
+    KT_TRY(complete_frame(t));
+    KT_ARG(i >= 0 && i < (int)t->pr_samples.size());
+    const PrSample& ps = t->pr_samples[i];
+    *utime = ps.utime;
+    memcpy(trans, ps.trans, sizeof(ps.trans));
+    memcpy(rotation, ps.rot, sizeof(ps.rot));
+    *pose_index = ps.pose_index;
+    return KT_OK;
+}
+int kt_tracker_slice_pr_id(kt_tracker* t, int i, int* pr_id)
+{
+    KT_ARG(t && pr_id);
+    KT_TRY(complete_frame(t));
+    KT_ARG(i >= 0 && i < (int)t->slices.size());
+    *pr_id = t->slices[i].pr_id;
+    return KT_OK;
 }
 
 int kt_tracker_get_pose(kt_tracker* t, float* R, float* tv, float* gc)

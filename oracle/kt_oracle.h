@@ -129,6 +129,7 @@ typedef struct {
     int disable_color_angle;    /* -dc */
     int reduce_order;           /* 0 reference float tree, 1 double */
     int dynamic_cube;           /* -d */
+    int place_recognition;      /* ConfigArgs::vocabFile.size() != 0 */
 } kto_tracker_config;
 
 kto_tracker* kto_tracker_create(const kto_tracker_config* cfg);
@@ -147,6 +148,10 @@ void kto_tracker_get_pose(const kto_tracker* t, float R[9], float tvec[3], float
 int  kto_tracker_num_poses(const kto_tracker* t);
 void kto_tracker_get_dense_pose(const kto_tracker* t, int i, uint64_t* ts, float pose16[16], int* is_loop);
 void kto_tracker_get_voxel_wrap(const kto_tracker* t, int wrap[3]);
+/* place-recognition tap (KintinuousTracker.cpp:601-624, 706-717, 917-958, 1035-1045): the sampled frames' metadata */
+int  kto_tracker_num_pr_samples(const kto_tracker* t);
+void kto_tracker_pr_sample(const kto_tracker* t, int i, uint64_t* utime, float trans[3], float rot[9]);
+int  kto_tracker_slice_pr_id(const kto_tracker* t, int i);
 int  kto_tracker_num_slices(const kto_tracker* t);
 size_t kto_tracker_slice_size(const kto_tracker* t, int i);
 int  kto_tracker_slice_dimension(const kto_tracker* t, int i);

@@ -213,7 +213,8 @@ static void pose_update(const double x[6], double resultRt[16], const float Rpre
 
 /* ---------------------------------------------------------------------------------------------- */
 typedef struct { uint64_t ts; float pose[16]; int is_loop; } dense_pose;
-typedef struct { kto_point* pts; size_t n; int dim; } slice_rec;
+typedef struct { kto_point* pts; size_t n; int dim; int pr; } slice_rec;
+typedef struct { uint64_t utime; float trans[3], rot[9]; } pr_rec; /* PlaceRecognitionInput.h:30-56 without the frame bytes */
 
 struct kto_tracker {
     kto_tracker_config cfg;
@@ -252,6 +253,9 @@ struct kto_tracker {
     int* traj_key;          /* the map's comparator is std::less<int>: keys are the timestamps narrowed to int */
     float (*traj_T)[12];    /* Isometry3f: R row-major [0..8], t [9..11] */
     uint64_t current_utime;
+    /* place recognition (KintinuousTracker.h:216, 248-249, 132-135) */
+    float last_pr_trans[3], last_pr_rot[9];
+    pr_rec* pr; int n_pr, cap_pr;
 };
 
 static int lvl_cols(const kto_tracker* t, int l) { return t->cfg.cols >> l; }
@@ -323,6 +327,7 @@ void kto_tracker_destroy(kto_tracker* t)
     for (int i = 0; i < t->n_slices; ++i) free(t->slices[i].pts);
     free(t->slices); free(t->poses);
     free(t->traj_key); free(t->traj_T);
+    free(t->pr);
     free(t);
 }
 
@@ -346,6 +351,9 @@ void kto_tracker_reset(kto_tracker* t)
     memcpy(t->tlast, t->volume_basis, sizeof(t->tlast));
     compute_global_camera(t, NULL); /* uses voxelWrap before it is zeroed, as the reference does */
     t->voxel_wrap[0] = t->voxel_wrap[1] = t->voxel_wrap[2] = 0;
+    memcpy(t->last_pr_trans, t->current_global_camera, sizeof(t->last_pr_trans)); /* :290-291 */
+    memcpy(t->last_pr_rot, t->initial_rotation, sizeof(t->last_pr_rot));
+    t->n_pr = 0;
     t->n_poses = 0;
     for (int i = 0; i < t->n_slices; ++i) free(t->slices[i].pts);
     t->n_slices = 0;
@@ -389,18 +397,34 @@ static void push_slice(kto_tracker* t, size_t n, int dim)
     slice_rec* s = &t->slices[t->n_slices++];
     s->n = n;
     s->dim = dim;
+    s->pr = -1;
     s->pts = malloc((n ? n : 1) * sizeof(kto_point));
     memcpy(s->pts, t->cloud_device, n * sizeof(kto_point));
 }
 
+/* addToPlaceRecognition :917-958 (the copies of the frame's image and depth are the caller's business) */
+static int add_to_place_recognition(kto_tracker* t)
+{
+    if (t->n_pr == t->cap_pr) {
+        t->cap_pr = t->cap_pr ? 2 * t->cap_pr : 64;
+        t->pr = realloc(t->pr, (size_t)t->cap_pr * sizeof(pr_rec));
+    }
+    pr_rec* r = &t->pr[t->n_pr];
+    r->utime = t->current_utime;
+    memcpy(r->trans, t->last_pr_trans, sizeof(r->trans));
+    memcpy(r->rot, t->last_pr_rot, sizeof(r->rot));
+    return t->n_pr++;
+}
+
 /* mutexOutCloudBuffer :1156-1208 */
-static void mutex_out_cloud_buffer(kto_tracker* t, size_t cloud_n, float device_tcurr[3], const int trans[3])
+static void mutex_out_cloud_buffer(kto_tracker* t, size_t cloud_n, float device_tcurr[3], const int trans[3], int pr_frame)
 {
     float voxel_trans_size[3];
     for (int k = 0; k < 3; ++k) voxel_trans_size[k] = t->voxel_size[k] * (float)trans[k];
     for (int k = 0; k < 3; ++k) t->tlast[k] -= voxel_trans_size[k];
     int dim = trans[0] > 0 ? 0 : trans[0] < 0 ? 1 : trans[1] > 0 ? 2 : trans[1] < 0 ? 3 : trans[2] > 0 ? 4 : 5; /* CloudSlice.h:33-36 */
     push_slice(t, cloud_n, dim);
+    t->slices[t->n_slices - 1].pr = pr_frame;
     for (int k = 0; k < 3; ++k) t->voxel_wrap[k] += trans[k];
     for (int k = 0; k < 3; ++k) device_tcurr[k] -= voxel_trans_size[k];
 }
@@ -728,6 +752,7 @@ void kto_tracker_process_frame(kto_tracker* t, const uint16_t* depth_raw, const 
         ++t->global_time;
         t->current_utime = timestamp; /* :527-528 */
         push_pose(t, timestamp, t->Rlast, 1);
+        if (t->cfg.place_recognition) add_to_place_recognition(t); /* :546-549 */
         return;
     }
 
@@ -748,6 +773,26 @@ void kto_tracker_process_frame(kto_tracker* t, const uint16_t* depth_raw, const 
     kto_mat33 Rc, Rc_inv;
     memcpy(Rc.m, Rcurr, sizeof(Rc.m));
     kto_mat33_inverse(&Rc, &Rc_inv);
+
+    /* [E] place-recognition sampling :601-624 */
+    int shift_send = 0, is_loop_pose = 0;
+    if (t->cfg.place_recognition) {
+        float rel[9], rvec[3];
+        mat3f_mul(Rc_inv.m, t->last_pr_rot, rel);            /* Rcurr.inverse() * lastPlaceRecognitionRot */
+        rodrigues2(rel, rvec);
+        const float rnorm = sqrtf((rvec[0] * rvec[0] + rvec[1] * rvec[1]) + rvec[2] * rvec[2]);
+        const float dx = t->current_global_camera[0] - t->last_pr_trans[0], dy = t->current_global_camera[1] - t->last_pr_trans[1],
+                    dz = t->current_global_camera[2] - t->last_pr_trans[2];
+        const float tnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float alpha = 1.f, place_recognition_movement = 0.15f; /* :76 */
+        if ((rnorm + alpha * tnorm) / 2 >= place_recognition_movement) {
+            memcpy(t->last_pr_rot, Rcurr, sizeof(t->last_pr_rot));
+            memcpy(t->last_pr_trans, t->current_global_camera, sizeof(t->last_pr_trans));
+            add_to_place_recognition(t);
+            is_loop_pose = 1;
+        } else
+            shift_send = 1;
+    }
 
     /* [F] shift decision :627-667 */
     float current_translation[3];
@@ -778,9 +823,17 @@ void kto_tracker_process_frame(kto_tracker* t, const uint16_t* depth_raw, const 
             cycled = 1;
         }
         if (cycled) {
+            int next_pr_frame = -1;
+            if (shift_send) { /* :706-717, :762-771, :816-825 */
+                memcpy(t->last_pr_rot, Rcurr, sizeof(t->last_pr_rot));
+                memcpy(t->last_pr_trans, t->current_global_camera, sizeof(t->last_pr_trans));
+                next_pr_frame = add_to_place_recognition(t);
+                is_loop_pose = 1;
+                shift_send = 0;
+            }
             int trans[3] = {0, 0, 0};
             trans[axis] = vt[axis];
-            mutex_out_cloud_buffer(t, cloud_n, tcurr, trans);
+            mutex_out_cloud_buffer(t, cloud_n, tcurr, trans, next_pr_frame);
         }
     }
     v_wrap_copy_update(t);
@@ -802,7 +855,7 @@ void kto_tracker_process_frame(kto_tracker* t, const uint16_t* depth_raw, const 
         }
     t1 = omp_get_wtime(); t->stage_s[5] += t1 - t0;
     ++t->global_time;
-    push_pose(t, timestamp, Rcurr, 0); /* [K] :903-909 */
+    push_pose(t, timestamp, Rcurr, is_loop_pose); /* [K] :903-909 */
 }
 
 void kto_tracker_finalise(kto_tracker* t)
@@ -812,7 +865,21 @@ void kto_tracker_finalise(kto_tracker* t)
     size_t n = kto_extract_cloud_slice(t->tsdf, t->volume_size, t->cloud_device, t->cloud_cap, t->v_wrap_copy, t->color, 0, t->N, 0,
                                        t->N, 0, t->N, 1, t->voxel_wrap, t->N);
     push_slice(t, n, 7 /* CloudSlice::FINAL */);
+    if (t->cfg.place_recognition) { /* :1035-1045 */
+        memcpy(t->last_pr_rot, t->Rlast, sizeof(t->last_pr_rot));
+        memcpy(t->last_pr_trans, t->current_global_camera, sizeof(t->last_pr_trans));
+        t->slices[t->n_slices - 1].pr = add_to_place_recognition(t);
+    }
 }
+
+int kto_tracker_num_pr_samples(const kto_tracker* t) { return t->n_pr; }
+void kto_tracker_pr_sample(const kto_tracker* t, int i, uint64_t* utime, float trans[3], float rot[9])
+{
+    *utime = t->pr[i].utime;
+    memcpy(trans, t->pr[i].trans, sizeof(t->pr[i].trans));
+    memcpy(rot, t->pr[i].rot, sizeof(t->pr[i].rot));
+}
+int kto_tracker_slice_pr_id(const kto_tracker* t, int i) { return t->slices[i].pr; }
 
 void kto_tracker_get_pose(const kto_tracker* t, float R[9], float tvec[3], float global_cam[3])
 {

@@ -39,7 +39,7 @@ class OTrackerConfig(C.Structure):
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
         ("volume_size", C.c_float), ("voxel_shift", C.c_int), ("overlap", C.c_int), ("static_mode", C.c_int),
         ("use_rgbd", C.c_int), ("use_rgbd_icp", C.c_int), ("fast_odometry", C.c_int), ("disable_color_angle", C.c_int),
-        ("reduce_order", C.c_int), ("dynamic_cube", C.c_int),
+        ("reduce_order", C.c_int), ("dynamic_cube", C.c_int), ("place_recognition", C.c_int),
     ]
 
 
@@ -390,6 +390,18 @@ class OracleTracker:
             return np.zeros(0, POINT_DTYPE), dim
         buf = (C.c_char * (n * 32)).from_address(ptr)
         return np.frombuffer(buf, dtype=POINT_DTYPE, count=n).copy(), dim
+
+    def pr_samples(self):
+        """[(utime, trans[3], rot[3,3])] of the frames sampled for place recognition, in order."""
+        out = []
+        for i in range(lib().kto_tracker_num_pr_samples(self.h)):
+            ut, tr, ro = C.c_uint64(0), (C.c_float * 3)(), (C.c_float * 9)()
+            lib().kto_tracker_pr_sample(self.h, i, C.byref(ut), tr, ro)
+            out.append((ut.value, np.array(tr, np.float32), np.array(ro, np.float32).reshape(3, 3)))
+        return out
+
+    def slice_pr_id(self, i) -> int:
+        return lib().kto_tracker_slice_pr_id(self.h, i)
 
     def _arr(self, ptr, dtype, shape):
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize

@@ -35,7 +35,7 @@ def test_struct_layouts():
     from kintinuous_amd import abi
     assert ctypes.sizeof(abi.Intr) == 16 and ctypes.sizeof(abi.Mat33) == 36
     assert abi.DATATERM_DTYPE.itemsize == 16 and abi.POINT_DTYPE.itemsize == 32
-    assert ctypes.sizeof(abi.TrackerConfig) == 17 * 4
+    assert ctypes.sizeof(abi.TrackerConfig) == 18 * 4
 
 
 def test_no_oracle_in_product_path():

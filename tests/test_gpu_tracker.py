@@ -13,12 +13,13 @@ def _cfgs(cam, N, **kw):
     from kintinuous_amd import abi
     from oracle import oracle
     d = dict(volume_size=6.0, voxel_shift=14, overlap=2, static_mode=0, use_rgbd=0, use_rgbd_icp=0, fast_odometry=0, disable_color_angle=0,
-             dynamic_cube=0)
+             dynamic_cube=0, place_recognition=0)
     d.update(kw)
     g = abi.TrackerConfig(cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, d["volume_size"], d["voxel_shift"], d["overlap"], d["static_mode"],
-                          d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0, d["dynamic_cube"])
+                          d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0, d["dynamic_cube"], d["place_recognition"])
     o = oracle.OTrackerConfig(cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, d["volume_size"], d["voxel_shift"], d["overlap"], d["static_mode"],
-                              d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0, d["dynamic_cube"])
+                              d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0, d["dynamic_cube"],
+                              d["place_recognition"])
     return g, o
 
 
@@ -330,3 +331,31 @@ def test_reset_replays_identically(ctx, small_scene):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     trk.close()
+
+
+@pytest.mark.parametrize("mode", ["icp", "rgbd_icp"])
+def test_place_recognition_tap(ctx, oracle_mod, mode):
+    """the loop-closure input tap (KintinuousTracker.cpp:601-624, 706-717, 917-958, 1035-1045) on a shifting
+    crab-walk: which frames are sampled (by movement, or taken along by a volume shift), their stored pose, the isLoopPose flags of
+    the dense pose graph and the sample each slice carries -- identical to the oracle."""
+    from kintinuous_amd import synth
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("wall")
+    traj = synth.crabwalk_trajectory(420)
+    frames = [synth.render(scene, cam, *traj[i]) for i in range(0, 90)]
+    trk, otr, max_t, max_r = _run_pair(ctx, cam, frames, 96, volume_size=7.0, voxel_shift=3, use_rgbd_icp=int(mode == "rgbd_icp"), place_recognition=1)
+    trk.finalise(); otr.finalise()
+    assert max_t < 1e-5 and max_r < 1e-5
+    assert trk.num_poses() == otr.num_poses()
+    gl = [trk.dense_pose(i)[2] for i in range(trk.num_poses())]
+    ol = [otr.dense_pose(i)[2] for i in range(otr.num_poses())]
+    assert gl == ol and sum(ol) >= 5 and not all(ol)
+    gs, os_ = trk.pr_samples(), otr.pr_samples()
+    assert len(gs) == len(os_) == sum(ol) + 1            # + the final slice's sample
+    for a, b in zip(gs, os_):
+        assert a[0] == b[0] and np.abs(a[1] - b[1]).max() < 1e-5 and np.abs(a[2] - b[2]).max() < 1e-5
+    assert [gs[i][3] for i in range(len(gs) - 1)] == [i for i, f in enumerate(ol) if f]     # sample i belongs to the i-th loop pose
+    assert trk.num_slices() == otr.num_slices() >= 5
+    ids = [trk.slice_pr_id(i) for i in range(trk.num_slices())]
+    assert ids == [otr.slice_pr_id(i) for i in range(otr.num_slices())]
+    assert ids[-1] == len(gs) - 1 and any(i >= 0 for i in ids[:-1]) and any(i < 0 for i in ids[:-1])

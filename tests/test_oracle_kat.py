@@ -340,3 +340,41 @@ def test_dynamic_cube_repositioning(oracle_mod):
     assert moved_at is not None and moved_at >= 2                    # not before the heading has swung the corner 3 voxels away
     assert trk.num_poses() == len(yaws)
     trk.close()
+
+
+def test_place_recognition_tap_known_answer(oracle_mod):
+    """KintinuousTracker.cpp:601-624, 706-717, 917-958 on -p ground truth (exact poses): a camera translating 40 mm per frame along x
+    passes the movement threshold ((|rotation| + |translation|) / 2 >= 0.15, i.e. 0.30 m without rotation) every 8th frame -- unless
+    a volume shift comes first and takes the pending sample with it (shiftSend).  Frame 0 and the final slice are always sampled."""
+    from kintinuous_amd import synth
+    from oracle.oracle import OTrackerConfig, OracleTracker
+    cam = synth.Camera.small(64, 48)
+    scene = synth.Scene("wall")
+    n = 24
+    poses = [(np.eye(3), np.array([0.04 * k, 0.0, 0.0])) for k in range(n)]
+    frames = [synth.render(scene, cam, R, c) for R, c in poses]
+    stamps = np.array([1000 * (k + 1) for k in range(n)], np.uint64)
+    rows = synth.ground_truth_rows(poses)
+    # 7 m / 32 voxels = 0.21875 m per voxel; threshold 2 voxels = 0.4375 m: shifts at frames 11 (0.44 m) and 22
+    trk = OracleTracker(OTrackerConfig(cam.cols, cam.rows, 32, cam.fx, cam.fy, cam.cx, cam.cy, 7.0, 2, 2, 0, 0, 0, 0, 0, 0, 0, 1))
+    trk.load_trajectory(stamps, rows)
+    for k, (d, rgb) in enumerate(frames):
+        trk.process_frame(d, rgb, int(stamps[k]))
+    trk.finalise()
+    loops = [k for k in range(trk.num_poses()) if trk.dense_pose(k)[2]]
+    # 0.32 m reached at frame 8 -> sample; from there 0.32 m more at frame 16 -> sample; the shift at frame 11 happens with a sample
+    # pending (shiftSend), so it samples too and restarts the distance: 8, 11, 19, (shift at 22: sample), ...
+    assert loops == [0, 8, 11, 19, 22], loops
+    samples = trk.pr_samples()
+    assert [int(s[0]) for s in samples] == [1000, 9000, 12000, 20000, 23000, 24000]      # + the final slice's sample (last frame's stamp)
+    assert np.allclose(samples[1][1], [0.32, 0, 0], atol=1e-5) and np.allclose(samples[1][2], np.eye(3))
+    assert trk.num_slices() == 3
+    assert [trk.slice_pr_id(i) for i in range(3)] == [2, 4, 5]     # the two shift slices and the final one carry their samples
+    trk.close()
+    # without a vocabulary nothing is sampled and only frame 0 is a loop pose
+    trk = OracleTracker(OTrackerConfig(cam.cols, cam.rows, 32, cam.fx, cam.fy, cam.cx, cam.cy, 7.0, 2, 2, 0, 0, 0, 0, 0, 0, 0, 0))
+    trk.load_trajectory(stamps, rows)
+    for k, (d, rgb) in enumerate(frames):
+        trk.process_frame(d, rgb, int(stamps[k]))
+    assert [k for k in range(trk.num_poses()) if trk.dense_pose(k)[2]] == [0] and trk.pr_samples() == []
+    trk.close()
