@@ -28,6 +28,7 @@ class ConfigArgs {
                      "  -g <gpu>       device\n"
                      "  -n <N>         volume resolution (default 512)\n"
                      "  -r | -ri       RGB-D odometry | RGB-D + ICP odometry\n"
+                     "  -v <vocab>     loop-closure vocabulary: sample frames into placeRecognitionBuffer (the DBoW backend itself is not part of this path)\n"
                      "  -p <file>      ground-truth odometry from a trajectory file (lines utime,x,y,z,qx,qy,qz,qw)\n"
                      "  -fod           fast odometry,  -sm static mode,  -d dynamic cube,  -dc no colour angle weight,  -no no overlap\n"
                      "  -f             flip colours (RGB <-> BGR)\n"
@@ -39,7 +40,7 @@ class ConfigArgs {
                      argv0.c_str());
     }
 
-    std::string calibrationFile, logFile, trajectoryFile, saveFile;
+    std::string calibrationFile, logFile, trajectoryFile, saveFile, vocabFile;
     int gpu, voxelShift, volumeResolution, width, height, totalNumFrames;
     float volumeSize;
     bool staticMode, dynamicCube, flipColors, extractOverlap, useRGBD, useRGBDICP, disableColorAngleWeight, fastOdometry, help;
@@ -65,6 +66,7 @@ class ConfigArgs {
         if ((v = value(argc, argv, "-c"))) calibrationFile = v;
         if ((v = value(argc, argv, "-l"))) logFile = v;
         if ((v = value(argc, argv, "-p"))) trajectoryFile = v;
+        if ((v = value(argc, argv, "-v"))) vocabFile = v;   // a DBoW vocabulary switches the place-recognition tap on (ConfigArgs.h:121)
         if ((v = value(argc, argv, "-g"))) gpu = std::atoi(v);
         if ((v = value(argc, argv, "-t"))) voxelShift = std::atoi(v);
         if ((v = value(argc, argv, "-n"))) volumeResolution = std::atoi(v);

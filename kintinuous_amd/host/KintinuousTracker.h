@@ -6,24 +6,53 @@
 //     reference composes it (bilateralFilter, pyrDown, createVMap, ..., ICPOdometry, integrateTsdfVolume, raycast,
 //     resizeVMap) -- the drop-in granularity of the reference, one sync per operator.  ICP odometry only.
 // getImage / getModelDepth (KintinuousTracker.cpp:960-981) render the predicted maps without OpenGL; -p ground truth is handled by
-// the device-resident path.  Not carried over: liveTsdf and place-recognition buffering (outside the tracked path).
+// the device-resident path.  The fields other threads of the reference touch (CloudSliceProcessor.cpp:38-83, PlaceRecognition, the GUI)
+// are here with their names and protocols: cloudMutex / cloudSignal / cycledMutex around sharedCloudSlices, init_utime,
+// firstRgbImage / firstDepthData, placeRecognitionId / placeRecognitionBuffer, latestDensePoseId, tsdfRequest / getLiveTsdf,
+// imageAvailable / getLiveImage (boost::mutex -> std::mutex, boost::condition_variable_any -> std::condition_variable_any).
 #pragma once
 
 #include <climits>
 #include <cmath>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "CloudSlice.h"
 #include "ConfigArgs.h"
 #include "ICPOdometry.h"
+#include "PlaceRecognitionInput.h"
 #include "Resolution.h"
+#include "ThreadMutexObject.h"
 #include "TSDFVolume.h"
 #include "Volume.h"
 
 class KintinuousTracker {
   public:
+    // KintinuousTracker.h:87-97: what the GUI and the backend threads synchronise on
+    ThreadMutexObject<bool> tsdfRequest;
+    bool tsdfAvailable;
+    std::mutex tsdfMutex;
+    bool imageAvailable;
+    std::mutex imageMutex;
+    bool cycledMutex;
+    std::mutex cloudMutex;
+    std::condition_variable_any cloudSignal;
+    // :135-147
+    ThreadMutexObject<uint64_t> init_utime;
+    ThreadMutexObject<unsigned char*> firstRgbImage;
+    ThreadMutexObject<unsigned short*> firstDepthData;
+    unsigned char* lastRgbImage;
+    unsigned short* lastDepthData;
+    ThreadMutexObject<int> placeRecognitionId;
+    static const int PR_BUFFER_SIZE = 3000;
+    PlaceRecognitionInput* placeRecognitionBuffer;   // [PR_BUFFER_SIZE] (an array member in the reference; on the heap here)
+    ThreadMutexObject<int> latestDensePoseId;
+
     class DensePose {  // KintinuousTracker.h:151-169
       public:
         DensePose(uint64_t timestamp, const kt::Matrix4f& pose, bool isLoopPose) : timestamp(timestamp), pose(pose), isLoopPose(isLoopPose) {}
@@ -38,9 +67,12 @@ class KintinuousTracker {
 
     // depthIntrinsics: fx, fy, cx, cy of the depth camera (the reference passes the 3x3 K as a cv::Mat)
     explicit KintinuousTracker(const Intr& depthIntrinsics, bool operatorPath = false)
-        : lastOdometry(CloudSlice::ICP), intr(depthIntrinsics), operatorPath(operatorPath), fast(0), tsdf_volume_(0), color_volume_(0),
-          icp(0), overlap(0), parked(false), global_time_(0), current_utime(0), nextSlice(0)
+        : tsdfRequest(false), tsdfAvailable(false), imageAvailable(false), cycledMutex(false), lastRgbImage(0), lastDepthData(0),
+          placeRecognitionId(0), placeRecognitionBuffer(new PlaceRecognitionInput[PR_BUFFER_SIZE]), latestDensePoseId(0),
+          lastOdometry(CloudSlice::ICP), intr(depthIntrinsics), operatorPath(operatorPath), fast(0), tsdf_volume_(0), color_volume_(0),
+          icp(0), overlap(0), parked(false), global_time_(0), current_utime(0), nextSlice(0), nextPrSample(0), liveTsdf(0), liveImage(0), lagTime(0)
     {
+        init_utime.assignValue(std::numeric_limits<unsigned long long>::max());   // KintinuousTracker.cpp:124
         const ConfigArgs& args = ConfigArgs::get();
         N = Volume::get().getResolution();
         if (!operatorPath) {
@@ -58,6 +90,7 @@ class KintinuousTracker {
             cfg.use_rgbd_icp = args.useRGBDICP;
             cfg.fast_odometry = args.fastOdometry;
             cfg.disable_color_angle = args.disableColorAngleWeight;
+            cfg.place_recognition = args.vocabFile.size() ? 1 : 0;
             config = cfg;
             lastOdometry = (args.useRGBD || args.useRGBDICP) ? CloudSlice::RGBD : CloudSlice::ICP;
             if (args.trajectoryFile.size()) {  // KintinuousTracker.cpp:128-138: ground truth wins over the odometry flags
@@ -92,18 +125,26 @@ class KintinuousTracker {
     {
         for (size_t i = 0; i < sharedCloudSlices.size(); ++i) delete sharedCloudSlices[i];
         if (fast) kt_tracker_destroy(fast);
+        delete liveTsdf;
+        delete liveImage;
+        delete[] firstRgbImage.getValue();
+        delete[] firstDepthData.getValue();
+        delete[] placeRecognitionBuffer;
         delete icp;
         delete color_volume_;
         delete tsdf_volume_;
     }
 
     void processFrame(const DeviceArray2D<unsigned short>& depth, const DeviceArray2D<PixelRGB>& colors, unsigned char* rgbImage,
-                      unsigned short* depthData, uint64_t timestamp, bool /*compression*/ = false, uint8_t* /*lastCompressedDepth*/ = 0,
-                      int /*depthSize*/ = 0, uint8_t* /*lastCompressedImage*/ = 0, int /*imageSize*/ = 0)
+                      unsigned short* depthData, uint64_t timestamp, bool compression = false, uint8_t* lastCompressedDepth = 0,
+                      int depthSize = 0, uint8_t* lastCompressedImage = 0, int imageSize = 0)
     {
+        lagTime = nowMicros();
         lastRgbImage = rgbImage;
         lastDepthData = depthData;
         current_utime = timestamp;
+        frameCompression = compression; frameCompressedDepth = lastCompressedDepth; frameDepthSize = depthSize;
+        frameCompressedImage = lastCompressedImage; frameImageSize = imageSize;
         if (!operatorPath) {
             ensureFast();
             const int before = global_time_;
@@ -124,11 +165,15 @@ class KintinuousTracker {
         ensureFast();
         ktSafeCall(kt_tracker_prefetch_frame_host(fast, depthData, rgbImage));
     }
-    void processFrameHost(unsigned short* depthData, unsigned char* rgbImage, uint64_t timestamp)
+    void processFrameHost(unsigned short* depthData, unsigned char* rgbImage, uint64_t timestamp, bool compression = false,
+                          uint8_t* lastCompressedDepth = 0, int depthSize = 0, uint8_t* lastCompressedImage = 0, int imageSize = 0)
     {
+        lagTime = nowMicros();
         lastRgbImage = rgbImage;
         lastDepthData = depthData;
         current_utime = timestamp;
+        frameCompression = compression; frameCompressedDepth = lastCompressedDepth; frameDepthSize = depthSize;
+        frameCompressedImage = lastCompressedImage; frameImageSize = imageSize;
         ensureFast();
         const int before = global_time_;
         ktSafeCall(kt_tracker_process_frame_host(fast, depthData, rgbImage, timestamp));
@@ -191,6 +236,8 @@ class KintinuousTracker {
     kt::Matrix3f getLastRotation() const { return lastRotation; }
     kt::Vector3f getCurrentGlobalCamera() const { return currentGlobalCamera; }
     std::vector<CloudSlice*>& getCloudSlices() { return sharedCloudSlices; }
+    CloudSlice* getLiveTsdf() { return liveTsdf; }     // KintinuousTracker.cpp:1065-1073
+    CloudSlice* getLiveImage() { return liveImage; }
     void setOverlap(int o)
     {
         overlap = o;
@@ -215,6 +262,16 @@ class KintinuousTracker {
     {
         global_time_ = 0;
         densePoseGraph.clear();
+        // KintinuousTracker.cpp:293-309
+        for (int i = 0; i < PR_BUFFER_SIZE; ++i) placeRecognitionBuffer[i].dump();
+        placeRecognitionId.assignValue(0);
+        latestDensePoseId.assignValue(0);
+        nextPrSample = 0;
+        delete[] firstRgbImage.getValue();
+        delete[] firstDepthData.getValue();
+        firstRgbImage.assignValue(0);
+        firstDepthData.assignValue(0);
+        init_utime.assignValue(std::numeric_limits<unsigned long long>::max());
         for (size_t i = 0; i < sharedCloudSlices.size(); ++i) delete sharedCloudSlices[i];
         sharedCloudSlices.clear();
         nextSlice = 0;
@@ -242,6 +299,8 @@ class KintinuousTracker {
     }
 
     kt_tracker* handle() { ensureFast(); return fast; }
+    // the reference renders the live image for its GUI on every frame the GUI has consumed the previous one; headless callers leave it off
+    bool liveViewsEnabled = false;
 
   private:
     Intr intr;
@@ -275,8 +334,100 @@ class KintinuousTracker {
     std::vector<float> trajectoryPoses;
     kt::Matrix3f lastRotation;
     kt::Vector3f lastTranslation, currentGlobalCamera;
-    unsigned char* lastRgbImage = 0;
-    unsigned short* lastDepthData = 0;
+    int nextPrSample;                 // samples of the library's place-recognition tap already copied into placeRecognitionBuffer
+    CloudSlice* liveTsdf;             // KintinuousTracker.h:243-244
+    CloudSlice* liveImage;
+    uint64_t lagTime;
+    bool frameCompression = false;    // the compressed payloads of the frame being processed, as the log delivered them (:917-958)
+    uint8_t* frameCompressedDepth = 0; int frameDepthSize = 0;
+    uint8_t* frameCompressedImage = 0; int frameImageSize = 0;
+    std::vector<PixelRGB> modelHost;
+
+    static uint64_t nowMicros()   // Stopwatch::getCurrentSystemTime()
+    {
+        return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+    }
+
+    // KintinuousTracker::addToPlaceRecognition :917-958 for sample `id` of the library's tap: the bytes of the frame being processed
+    // (compressed as the log had them, or raw) are copied into the next slot of placeRecognitionBuffer
+    PlaceRecognitionInput* addToPlaceRecognition(uint64_t utime, const kt::Vector3f& trans, const kt::Matrix3f& rot, bool compression)
+    {
+        const int nextSlot = placeRecognitionId.getValue();
+        if (nextSlot >= PR_BUFFER_SIZE) { std::fprintf(stderr, "placeRecognitionBuffer is full\n"); std::exit(1); }
+        const int depthDataSize = compression ? frameDepthSize : Resolution::get().numPixels() * 2;
+        const int rgbDataSize = compression ? frameImageSize : Resolution::get().numPixels() * 3;
+        unsigned char* depthPr = new unsigned char[depthDataSize];
+        unsigned char* imgPr = new unsigned char[rgbDataSize];
+        std::memcpy(depthPr, compression ? (const void*)frameCompressedDepth : (const void*)lastDepthData, depthDataSize);
+        std::memcpy(imgPr, compression ? (const void*)frameCompressedImage : (const void*)lastRgbImage, rgbDataSize);
+        PlaceRecognitionInput& slot = placeRecognitionBuffer[nextSlot];
+        slot.dump();
+        slot.rgbImage = imgPr;
+        slot.imageSize = rgbDataSize;
+        slot.depthMap = (unsigned short*)depthPr;
+        slot.depthSize = depthDataSize;
+        slot.isCompressed = compression;
+        slot.originallyCompressed = compression;
+        slot.imageIsRaw = !compression;
+        slot.utime = utime;
+        slot.lagTime = lagTime;
+        slot.trans = trans;
+        slot.rotation = rot;
+        placeRecognitionId++;
+        return &slot;
+    }
+
+    // mutexOutLiveTsdf / mutexOutLiveImage (KintinuousTracker.cpp:1087-1154, called from processFrame :835-862 when the GUI asked):
+    // the whole surface at subsample 1 and the shaded / colour views of the predicted map.  On the device-resident path they are
+    // taken after the frame has been fused (the reference takes them just before fusing it: one frame earlier).
+    void serveLiveViews()
+    {
+        if (tsdfRequest.getValue()) {
+            bool needed;
+            { std::lock_guard<std::mutex> l(tsdfMutex); needed = !tsdfAvailable; }
+            if (needed) {
+                CloudSlice::PointCloud* pts = new CloudSlice::PointCloud();
+                if (operatorPath) {
+                    vWrapCopyUpdate();
+                    DeviceArray<PointXYZRGB> c = tsdf_volume_->fetchCloud(cloud_device_, vWrapCopy, color_volume_->data(), 0, N, 0, N, 0, N, voxelWrap, 1);
+                    c.download(*pts);
+                } else {
+                    int w[3], wc[3];
+                    ktSafeCall(kt_tracker_get_voxel_wrap(fast, w));
+                    for (int k = 0; k < 3; ++k) wc[k] = w[k] < 0 ? N - ((-w[k]) % N) : w[k];
+                    DeviceArray<PointXYZRGB> buf((size_t)Resolution::get().numPixels() * 3);
+                    const float vs = Volume::get().getVolumeSize(), size[3] = {vs, vs, vs};
+                    size_t n = 0;
+                    ktSafeCall(kt_extract_cloud_slice(kt::device::context(), kt_tracker_volume(fast), size, buf.ptr(), buf.size(), wc, kt_tracker_color_volume(fast),
+                                                      0, N, 0, N, 0, N, 1, w, N, &n));
+                    pts->resize(n);
+                    if (n) ktSafeCall(kt_download(kt::device::context(), pts->data(), buf.ptr(), n * sizeof(PointXYZRGB)));
+                }
+                std::lock_guard<std::mutex> l(tsdfMutex);
+                tsdfAvailable = true;
+                delete liveTsdf;
+                liveTsdf = new CloudSlice(pts, CloudSlice::TSDF, lastOdometry, currentGlobalCamera, lastRotation, current_utime, nowMicros(), 0);
+            }
+        }
+        bool imageNeeded;
+        { std::lock_guard<std::mutex> l(imageMutex); imageNeeded = !imageAvailable && liveViewsEnabled; }
+        if (imageNeeded) {
+            int cols;
+            getImage();
+            const size_t bytes = (size_t)Resolution::get().numPixels() * 3;
+            modelColor.download(modelHost, cols);
+            unsigned char* tsdfImageColor = new unsigned char[bytes];
+            std::memcpy(tsdfImageColor, &modelHost[0], bytes);
+            modelSurface.download(modelHost, cols);
+            unsigned char* tsdfImage = new unsigned char[bytes];
+            std::memcpy(tsdfImage, &modelHost[0], bytes);
+            std::lock_guard<std::mutex> l(imageMutex);
+            imageAvailable = true;
+            delete liveImage;
+            liveImage = new CloudSlice(0, CloudSlice::TSDF, lastOdometry, currentGlobalCamera, lastRotation, current_utime, nowMicros(), lastRgbImage,
+                                       tsdfImageColor, tsdfImage, lastDepthData);
+        }
+    }
 
     kt::Vector3f volumeBasisValue() const
     {
@@ -303,10 +454,12 @@ class KintinuousTracker {
         }
     }
 
-    // pull pose, dense pose graph and new slices out of the device-resident tracker
+    // pull pose, dense pose graph, place-recognition samples and new slices out of the device-resident tracker, publishing them with
+    // the reference's protocol (first frame :523-556, shift slices :1156-1208, dense poses :903-909)
     void syncFromFast()
     {
         ktSafeCall(kt_tracker_get_pose(fast, lastRotation.data(), lastTranslation.data(), currentGlobalCamera.data()));
+        const int before = global_time_;
         global_time_ = kt_tracker_num_poses(fast);
         for (int i = (int)densePoseGraph.size(); i < global_time_; ++i) {
             uint64_t ts;
@@ -314,12 +467,41 @@ class KintinuousTracker {
             int loop;
             ktSafeCall(kt_tracker_get_dense_pose(fast, i, &ts, pose.m, &loop));
             densePoseGraph.push_back(DensePose(ts, pose, loop != 0));
+            latestDensePoseId++;
+        }
+        // the frames the library sampled for place recognition belong to the frame just processed: copy its bytes now
+        std::vector<PlaceRecognitionInput*> sampleSlot;
+        const int np = kt_tracker_num_pr_samples(fast);
+        for (; nextPrSample < np; ++nextPrSample) {
+            uint64_t ut;
+            kt::Vector3f tr;
+            kt::Matrix3f ro;
+            int poseIndex;
+            ktSafeCall(kt_tracker_pr_sample(fast, nextPrSample, &ut, tr.data(), ro.data(), &poseIndex));
+            // the final slice's sample is stored uncompressed (:1041)
+            const bool finalSample = kt_tracker_num_slices(fast) > 0 && lastSliceIsFinal();
+            addToPlaceRecognition(ut, tr, ro, finalSample ? false : frameCompression);
+        }
+        if (before == 0 && global_time_ >= 1) {   // first frame :523-556
+            init_utime.assignValue(current_utime);
+            const int n = Resolution::get().numPixels();
+            if (lastDepthData && lastRgbImage) {
+                unsigned short* firstDepth = new unsigned short[n];
+                std::memcpy(firstDepth, lastDepthData, (size_t)n * 2);
+                unsigned char* firstImg = new unsigned char[n * 3];
+                std::memcpy(firstImg, lastRgbImage, (size_t)n * 3);
+                firstDepthData.assignValue(firstDepth);
+                firstRgbImage.assignValue(firstImg);
+            }
+            std::lock_guard<std::mutex> lock(cloudMutex);
+            cloudSignal.notify_all();
         }
         const int ns = kt_tracker_num_slices(fast);
         for (; nextSlice < ns; ++nextSlice) {
             size_t n;
-            int dim;
+            int dim, prId;
             ktSafeCall(kt_tracker_slice_info(fast, nextSlice, &n, &dim));
+            ktSafeCall(kt_tracker_slice_pr_id(fast, nextSlice, &prId));
             CloudSlice::PointCloud* cloud = new CloudSlice::PointCloud(n);
             if (n) ktSafeCall(kt_tracker_slice_points(fast, nextSlice, cloud->data()));
             kt::Matrix3f R;
@@ -327,9 +509,21 @@ class KintinuousTracker {
             uint64_t ts;
             ktSafeCall(kt_tracker_slice_pose(fast, nextSlice, R.data(), cam.data(), &ts));
             const bool fin = dim == CloudSlice::FINAL;
-            sharedCloudSlices.push_back(new CloudSlice(cloud, (CloudSlice::Dimension)dim, lastOdometry, cam, R, ts, 0, fin ? lastRgbImage : 0,
-                                                       fin ? lastDepthData : 0));
+            PlaceRecognitionInput* pr = (prId >= 0 && prId < PR_BUFFER_SIZE) ? &placeRecognitionBuffer[prId] : 0;
+            std::lock_guard<std::mutex> lock(cloudMutex);
+            cycledMutex = true;
+            sharedCloudSlices.push_back(new CloudSlice(cloud, (CloudSlice::Dimension)dim, lastOdometry, cam, R, ts, fin ? nowMicros() : lagTime,
+                                                       fin ? lastRgbImage : 0, 0, 0, fin ? lastDepthData : 0, pr));
+            cloudSignal.notify_all();
         }
+        if (global_time_ > before && global_time_ > 1) serveLiveViews();
+    }
+    bool lastSliceIsFinal()
+    {
+        size_t n;
+        int dim;
+        ktSafeCall(kt_tracker_slice_info(fast, kt_tracker_num_slices(fast) - 1, &n, &dim));
+        return dim == CloudSlice::FINAL;
     }
 
     // KintinuousTracker::loadTrajectory (KintinuousTracker.cpp:216-260): lines "utime,x,y,z,qx,qy,qz,qw"; the poses themselves are
@@ -424,13 +618,18 @@ class KintinuousTracker {
             pose(i, 3) = currentGlobalCamera(i);
         }
         densePoseGraph.push_back(DensePose(ts, pose, loop));
+        latestDensePoseId++;
     }
 
     void pushSlice(const DeviceArray<PointXYZRGB>& cloud, CloudSlice::Dimension dim, unsigned char* rgb, unsigned short* depth)
     {
         CloudSlice::PointCloud* pts = new CloudSlice::PointCloud();
         cloud.download(*pts);
-        sharedCloudSlices.push_back(new CloudSlice(pts, dim, lastOdometry, currentGlobalCamera, rmats_.back(), current_utime, 0, rgb, depth));
+        std::lock_guard<std::mutex> lock(cloudMutex);
+        cycledMutex = true;
+        sharedCloudSlices.push_back(new CloudSlice(pts, dim, lastOdometry, currentGlobalCamera, rmats_.back(), current_utime,
+                                                   dim == CloudSlice::FINAL ? nowMicros() : lagTime, rgb, 0, 0, depth));
+        cloudSignal.notify_all();
     }
 
     static int voxelTranslation(float translation, float voxel, int thresh)  // KintinuousTracker.cpp:640-667
@@ -465,6 +664,18 @@ class KintinuousTracker {
                              vmaps_g_prev_[i], nmaps_g_prev_[i]);
             ++global_time_;
             pushDensePose(timestamp, init_Rcam, true);
+            init_utime.assignValue(timestamp);   // :525-556
+            {
+                const int n = Resolution::get().numPixels();
+                unsigned short* firstDepth = new unsigned short[n];
+                std::memcpy(firstDepth, lastDepthData, (size_t)n * 2);
+                unsigned char* firstImg = new unsigned char[n * 3];
+                std::memcpy(firstImg, lastRgbImage, (size_t)n * 3);
+                firstDepthData.assignValue(firstDepth);
+                firstRgbImage.assignValue(firstImg);
+                std::lock_guard<std::mutex> lock(cloudMutex);
+                cloudSignal.notify_all();
+            }
             return;
         }
 

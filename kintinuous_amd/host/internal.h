@@ -41,7 +41,19 @@ struct PixelRGB { unsigned char r, g, b; };  // internal.h:186-189
 
 static_assert(sizeof(Mat33) == sizeof(kt_mat33), "Mat33 layout");
 static_assert(sizeof(Intr) == sizeof(kt_intr), "Intr layout");
-static_assert(sizeof(PointXYZRGB) == 32 && sizeof(DataTerm) == 16 && sizeof(JtJJtrSE3) == 116, "boundary struct layout");
+// internal.h:186-229 == pcl::PointXYZRGBNormal (48 bytes): what CloudSliceProcessor fills processedCloud with
+struct PointXYZRGBNormal {
+    float x, y, z, pad0;
+    float normal_x, normal_y, normal_z, pad1;
+    union {
+        struct { unsigned char b, g, r, a; };
+        float rgb;
+        int rgba;
+    };
+    float curvature;
+    float pad2[2];
+};
+static_assert(sizeof(PointXYZRGB) == 32 && sizeof(PointXYZRGBNormal) == 48 && sizeof(DataTerm) == 16 && sizeof(JtJJtrSE3) == 116, "boundary struct layout");
 
 namespace kt {
 inline const kt_intr* abi(const Intr& i) { return reinterpret_cast<const kt_intr*>(&i); }

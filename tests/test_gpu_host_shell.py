@@ -170,3 +170,44 @@ def test_logger2_style_log_with_jpeg_colour(ctx, tmp_path):
             _, _, gc = trk.pose()
             assert np.allclose(P[k - 1, 1:4], gc, rtol=2e-6, atol=1e-6)
     trk.close()
+
+
+def test_backend_consumer_runs_against_the_shell(ctx, tmp_path):
+    """The tracker-facing half of the reference's CloudSliceProcessor::process (backend/CloudSliceProcessor.cpp:38-83, 163-181), restated
+    in host/consumer_test.cpp, compiles against host/KintinuousTracker.h and runs in its own thread while the tracker plays a shifting
+    log: cloudMutex / cloudSignal / cycledMutex, init_utime, placeRecognitionBuffer[0], the 12-argument CloudSlice constructor,
+    processedCloud, FINAL.  With -v the place-recognition tap fills placeRecognitionBuffer; the counts must match the C-ABI tracker's."""
+    from kintinuous_amd import abi, synth
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("wall")
+    traj = synth.crabwalk_trajectory(420)
+    frames = [synth.render(scene, cam, *traj[i]) for i in range(60)]
+    log, calib = _make_log(tmp_path, cam, frames)
+    exe = os.path.join(ROOT, "kintinuous_amd", "host", "bin", "consumer_test")
+    assert os.path.exists(exe)
+    args = ["-l", log, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "7", "-t", "3", "-v", "vocab.yml.gz"]
+    r = subprocess.run([exe] + args, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    head = r.stdout.splitlines()[0].split()
+    got = {head[i]: head[i + 1] for i in range(0, len(head) - 1, 2) if not head[i].isdigit()}
+    # the same run through the C-ABI tracker.  consumer_test derives its intrinsics from the image size like MainController's default
+    k = (528.0 * cam.cols / 640.0, 528.0 * cam.rows / 480.0, 320.0 * cam.cols / 640.0, 240.0 * cam.rows / 480.0)
+    trk = abi.Tracker(ctx, abi.TrackerConfig(cam.cols, cam.rows, 96, k[0], k[1], k[2], k[3], 7.0, 3, 2, 0, 0, 0, 0, 0, 0, 0, 1))
+    for i, (d, rgb) in enumerate(frames):
+        trk.process_frame_host(d, rgb, 33333 * i)
+    trk.finalise()
+    nslices = trk.num_slices()
+    assert nslices >= 4
+    assert int(got["consumed"]) == nslices + 1 and got["finished"] == "1"            # + the consumer's own FIRST slice
+    assert int(got["poses"]) == trk.num_poses() == int(got["latest"]) == len(frames)
+    assert int(got["loops"]) == sum(trk.dense_pose(i)[2] for i in range(trk.num_poses()))
+    assert int(got["pr"]) == len(trk.pr_samples()) >= 3
+    assert int(got["first_utime"]) == 0 and got["first_frame"] == "1"
+    live = head[head.index("live") + 1: head.index("live") + 3]
+    assert int(live[0]) > 1000 and live[1] == "1"                                       # getLiveTsdf / getLiveImage were served
+    lines = [l.split() for l in r.stdout.splitlines()[1:]]
+    assert len(lines) == nslices
+    for i, l in enumerate(lines):
+        n, dim = trk.slice_info(i)
+        assert int(l[3]) == dim and int(l[5]) == n == int(l[7]) and int(l[9]) == trk.slice_pr_id(i)
+    trk.close()
