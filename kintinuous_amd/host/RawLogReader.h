@@ -18,11 +18,16 @@
 
 class LogReader {
   public:
-    LogReader() : decompressedDepth(0), decompressedImage(0), timestamp(0), isCompressed(false) {}
+    LogReader() : decompressedDepth(0), decompressedImage(0), compressedDepth(0), compressedImage(0), compressedDepthSize(0), compressedImageSize(0),
+                  timestamp(0), isCompressed(false) {}
     virtual ~LogReader() {}
     virtual bool grabNext(bool& returnVal, int& currentFrame) = 0;
     unsigned short* decompressedDepth;
     unsigned char* decompressedImage;
+    unsigned char* compressedDepth;      // the frame's payloads as stored in the log (LogReader.h:51-54): what the place-recognition tap keeps
+    unsigned char* compressedImage;
+    int32_t compressedDepthSize;
+    int32_t compressedImageSize;
     int64_t timestamp;
     bool isCompressed;
 };
@@ -69,31 +74,43 @@ class RawLogReader : public LogReader {
             std::fprintf(stderr, "corrupt frame header in frame %d (payload sizes %d / %d)\n", currentFrame, depthSize, imageSize);
             std::exit(1);
         }
-        scratch.resize((size_t)(depthSize > imageSize ? depthSize : imageSize));
-        if (depthSize > 0 && std::fread(scratch.data(), (size_t)depthSize, 1, fp) != 1) { returnVal = false; return false; }
-        if ((size_t)depthSize == n * 2) {
-            std::memcpy(depthBuffer.data(), scratch.data(), n * 2);
+        std::vector<unsigned char>& rawDepth = rawDepthBuffers[flip];
+        std::vector<unsigned char>& rawImage = rawImageBuffers[flip];
+        rawDepth.resize((size_t)depthSize);
+        rawImage.resize((size_t)imageSize);
+        if (depthSize > 0 && std::fread(rawDepth.data(), (size_t)depthSize, 1, fp) != 1) { returnVal = false; return false; }
+        if (imageSize > 0 && std::fread(rawImage.data(), (size_t)imageSize, 1, fp) != 1) { returnVal = false; return false; }
+        compressedDepth = rawDepth.data(); compressedDepthSize = depthSize;
+        compressedImage = rawImage.data(); compressedImageSize = imageSize;
+        // the image decides isCompressed (RawLogReader.cpp:73-97); the depth payload has to agree (:99-117, asserts there)
+        if ((size_t)imageSize == n * 3) {
             isCompressed = false;
-        } else if (depthSize > 0) {
-            uLongf decomp = (uLongf)(n * 2);
-            if (uncompress((Bytef*)depthBuffer.data(), &decomp, (const Bytef*)scratch.data(), (uLong)depthSize) != Z_OK) {
-                std::fprintf(stderr, "corrupt zlib depth in frame %d\n", currentFrame);
-                std::exit(1);
-            }
+            std::memcpy(imageBuffer.data(), rawImage.data(), n * 3);
+        } else if (imageSize > 0) {  // anything else is handed to cvDecodeImage -> B G R bytes
             isCompressed = true;
-        } else {
-            std::memset(depthBuffer.data(), 0, n * 2);
-        }
-        if (imageSize > 0 && std::fread(scratch.data(), (size_t)imageSize, 1, fp) != 1) { returnVal = false; return false; }
-        if ((size_t)imageSize == n * 3) std::memcpy(imageBuffer.data(), scratch.data(), n * 3);
-        else if (imageSize == 0) std::memset(imageBuffer.data(), 0, n * 3);
-        else {  // RawLogReader.cpp:81-86: anything else is handed to cvDecodeImage -> B G R bytes
             std::string err;
-            if (!kt::jpeg::decodeBGR(scratch.data(), (size_t)imageSize, Resolution::get().width(), Resolution::get().height(), imageBuffer.data(), &err)) {
+            if (!kt::jpeg::decodeBGR(rawImage.data(), (size_t)imageSize, Resolution::get().width(), Resolution::get().height(), imageBuffer.data(), &err)) {
                 std::fprintf(stderr, "cannot decode the colour image of frame %d: %s\n", currentFrame, err.c_str());
                 std::exit(1);
             }
-            isCompressed = true;
+        } else {
+            isCompressed = false;
+            std::memset(imageBuffer.data(), 0, n * 3);
+        }
+        if ((size_t)depthSize == n * 2) {
+            if (isCompressed) { std::fprintf(stderr, "frame %d: raw depth with a compressed image\n", currentFrame); std::exit(1); }
+            std::memcpy(depthBuffer.data(), rawDepth.data(), n * 2);
+        } else if (depthSize > 0) {
+            // (the reference asserts isCompressed here; logs with zlib depth and a raw or empty image are accepted, depth decoded as is)
+            uLongf decomp = (uLongf)(n * 2);
+            if (uncompress((Bytef*)depthBuffer.data(), &decomp, (const Bytef*)rawDepth.data(), (uLong)depthSize) != Z_OK || decomp != (uLongf)(n * 2)) {
+                std::fprintf(stderr, "corrupt zlib depth in frame %d (inflates to %lu of %zu bytes)\n", currentFrame, (unsigned long)decomp, n * 2);
+                std::exit(1);   // a short stream would leave the tail of the rotating buffer holding a frame from 4 reads ago
+            }
+            if ((size_t)imageSize != n * 3 && imageSize > 0) isCompressed = true;
+        } else {
+            isCompressed = false;
+            std::memset(depthBuffer.data(), 0, n * 2);
         }
         if (ConfigArgs::get().flipColors)  // RawLogReader.cpp:118-121 (cv::cvtColor RGB2BGR)
             for (size_t i = 0; i < n; ++i) { unsigned char t = imageBuffer[i * 3]; imageBuffer[i * 3] = imageBuffer[i * 3 + 2]; imageBuffer[i * 3 + 2] = t; }
@@ -108,5 +125,5 @@ class RawLogReader : public LogReader {
     static const int kBuffers = 4;
     int flip;
     std::vector<unsigned short> depthBuffers[kBuffers];
-    std::vector<unsigned char> imageBuffers[kBuffers], scratch;
+    std::vector<unsigned char> imageBuffers[kBuffers], rawDepthBuffers[kBuffers], rawImageBuffers[kBuffers];
 };

@@ -38,29 +38,43 @@ class TrackerInterface {
             depth_device.upload(logRead->decompressedDepth, (size_t)cols * 2, rows, cols);
             colors_device.upload(logRead->decompressedImage, (size_t)cols * 3, rows, cols);
             frontend->processFrame(depth_device, colors_device, logRead->decompressedImage, logRead->decompressedDepth,
-                                   (uint64_t)logRead->timestamp, logRead->isCompressed);
+                                   (uint64_t)logRead->timestamp, logRead->isCompressed, logRead->compressedDepth, logRead->compressedDepthSize,
+                                   logRead->compressedImage, logRead->compressedImageSize);
             return true;
         }
         if (!primed) {
             primed = true;
             haveNext = logRead->grabNext(returnVal, currentFrame);
-            if (haveNext) { nextDepth = logRead->decompressedDepth; nextImage = logRead->decompressedImage; nextTime = (uint64_t)logRead->timestamp; }
+            if (haveNext) latchNext();
         }
         if (!haveNext) { finalise(); return false; }
         unsigned short* depth = nextDepth;
         unsigned char* image = nextImage;
         const uint64_t time = nextTime;
+        const bool comp = nextCompressed;
+        unsigned char *cd = nextCompDepth, *ci = nextCompImage;
+        const int cds = nextCompDepthSize, cis = nextCompImageSize;
         haveNext = logRead->grabNext(returnVal, currentFrame);   // the reader rotates its frame buffers: `depth` / `image` stay valid
         if (haveNext) {
-            nextDepth = logRead->decompressedDepth; nextImage = logRead->decompressedImage; nextTime = (uint64_t)logRead->timestamp;
+            latchNext();
             frontend->announceFrame(nextDepth, nextImage);
         }
         ++currentFrame;
-        frontend->processFrameHost(depth, image, time);
+        frontend->processFrameHost(depth, image, time, comp, cd, cds, ci, cis);   // TrackerInterface.cpp:93-102
         return true;
     }
 
   private:
+    void latchNext()
+    {
+        nextDepth = logRead->decompressedDepth; nextImage = logRead->decompressedImage; nextTime = (uint64_t)logRead->timestamp;
+        nextCompressed = logRead->isCompressed;
+        nextCompDepth = logRead->compressedDepth; nextCompDepthSize = logRead->compressedDepthSize;
+        nextCompImage = logRead->compressedImage; nextCompImageSize = logRead->compressedImageSize;
+    }
+    bool nextCompressed = false;
+    unsigned char *nextCompDepth = 0, *nextCompImage = 0;
+    int nextCompDepthSize = 0, nextCompImageSize = 0;
     LogReader* logRead;
     KintinuousTracker* frontend;
     DeviceArray2D<unsigned short> depth_device;

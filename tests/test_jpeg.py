@@ -130,7 +130,7 @@ def test_cxx_log_reader(tool, tmp_path, layout):
         assert int(ts) == wts
         assert int(cd, 16) == zlib.crc32(np.ascontiguousarray(wd, "<u2").tobytes())
         assert int(ci, 16) == zlib.crc32(np.ascontiguousarray(wrgb).tobytes())
-        assert int(comp) == int(layout != "raw")
+        assert int(comp) == int(layout.startswith("jpeg"))      # the image decides isCompressed (RawLogReader.cpp:73-97)
 
 
 def _pillow():
