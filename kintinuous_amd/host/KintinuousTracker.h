@@ -748,15 +748,14 @@ class KintinuousTracker {
 
     void clearAxis(int axis, bool back, int cur, int next)
     {
-        DeviceArray2D<short>& v = tsdf_volume_->data();
-        DeviceArray2D<uchar4>& c = color_volume_->data();
+        // the reference's call shape (KintinuousTracker.cpp:685-686): data() by value into PtrStep<short> / PtrStep<uchar4>
         switch (axis * 2 + (back ? 1 : 0)) {
-            case 0: clearVolumeX(v, cur, next); clearVolumeXc(c, cur, next); break;
-            case 1: clearVolumeXBack(v, cur, next); clearVolumeXBackc(c, cur, next); break;
-            case 2: clearVolumeY(v, cur, next); clearVolumeYc(c, cur, next); break;
-            case 3: clearVolumeYBack(v, cur, next); clearVolumeYBackc(c, cur, next); break;
-            case 4: clearVolumeZ(v, cur, next); clearVolumeZc(c, cur, next); break;
-            default: clearVolumeZBack(v, cur, next); clearVolumeZBackc(c, cur, next); break;
+            case 0: clearVolumeX(tsdf_volume_->data(), cur, next); clearVolumeXc(color_volume_->data(), cur, next); break;
+            case 1: clearVolumeXBack(tsdf_volume_->data(), cur, next); clearVolumeXBackc(color_volume_->data(), cur, next); break;
+            case 2: clearVolumeY(tsdf_volume_->data(), cur, next); clearVolumeYc(color_volume_->data(), cur, next); break;
+            case 3: clearVolumeYBack(tsdf_volume_->data(), cur, next); clearVolumeYBackc(color_volume_->data(), cur, next); break;
+            case 4: clearVolumeZ(tsdf_volume_->data(), cur, next); clearVolumeZc(color_volume_->data(), cur, next); break;
+            default: clearVolumeZBack(tsdf_volume_->data(), cur, next); clearVolumeZBackc(color_volume_->data(), cur, next); break;
         }
     }
 };

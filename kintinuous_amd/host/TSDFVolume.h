@@ -35,7 +35,7 @@ class TsdfVolume {
     void reset() { initVolume(volume_); }
 
     // TSDFVolume.cpp:135-172: returns a view of cloud_buffer holding the extracted points
-    DeviceArray<PointXYZRGB> fetchCloud(DeviceArray<PointXYZRGB>& cloud_buffer, int3& voxelWrap, DeviceArray2D<uchar4>& color_volume,
+    DeviceArray<PointXYZRGB> fetchCloud(DeviceArray<PointXYZRGB>& cloud_buffer, int3& voxelWrap, PtrStep<uchar4> color_volume,
                                         int minX, int maxX, int minY, int maxY, int minZ, int maxZ, int3 realVoxelWrap,
                                         int subsample = 1) const
     {
@@ -70,10 +70,11 @@ class ColorVolume {
         reset();
     }
     void reset() { initColorVolume(color_volume_); }
-    DeviceArray2D<uchar4>& data() { return color_volume_; }
-    const DeviceArray2D<uchar4>& data() const { return color_volume_; }
+    // ColorVolume.cpp:77-83: the volume is a DeviceArray2D<int> handed out BY VALUE (a shared handle); the operators take it as
+    // PtrStep<uchar4> through DeviceArray2D's converting operator
+    DeviceArray2D<int> data() const { return color_volume_; }
 
   private:
     int resolution_;
-    DeviceArray2D<uchar4> color_volume_;
+    DeviceArray2D<int> color_volume_;
 };

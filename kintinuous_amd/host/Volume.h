@@ -25,3 +25,7 @@ class Volume {
     const int resolution;
     float3 voxelSizeMeters;
 };
+
+namespace kt {
+inline int volSide() { return Volume::get().getResolution(); }
+}

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../../include/kt_abi.h"
+#include "kernel_containers.hpp"
 
 namespace kt {
 
@@ -75,6 +76,8 @@ class DeviceArray {
     size_t size() const { return size_; }
     size_t sizeBytes() const { return size_ * sizeof(T); }
     bool empty() const { return ptr() == nullptr; }
+    // DeviceMemory -> PtrSz<U> for any U (device_memory_impl.hpp:44-50)
+    template <class U> operator PtrSz<U>() const { return PtrSz<U>((U*)ptr(), size_ * sizeof(T) / sizeof(U)); }
 
   private:
     std::shared_ptr<void> mem_;
@@ -132,6 +135,10 @@ class DeviceArray2D {
     int rows() const { return rows_; }
     size_t step() const { return (size_t)cols_ * sizeof(T); }
     bool empty() const { return !mem_; }
+    // DeviceMemory2D -> PtrStep<U> / PtrStepSz<U> for ANY U (device_memory_impl.hpp:56-72): how the reference passes its
+    // DeviceArray2D<int> colour volume as PtrStep<uchar4> and DeviceArray2D<PixelRGB> as PtrStepSz<uchar3>
+    template <class U> operator PtrStep<U>() const { return PtrStep<U>((U*)ptr(), step()); }
+    template <class U> operator PtrStepSz<U>() const { return PtrStepSz<U>(rows_, (int)(step() / sizeof(U)), (U*)ptr(), step()); }
 
   private:
     std::shared_ptr<void> mem_;

@@ -212,6 +212,82 @@ inline size_t extractCloudSlice(const DeviceArray2D<short>& volume, const float3
     return count;
 }
 
+// ---- the same operators with the reference's own parameter lists (internal.h:349-470): PtrStep / PtrStepSz / PtrSz views, so that
+// call sites written against the reference -- tsdf_volume_->data() and color_volume_->data() returned BY VALUE, the colour volume a
+// DeviceArray2D<int> (ColorVolume.cpp:80, TSDFVolume.cpp:100, KintinuousTracker.cpp:504-521, 677-809, 864-890) -- compile as they are.
+// A view carries no size: the volume side is Volume::get().getResolution(), the reference's compile-time VOL.  Rows must be dense.
+namespace kt {
+inline int volSide();   // Volume.h (included after this header by every user of the volume operators)
+template <class T> inline T* dense(const PtrStep<T>& v, size_t row_bytes)
+{
+    if (v.step != row_bytes) { std::fprintf(stderr, "Error: view with padded rows (step %zu, row %zu)\t%s:%d\n", v.step, row_bytes, __FILE__, __LINE__); std::exit(0); }
+    return const_cast<T*>(v.data);
+}
+}  // namespace kt
+inline void initVolume(PtrStep<short> array) { const int N = kt::volSide(); ktSafeCall(kt_init_volume(KT_CTX, kt::dense(array, (size_t)N * 2), N)); }
+inline void initColorVolume(PtrStep<uchar4> array)
+{
+    const int N = kt::volSide();
+    ktSafeCall(kt_init_color_volume(KT_CTX, &kt::dense(array, (size_t)N * 4)->x, N));
+}
+#define KT_CLEAR_VIEW(NAME, AXIS, BACK)                                                                                              \
+    inline void NAME(PtrStep<short> array, const int currentVoxelWrap, const int deltaVoxelWrap)                                     \
+    {                                                                                                                                \
+        const int N = kt::volSide();                                                                                                 \
+        ktSafeCall(kt_clear_volume(KT_CTX, kt::dense(array, (size_t)N * 2), 2, N, AXIS, BACK, currentVoxelWrap, deltaVoxelWrap));    \
+    }                                                                                                                                \
+    inline void NAME##c(PtrStep<uchar4> array, const int currentVoxelWrap, const int deltaVoxelWrap)                                 \
+    {                                                                                                                                \
+        const int N = kt::volSide();                                                                                                 \
+        ktSafeCall(kt_clear_volume(KT_CTX, kt::dense(array, (size_t)N * 4), 4, N, AXIS, BACK, currentVoxelWrap, deltaVoxelWrap));    \
+    }
+KT_CLEAR_VIEW(clearVolumeX, 0, 0)
+KT_CLEAR_VIEW(clearVolumeXBack, 0, 1)
+KT_CLEAR_VIEW(clearVolumeY, 1, 0)
+KT_CLEAR_VIEW(clearVolumeYBack, 1, 1)
+KT_CLEAR_VIEW(clearVolumeZ, 2, 0)
+KT_CLEAR_VIEW(clearVolumeZBack, 2, 1)
+#undef KT_CLEAR_VIEW
+inline void integrateTsdfVolume(const PtrStepSz<unsigned short>& depth_raw, const Intr& intr, const float3& volume_size, const Mat33& Rcurr_inv,
+                                const float3& tcurr, float tranc_dist, PtrStep<short> volume, DeviceArray2D<float>& depthRawScaled,
+                                const int3& voxelWrap, PtrStep<uchar4> color_volume, PtrStepSz<uchar3> colors,
+                                const DeviceArray2D<float>& nmap_curr, bool angleColor)
+{
+    const int N = kt::volSide();
+    depthRawScaled.create(depth_raw.rows, depth_raw.cols);
+    ktSafeCall(kt_integrate_tsdf(KT_CTX, kt::dense(depth_raw, (size_t)depth_raw.cols * 2), depth_raw.cols, depth_raw.rows, kt::abi(intr),
+                                 kt::abi(volume_size), kt::abi(Rcurr_inv), kt::abi(tcurr), tranc_dist, kt::dense(volume, (size_t)N * 2),
+                                 depthRawScaled.ptr(), kt::abi(voxelWrap), &kt::dense(color_volume, (size_t)N * 4)->x,
+                                 &kt::dense(colors, (size_t)depth_raw.cols * 3)->x, nmap_curr.ptr(), angleColor ? 1 : 0, N));
+}
+inline void raycast(const Intr& intr, const Mat33& Rcurr, const float3& tcurr, float tranc_dist, const float3& volume_size,
+                    const PtrStep<short>& volume, DeviceArray2D<float>& vmap, DeviceArray2D<float>& nmap, const int3& voxelWrap,
+                    DeviceArray2D<uchar4>& vmap_curr_color, PtrStep<uchar4> color_volume)
+{
+    const int N = kt::volSide(), cols = vmap.cols(), rows = vmap.rows() / 3;
+    ktSafeCall(kt_raycast(KT_CTX, kt::abi(intr), kt::abi(Rcurr), kt::abi(tcurr), tranc_dist, kt::abi(volume_size), kt::dense(volume, (size_t)N * 2),
+                          vmap.ptr(), nmap.ptr(), cols, rows, kt::abi(voxelWrap), &vmap_curr_color.ptr()->x,
+                          &kt::dense(color_volume, (size_t)N * 4)->x, N));
+}
+inline void generateImage(const DeviceArray2D<float>& vmap, const DeviceArray2D<float>& nmap, const DeviceArray2D<uchar4>& vmap_curr_color,
+                          const LightSource& light, PtrStepSz<uchar3> dst, PtrStepSz<uchar3> dstColor)
+{
+    const int cols = vmap.cols(), rows = vmap.rows() / 3;
+    ktSafeCall(kt_generate_image(KT_CTX, vmap.ptr(), nmap.ptr(), &vmap_curr_color.ptr()->x, cols, rows, kt::abi(light.pos[0]), light.number,
+                                 &kt::dense(dst, (size_t)cols * 3)->x, &kt::dense(dstColor, (size_t)cols * 3)->x));
+}
+inline size_t extractCloudSlice(const PtrStep<short>& volume, const float3& volume_size, PtrSz<PointXYZRGB> output, int3 voxelWrap,
+                                PtrStep<uchar4>& color_volume, int minX, int maxX, int minY, int maxY, int minZ, int maxZ, int subsample,
+                                int3 realVoxelWrap)
+{
+    const int N = kt::volSide();
+    size_t count = 0;
+    ktSafeCall(kt_extract_cloud_slice(KT_CTX, kt::dense(volume, (size_t)N * 2), kt::abi(volume_size), output.data, output.size, kt::abi(voxelWrap),
+                                      &kt::dense(color_volume, (size_t)N * 4)->x, minX, maxX, minY, maxY, minZ, maxZ, subsample,
+                                      kt::abi(realVoxelWrap), N, &count));
+    return count;
+}
+
 // ---- tracking reductions ----------------------------------------------------------------------------------------
 inline void icpStep(const Mat33& Rcurr, const float3& tcurr, const DeviceArray2D<float>& vmap_curr,
                     const DeviceArray2D<float>& nmap_curr, const Mat33& Rprev_inv, const float3& tprev, const Intr& intr,
