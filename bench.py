@@ -20,6 +20,28 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """librccl prints a version banner through C stdio on stdout (at init or at its first collective); the driver reads ONE JSON line
+    from stdout.  While RCCL code runs, file descriptor 1 points at stderr, and C stdio is flushed before it is restored."""
+    import ctypes
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,14 +134,8 @@ def main():
     comm = None
     if not os.environ.get("KT_BENCH_NO_COMM"):
         try:
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)            # librccl prints a version banner on stdout at init: the driver reads ONE JSON line from it
-            try:
+            with stdout_to_stderr():
                 comm = make_comm(dist, ctx, rank, world)
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
         except Exception as e:   # no librccl on this host: the single-GPU measurement does not depend on it
             if world > 1:
                 raise
@@ -144,7 +160,8 @@ def main():
     pose_bytes = 0
     if comm is not None:
         k = min(args.steps, trk.num_poses())
-        allp = comm.gather_poses(trk, k)  # the single RCCL gather of per-stream poses, inside the timed region
+        with stdout_to_stderr():
+            allp = comm.gather_poses(trk, k)  # the single RCCL gather of per-stream poses, inside the timed region
         pose_bytes = int(allp.size * 4)
     ctx.sync()
     if dist is not None:
@@ -255,9 +272,12 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
+    os.dup2(2, 1)   # whatever the libraries still print while shutting down does not reach the driver's stdout
     if comm is not None:
         assert np.array_equal(allp[rank], np.stack([p.reshape(16) for p in timed_poses])), "the gathered poses are not this rank's"
-        comm.close()
+        with stdout_to_stderr():
+            comm.close()
     trk.close()
     ctx.close()
     if dist is not None:

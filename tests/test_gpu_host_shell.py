@@ -189,7 +189,7 @@ def test_backend_consumer_runs_against_the_shell(ctx, tmp_path):
     r = subprocess.run([exe] + args, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     head = r.stdout.splitlines()[0].split()
-    got = {head[i]: head[i + 1] for i in range(0, len(head) - 1, 2) if not head[i].isdigit()}
+    got = {k: head[head.index(k) + 1] for k in ("consumed", "finished", "first_utime", "pr", "loops", "poses", "latest", "first_frame")}
     # the same run through the C-ABI tracker.  consumer_test derives its intrinsics from the image size like MainController's default
     k = (528.0 * cam.cols / 640.0, 528.0 * cam.rows / 480.0, 320.0 * cam.cols / 640.0, 240.0 * cam.rows / 480.0)
     trk = abi.Tracker(ctx, abi.TrackerConfig(cam.cols, cam.rows, 96, k[0], k[1], k[2], k[3], 7.0, 3, 2, 0, 0, 0, 0, 0, 0, 0, 1))
