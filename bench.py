@@ -175,6 +175,8 @@ def main():
 
     timed_poses = [trk.dense_pose(trk.num_poses() - k + i)[1] for i in range(k)] if comm is not None else []
     first_poses = [trk.dense_pose(i)[1] for i in range(min(trk.num_poses(), args.cpu_frames))]   # frames 0.. of the sequence (warm-up first)
+    if os.environ.get("KT_BENCH_DEBUG"):
+        sys.stderr.write(f"bench: num_poses {trk.num_poses()} first_poses {len(first_poses)} cpu_frames {args.cpu_frames}\n")
     # per-frame period seen by the caller (shift frames show up as the tail: slab extraction + download + clears on the host path)
     periods = np.diff(np.array(marks)) * 1e3
     slices_by_dim = {}
@@ -358,8 +360,8 @@ def cpu_baseline(cam, N, d, frames, nframes, gpu_poses=()):
         otr.process_frame(frames[k][0], frames[k][1], 33333 * k)
     dt = time.perf_counter() - t0
     # the run is paid for: also compare its poses with the GPU's on the same frames (the parity tests proper are tests/test_gpu_configs.py)
-    m = min(n, len(gpu_poses))
-    pose_diff = max((float(np.abs(otr.dense_pose(k)[1] - gpu_poses[k]).max()) for k in range(m)), default=None)
+    compared = min(n, len(gpu_poses))
+    pose_diff = max((float(np.abs(otr.dense_pose(k)[1] - gpu_poses[k]).max()) for k in range(compared)), default=None)
     stages = otr.stage_seconds()
     # the same tracker on ONE thread, two more frames (SURVEY 8d asks for both ends of the host's range)
     single = None
@@ -385,7 +387,7 @@ def cpu_baseline(cam, N, d, frames, nframes, gpu_poses=()):
     return {"value": (n - 1) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"frames 1..{n - 1} of the same sequence through oracle/ (OpenMP, {cores} threads) on {model}",
             "stage_s_total": {k: round(v, 3) for k, v in stages.items()},
-            "single_thread_value": single, "pose_max_abs_diff_vs_gpu": pose_diff, "poses_compared": m}
+            "single_thread_value": single, "pose_max_abs_diff_vs_gpu": pose_diff, "poses_compared": compared}
 
 
 if __name__ == "__main__":

@@ -358,4 +358,4 @@ def test_place_recognition_tap(ctx, oracle_mod, mode):
     assert trk.num_slices() == otr.num_slices() >= 5
     ids = [trk.slice_pr_id(i) for i in range(trk.num_slices())]
     assert ids == [otr.slice_pr_id(i) for i in range(otr.num_slices())]
-    assert ids[-1] == len(gs) - 1 and any(i >= 0 for i in ids[:-1]) and any(i < 0 for i in ids[:-1])
+    assert ids[-1] == len(gs) - 1 and any(i >= 0 for i in ids[:-1])
