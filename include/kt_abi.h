@@ -53,6 +53,14 @@ typedef struct {                                    /* PointXYZRGB, internal.h:1
     uint8_t b, g, r, a;
     uint32_t pad1[3];
 } kt_point_xyzrgb;
+/* internal.h:186-229 == pcl::PointXYZRGBNormal (48 bytes): what CloudSliceProcessor fills CloudSlice::processedCloud with */
+typedef struct {
+    float x, y, z, pad0;                    /* data[3] = 1 */
+    float normal_x, normal_y, normal_z, pad1;
+    uint8_t b, g, r, a;
+    float curvature;
+    float pad2[2];
+} kt_point_xyzrgbnormal;
 
 /* ---- context / memory: replaces containers/device_memory.cpp, initialization.cpp, cudaSetDevice ---- */
 const char* kt_last_error(void);
@@ -267,6 +275,14 @@ int kt_debug_stream(kt_ctx* ctx, void* buf, size_t bytes, int elem_size, int rmw
 int kt_debug_unpack_table(kt_ctx* ctx, float* out_host65536);
 /* test hook: number of floats d, 2^-20 <= |d| <= 2^20, for which the voxel kernel's unwrapped reciprocal chain differs from 1.0f / d */
 int kt_debug_rcp_check(kt_ctx* ctx, unsigned int* mismatches_host);
+
+/* The per-slice stage of the backend's CloudSliceProcessor (backend/CloudSliceProcessor.cpp:87-163), the consumer right behind every
+ * volume shift: keep points with alpha >= weight_cull (if weight_cull > 0; ConfigArgs::weightCull), pcl::VoxelGrid down-sampling at
+ * `leaf` (the voxel size, :124-130), pcl::NormalEstimation with the k (= 20, :148) nearest neighbours, normals flipped towards the sensor
+ * origin, output pcl::PointXYZRGBNormal in leaf order.  points_host / out_host are host arrays (a CloudSlice's cloud / processedCloud);
+ * out_host needs room for n points; *n_out receives the count. */
+int kt_slice_process(kt_ctx* ctx, const kt_point_xyzrgb* points_host, size_t n, int weight_cull, float leaf, int k,
+                     kt_point_xyzrgbnormal* out_host, size_t* n_out);
 
 /* Place-recognition tap (KintinuousTracker::addToPlaceRecognition, KintinuousTracker.cpp:917-958): the frames sampled for the
  * loop-closure backend, in order.  The library keeps the sample's metadata (PlaceRecognitionInput::utime / trans / rotation and the

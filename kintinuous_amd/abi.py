@@ -137,6 +137,7 @@ _PROTOS = {
     "kt_tracker_pr_sample": (_i, [_vp, _i, C.POINTER(_u64), _pf, _pf, C.POINTER(C.c_int)]),
     "kt_tracker_slice_pr_id": (_i, [_vp, _i, C.POINTER(C.c_int)]),
     "kt_host_place_recognition_movement": (_f, [_pf, _pf, _pf, _pf]),
+    "kt_slice_process": (_i, [_vp, _vp, _sz, _i, _f, _i, _vp, C.POINTER(_sz)]),
     "kt_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
     "kt_comm_init": (_i, [_vp, _i, _i, C.POINTER(C.c_ubyte), C.POINTER(_vp)]),
     "kt_pose_gather": (_i, [_vp, _vp, _i, _pf]),
@@ -564,6 +565,22 @@ def host_pose_update(x, result_rt, Rprev, tprev):
     _chk(lib().kt_host_pose_update(_dp(x), _dp(rt), Rp.ctypes.data_as(_pf), tp.ctypes.data_as(_pf),
                                    Rc.ctypes.data_as(_pf), tc.ctypes.data_as(_pf)))
     return rt.reshape(4, 4), Rc.reshape(3, 3), tc
+
+
+NPOINT_DTYPE = np.dtype([("xyz", np.float32, 3), ("one", np.float32), ("normal", np.float32, 3), ("zero", np.float32), ("bgra", np.uint8, 4),
+                         ("curvature", np.float32), ("pad", np.float32, 2)])
+assert NPOINT_DTYPE.itemsize == 48
+
+
+def slice_process(ctx: "Ctx", points: np.ndarray, weight_cull: int, leaf: float, k: int = 20) -> np.ndarray:
+    """kt_slice_process: CloudSliceProcessor's per-slice stage on a host array of extracted points -> pcl::PointXYZRGBNormal records."""
+    points = np.ascontiguousarray(points)
+    assert points.dtype == POINT_DTYPE
+    out = np.zeros(max(len(points), 1), NPOINT_DTYPE)
+    n = C.c_size_t(0)
+    _chk(lib().kt_slice_process(ctx.h, points.ctypes.data_as(C.c_void_p), len(points), int(weight_cull), float(leaf), int(k),
+                                out.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return out[: n.value]
 
 
 class Comm:

@@ -41,7 +41,7 @@ class ConfigArgs {
     }
 
     std::string calibrationFile, logFile, trajectoryFile, saveFile, vocabFile;
-    int gpu, voxelShift, volumeResolution, width, height, totalNumFrames;
+    int gpu, voxelShift, volumeResolution, width, height, totalNumFrames, weightCull;
     float volumeSize;
     bool staticMode, dynamicCube, flipColors, extractOverlap, useRGBD, useRGBDICP, disableColorAngleWeight, fastOdometry, help;
 
@@ -60,7 +60,7 @@ class ConfigArgs {
     }
 
     ConfigArgs(int argc, char** argv)
-        : gpu(0), voxelShift(14), volumeResolution(512), width(640), height(480), totalNumFrames(0), volumeSize(6.0f)
+        : gpu(0), voxelShift(14), volumeResolution(512), width(640), height(480), totalNumFrames(0), weightCull(8), volumeSize(6.0f)
     {
         const char* v;
         if ((v = value(argc, argv, "-c"))) calibrationFile = v;
@@ -74,6 +74,7 @@ class ConfigArgs {
         if ((v = value(argc, argv, "-h"))) height = std::atoi(v);
         if ((v = value(argc, argv, "-s"))) volumeSize = (float)std::atof(v);
         if ((v = value(argc, argv, "-fl"))) totalNumFrames = std::atoi(v);
+        if ((v = value(argc, argv, "-cw"))) weightCull = std::atoi(v);   // ConfigArgs.h:118 (default 8)
         staticMode = flag(argc, argv, "-sm");
         dynamicCube = flag(argc, argv, "-d");
         flipColors = flag(argc, argv, "-f");

@@ -20,6 +20,14 @@ struct ThreadDataPack {   // backend/ThreadDataPack.h: only what the cloud slice
     ThreadDataPack() : tracker(0), latestPoseId(0), cloudSliceProcessorFinished(false), trackerFinished(false) {}
 };
 
+// the backend thread's own context (its own stream): kt_ctx is not shared between threads
+static kt_ctx* consumerContext()
+{
+    static kt_ctx* ctx = 0;
+    if (!ctx) ktSafeCall(kt_ctx_create(ConfigArgs::get().gpu, &ctx));
+    return ctx;
+}
+
 static bool processOnce(ThreadDataPack& threadPack, int& latestPushedCloud, ThreadMutexObject<uint64_t>& lagTime)
 {
     std::unique_lock<std::mutex> lock(threadPack.tracker->cloudMutex);
@@ -45,11 +53,17 @@ static bool processOnce(ThreadDataPack& threadPack, int& latestPushedCloud, Thre
     if (cycledMutex || latestPushedCloud < numClouds) {
         while (latestPushedCloud < numClouds) {
             CloudSlice* s = trackerSlices->at(latestPushedCloud);
-            s->processedCloud = new CloudSlice::PointCloudNormal(s->cloud->size());   // (weight cull, voxel grid, normals: kt_slice_process)
-            for (size_t i = 0; i < s->cloud->size(); ++i) {
-                (*s->processedCloud)[i].x = (*s->cloud)[i].x; (*s->processedCloud)[i].y = (*s->cloud)[i].y; (*s->processedCloud)[i].z = (*s->cloud)[i].z;
-                (*s->processedCloud)[i].rgba = *reinterpret_cast<const int*>(&(*s->cloud)[i].b);
+            // CloudSliceProcessor.cpp:87-163: weight cull, voxel grid at the voxel leaf size, kNN(20) normals -- one call on the GPU
+            s->processedCloud = new CloudSlice::PointCloudNormal(s->cloud->size());
+            size_t np = 0;
+            if (s->cloud->size()) {
+                const float3& vs = Volume::get().getVoxelSizeMeters();
+                const float leafSize = std::max(vs.x, std::max(vs.y, vs.z));
+                static_assert(sizeof(PointXYZRGBNormal) == sizeof(kt_point_xyzrgbnormal), "processedCloud layout");
+                ktSafeCall(kt_slice_process(consumerContext(), s->cloud->data(), s->cloud->size(), ConfigArgs::get().weightCull, leafSize, 20,
+                                            reinterpret_cast<kt_point_xyzrgbnormal*>(s->processedCloud->data()), &np));
             }
+            s->processedCloud->resize(np);
             threadPack.cloudSlices.push_back(s);
             threadPack.latestPoseId.assignAndNotifyAll((int)threadPack.cloudSlices.size());
             latestPushedCloud++;

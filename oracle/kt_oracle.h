@@ -109,6 +109,9 @@ size_t kto_extract_cloud_slice(const int16_t* volume, const float volume_size[3]
                                int minX, int maxX, int minY, int maxY, int minZ, int maxZ, int subsample,
                                const int real_voxel_wrap[3], int N);
 
+/* ---- f2: the per-slice stage of CloudSliceProcessor (weight cull, VoxelGrid, kNN normals); out48 = 12 floats per point ---- */
+size_t kto_slice_process(const kto_point* in, size_t n, int weight_cull, float leaf, int k, float* out48);
+
 /* ---- a7 / a10 host math ---- */
 void kto_mat33_inverse(const kto_mat33* in, kto_mat33* out);            /* Eigen Matrix3f::inverse() (cofactor) */
 void kto_ldlt_solve6(const double A[36], const double b[6], double x[6]); /* Eigen LDLT (pivoted) solve */

@@ -1098,3 +1098,192 @@ size_t kto_extract_cloud_slice(const int16_t* volume, const float volume_size[3]
             }
     return count < out_cap ? count : out_cap;
 }
+
+/* ================================================================================================
+ * f2  CloudSliceProcessor::process, the per-slice stage      backend/CloudSliceProcessor.cpp:87-163
+ *   weight cull -> pcl::VoxelGrid<PointXYZRGB> (leaf = voxel size) -> pcl::NormalEstimation (kNN 20) -> PointXYZRGBNormal
+ * PCL 1.7 (README.md:14-31) is not vendored with the reference and not installed here: this restates its published
+ * algorithms -- filters/impl/voxel_grid.hpp (applyFilter), common/impl/centroid.hpp (computeMeanAndCovarianceMatrix, float
+ * single-pass form), features/normal_3d.h (solvePlaneParameters, flipNormalTowardsViewpoint with the default sensor origin 0),
+ * common/impl/eigen.hpp (computeRoots, eigen33) -- in float without contraction (the reference builds host code with -msse3).
+ * PARITY UNPINNED against PCL itself.  Two orders PCL leaves to its implementation are FIXED here and in the HIP stage:
+ *   - VoxelGrid sorts (leaf index, point) pairs with std::sort, which is not stable: here the points of a leaf are summed in
+ *     their original order;
+ *   - FLANN breaks distance ties arbitrarily: here neighbours are ordered by (squared distance, index).
+ * ============================================================================================== */
+typedef struct { unsigned key; unsigned src; } sp_pair;
+static int sp_pair_cmp(const void* a, const void* b)
+{
+    const sp_pair *x = a, *y = b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->src < y->src ? -1 : (x->src > y->src);
+}
+static void sp_compute_roots2(float b, float c, float r[3])
+{
+    r[0] = 0.f;
+    float d = b * b - 4.0f * c;
+    if (d < 0.0f) d = 0.0f;
+    const float sd = sqrtf(d);
+    r[2] = 0.5f * (b + sd);
+    r[1] = 0.5f * (b - sd);
+}
+static void sp_compute_roots(const float m[9], float r[3])
+{
+    const float c0 = m[0] * m[4] * m[8] + 2.0f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
+    const float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+    const float c2 = m[0] + m[4] + m[8];
+    if (fabsf(c0) < 1.1920929e-07f) { sp_compute_roots2(c2, c1, r); return; }
+    const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = sqrtf(3.0f);
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.0f) q = 0.0f;
+    const float rho = sqrtf(-a_over_3);
+    const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+    const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+    r[0] = c2_over_3 + 2.0f * rho * cos_theta;
+    r[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    r[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    float t;
+    if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+    if (r[1] >= r[2]) {
+        t = r[1]; r[1] = r[2]; r[2] = t;
+        if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+    }
+    if (r[0] <= 0.0f) sp_compute_roots2(c2, c1, r);
+}
+/* pcl::eigen33(mat, eigenvalue, eigenvector): smallest eigenvalue and its eigenvector */
+static void sp_eigen33(const float mat[9], float* eigenvalue, float v[3])
+{
+    float scale = 0.0f;
+    for (int i = 0; i < 9; ++i) scale = fmaxf(scale, fabsf(mat[i]));
+    if (scale <= 1.17549435e-38f) scale = 1.0f;
+    float s[9], roots[3];
+    for (int i = 0; i < 9; ++i) s[i] = mat[i] / scale;
+    sp_compute_roots(s, roots);
+    *eigenvalue = roots[0] * scale;
+    s[0] -= roots[0]; s[4] -= roots[0]; s[8] -= roots[0];
+    const float *r0 = &s[0], *r1 = &s[3], *r2 = &s[6];
+    const float v1[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    const float v2[3] = {r0[1] * r2[2] - r0[2] * r2[1], r0[2] * r2[0] - r0[0] * r2[2], r0[0] * r2[1] - r0[1] * r2[0]};
+    const float v3[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    const float l1 = (v1[0] * v1[0] + v1[1] * v1[1]) + v1[2] * v1[2], l2 = (v2[0] * v2[0] + v2[1] * v2[1]) + v2[2] * v2[2],
+                l3 = (v3[0] * v3[0] + v3[1] * v3[1]) + v3[2] * v3[2];
+    const float* w = v3;
+    float len = l3;
+    if (l1 >= l2 && l1 >= l3) { w = v1; len = l1; }
+    else if (l2 >= l1 && l2 >= l3) { w = v2; len = l2; }
+    const float sl = sqrtf(len);
+    v[0] = w[0] / sl; v[1] = w[1] / sl; v[2] = w[2] / sl;
+}
+
+/* in: n points (32 B, kto_point); out: up to n points of 48 B {x y z 1 | nx ny nz 0 | b g r a, curvature, 0, 0}.  Returns the count. */
+size_t kto_slice_process(const kto_point* in, size_t n, int weight_cull, float leaf, int k, float* out48)
+{
+    kto_point* pts = malloc((n ? n : 1) * sizeof(kto_point));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) /* CloudSliceProcessor.cpp:99-117 */
+        if (!(weight_cull > 0) || in[i].a >= weight_cull) pts[m++] = in[i];
+    if (m == 0) { free(pts); return 0; }
+    /* ---- VoxelGrid::applyFilter ---- */
+    const float inv_leaf = 1.0f / leaf;
+    float mn[3] = {pts[0].x, pts[0].y, pts[0].z}, mx[3] = {pts[0].x, pts[0].y, pts[0].z};
+    for (size_t i = 1; i < m; ++i) {
+        const float p[3] = {pts[i].x, pts[i].y, pts[i].z};
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], p[a]); mx[a] = fmaxf(mx[a], p[a]); }
+    }
+    int min_b[3], max_b[3], div_b[3];
+    for (int a = 0; a < 3; ++a) {
+        min_b[a] = (int)floorf(mn[a] * inv_leaf);
+        max_b[a] = (int)floorf(mx[a] * inv_leaf);
+        div_b[a] = max_b[a] - min_b[a] + 1;
+    }
+    size_t nout = 0;
+    float* cen = NULL;        /* per leaf: x y z r g b */
+    int* cell = NULL;         /* per leaf: i j k */
+    const long long cells = (long long)div_b[0] * div_b[1] * div_b[2];
+    if (cells > 2147483647LL) { /* "Leaf size is too small for the input dataset": the cloud passes through unfiltered */
+        cen = malloc(m * 6 * sizeof(float)); cell = malloc(m * 3 * sizeof(int));
+        for (size_t i = 0; i < m; ++i) {
+            cen[6 * i] = pts[i].x; cen[6 * i + 1] = pts[i].y; cen[6 * i + 2] = pts[i].z;
+            cen[6 * i + 3] = pts[i].r; cen[6 * i + 4] = pts[i].g; cen[6 * i + 5] = pts[i].b;
+            cell[3 * i] = cell[3 * i + 1] = cell[3 * i + 2] = 0;
+        }
+        nout = m;
+    } else {
+        sp_pair* pr = malloc(m * sizeof(sp_pair));
+        for (size_t i = 0; i < m; ++i) {
+            const int i0 = (int)(floorf(pts[i].x * inv_leaf) - (float)min_b[0]), i1 = (int)(floorf(pts[i].y * inv_leaf) - (float)min_b[1]),
+                      i2 = (int)(floorf(pts[i].z * inv_leaf) - (float)min_b[2]);
+            pr[i].key = (unsigned)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]);
+            pr[i].src = (unsigned)i;
+        }
+        qsort(pr, m, sizeof(sp_pair), sp_pair_cmp);
+        cen = malloc(m * 6 * sizeof(float)); cell = malloc(m * 3 * sizeof(int));
+        size_t i = 0;
+        while (i < m) {
+            size_t j = i;
+            float acc[6] = {0, 0, 0, 0, 0, 0};
+            while (j < m && pr[j].key == pr[i].key) {
+                const kto_point* p = &pts[pr[j].src];
+                acc[0] += p->x; acc[1] += p->y; acc[2] += p->z; acc[3] += (float)p->r; acc[4] += (float)p->g; acc[5] += (float)p->b;
+                ++j;
+            }
+            const float cnt = (float)(j - i);
+            for (int a = 0; a < 6; ++a) cen[6 * nout + a] = acc[a] / cnt;
+            const unsigned key = pr[i].key;
+            cell[3 * nout] = (int)(key % (unsigned)div_b[0]);
+            cell[3 * nout + 1] = (int)((key / (unsigned)div_b[0]) % (unsigned)div_b[1]);
+            cell[3 * nout + 2] = (int)(key / ((unsigned)div_b[0] * (unsigned)div_b[1]));
+            ++nout;
+            i = j;
+        }
+        free(pr);
+    }
+    /* ---- NormalEstimation::computeFeature ---- */
+    const int kk = (size_t)k < nout ? k : (int)nout;
+#pragma omp parallel for schedule(static)
+    for (long long q = 0; q < (long long)nout; ++q) {
+        const float px = cen[6 * q], py = cen[6 * q + 1], pz = cen[6 * q + 2];
+        float bd[64]; int bi[64]; int cnt = 0;     /* the k nearest so far, ascending (distance, index) */
+        for (size_t j = 0; j < nout; ++j) {
+            const float dx = cen[6 * j] - px, dy = cen[6 * j + 1] - py, dz = cen[6 * j + 2] - pz;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            if (cnt == kk && !(d < bd[cnt - 1])) continue;        /* an equal distance with a larger index never displaces */
+            int pos = cnt < kk ? cnt : kk - 1;
+            while (pos > 0 && d < bd[pos - 1]) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; --pos; }
+            bd[pos] = d; bi[pos] = (int)j;
+            if (cnt < kk) ++cnt;
+        }
+        float* o = &out48[12 * q];
+        o[0] = px; o[1] = py; o[2] = pz; o[3] = 1.0f;
+        o[7] = 0.0f; o[10] = 0.0f; o[11] = 0.0f;
+        /* VoxelGrid: r, g, b = (uint8) of the float means, packed into rgb with a zero alpha byte */
+        unsigned char* c = (unsigned char*)&o[8];
+        c[0] = (unsigned char)cen[6 * q + 5]; c[1] = (unsigned char)cen[6 * q + 4]; c[2] = (unsigned char)cen[6 * q + 3]; c[3] = 0;
+        if (cnt < 3) { o[4] = o[5] = o[6] = o[9] = NAN; continue; }
+        float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < cnt; ++t) {
+            const float x = cen[6 * bi[t]], y = cen[6 * bi[t] + 1], z = cen[6 * bi[t] + 2];
+            acc[0] += x * x; acc[1] += x * y; acc[2] += x * z; acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
+            acc[6] += x; acc[7] += y; acc[8] += z;
+        }
+        for (int a = 0; a < 9; ++a) acc[a] /= (float)cnt;
+        float cov[9];
+        cov[0] = acc[0] - acc[6] * acc[6]; cov[1] = acc[1] - acc[6] * acc[7]; cov[2] = acc[2] - acc[6] * acc[8];
+        cov[4] = acc[3] - acc[7] * acc[7]; cov[5] = acc[4] - acc[7] * acc[8]; cov[8] = acc[5] - acc[8] * acc[8];
+        cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+        float ev, nv[3];
+        sp_eigen33(cov, &ev, nv);
+        const float eig_sum = cov[0] + cov[4] + cov[8];
+        o[9] = eig_sum != 0 ? fabsf(ev / eig_sum) : 0;
+        /* flipNormalTowardsViewpoint, viewpoint = sensor origin (0, 0, 0) */
+        const float cos_theta = ((0.0f - px) * nv[0] + (0.0f - py) * nv[1]) + (0.0f - pz) * nv[2];
+        if (cos_theta < 0) { nv[0] *= -1; nv[1] *= -1; nv[2] *= -1; }
+        o[4] = nv[0]; o[5] = nv[1]; o[6] = nv[2];
+    }
+    free(cen); free(cell); free(pts);
+    return nout;
+}

@@ -298,6 +298,20 @@ def extract_cloud_slice(volume, volume_size, cap, voxel_wrap, color_volume, minX
     return out[: int(n)]
 
 
+NPOINT_DTYPE = np.dtype([("xyz", np.float32, 3), ("one", np.float32), ("normal", np.float32, 3), ("zero", np.float32), ("bgra", np.uint8, 4),
+                         ("curvature", np.float32), ("pad", np.float32, 2)])
+
+
+def slice_process(points, weight_cull: int, leaf: float, k: int = 20) -> np.ndarray:
+    """CloudSliceProcessor's per-slice stage (weight cull, VoxelGrid at `leaf`, kNN(k) normals) -> pcl::PointXYZRGBNormal records."""
+    points = np.ascontiguousarray(points)
+    assert points.dtype == POINT_DTYPE
+    out = np.zeros(max(len(points), 1), NPOINT_DTYPE)
+    lib().kto_slice_process.restype = C.c_size_t
+    n = lib().kto_slice_process(_p(points), C.c_size_t(len(points)), int(weight_cull), C.c_float(leaf), int(k), _p(out))
+    return out[: int(n)]
+
+
 # ---- host math -------------------------------------------------------------------------------------
 def mat33_inverse(R) -> np.ndarray:
     o = OMat33()

@@ -185,7 +185,7 @@ def test_backend_consumer_runs_against_the_shell(ctx, tmp_path):
     log, calib = _make_log(tmp_path, cam, frames)
     exe = os.path.join(ROOT, "kintinuous_amd", "host", "bin", "consumer_test")
     assert os.path.exists(exe)
-    args = ["-l", log, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "7", "-t", "3", "-v", "vocab.yml.gz"]
+    args = ["-l", log, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "7", "-t", "3", "-v", "vocab.yml.gz", "-cw", "2"]
     r = subprocess.run([exe] + args, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     head = r.stdout.splitlines()[0].split()
@@ -209,5 +209,8 @@ def test_backend_consumer_runs_against_the_shell(ctx, tmp_path):
     assert len(lines) == nslices
     for i, l in enumerate(lines):
         n, dim = trk.slice_info(i)
-        assert int(l[3]) == dim and int(l[5]) == n == int(l[7]) and int(l[9]) == trk.slice_pr_id(i)
+        assert int(l[3]) == dim and int(l[5]) == n and int(l[9]) == trk.slice_pr_id(i)
+        # processedCloud = kt_slice_process(cloud): exactly what the Python binding computes from the same slice
+        assert int(l[7]) == len(abi.slice_process(ctx, trk.slice(i)[0], 2, 7.0 / 96))
+        assert (int(l[7]) > 0) == (n > 0) or int(l[7]) == 0
     trk.close()
