@@ -61,24 +61,24 @@ def test_oracle_known_answers(oracle_mod):
 def _real_slices(ctx):
     """Slices as the tracker extracts them: a crab-walk with shifts (shift slabs) plus the final full-volume cloud."""
     from kintinuous_amd import abi, synth
-    cam = synth.Camera.small(160, 120)
+    cam = synth.Camera.small(320, 240)
     scene = synth.Scene("wall")
     traj = synth.crabwalk_trajectory(420)
-    frames = [synth.render(scene, cam, *traj[i]) for i in range(40)]
-    trk = abi.Tracker(ctx, abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 7.0, 3, 2, 0, 0, 0, 0, 0, 0))
+    frames = [synth.render(scene, cam, *traj[i]) for i in range(60)]
+    trk = abi.Tracker(ctx, abi.TrackerConfig(cam.cols, cam.rows, 160, cam.fx, cam.fy, cam.cx, cam.cy, 7.0, 6, 2, 0, 0, 0, 0, 0, 0))
     for k, (d, rgb) in enumerate(frames):
         trk.process_frame_host(d, rgb, 33333 * k)
     trk.finalise()
     slices = [trk.slice(i)[0] for i in range(trk.num_slices())]
     trk.close()
-    return slices, 7.0 / 96
+    return slices, 7.0 / 160
 
 
 @pytest.mark.gpu
 def test_gpu_matches_oracle_on_extracted_slices(ctx, oracle_mod):
     from kintinuous_amd import abi
     slices, leaf = _real_slices(ctx)
-    assert len(slices) >= 4 and max(len(s) for s in slices) > 5000
+    assert len(slices) >= 3 and max(len(s) for s in slices) > 3000, [len(s) for s in slices]
     checked = 0
     for s in slices:
         if len(s) == 0:
@@ -97,7 +97,7 @@ def test_gpu_matches_oracle_on_extracted_slices(ctx, oracle_mod):
             assert np.abs(got["normal"][ok] - want["normal"][ok]).max() < 1e-4
             assert np.abs(got["curvature"][ok] - want["curvature"][ok]).max() < 1e-4
             checked += int(ok.sum())
-    assert checked > 10000
+    assert checked > 4000
 
 
 @pytest.mark.gpu
