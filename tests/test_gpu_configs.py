@@ -205,3 +205,58 @@ def test_ground_truth_mode_with_a_lagging_gpu(ctx, oracle_mod):
         assert a[0] == b[0] and np.array_equal(a[1], b[1])
     _volume_close(trk, otr)
     trk.close(); otr.close()
+
+
+def test_integrate_pointer_path(ctx, oracle_mod, small_scene, monkeypatch):
+    """tsdf23's pointer-addressed variant (kt_tsdf23_kernel<*, false>: volumes beyond the 32-bit byte offsets of a buffer descriptor,
+    N >= 1024) forced at a small N: accumulated frames, wrapped storage, against the oracle."""
+    from hip_kernels import HipKernels
+    from oracle.oracle import OIntr
+    monkeypatch.setenv("KT_TSDF_POINTERS", "1")
+    cam, frames, traj = small_scene
+    O, H = oracle_mod, HipKernels(ctx)
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    N, size, wrap = 96, 6.0, [5, 90, 41]
+    trunc = max(0.06, 2.1 * size / N)
+    vo, co = np.zeros((N, N, N), np.int16), np.zeros((N, N, N, 4), np.uint8)
+    vh, ch = vo.copy(), co.copy()
+    for k in range(3):
+        d, c = frames[k]
+        n = O.create_nmap(O.create_vmap(intr, O.bilateral_filter(d)))
+        Rk = np.asarray(traj[k][0], np.float32)
+        tk = (np.asarray(traj[k][1], np.float32) + 3).astype(np.float32)
+        Rinv = O.mat33_inverse(Rk)
+        O.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vo, wrap, co, c, n, True)
+        H.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vh, wrap, ch, c, n, True)
+        assert np.array_equal(vo, vh) and np.array_equal(co, ch), k
+
+
+def test_integrate_1024_cubed(ctx, oracle_mod):
+    """The same variant where it is needed: one 640x480 frame into a 1024^3 volume (2 GiB of tsdf, 4 GiB of colour), voxel indices past
+    2^30, against the oracle.  Needs ~14 GB of host memory for the two copies."""
+    import psutil
+    if psutil.virtual_memory().available < 24e9:
+        pytest.skip("not enough host memory for two 1024^3 volume pairs")
+    from hip_kernels import HipKernels
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr
+    O, H = oracle_mod, HipKernels(ctx)
+    cam = synth.Camera()
+    d, c = synth.render(synth.Scene("room"), cam, *synth.orbit_trajectory(2)[0])
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    n = O.create_nmap(O.create_vmap(intr, O.bilateral_filter(d)))
+    N, size, wrap = 1024, 6.0, [1000, 3, 517]
+    trunc = max(0.06, 2.1 * size / N)
+    vo, co = np.zeros((N, N, N), np.int16), np.zeros((N, N, N, 4), np.uint8)
+    U, _ = O.integrate_tsdf(d, intr, [size] * 3, np.eye(3), [3, 3, 3], trunc, vo, wrap, co, c, n, True)
+    assert U > 2e7
+    dv, dc = ctx.zeros(N ** 3 * 2), ctx.zeros(N ** 3 * 4)
+    sc = ctx.zeros(cam.rows * cam.cols * 4)
+    ctx.integrate_tsdf(ctx.upload(d), cam.cols, cam.rows, H._intr(intr), [size] * 3, np.eye(3), [3, 3, 3], trunc, dv, sc, wrap, dc, ctx.upload(c),
+                       ctx.upload(n), True, N)
+    ctx.sync()
+    vh = ctx.download(dv, np.int16, (N, N, N))
+    assert np.array_equal(vo, vh)
+    del vh, vo
+    chh = ctx.download(dc, np.uint8, (N, N, N, 4))
+    assert np.array_equal(co, chh)
