@@ -114,7 +114,7 @@ struct kt_tsdf23_args {
     const float* zs;
     const unsigned int* interval;  // per storage column: z0 | z1 << 16 (kt_tsdf_interval_kernel)
     const unsigned int* tasks;     // compact list of (wave-column, z-chunk) units that contain work (kt_tsdf_tasks_kernel)
-    unsigned int* task_count;      // [0] number of tasks, [1..8] per-XCD cursors
+    const unsigned int* task_count;
     const unsigned int* wrange;    // per wave-column: union of its 64 column intervals, z0 | z1 << 16
     const float2* walk0;           // per column: (v_x, v_y) of the reference walk at z = the wave-column's first z
     const float* dpmax;            // [ceil(rows / 32)][ceil(cols / 32)] largest |scaled depth| per pixel tile (kt_tile_max_kernel), or null
@@ -364,7 +364,6 @@ __global__ __launch_bounds__(1024) void kt_tsdf_tasks_kernel(const unsigned int*
                 if (c >= c0[k] && c <= c1[k]) tasks[pos++] = key[k] | ((unsigned int)c << 24);
     }
     if (tid == 0) *task_count = total;
-    if (tid < 8) task_count[1 + tid] = 0;   // per-XCD cursors of the voxel kernel's dynamic task hand-out
 }
 
 // One in-flight batch of KT_TSDF_UNROLL consecutive z steps of a wave: everything phase A produces for phase B.
@@ -571,17 +570,7 @@ __global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_ts
     // consecutive tasks (neighbouring chunks of one wave-column) go to the 4 waves of one workgroup.
     const unsigned int per_xcd = (n_tasks + 7u) / 8u;
     const unsigned int t_begin = (blockIdx.x & 7u) * per_xcd, t_end = min(t_begin + per_xcd, n_tasks);
-#ifdef KT_TSDF_DYNAMIC
-    // tasks differ in length (lanes in the image, depth of the band): the waves of an XCD draw from a shared cursor instead of
-    // striding, so a wave that drew short tasks takes more of them
-    for (;;) {
-        unsigned int k = 0;
-        if (lane == 0) k = atomicAdd(&a.task_count[1 + (blockIdx.x & 7u)], 1u);
-        const unsigned int t = t_begin + (unsigned int)__builtin_amdgcn_readfirstlane((int)k);
-        if (t >= t_end) break;
-#else
     for (unsigned int t = t_begin + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); t < t_end; t += (gridDim.x >> 3) * 4u) {
-#endif
         const unsigned int task = __builtin_amdgcn_readfirstlane(a.tasks[t]);
         const int yg = (int)(task & 0xffffu), xg = (int)((task >> 16) & 0xffu), chunk = (int)(task >> 24);
         const int sx = xg * KT_WX + (lane & (KT_WX - 1));
@@ -694,7 +683,7 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
         KT_HIP(hipMalloc((void**)&s.wrange, sizeof(unsigned int) * wave_cols));
         KT_HIP(hipMalloc((void**)&s.walk0, sizeof(float2) * (size_t)N * N));
         KT_HIP(hipMalloc((void**)&s.tasks, sizeof(unsigned int) * wave_cols * kt_div_up(N, KT_TSDF_ZCHUNK)));
-        KT_HIP(hipMalloc((void**)&s.task_count, 16 * sizeof(unsigned int)));
+        KT_HIP(hipMalloc((void**)&s.task_count, sizeof(unsigned int)));
         KT_HIP(hipMalloc((void**)&s.vgz, sizeof(float) * 2 * N));
         s.zs = s.vgz + N;
         for (int k = 0; k < 2; ++k) {
