@@ -4,9 +4,9 @@
 // 15.04 (README.md:14-31), which is libjpeg-turbo with the library defaults: dct_method = JDCT_ISLOW, do_fancy_upsampling = TRUE,
 // out_color_space = JCS_RGB, then OpenCV's RGB -> BGR swap.  Neither library is in this image, so this is a restatement of those
 // published algorithms (IJG libjpeg 6b / libjpeg-turbo: jidctint.c "slow-but-accurate integer IDCT", jdsample.c "fancy" triangle
-// upsampling for 2h1v and 2h2v, jdcolor.c fixed-point YCbCr -> RGB), written to give the same bytes.  PARITY UNPINNED: there is no
-// libjpeg here to compare against; tests/test_jpeg.py checks it against an independent numpy restatement of the same integer
-// algorithms (bit-exact) and against a floating-point decode (within 2 grey levels).
+// upsampling for 2h1v and 2h2v, jdcolor.c fixed-point YCbCr -> RGB), written to give the same bytes.  Pinned: tests/test_jpeg.py
+// compares it byte for byte with libjpeg-turbo itself (through Pillow, which bundles it) on 4:4:4 / 4:2:2 / 4:2:0 / grey streams from
+// two encoders, and with an independent numpy restatement of the same integer algorithms.
 //
 // Supported: SOF0 / SOF1 (8-bit sequential Huffman), 1 or 3 components, sampling factors 1 or 2, interleaved or per-component scans,
 // restart intervals, 8- and 16-bit quantisation tables.  Progressive, arithmetic, lossless, CMYK: rejected with a message.

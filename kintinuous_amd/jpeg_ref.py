@@ -1,8 +1,8 @@
 """Baseline JPEG in numpy: an encoder (to make Logger2-style .klg colour payloads and test streams) and a reference decoder that
 restates libjpeg's default decode path (ISLOW integer IDCT, "fancy" triangle chroma upsampling, fixed-point YCbCr -> RGB) with
 vectorised integer arithmetic.  Test infrastructure for kintinuous_amd/host/JpegDecoder.h -- written independently of it (different
-structure: whole-plane numpy ops, table-driven Huffman) so that the two can be compared bit for bit.  No libjpeg in this image:
-parity with the real library is unpinned.
+structure: whole-plane numpy ops, table-driven Huffman) so that the two can be compared bit for bit.  tests/test_jpeg.py also compares both with libjpeg-turbo
+(through Pillow).
 """
 from typing import Dict, List, Optional, Tuple
 

@@ -2,7 +2,9 @@
  * kt_oracle_host.c -- CPU restatement of the reference's host-side hot-path logic
  * (SURVEY.md 8a rows a7, a10, a16): ICPOdometry / RGBDOdometry Gauss-Newton loops and the
  * KintinuousTracker::processFrame state machine, with the Eigen / OpenCV calls restated in plain C.
- * TEST INFRASTRUCTURE ONLY (see kt_oracle.h).  PARITY UNPINNED.
+ * TEST INFRASTRUCTURE ONLY (see kt_oracle.h).  PARITY UNPINNED for this file: Eigen / OpenCV / PCL are neither vendored with the
+ * reference nor installed, so the host logic is pinned by known-answer tests only (the device kernels are pinned
+ * against the reference's own sources, see kt_oracle.h).
  * Paths cited are relative to /root/reference/src/.
  *
  * Third-party arithmetic restated here (not vendored in the reference; versions README.md:14-31):

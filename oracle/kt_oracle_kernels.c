@@ -1,6 +1,7 @@
 /*
  * kt_oracle_kernels.c -- CPU restatement of the reference's device kernels.
- * TEST INFRASTRUCTURE ONLY (see kt_oracle.h).  PARITY UNPINNED (no reference golden vectors exist).
+ * TEST INFRASTRUCTURE ONLY (see kt_oracle.h).  Pinned bit for bit against the reference's own .cu files built for the host
+ * (oracle/_ref, tests/test_oracle_vs_ref.py).
  * Every function cites the reference file:line it follows (paths relative to /root/reference/src/).
  * Build: gcc -O2 -ffp-contract=off -fopenmp (see oracle/Makefile).  Never build with -ffast-math.
  */

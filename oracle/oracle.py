@@ -1,7 +1,8 @@
 """ctypes binding of oracle/libkt_oracle.so -- the CPU restatement of the reference (see kt_oracle.h).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
-Nothing under kintinuous_amd/ may import this module.  PARITY UNPINNED (no reference golden vectors).
+Nothing under kintinuous_amd/ may import this module.  Parity status: kernels pinned bit for bit against the
+reference's own .cu files built for the host (oracle/ref.py, tests/test_oracle_vs_ref.py); host logic by known-answer tests only.
 """
 from __future__ import annotations
 

@@ -1,7 +1,8 @@
 """Generates tests/golden/golden_v1.npz: seeded synthetic inputs and the oracle's outputs for every hot-path function.
 
 The reference has no fixtures of its own and cannot run here, so these vectors are dumps of the CPU
-restatement (PARITY UNPINNED): they pin the oracle against silent drift (compiler, flags, edits) and give the GPU tests
+restatement (since round 2 the restatement itself is pinned against the reference's kernel sources,
+tests/test_oracle_vs_ref.py, and golden_ref_v1.npz holds outputs of that build): they pin the oracle against silent drift (compiler, flags, edits) and give the GPU tests
 a committed known answer that does not depend on rebuilding the oracle.  Run:  python tests/golden/make_golden.py
 """
 import os

@@ -1,7 +1,7 @@
 """Generates tests/golden/golden_v2.npz: known answers for the pieces added after golden_v1 -- the full colour volume of the
 tracker runs (r, g, b and weight), ground-truth odometry (-p) with a dropped frame, the dynamic cube (-d), the view products
 (generateImage / generateDepth) and the .klg JPEG colour path (a stream from kintinuous_amd/jpeg_ref.py with its decoded bytes).
-Same status as golden_v1: dumps of the CPU restatement (PARITY UNPINNED).   Run:  python tests/golden/make_golden_v2.py
+Same status as golden_v1: dumps of the CPU restatement (see make_golden.py).   Run:  python tests/golden/make_golden_v2.py
 """
 import os
 import sys

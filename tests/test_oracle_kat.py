@@ -1,4 +1,5 @@
-"""Known-answer tests that pin the CPU oracle (the reference ships no tests or golden vectors: PARITY UNPINNED).
+"""Known-answer tests that pin the CPU oracle (the reference ships no tests or golden vectors; the kernels are
+also pinned against the reference's own sources in test_oracle_vs_ref.py -- these tests are the only pin of the HOST logic).
 Analytic checks only: what the reference's algorithm must produce on inputs whose answer is known in closed form."""
 import math
 
