@@ -92,12 +92,11 @@ struct kt_tracker {
     int last_assigned;                 // set handed to the most recent frame (prefetched or inline)
     std::vector<Pending> pending;      // prefetched frames not yet processed (at most 2)
     long long frames_started;          // process_frame calls so far
+    long long frames_observed;         // 1 + ordinal of the latest frame whose pose the host has seen in the mirror (complete_frame)
+    long long out_ordinal;             // ordinal of the frame in flight (t->outstanding)
     hipEvent_t guard_ev;               // only for out-of-pattern read-aheads (see kt_tracker_prefetch_frame)
-    // odo_ev[f % KT_NODO]: recorded on the main stream once everything of frame f up to the end of its odometry is enqueued, i.e.
-    // AFTER fusion(f - 1) and the RGB-D "last" reads of frame f - 1's set.  The read-ahead stream waits on odo_ev[u + 1] before it
-    // overwrites the set (or the staging slot) frame u consumed: explicit ordering in every mode -- with the pose mirror the host has
-    // already observed that point and the wait is free; under -p (no device odometry, the host never waits) it is what keeps a
-    // lagging GPU's fusion from reading a recycled set.
+    // odo_ev[f % KT_NODO]: recorded on the main stream between fusion(f - 1) and fusion(f), in -p mode only -- there the host never
+    // waits for a pose, so a lagging GPU's fusion could otherwise read a frame set the read-ahead stream has recycled (wait_frame_consumed).
     hipEvent_t odo_ev[8];
     long long slot_frame[4];           // ordinal of the frame that consumed staging slot k (-1: none)
     hipStream_t pre_stream;
@@ -189,12 +188,24 @@ static int pick_free_set(kt_tracker* t)
     return -1;
 }
 
+// Events that only order one stream of this device behind another: no timing, no system-scope fence (the cache write-back of the
+// default record is a 6 us bubble on the main stream; kernel boundaries already order device memory between streams of one agent).
+#ifndef KT_EV_DEVICE
+#define KT_EV_DEVICE (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
+
 // `stream` may overwrite what frame `u` consumed (its frame set, its staging slot) only after fusion(u) and the RGB-D "last" reads of
-// odometry(u + 1): both precede odo_ev[u + 1] on the main stream.  If frame u + 1 has not been started, order against "now".
+// odometry(u + 1).  Three ways to know, cheapest first:
+//   1. the host has seen the pose of frame u + 1 in the mirror: the set-up kernel that posted it runs behind odometry(u + 1), which
+//      runs behind fusion(u) -- the normal case (kt_tracker_prefetch_frame observes the frame in flight first), no stream operation;
+//   2. -p mode, where the host never waits for a pose: odo_ev[u + 1], recorded between fusion(u) and fusion(u + 1);
+//   3. otherwise order against everything enqueued so far.
+// (A record per frame in every mode is a 5 us bubble on the main stream, rocprofv3 kernel trace: a marker packet between two kernels.)
 static int wait_frame_consumed(kt_tracker* t, hipStream_t stream, long long u)
 {
     if (u < 0 || stream == t->ctx->stream) return KT_OK;   // the main stream is ordered by itself
-    if (u + 1 < t->frames_started) {
+    if (u + 2 <= t->frames_observed) return KT_OK;
+    if (t->has_trajectory && u + 1 < t->frames_started) {
         // a slot of the ring that has since been re-recorded by frame u + 1 + k * KT_NODO only waits longer, never less
         KT_HIP(hipStreamWaitEvent(stream, t->odo_ev[(u + 1) % KT_NODO], 0));
     } else {
@@ -398,12 +409,14 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
         unsigned char* dpm = nullptr;
         KT_TRY(dev_alloc(&dpm, kt_integrate_dpmax_bytes(), true));
         t->sets[q].dpmax = (float*)dpm;
-        KT_HIP(hipEventCreateWithFlags(&t->sets[q].ready, hipEventDisableTiming));
+        KT_HIP(hipEventCreateWithFlags(&t->sets[q].ready, KT_EV_DEVICE));
         t->sets[q].user = -1;
     }
     t->frames_started = 0;
-    KT_HIP(hipEventCreateWithFlags(&t->guard_ev, hipEventDisableTiming));
-    for (int k = 0; k < KT_NODO; ++k) KT_HIP(hipEventCreateWithFlags(&t->odo_ev[k], hipEventDisableTiming));
+    t->frames_observed = 0;
+    t->out_ordinal = -1;
+    KT_HIP(hipEventCreateWithFlags(&t->guard_ev, KT_EV_DEVICE));
+    for (int k = 0; k < KT_NODO; ++k) KT_HIP(hipEventCreateWithFlags(&t->odo_ev[k], KT_EV_DEVICE));
     for (int k = 0; k < KT_NSLOTS; ++k) t->slot_frame[k] = -1;
     KT_HIP(hipStreamCreateWithFlags(&t->pre_stream, hipStreamNonBlocking));
     KT_TRY(kt_bilateral_lut_ensure(ctx));   // before the context is cloned: both streams share the table
@@ -999,6 +1012,7 @@ static int complete_frame(kt_tracker* t)
         }
         t->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
     }
+    if (t->out_ordinal + 1 > t->frames_observed) t->frames_observed = t->out_ordinal + 1;
     ev_collect(t);
     if (t->mirror->handoff_timeout) { kt_set_error("odometry: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
     float Rcurr[9], tcurr[3];
@@ -1147,11 +1161,11 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     v_wrap_copy_update(t);
     if (++t->frame_seq == 0) t->frame_seq = 1;  // 0 is the mirror's initial value
     KT_TRY(launch_setup(t, 0, nullptr, nullptr));
-    KT_HIP(hipEventRecord(t->odo_ev[ordinal % KT_NODO], c->stream));
     // -d: the cube may be repositioned once the pose is known, which changes the shift decision -- nothing to speculate on
     t->out_speculated = !t->cfg.dynamic_cube;
     if (t->out_speculated) KT_TRY(enqueue_fusion(t, set, depth_raw, colors));
     t->outstanding = true;
+    t->out_ordinal = ordinal;
     t->gt_utime = timestamp;
     if (!t->out_speculated) KT_TRY(complete_frame(t));   // observe the pose, reposition, shift if needed, enqueue the fusion
     t->ev_par ^= 1;
