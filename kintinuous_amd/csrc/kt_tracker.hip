@@ -704,6 +704,7 @@ __global__ __launch_bounds__(256) void kt_frame_setup_kernel(const kt_setup_args
             const int vt = voxel_trans(tv[k] - a.basis[k], a.voxel[k], a.thresh);
             if (vt >= a.thresh || vt <= -a.thresh) skip = 1;
         }
+        if (a.st->handoff_timeout) skip = 1;   // no pose: nothing may be fused with it (complete_frame reports the error)
     } else {
         for (int k = 0; k < 9; ++k) R[k] = a.R[k];
         for (int k = 0; k < 3; ++k) tv[k] = a.t[k];
