@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <array>
+#include <deque>
 #include <chrono>
 #include <map>
 #include <thread>
@@ -101,7 +102,7 @@ struct kt_tracker {
     long long slot_frame[4];           // ordinal of the frame that consumed staging slot k (-1: none)
     hipStream_t pre_stream;
     kt_ctx pre_ctx;                    // the context with pre_stream as its stream (image kernels only)
-    kt_point_xyzrgb* cloud_device; size_t cloud_cap;
+    size_t cloud_cap;
     // RGBDOdometry buffers (RGBDOdometry.h:96-111)
     int prev_set;                      // set of the previous frame ("last" of RGBDOdometry), -1 before the first frame
     kt_dataterm* corres[KT_LEVELS];
@@ -115,7 +116,14 @@ struct kt_tracker {
     int next_slot;
     // outputs
     std::vector<DensePose> poses;
-    std::vector<Slice> slices;
+    std::deque<Slice> slices;          // a deque: the download thread fills slices[i].pts while new slices may be appended
+    // Slice download off the frame's critical path.  The extraction kernel writes the points into pinned host memory (two buffers,
+    // alternating), the count follows by an asynchronous copy and an event; a helper thread waits for the event and copies the n points
+    // into the slice while the main thread has long gone on enqueueing the clears and the fusion.  Getters join (join_slice_jobs).
+    struct SliceJob { std::thread th; bool active; size_t slice; hipError_t status; };
+    SliceJob jobs[2];
+    kt_point_xyzrgb* cloud_host[2]; unsigned int* cloud_count_host[2]; hipEvent_t cloud_ev[2];
+    int cloud_next;
     // place-recognition tap (KintinuousTracker.h:216, 248-249): pose of the last sampled frame, the samples
     float pr_rot[9], pr_trans[3];
     std::vector<PrSample> pr_samples;
@@ -142,6 +150,7 @@ struct kt_tracker {
     unsigned long long last_U, last_S;
 };
 
+static int join_slice_jobs(kt_tracker* t);
 static int lvl_cols(const kt_tracker* t, int l) { return t->cfg.cols >> l; }
 static int lvl_rows(const kt_tracker* t, int l) { return t->cfg.rows >> l; }
 static kt_intr lvl_intr(kt_intr k, int l)  // Intr::operator() internal.h:255-259
@@ -413,6 +422,8 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
         t->sets[q].user = -1;
     }
     t->frames_started = 0;
+    t->cloud_next = 0;
+    for (int b = 0; b < 2; ++b) { t->jobs[b].active = false; t->jobs[b].status = hipSuccess; t->cloud_host[b] = nullptr; t->cloud_count_host[b] = nullptr; t->cloud_ev[b] = nullptr; }
     t->frames_observed = 0;
     t->out_ordinal = -1;
     KT_HIP(hipEventCreateWithFlags(&t->guard_ev, KT_EV_DEVICE));
@@ -426,7 +437,11 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     t->last_assigned = KT_NSETS - 1;
     select_set(t, 0);
     t->cloud_cap = cfg->max_slice_points > 0 ? (size_t)cfg->max_slice_points : P * 3;  // cloud_device_(numPixels * 3) :77
-    KT_TRY(dev_alloc(&t->cloud_device, t->cloud_cap, false));
+    for (int b = 0; b < 2; ++b) {
+        KT_HIP(hipHostMalloc((void**)&t->cloud_host[b], t->cloud_cap * sizeof(kt_point_xyzrgb), hipHostMallocDefault));
+        KT_HIP(hipHostMalloc((void**)&t->cloud_count_host[b], sizeof(unsigned int), hipHostMallocDefault));
+        KT_HIP(hipEventCreateWithFlags(&t->cloud_ev[b], hipEventDisableTiming));
+    }
     KT_TRY(dev_alloc(&t->state_dev, 1, true));
     KT_HIP(hipHostMalloc((void**)&t->state_host, sizeof(kt_track_state), hipHostMallocDefault));
     for (int k = 0; k < KT_NSLOTS; ++k) {
@@ -466,6 +481,7 @@ int kt_tracker_destroy(kt_tracker* t)
 {
     if (!t) return KT_OK;
     (void)hipStreamSynchronize(t->ctx->stream);
+    (void)join_slice_jobs(t);
     (void)hipFree(t->tsdf); (void)hipFree(t->color);
     for (int l = 0; l < KT_LEVELS; ++l) {
         for (int q = 0; q < KT_NSETS; ++q) { (void)hipFree(t->sets[q].depths[l]); (void)hipFree(t->sets[q].vmaps[l]); (void)hipFree(t->sets[q].nmaps[l]); }
@@ -485,7 +501,11 @@ int kt_tracker_destroy(kt_tracker* t)
     for (int k = 0; k < KT_NODO; ++k)
         if (t->odo_ev[k]) (void)hipEventDestroy(t->odo_ev[k]);
     if (t->pre_stream) (void)hipStreamDestroy(t->pre_stream);
-    (void)hipFree(t->vmap_curr_color); (void)hipFree(t->cloud_device);
+    (void)hipFree(t->vmap_curr_color);
+    for (int b = 0; b < 2; ++b) {
+        (void)hipHostFree(t->cloud_host[b]); (void)hipHostFree(t->cloud_count_host[b]);
+        if (t->cloud_ev[b]) (void)hipEventDestroy(t->cloud_ev[b]);
+    }
     (void)hipFree(t->state_dev); (void)hipHostFree(t->state_host);
     for (int k = 0; k < KT_NSLOTS; ++k) {
         (void)hipFree(t->depth_stage[k]); (void)hipFree(t->rgb_stage[k]);
@@ -518,6 +538,7 @@ int kt_tracker_reset(kt_tracker* t)
     compute_global_camera(t, nullptr);
     t->voxel_wrap[0] = t->voxel_wrap[1] = t->voxel_wrap[2] = 0;
     t->poses.clear();
+    (void)join_slice_jobs(t);
     t->slices.clear();
     t->pr_samples.clear();
     memcpy(t->pr_trans, t->current_global_camera, sizeof(t->pr_trans));   // :290-291
@@ -799,16 +820,37 @@ static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, con
     return KT_OK;
 }
 
-// fetchCloud + download (TSDFVolume.cpp:135-172, KintinuousTracker.cpp:1164-1166): returns the slice on the host
+// wait for the slice downloads in flight (every reader of slices[i].pts goes through here)
+static int join_slice_jobs(kt_tracker* t)
+{
+    int rc = KT_OK;
+    for (int b = 0; b < 2; ++b) {
+        kt_tracker::SliceJob& j = t->jobs[b];
+        if (!j.active) continue;
+        if (j.th.joinable()) j.th.join();
+        j.active = false;
+        if (j.status != hipSuccess) { kt_set_error("slice download: %s", hipGetErrorString(j.status)); rc = KT_ERR_HIP; }
+    }
+    return rc;
+}
+
+// fetchCloud + download (TSDFVolume.cpp:135-172, KintinuousTracker.cpp:1164-1166).  Nothing here waits for the GPU: the kernel, the copy
+// of its count and an event are enqueued, and a helper thread moves the points into the slice once the event has fired.
 static int fetch_slice(kt_tracker* t, const int lo[3], const int hi[3], int dim)
 {
     kt_ctx* c = t->ctx;
-    KT_TRY(kt_extract_cloud_slice_async(c, t->tsdf, t->volume_size, t->cloud_device, t->cloud_cap, t->v_wrap_copy, t->color, lo[0], hi[0],
+    const int b = t->cloud_next;
+    t->cloud_next ^= 1;
+    kt_tracker::SliceJob& j = t->jobs[b];
+    if (j.active) {   // the download that used this buffer two slices ago
+        if (j.th.joinable()) j.th.join();
+        j.active = false;
+        if (j.status != hipSuccess) { kt_set_error("slice download: %s", hipGetErrorString(j.status)); return KT_ERR_HIP; }
+    }
+    KT_TRY(kt_extract_cloud_slice_async(c, t->tsdf, t->volume_size, t->cloud_host[b], t->cloud_cap, t->v_wrap_copy, t->color, lo[0], hi[0],
                                         lo[1], hi[1], lo[2], hi[2], 1, t->voxel_wrap, t->N, &c->counters[1]));
-    KT_HIP(hipMemcpyAsync(c->int_out_host, &c->counters[1], sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-    KT_HIP(hipStreamSynchronize(c->stream));
-    size_t n = (size_t)(unsigned int)c->int_out_host[0];
-    if (n > t->cloud_cap) n = t->cloud_cap;
+    KT_HIP(hipMemcpyAsync(t->cloud_count_host[b], &c->counters[1], sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipEventRecord(t->cloud_ev[b], c->stream));
     t->slices.emplace_back();
     Slice& s = t->slices.back();
     s.dim = dim;
@@ -816,11 +858,24 @@ static int fetch_slice(kt_tracker* t, const int lo[3], const int hi[3], int dim)
     memcpy(s.R, t->Rlast, sizeof(s.R));                          // rmats_.back(), currentGlobalCamera, current_utime:
     memcpy(s.cam, t->current_global_camera, sizeof(s.cam));      // KintinuousTracker.cpp:1186-1191
     s.ts = t->current_ts;
-    s.pts.resize(n);
-    if (n) {
-        KT_HIP(hipMemcpyAsync(s.pts.data(), t->cloud_device, n * sizeof(kt_point_xyzrgb), hipMemcpyDeviceToHost, c->stream));
-        KT_HIP(hipStreamSynchronize(c->stream));
-    }
+    j.slice = t->slices.size() - 1;
+    j.status = hipSuccess;
+    j.active = true;
+    Slice* dst = &s;   // references into a deque survive push_back
+    const kt_point_xyzrgb* src = t->cloud_host[b];
+    const unsigned int* cnt = t->cloud_count_host[b];
+    const size_t cap = t->cloud_cap;
+    hipEvent_t ev = t->cloud_ev[b];
+    hipError_t* status = &j.status;
+    const int device = c->device;
+    j.th = std::thread([dst, src, cnt, cap, ev, status, device]() {
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipEventSynchronize(ev);   // the kernel's stores to host memory and the count are complete
+        if (e != hipSuccess) { *status = e; return; }
+        size_t n = (size_t)*cnt;
+        if (n > cap) n = cap;
+        dst->pts.assign(src, src + n);
+    });
     return KT_OK;
 }
 
@@ -1349,6 +1404,7 @@ int kt_tracker_slice_info(kt_tracker* t, int i, size_t* n_points, int* dimension
     KT_ARG(t);
     KT_TRY(complete_frame(t));
     KT_ARG(t && i >= 0 && i < (int)t->slices.size() && n_points && dimension);
+    KT_TRY(join_slice_jobs(t));
     *n_points = t->slices[i].pts.size();
     *dimension = t->slices[i].dim;
     return KT_OK;
@@ -1375,6 +1431,7 @@ int kt_tracker_slice_points(kt_tracker* t, int i, kt_point_xyzrgb* out)
     KT_ARG(t);
     KT_TRY(complete_frame(t));
     KT_ARG(t && i >= 0 && i < (int)t->slices.size() && out);
+    KT_TRY(join_slice_jobs(t));
     if (!t->slices[i].pts.empty()) memcpy(out, t->slices[i].pts.data(), t->slices[i].pts.size() * sizeof(kt_point_xyzrgb));
     return KT_OK;
 }

@@ -1372,6 +1372,7 @@ struct kt_clear_args {
     int start;    // first storage index along the axis
     int count;    // number of planes (walk length), consecutive modulo N
     int xthreads; // X variants: number of x "threads" the reference launched (multiple of 16)
+    int xw_log2;  // X variants: a wave covers 2^xw_log2 slab indices of 64 >> xw_log2 consecutive y rows
 };
 
 template <typename T>
@@ -1380,9 +1381,11 @@ __global__ __launch_bounds__(256) void kt_clear_kernel(const kt_clear_args a)
     const int N = a.N;
     T* vol = (T*)a.vol;
     if (a.axis == 0) {
-        // grid: (ceil(count / 64), N, N): x index inside the slab, y, z
-        const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-        const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+        // grid: (ceil(count / xw), ceil(N / (4 * rows per wave)), N): x index inside the slab, y, z.  An X slab is a few voxels thin in the
+        // fastest dimension: a wave takes xw = 2^xw_log2 >= slab width indices of 64 / xw rows, so that most of its lanes store.
+        const int xw = 1 << a.xw_log2, lane = threadIdx.x & 63;
+        const int i = blockIdx.x * xw + (lane & (xw - 1));
+        const int y = (blockIdx.y * 4 + (threadIdx.x >> 6)) * (64 >> a.xw_log2) + (lane >> a.xw_log2);
         const int z = blockIdx.z;
         if (i >= a.count || i >= a.xthreads || y >= N) return;
         int x = a.start + i; if (x >= N) x -= N;
@@ -1438,7 +1441,13 @@ extern "C" int kt_clear_volume(kt_ctx* c, void* volume, int elem_size, int N, in
         a.xthreads = grid_x * 16;
     }
     dim3 b(256), g;
-    if (axis == 0) g = dim3(kt_div_up(a.count, 64), kt_div_up(N, 4), N);
+    a.xw_log2 = 6;
+    if (axis == 0) {
+        const int w = a.count < a.xthreads ? a.count : a.xthreads;   // indices that are actually written
+        a.xw_log2 = 0;
+        while ((1 << a.xw_log2) < w && a.xw_log2 < 6) ++a.xw_log2;
+        g = dim3(kt_div_up(w, 1 << a.xw_log2), kt_div_up(N, 4 * (64 >> a.xw_log2)), N);
+    }
     else g = dim3(kt_div_up(N, 64), kt_div_up(N, 4), a.count);
     if (elem_size == 2) hipLaunchKernelGGL(kt_clear_kernel<int16_t>, g, b, 0, c->stream, a);
     else hipLaunchKernelGGL(kt_clear_kernel<uint32_t>, g, b, 0, c->stream, a);
