@@ -172,6 +172,14 @@ int kt_host_mat33_inverse(const float m[9], float out[9]);
  * ICPOdometry.cpp:133-178 */
 int kt_host_pose_update(const double x[6], double resultRt[16], const float Rprev[9], const float tprev[3],
                         float Rcurr[9], float tcurr[3]);
+/* K R K^-1 and K t of resultRt^-1 for computeRgbResidual  RGBDOdometry.cpp:213-231 (rigid Mat::inv(DECOMP_SVD), 3x3 products in double) */
+int kt_host_compute_krk(const double resultRt[16], double fx, double fy, double cx, double cy, float krkinv[9], float kt[3]);
+/* one line of a -p trajectory file {x y z qx qy qz qw} -> Isometry3f {R row-major (9), t (3)}  KintinuousTracker.cpp:244-256 */
+void kt_host_trajectory_pose(const float pose7[7], float T[12]);
+/* GroundTruthOdometry::getIncrementalTransformation  GroundTruthOdometry.cpp:42-74: A, B = trajectory poses of the previous and the
+ * current frame's stamp, (Rlast, tlast) = rmats_.back(), tvecs_.back() */
+void kt_host_ground_truth_pose(const float A[12], const float B[12], const float Rlast[9], const float tlast[3], float Rcurr[9],
+                               float tcurr[3]);
 
 /* ---- frame-level tracker (KintinuousTracker::processFrame, KintinuousTracker.cpp:444-915) ----
  * Device-resident fast path: the whole per-frame pipeline is enqueued on the context stream, the ICP /

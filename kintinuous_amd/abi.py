@@ -151,6 +151,9 @@ _PROTOS = {
     "kt_host_rodrigues": (_i, [_pd, _pd]),
     "kt_host_mat33_inverse": (_i, [_pf, _pf]),
     "kt_host_pose_update": (_i, [_pd, _pd, _pf, _pf, _pf, _pf]),
+    "kt_host_compute_krk": (_i, [_pd, C.c_double, C.c_double, C.c_double, C.c_double, _pf, _pf]),
+    "kt_host_trajectory_pose": (None, [_pf, _pf]),
+    "kt_host_ground_truth_pose": (None, [_pf, _pf, _pf, _pf, _pf, _pf]),
     "kt_tracker_export_poses_device": (_i, [_vp, _i, _vp]),
 }
 

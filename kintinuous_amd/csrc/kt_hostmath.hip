@@ -4,6 +4,7 @@
 #include "kt_track.hpp"
 
 #include <math.h>
+#include <string.h>
 
 extern "C" {
 
@@ -108,3 +109,63 @@ extern "C" float kt_host_place_recognition_movement(const float Rcurr[9], const 
     const float alpha = 1.f;
     return (rnorm + alpha * tnorm) / 2;
 }
+
+// ---- host math of the other two odometry providers (for callers that drive the operators themselves) ----
+
+extern "C" int kt_host_compute_krk(const double resultRt[16], double fx, double fy, double cx, double cy, float krkinv[9], float kt[3])
+{
+    KT_ARG(resultRt && krkinv && kt);
+    kt_level_k k;
+    k.fx = fx; k.fy = fy; k.cx = cx; k.cy = cy;
+    kt_compute_krk(resultRt, k, krkinv, kt);
+    return KT_OK;
+}
+
+// KintinuousTracker::loadTrajectory, KintinuousTracker.cpp:244-256: T.setIdentity(); T.pretranslate(t).rotate(q) -- the linear part is
+// Quaternionf::toRotationMatrix() (no normalisation), the translation is t.  T = {R row-major (9), t (3)}.
+extern "C" void kt_host_trajectory_pose(const float pose7[7], float T[12])
+{
+    const float* p = pose7;
+    const float qx = p[3], qy = p[4], qz = p[5], qw = p[6];
+    const float x2 = 2.f * qx, y2 = 2.f * qy, z2 = 2.f * qz;
+    const float wx = x2 * qw, wy = y2 * qw, wz = z2 * qw;
+    const float xx = x2 * qx, xy = y2 * qx, xz = z2 * qx;
+    const float yy = y2 * qy, yz = z2 * qy, zz = z2 * qz;
+    const float out[12] = {1.f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.f - (xx + yy), p[0], p[1], p[2]};
+    memcpy(T, out, sizeof(out));
+}
+
+// GroundTruthOdometry::getIncrementalTransformation, GroundTruthOdometry.cpp:42-74, with Eigen 3.2's float evaluation order:
+// delta = Ta^-1 * Tb as Isometry3f (3x3 products, translation = linear * t + t), then currentTsdf * M^-1 * delta * M left to right as
+// 4x4 products.  M permutes and negates axes, so the first and last product are exact column moves; the middle one rounds, with
+// its sums running over the moved columns.  A, B: trajectory poses of the previous and the current stamp (kt_host_trajectory_pose).
+extern "C" void kt_host_ground_truth_pose(const float A[12], const float B[12], const float Rlast[9], const float tlast[3], float Rcurr[9],
+                                          float tcurr[3])
+{
+    float Ainv[9], ainv[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Ainv[i * 3 + j] = A[j * 3 + i];
+    for (int i = 0; i < 3; ++i) ainv[i] = ((-Ainv[i * 3]) * A[9] + (-Ainv[i * 3 + 1]) * A[10]) + (-Ainv[i * 3 + 2]) * A[11];
+    float delta[4][4];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) delta[i][j] = (Ainv[i * 3] * B[j] + Ainv[i * 3 + 1] * B[3 + j]) + Ainv[i * 3 + 2] * B[6 + j];
+        delta[i][3] = ((Ainv[i * 3] * B[9] + Ainv[i * 3 + 1] * B[10]) + Ainv[i * 3 + 2] * B[11]) + ainv[i];
+    }
+    delta[3][0] = delta[3][1] = delta[3][2] = 0.f;
+    delta[3][3] = 1.f;
+    float Rn[9], tn[3];
+    for (int i = 0; i < 3; ++i) {
+        // row i of currentTsdf * M^-1: (z column, -x column, -y column, translation)
+        const float moved[4] = {Rlast[i * 3 + 2], -Rlast[i * 3], -Rlast[i * 3 + 1], tlast[i]};
+        float q[4];
+        for (int j = 0; j < 4; ++j) q[j] = ((moved[0] * delta[0][j] + moved[1] * delta[1][j]) + moved[2] * delta[2][j]) + moved[3] * delta[3][j];
+        // ... * M: columns (-q1, -q2, q0, q3)
+        Rn[i * 3] = -q[1];
+        Rn[i * 3 + 1] = -q[2];
+        Rn[i * 3 + 2] = q[0];
+        tn[i] = q[3];
+    }
+    memcpy(Rcurr, Rn, sizeof(Rn));
+    memcpy(tcurr, tn, sizeof(tn));
+}
+

@@ -905,28 +905,7 @@ static void ground_truth_pose(kt_tracker* t, uint64_t timestamp, float Rcurr[9],
     if (t->gt_utime == 0 || t->trajectory.empty()) return;   // :50 -- a previous stamp of 0 reads as "no previous frame"
     const std::array<float, 12>& A = t->trajectory[(int)(uint32_t)t->gt_utime];   // operator[], as the reference
     const std::array<float, 12>& B = t->trajectory[(int)(uint32_t)timestamp];
-    float Ainv[9], ainv[3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Ainv[i * 3 + j] = A[j * 3 + i];
-    for (int i = 0; i < 3; ++i) ainv[i] = ((-Ainv[i * 3]) * A[9] + (-Ainv[i * 3 + 1]) * A[10]) + (-Ainv[i * 3 + 2]) * A[11];
-    float delta[4][4];
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) delta[i][j] = (Ainv[i * 3] * B[j] + Ainv[i * 3 + 1] * B[3 + j]) + Ainv[i * 3 + 2] * B[6 + j];
-        delta[i][3] = ((Ainv[i * 3] * B[9] + Ainv[i * 3 + 1] * B[10]) + Ainv[i * 3 + 2] * B[11]) + ainv[i];
-    }
-    delta[3][0] = delta[3][1] = delta[3][2] = 0.f;
-    delta[3][3] = 1.f;
-    for (int i = 0; i < 3; ++i) {
-        // row i of currentTsdf * M^-1: (z column, -x column, -y column, translation)
-        const float moved[4] = {t->Rlast[i * 3 + 2], -t->Rlast[i * 3], -t->Rlast[i * 3 + 1], t->tlast[i]};
-        float q[4];
-        for (int j = 0; j < 4; ++j) q[j] = ((moved[0] * delta[0][j] + moved[1] * delta[1][j]) + moved[2] * delta[2][j]) + moved[3] * delta[3][j];
-        // ... * M: columns (-q1, -q2, q0, q3)
-        Rcurr[i * 3] = -q[1];
-        Rcurr[i * 3 + 1] = -q[2];
-        Rcurr[i * 3 + 2] = q[0];
-        tcurr[i] = q[3];
-    }
+    kt_host_ground_truth_pose(A.data(), B.data(), t->Rlast, t->tlast, Rcurr, tcurr);
 }
 
 // KintinuousTracker::addToPlaceRecognition :917-958: the sample carries lastPlaceRecognitionTrans / Rot (set by the caller just before)
@@ -1308,16 +1287,8 @@ int kt_tracker_load_trajectory(kt_tracker* t, int n, const uint64_t* utimes, con
     KT_TRY(complete_frame(t));
     t->has_trajectory = true;
     for (int i = 0; i < n; ++i) {
-        const float* p = pose7 + (size_t)i * 7;
-        const float qx = p[3], qy = p[4], qz = p[5], qw = p[6];
-        const float x2 = 2.f * qx, y2 = 2.f * qy, z2 = 2.f * qz;
-        const float wx = x2 * qw, wy = y2 * qw, wz = z2 * qw;
-        const float xx = x2 * qx, xy = y2 * qx, xz = z2 * qx;
-        const float yy = y2 * qy, yz = z2 * qy, zz = z2 * qz;
-        std::array<float, 12> T = {1.f - (yy + zz), xy - wz, xz + wy,
-                                   xy + wz, 1.f - (xx + zz), yz - wx,
-                                   xz - wy, yz + wx, 1.f - (xx + yy),
-                                   p[0], p[1], p[2]};
+        std::array<float, 12> T;
+        kt_host_trajectory_pose(pose7 + (size_t)i * 7, T.data());
         t->trajectory[(int)(uint32_t)utimes[i]] = T;
     }
     t->gt_utime = 0;   // :259

@@ -4,7 +4,8 @@
 //     predicted-map pyramid stay on the GPU, one host sync per frame;
 //   * operator path (operatorPath = true): the frame is composed on the host from the internal.h operators exactly as the
 //     reference composes it (bilateralFilter, pyrDown, createVMap, ..., ICPOdometry, integrateTsdfVolume, raycast,
-//     resizeVMap) -- the drop-in granularity of the reference, one sync per operator.  ICP odometry only.
+//     resizeVMap) -- the drop-in granularity of the reference, one sync per operator.  All three odometry providers
+//     (ICPOdometry, RGBDOdometry for -r / -ri, GroundTruthOdometry for -p), selected as KintinuousTracker.cpp:128-178 does.
 // getImage / getModelDepth (KintinuousTracker.cpp:960-981) render the predicted maps without OpenGL; -p ground truth is handled by
 // the device-resident path.  The fields other threads of the reference touch (CloudSliceProcessor.cpp:38-83, PlaceRecognition, the GUI)
 // are here with their names and protocols: cloudMutex / cloudSignal / cycledMutex around sharedCloudSlices, init_utime,
@@ -24,7 +25,9 @@
 
 #include "CloudSlice.h"
 #include "ConfigArgs.h"
+#include "GroundTruthOdometry.h"
 #include "ICPOdometry.h"
+#include "RGBDOdometry.h"
 #include "PlaceRecognitionInput.h"
 #include "Resolution.h"
 #include "ThreadMutexObject.h"
@@ -70,7 +73,7 @@ class KintinuousTracker {
         : tsdfRequest(false), tsdfAvailable(false), imageAvailable(false), cycledMutex(false), lastRgbImage(0), lastDepthData(0),
           placeRecognitionId(0), placeRecognitionBuffer(new PlaceRecognitionInput[PR_BUFFER_SIZE]), latestDensePoseId(0),
           lastOdometry(CloudSlice::ICP), intr(depthIntrinsics), operatorPath(operatorPath), fast(0), tsdf_volume_(0), color_volume_(0),
-          icp(0), overlap(0), parked(false), global_time_(0), current_utime(0), nextSlice(0), nextPrSample(0), liveTsdf(0), liveImage(0), lagTime(0)
+          icp(0), rgbd(0), groundTruth(0), odometryProvider(0), odom_utime(0), overlap(0), parked(false), global_time_(0), current_utime(0), nextSlice(0), nextPrSample(0), liveTsdf(0), liveImage(0), lagTime(0)
     {
         init_utime.assignValue(std::numeric_limits<unsigned long long>::max());   // KintinuousTracker.cpp:124
         const ConfigArgs& args = ConfigArgs::get();
@@ -99,14 +102,6 @@ class KintinuousTracker {
             }
             return;
         }
-        if (args.trajectoryFile.size()) {
-            std::fprintf(stderr, "the operator path implements ICP odometry only; use the device-resident tracker for -p\n");
-            std::exit(1);
-        }
-        if (args.useRGBD || args.useRGBDICP) {
-            std::fprintf(stderr, "the operator path implements ICP odometry only; use the device-resident tracker for -r / -ri\n");
-            std::exit(1);
-        }
         // KintinuousTracker.cpp:86-118
         const float vs = Volume::get().getVolumeSize();
         volumeBasis = kt::Vector3f(vs * 0.5f, vs * 0.5f, vs * 0.5f);
@@ -117,7 +112,22 @@ class KintinuousTracker {
         color_volume_ = new ColorVolume(*tsdf_volume_);
         cloud_device_.create((size_t)Resolution::get().numPixels() * 3);
         allocateBuffers();
-        icp = new ICPOdometry(tvecs_, rmats_, vmaps_g_prev_, nmaps_g_prev_, vmaps_curr_, nmaps_curr_, intr, args.fastOdometry);
+        // the odometry provider, KintinuousTracker.cpp:128-178: a trajectory file wins over the odometry flags
+        if (args.trajectoryFile.size()) {
+            loadTrajectory(args.trajectoryFile);
+            for (size_t k = 0; k < trajectoryTimes.size(); ++k)
+                kt_host_trajectory_pose(&trajectoryPoses[k * 7], camera_trajectory[trajectoryTimes[k]].data());
+            groundTruth = new GroundTruthOdometry(tvecs_, rmats_, camera_trajectory, odom_utime);
+            odometryProvider = groundTruth;
+            lastOdometry = CloudSlice::GROUNDTRUTH;
+        } else if (args.useRGBD || args.useRGBDICP) {
+            rgbd = new RGBDOdometry(tvecs_, rmats_, vmaps_g_prev_, nmaps_g_prev_, vmaps_curr_, nmaps_curr_, intr);
+            odometryProvider = rgbd;
+            lastOdometry = CloudSlice::RGBD;
+        } else {
+            icp = new ICPOdometry(tvecs_, rmats_, vmaps_g_prev_, nmaps_g_prev_, vmaps_curr_, nmaps_curr_, intr, args.fastOdometry);
+            odometryProvider = icp;
+        }
         reset();
     }
 
@@ -131,6 +141,8 @@ class KintinuousTracker {
         delete[] firstDepthData.getValue();
         delete[] placeRecognitionBuffer;
         delete icp;
+        delete rgbd;
+        delete groundTruth;
         delete color_volume_;
         delete tsdf_volume_;
     }
@@ -152,7 +164,9 @@ class KintinuousTracker {
             syncFromFast();
             if (global_time_ == before) return;  // no trajectory entry for this timestamp: the frame was dropped (:460-463)
         } else {
+            const int before = global_time_;
             processFrameOperators(depth, colors, timestamp);
+            if (global_time_ == before) return;  // dropped: no trajectory entry for this timestamp (:460-463)
         }
         if (global_time_ > 1 && ConfigArgs::get().saveFile.size()) outputPose(timestamp, lastRotation);
     }
@@ -280,6 +294,8 @@ class KintinuousTracker {
             return;
         }
         // KintinuousTracker.cpp:262-354
+        odom_utime = 0;   // :259
+        if (odometryProvider) odometryProvider->reset();   // :307
         rmats_.clear();
         tvecs_.clear();
         rmats_.push_back(kt::Matrix3f());
@@ -313,6 +329,11 @@ class KintinuousTracker {
     TsdfVolume* tsdf_volume_;
     ColorVolume* color_volume_;
     ICPOdometry* icp;
+    RGBDOdometry* rgbd;
+    GroundTruthOdometry* groundTruth;
+    OdometryProvider* odometryProvider;
+    GroundTruthOdometry::Trajectory camera_trajectory;
+    uint64_t odom_utime;   // the reference's current_utime as the providers see it: the PREVIOUS frame's stamp during the odometry (:574-575)
     kt::Vector3f volumeBasis;
     std::vector<DeviceArray2D<unsigned short> > depths_curr_;
     std::vector<DeviceArray2D<float> > vmaps_g_prev_, nmaps_g_prev_, vmaps_curr_, nmaps_curr_;
@@ -643,12 +664,15 @@ class KintinuousTracker {
     {
         const bool angleColor = !ConfigArgs::get().disableColorAngleWeight;
         const float3 device_volume_size = make_float3(tsdf_volume_->getSize()(0), tsdf_volume_->getSize()(1), tsdf_volume_->getSize()(2));
-        // pyramid, KintinuousTracker.cpp:465-479
-        bilateralFilter(depth_raw, depths_curr_[0]);
-        for (int i = 1; i < ICPOdometry::LEVELS; ++i) pyrDown(depths_curr_[i - 1], depths_curr_[i]);
-        for (int i = 0; i < ICPOdometry::LEVELS; ++i) {
-            createVMap(intr(i), depths_curr_[i], vmaps_curr_[i]);
-            createNMap(vmaps_curr_[i], nmaps_curr_[i]);
+        if (groundTruth && !groundTruth->preRun(lastRgbImage, lastDepthData, timestamp)) return;   // :460-463
+        // pyramid, KintinuousTracker.cpp:465-479: skipped by pure RGB-D odometry without the colour angle weight (nothing reads it)
+        if (icp || ConfigArgs::get().useRGBDICP || angleColor) {
+            bilateralFilter(depth_raw, depths_curr_[0]);
+            for (int i = 1; i < ICPOdometry::LEVELS; ++i) pyrDown(depths_curr_[i - 1], depths_curr_[i]);
+            for (int i = 0; i < ICPOdometry::LEVELS; ++i) {
+                createVMap(intr(i), depths_curr_[i], vmaps_curr_[i]);
+                createNMap(vmaps_curr_[i], nmaps_curr_[i]);
+            }
         }
 
         if (global_time_ == 0) {  // :481-557
@@ -656,6 +680,7 @@ class KintinuousTracker {
             kt::Vector3f init_tcam = tvecs_.back();
             ktSafeCall(kt_host_mat33_inverse(init_Rcam.data(), init_Rcam_inv.data()));
             const int3 emptyVoxel = make_int3(0, 0, 0);
+            if (rgbd) rgbd->firstRun(depth_raw, colors);   // :499-502
             integrateTsdfVolume(depth_raw, intr, device_volume_size, kt::dev(init_Rcam_inv), kt::dev(init_tcam),
                                 tsdf_volume_->getTsdfTruncDist(), tsdf_volume_->data(), depthRawScaled_, emptyVoxel, color_volume_->data(),
                                 colors, nmaps_curr_[0], angleColor);
@@ -663,6 +688,7 @@ class KintinuousTracker {
                 tranformMaps(vmaps_curr_[i], nmaps_curr_[i], kt::dev(init_Rcam), kt::dev(init_tcam),
                              vmaps_g_prev_[i], nmaps_g_prev_[i]);
             ++global_time_;
+            odom_utime = timestamp;   // :527-528
             pushDensePose(timestamp, init_Rcam, true);
             init_utime.assignValue(timestamp);   // :525-556
             {
@@ -682,7 +708,8 @@ class KintinuousTracker {
         // odometry :564-572
         kt::Matrix3f Rcurr;
         kt::Vector3f tcurr;
-        lastOdometry = icp->getIncrementalTransformation(tcurr, Rcurr, depth_raw, colors, timestamp, lastRgbImage, lastDepthData);
+        lastOdometry = odometryProvider->getIncrementalTransformation(tcurr, Rcurr, depth_raw, colors, timestamp, lastRgbImage, lastDepthData);
+        odom_utime = timestamp;   // :574-575
         rmats_.push_back(Rcurr);
         tvecs_.push_back(tcurr);
         computeGlobalCamera(&tcurr);
@@ -735,10 +762,11 @@ class KintinuousTracker {
                             nmaps_curr_[0], angleColor);
         raycast(intr, kt::dev(Rcurr), kt::dev(tcurr), tsdf_volume_->getTsdfTruncDist(), device_volume_size,
                 tsdf_volume_->data(), vmaps_g_prev_[0], nmaps_g_prev_[0], vWrapCopy, vmap_curr_color, color_volume_->data());
-        for (int i = 1; i < ICPOdometry::LEVELS; ++i) {
-            resizeVMap(vmaps_g_prev_[i - 1], vmaps_g_prev_[i]);
-            resizeNMap(nmaps_g_prev_[i - 1], nmaps_g_prev_[i]);
-        }
+        if (icp || ConfigArgs::get().useRGBDICP)   // :892-899
+            for (int i = 1; i < ICPOdometry::LEVELS; ++i) {
+                resizeVMap(vmaps_g_prev_[i - 1], vmaps_g_prev_[i]);
+                resizeNMap(nmaps_g_prev_[i - 1], nmaps_g_prev_[i]);
+            }
         kt::device::sync();
         ++global_time_;
         lastRotation = Rcurr;

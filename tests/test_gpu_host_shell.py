@@ -78,6 +78,54 @@ def test_operator_path_equals_device_path(ctx, oracle_mod, small_scene, tmp_path
     trk.close()
 
 
+@pytest.mark.parametrize("flags", [["-r"], ["-ri"], ["-r", "-dc"], ["-ri", "-fod"]])
+def test_operator_path_rgbd_odometry(small_scene, tmp_path, flags):
+    """host/RGBDOdometry.h (the reference's RGBDOdometry composed from computeRgbResidual / icpStep / rgbStep with the Gauss-Newton step
+    on the host) against the device-resident tracker: byte-identical pose files and final views.  -dc exercises the reference's
+    "no depth pyramid for pure RGB-D without the colour angle weight" branch (KintinuousTracker.cpp:465)."""
+    cam, frames, traj = small_scene
+    frames = frames[:5]
+    log, calib = _make_log(tmp_path, cam, frames)
+    common = ["-l", log, "-c", calib, "-n", "64", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "6"] + flags
+    a = _summary(_run(common + ["-o", str(tmp_path / "dev"), "-ppm"], str(tmp_path)))
+    b = _summary(_run(common + ["-o", str(tmp_path / "ops"), "-ops", "-ppm"], str(tmp_path)))
+    assert a == b and a["frames"] == len(frames)
+    ta, tb = open(tmp_path / "dev.poses").read(), open(tmp_path / "ops.poses").read()
+    assert ta == tb and len(ta.splitlines()) == len(frames) - 1
+    for name in ("_model.ppm", "_color.ppm", "_depth.pgm"):
+        assert open(str(tmp_path / "dev") + name, "rb").read() == open(str(tmp_path / "ops") + name, "rb").read()
+    # the camera moved: RGB-D odometry tracked something
+    P = _poses(tmp_path / "dev.poses")
+    assert np.abs(P[-1, 1:4] - P[0, 1:4]).max() > 1e-3
+
+
+def test_operator_path_ground_truth_odometry(tmp_path):
+    """host/GroundTruthOdometry.h on the operator path (-ops -p): same pose file as the device-resident tracker, dropped frame included."""
+    from kintinuous_amd import klg, synth
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("room")
+    poses = synth.orbit_trajectory(8)
+    frames = [synth.render(scene, cam, R, c) for (R, c) in poses]
+    stamps = [33333 * (k + 1) for k in range(len(frames))]
+    rows = synth.ground_truth_rows(poses)
+    keep = [k for k in range(len(frames)) if k != 4]
+    log = str(tmp_path / "gt.klg")
+    klg.write_klg(log, list(frames) + [frames[-1]], timestamps=stamps + [stamps[-1] + 33333], cols=cam.cols, rows=cam.rows)
+    calib = str(tmp_path / "calib.txt")
+    with open(calib, "w") as f:
+        f.write(f"{cam.fx!r} {cam.fy!r} {cam.cx!r} {cam.cy!r}\n")
+    tfile = str(tmp_path / "traj.csv")
+    synth.write_trajectory_file(tfile, [stamps[k] for k in keep], rows[keep])
+    common = ["-l", log, "-c", calib, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "6", "-p", tfile]
+    a = _summary(_run(common + ["-o", str(tmp_path / "dev"), "-ppm"], str(tmp_path)))
+    b = _summary(_run(common + ["-o", str(tmp_path / "ops"), "-ops", "-ppm"], str(tmp_path)))
+    assert a == b
+    ta, tb = open(tmp_path / "dev.poses").read(), open(tmp_path / "ops.poses").read()
+    assert ta == tb and len(ta.splitlines()) == len(keep) - 1
+    for name in ("_model.ppm", "_color.ppm", "_depth.pgm"):
+        assert open(str(tmp_path / "dev") + name, "rb").read() == open(str(tmp_path / "ops") + name, "rb").read()
+
+
 def test_shifting_log_slices(tmp_path):
     from kintinuous_amd import synth
     cam = synth.Camera.small(160, 120)
