@@ -575,6 +575,32 @@ NPOINT_DTYPE = np.dtype([("xyz", np.float32, 3), ("one", np.float32), ("normal",
 assert NPOINT_DTYPE.itemsize == 48
 
 
+def host_compute_krk(result_rt, fx, fy, cx, cy):
+    """K R K^-1 (3x3 float32) and K t (3) of resultRt^-1, RGBDOdometry.cpp:213-231."""
+    rt = np.ascontiguousarray(result_rt, np.float64).reshape(16)
+    krk, kt = np.zeros(9, np.float32), np.zeros(3, np.float32)
+    _chk(lib().kt_host_compute_krk(_dp(rt), float(fx), float(fy), float(cx), float(cy), krk.ctypes.data_as(_pf), kt.ctypes.data_as(_pf)))
+    return krk.reshape(3, 3), kt
+
+
+def host_trajectory_pose(pose7) -> np.ndarray:
+    """{x y z qx qy qz qw} -> (R | t) as 12 floats, KintinuousTracker.cpp:244-256."""
+    p = np.ascontiguousarray(pose7, np.float32).reshape(7)
+    T = np.zeros(12, np.float32)
+    lib().kt_host_trajectory_pose(p.ctypes.data_as(_pf), T.ctypes.data_as(_pf))
+    return T
+
+
+def host_ground_truth_pose(A, B, Rlast, tlast):
+    """GroundTruthOdometry::getIncrementalTransformation on explicit state: returns (Rcurr, tcurr)."""
+    A, B = np.ascontiguousarray(A, np.float32).reshape(12), np.ascontiguousarray(B, np.float32).reshape(12)
+    Rl, tl = np.ascontiguousarray(Rlast, np.float32).reshape(9), np.ascontiguousarray(tlast, np.float32).reshape(3)
+    R, t = np.zeros(9, np.float32), np.zeros(3, np.float32)
+    lib().kt_host_ground_truth_pose(A.ctypes.data_as(_pf), B.ctypes.data_as(_pf), Rl.ctypes.data_as(_pf), tl.ctypes.data_as(_pf),
+                                    R.ctypes.data_as(_pf), t.ctypes.data_as(_pf))
+    return R.reshape(3, 3), t
+
+
 def slice_process(ctx: "Ctx", points: np.ndarray, weight_cull: int, leaf: float, k: int = 20) -> np.ndarray:
     """kt_slice_process: CloudSliceProcessor's per-slice stage on a host array of extracted points -> pcl::PointXYZRGBNormal records."""
     points = np.ascontiguousarray(points)

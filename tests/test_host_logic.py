@@ -161,3 +161,54 @@ def test_reposition_cube_abi_matches_oracle(oracle_mod):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (R, t, thresh, a, b)
             moved += int(not np.array_equal(a, basis))
     assert moved > 50      # both outcomes are exercised
+
+
+def test_rgbd_and_ground_truth_host_math_known_answers():
+    """kt_host_compute_krk, kt_host_trajectory_pose, kt_host_ground_truth_pose (the host math of host/RGBDOdometry.h and
+    host/GroundTruthOdometry.h) against float64 closed forms."""
+    from kintinuous_amd import abi
+    rng = np.random.default_rng(3)
+
+    def rot(axis, a):
+        axis = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+
+    # K R K^-1, K t of the inverse of a rigid increment
+    fx, fy, cx, cy = 525.0, 520.0, 319.5, 239.5
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]])
+    for _ in range(20):
+        Rt = np.eye(4)
+        Rt[:3, :3] = rot(rng.normal(size=3), rng.uniform(-0.2, 0.2))
+        Rt[:3, 3] = rng.uniform(-0.1, 0.1, 3)
+        inv = np.linalg.inv(Rt)
+        krk, kt = abi.host_compute_krk(Rt, fx, fy, cx, cy)
+        assert np.allclose(krk, K @ inv[:3, :3] @ np.linalg.inv(K), rtol=1e-6, atol=1e-4)
+        assert np.allclose(kt, K @ inv[:3, 3], rtol=1e-6, atol=1e-5)
+    krk, kt = abi.host_compute_krk(np.eye(4), fx, fy, cx, cy)
+    assert np.array_equal(krk, np.eye(3, dtype=np.float32)) and not kt.any()
+
+    # trajectory line -> pose: unit quaternion gives the rotation matrix, translation copied
+    for _ in range(20):
+        ax, a = rng.normal(size=3), rng.uniform(-3, 3)
+        ax /= np.linalg.norm(ax)
+        q = np.r_[np.sin(a / 2) * ax, np.cos(a / 2)]
+        t = rng.uniform(-2, 2, 3)
+        T = abi.host_trajectory_pose(np.r_[t, q])
+        assert np.allclose(T[:9].reshape(3, 3), rot(ax, a), atol=2e-6) and np.array_equal(T[9:], t.astype(np.float32))
+
+    # ground-truth increment: current = last * M^-1 * (A^-1 B) * M with M = camera axes -> volume axes (x, y, z) -> (z, -x, -y)
+    M = np.array([[0, 0, 1, 0], [-1, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float64)
+    def mat(T12):
+        m = np.eye(4); m[:3, :3] = np.asarray(T12[:9], np.float64).reshape(3, 3); m[:3, 3] = T12[9:]; return m
+    for _ in range(20):
+        A = np.r_[rot(rng.normal(size=3), rng.uniform(-1, 1)).ravel(), rng.uniform(-1, 1, 3)].astype(np.float32)
+        B = np.r_[rot(rng.normal(size=3), rng.uniform(-1, 1)).ravel(), rng.uniform(-1, 1, 3)].astype(np.float32)
+        last = np.r_[rot(rng.normal(size=3), rng.uniform(-1, 1)).ravel(), rng.uniform(2, 4, 3)].astype(np.float32)
+        R, t = abi.host_ground_truth_pose(A, B, last[:9], last[9:])
+        want = mat(last) @ np.linalg.inv(M) @ np.linalg.inv(mat(A)) @ mat(B) @ M
+        assert np.allclose(R, want[:3, :3], atol=5e-6) and np.allclose(t, want[:3, 3], atol=1e-5)
+    # no motion between equal stamps
+    R, t = abi.host_ground_truth_pose(A, A, last[:9], last[9:])
+    assert np.allclose(R, last[:9].reshape(3, 3), atol=1e-6) and np.allclose(t, last[9:], atol=1e-6)
+
