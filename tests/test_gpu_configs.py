@@ -260,3 +260,32 @@ def test_integrate_1024_cubed(ctx, oracle_mod):
     del vh, vo
     chh = ctx.download(dc, np.uint8, (N, N, N, 4))
     assert np.array_equal(co, chh)
+
+
+def test_integrate_without_the_depth_range_prune(ctx, oracle_mod):
+    """An image with more than 2048 pixel tiles (here 2048x1120: 64 x 35 tiles of 32 x 32) does not fit the interval pre-pass's tile-max
+    table, so the depth-range prune is switched off and only the frustum bounds the column intervals.  The results may not depend on how
+    tight the intervals are: two frames into a 128^3 volume, against the oracle."""
+    from hip_kernels import HipKernels
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr
+    O, H = oracle_mod, HipKernels(ctx)
+    cols, rows = 2048, 1120
+    cam = synth.Camera.small(cols, rows)
+    assert ((cols + 31) // 32) * ((rows + 31) // 32) > 2048
+    poses = synth.orbit_trajectory(6)
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    N, size, wrap = 128, 6.0, [3, 120, 64]
+    trunc = max(0.06, 2.1 * size / N)
+    vo, co = np.zeros((N, N, N), np.int16), np.zeros((N, N, N, 4), np.uint8)
+    vh, ch = vo.copy(), co.copy()
+    for k in (0, 5):
+        d, c = synth.render(synth.Scene("room"), cam, *poses[k])
+        n = O.create_nmap(O.create_vmap(intr, O.bilateral_filter(d)))
+        Rk = np.asarray(poses[k][0], np.float32)
+        tk = (np.asarray(poses[k][1], np.float32) + 3).astype(np.float32)
+        Rinv = O.mat33_inverse(Rk)
+        O.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vo, wrap, co, c, n, True)
+        H.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vh, wrap, ch, c, n, True)
+        assert np.array_equal(vo, vh) and np.array_equal(co, ch), k
+    assert int((co[..., 3] != 0).sum()) > 30000
