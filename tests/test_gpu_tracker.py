@@ -359,3 +359,42 @@ def test_place_recognition_tap(ctx, oracle_mod, mode):
     ids = [trk.slice_pr_id(i) for i in range(trk.num_slices())]
     assert ids == [otr.slice_pr_id(i) for i in range(otr.num_slices())]
     assert ids[-1] == len(gs) - 1 and any(i >= 0 for i in ids[:-1])
+
+
+@pytest.mark.parametrize("shared_ctx", [True, False])
+def test_two_trackers_interleaved(ctx, small_scene, shared_ctx):
+    """Two trackers in one process, fed alternately (one ICP, one RGB-D + ICP with read-ahead) -- on one context (one stream: the scratch
+    buffers, reduction granules and epochs are shared) and on two contexts (two streams running concurrently on the GPU).  Each must
+    produce exactly what it produces alone: nothing of a tracker's state may live in the context or in the library's globals."""
+    from kintinuous_amd import abi
+    cam, frames, traj = small_scene
+
+    def solo(c, kw, seq):
+        g, _ = _cfgs(cam, 64, **kw)
+        t = abi.Tracker(c, g)
+        for k, (d, rgb) in enumerate(seq):
+            t.process_frame_host(d, rgb, 33333 * k)
+        out = ([t.dense_pose(i)[1].copy() for i in range(t.num_poses())], t.volume().copy(), t.color_volume().copy())
+        t.close()
+        return out
+
+    seq_a, seq_b = frames[:6], frames[1:7][::-1]
+    want_a, want_b = solo(ctx, {}, seq_a), solo(ctx, dict(use_rgbd_icp=1), seq_b)
+    ctx2 = ctx if shared_ctx else abi.Ctx(0)
+    ga, _ = _cfgs(cam, 64)
+    gb, _ = _cfgs(cam, 64, use_rgbd_icp=1)
+    ta, tb = abi.Tracker(ctx, ga), abi.Tracker(ctx2, gb)
+    for k in range(6):
+        if k + 1 < 6:
+            tb.prefetch_frame_host(*seq_b[k + 1])
+        ta.process_frame_host(seq_a[k][0], seq_a[k][1], 33333 * k)
+        tb.process_frame_host(seq_b[k][0], seq_b[k][1], 33333 * k)
+    for t, want in ((ta, want_a), (tb, want_b)):
+        poses = [t.dense_pose(i)[1] for i in range(t.num_poses())]
+        assert len(poses) == len(want[0])
+        for p, q in zip(poses, want[0]):
+            assert np.array_equal(p, q)
+        assert np.array_equal(t.volume(), want[1]) and np.array_equal(t.color_volume(), want[2])
+    ta.close(); tb.close()
+    if not shared_ctx:
+        ctx2.close()
