@@ -1,15 +1,17 @@
-"""Soak: long shifting sequence, HIP tracker (device frames + read-ahead) vs the oracle tracker, every pose compared."""
+"""Soak: long shifting sequence, HIP tracker (device frames + read-ahead) vs the oracle tracker, every pose compared.
+usage: soak.py [icp|rgbd_icp|rgbd] [cols=160] [N=96]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("OMP_NUM_THREADS", "16")
 import numpy as np
 from kintinuous_amd import abi, synth
 from oracle import oracle
-cam = synth.Camera.small(160, 120)
+COLS = int(sys.argv[2]) if len(sys.argv) > 2 else 160
+cam = synth.Camera.small(COLS, COLS * 3 // 4)
 scene = synth.Scene("wall")
 traj = synth.crabwalk_trajectory(420)
 frames = [synth.render(scene, cam, *traj[i]) for i in range(0, 420, 1)]
-N = 96
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 96
 MODE = sys.argv[1] if len(sys.argv) > 1 else "icp"          # icp | rgbd_icp | rgbd
 if MODE != "icp":
     frames = frames[:160]                                   # the RGB-D oracle is slower; 160 frames still shift the volume 10 times
