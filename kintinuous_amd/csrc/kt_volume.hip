@@ -86,24 +86,66 @@ __global__ __launch_bounds__(256) void kt_scale_depth_kernel(const uint16_t* __r
     }
 }
 
-// Coarse map of the largest |scaled depth| per KT_DPT x KT_DPT pixel tile: lets the interval pre-pass bound, per voxel column, how far
-// from the camera an update is still possible (sdf >= -trunc needs |v| <= Dp + trunc).  One workgroup per tile.
-#define KT_DPT 32
-#define KT_DPT_MAX_TILES 2048
-__global__ __launch_bounds__(256) void kt_tile_max_kernel(const kt_pixrec* __restrict__ rec, int cols, int rows, float* __restrict__ dpmax)
+// Coarse map of the largest |scaled depth| per T x T pixel tile: lets the interval pre-pass bound, per voxel column, how far
+// from the camera an update is still possible (sdf >= -trunc needs |v| <= Dp + trunc).  One wave per tile.  T = 8, 16 or 32: the
+// smallest that keeps the map within KT_DPT_MAX_TILES entries (it is staged in LDS by the interval kernel): 8 at 640x480, 16 at 1280x960.
+#define KT_DPT_MAX_TILES 8192
+static int kt_dpt_log2(int cols, int rows)
 {
-    __shared__ float wmax[4];
-    const int x0 = blockIdx.x * KT_DPT, y0 = blockIdx.y * KT_DPT;
+    for (int l = 3; l <= 5; ++l)
+        if (kt_div_up(cols, 1 << l) * kt_div_up(rows, 1 << l) <= KT_DPT_MAX_TILES && kt_div_up(cols, 32) * kt_div_up(rows, 32) <= 2048) return l;
+    return 0;   // too many tiles even at 32 x 32: no depth-range prune
+}
+__global__ __launch_bounds__(256) void kt_tile_max_kernel(const kt_pixrec* __restrict__ rec, int cols, int rows, float* __restrict__ dpmax, int tl2, int tcols,
+                                                          int ntiles)
+{
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= ntiles) return;
+    const int T = 1 << tl2;
+    const int x0 = (tile % tcols) * T, y0 = (tile / tcols) * T;
     float m = 0.0f;
-    for (int i = threadIdx.x; i < KT_DPT * KT_DPT; i += 256) {
-        const int x = x0 + (i & (KT_DPT - 1)), y = y0 + i / KT_DPT;
+    for (int i = lane; i < T * T; i += 64) {
+        const int x = x0 + (i & (T - 1)), y = y0 + (i >> tl2);
         if (x < cols && y < rows) m = fmaxf(m, fabsf(rec[y * cols + x].dp));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    if (lane == 0) dpmax[tile] = m;
+}
+// Second level of the map: the same maxima per 32 x 32 pixels at dpmax[KT_DPT_MAX_TILES ..] (<= KT_DPT_COARSE_TILES of them: the coarse pass
+// of the prune) and the overall maximum at dpmax[KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES].  One workgroup.
+#define KT_DPT_COARSE_TILES 2048
+#define KT_DPT_FLOATS (KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES + 1)
+__global__ __launch_bounds__(1024) void kt_tile_max_coarse_kernel(float* __restrict__ dpmax, int tl2, int tcols, int trows, int tc32, int tr32)
+{
+    __shared__ float wmax[16];
+    const int f = 5 - tl2;
+    float all = 0.0f;
+    for (int i = threadIdx.x; i < tc32 * tr32; i += 1024) {
+        const int cx = i % tc32, cy = i / tc32;
+        float v = 0.0f;
+        for (int dy = 0; dy < (1 << f); ++dy)
+            for (int dx = 0; dx < (1 << f); ++dx) {
+                const int tx = (cx << f) + dx, ty = (cy << f) + dy;
+                if (tx < tcols && ty < trows) v = fmaxf(v, dpmax[ty * tcols + tx]);
+            }
+        dpmax[KT_DPT_MAX_TILES + i] = v;
+        all = fmaxf(all, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) all = fmaxf(all, __shfl_xor(all, off, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = all;
     __syncthreads();
-    if (threadIdx.x == 0) dpmax[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) all = fmaxf(all, wmax[w]);
+        dpmax[KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES] = all;
+    }
+}
+static void kt_launch_tile_max(kt_ctx* c, const kt_pixrec* rec, int cols, int rows, float* dpmax, int tl2)
+{
+    const int tcols = kt_div_up(cols, 1 << tl2), trows = kt_div_up(rows, 1 << tl2), ntiles = tcols * trows;
+    hipLaunchKernelGGL(kt_tile_max_kernel, dim3(kt_div_up(ntiles, 4)), dim3(256), 0, c->stream, rec, cols, rows, dpmax, tl2, tcols, ntiles);
+    hipLaunchKernelGGL(kt_tile_max_coarse_kernel, dim3(1), dim3(1024), 0, c->stream, dpmax, tl2, tcols, trows, kt_div_up(cols, 32), kt_div_up(rows, 32));
 }
 
 struct kt_tsdf23_args {
@@ -117,7 +159,8 @@ struct kt_tsdf23_args {
     const unsigned int* task_count;
     const unsigned int* wrange;    // per wave-column: union of its 64 column intervals, z0 | z1 << 16
     const float2* walk0;           // per column: (v_x, v_y) of the reference walk at z = the wave-column's first z
-    const float* dpmax;            // [ceil(rows / 32)][ceil(cols / 32)] largest |scaled depth| per pixel tile (kt_tile_max_kernel), or null
+    const float* dpmax;            // [ceil(rows / T)][ceil(cols / T)] largest |scaled depth| per pixel tile (kt_tile_max_kernel), or null
+    int dpt_log2;                  // log2 T (kt_dpt_log2)
     unsigned int* updated;  // optional counter (U of SURVEY 8d)
     kt_mat33 Ri;            // Rcurr_inv
     float tx, ty, tz;
@@ -203,30 +246,35 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
     const int sx = xg * KT_WX + (lane_ & (KT_WX - 1));
     const int sy = yg * KT_WY + (lane_ / KT_WX);
     const bool column = sx < N && sy < N;
-    __shared__ float s_dpmax[KT_DPT_MAX_TILES];
-    const int tcols = (a.cols + KT_DPT - 1) / KT_DPT, trows = (a.rows + KT_DPT - 1) / KT_DPT;
-    const bool prune = a.dpmax != nullptr && tcols * trows <= KT_DPT_MAX_TILES;
-    if (prune) {
-        for (int i = threadIdx.x; i < tcols * trows; i += 256) s_dpmax[i] = a.dpmax[i];
-        __syncthreads();
-    }
+    // dynamic LDS, sized to the two maps of this image (19 + 1.2 KB at 640x480): with the 40 KB of the largest case allocated
+    // statically only three workgroups fit a CU and the 1024 workgroups of a 512^3 launch need two rounds
+    extern __shared__ float s_maps[];
+    float* const s_dpmax = s_maps;
+    float* const s_dp32 = s_maps + ((((a_in.cols + (1 << a_in.dpt_log2) - 1) >> a_in.dpt_log2) * ((a_in.rows + (1 << a_in.dpt_log2) - 1) >> a_in.dpt_log2) + 3) & ~3);   // 32 x 32 pixel level
+    const int tl2 = a.dpt_log2;
+    const float Tinv = 1.0f / (float)(1 << tl2);
+    const int tcols = (a.cols + (1 << tl2) - 1) >> tl2, trows = (a.rows + (1 << tl2) - 1) >> tl2;
+    const bool prune = a.dpmax != nullptr && tl2 != 0;
     int z0 = N, z1 = 0;
-    if (column && !skip) {  // a frame parked for the host's shift path has no work
+    float v_g_x = 0.f, v_g_y = 0.f, ax = 0.f, ay = 0.f, az = 1.f, bx = 0.f, by = 0.f, bz = 0.f;
+    float flo = 1e30f, fhi = -1e30f, nlo = 1e30f, nhi = -1e30f;
+    const bool live = column && !skip;  // a frame parked for the host's shift path has no work
+    if (live) {
         int x = sx - a.wx; if (x < 0) x += N;
         int y = sy - a.wy; if (y < 0) y += N;
         const float* Ri = a.Ri.m;
-        const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
-        const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
+        v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
+        v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
         const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
         // camera coordinates (unscaled) at z index 0 and the per-index step: p(z) = A + z * B
-        const float ax = Ri[0] * v_g_x + Ri[1] * v_g_y + Ri[2] * v_g_z0;
-        const float ay = Ri[3] * v_g_x + Ri[4] * v_g_y + Ri[5] * v_g_z0;
-        const float az = Ri[6] * v_g_x + Ri[7] * v_g_y + Ri[8] * v_g_z0;
-        const float bx = Ri[2] * a.cell_z, by = Ri[5] * a.cell_z, bz = Ri[8] * a.cell_z;
+        ax = Ri[0] * v_g_x + Ri[1] * v_g_y + Ri[2] * v_g_z0;
+        ay = Ri[3] * v_g_x + Ri[4] * v_g_y + Ri[5] * v_g_z0;
+        az = Ri[6] * v_g_x + Ri[7] * v_g_y + Ri[8] * v_g_z0;
+        bx = Ri[2] * a.cell_z; by = Ri[5] * a.cell_z; bz = Ri[8] * a.cell_z;
         const float m = 2.0f;       // pixel margin: this linear model and the kernel's accumulated walk differ by << 1 pixel
         const float znear = 0.05f;  // below this depth the pixel bounds are not trusted
         const float lo = 0.0f, hi = (float)(N - 1);
-        float flo = lo, fhi = hi;   // frustum part: p_z >= znear and the four image sides padded by m pixels
+        flo = lo; fhi = hi;         // frustum part: p_z >= znear and the four image sides padded by m pixels
         kt_clip_halfline(az - znear, bz, flo, fhi);
         const float ul = -0.5f - m - a.intr.cx, uh = (float)a.cols - 0.5f + m - a.intr.cx;
         const float vl = -0.5f - m - a.intr.cy, vh = (float)a.rows - 0.5f + m - a.intr.cy;
@@ -237,7 +285,7 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
         // near slab: -cell <= p_z <= znear.  There the pixel coordinates are ill-conditioned, so the slab is kept without
         // testing them -- but a voxel that close to the camera plane can only project into the image when it is also within
         // |p_x|, |p_y| <= znear * (image half-size / f) ~ 0.06 m of the optical axis; columns that stay 0.2 m away skip it.
-        float nlo = lo, nhi = hi;
+        nlo = lo; nhi = hi;
         kt_clip_halfline(az + a.cell_z + a.cell_x + a.cell_y, bz, nlo, nhi);
         kt_clip_halfline(znear - az, -bz, nlo, nhi);
         if (nlo <= nhi) {
@@ -247,37 +295,98 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
             const bool far_y = (pya > rlim && pyb > rlim) || (pya < -rlim && pyb < -rlim);
             if (far_x || far_y) { nlo = 1e30f; nhi = -1e30f; }
         }
-        // Depth-range prune of the frustum part.  The voxels of the column project onto a straight image segment; with D the largest
-        // |scaled depth| in the tiles that segment touches, a voxel farther than D + trunc from the camera has sdf < -trunc
-        // whatever pixel it meets, and one whose pixel has no depth is never updated: only z with
-        // |v|^2 = v_g_x^2 + v_g_y^2 + ((z + 0.5) cell_z - t_z)^2 <= (D + trunc)^2 can be updated.  (Skipped when the near slab is
-        // kept: the segment's end is ill-defined there.)
-        if (prune && flo <= fhi && !(nlo <= nhi)) {
-            const float pza = az + flo * bz, pzb = az + fhi * bz;   // >= znear by the clip above
-            const float ua = a.intr.fx * (ax + flo * bx) / pza + a.intr.cx, va = a.intr.fy * (ay + flo * by) / pza + a.intr.cy;
-            const float ub = a.intr.fx * (ax + fhi * bx) / pzb + a.intr.cx, vb = a.intr.fy * (ay + fhi * by) / pzb + a.intr.cy;
+        // (the depth-range prune of the frustum part follows below, once the workgroup has staged the tile maps)
+    }
+    // the two levels of the map are staged in LDS only by workgroups that have a column to prune (most lie outside the frustum)
+    const bool pruned = live && prune && flo <= fhi && !(nlo <= nhi);
+    float Dall = 0.0f;   // the largest entry of the map: the bound of a piece that covers too many tiles to look at
+    if (prune && __syncthreads_or(pruned)) {
+        const int nc = ((a.cols + 31) >> 5) * ((a.rows + 31) >> 5);
+        for (int i = threadIdx.x; i < tcols * trows; i += 256) s_dpmax[i] = a.dpmax[i];
+        for (int i = threadIdx.x; i < nc; i += 256) s_dp32[i] = a.dpmax[KT_DPT_MAX_TILES + i];
+        Dall = a.dpmax[KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES];
+        __syncthreads();
+    }
+    if (live) {
+        // Depth-range prune of the frustum part.  A voxel farther from the camera than D + trunc, D = the scaled depth of the pixel it
+        // projects to, has sdf < -trunc, and one whose pixel has no depth is never updated.  The voxels of the column project onto a
+        // straight image segment; it is cut into pieces of equal length in z, and for each piece D is bounded by the tile maxima under the
+        // bounding box of its two end pixels (padded by 2.5 pixels: rounding to the pixel, and the difference between this linear model and
+        // the kernel's accumulated walk).  Inside a piece |v|^2 = v_g_x^2 + v_g_y^2 + ((z + 0.5) cell_z - t_z)^2 <= (D + trunc)^2 bounds
+        // z from above.  The pieces are visited from the far end, first in steps of about one 32-pixel tile against the coarse map, then
+        // inside the first coarse piece that keeps anything in steps of one fine tile; the first fine piece that keeps anything ends the
+        // interval (everything in front of a surface is updated, so the near end stays the frustum's).  Skipped when the near slab is
+        // kept: the segment's end is ill-defined there.  (One bound for the whole column from 32 x 32 tiles, round 1: 7.4 M lane z-steps on
+        // the 512^3 orbit; this: 6.6 M; an exact per-wave-column interval would need 5.5 M.)
+        if (pruned) {
+            const float r2xy = v_g_x * v_g_x + v_g_y * v_g_y;
+            const float inv_cell = 1.0f / a.cell_z;
+            const int tc32 = (a.cols + 31) >> 5, tr32 = (a.rows + 31) >> 5;
+            // pixel of the column at (fractional) z; the reciprocal is the hardware's (1 ulp): far inside the 2.5-pixel pad
+            auto pix = [&](float z, float& u, float& v) {
+                const float inv = __builtin_amdgcn_rcpf(az + z * bz);
+                u = a.intr.fx * (ax + z * bx) * inv + a.intr.cx;
+                v = a.intr.fy * (ay + z * by) * inv + a.intr.cy;
+            };
+            // largest tile maximum under the padded bounding box of two pixels, in the map of tile size 2^l2
+            auto bound = [&](float u0, float v0, float u1, float v1, const float* map, int l2, int mc, int mr) -> float {
+                const float pad = 2.5f, ti = 1.0f / (float)(1 << l2);
+                const int tx0 = min(mc - 1, max(0, (int)floorf((fminf(u0, u1) - pad) * ti))), tx1 = min(mc - 1, max(0, (int)floorf((fmaxf(u0, u1) + pad) * ti)));
+                const int ty0 = min(mr - 1, max(0, (int)floorf((fminf(v0, v1) - pad) * ti))), ty1 = min(mr - 1, max(0, (int)floorf((fmaxf(v0, v1) + pad) * ti)));
+                if (tx1 - tx0 > 2 || ty1 - ty0 > 2) return Dall;   // a piece is sized to move about one tile: rare
+                float D = 0.0f;   // 3 x 3 tiles with clamped indices: nine independent LDS reads, one latency
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) D = fmaxf(D, map[min(ty0 + dy, ty1) * mc + min(tx0 + dx, tx1)]);
+                return D;
+            };
+            // the part of [z0, z1] that can still be updated when no pixel under it is deeper than D: false = none, else its upper end.
+            // |v(z)|^2 = r2xy + w(z)^2 with w(z) = (z + 0.5) cell_z - t_z linear in z, so the smallest |v| of the piece needs no square root;
+            // two voxels of slack in R cover the rounding of z to voxel centres and of this arithmetic.
+            auto keep = [&](float z0, float z1, float D, float& top) -> bool {
+                const float R = (D + a.tranc_dist) * 1.001f + 1e-4f + 2.0f * a.cell_z;
+                const float w0 = __builtin_fmaf(z0 + 0.5f, a.cell_z, -a.tz), w1 = __builtin_fmaf(z1 + 0.5f, a.cell_z, -a.tz);
+                const float wmin2 = (w0 <= 0.0f && w1 >= 0.0f) ? 0.0f : fminf(w0 * w0, w1 * w1);
+                const float s2 = R * R - r2xy;
+                if (!(wmin2 <= s2)) return false;
+                top = fminf(z1, (a.tz + __builtin_amdgcn_sqrtf(s2) * 1.00001f) * inv_cell - 0.5f);
+                return true;
+            };
+            float ua, va, ub, vb;
+            pix(flo, ua, va);
+            pix(fhi, ub, vb);
             const float len = fmaxf(fabsf(ub - ua), fabsf(vb - va));
-            const int n = min(256, (int)(len * (2.0f / KT_DPT)) + 1);   // samples every <= 16 pixels
-            const float du = (ub - ua) / (float)n, dv = (vb - va) / (float)n;
-            float D = 0.0f;
-            for (int i = 0; i <= n; ++i) {
-                const float u = ua + du * (float)i, v = va + dv * (float)i;
-                // the tiles covering the 32 x 32 pixel square around the sample (clamped: outside the image nothing is updated)
-                const int tx0 = min(tcols - 1, max(0, (int)floorf((u - 0.5f * KT_DPT) * (1.0f / KT_DPT))));
-                const int tx1 = min(tcols - 1, max(0, (int)floorf((u + 0.5f * KT_DPT) * (1.0f / KT_DPT))));
-                const int ty0 = min(trows - 1, max(0, (int)floorf((v - 0.5f * KT_DPT) * (1.0f / KT_DPT))));
-                const int ty1 = min(trows - 1, max(0, (int)floorf((v + 0.5f * KT_DPT) * (1.0f / KT_DPT))));
-                D = fmaxf(D, fmaxf(fmaxf(s_dpmax[ty0 * tcols + tx0], s_dpmax[ty0 * tcols + tx1]),
-                                   fmaxf(s_dpmax[ty1 * tcols + tx0], s_dpmax[ty1 * tcols + tx1])));
+            // coarse pass: pieces of about one 32-pixel tile, from the far end; a piece that keeps nothing under the coarse (larger) bound
+            // keeps nothing under the fine one
+            const int Kc = min(32, (int)(len * (1.0f / 32.0f)) + 1);
+            const float dzc = (fhi - flo) / (float)Kc;
+            float zc1 = fhi, uc1 = ub, vc1 = vb, hi_new = -1e30f;
+            bool any = false;
+            for (int ic = Kc - 1; ic >= 0 && !any; --ic) {
+                const float zc0 = ic == 0 ? flo : flo + dzc * (float)ic;
+                float uc0 = ua, vc0 = va;
+                if (ic != 0) pix(zc0, uc0, vc0);
+                float top;
+                if (keep(zc0, zc1, bound(uc0, vc0, uc1, vc1, s_dp32, 5, tc32, tr32), top)) {
+                    if (tl2 == 5) { hi_new = top; any = true; break; }
+                    // fine pass inside this piece
+                    const float lenf = fmaxf(fabsf(uc1 - uc0), fabsf(vc1 - vc0));
+                    const int Kf = min(8, (int)(lenf * Tinv) + 1);
+                    const float dzf = (zc1 - zc0) / (float)Kf;
+                    float zf1 = zc1, uf1 = uc1, vf1 = vc1;
+                    for (int jf = Kf - 1; jf >= 0; --jf) {
+                        const float zf0 = jf == 0 ? zc0 : zc0 + dzf * (float)jf;
+                        float uf0 = uc0, vf0 = vc0;
+                        if (jf != 0) pix(zf0, uf0, vf0);
+                        if (keep(zf0, zf1, bound(uf0, vf0, uf1, vf1, s_dpmax, tl2, tcols, trows), top)) { hi_new = top; any = true; break; }
+                        zf1 = zf0; uf1 = uf0; vf1 = vf0;
+                    }
+                }
+                zc1 = zc0; uc1 = uc0; vc1 = vc0;
             }
-            const float R = (D + a.tranc_dist) * 1.001f + 1e-4f;
-            const float s2 = R * R - (v_g_x * v_g_x + v_g_y * v_g_y);
-            if (s2 < 0.0f) { flo = 1e30f; fhi = -1e30f; }
-            else {
-                const float sroot = __builtin_sqrtf(s2);
-                flo = fmaxf(flo, (a.tz - sroot) / a.cell_z - 0.5f - 1.5f);
-                fhi = fminf(fhi, (a.tz + sroot) / a.cell_z - 0.5f + 1.5f);
-            }
+            if (!any) { flo = 1e30f; fhi = -1e30f; }
+            else fhi = fminf(fhi, hi_new);
         }
         float l = 1e30f, h = -1e30f;
         if (flo <= fhi) { l = fminf(l, flo); h = fmaxf(h, fhi); }
@@ -645,7 +754,7 @@ struct kt_integrate_scratch {
     unsigned int* interval = nullptr;          // N * N column intervals
     unsigned int* wrange = nullptr;            // N * ceil(N / 64) wave-column unions
     float2* walk0 = nullptr;                   // N * N walk checkpoints at the wave-column's first z
-    float* dpmax = nullptr;                    // KT_DPT_MAX_TILES tile maxima of |scaled depth| (non-prepared path)
+    float* dpmax = nullptr;                    // KT_DPT_FLOATS: tile maxima of |scaled depth|, two levels (non-prepared path)
     unsigned int* tasks = nullptr;             // up to N * ceil(N / 64) * ceil(N / ZCHUNK) tasks
     unsigned int* task_count = nullptr;
     int flip = 0;
@@ -666,7 +775,7 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
 {
     if (!c->integ) c->integ = new kt_integrate_scratch();
     kt_integrate_scratch& s = *c->integ;
-    if (!s.dpmax) KT_HIP(hipMalloc((void**)&s.dpmax, sizeof(float) * KT_DPT_MAX_TILES));
+    if (!s.dpmax) KT_HIP(hipMalloc((void**)&s.dpmax, sizeof(float) * KT_DPT_FLOATS));
     if (s.rec_px < px) {
         KT_HIP(hipStreamSynchronize(c->stream));
         if (s.rec) KT_HIP(hipFree(s.rec));
@@ -730,9 +839,8 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
                            cols, rows, *intr, angle_color);
         KT_LAUNCH_CHECK();
         prepared_dpmax = nullptr;
-        if (kt_div_up(cols, KT_DPT) * kt_div_up(rows, KT_DPT) <= KT_DPT_MAX_TILES) {
-            hipLaunchKernelGGL(kt_tile_max_kernel, dim3(kt_div_up(cols, KT_DPT), kt_div_up(rows, KT_DPT)), dim3(256), 0, c->stream, c->integ->rec, cols,
-                               rows, c->integ->dpmax);
+        if (kt_dpt_log2(cols, rows)) {
+            kt_launch_tile_max(c, c->integ->rec, cols, rows, c->integ->dpmax, kt_dpt_log2(cols, rows));
             KT_LAUNCH_CHECK();
             prepared_dpmax = c->integ->dpmax;
         }
@@ -762,8 +870,10 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     a.wrange = c->integ->wrange;
     a.walk0 = c->integ->walk0;
     a.dpmax = prepared_dpmax;
+    a.dpt_log2 = kt_dpt_log2(cols, rows);
     const int XG = kt_div_up(N, KT_WX), YG = kt_div_up(N, KT_WY);
-    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(kt_div_up(N, 2 * KT_WX), kt_div_up(N, 2 * KT_WY)), dim3(256), 0, c->stream, a, c->integ->interval, c->integ->wrange, c->integ->walk0);
+    const size_t maps_lds = a.dpmax && a.dpt_log2 ? sizeof(float) * (size_t)(((kt_div_up(cols, 1 << a.dpt_log2) * kt_div_up(rows, 1 << a.dpt_log2) + 3) & ~3) + kt_div_up(cols, 32) * kt_div_up(rows, 32)) : 0;
+    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(kt_div_up(N, 2 * KT_WX), kt_div_up(N, 2 * KT_WY)), dim3(256), maps_lds, c->stream, a, c->integ->interval, c->integ->wrange, c->integ->walk0);
     KT_LAUNCH_CHECK();
     hipLaunchKernelGGL(kt_tsdf_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, c->integ->wrange, XG * YG, XG, c->integ->tasks, c->integ->task_count);
     KT_LAUNCH_CHECK();
@@ -797,7 +907,7 @@ int kt_integrate_tables(kt_ctx* c, int cols, int rows, int N, float** vgz, float
 // The pose-independent half of integrateTsdfVolume (scaleDepth, tsdf_volume.cu:493-511, plus the per-pixel records): the tracker
 // runs it for frame k + 1 on its prefetch stream while frame k is still being tracked.
 size_t kt_integrate_rec_bytes(int cols, int rows) { return (size_t)cols * rows * sizeof(kt_pixrec); }
-size_t kt_integrate_dpmax_bytes(void) { return sizeof(float) * KT_DPT_MAX_TILES; }
+size_t kt_integrate_dpmax_bytes(void) { return sizeof(float) * KT_DPT_FLOATS; }
 int kt_integrate_prepare(kt_ctx* c, const uint16_t* depth_raw, const uint8_t* colors, const float* nmap_curr, int cols, int rows,
                          const kt_intr* intr, int angle_color, float* depth_raw_scaled, void* rec, float* dpmax)
 {
@@ -805,9 +915,8 @@ int kt_integrate_prepare(kt_ctx* c, const uint16_t* depth_raw, const uint8_t* co
     hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, (kt_pixrec*)rec, colors, nmap_curr, cols, rows,
                        *intr, angle_color);
     KT_LAUNCH_CHECK();
-    if (dpmax && kt_div_up(cols, KT_DPT) * kt_div_up(rows, KT_DPT) <= KT_DPT_MAX_TILES) {
-        hipLaunchKernelGGL(kt_tile_max_kernel, dim3(kt_div_up(cols, KT_DPT), kt_div_up(rows, KT_DPT)), dim3(256), 0, c->stream, (const kt_pixrec*)rec,
-                           cols, rows, dpmax);
+    if (dpmax && kt_dpt_log2(cols, rows)) {
+        kt_launch_tile_max(c, (const kt_pixrec*)rec, cols, rows, dpmax, kt_dpt_log2(cols, rows));
         KT_LAUNCH_CHECK();
     }
     return KT_OK;

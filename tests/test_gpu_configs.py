@@ -263,16 +263,16 @@ def test_integrate_1024_cubed(ctx, oracle_mod):
 
 
 def test_integrate_without_the_depth_range_prune(ctx, oracle_mod):
-    """An image with more than 2048 pixel tiles (here 2048x1120: 64 x 35 tiles of 32 x 32) does not fit the interval pre-pass's tile-max
+    """An image with more than 8192 pixel tiles (here 4096x2176: 128 x 68 tiles of 32 x 32) does not fit the interval pre-pass's tile-max
     table, so the depth-range prune is switched off and only the frustum bounds the column intervals.  The results may not depend on how
     tight the intervals are: two frames into a 128^3 volume, against the oracle."""
     from hip_kernels import HipKernels
     from kintinuous_amd import synth
     from oracle.oracle import OIntr
     O, H = oracle_mod, HipKernels(ctx)
-    cols, rows = 2048, 1120
+    cols, rows = 4096, 2176
     cam = synth.Camera.small(cols, rows)
-    assert ((cols + 31) // 32) * ((rows + 31) // 32) > 2048
+    assert ((cols + 31) // 32) * ((rows + 31) // 32) > 8192
     poses = synth.orbit_trajectory(6)
     intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
     N, size, wrap = 128, 6.0, [3, 120, 64]
