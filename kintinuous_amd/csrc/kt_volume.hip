@@ -112,12 +112,30 @@ __global__ __launch_bounds__(256) void kt_tile_max_kernel(const kt_pixrec* __res
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if (lane == 0) dpmax[tile] = m;
 }
-// Second level of the map: the same maxima per 32 x 32 pixels at dpmax[KT_DPT_MAX_TILES ..] (<= KT_DPT_COARSE_TILES of them: the coarse pass
-// of the prune) and the overall maximum at dpmax[KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES].  One workgroup.
+// What the interval pre-pass looks up is the DILATED map: entry (tx, ty) = the largest raw maximum of the 3 x 3 tiles around it, so that a
+// piece of a column whose padded pixel bounding box is at most two tiles wide is bounded by the ONE entry under its centre.  Layout of the
+// buffer (KT_DPT_FLOATS): dilated fine map [0 ..), dilated 32 x 32 pixel map [KT_DPT_MAX_TILES ..) for the coarse pass, the overall
+// maximum at [KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES], raw fine map (scratch of this stage) behind it.
 #define KT_DPT_COARSE_TILES 2048
-#define KT_DPT_FLOATS (KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES + 1)
+#define KT_DPT_RAW (KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES + 1)
+#define KT_DPT_FLOATS (KT_DPT_RAW + KT_DPT_MAX_TILES)
+__global__ __launch_bounds__(256) void kt_tile_dilate_kernel(float* __restrict__ dpmax, int tcols, int trows)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= tcols * trows) return;
+    const int tx = i % tcols, ty = i / tcols;
+    float v = 0.0f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int x = tx + dx, y = ty + dy;
+            if (x >= 0 && x < tcols && y >= 0 && y < trows) v = fmaxf(v, dpmax[KT_DPT_RAW + y * tcols + x]);
+        }
+    dpmax[i] = v;
+}
+// one workgroup: raw 32 x 32 pixel maxima into LDS, their dilation and the overall maximum out
 __global__ __launch_bounds__(1024) void kt_tile_max_coarse_kernel(float* __restrict__ dpmax, int tl2, int tcols, int trows, int tc32, int tr32)
 {
+    __shared__ float raw32[KT_DPT_COARSE_TILES];
     __shared__ float wmax[16];
     const int f = 5 - tl2;
     float all = 0.0f;
@@ -127,10 +145,21 @@ __global__ __launch_bounds__(1024) void kt_tile_max_coarse_kernel(float* __restr
         for (int dy = 0; dy < (1 << f); ++dy)
             for (int dx = 0; dx < (1 << f); ++dx) {
                 const int tx = (cx << f) + dx, ty = (cy << f) + dy;
-                if (tx < tcols && ty < trows) v = fmaxf(v, dpmax[ty * tcols + tx]);
+                if (tx < tcols && ty < trows) v = fmaxf(v, dpmax[KT_DPT_RAW + ty * tcols + tx]);
+            }
+        raw32[i] = v;
+        all = fmaxf(all, v);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < tc32 * tr32; i += 1024) {
+        const int cx = i % tc32, cy = i / tc32;
+        float v = 0.0f;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = cx + dx, y = cy + dy;
+                if (x >= 0 && x < tc32 && y >= 0 && y < tr32) v = fmaxf(v, raw32[y * tc32 + x]);
             }
         dpmax[KT_DPT_MAX_TILES + i] = v;
-        all = fmaxf(all, v);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) all = fmaxf(all, __shfl_xor(all, off, 64));
@@ -144,7 +173,8 @@ __global__ __launch_bounds__(1024) void kt_tile_max_coarse_kernel(float* __restr
 static void kt_launch_tile_max(kt_ctx* c, const kt_pixrec* rec, int cols, int rows, float* dpmax, int tl2)
 {
     const int tcols = kt_div_up(cols, 1 << tl2), trows = kt_div_up(rows, 1 << tl2), ntiles = tcols * trows;
-    hipLaunchKernelGGL(kt_tile_max_kernel, dim3(kt_div_up(ntiles, 4)), dim3(256), 0, c->stream, rec, cols, rows, dpmax, tl2, tcols, ntiles);
+    hipLaunchKernelGGL(kt_tile_max_kernel, dim3(kt_div_up(ntiles, 4)), dim3(256), 0, c->stream, rec, cols, rows, dpmax + KT_DPT_RAW, tl2, tcols, ntiles);
+    hipLaunchKernelGGL(kt_tile_dilate_kernel, dim3(kt_div_up(ntiles, 256)), dim3(256), 0, c->stream, dpmax, tcols, trows);
     hipLaunchKernelGGL(kt_tile_max_coarse_kernel, dim3(1), dim3(1024), 0, c->stream, dpmax, tl2, tcols, trows, kt_div_up(cols, 32), kt_div_up(rows, 32));
 }
 
@@ -317,7 +347,7 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
         // inside the first coarse piece that keeps anything in steps of one fine tile; the first fine piece that keeps anything ends the
         // interval (everything in front of a surface is updated, so the near end stays the frustum's).  Skipped when the near slab is
         // kept: the segment's end is ill-defined there.  (One bound for the whole column from 32 x 32 tiles, round 1: 7.4 M lane z-steps on
-        // the 512^3 orbit; this: 6.6 M; an exact per-wave-column interval would need 5.5 M.)
+        // the 512^3 orbit; this: 6.9 M; an exact per-wave-column interval would need 5.5 M.)
         if (pruned) {
             const float r2xy = v_g_x * v_g_x + v_g_y * v_g_y;
             const float inv_cell = 1.0f / a.cell_z;
@@ -328,18 +358,14 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
                 u = a.intr.fx * (ax + z * bx) * inv + a.intr.cx;
                 v = a.intr.fy * (ay + z * by) * inv + a.intr.cy;
             };
-            // largest tile maximum under the padded bounding box of two pixels, in the map of tile size 2^l2
+            // Bound of |scaled depth| under the padded bounding box of two pixels from the dilated map of tile size 2^l2: a box at most two
+            // tiles wide lies inside the 3 x 3 tiles around the tile of its centre, whose maximum is that entry.  (Wider: the map's maximum.)
             auto bound = [&](float u0, float v0, float u1, float v1, const float* map, int l2, int mc, int mr) -> float {
                 const float pad = 2.5f, ti = 1.0f / (float)(1 << l2);
-                const int tx0 = min(mc - 1, max(0, (int)floorf((fminf(u0, u1) - pad) * ti))), tx1 = min(mc - 1, max(0, (int)floorf((fmaxf(u0, u1) + pad) * ti)));
-                const int ty0 = min(mr - 1, max(0, (int)floorf((fminf(v0, v1) - pad) * ti))), ty1 = min(mr - 1, max(0, (int)floorf((fmaxf(v0, v1) + pad) * ti)));
-                if (tx1 - tx0 > 2 || ty1 - ty0 > 2) return Dall;   // a piece is sized to move about one tile: rare
-                float D = 0.0f;   // 3 x 3 tiles with clamped indices: nine independent LDS reads, one latency
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) D = fmaxf(D, map[min(ty0 + dy, ty1) * mc + min(tx0 + dx, tx1)]);
-                return D;
+                if (fmaxf(fabsf(u1 - u0), fabsf(v1 - v0)) + 2.0f * pad > (float)(2 << l2)) return Dall;
+                const int tx = min(mc - 1, max(0, (int)floorf(0.5f * (u0 + u1) * ti)));
+                const int ty = min(mr - 1, max(0, (int)floorf(0.5f * (v0 + v1) * ti)));
+                return map[ty * mc + tx];
             };
             // the part of [z0, z1] that can still be updated when no pixel under it is deeper than D: false = none, else its upper end.
             // |v(z)|^2 = r2xy + w(z)^2 with w(z) = (z + 0.5) cell_z - t_z linear in z, so the smallest |v| of the piece needs no square root;
@@ -357,33 +383,43 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
             pix(flo, ua, va);
             pix(fhi, ub, vb);
             const float len = fmaxf(fabsf(ub - ua), fabsf(vb - va));
-            // coarse pass: pieces of about one 32-pixel tile, from the far end; a piece that keeps nothing under the coarse (larger) bound
-            // keeps nothing under the fine one
+            // Coarse pass: pieces of about one 32-pixel tile, from the far end; a piece that keeps nothing under the coarse (larger) bound
+            // keeps nothing under the fine one.  The refinement of a surviving piece (a fine pass of up to 8 pieces) is kept OUT of the coarse
+            // loop: lanes reach their first surviving piece at different trip counts, and a fine pass nested in the loop would run once
+            // per trip for whichever lanes need it then (measured: that divergence was half of the kernel).  So, in rounds: every lane scans
+            // to its next surviving coarse piece, then all of them refine together; a lane whose refinement keeps nothing scans on.  After
+            // two refinements a lane takes the coarse answer.
             const int Kc = min(32, (int)(len * (1.0f / 32.0f)) + 1);
             const float dzc = (fhi - flo) / (float)Kc;
             float zc1 = fhi, uc1 = ub, vc1 = vb, hi_new = -1e30f;
             bool any = false;
-            for (int ic = Kc - 1; ic >= 0 && !any; --ic) {
-                const float zc0 = ic == 0 ? flo : flo + dzc * (float)ic;
-                float uc0 = ua, vc0 = va;
-                if (ic != 0) pix(zc0, uc0, vc0);
-                float top;
-                if (keep(zc0, zc1, bound(uc0, vc0, uc1, vc1, s_dp32, 5, tc32, tr32), top)) {
-                    if (tl2 == 5) { hi_new = top; any = true; break; }
-                    // fine pass inside this piece
-                    const float lenf = fmaxf(fabsf(uc1 - uc0), fabsf(vc1 - vc0));
-                    const int Kf = min(8, (int)(lenf * Tinv) + 1);
-                    const float dzf = (zc1 - zc0) / (float)Kf;
-                    float zf1 = zc1, uf1 = uc1, vf1 = vc1;
-                    for (int jf = Kf - 1; jf >= 0; --jf) {
-                        const float zf0 = jf == 0 ? zc0 : zc0 + dzf * (float)jf;
-                        float uf0 = uc0, vf0 = vc0;
-                        if (jf != 0) pix(zf0, uf0, vf0);
-                        if (keep(zf0, zf1, bound(uf0, vf0, uf1, vf1, s_dpmax, tl2, tcols, trows), top)) { hi_new = top; any = true; break; }
-                        zf1 = zf0; uf1 = uf0; vf1 = vf0;
-                    }
+            int ic = Kc - 1;
+            for (int round = 0; round < 3 && ic >= 0 && !any; ++round) {
+                float zc0 = flo, uc0 = ua, vc0 = va, top = 0.0f;
+                bool found = false;
+                for (; ic >= 0; --ic) {   // (a) scan
+                    zc0 = ic == 0 ? flo : flo + dzc * (float)ic;
+                    uc0 = ua; vc0 = va;
+                    if (ic != 0) pix(zc0, uc0, vc0);
+                    if (keep(zc0, zc1, bound(uc0, vc0, uc1, vc1, s_dp32, 5, tc32, tr32), top)) { found = true; break; }
+                    zc1 = zc0; uc1 = uc0; vc1 = vc0;
                 }
-                zc1 = zc0; uc1 = uc0; vc1 = vc0;
+                if (!found) break;
+                if (tl2 == 5 || round == 2) { hi_new = top; any = true; break; }
+                // (b) refine [zc0, zc1]
+                const float lenf = fmaxf(fabsf(uc1 - uc0), fabsf(vc1 - vc0));
+                const int Kf = min(8, (int)(lenf * Tinv) + 1);
+                const float dzf = (zc1 - zc0) / (float)Kf;
+                float zf1 = zc1, uf1 = uc1, vf1 = vc1;
+                for (int jf = Kf - 1; jf >= 0; --jf) {
+                    const float zf0 = jf == 0 ? zc0 : zc0 + dzf * (float)jf;
+                    float uf0 = uc0, vf0 = vc0;
+                    if (jf != 0) pix(zf0, uf0, vf0);
+                    if (keep(zf0, zf1, bound(uf0, vf0, uf1, vf1, s_dpmax, tl2, tcols, trows), top)) { hi_new = top; any = true; break; }
+                    zf1 = zf0; uf1 = uf0; vf1 = vf0;
+                }
+                zc1 = zc0; uc1 = uc0; vc1 = vc0;   // nothing kept in there: scan on below it
+                --ic;
             }
             if (!any) { flo = 1e30f; fhi = -1e30f; }
             else fhi = fminf(fhi, hi_new);
