@@ -15,61 +15,61 @@
 #include "ThreadMutexObject.h"
 #include "internal.h"
 
+// deep copy of a frame buffer that the slice owns from then on (null stays null)
+template <class T> inline T* ktCloneFrame(const T* src, size_t count)
+{
+    if (!src) return 0;
+    T* copy = new T[count];
+    std::memcpy(copy, src, count * sizeof(T));
+    return copy;
+}
+
 class CloudSlice {
+    CloudSlice();                               // slices are made from an extracted cloud only, and never copied:
+    CloudSlice(const CloudSlice&);              // they own their buffers
+    CloudSlice& operator=(const CloudSlice&);
+
   public:
-    enum Dimension { XPlus, XMinus, YPlus, YMinus, ZPlus, ZMinus, FIRST, FINAL, TSDF };
-    enum Odometry { ICP, GROUNDTRUTH, RGBD, FAIL };
+    // the face of the cube a slice left through (or what kind of snapshot it is) and the odometry that produced its pose
+    enum Dimension { XPlus = 0, XMinus = 1, YPlus = 2, YMinus = 3, ZPlus = 4, ZMinus = 5, FIRST = 6, FINAL = 7, TSDF = 8 };
+    enum Odometry { ICP = 0, GROUNDTRUTH = 1, RGBD = 2, FAIL = 3 };
 
     typedef std::vector<PointXYZRGB> PointCloud;
     typedef std::vector<PointXYZRGBNormal> PointCloudNormal;
 
-    CloudSlice(PointCloud* cloud, Dimension dimension, Odometry odometry, const kt::Vector3f& cameraTranslation,
-               const kt::Matrix3f& cameraRotation, uint64_t utime, uint64_t lagTime, unsigned char* rgbImage,
-               unsigned char* tsdfImageColor = 0, unsigned char* tsdfImage = 0, unsigned short* depthData = 0,
-               PlaceRecognitionInput* placeRecognitionFrame = 0)
-        : cloud(cloud), processedCloud(0), dimension(dimension), odometry(odometry), cameraTranslation(cameraTranslation),
-          cameraRotation(cameraRotation), poseIsam(false), utime(utime), lagTime(lagTime), tsdfImageColor(tsdfImageColor), tsdfImage(tsdfImage),
-          depthData(0), placeRecognitionFrame(placeRecognitionFrame)
-    {
-        const int n = Resolution::get().numPixels();
-        if (rgbImage != 0) {
-            this->rgbImage = new unsigned char[n * 3];
-            std::memcpy(this->rgbImage, rgbImage, (size_t)n * 3);
-        } else {
-            this->rgbImage = 0;
-        }
-        if (depthData != 0) {
-            this->depthData = new unsigned short[n];
-            std::memcpy(this->depthData, depthData, (size_t)n * 2);
-        }
-    }
-    virtual ~CloudSlice()
-    {
-        delete cloud;
-        delete processedCloud;
-        delete[] rgbImage;
-        delete[] tsdfImageColor;
-        delete[] tsdfImage;
-        delete[] depthData;
-    }
-
-    PointCloud* cloud;
-    PointCloudNormal* processedCloud;
+    // ---- payload (public, as the backend reads and fills it) ----
+    PointCloud* cloud;                          // extracted points; owned
+    PointCloudNormal* processedCloud;           // filled by CloudSliceProcessor; owned
     Dimension dimension;
     Odometry odometry;
     kt::Vector3f cameraTranslation;
     kt::Matrix3f cameraRotation;
-    ThreadMutexObject<bool> poseIsam;
-    uint64_t utime;
-    uint64_t lagTime;
-    unsigned char* rgbImage;
-    unsigned char* tsdfImageColor;
-    unsigned char* tsdfImage;
+    ThreadMutexObject<bool> poseIsam;           // set once iSAM has optimised the slice's pose
+    uint64_t utime, lagTime;
+    unsigned char* rgbImage;                    // copies of the frame the slice was cut at; owned
+    unsigned char *tsdfImageColor, *tsdfImage;  // live-view renderings (TSDF slices); owned, taken over from the caller
     unsigned short* depthData;
     PlaceRecognitionInput* placeRecognitionFrame;
 
-  private:
-    CloudSlice();
-    CloudSlice(const CloudSlice&);
-    CloudSlice& operator=(const CloudSlice&);
+    // KintinuousTracker.cpp:1186: cloud and the two tsdf images are taken over, rgbImage / depthData are copied (one frame each)
+    CloudSlice(PointCloud* cloud_, Dimension dimension_, Odometry odometry_, const kt::Vector3f& cameraTranslation_,
+               const kt::Matrix3f& cameraRotation_, uint64_t utime_, uint64_t lagTime_, unsigned char* rgbImage_,
+               unsigned char* tsdfImageColor_ = 0, unsigned char* tsdfImage_ = 0, unsigned short* depthData_ = 0,
+               PlaceRecognitionInput* placeRecognitionFrame_ = 0)
+        : cloud(cloud_), processedCloud(0), dimension(dimension_), odometry(odometry_), cameraTranslation(cameraTranslation_),
+          cameraRotation(cameraRotation_), poseIsam(false), utime(utime_), lagTime(lagTime_),
+          rgbImage(ktCloneFrame(rgbImage_, (size_t)Resolution::get().numPixels() * 3)), tsdfImageColor(tsdfImageColor_), tsdfImage(tsdfImage_),
+          depthData(ktCloneFrame(depthData_, (size_t)Resolution::get().numPixels())), placeRecognitionFrame(placeRecognitionFrame_)
+    {
+    }
+
+    virtual ~CloudSlice()
+    {
+        delete[] depthData;
+        delete[] tsdfImage;
+        delete[] tsdfImageColor;
+        delete[] rgbImage;
+        delete processedCloud;
+        delete cloud;
+    }
 };

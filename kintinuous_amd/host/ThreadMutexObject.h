@@ -1,5 +1,6 @@
-// ThreadMutexObject.h -- the value-behind-a-mutex helper the tracker's public fields are made of (utils/ThreadMutexObject.h:26-138),
-// on std::mutex / std::condition_variable_any instead of the boost types (no boost in this image); same member functions.
+// ThreadMutexObject.h -- a value guarded by its own mutex, with a condition variable to announce changes: the helper the tracker's
+// shared fields are made of (interface of utils/ThreadMutexObject.h:26-138: assignValue, getValue, waitForSignal, ...).
+// Built on the C++11 primitives (no boost in this image); every accessor goes through one private `guarded()` helper.
 #pragma once
 
 #include <stdint.h>
@@ -10,69 +11,42 @@
 
 template <class T>
 class ThreadMutexObject {
-  public:
-    ThreadMutexObject() : object(), lastCopy() {}
-    ThreadMutexObject(T initialValue) : object(initialValue), lastCopy(initialValue) {}
+    typedef std::lock_guard<std::mutex> Guard;
 
-    void assignValue(T newValue)
-    {
-        std::lock_guard<std::mutex> lock(mutex);
-        object = lastCopy = newValue;
-    }
-    std::mutex& getMutex() { return mutex; }
-    T& getReference() { return object; }
-    void assignAndNotifyAll(T newValue)
-    {
-        std::lock_guard<std::mutex> lock(mutex);
-        object = newValue;
-        signal.notify_all();
-    }
-    void notifyAll()
-    {
-        std::lock_guard<std::mutex> lock(mutex);
-        signal.notify_all();
-    }
-    T getValue()
-    {
-        std::lock_guard<std::mutex> lock(mutex);
-        lastCopy = object;
-        return lastCopy;
-    }
+    T value_;                               // the shared value
+    T snapshot_;                            // what the last getter returned (getReferenceWait hands out a reference to it)
+    std::mutex lock_;
+    std::condition_variable_any changed_;
+
+    // run f(value_) under the lock
+    template <class F> void guarded(F f) { Guard g(lock_); f(value_); }
+    T& refresh() { Guard g(lock_); snapshot_ = value_; return snapshot_; }
+    static void nap(int microseconds) { std::this_thread::sleep_for(std::chrono::microseconds(microseconds)); }
+
+  public:
+    ThreadMutexObject() : value_(), snapshot_() {}
+    ThreadMutexObject(T initialValue) : value_(initialValue), snapshot_(initialValue) {}
+
+    // writers
+    void assignValue(T newValue) { Guard g(lock_); value_ = newValue; snapshot_ = newValue; }
+    void assignAndNotifyAll(T newValue) { guarded([&](T& v) { v = newValue; changed_.notify_all(); }); }
+    void notifyAll() { guarded([&](T&) { changed_.notify_all(); }); }
+    void operator++(int) { guarded([](T& v) { v++; }); }
+    void operator+=(const uint64_t& other) { guarded([&](T& v) { v += other; }); }
+
+    // readers: a copy of the value as it is now / after the next notification / after `wait` microseconds
+    T getValue() { return refresh(); }
     T waitForSignal()
     {
-        std::unique_lock<std::mutex> lock(mutex);
-        signal.wait(lock);
-        lastCopy = object;
-        return lastCopy;
+        std::unique_lock<std::mutex> ul(lock_);
+        changed_.wait(ul);
+        snapshot_ = value_;
+        return snapshot_;
     }
-    T getValueWait(int wait = 33000)
-    {
-        std::this_thread::sleep_for(std::chrono::microseconds(wait));
-        std::lock_guard<std::mutex> lock(mutex);
-        lastCopy = object;
-        return lastCopy;
-    }
-    T& getReferenceWait(int wait = 33000)
-    {
-        std::this_thread::sleep_for(std::chrono::microseconds(wait));
-        std::lock_guard<std::mutex> lock(mutex);
-        lastCopy = object;
-        return lastCopy;
-    }
-    void operator++(int)
-    {
-        std::lock_guard<std::mutex> lock(mutex);
-        object++;
-    }
-    void operator+=(const uint64_t& other)
-    {
-        std::lock_guard<std::mutex> lock(mutex);
-        object += other;
-    }
+    T getValueWait(int wait = 33000) { nap(wait); return refresh(); }
+    T& getReferenceWait(int wait = 33000) { nap(wait); return refresh(); }
 
-  private:
-    T object;
-    T lastCopy;
-    std::mutex mutex;
-    std::condition_variable_any signal;
+    // raw access for callers that hold getMutex() themselves
+    std::mutex& getMutex() { return lock_; }
+    T& getReference() { return value_; }
 };

@@ -1,29 +1,36 @@
-// Volume.h -- volume size singleton (frontend/Volume.h:27-57).  The reference's compile-time VOLUME_X/Y/Z become the
-// runtime resolution N given on the first call.
+// Volume.h -- edge length (metres) and resolution (voxels per edge) of the TSDF cube, process-wide (interface of frontend/Volume.h:27-57).
+// The reference fixes the resolution at compile time (VOLUME_X/Y/Z, internal.h:243); here it is the second argument of the first get().
 #pragma once
-#include <cassert>
+
+#include <cstdio>
+#include <cstdlib>
+
 #include "internal.h"
 
 class Volume {
+    float edge;      // metres
+    int voxels;      // per edge
+    float3 voxel;    // metres per voxel, per axis
+
+    Volume(float edge_m, int n) : edge(edge_m), voxels(n)
+    {
+        if (!(edge_m > 0) || n <= 0) {
+            std::fprintf(stderr, "Volume: get(size, resolution) must be called with the cube's size before anything asks for it\n");
+            std::abort();
+        }
+        const float v = edge_m / (float)n;
+        voxel = make_float3(v, v, v);
+    }
+
   public:
     static Volume& get(float volumeSize = 0, int resolution = 0)
     {
-        static Volume instance(volumeSize, resolution);
-        return instance;
+        static Volume the_one(volumeSize, resolution);
+        return the_one;
     }
-    const float& getVolumeSize() { return volumeSize; }
-    const float3& getVoxelSizeMeters() { return voxelSizeMeters; }
-    int getResolution() const { return resolution; }
-
-  private:
-    Volume(float inVolumeSize, int inResolution) : volumeSize(inVolumeSize), resolution(inResolution)
-    {
-        assert(volumeSize > 0 && resolution > 0);
-        voxelSizeMeters.x = voxelSizeMeters.y = voxelSizeMeters.z = volumeSize / float(resolution);
-    }
-    const float volumeSize;
-    const int resolution;
-    float3 voxelSizeMeters;
+    int getResolution() const { return voxels; }
+    const float& getVolumeSize() { return edge; }
+    const float3& getVoxelSizeMeters() { return voxel; }
 };
 
 namespace kt {

@@ -1,37 +1,55 @@
-// kernel_containers.hpp -- the pointer views the reference's operator signatures are written in (frontend/cuda/containers/
-// kernel_containers.hpp:49-92): DevPtr / PtrSz / PtrStep / PtrStepSz.  Plain structs: a device pointer, a byte step, optionally a size.
+// kernel_containers.hpp -- the four pointer views the reference's operator signatures are written in (interface of
+// frontend/cuda/containers/kernel_containers.hpp:49-92): DevPtr (pointer), PtrSz (+ element count), PtrStep (+ row stride in bytes),
+// PtrStepSz (+ rows and columns).  They own nothing; DeviceArray / DeviceArray2D convert to them implicitly (device_array.hpp).
 #pragma once
 
 #include <cstddef>
+#include <type_traits>
 
-template <typename T> struct DevPtr {
+template <typename T>
+struct DevPtr {
     typedef T elem_type;
-    const static size_t elem_size = sizeof(elem_type);
+    const static size_t elem_size = sizeof(T);
+
     T* data;
-    DevPtr() : data(0) {}
-    DevPtr(T* data_arg) : data(data_arg) {}
-    size_t elemSize() const { return elem_size; }
+
+    DevPtr(T* p = 0) : data(p) {}
+    size_t elemSize() const { return sizeof(T); }
     operator T*() { return data; }
     operator const T*() const { return data; }
 };
 
-template <typename T> struct PtrSz : public DevPtr<T> {
-    PtrSz() : size(0) {}
-    PtrSz(T* data_arg, size_t size_arg) : DevPtr<T>(data_arg), size(size_arg) {}
-    size_t size;
+template <typename T>
+struct PtrSz : DevPtr<T> {
+    size_t size;   // elements
+
+    PtrSz() : DevPtr<T>(0), size(0) {}
+    PtrSz(T* p, size_t count) : DevPtr<T>(p), size(count) {}
 };
 
-template <typename T> struct PtrStep : public DevPtr<T> {
-    PtrStep() : step(0) {}
-    PtrStep(T* data_arg, size_t step_arg) : DevPtr<T>(data_arg), step(step_arg) {}
-    size_t step;   // stride between two consecutive rows in BYTES
-    T* ptr(int y = 0) { return (T*)((char*)DevPtr<T>::data + y * step); }
-    const T* ptr(int y = 0) const { return (const T*)((const char*)DevPtr<T>::data + y * step); }
+template <typename T>
+struct PtrStep : DevPtr<T> {
+    size_t step;   // bytes from one row to the next
+
+    PtrStep() : DevPtr<T>(0), step(0) {}
+    PtrStep(T* p, size_t row_bytes) : DevPtr<T>(p), step(row_bytes) {}
+
+    // first element of row y
+    T* ptr(int y = 0) { return row(this->data, y); }
+    const T* ptr(int y = 0) const { return row(this->data, y); }
+
+  private:
+    template <typename P> P* row(P* base, int y) const
+    {
+        typedef typename std::conditional<std::is_const<P>::value, const char, char>::type Byte;
+        return reinterpret_cast<P*>(reinterpret_cast<Byte*>(base) + (size_t)y * step);
+    }
 };
 
-template <typename T> struct PtrStepSz : public PtrStep<T> {
-    PtrStepSz() : cols(0), rows(0) {}
-    PtrStepSz(int rows_arg, int cols_arg, T* data_arg, size_t step_arg) : PtrStep<T>(data_arg, step_arg), cols(cols_arg), rows(rows_arg) {}
-    int cols;
-    int rows;
+template <typename T>
+struct PtrStepSz : PtrStep<T> {
+    int cols, rows;
+
+    PtrStepSz() : PtrStep<T>(), cols(0), rows(0) {}
+    PtrStepSz(int nrows, int ncols, T* p, size_t row_bytes) : PtrStep<T>(p, row_bytes), cols(ncols), rows(nrows) {}
 };
