@@ -398,3 +398,50 @@ def test_two_trackers_interleaved(ctx, small_scene, shared_ctx):
     ta.close(); tb.close()
     if not shared_ctx:
         ctx2.close()
+
+
+def test_slice_downloads_survive_reset_and_destroy(ctx):
+    """Slices are downloaded by helper threads behind an event (fetch_slice).  Shifts in quick succession, a reset and a destroy while
+    downloads may still be in flight, slices read out of order: nothing may hang, crash or hand out a half-filled slice."""
+    from kintinuous_amd import abi, synth
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("wall")
+    traj = synth.crabwalk_trajectory(420)
+    idx = list(range(0, 40, 2)) + list(range(40, 0, -2))   # 30 mm steps out and back (test_shifting_crabwalk): X+ and X- slabs with points
+    frames = [synth.render(scene, cam, *traj[i]) for i in idx]
+    g, _ = _cfgs(cam, 96, volume_size=7.0, voxel_shift=3)
+
+    def run(read_between):
+        t = abi.Tracker(ctx, g)
+        sizes = []
+        for k, (d, rgb) in enumerate(frames):
+            t.process_frame_host(d, rgb, 33333 * k)
+            if read_between and k % 7 == 0 and t.num_slices():
+                sizes.append(len(t.slice(t.num_slices() - 1)[0]))
+        t.finalise()                            # the whole volume as one more, large slice
+        n = t.num_slices()
+        pts = [t.slice(i)[0] for i in reversed(range(n))]
+        return t, n, pts[::-1]
+
+    t, n, pts = run(False)
+    assert n >= 4
+    # the oracle says what each slice holds (slabs at the cube's unobserved side faces are legitimately empty)
+    from oracle import oracle
+    _, o = _cfgs(cam, 96, volume_size=7.0, voxel_shift=3)
+    otr = oracle.OracleTracker(o)
+    for k, (d, rgb) in enumerate(frames):
+        otr.process_frame(d, rgb, 33333 * k)
+    otr.finalise()
+    assert otr.num_slices() == n
+    for i in range(n):
+        assert _same_points(pts[i], otr.slice(i)[0]), i
+    assert len(pts[-1]) > 1000
+    otr.close()
+    t.reset()                                   # joins whatever is still in flight, drops the slices
+    assert t.num_slices() == 0
+    for k, (d, rgb) in enumerate(frames[:12]):  # shifts again ...
+        t.process_frame_host(d, rgb, 33333 * k)
+    t.close()                                   # ... and is destroyed with the last downloads possibly unfinished
+    t2, n2, pts2 = run(True)
+    assert n2 == n and all(_same_points(a, b) for a, b in zip(pts, pts2))
+    t2.close()
