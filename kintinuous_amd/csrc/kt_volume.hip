@@ -1688,9 +1688,11 @@ __global__ __launch_bounds__(256) void kt_extract_kernel(const kt_extract_args a
         if (o < a.out_cap) {
             // store_point_type  extract.cu:307-317
             float4 lo, hi;
-            lo.x = __builtin_fmaf((float)a.rwx, a.cx, pts[l].x) - ((a.cx * a.N) / 2);
-            lo.y = __builtin_fmaf((float)a.rwy, a.cy, pts[l].y) - ((a.cy * a.N) / 2);
-            lo.z = __builtin_fmaf((float)a.rwz, a.cz, pts[l].z) - ((a.cz * a.N) / 2);
+            // store_point_type extract.cu:307-317: the product realVoxelWrap * cell_size is loop invariant in the reference and ends up in
+            // front of its loops, out of reach of the addition: not contracted (oracle/_ref pins it)
+            lo.x = (pts[l].x + (float)a.rwx * a.cx) - ((a.cx * a.N) / 2);
+            lo.y = (pts[l].y + (float)a.rwy * a.cy) - ((a.cy * a.N) / 2);
+            lo.z = (pts[l].z + (float)a.rwz * a.cz) - ((a.cz * a.N) / 2);
             lo.w = 0.f;
             hi.x = __uint_as_float(cols[l]); hi.y = 0.f; hi.z = 0.f; hi.w = 0.f;
             float4* dst = (float4*)&a.out[o];  // two 16-byte stores per 32-byte point

@@ -1084,10 +1084,13 @@ size_t kto_extract_cloud_slice(const int16_t* volume, const float volume_size[3]
                     if (count < out_cap) {
                         kto_point* o = &out[count];
                         memset(o, 0, sizeof(*o));
-                        /* store_point_type extract.cu:307-317 */
-                        o->x = fmaf((float)real_voxel_wrap[0], cell[0], p[0]) - ((cell[0] * N) / 2);
-                        o->y = fmaf((float)real_voxel_wrap[1], cell[1], p[1]) - ((cell[1] * N) / 2);
-                        o->z = fmaf((float)real_voxel_wrap[2], cell[2], p[2]) - ((cell[2] * N) / 2);
+                        /* store_point_type extract.cu:307-317: x + realVoxelWrap.x * cell_size.x - half.  The product is invariant over
+                         * the whole kernel, so the compiler computes it once in front of the loops, where it cannot fuse with the
+                         * addition inside them: NOT contracted (pinned by oracle/_ref with real wraps of a few hundred voxels,
+                         * tests/test_oracle_vs_ref.py::test_randomized_sweep; with small wraps both forms round alike). */
+                        o->x = (p[0] + (float)real_voxel_wrap[0] * cell[0]) - ((cell[0] * N) / 2);
+                        o->y = (p[1] + (float)real_voxel_wrap[1] * cell[1]) - ((cell[1] * N) / 2);
+                        o->z = (p[2] + (float)real_voxel_wrap[2] * cell[2]) - ((cell[2] * N) / 2);
                         /* r = colour.x of the NEIGHBOUR, stored swapped: ptr->r = b, ptr->b = r (quirk A.14) */
                         o->r = color_volume[4 * ni + 2];
                         o->g = color_volume[4 * ni + 1];

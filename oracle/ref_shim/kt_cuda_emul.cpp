@@ -141,15 +141,29 @@ void run_block(int nthreads)
     g_live = nthreads;
     g_bar_arrived = 0;
     g_bar_gen = 0;
-    while (g_live > 0) {
-        unsigned long long before = g_progress;
-        for (int t = 0; t < nthreads; ++t) {
+    /* Schedule: any interleaving of the warps of a block is a legal execution.  This one lets warps 1.. run as far as they can before
+     * warp 0 gets a turn, so that warp 0 is the last warp of its block to finish.  The reference's extractKernelSlice depends on that:
+     * its thread 0 publishes output_count and zeroes global_count as soon as ITS warp leaves the z loop, with no block barrier in
+     * front (extract.cu:289-303), so a warp of the last block that is still extracting then adds its points to the zeroed counter --
+     * they overwrite the head of the output and are missing from the count.  (Found by tests/test_oracle_vs_ref.py::test_randomized_sweep
+     * under a plain round-robin schedule; a race of the reference, not a property to reproduce.) */
+    auto run_range = [&](int t0, int t1) {
+        for (int t = t0; t < t1; ++t) {
             Fiber& f = g_fibers[t];
             if (f.done) continue;
             g_cur = &f;
             threadIdx = f.tidx;
             ktemu_switch(&g_sched_sp, f.sp);
         }
+    };
+    while (g_live > 0) {
+        unsigned long long before = g_progress;
+        for (;;) {   // warps 1 .. : until they are done or all of them wait for warp 0 (a block barrier)
+            const unsigned long long b2 = g_progress;
+            run_range(nthreads < 32 ? nthreads : 32, nthreads);
+            if (g_progress == b2) break;
+        }
+        run_range(0, nthreads < 32 ? nthreads : 32);
         if (g_live > 0 && g_progress == before)
             die("deadlock: a barrier or warp collective was reached by only part of its threads");
     }
@@ -238,11 +252,20 @@ unsigned warp_ballot(int pred)
 static size_t g_pitch_align = 256;   /* rows of 2-D allocations are padded to this many bytes (exercises pitch handling) */
 extern "C" void ktref_set_pitch_alignment(int bytes) { g_pitch_align = bytes > 0 ? (size_t)bytes : 1; }
 
+/* Every "device" allocation sits between two guard zones that are checked when it is freed: a kernel of the reference that writes
+ * outside its buffer (some do for argument combinations the reference itself never uses) is reported instead of corrupting the heap. */
+static const size_t kGuard = 4096;
+struct AllocHeader { size_t n; size_t magic; };
 cudaError_t cudaMalloc(void** p, size_t n)
 {
-    *p = aligned_alloc(256, (n + 255) & ~(size_t)255);
-    if (!*p) return cudaErrorMemoryAllocation;
-    memset(*p, 0xCD, n);   /* fresh device memory is not zero: make reads of it visible */
+    const size_t body = (n + 255) & ~(size_t)255;
+    char* raw = (char*)aligned_alloc(256, kGuard + body + kGuard);
+    if (!raw) return cudaErrorMemoryAllocation;
+    memset(raw, 0xA5, kGuard + body + kGuard);
+    AllocHeader h = {n, 0x6b745f7265665f31ull};
+    memcpy(raw, &h, sizeof(h));
+    memset(raw + kGuard, 0xCD, n);   /* fresh device memory is not zero: make reads of it visible */
+    *p = raw + kGuard;
     return cudaSuccess;
 }
 
@@ -252,7 +275,21 @@ cudaError_t cudaMallocPitch(void** p, size_t* pitch, size_t width_bytes, size_t 
     return cudaMalloc(p, *pitch * (height ? height : 1));
 }
 
-cudaError_t cudaFree(void* p) { free(p); return cudaSuccess; }
+cudaError_t cudaFree(void* p)
+{
+    if (!p) return cudaSuccess;
+    char* raw = (char*)p - kGuard;
+    AllocHeader h;
+    memcpy(&h, raw, sizeof(h));
+    if (h.magic != 0x6b745f7265665f31ull) { fprintf(stderr, "kt_cuda_emul: cudaFree of a pointer cudaMalloc did not return\n"); abort(); }
+    const size_t body = (h.n + 255) & ~(size_t)255;
+    for (size_t i = sizeof(h); i < kGuard; ++i)
+        if ((unsigned char)raw[i] != 0xA5) { fprintf(stderr, "kt_cuda_emul: a kernel wrote %zu bytes BELOW a device buffer of %zu bytes\n", kGuard - i, h.n); abort(); }
+    for (size_t i = h.n; i < body + kGuard; ++i)
+        if (i >= body ? (unsigned char)raw[kGuard + i] != 0xA5 : false) { fprintf(stderr, "kt_cuda_emul: a kernel wrote %zu bytes PAST a device buffer of %zu bytes\n", i - h.n + 1, h.n); abort(); }
+    free(raw);
+    return cudaSuccess;
+}
 cudaError_t cudaMemcpy(void* dst, const void* src, size_t n, cudaMemcpyKind) { memmove(dst, src, n); return cudaSuccess; }
 cudaError_t cudaMemset(void* p, int v, size_t n) { memset(p, v, n); return cudaSuccess; }
 

@@ -366,3 +366,87 @@ def test_rgb_residual_and_step(oracle_mod, R, level):
     Ao, bo = O.rgb_step(co, sigma, cloud, fx, fy, dx, dy, 0.125, 0)
     Ar, br = R.rgb_step(cr, sigma, cloud, fx, fy, dx, dy, 0.125)
     assert same(Ao, Ar) and same(bo, br), (Ao - Ar, bo - br)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_randomized_sweep(oracle_mod, R, seed):
+    """The same comparison over seeded random configurations -- scene, image size (including sizes that are no multiple of the tile and
+    block shapes), volume resolution and extent, storage wrap, poses with large rotations, holes and sensor noise in the depth, the
+    colour-angle flag -- through integrate (4 frames into one volume), raycast (2 poses), extraction (a random box), a slab clear and
+    one ICP reduction: every output bit for bit, the one documented exception aside (the heat byte next to a volume face)."""
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr
+    O = oracle_mod
+    rng = np.random.default_rng(1000 + seed)
+    cols, rows = [(160, 120), (200, 150), (136, 104), (320, 240)][seed % 4]
+    N = int(rng.choice([48, 64, 72, 100]))
+    size = float(rng.choice([4.0, 6.0, 7.0]))
+    wrap = [int(v) for v in rng.integers(0, N, 3)]
+    angle = bool(rng.integers(0, 2))
+    kind = ["room", "wall", "room", "farwall"][seed % 4]
+    cam = synth.Camera.small(cols, rows)
+    scene = synth.Scene(kind, seed=1234 + seed)
+    base = synth.orbit_trajectory(40)
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    trunc = max(0.06 if size == 6.0 else max(0.01, size / 100), 2.1 * size / N)
+    vo, co = np.zeros((N, N, N), np.int16), np.zeros((N, N, N, 4), np.uint8)
+    vr, cr = vo.copy(), co.copy()
+    poses, maps = [], []
+    for k in range(4):
+        Rm, c0 = base[int(rng.integers(0, 40))]
+        d, c = synth.render(scene, cam, Rm, c0, noise_mm=float(rng.choice([0.0, 1.5])), rng=rng)
+        d = _holes(d, rng, float(rng.choice([0.0, 0.02])))
+        Rk = (random_rotation(rng, 0.5) @ np.asarray(Rm, np.float32)).astype(np.float32)
+        tk = (np.asarray(c0, np.float32) + np.float32(size / 2) + rng.uniform(-0.3, 0.3, 3)).astype(np.float32)
+        v = O.create_vmap(intr, O.bilateral_filter(d))
+        n = O.create_nmap(v)
+        Rinv = O.mat33_inverse(Rk)
+        U, so = O.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vo, wrap, co, c, n, angle)
+        sr = R.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vr, wrap, cr, c, n, angle)
+        assert same(so, sr) and same(vo, vr) and same(co, cr), (seed, k, int((vo != vr).sum()), int((co != cr).any(axis=-1).sum()))
+        poses.append((Rk, tk))
+        maps.append((v, n))
+    assert int((co[..., 3] != 0).sum()) > 200
+    # raycast from two of the poses
+    cell = np.float32(size / N)
+    pred = None
+    for Rk, tk in poses[2:]:
+        outs = []
+        for M in (O, R):
+            vm, nm = np.full((3 * rows, cols), 7.0, np.float32), np.full((3 * rows, cols), -3.0, np.float32)
+            cm = np.full((rows, cols, 4), 9, np.uint8)
+            M.raycast(intr, Rk, tk, trunc, [size] * 3, vo, vm, nm, wrap, cm, co)
+            outs.append((vm, nm, cm))
+        (a, b, c_), (a2, b2, c2) = outs
+        assert same(a, a2) and same(b, b2) and same(c_[..., :3], c2[..., :3]), seed
+        hit = np.isfinite(a[:rows])
+        g = np.floor(np.stack([a[:rows], a[rows: 2 * rows], a[2 * rows:]], -1) / cell)
+        border = hit & ((g <= 0) | (g >= N - 1)).any(axis=-1)
+        assert same(c_[..., 3][~border], c2[..., 3][~border])
+        pred = (Rk, tk, a, b)
+    # one ICP reduction of the last frame's maps against the last prediction, from a perturbed pose
+    Rp, tp, vprev, nprev = pred
+    Rc = (random_rotation(rng, 0.03) @ Rp).astype(np.float32)
+    tc = (tp + rng.uniform(-0.02, 0.02, 3)).astype(np.float32)
+    th = float(np.sin(np.float32(20.0 * 3.14159265 / 180.0)))
+    Ao, bo, ro = O.icp_step(Rc, tc, maps[3][0], maps[3][1], O.mat33_inverse(Rp), tp, intr, vprev, nprev, 0.10, th, 0)
+    Ar, br, rr = R.icp_step(Rc, tc, maps[3][0], maps[3][1], O.mat33_inverse(Rp), tp, intr, vprev, nprev, 0.10, th)
+    assert same(Ao, Ar) and same(bo, br) and same(ro, rr), seed
+    # extraction of a random box, then a slab clear on both copies
+    lo = [int(v) for v in rng.integers(0, N // 2, 3)]
+    hi = [int(min(N, l + rng.integers(4, N))) for l in lo]
+    real = [int(v) for v in rng.integers(-3 * N, 3 * N, 3)]
+    sub = int(rng.choice([1, 1, 2]))
+    po = O.extract_cloud_slice(vo, [size] * 3, 600000, wrap, co, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], sub, real)
+    pr = R.extract_cloud_slice(vr, [size] * 3, 600000, wrap, cr, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], sub, real)
+    assert len(po) == len(pr) and _point_set(po) == _point_set(pr), (seed, len(po), len(pr))
+    if N % 32:
+        return   # the reference's clear kernels have no bounds checks (its VOLUME is 512): at a side length that is no multiple of their
+                 # block shape they write past the volume (the emulator's guard zones report it); the oracle and the HIP kernel are defined there
+    axis, back = int(rng.integers(0, 3)), bool(rng.integers(0, 2))
+    cur = int(rng.integers(-2 * N, 2 * N))
+    delta = cur + int(rng.integers(1, 20)) * (-1 if back else 1)
+    for vol_o, vol_r in ((vo, vr), (co.view(np.uint32).reshape(N, N, N), cr.view(np.uint32).reshape(N, N, N))):
+        O.clear_volume(vol_o, axis, back, cur, delta)
+        R.clear_volume(vol_r, axis, back, cur, delta)
+        assert same(vol_o, vol_r), (seed, axis, back, cur, delta)
