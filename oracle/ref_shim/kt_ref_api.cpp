@@ -19,6 +19,10 @@ template <class T> struct Img : DeviceArray2D<T> {
     Img(int rows, int cols) : DeviceArray2D<T>(rows, cols) {}
     Img(int rows, int cols, const void* host) : DeviceArray2D<T>(rows, cols) { this->upload(host, (size_t)cols * sizeof(T), rows, cols); }
     void get(void* host) const { this->download(host, (size_t)this->cols() * sizeof(T)); }
+    /* the DataTerm image is addressed as ONE linear array by both kernels that touch it (reduce.cu:444, :767: corresImg.data[k], k the
+     * pixel index) whatever the row pitch of its allocation: its contents are the first rows * cols entries behind the base pointer */
+    void put_linear(const void* host) { cudaSafeCall(cudaMemcpy(this->ptr(), host, (size_t)this->rows() * this->cols() * sizeof(T), cudaMemcpyHostToDevice)); }
+    void get_linear(void* host) const { cudaSafeCall(cudaMemcpy(host, this->ptr(), (size_t)this->rows() * this->cols() * sizeof(T), cudaMemcpyDeviceToHost)); }
 };
 
 Mat33 mat33(const float* m)
@@ -202,16 +206,18 @@ void ktref_rgb_residual(float min_scale, const int16_t* dIdx, const int16_t* dId
     Img<short> gx(rows, cols, dIdx), gy(rows, cols, dIdy);
     Img<float> ld(rows, cols, last_depth), nd(rows, cols, next_depth);
     Img<unsigned char> li(rows, cols, last_image), ni(rows, cols, next_image);
-    Img<DataTerm> c(rows, cols, corres);
+    Img<DataTerm> c(rows, cols);
+    c.put_linear(corres);
     DeviceArray<int2> sum(MAX_THREADS);                /* RGBDOdometry.cpp:45-47 */
     computeRgbResidual(min_scale, gx, gy, ld, nd, li, ni, c, sum, max_depth_delta, f3(kt), mat33(krkinv->m), *sigma_sum, *count, threads, blocks);
-    c.get(corres);
+    c.get_linear(corres);
 }
 
 void ktref_rgb_step(const void* corres, float sigma, const float* cloud_xyz, float fx, float fy, const int16_t* dIdx, const int16_t* dIdy,
                     float sobel_scale, int cols, int rows, int threads, int blocks, float A[36], float b[6])
 {
-    Img<DataTerm> c(rows, cols, corres);
+    Img<DataTerm> c(rows, cols);
+    c.put_linear(corres);
     Img<float3> cl(rows, cols, cloud_xyz);
     Img<short> gx(rows, cols, dIdx), gy(rows, cols, dIdy);
     DeviceArray<JtJJtrSE3> sum(MAX_THREADS), out(1);

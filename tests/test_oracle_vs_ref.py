@@ -450,3 +450,92 @@ def test_randomized_sweep(oracle_mod, R, seed):
         O.clear_volume(vol_o, axis, back, cur, delta)
         R.clear_volume(vol_r, axis, back, cur, delta)
         assert same(vol_o, vol_r), (seed, axis, back, cur, delta)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomized_sweep_image_and_rgbd(oracle_mod, R, seed):
+    """Seeded random configurations of the image side: vertex / normal maps under random intrinsics and rigid transforms (large
+    rotations, translations of metres), the 2x2 map down-sampling, the view products with random light positions and poses, and the RGB-D
+    residual + Jacobian reduction at a random pyramid level with random increments -- bit for bit."""
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr
+    O = oracle_mod
+    rng = np.random.default_rng(7000 + seed)
+    cols, rows = [(160, 120), (200, 150), (136, 104), (320, 240)][seed % 4]
+    cam = synth.Camera.small(cols, rows)
+    scene = synth.Scene(["room", "wall", "farwall"][seed % 3], seed=1234 + seed)
+    base = synth.orbit_trajectory(40)
+    i0 = int(rng.integers(0, 38))
+    (d0, c0), (d1, c1) = [synth.render(scene, cam, *base[i0 + k], noise_mm=float(rng.choice([0.0, 2.0])), rng=rng) for k in (0, 1)]
+    d0, d1 = _holes(d0, rng, 0.02), _holes(d1, rng, float(rng.choice([0.0, 0.05])))
+    # intrinsics off the nominal ones (principal point off-centre, unequal focal lengths)
+    intr = OIntr(cam.fx * float(rng.uniform(0.8, 1.3)), cam.fy * float(rng.uniform(0.8, 1.3)), cam.cx + float(rng.uniform(-20, 20)), cam.cy + float(rng.uniform(-15, 15)))
+    lvl = intr.level(int(rng.integers(0, 3)))
+    fo = O.bilateral_filter(d0)
+    depth_l = fo
+    for _ in range(int(round(np.log2(intr.fx / lvl.fx)))):
+        depth_l = O.pyr_down(depth_l)
+    assert same(depth_l, (lambda x: x)(depth_l))
+    v = O.create_vmap(lvl, depth_l)
+    assert same(v, R.create_vmap(lvl, depth_l))
+    n = O.create_nmap(v)
+    assert same(n, R.create_nmap(v))
+    Rm = random_rotation(rng, 2.5)
+    t = rng.uniform(-3, 3, 3).astype(np.float32)
+    a, b = O.transform_maps(v, n, Rm, t)
+    c, d = R.transform_maps(v, n, Rm, t)
+    assert same(a, c) and same(b, d)
+    if v.shape[1] % 2 == 0 and (v.shape[0] // 3) % 2 == 0:
+        assert same(O.resize_map(a, False), R.resize_map(a, False)) and same(O.resize_map(b, True), R.resize_map(b, True))
+    # view products from the transformed maps
+    rows_l, cols_l = v.shape[0] // 3, v.shape[1]
+    colimg = rng.integers(0, 256, (rows_l, cols_l, 4)).astype(np.uint8)
+    light = rng.uniform(-20, 20, 3).astype(np.float32)
+    ia, ib = O.generate_image(a, b, colimg, light)
+    ic, id_ = R.generate_image(a, b, colimg, light)
+    assert same(ia, ic) and same(ib, id_)
+    Rinv = O.mat33_inverse(random_rotation(rng, 0.3))
+    tt = rng.uniform(-0.5, 0.5, 3).astype(np.float32)
+    # (the camera-frame maps: a depth behind the camera or beyond 65.5 m converts to unsigned short differently on x86 than CUDA's saturating cvt)
+    assert same(O.generate_depth(Rinv, tt, v, n), R.generate_depth(Rinv, tt, v, n, 6.0))
+    # RGB-D pyramids, residual and step at a random level
+    level = int(rng.integers(0, 3))
+    pyr = []
+    for dd, rgb in ((d0, c0), (d1, c1)):
+        dm, it = O.depth_to_metres(dd, 6000), O.bgr_to_intensity(rgb)
+        assert same(dm, R.depth_to_metres(dd, 6000)) and same(it, R.bgr_to_intensity(rgb))
+        for _ in range(level):
+            if dm.shape[0] % 2 or dm.shape[1] % 2:
+                break
+            dm2, it2 = O.pyr_down_gauss_f32(dm), O.pyr_down_gauss_u8(it)
+            assert same(dm2, R.pyr_down_gauss_f32(dm)) and same(it2, R.pyr_down_gauss_u8(it))
+            dm, it = dm2, it2
+        pyr.append((dm, it))
+    (ld, li), (nd, ni) = pyr
+    if ld.shape != nd.shape:
+        return
+    f = ld.shape[1] / float(cols)
+    fx, fy, cx, cy = intr.fx * f, intr.fy * f, intr.cx * f, intr.cy * f
+    dx, dy = O.derivative_images(ni)
+    dxr, dyr = R.derivative_images(ni)
+    assert same(dx, dxr) and same(dy, dyr)
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
+    Rinc = O.rodrigues(rng.uniform(-0.01, 0.01, 3))
+    krkinv = (K @ Rinc @ np.linalg.inv(K)).astype(np.float32)
+    kt = (K @ rng.uniform(-0.01, 0.01, 3)).astype(np.float32)
+    min_scale = (np.float32(rng.choice([12, 5, 3, 1])) / np.float32(0.125)) ** 2
+    co_, so, no = O.rgb_residual(min_scale, dx, dy, ld, nd, li, ni, 0.07, kt, krkinv)
+    cr_, sr, nr = R.rgb_residual(min_scale, dx, dy, ld, nd, li, ni, 0.07, kt, krkinv)
+    assert (so, no) == (sr, nr), seed
+    assert np.array_equal(co_["valid"], cr_["valid"] != 0)
+    m = co_["valid"] != 0
+    for f_ in ("zero", "one", "diff"):
+        assert same(co_[f_][m], cr_[f_][m])
+    if no == 0:
+        return
+    cloud = O.project_to_cloud(ld, fx, fy, cx, cy, 0)
+    assert same(cloud, R.project_to_cloud(ld, fx, fy, cx, cy, 0))
+    sigma = float(np.sqrt(np.float32(no))) if rng.integers(0, 2) else -1.0
+    Ao, bo = O.rgb_step(co_, sigma, cloud, fx, fy, dx, dy, 0.125, 0)
+    Ar, br = R.rgb_step(cr_, sigma, cloud, fx, fy, dx, dy, 0.125)
+    assert same(Ao, Ar) and same(bo, br), (seed, Ao - Ar, bo - br)
