@@ -658,9 +658,10 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
                 // 1e-4, 0 / 0, a NaN weight -- the IEEE divisions run (wave-uniform branch, rare).
                 const float Wrkc = b.rec[u].wrkc;
                 const float den = weight_prev + Wrkc;
-                const float nx = __builtin_fmaf((float)(c & 0xffu), weight_prev, Wrkc * (float)(rgbf & 0xffu));
-                const float ny = __builtin_fmaf((float)((c >> 8) & 0xffu), weight_prev, Wrkc * (float)((rgbf >> 8) & 0xffu));
-                const float nz = __builtin_fmaf((float)((c >> 16) & 0xffu), weight_prev, Wrkc * (float)((rgbf >> 16) & 0xffu));
+                // numerators c_prev * W + Wrkc * c_new: the SECOND product is the fused one (oracle/_ref pins it at a .5 tie of the quotient)
+                const float nx = __builtin_fmaf(Wrkc, (float)(rgbf & 0xffu), (float)(c & 0xffu) * weight_prev);
+                const float ny = __builtin_fmaf(Wrkc, (float)((rgbf >> 8) & 0xffu), (float)((c >> 8) & 0xffu) * weight_prev);
+                const float nz = __builtin_fmaf(Wrkc, (float)((rgbf >> 16) & 0xffu), (float)((c >> 16) & 0xffu) * weight_prev);
                 const float rden = __builtin_amdgcn_rcpf(den);
                 float kx = __builtin_rintf(nx * rden), ky = __builtin_rintf(ny * rden), kz = __builtin_rintf(nz * rden);
                 const float lim = 0.4999f * den;

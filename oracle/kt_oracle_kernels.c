@@ -803,9 +803,12 @@ long long kto_integrate_tsdf(const uint16_t* depth_raw, int cols, int rows, kto_
                         if ((!kto_isnan(ncurr_x) && !no_color) || (pc[0] == 0 && pc[1] == 0 && pc[2] == 0)) {
                             const float Wrkc = (angle_color ? fminf(1.0f, ncurr_z / KTO_RGB_VIEW_ANGLE_WEIGHT) : 1.0f) * 2.0f;
                             const uint8_t* rgb = &colors[3 * (coo_y * cols + coo_x)];
-                            float new_x = fmaf((float)pc[0], weight_prev, Wrkc * (float)rgb[0]) / (weight_prev + Wrkc);
-                            float new_y = fmaf((float)pc[1], weight_prev, Wrkc * (float)rgb[1]) / (weight_prev + Wrkc);
-                            float new_z = fmaf((float)pc[2], weight_prev, Wrkc * (float)rgb[2]) / (weight_prev + Wrkc);
+                            /* (c_prev * W + Wrkc * c_new) / (W + Wrkc), tsdf_volume.cu:627-629: of the two products it is the SECOND that the
+                             * compiler fuses into the addition (the first is rounded).  Only a quotient within an ulp of a .5 tie can tell:
+                             * one voxel in ~600 random configurations (tests/tools/deep_pin.py seeds 247, 492 pinned it against oracle/_ref). */
+                            float new_x = fmaf(Wrkc, (float)rgb[0], (float)pc[0] * weight_prev) / (weight_prev + Wrkc);
+                            float new_y = fmaf(Wrkc, (float)rgb[1], (float)pc[1] * weight_prev) / (weight_prev + Wrkc);
+                            float new_z = fmaf(Wrkc, (float)rgb[2], (float)pc[2] * weight_prev) / (weight_prev + Wrkc);
                             pc[0] = (uint8_t)imin(255, imax(0, kto_f2i_rn(new_x)));
                             pc[1] = (uint8_t)imin(255, imax(0, kto_f2i_rn(new_y)));
                             pc[2] = (uint8_t)imin(255, imax(0, kto_f2i_rn(new_z)));
