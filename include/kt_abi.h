@@ -142,7 +142,11 @@ int kt_rgb_step(kt_ctx* ctx, const kt_dataterm* corres_img, float sigma, const f
 /* initVolume / initColorVolume  internal.h:353,417 / tsdf_volume.cu:468-479, 76-87 */
 int kt_init_volume(kt_ctx* ctx, int16_t* volume, int N);
 int kt_init_color_volume(kt_ctx* ctx, uint8_t* color_volume, int N);
-/* integrateTsdfVolume  internal.h:404-409 / tsdf_volume.cu:642-674.  colors = rgb24, nmap_curr = level-0 normal map */
+/* integrateTsdfVolume  internal.h:404-409 / tsdf_volume.cu:642-674.  colors = rgb24, nmap_curr = level-0 normal map.
+ * Precondition on the volume pair: a state these kernels can leave behind, i.e. grown from kt_init_volume / kt_init_color_volume by
+ * integrate and the clears -- weight bytes <= 128 (MAX_WEIGHT).  Any tsdf word and any colour is followed bit for bit
+ * (tests/test_gpu_sweep.py::test_random_state_integrate_hip); a foreign volume with a weight byte above 128 keeps that weight where the
+ * reference would clamp it to 128 (tests/tools/state_probe.py). */
 int kt_integrate_tsdf(kt_ctx* ctx, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
                       const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
                       int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,

@@ -56,3 +56,21 @@ def random_rotation(rng, max_angle):
     axis = rng.normal(size=3)
     axis /= np.linalg.norm(axis)
     return oracle.rodrigues(axis * rng.uniform(0, max_angle)).astype(np.float32)
+
+
+def random_volume_state(rng, N, reachable):
+    """A volume in a random STATE instead of one grown from a cleared volume: every tsdf word, colour and weight drawn at random, so that
+    one integrate call puts a few hundred thousand different (stored value, weight, pixel colour, colour weight) combinations through the
+    running averages and their quantisation (pack truncation, the .5 ties of the colour bytes).  `reachable` restricts the draw to
+    states the reference's own kernels can leave behind (weights <= 128, a voxel of weight 0 holds colour 0, no raw -32768)."""
+    vol = rng.integers(-32767 if reachable else -32768, 32768, (N, N, N)).astype(np.int16)
+    vol[rng.random((N, N, N)) < 0.3] = 32767          # saturated free space, the common state
+    col = rng.integers(0, 256, (N, N, N, 4)).astype(np.uint8)
+    w = rng.integers(0, 129 if reachable else 256, (N, N, N))
+    w[rng.random((N, N, N)) < 0.2] = 128
+    col[..., 3] = w
+    if reachable:
+        col[w == 0] = 0
+    else:
+        col[rng.random((N, N, N)) < 0.05, :3] = 0     # the "stored colour is black" branch of tsdf_volume.cu:623
+    return vol, col

@@ -185,3 +185,42 @@ def test_randomized_sweep_hip_image_and_rgbd(ctx, oracle_mod, seed):
     Ao, bo = O.rgb_step(co_, sigma, cloud, fx, fy, dx, dy, 0.125, 0)
     Ah, bh = H.rgb_step(ch_, sigma, cloud, fx, fy, dx, dy, 0.125)
     assert _same(np.asarray(Ao, np.float32), np.asarray(Ah, np.float32)) and _same(np.asarray(bo, np.float32), np.asarray(bh, np.float32)), seed
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_state_integrate_hip(ctx, oracle_mod, seed):
+    """integrate into volumes in random STATES (conftest.random_volume_state, the draw restricted to states the kernels can leave behind:
+    weights <= 128, colour 0 where the weight is 0 -- the two invariants the HIP kernel's weight clamp and same-colour shortcut lean on,
+    kt_abi.h): a few hundred thousand (stored value, weight, pixel colour, colour weight) combinations per call through the running
+    averages and their quantisation.  HIP == oracle, every tsdf word and colour byte."""
+    from conftest import random_volume_state
+    from hip_kernels import HipKernels
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr
+    O, H = oracle_mod, HipKernels(ctx)
+    rng = np.random.default_rng(9000 + seed)
+    cols, rows = [(160, 120), (200, 150)][seed % 2]
+    N = int(rng.choice([64, 72, 96]))
+    size = float(rng.choice([4.0, 6.0]))
+    cam = synth.Camera.small(cols, rows)
+    scene = synth.Scene(["room", "farwall", "wall"][seed % 3], seed=77 + seed)
+    base = synth.orbit_trajectory(40)
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    trunc = max(0.06 if size == 6.0 else max(0.01, size / 100), 2.1 * size / N)
+    vo, co = random_volume_state(rng, N, reachable=True)
+    vh, ch = vo.copy(), co.copy()
+    wrap = [int(v) for v in rng.integers(0, N, 3)]
+    for k in range(3):
+        Rm, c0 = base[int(rng.integers(0, 40))]
+        d, c = synth.render(scene, cam, Rm, c0, noise_mm=1.5, rng=rng)
+        c = rng.integers(0, 256, c.shape).astype(np.uint8) if k == 0 else c
+        Rk = (random_rotation(rng, 0.3) @ np.asarray(Rm, np.float32)).astype(np.float32)
+        tk = (np.asarray(c0, np.float32) + np.float32(size / 2) + rng.uniform(-0.2, 0.2, 3)).astype(np.float32)
+        n = O.create_nmap(O.create_vmap(intr, O.bilateral_filter(d)))
+        Rinv = O.mat33_inverse(Rk)
+        angle = bool(rng.integers(0, 2))
+        U, so = O.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vo, wrap, co, c, n, angle)
+        sh = H.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vh, wrap, ch, c, n, angle)
+        assert U > 4000
+        bad_v, bad_c = np.argwhere(vo != vh), np.argwhere((co != ch).any(axis=-1))
+        assert _same(so, sh) and len(bad_v) == 0 and len(bad_c) == 0, (seed, k, len(bad_v), len(bad_c), bad_v[:3].tolist(), bad_c[:3].tolist())

@@ -15,7 +15,7 @@ host-side code of the path (Eigen / OpenCV), see DESIGN.md section 5.
 import numpy as np
 import pytest
 
-from conftest import random_rotation
+from conftest import random_rotation, random_volume_state
 
 pytestmark = pytest.mark.skipif(not __import__("oracle.ref", fromlist=["available"]).available(), reason="oracle/_ref not built and /root/reference absent")
 
@@ -560,3 +560,37 @@ def test_randomized_sweep_image_and_rgbd(oracle_mod, R, seed):
     Ao, bo = O.rgb_step(co_, sigma, cloud, fx, fy, dx, dy, 0.125, 0)
     Ar, br = R.rgb_step(cr_, sigma, cloud, fx, fy, dx, dy, 0.125)
     assert same(Ao, Ar) and same(bo, br), (seed, Ao - Ar, bo - br)
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_state_integrate(oracle_mod, R, seed):
+    """integrate into volumes in random states (see conftest.random_volume_state; both the reachable and the unrestricted draw): oracle == reference,
+    every tsdf word and colour byte."""
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr
+    O = oracle_mod
+    rng = np.random.default_rng(9000 + seed)
+    cols, rows = [(160, 120), (200, 150)][seed % 2]
+    N = int(rng.choice([64, 72, 96]))
+    size = float(rng.choice([4.0, 6.0]))
+    cam = synth.Camera.small(cols, rows)
+    scene = synth.Scene(["room", "farwall", "wall"][seed % 3], seed=77 + seed)
+    base = synth.orbit_trajectory(40)
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    trunc = max(0.06 if size == 6.0 else max(0.01, size / 100), 2.1 * size / N)
+    vo, co = random_volume_state(rng, N, reachable=bool(seed % 2))
+    vr, cr = vo.copy(), co.copy()
+    wrap = [int(v) for v in rng.integers(0, N, 3)]
+    for k in range(3):
+        Rm, c0 = base[int(rng.integers(0, 40))]
+        d, c = synth.render(scene, cam, Rm, c0, noise_mm=1.5, rng=rng)
+        c = rng.integers(0, 256, c.shape).astype(np.uint8) if k == 0 else c     # random pixel colours against random stored ones
+        Rk = (random_rotation(rng, 0.3) @ np.asarray(Rm, np.float32)).astype(np.float32)
+        tk = (np.asarray(c0, np.float32) + np.float32(size / 2) + rng.uniform(-0.2, 0.2, 3)).astype(np.float32)
+        n = O.create_nmap(O.create_vmap(intr, O.bilateral_filter(d)))
+        Rinv = O.mat33_inverse(Rk)
+        angle = bool(rng.integers(0, 2))
+        U, so = O.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vo, wrap, co, c, n, angle)
+        sr = R.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vr, wrap, cr, c, n, angle)
+        assert U > 4000
+        assert same(so, sr) and same(vo, vr) and same(co, cr), (seed, k, int((vo != vr).sum()), int((co != cr).any(axis=-1).sum()))
