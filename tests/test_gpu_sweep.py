@@ -224,3 +224,56 @@ def test_random_state_integrate_hip(ctx, oracle_mod, seed):
         assert U > 4000
         bad_v, bad_c = np.argwhere(vo != vh), np.argwhere((co != ch).any(axis=-1))
         assert _same(so, sh) and len(bad_v) == 0 and len(bad_c) == 0, (seed, k, len(bad_v), len(bad_c), bad_v[:3].tolist(), bad_c[:3].tolist())
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_state_raycast_and_extract_hip(ctx, oracle_mod, seed):
+    """raycast and extraction on volumes in random states (one frame integrated on top of conftest.random_volume_state): rays meet zero
+    crossings between arbitrary pairs of stored values, weights and colours.  HIP == oracle (the CPU twin of this test holds the oracle
+    against the reference's kernels on the same cases)."""
+    from conftest import random_volume_state
+    from hip_kernels import HipKernels
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr
+    O, H = oracle_mod, HipKernels(ctx)
+    rng = np.random.default_rng(11000 + seed)
+    cols, rows = [(160, 120), (136, 104)][seed % 2]
+    N = int(rng.choice([48, 64]))
+    size = float(rng.choice([4.0, 6.0]))
+    cam = synth.Camera.small(cols, rows)
+    scene = synth.Scene(["room", "wall"][seed % 2], seed=3 + seed)
+    base = synth.orbit_trajectory(40)
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    trunc = max(0.06 if size == 6.0 else max(0.01, size / 100), 2.1 * size / N)
+    vo, co = random_volume_state(rng, N, reachable=bool(seed % 2))
+    if seed % 4 < 2:
+        vo[rng.random((N, N, N)) < 0.5] = 32767
+    wrap = [int(v) for v in rng.integers(0, N, 3)]
+    Rm, c0 = base[int(rng.integers(0, 40))]
+    d, c = synth.render(scene, cam, Rm, c0, noise_mm=1.5, rng=rng)
+    Rk = (random_rotation(rng, 0.3) @ np.asarray(Rm, np.float32)).astype(np.float32)
+    tk = (np.asarray(c0, np.float32) + np.float32(size / 2) + rng.uniform(-0.2, 0.2, 3)).astype(np.float32)
+    n = O.create_nmap(O.create_vmap(intr, O.bilateral_filter(d)))
+    O.integrate_tsdf(d, intr, [size] * 3, O.mat33_inverse(Rk), tk, trunc, vo, wrap, co, c, n, True)   # (states above weight 128: raycast and extraction only)
+    vh, ch = vo.copy(), co.copy()
+    hits = 0
+    for _ in range(3):
+        Rq = (random_rotation(rng, 0.6) @ Rk).astype(np.float32)
+        tq = (tk + rng.uniform(-0.5, 0.5, 3)).astype(np.float32)
+        outs = []
+        for M, vol, col in ((O, vo, co), (H, vh, ch)):
+            vm, nm = np.full((3 * rows, cols), 7.0, np.float32), np.full((3 * rows, cols), -3.0, np.float32)
+            cm = np.full((rows, cols, 4), 9, np.uint8)
+            M.raycast(intr, Rq, tq, trunc, [size] * 3, vol, vm, nm, wrap, cm, col)
+            outs.append((vm, nm, cm))
+        (a, b, c_), (a2, b2, c2) = outs
+        hits += int(np.isfinite(a[:rows]).sum())
+        assert _same_maps(a, a2) and _same_maps(b, b2) and _same(c_, c2), (seed, "raycast", int((a.view(np.uint32) != a2.view(np.uint32)).sum()),
+                                                                           int((b.view(np.uint32) != b2.view(np.uint32)).sum()), int((c_ != c2).sum()))
+    assert hits > 500
+    lo = [int(v) for v in rng.integers(0, N // 2, 3)]
+    hi = [int(min(N, l + rng.integers(4, N))) for l in lo]
+    real = [int(v) for v in rng.integers(-3 * N, 3 * N, 3)]
+    po = O.extract_cloud_slice(vo, [size] * 3, 2000000, wrap, co, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], 1, real)
+    ph = H.extract_cloud_slice(vh, [size] * 3, 2000000, wrap, ch, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], 1, real)
+    assert len(po) == len(ph) and _point_set(po) == _point_set(ph), (seed, len(po), len(ph))

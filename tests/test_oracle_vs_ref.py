@@ -594,3 +594,60 @@ def test_random_state_integrate(oracle_mod, R, seed):
         sr = R.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vr, wrap, cr, c, n, angle)
         assert U > 4000
         assert same(so, sr) and same(vo, vr) and same(co, cr), (seed, k, int((vo != vr).sum()), int((co != cr).any(axis=-1).sum()))
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_state_raycast_and_extract(oracle_mod, R, seed):
+    """raycast and extraction on volumes in random states (conftest.random_volume_state with one frame integrated on top, so that rays meet
+    zero crossings between arbitrary pairs of stored values, weights and colours -- the trilinear interpolation, the crossing refinement
+    and the colour / heat bytes see value combinations a volume grown from empty never holds): oracle == reference."""
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr
+    O = oracle_mod
+    rng = np.random.default_rng(11000 + seed)
+    cols, rows = [(160, 120), (136, 104)][seed % 2]
+    N = int(rng.choice([48, 64]))
+    size = float(rng.choice([4.0, 6.0]))
+    cam = synth.Camera.small(cols, rows)
+    scene = synth.Scene(["room", "wall"][seed % 2], seed=3 + seed)
+    base = synth.orbit_trajectory(40)
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    trunc = max(0.06 if size == 6.0 else max(0.01, size / 100), 2.1 * size / N)
+    vo, co = random_volume_state(rng, N, reachable=bool(seed % 2))
+    if seed % 4 < 2:
+        vo[rng.random((N, N, N)) < 0.5] = 32767        # sparser: rays travel before they meet a crossing
+    wrap = [int(v) for v in rng.integers(0, N, 3)]
+    Rm, c0 = base[int(rng.integers(0, 40))]
+    d, c = synth.render(scene, cam, Rm, c0, noise_mm=1.5, rng=rng)
+    Rk = (random_rotation(rng, 0.3) @ np.asarray(Rm, np.float32)).astype(np.float32)
+    tk = (np.asarray(c0, np.float32) + np.float32(size / 2) + rng.uniform(-0.2, 0.2, 3)).astype(np.float32)
+    n = O.create_nmap(O.create_vmap(intr, O.bilateral_filter(d)))
+    O.integrate_tsdf(d, intr, [size] * 3, O.mat33_inverse(Rk), tk, trunc, vo, wrap, co, c, n, True)
+    vr, cr = vo.copy(), co.copy()
+    cell = np.float32(size / N)
+    hits = 0
+    for _ in range(3):
+        Rq = (random_rotation(rng, 0.6) @ Rk).astype(np.float32)
+        tq = (tk + rng.uniform(-0.5, 0.5, 3)).astype(np.float32)
+        outs = []
+        for M, vol, col in ((O, vo, co), (R, vr, cr)):
+            vm, nm = np.full((3 * rows, cols), 7.0, np.float32), np.full((3 * rows, cols), -3.0, np.float32)
+            cm = np.full((rows, cols, 4), 9, np.uint8)
+            M.raycast(intr, Rq, tq, trunc, [size] * 3, vol, vm, nm, wrap, cm, col)
+            outs.append((vm, nm, cm))
+        (a, b, c_), (a2, b2, c2) = outs
+        hits += int(np.isfinite(a[:rows]).sum())   # (a camera inside a negative voxel with positive neighbours sees nothing)
+        assert same(a, a2) and same(b, b2) and same(c_[..., :3], c2[..., :3]), seed
+        hit = np.isfinite(a[:rows])
+        g = np.floor(np.stack([a[:rows], a[rows: 2 * rows], a[2 * rows:]], -1) / cell)
+        border = hit & ((g <= 0) | (g >= N - 1)).any(axis=-1)
+        assert same(c_[..., 3][~border], c2[..., 3][~border])
+    assert hits > 500
+    lo = [int(v) for v in rng.integers(0, N // 2, 3)]
+    hi = [int(min(N, l + rng.integers(4, N))) for l in lo]
+    if not _extract_geometry_ok(N, lo, hi):
+        lo, hi = [0, 0, lo[2]], [N, N, hi[2]]
+    real = [int(v) for v in rng.integers(-3 * N, 3 * N, 3)]
+    po = O.extract_cloud_slice(vo, [size] * 3, 2000000, wrap, co, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], 1, real)
+    pr = R.extract_cloud_slice(vr, [size] * 3, 2000000, wrap, cr, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], 1, real)
+    assert len(po) > 1000 and len(po) == len(pr) and _point_set(po) == _point_set(pr), (seed, len(po), len(pr))
