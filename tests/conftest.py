@@ -74,3 +74,20 @@ def random_volume_state(rng, N, reachable):
     else:
         col[rng.random((N, N, N)) < 0.05, :3] = 0     # the "stored colour is black" branch of tsdf_volume.cu:623
     return vol, col
+
+
+def perturbed_maps(rng, v, n, frac=0.2):
+    """Vertex / normal maps (3 planes of rows) with a fraction of the pixels replaced by random vertices (metres away from their
+    neighbours), random un-normalised normals and NaN holes: the correspondence search of the ICP kernels then meets every branch of its
+    validity tests next to every other."""
+    rows = v.shape[0] // 3
+    v, n = v.copy(), n.copy()
+    for arr, scale in ((v, 3.0), (n, 1.5)):
+        m = rng.random((rows, v.shape[1])) < frac
+        for k in range(3):
+            arr[k * rows:(k + 1) * rows][m] = rng.uniform(-scale, scale, int(m.sum())).astype(np.float32)
+    hole = rng.random((rows, v.shape[1])) < frac / 4
+    v[:rows][hole] = np.nan
+    hole = rng.random((rows, v.shape[1])) < frac / 4
+    n[:rows][hole] = np.nan
+    return v, n

@@ -277,3 +277,38 @@ def test_random_state_raycast_and_extract_hip(ctx, oracle_mod, seed):
     po = O.extract_cloud_slice(vo, [size] * 3, 2000000, wrap, co, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], 1, real)
     ph = H.extract_cloud_slice(vh, [size] * 3, 2000000, wrap, ch, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], 1, real)
     assert len(po) == len(ph) and _point_set(po) == _point_set(ph), (seed, len(po), len(ph))
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_perturbed_maps_icp_hip(ctx, oracle_mod, seed):
+    """The ICP reduction on perturbed maps (conftest.perturbed_maps: random vertices, un-normalised normals, NaN holes) at small and large
+    relative poses and several thresholds: HIP == oracle in A, b and the residual pair (CPU twin: oracle == reference)."""
+    from conftest import perturbed_maps
+    from hip_kernels import HipKernels
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr
+    O, H = oracle_mod, HipKernels(ctx)
+    rng = np.random.default_rng(13000 + seed)
+    cols, rows = [(160, 120), (200, 150), (320, 240)][seed % 3]
+    cam = synth.Camera.small(cols, rows)
+    scene = synth.Scene(["room", "wall", "farwall"][seed % 3], seed=9 + seed)
+    base = synth.orbit_trajectory(40)
+    i0 = int(rng.integers(0, 38))
+    intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+    ms = []
+    for k in (0, 1):
+        d, _ = synth.render(scene, cam, *base[i0 + k], noise_mm=1.0, rng=rng)
+        v = O.create_vmap(intr, O.bilateral_filter(d))
+        ms.append(perturbed_maps(rng, v, O.create_nmap(v), float(rng.choice([0.05, 0.3]))))
+    (vc, nc), (vp, npv) = ms
+    Rp = random_rotation(rng, 0.4)
+    tp = rng.uniform(-0.5, 0.5, 3).astype(np.float32)
+    vg, ng = O.transform_maps(vp, npv, Rp, tp)
+    for mag in (0.01, 0.2):
+        Rc = (random_rotation(rng, mag) @ Rp).astype(np.float32)
+        tc = (tp + rng.uniform(-mag, mag, 3)).astype(np.float32)
+        dist, th = float(rng.choice([0.10, 0.5, 5.0])), float(np.sin(np.float32(rng.choice([20.0, 60.0]) * 3.14159265 / 180.0)))
+        Ao, bo, ro = O.icp_step(Rc, tc, vc, nc, O.mat33_inverse(Rp), tp, intr, vg, ng, dist, th, 0)
+        Ah, bh, rh = H.icp_step(Rc, tc, vc, nc, O.mat33_inverse(Rp), tp, intr, vg, ng, dist, th)
+        f = lambda x: np.asarray(x, np.float32)
+        assert _same_maps(f(Ao), f(Ah)) and _same_maps(f(bo), f(bh)) and _same_maps(f(ro), f(rh)), (seed, mag, f(ro), f(rh))
