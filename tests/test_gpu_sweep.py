@@ -312,3 +312,55 @@ def test_perturbed_maps_icp_hip(ctx, oracle_mod, seed):
         Ah, bh, rh = H.icp_step(Rc, tc, vc, nc, O.mat33_inverse(Rp), tp, intr, vg, ng, dist, th)
         f = lambda x: np.asarray(x, np.float32)
         assert _same_maps(f(Ao), f(Ah)) and _same_maps(f(bo), f(bh)) and _same_maps(f(ro), f(rh)), (seed, mag, f(ro), f(rh))
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_noise_images_rgbd_hip(ctx, oracle_mod, seed):
+    """The photometric side on noise images (random bytes or 4x4 plateaus, zeroed pixels), depths with holes, steps and -- in one case --
+    NaNs, small and large increments: residual search, sigma, count and the Jacobian reduction, HIP == oracle (CPU twin: oracle ==
+    reference)."""
+    from hip_kernels import HipKernels
+    O, H = oracle_mod, HipKernels(ctx)
+    rng = np.random.default_rng(15000 + seed)
+    cols, rows = [(160, 120), (80, 60), (320, 240)][seed % 3]
+    fx = fy = 528.0 * cols / 640
+    cx, cy = cols / 2 - 0.5 + float(rng.uniform(-5, 5)), rows / 2 - 0.5 + float(rng.uniform(-5, 5))
+    imgs, deps = [], []
+    for k in range(2):
+        it = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
+        if seed % 2:
+            it = np.repeat(np.repeat(rng.integers(0, 256, (rows // 4, cols // 4)).astype(np.uint8), 4, 0), 4, 1)
+        it[rng.random((rows, cols)) < 0.1] = 0
+        dm = rng.uniform(0.4, 5.0, (rows, cols)).astype(np.float32)
+        dm = np.where(rng.random((rows, cols)) < 0.7, np.float32(1.5) + np.float32(0.3) * np.sin(np.arange(cols, dtype=np.float32) / 9)[None, :], dm).astype(np.float32)
+        dm[rng.random((rows, cols)) < 0.1] = 0
+        if seed == 5:
+            dm[rng.random((rows, cols)) < 0.02] = np.nan
+        imgs.append(it); deps.append(dm)
+    (li, ni), (ld, nd) = imgs, deps
+    dx, dy = O.derivative_images(ni)
+    dxh, dyh = H.derivative_images(ni)
+    assert _same(dx, dxh) and _same(dy, dyh)
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
+    for mag in (0.002, 0.05):
+        Rinc = O.rodrigues(rng.uniform(-mag, mag, 3))
+        krkinv = (K @ Rinc @ np.linalg.inv(K)).astype(np.float32)
+        kt = (K @ rng.uniform(-mag, mag, 3)).astype(np.float32)
+        min_scale = (np.float32(rng.choice([12, 5, 3, 1])) / np.float32(0.125)) ** 2
+        delta = float(rng.choice([0.07, 1.0]))
+        co_, so, no = O.rgb_residual(min_scale, dx, dy, ld, nd, li, ni, delta, kt, krkinv)
+        ch_, sh, nh = H.rgb_residual(min_scale, dx, dy, ld, nd, li, ni, delta, kt, krkinv)
+        assert (so, no) == (sh, nh), (seed, mag, so, sh, no, nh)
+        assert np.array_equal(co_["valid"] != 0, ch_["valid"] != 0)
+        m = co_["valid"] != 0
+        for f_ in ("zero", "one", "diff"):
+            assert _same(co_[f_][m], ch_[f_][m])
+        if no == 0:
+            continue
+        cloud = O.project_to_cloud(ld, fx, fy, cx, cy, 0)
+        assert _same_maps(cloud, H.project_to_cloud(ld, fx, fy, cx, cy, 0))
+        sigma = float(np.sqrt(np.float32(no))) if rng.integers(0, 2) else -1.0
+        Ao, bo = O.rgb_step(co_, sigma, cloud, fx, fy, dx, dy, 0.125, 0)
+        Ah, bh = H.rgb_step(ch_, sigma, cloud, fx, fy, dx, dy, 0.125)
+        f = lambda x: np.asarray(x, np.float32)
+        assert _same_maps(f(Ao), f(Ah)) and _same_maps(f(bo), f(bh)), (seed, mag)

@@ -685,3 +685,53 @@ def test_perturbed_maps_icp(oracle_mod, R, seed):
         Ar, br, rr = R.icp_step(Rc, tc, vc, nc, O.mat33_inverse(Rp), tp, intr, vg, ng, dist, th)
         assert np.asarray(ro).ravel()[1] > 50 or mag > 0.1, (seed, ro)
         assert same(Ao, Ar) and same(bo, br) and same(ro, rr), (seed, mag)
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_noise_images_rgbd(oracle_mod, R, seed):
+    """The photometric side on NOISE: intensity images of random bytes (every pixel passes the gradient threshold, every 4x4 window is
+    non-zero or not at random), depths with random holes and steps, large increments -- residual search, sigma, count and the Jacobian
+    reduction, bit for bit."""
+    O = oracle_mod
+    rng = np.random.default_rng(15000 + seed)
+    cols, rows = [(160, 120), (80, 60), (320, 240)][seed % 3]
+    fx = fy = 528.0 * cols / 640
+    cx, cy = cols / 2 - 0.5 + float(rng.uniform(-5, 5)), rows / 2 - 0.5 + float(rng.uniform(-5, 5))
+    imgs, deps = [], []
+    for k in range(2):
+        it = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
+        if seed % 2:
+            it = np.repeat(np.repeat(rng.integers(0, 256, (rows // 4, cols // 4)).astype(np.uint8), 4, 0), 4, 1)   # 4x4 plateaus: zero gradients too
+        it[rng.random((rows, cols)) < 0.1] = 0
+        dm = rng.uniform(0.4, 5.0, (rows, cols)).astype(np.float32)
+        dm = np.where(rng.random((rows, cols)) < 0.7, np.float32(1.5) + np.float32(0.3) * np.sin(np.arange(cols, dtype=np.float32) / 9)[None, :], dm).astype(np.float32)
+        dm[rng.random((rows, cols)) < 0.1] = 0
+        if seed == 5:
+            dm[rng.random((rows, cols)) < 0.02] = np.nan
+        imgs.append(it); deps.append(dm)
+    (li, ni), (ld, nd) = imgs, deps
+    dx, dy = O.derivative_images(ni)
+    dxr, dyr = R.derivative_images(ni)
+    assert same(dx, dxr) and same(dy, dyr)
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
+    for mag in (0.002, 0.05):
+        Rinc = O.rodrigues(rng.uniform(-mag, mag, 3))
+        krkinv = (K @ Rinc @ np.linalg.inv(K)).astype(np.float32)
+        kt = (K @ rng.uniform(-mag, mag, 3)).astype(np.float32)
+        min_scale = (np.float32(rng.choice([12, 5, 3, 1])) / np.float32(0.125)) ** 2
+        delta = float(rng.choice([0.07, 1.0]))
+        co_, so, no = O.rgb_residual(min_scale, dx, dy, ld, nd, li, ni, delta, kt, krkinv)
+        cr_, sr, nr = R.rgb_residual(min_scale, dx, dy, ld, nd, li, ni, delta, kt, krkinv)
+        assert (so, no) == (sr, nr), (seed, mag, so, sr, no, nr)
+        assert np.array_equal(co_["valid"], cr_["valid"] != 0)
+        m = co_["valid"] != 0
+        for f_ in ("zero", "one", "diff"):
+            assert same(co_[f_][m], cr_[f_][m])
+        if no == 0:
+            continue
+        cloud = O.project_to_cloud(ld, fx, fy, cx, cy, 0)
+        assert same(cloud, R.project_to_cloud(ld, fx, fy, cx, cy, 0))
+        sigma = float(np.sqrt(np.float32(no))) if rng.integers(0, 2) else -1.0
+        Ao, bo = O.rgb_step(co_, sigma, cloud, fx, fy, dx, dy, 0.125, 0)
+        Ar, br = R.rgb_step(cr_, sigma, cloud, fx, fy, dx, dy, 0.125)
+        assert same(Ao, Ar) and same(bo, br), (seed, mag)

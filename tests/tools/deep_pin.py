@@ -1,5 +1,5 @@
 """Runs the randomized oracle-vs-reference sweeps of tests/test_oracle_vs_ref.py over a range of seeds (the pytest run keeps 16 + 12 + 8 + 8 + 8 of
-them): python tests/tools/deep_pin.py <first seed> <last seed + 1>.  Needs /root/reference (oracle/_ref)."""
+them): python tests/tools/deep_pin.py <first seed> <last seed + 1>  (KT_PIN_FROM=k skips the first k families).  Needs /root/reference (oracle/_ref)."""
 import sys, os, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
