@@ -257,7 +257,9 @@ def test_random_state_raycast_and_extract_hip(ctx, oracle_mod, seed):
     O.integrate_tsdf(d, intr, [size] * 3, O.mat33_inverse(Rk), tk, trunc, vo, wrap, co, c, n, True)   # (states above weight 128: raycast and extraction only)
     vh, ch = vo.copy(), co.copy()
     hits = 0
-    for _ in range(3):
+    for view in range(8):
+        if view >= 3 and hits > 500:   # (a camera inside a negative voxel with positive neighbours sees nothing: look again)
+            break
         Rq = (random_rotation(rng, 0.6) @ Rk).astype(np.float32)
         tq = (tk + rng.uniform(-0.5, 0.5, 3)).astype(np.float32)
         outs = []
