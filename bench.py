@@ -206,17 +206,28 @@ def main():
     # without read-ahead), so the same frames are replayed from a reset tracker with the counting kernel variants
     trk.reset()
     trk.enable_counts(True)
-    Us, Ss = [], []
+    Us, Ss, Ls = [], [], []
     for i in range(args.warmup + args.steps):
         step(i, announce_next=False)
         if i >= args.warmup:
             U, S = trk.last_counts()
             Us.append(U)
             Ss.append(S)
+            if len(Ls) < 16:   # lane-steps of the tsdf23 launch = wave batches x 4 z-steps x 64 lanes (diagnostic; drains the GPU)
+                try:
+                    ctx.sync()
+                    dc = trk.debug_counts()
+                    if dc[0] > 0:
+                        Ls.append((dc[0], dc[1] * 4 * 64))
+                except Exception as e:  # noqa: BLE001 -- a diagnostic must not cost the bench line
+                    sys.stderr.write(f"bench: lane-step diagnostic unavailable ({e})\n")
+                    Ls = [None] * 16
     trk.enable_counts(False)
     if trk.num_poses() != args.warmup + args.steps:
         sys.stderr.write(f"bench: the counting replay produced {trk.num_poses()} poses for {args.warmup + args.steps} frames\n")
     U = float(np.mean(Us))
+    Lok = [x for x in Ls if x]
+    lane_eff = round(sum(u for u, _ in Lok) / max(1, sum(l for _, l in Lok)), 4) if Lok else None
     P = cam.cols * cam.rows
     # algorithmic bytes of the tsdf23 launch (DESIGN.md "integrate"): 12 B per updated voxel (2 B tsdf + 4 B colour/weight,
     # read and written) + the per-pixel record gathered by the voxels (16 B, counted once per pixel)
@@ -256,6 +267,9 @@ def main():
         "roofline": {"kernel": "kt_tsdf23_kernel", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                      "frac": achieved / peak, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_tsdf23,
                      "avg_launch_ms": tsdf23_ms, "launches_timed": tsdf23_n, "U_voxels_updated": U, "S_raycast_steps": float(np.mean(Ss)),
+                     # lanes the launch spends per updated voxel (first 16 timed frames): 64-lane wave z-steps over wave-columns of 32 x 2
+                     # voxel columns, profiles/r02_tsdf23_whatif.md
+                     "lane_efficiency": lane_eff,
                      # in the timed region the kernel shares the GPU with the read-ahead stream (next frame's bilateral / pyramid);
                      # the same launch with nothing else running (untimed stage pass below):
                      "avg_launch_ms_alone": stage_all["tsdf23"][0],

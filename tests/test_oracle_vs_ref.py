@@ -495,8 +495,9 @@ def test_randomized_sweep_image_and_rgbd(oracle_mod, R, seed):
     fo = O.bilateral_filter(d0)
     depth_l = fo
     for _ in range(int(round(np.log2(intr.fx / lvl.fx)))):
-        depth_l = O.pyr_down(depth_l)
-    assert same(depth_l, (lambda x: x)(depth_l))
+        nxt = O.pyr_down(depth_l)
+        assert same(nxt, R.pyr_down(depth_l))
+        depth_l = nxt
     v = O.create_vmap(lvl, depth_l)
     assert same(v, R.create_vmap(lvl, depth_l))
     n = O.create_nmap(v)

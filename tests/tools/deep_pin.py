@@ -1,4 +1,4 @@
-"""Runs the randomized oracle-vs-reference sweeps of tests/test_oracle_vs_ref.py over a range of seeds (the pytest run keeps 16 + 12 + 8 + 8 + 8 of
+"""Runs the randomized oracle-vs-reference sweeps of tests/test_oracle_vs_ref.py over a range of seeds (the pytest run keeps 16 + 12 + 8 + 8 + 8 + 6 of
 them): python tests/tools/deep_pin.py <first seed> <last seed + 1>  (KT_PIN_FROM=k skips the first k families).  Needs /root/reference (oracle/_ref)."""
 import sys, os, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ R.build(); R.lib(); O.build(); O.lib()
 bad = []
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 for seed in range(lo, hi):
-    for fn in (T.test_randomized_sweep, T.test_randomized_sweep_image_and_rgbd, T.test_random_state_integrate, T.test_random_state_raycast_and_extract, T.test_perturbed_maps_icp)[int(os.environ.get("KT_PIN_FROM", 0)):]:
+    for fn in (T.test_randomized_sweep, T.test_randomized_sweep_image_and_rgbd, T.test_random_state_integrate, T.test_random_state_raycast_and_extract, T.test_perturbed_maps_icp, T.test_noise_images_rgbd)[int(os.environ.get("KT_PIN_FROM", 0)):]:
         try:
             fn(O, R, seed)
         except AssertionError as e:
