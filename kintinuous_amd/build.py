@@ -81,18 +81,18 @@ def build_host(force: bool = False) -> str:
         return HOST_BIN
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
     # the .klg colour decoder on its own (no HIP dependency): used by the CPU tests
-    for src, out, libs in (("jpeg_tool.cpp", JPEG_TOOL, []), ("klg_tool.cpp", KLG_TOOL, ["-lz"])):
+    for src, out, libs in (("jpeg_tool.cpp", JPEG_TOOL, []), ("klg_tool.cpp", KLG_TOOL, ["-lz", "-pthread"])):
         r = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", os.path.join(HOST_DIR, src), "-o", out] + libs, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{src} build failed:\n{r.stderr}")
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.dirname(_HERE), os.path.join(HOST_DIR, "main.cpp"), "-o", HOST_BIN,
-           "-L", _HERE, "-lkt_hip", "-lz", "-Wl,-rpath,$ORIGIN/../..", "-Wl,-rpath,/opt/rocm/lib"]
+           "-L", _HERE, "-lkt_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/../..", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"host shell build failed:\n{r.stderr}")
     # the backend-consumer stand-in (CloudSliceProcessor's tracker-facing half) against the same shell: compiling it is half the test
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", os.path.dirname(_HERE), os.path.join(HOST_DIR, "consumer_test.cpp"), "-o", CONSUMER_TEST,
-           "-L", _HERE, "-lkt_hip", "-lz", "-Wl,-rpath,$ORIGIN/../..", "-Wl,-rpath,/opt/rocm/lib"]
+           "-L", _HERE, "-lkt_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/../..", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"consumer_test build failed:\n{r.stderr}")

@@ -21,7 +21,8 @@ class ConfigArgs {
     {
         std::fprintf(stderr,
                      "Usage: %s [Options]\n"
-                     "  -l <log.klg>   log file (raw or zlib depth, raw rgb)\n"
+                     "  -l <log.klg>   log file (raw or zlib depth, raw or JPEG colour)\n"
+                     "  -dt <threads>  decode the log ahead on this many threads (compressed logs: ~5 ms of inflate + JPEG per VGA frame; default 0)\n"
                      "  -c <calib>     calibration file: fx fy cx cy\n"
                      "  -s <metres>    volume size (default 6)\n"
                      "  -t <voxels>    voxel shift threshold (default 14)\n"
@@ -41,7 +42,7 @@ class ConfigArgs {
     }
 
     std::string calibrationFile, logFile, trajectoryFile, saveFile, vocabFile;
-    int gpu, voxelShift, volumeResolution, width, height, totalNumFrames, weightCull;
+    int gpu, voxelShift, volumeResolution, width, height, totalNumFrames, weightCull, decodeThreads;
     float volumeSize;
     bool staticMode, dynamicCube, flipColors, extractOverlap, useRGBD, useRGBDICP, disableColorAngleWeight, fastOdometry, help;
 
@@ -60,7 +61,7 @@ class ConfigArgs {
     }
 
     ConfigArgs(int argc, char** argv)
-        : gpu(0), voxelShift(14), volumeResolution(512), width(640), height(480), totalNumFrames(0), weightCull(8), volumeSize(6.0f)
+        : gpu(0), voxelShift(14), volumeResolution(512), width(640), height(480), totalNumFrames(0), weightCull(8), decodeThreads(0), volumeSize(6.0f)
     {
         const char* v;
         if ((v = value(argc, argv, "-c"))) calibrationFile = v;
@@ -74,6 +75,7 @@ class ConfigArgs {
         if ((v = value(argc, argv, "-h"))) height = std::atoi(v);
         if ((v = value(argc, argv, "-s"))) volumeSize = (float)std::atof(v);
         if ((v = value(argc, argv, "-fl"))) totalNumFrames = std::atoi(v);
+        if ((v = value(argc, argv, "-dt"))) decodeThreads = std::atoi(v);   // shell only: RawLogReader decode-ahead
         if ((v = value(argc, argv, "-cw"))) weightCull = std::atoi(v);   // ConfigArgs.h:118 (default 8)
         staticMode = flag(argc, argv, "-sm");
         dynamicCube = flag(argc, argv, "-d");

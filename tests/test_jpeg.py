@@ -158,3 +158,77 @@ def test_decoder_matches_libjpeg(tool, tmp_path, name, sub):
         pil = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
         got = _cxx_decode(tool, data, w, h, tmp_path, name=f"s{k}")
         assert np.array_equal(got, pil[..., ::-1]), (k, int((got != pil[..., ::-1]).sum()))
+
+
+def _run_klg_tool(path, cols, rows, threads, extra=()):
+    from kintinuous_amd import build
+    args = [build.KLG_TOOL, "-l", path, "-w", str(cols), "-h", str(rows), "-dt", str(threads)] + list(extra)
+    r = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    return r.returncode, r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("layout", ["raw", "zlib", "jpeg"])
+def test_cxx_log_reader_decode_ahead(tool, tmp_path, layout):
+    """RawLogReader with decode-ahead worker threads (-dt 1 / 3 / 8 / 33) hands out exactly what the synchronous reader does: every
+    frame's timestamp, depth and colour checksums and isCompressed, in order, over a log much longer than the ring of slots."""
+    from kintinuous_amd import klg, synth
+    cam = synth.Camera.small(160, 120)
+    poses = synth.orbit_trajectory(70)
+    frames = [synth.render(synth.Scene("room"), cam, *p) for p in poses[:10]]
+    frames = [frames[k % 10] if k % 7 else (np.roll(frames[k % 10][0], k, axis=1), frames[k % 10][1]) for k in range(70)]
+    path = str(tmp_path / "long.klg")
+    klg.write_klg(path, frames, timestamps=[11 + 33333 * k for k in range(70)], cols=cam.cols, rows=cam.rows, compress_depth=layout != "raw",
+                  jpeg_quality=85 if layout == "jpeg" else 0)
+    rc0, out0, err0 = _run_klg_tool(path, cam.cols, cam.rows, 0)
+    assert rc0 == 0 and len(out0.splitlines()) == 69, err0
+    for threads in (1, 3, 8, 33):
+        rc, out, err = _run_klg_tool(path, cam.cols, cam.rows, threads, ["-f"] if threads == 3 else [])
+        if threads == 3:
+            rc0f, out0f, _ = _run_klg_tool(path, cam.cols, cam.rows, 0, ["-f"])
+            assert (rc, out) == (rc0f, out0f)
+        else:
+            assert (rc, out) == (rc0, out0), (threads, err)
+
+
+@pytest.mark.parametrize("damage", ["truncated_payload", "truncated_header", "bad_zlib", "bad_jpeg", "bad_sizes", "short_count"])
+def test_cxx_log_reader_decode_ahead_on_damaged_logs(tool, tmp_path, damage):
+    """A damaged log stops the decode-ahead reader at the same frame, with the same frames delivered before it, the same exit code and
+    the same message as the synchronous reader (a truncated file ends the log quietly, a corrupt frame is an error)."""
+    import struct
+    from kintinuous_amd import klg, synth
+    cam = synth.Camera.small(160, 120)
+    fr = [synth.render(synth.Scene("room"), cam, *p) for p in synth.orbit_trajectory(4)]
+    frames = [fr[k % 4] for k in range(24)]
+    path = str(tmp_path / "d.klg")
+    klg.write_klg(path, frames, timestamps=[5 + 1000 * k for k in range(24)], cols=cam.cols, rows=cam.rows, compress_depth=True, jpeg_quality=85)
+    data = bytearray(open(path, "rb").read())
+    # walk the records to find frame 13
+    off, starts = 4, []
+    for k in range(24):
+        starts.append(off)
+        ds, is_ = struct.unpack_from("<ii", data, off + 8)
+        off += 16 + ds + is_
+    s13 = starts[13]
+    ds13, is13 = struct.unpack_from("<ii", data, s13 + 8)
+    if damage == "truncated_payload":
+        data = data[:s13 + 16 + ds13 // 2]
+    elif damage == "truncated_header":
+        data = data[:s13 + 10]
+    elif damage == "bad_zlib":
+        for i in range(s13 + 16 + 20, s13 + 16 + 60):
+            data[i] ^= 0x5A
+    elif damage == "bad_jpeg":
+        j = s13 + 16 + ds13
+        data[j:j + 2] = b"\x00\x00"      # no SOI marker
+    elif damage == "bad_sizes":
+        struct.pack_into("<ii", data, s13 + 8, -5, 1 << 30)
+    elif damage == "short_count":
+        struct.pack_into("<i", data, 0, 9)   # the header announces fewer frames than the file holds
+    open(path, "wb").write(bytes(data))
+    rc0, out0, err0 = _run_klg_tool(path, cam.cols, cam.rows, 0)
+    want_frames = {"short_count": 8}.get(damage, 13)
+    assert len(out0.splitlines()) == want_frames, (damage, rc0, err0)
+    assert (rc0 == 0) == (damage in ("truncated_payload", "truncated_header", "short_count"))
+    for threads in (1, 4, 16):
+        rc, out, err = _run_klg_tool(path, cam.cols, cam.rows, threads)
+        assert (rc, out, err) == (rc0, out0, err0), (damage, threads, rc, err)
