@@ -1,5 +1,5 @@
 """Fuzzes the untrusted-input parsers of the host side under AddressSanitizer + UBSan: the JPEG decoder (host/JpegDecoder.h via
-jpeg_tool) and the .klg reader (host/RawLogReader.h via klg_tool).  Mutated and truncated streams must either decode or be rejected
+jpeg_tool) and the .klg reader (host/RawLogReader.h via klg_tool, synchronous and with decode-ahead threads, which must agree).  Mutated and truncated streams must either decode or be rejected
 with exit code 1 -- never crash.  Not part of the pytest run (minutes);   python tests/tools/fuzz_host_io.py [iterations]"""
 import os
 import subprocess
@@ -21,7 +21,7 @@ def main():
     tmp = tempfile.mkdtemp()
     jt, kt = os.path.join(tmp, "jpeg_tool_san"), os.path.join(tmp, "klg_tool_san")
     subprocess.check_call(["g++"] + SAN + [os.path.join(HOST, "jpeg_tool.cpp"), "-o", jt])
-    subprocess.check_call(["g++"] + SAN + [os.path.join(HOST, "klg_tool.cpp"), "-o", kt, "-lz"])
+    subprocess.check_call(["g++"] + SAN + [os.path.join(HOST, "klg_tool.cpp"), "-o", kt, "-lz", "-pthread"])
     rng = np.random.default_rng(123)
     yy, xx = np.mgrid[0:50, 0:67]
     img = np.stack([(xx * 3) % 256, (yy * 5) % 256, (xx + yy) % 256], -1).astype(np.uint8)
@@ -61,6 +61,11 @@ def main():
         if r.returncode not in (0, 1):
             crashes += 1
             print("KLG CRASH", k, r.returncode, r.stderr[-800:])
+        # the decode-ahead reader on the same damaged log: same frames, same verdict, same message
+        r2 = subprocess.run([kt, "-l", f, "-w", "64", "-h", "48", "-dt", str(1 + k % 5)], capture_output=True, text=True, timeout=60)
+        if (r2.returncode, r2.stdout, r2.stderr) != (r.returncode, r.stdout, r.stderr):
+            crashes += 1
+            print("KLG DECODE-AHEAD DIFFERS", k, r.returncode, r2.returncode, r.stderr[-300:], r2.stderr[-800:])
     print("iterations", iters, "crashes", crashes)
     return 1 if crashes else 0
 
