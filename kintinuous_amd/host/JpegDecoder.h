@@ -33,7 +33,10 @@ struct Huffman {
     int mincode[17], maxcode[18], valptr[17];
     unsigned char vals[256];
     int nvals;
-    Huffman() : present(false), nvals(0) {}
+    // look-ahead for the short codes: entry = code length << 8 | symbol for every kLookBits-bit window that starts with that code, 0 = longer
+    static const int kLookBits = 9;
+    unsigned short look[1 << kLookBits];
+    Huffman() : present(false), nvals(0) { std::memset(look, 0, sizeof(look)); }
 };
 
 struct Component {
@@ -59,32 +62,25 @@ struct RangeLimit {
     }
 };
 
+// Entropy-coded segment reader: a 64-bit window topped up a byte at a time (0xFF00 un-stuffed; a marker or the end of the data stops
+// the consumption and zero bits follow -- libjpeg feeds zeros there too: a corrupt tail decodes to grey, not a crash).
 class BitReader {
   public:
     BitReader(const unsigned char* d, size_t n) : d(d), n(n), pos(0), acc(0), cnt(0), marker(0) {}
-    size_t pos_bytes() const { return pos; }
+    size_t pos_bytes() const { return pos; }   // never past a marker: the window stops in front of it
     void seek(size_t p) { pos = p; acc = 0; cnt = 0; marker = 0; }
-    // returns -1 past the end of the entropy-coded segment (libjpeg feeds zero bits there; a corrupt tail decodes to grey, not a crash)
-    int bit()
+    // the next k bits (k <= 16) without consuming them
+    unsigned int peek(int k)
     {
-        if (cnt == 0) {
-            if (marker || pos >= n) { acc = 0; cnt = 8; }
-            else {
-                unsigned char b = d[pos++];
-                if (b == 0xFF) {
-                    if (pos < n && d[pos] == 0x00) ++pos;          // stuffed zero
-                    else { marker = (pos < n) ? d[pos] : 0xD9; --pos; b = 0; }   // a marker: stop consuming, feed zeros
-                }
-                acc = b; cnt = 8;
-            }
-        }
-        --cnt;
-        return (acc >> cnt) & 1;
+        if (cnt < k) refill();
+        return (unsigned int)(acc >> (cnt - k)) & ((1u << k) - 1u);
     }
+    void skip(int k) { cnt -= k; }
     int bits(int k)
     {
-        int v = 0;
-        for (int i = 0; i < k; ++i) v = (v << 1) | bit();
+        if (k == 0) return 0;
+        const int v = (int)peek(k);
+        cnt -= k;
         return v;
     }
     // after an MCU row / restart interval: drop the partial byte and consume an RSTn marker if one follows
@@ -104,20 +100,43 @@ class BitReader {
     bool hit_marker() const { return marker != 0; }
 
   private:
+    void refill()
+    {
+        while (cnt <= 56) {
+            unsigned int b = 0;
+            if (!marker && pos < n) {
+                b = d[pos++];
+                if (b == 0xFF) {
+                    if (pos < n && d[pos] == 0x00) ++pos;          // stuffed zero
+                    else { marker = (pos < n) ? d[pos] : 0xD9; --pos; b = 0; }   // a marker: stop consuming, feed zeros
+                }
+            }
+            acc = (acc << 8) | b;
+            cnt += 8;
+        }
+    }
     const unsigned char* d;
     size_t n, pos;
-    unsigned int acc;
+    unsigned long long acc;   // the low cnt bits are the unread ones, oldest on top
     int cnt;
     int marker;
 };
 
+// One symbol: codes of up to kLookBits bits come out of Huffman::look (length << 8 | symbol, indexed by the next kLookBits bits), longer
+// ones out of the canonical search of T.81 F.2.2.3 continued from there.
 inline int decode_symbol(BitReader& br, const Huffman& h)
 {
-    int code = 0;
-    for (int len = 1; len <= 16; ++len) {
-        code = (code << 1) | br.bit();
+    const unsigned int w = br.peek(16);
+    const unsigned int e = h.look[w >> (16 - Huffman::kLookBits)];
+    if (e) {
+        br.skip((int)(e >> 8));
+        return (int)(e & 0xffu);
+    }
+    for (int len = Huffman::kLookBits + 1; len <= 16; ++len) {
+        const int code = (int)(w >> (16 - len));
         if (h.maxcode[len] >= 0 && code <= h.maxcode[len] && code >= h.mincode[len]) {
             const int idx = h.valptr[len] + code - h.mincode[len];
+            br.skip(len);
             return idx < h.nvals ? h.vals[idx] : -1;
         }
     }
@@ -315,6 +334,14 @@ inline bool decodeBGR(const unsigned char* data, size_t size, int width, int hei
                     code <<= 1;
                 }
                 h.maxcode[17] = -1;
+                std::memset(h.look, 0, sizeof(h.look));
+                for (int l = 1; l <= Huffman::kLookBits; ++l)
+                    for (int c = h.mincode[l]; c <= h.maxcode[l]; ++c) {   // (empty lengths have maxcode -1)
+                        const int idx = h.valptr[l] + c - h.mincode[l];
+                        if (idx >= h.nvals) continue;
+                        const int first = c << (Huffman::kLookBits - l);
+                        for (int f = 0; f < (1 << (Huffman::kLookBits - l)); ++f) h.look[first + f] = (unsigned short)((l << 8) | h.vals[idx]);
+                    }
                 h.present = true;
             }
             break;
