@@ -44,7 +44,8 @@ class LogReader {
 class RawLogReader : public LogReader {
   public:
     explicit RawLogReader(const std::string& file = ConfigArgs::get().logFile, int decodeThreads = ConfigArgs::get().decodeThreads)
-        : fp(0), numFrames(0), currentFrame(0), nextToRead(0), stopping(false), inputEnded(false)
+        : fp(0), numFrames(0), currentFrame(0), cols(Resolution::get().width()), rows(Resolution::get().height()),
+          flipColors(ConfigArgs::get().flipColors), nextToRead(0), stopping(false), inputEnded(false)
     {
         fp = std::fopen(file.c_str(), "rb");
         if (!fp) { std::fprintf(stderr, "cannot open log %s\n", file.c_str()); std::exit(1); }
@@ -67,12 +68,7 @@ class RawLogReader : public LogReader {
     }
     virtual ~RawLogReader()
     {
-        {
-            std::lock_guard<std::mutex> lock(m);
-            stopping = true;
-        }
-        wake.notify_all();
-        for (size_t k = 0; k < workers.size(); ++k) workers[k].join();
+        stopWorkers();
         if (fp) std::fclose(fp);
     }
 
@@ -94,6 +90,7 @@ class RawLogReader : public LogReader {
         if (s->state == Slot::ENDED) { returnVal = false; return false; }   // a truncated file ends the log
         if (s->state == Slot::BAD) {   // a log is untrusted input: stop at the frame that is corrupt, having delivered the ones before it
             std::fprintf(stderr, "%s\n", s->error.c_str());
+            stopWorkers();   // exit() runs the static destructors: no decoder may still be at work
             std::exit(1);
         }
         decompressedDepth = s->depth.data();
@@ -112,6 +109,17 @@ class RawLogReader : public LogReader {
     }
 
   private:
+    void stopWorkers()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            stopping = true;
+        }
+        wake.notify_all();
+        for (size_t k = 0; k < workers.size(); ++k) workers[k].join();
+        workers.clear();
+    }
+
     struct Slot {
         enum State { EMPTY, BUSY, READY, ENDED, BAD };
         Slot() : timestamp(0), depthSize(0), imageSize(0), compressed(false), index(-1), state(EMPTY) {}
@@ -128,7 +136,7 @@ class RawLogReader : public LogReader {
     // the next record of the file into the slot's raw buffers (file order: one caller at a time).  false: the file ends here.
     bool readRecord(Slot& s, int frame)
     {
-        const size_t n = (size_t)Resolution::get().numPixels();
+        const size_t n = (size_t)cols * (size_t)rows;
         s.index = frame;
         s.error.clear();
         int32_t depthSize = 0, imageSize = 0;
@@ -152,11 +160,11 @@ class RawLogReader : public LogReader {
         return true;
     }
 
-    // raw payloads -> depth / image of the slot (touches nothing but the slot).  false: s.error says why the frame is unusable.
-    static bool decode(Slot& s)
+    // raw payloads -> depth / image of the slot (touches nothing but the slot and the reader's constants).  false: s.error says why the frame is unusable.
+    bool decode(Slot& s) const
     {
         if (!s.error.empty()) return false;
-        const size_t n = (size_t)Resolution::get().numPixels();
+        const size_t n = (size_t)cols * (size_t)rows;
         const int32_t depthSize = s.depthSize, imageSize = s.imageSize;
         char msg[200];
         // the image decides isCompressed (RawLogReader.cpp:73-97); the depth payload has to agree (:99-117, asserts there)
@@ -166,7 +174,7 @@ class RawLogReader : public LogReader {
         } else if (imageSize > 0) {  // anything else is handed to cvDecodeImage -> B G R bytes
             s.compressed = true;
             std::string err;
-            if (!kt::jpeg::decodeBGR(s.rawImage.data(), (size_t)imageSize, Resolution::get().width(), Resolution::get().height(), s.image.data(), &err)) {
+            if (!kt::jpeg::decodeBGR(s.rawImage.data(), (size_t)imageSize, cols, rows, s.image.data(), &err)) {
                 std::snprintf(msg, sizeof(msg), "cannot decode the colour image of frame %d: %s", s.index, err.c_str());
                 s.error = msg;
                 return false;
@@ -196,7 +204,7 @@ class RawLogReader : public LogReader {
             s.compressed = false;
             std::memset(s.depth.data(), 0, n * 2);
         }
-        if (ConfigArgs::get().flipColors)  // RawLogReader.cpp:118-121 (cv::cvtColor RGB2BGR)
+        if (flipColors)  // RawLogReader.cpp:118-121 (cv::cvtColor RGB2BGR)
             for (size_t i = 0; i < n; ++i) { unsigned char t = s.image[i * 3]; s.image[i * 3] = s.image[i * 3 + 2]; s.image[i * 3 + 2] = t; }
         return true;
     }
@@ -231,6 +239,8 @@ class RawLogReader : public LogReader {
 
     FILE* fp;
     int numFrames, currentFrame;
+    const int cols, rows;       // fixed at construction: the workers never ask the singletons
+    const bool flipColors;
     static const int kKeep = 4;
     std::vector<Slot> ring;
     // decode-ahead state, all under m
