@@ -22,7 +22,7 @@ class ConfigArgs {
         std::fprintf(stderr,
                      "Usage: %s [Options]\n"
                      "  -l <log.klg>   log file (raw or zlib depth, raw or JPEG colour)\n"
-                     "  -dt <threads>  decode the log ahead on this many threads (compressed logs: ~5 ms of inflate + JPEG per VGA frame; default 0)\n"
+                     "  -dt <threads>  decode the log ahead on this many threads (compressed logs: ~5 ms of inflate + JPEG per VGA frame; default: hardware threads / 4, at most 8; 0 = inside the read call)\n"
                      "  -c <calib>     calibration file: fx fy cx cy\n"
                      "  -s <metres>    volume size (default 6)\n"
                      "  -t <voxels>    voxel shift threshold (default 14)\n"
@@ -61,7 +61,7 @@ class ConfigArgs {
     }
 
     ConfigArgs(int argc, char** argv)
-        : gpu(0), voxelShift(14), volumeResolution(512), width(640), height(480), totalNumFrames(0), weightCull(8), decodeThreads(0), volumeSize(6.0f)
+        : gpu(0), voxelShift(14), volumeResolution(512), width(640), height(480), totalNumFrames(0), weightCull(8), decodeThreads(-1), volumeSize(6.0f)
     {
         const char* v;
         if ((v = value(argc, argv, "-c"))) calibrationFile = v;

@@ -3,8 +3,9 @@
 // zlib stream; image: raw rgb24 (imageSize == 3*W*H), absent (imageSize == 0 -> zeros) or a JPEG stream (cvDecodeImage in the
 // reference, JpegDecoder.h here).  hasMore() keeps the reference's off-by-one: the last frame of a log is never returned.
 //
-// Decode-ahead (`-dt <threads>`, ConfigArgs::decodeThreads; 0 = decode inside grabNext like the reference): a compressed VGA frame
-// costs ~3 ms of JPEG decoding and ~2 ms of inflate on one core, the GPU path consumes a frame in 0.35 ms.  With N worker threads the
+// Decode-ahead (`-dt <threads>`, ConfigArgs::decodeThreads; default: a quarter of the hardware threads, at most 8; 0 = decode inside
+// grabNext like the reference): a compressed VGA frame costs ~3 ms of JPEG decoding and ~2 ms of inflate on one core, the GPU path
+// consumes a frame in 0.35 ms.  With N worker threads the
 // records are still read from the file strictly in order (one reader at a time), decoded in parallel into a ring of frame slots and
 // handed out in order; what grabNext returns -- buffers, sizes, isCompressed, the points at which a corrupt or truncated log stops
 // the run -- is the same in both modes (tests/test_jpeg.py compares them frame by frame).
@@ -49,7 +50,10 @@ class RawLogReader : public LogReader {
     {
         fp = std::fopen(file.c_str(), "rb");
         if (!fp) { std::fprintf(stderr, "cannot open log %s\n", file.c_str()); std::exit(1); }
-        if (decodeThreads < 0) decodeThreads = 0;
+        if (decodeThreads < 0) {   // not given: a quarter of the hardware threads, 1..8 (0 = the reference's synchronous reader)
+            const unsigned hw = std::thread::hardware_concurrency();
+            decodeThreads = hw / 4 < 1 ? 1 : (hw / 4 > 8 ? 8 : (int)(hw / 4));
+        }
         if (decodeThreads > 64) decodeThreads = 64;
         // a frame handed out stays valid for kKeep - 1 further grabNext calls (the tracker's read-ahead keeps up to two earlier frames
         // alive by address); the workers may run 2 frames per thread ahead of the consumer
