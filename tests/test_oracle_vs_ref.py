@@ -12,6 +12,8 @@ flushed inside kernels as --ftz=true does).  The two documented exceptions are a
 What _ref cannot pin: nvcc's --prec-div=false / --prec-sqrt=false / ex2.approx (hardware approximations) and the
 host-side code of the path (Eigen / OpenCV), see DESIGN.md section 5.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -738,3 +740,14 @@ def test_noise_images_rgbd(oracle_mod, R, seed):
         Ao, bo = O.rgb_step(co_, sigma, cloud, fx, fy, dx, dy, 0.125, 0)
         Ar, br = R.rgb_step(cr_, sigma, cloud, fx, fy, dx, dy, 0.125)
         assert same(Ao, Ar) and same(bo, br), (seed, mag)
+
+
+def test_full_size_frames(oracle_mod, R):
+    """The bench's own configuration -- 640x480 frames of the orbit sequence into a 512^3 volume with a storage wrap, the raycast from the
+    next pose, an ICP reduction at full resolution, the whole volume extracted -- through tests/tools/full_size_pin.py (its own process:
+    two volume pairs are 1.6 GB).  The tool has been run over 40 frames (160 M voxel updates); two here."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "full_size_pin.py")
+    r = subprocess.run([sys.executable, tool, "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

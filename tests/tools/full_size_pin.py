@@ -1,0 +1,68 @@
+"""oracle == reference at the bench's own size: 640x480 frames of the orbit sequence integrated into a 512^3 volume (with a storage wrap),
+raycast from the next pose, the whole volume extracted -- every output bit for bit.  Minutes of CPU and ~2 GB; not part of the pytest run.
+python tests/tools/full_size_pin.py [frames]      (needs /root/reference: oracle/_ref)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import test_oracle_vs_ref as T
+from oracle import oracle as O, ref as R
+from oracle.oracle import OIntr
+from kintinuous_amd import synth
+R.build(); R.lib(); O.build(); O.lib()
+nf = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+N, size = 512, 6.0
+cam = synth.Camera.scaled(1)
+_, frames, traj, _ = synth.sequence("orbit", nf + 1, cam, 1234)
+intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
+trunc = max(0.06, 2.1 * size / N)
+wrap = [37, 501, 130]
+vo, co = np.zeros((N, N, N), np.int16), np.zeros((N, N, N, 4), np.uint8)
+vr, cr = vo.copy(), co.copy()
+ok = True
+for k in range(nf):
+    d, c = frames[k]
+    Rm, c0 = traj[k]
+    Rk = np.asarray(Rm, np.float32); tk = (np.asarray(c0, np.float32) + np.float32(size / 2)).astype(np.float32)
+    n = O.create_nmap(O.create_vmap(intr, O.bilateral_filter(d)))
+    Rinv = O.mat33_inverse(Rk)
+    t0 = time.time()
+    U, so = O.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vo, wrap, co, c, n, True)
+    t1 = time.time()
+    sr = R.integrate_tsdf(d, intr, [size] * 3, Rinv, tk, trunc, vr, wrap, cr, c, n, True)
+    t2 = time.time()
+    same = T.same(so, sr) and T.same(vo, vr) and T.same(co, cr)
+    ok &= same
+    print(f"frame {k}: U {U}  oracle {t1 - t0:.1f} s  reference kernels {t2 - t1:.1f} s  identical {same}", flush=True)
+Rm, c0 = traj[nf]
+Rk = np.asarray(Rm, np.float32); tk = (np.asarray(c0, np.float32) + np.float32(size / 2)).astype(np.float32)
+outs = []
+for M, vol, col in ((O, vo, co), (R, vr, cr)):
+    vm, nm = np.full((3 * cam.rows, cam.cols), 7.0, np.float32), np.full((3 * cam.rows, cam.cols), -3.0, np.float32)
+    cm = np.full((cam.rows, cam.cols, 4), 9, np.uint8)
+    t0 = time.time()
+    M.raycast(intr, Rk, tk, trunc, [size] * 3, vol, vm, nm, wrap, cm, col)
+    outs.append((vm, nm, cm, time.time() - t0))
+(a, b, c_, ta), (a2, b2, c2, tb) = outs
+same = T.same(a, a2) and T.same(b, b2) and T.same(c_[..., :3], c2[..., :3])
+ok &= same
+print(f"raycast: hits {int(np.isfinite(a[:cam.rows]).sum())}  oracle {ta:.1f} s  reference kernel {tb:.1f} s  identical {same}", flush=True)
+# one ICP reduction at full resolution against the prediction, from a slightly wrong pose
+from conftest import random_rotation
+rng = np.random.default_rng(5)
+d, c = frames[nf]
+vcur = O.create_vmap(intr, O.bilateral_filter(d)); ncur = O.create_nmap(vcur)
+Rc = (random_rotation(rng, 0.01) @ Rk).astype(np.float32); tc = (tk + rng.uniform(-0.01, 0.01, 3)).astype(np.float32)
+th = float(np.sin(np.float32(20.0 * 3.14159265 / 180.0)))
+Ao, bo, ro = O.icp_step(Rc, tc, vcur, ncur, O.mat33_inverse(Rk), tk, intr, a, b, 0.10, th, 0)
+Ar, br, rr = R.icp_step(Rc, tc, vcur, ncur, O.mat33_inverse(Rk), tk, intr, a, b, 0.10, th)
+same = T.same(Ao, Ar) and T.same(bo, br) and T.same(ro, rr)
+ok &= same
+print(f"ICP reduction at 640x480: inliers {np.asarray(ro).ravel()[1]:.0f}  identical {same}", flush=True)
+po = O.extract_cloud_slice(vo, [size] * 3, 6000000, wrap, co, 0, N, 0, N, 0, N, 1, [37, -11, 642])
+pr = R.extract_cloud_slice(vr, [size] * 3, 6000000, wrap, cr, 0, N, 0, N, 0, N, 1, [37, -11, 642])
+same = len(po) == len(pr) and T._point_set(po) == T._point_set(pr)
+ok &= same
+print(f"extraction of the whole volume: {len(po)} points  identical {same}")
+print("PASS" if ok else "FAIL")
+sys.exit(0 if ok else 1)
