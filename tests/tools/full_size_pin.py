@@ -1,5 +1,6 @@
 """oracle == reference at the bench's own size: 640x480 frames of the orbit sequence integrated into a 512^3 volume (with a storage wrap),
-raycast from the next pose, an ICP reduction and the RGB-D residual + step at full resolution, the whole volume extracted -- every output bit for bit.  Minutes of CPU and ~2 GB; not part of the pytest run.
+raycast from the next pose, an ICP reduction and the RGB-D residual + step at full resolution, the whole volume extracted, then the kernels of a volume shift on every axis (the 18-plane slab extracted, tsdf and colour slabs cleared forward and back)
+-- every output bit for bit.  Minutes of CPU and ~2 GB; not part of the pytest run.
 python tests/tools/full_size_pin.py [frames] [farwall768]      (needs /root/reference: oracle/_ref)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -90,5 +91,26 @@ pr = R.extract_cloud_slice(vr, [size] * 3, 12000000, wrap, cr, 0, N, 0, N, 0, N,
 same = len(po) == len(pr) and T._point_set(po) == T._point_set(pr)
 ok &= same
 print(f"extraction of the whole volume: {len(po)} points  identical {same}")
+# a volume shift's kernels on every axis: the 16 + 2 plane slab extracted, then cleared (tsdf and colour volumes), forward and back
+for axis in range(3):
+    best = (-1, 0)
+    for start in range(0, N - 18, 36):   # the slab position with the most surface in it (oracle only: cheap)
+        lo, hi = [0, 0, 0], [N, N, N]
+        lo[axis], hi[axis] = start, start + 18
+        best = max(best, (len(O.extract_cloud_slice(vo, [size] * 3, 12000000, wrap, co, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], 1, [37, -11, 642])), start))
+    lo, hi = [0, 0, 0], [N, N, N]
+    lo[axis], hi[axis] = best[1], best[1] + 18
+    po = O.extract_cloud_slice(vo, [size] * 3, 12000000, wrap, co, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], 1, [37, -11, 642])
+    pr = R.extract_cloud_slice(vr, [size] * 3, 12000000, wrap, cr, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], 1, [37, -11, 642])
+    same = len(po) == len(pr) and T._point_set(po) == T._point_set(pr)
+    for back in (False, True):
+        cur = wrap[axis] + (N if back else 0)
+        delta = cur + (-14 if back else 14)
+        for vol_o, vol_r in ((vo, vr), (co.view(np.uint32).reshape(N, N, N), cr.view(np.uint32).reshape(N, N, N))):
+            O.clear_volume(vol_o, axis, back, cur, delta)
+            R.clear_volume(vol_r, axis, back, cur, delta)
+            same &= T.same(vol_o, vol_r)
+    ok &= bool(same)
+    print(f"shift kernels, axis {axis}: slab of {len(po)} points, 4 clears  identical {bool(same)}", flush=True)
 print("PASS" if ok else "FAIL")
 sys.exit(0 if ok else 1)
