@@ -744,10 +744,10 @@ def test_noise_images_rgbd(oracle_mod, R, seed):
 
 def test_full_size_frames(oracle_mod, R):
     """The bench's own configuration -- 640x480 frames of the orbit sequence into a 512^3 volume with a storage wrap, the raycast from the
-    next pose, an ICP reduction at full resolution, the whole volume extracted -- through tests/tools/full_size_pin.py (its own process:
+    next pose, an ICP reduction and the RGB-D residual + step at full resolution, the whole volume extracted -- through tests/tools/full_size_pin.py (its own process:
     two volume pairs are 1.6 GB).  The tool has been run over 40 frames (160 M voxel updates); two here."""
     import subprocess
     import sys
     tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "full_size_pin.py")
-    r = subprocess.run([sys.executable, tool, "2"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, tool, "2", "orbit512", "quick"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

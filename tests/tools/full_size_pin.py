@@ -1,7 +1,7 @@
 """oracle == reference at the bench's own size: 640x480 frames of the orbit sequence integrated into a 512^3 volume (with a storage wrap),
 raycast from the next pose, an ICP reduction and the RGB-D residual + step at full resolution, the whole volume extracted, then the kernels of a volume shift on every axis (the 18-plane slab extracted, tsdf and colour slabs cleared forward and back)
 -- every output bit for bit.  Minutes of CPU and ~2 GB; not part of the pytest run.
-python tests/tools/full_size_pin.py [frames] [farwall768]      (needs /root/reference: oracle/_ref)"""
+python tests/tools/full_size_pin.py [frames] [orbit512|farwall768] [quick]      (needs /root/reference: oracle/_ref)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +12,7 @@ from oracle.oracle import OIntr
 from kintinuous_amd import synth
 R.build(); R.lib(); O.build(); O.lib()
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+quick = "quick" in sys.argv[2:]                              # the CPU suite's run: without the shift kernels at the end
 big = len(sys.argv) > 2 and sys.argv[2] == "farwall768"     # BASELINE configs[4]: 1280x960 into 768^3 (6 GB)
 N, size = (768, 6.0) if big else (512, 6.0)
 cam = synth.Camera.scaled(2 if big else 1)
@@ -92,7 +93,7 @@ same = len(po) == len(pr) and T._point_set(po) == T._point_set(pr)
 ok &= same
 print(f"extraction of the whole volume: {len(po)} points  identical {same}")
 # a volume shift's kernels on every axis: the 16 + 2 plane slab extracted, then cleared (tsdf and colour volumes), forward and back
-for axis in range(3):
+for axis in ([] if quick else range(3)):
     best = (-1, 0)
     for start in range(0, N - 18, 36):   # the slab position with the most surface in it (oracle only: cheap)
         lo, hi = [0, 0, 0], [N, N, N]
