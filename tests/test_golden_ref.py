@@ -65,3 +65,52 @@ def test_hip_reproduces_reference_golden(ctx, gold):
     from oracle.oracle import OIntr      # a plain (fx, fy, cx, cy) record; no oracle code runs in this test
     from ref_scenario import scenario
     _check(scenario(HipKernels(ctx), gold[0], OIntr), gold[1])
+
+
+# ---- the bench's own configuration (640x480 into 512^3), as digests: tests/golden/full_size_scenario.py ----------------------------
+def _full_size_gold():
+    import json
+    return json.load(open(os.path.join(HERE, "golden", "full_size_ref_v1.json")))
+
+
+def _compare_digests(got, want):
+    assert set(got) == set(want)
+    bad = {k: (got[k], want[k]) for k in want if got[k] != want[k]}
+    assert not bad, bad
+
+
+def test_oracle_reproduces_reference_full_size_digests(oracle_mod):
+    """Two VGA frames into 512^3, raycast, full-resolution ICP reduction, whole-volume extraction: the oracle's outputs hash to what the
+    reference's own kernels produced (tests/golden/make_full_size_ref.py)."""
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr
+    from full_size_scenario import scenario
+
+    class M:
+        def __getattr__(self, n):
+            return getattr(oracle_mod, n)
+
+        def icp_step(self, *a):
+            return oracle_mod.icp_step(*a, 0)
+
+    cam = synth.Camera.scaled(1)
+    _, frames, _, _ = synth.sequence("orbit", 3, cam, 1234)
+    filtered = [oracle_mod.bilateral_filter(d) for d, _ in frames]
+    _compare_digests(scenario(M(), OIntr, oracle_mod.mat33_inverse, filtered), _full_size_gold())
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_reference_full_size_digests(ctx):
+    """The same scenario through the HIP path (C-ABI): HIP against the reference's own kernels at the bench's configuration, with no
+    oracle kernel in between (oracle.mat33_inverse is the host-side 3x3 inverse the reference computes with Eigen before the launch; the
+    filtered frames are the HIP bilateral filter's, and their digest is part of the comparison)."""
+    from hip_kernels import HipKernels
+    from kintinuous_amd import synth
+    from oracle.oracle import OIntr      # a plain (fx, fy, cx, cy) record
+    from oracle import oracle as O       # mat33_inverse only: the host-side inverse the reference computes with Eigen before the launch
+    from full_size_scenario import scenario
+    H = HipKernels(ctx)
+    cam = synth.Camera.scaled(1)
+    _, frames, _, _ = synth.sequence("orbit", 3, cam, 1234)
+    filtered = [H.bilateral_filter(d) for d, _ in frames]
+    _compare_digests(scenario(H, OIntr, O.mat33_inverse, filtered), _full_size_gold())
