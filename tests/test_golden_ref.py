@@ -100,17 +100,16 @@ def test_oracle_reproduces_reference_full_size_digests(oracle_mod):
 
 
 @pytest.mark.gpu
-def test_hip_reproduces_reference_full_size_digests(ctx):
+def test_hip_reproduces_reference_full_size_digests(ctx, oracle_mod):
     """The same scenario through the HIP path (C-ABI): HIP against the reference's own kernels at the bench's configuration, with no
     oracle kernel in between (oracle.mat33_inverse is the host-side 3x3 inverse the reference computes with Eigen before the launch; the
     filtered frames are the HIP bilateral filter's, and their digest is part of the comparison)."""
     from hip_kernels import HipKernels
     from kintinuous_amd import synth
     from oracle.oracle import OIntr      # a plain (fx, fy, cx, cy) record
-    from oracle import oracle as O       # mat33_inverse only: the host-side inverse the reference computes with Eigen before the launch
     from full_size_scenario import scenario
     H = HipKernels(ctx)
     cam = synth.Camera.scaled(1)
     _, frames, _, _ = synth.sequence("orbit", 3, cam, 1234)
     filtered = [H.bilateral_filter(d) for d, _ in frames]
-    _compare_digests(scenario(H, OIntr, O.mat33_inverse, filtered), _full_size_gold())
+    _compare_digests(scenario(H, OIntr, oracle_mod.mat33_inverse, filtered), _full_size_gold())   # (mat33_inverse: host math only)
