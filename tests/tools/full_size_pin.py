@@ -1,7 +1,7 @@
 """oracle == reference at the bench's own size: 640x480 frames of the orbit sequence integrated into a 512^3 volume (with a storage wrap),
 raycast from the next pose, an ICP reduction and the RGB-D residual + step at full resolution, the whole volume extracted, then the kernels of a volume shift on every axis (the 18-plane slab extracted, tsdf and colour slabs cleared forward and back)
 -- every output bit for bit.  Minutes of CPU and ~2 GB; not part of the pytest run.
-python tests/tools/full_size_pin.py [frames] [orbit512|farwall768] [quick]      (needs /root/reference: oracle/_ref)"""
+python tests/tools/full_size_pin.py [frames] [orbit512|crabwalk512|farwall768] [quick]      (needs /root/reference: oracle/_ref)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,11 +14,12 @@ R.build(); R.lib(); O.build(); O.lib()
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 quick = "quick" in sys.argv[2:]                              # the CPU suite's run: without the shift kernels at the end
 big = len(sys.argv) > 2 and sys.argv[2] == "farwall768"     # BASELINE configs[4]: 1280x960 into 768^3 (6 GB)
-N, size = (768, 6.0) if big else (512, 6.0)
+crab = len(sys.argv) > 2 and sys.argv[2] == "crabwalk512"   # BASELINE configs[2]: the shifting crab-walk, 7 m volume
+N, size = (768, 6.0) if big else ((512, 7.0) if crab else (512, 6.0))
 cam = synth.Camera.scaled(2 if big else 1)
-_, frames, traj, _ = synth.sequence("farwall" if big else "orbit", nf + 1, cam, 1234)
+_, frames, traj, _ = synth.sequence("farwall" if big else ("crabwalk" if crab else "orbit"), nf + 1, cam, 1234)
 intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
-trunc = max(0.06, 2.1 * size / N)
+trunc = max(0.06 if size == 6.0 else max(0.01, size / 100), 2.1 * size / N)
 basis = np.array([size / 2, size / 2, -0.45 if big else size / 2], np.float32)   # static mode looks into the volume from 0.45 m in front of it
 wrap = [37, N - 11, 130]
 vo, co = np.zeros((N, N, N), np.int16), np.zeros((N, N, N, 4), np.uint8)
