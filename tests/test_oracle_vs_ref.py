@@ -751,3 +751,39 @@ def test_full_size_frames(oracle_mod, R):
     tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "full_size_pin.py")
     r = subprocess.run([sys.executable, tool, "2", "orbit512", "quick"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+# the emulated kernels make a frame cost seconds: the suite keeps two short runs (one of them through a volume shift), KT_DEEP_PIN=1 the
+# full set (11 minutes; run for round 2: all identical)
+_TRACKER_RUNS = [("icp", 70), ("rgbd_icp", 36), ("rgbd", 24), ("fast_odometry", 40), ("dynamic_cube", 30), ("static", 8)] \
+    if os.environ.get("KT_DEEP_PIN") else [("icp", 28), ("static", 5)]
+
+
+@pytest.mark.parametrize("mode,frames", _TRACKER_RUNS)
+def test_tracker_on_reference_kernels(oracle_mod, R, tmp_path, mode, frames):
+    """Whole runs instead of constructed inputs: the oracle's tracker (processFrame state machine, Gauss-Newton loops, volume shifts,
+    place-recognition tap) once on the oracle's kernels and once with EVERY kernel call rerouted to the reference's own kernels
+    (oracle/_ref/libkt_oracle_on_ref.so, ref_shim/kt_oracle_on_ref.h; the bilateral filter aside, whose exp() model is the documented
+    difference).  Every pose, the wraps along the way, the final volumes, every slice and the last prediction: bit for bit."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    tool = os.path.join(here, "tools", "tracker_dump.py")
+    hybrid = os.path.join(os.path.dirname(here), "oracle", "_ref", "libkt_oracle_on_ref.so")
+    subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(here), "oracle"), "_ref/libkt_oracle_on_ref.so"], stdout=subprocess.DEVNULL)
+    outs = []
+    for name, lib in (("oracle", None), ("on_ref", hybrid)):
+        env = dict(os.environ)
+        env.pop("KT_ORACLE_LIB", None)
+        if lib:
+            env["KT_ORACLE_LIB"] = lib
+        out = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, tool, mode, str(frames), out], env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(dict(np.load(out)))
+    a, b = outs
+    assert set(a) == set(b)
+    if mode in ("icp", "rgbd_icp", "fast_odometry"):
+        assert len(a["slice_sizes"]) >= 2 and int(np.abs(a["wraps"][-1]).sum()) > 0, a["wraps"][-1]     # the run did shift
+    for k in a:
+        assert a[k].shape == b[k].shape and np.array_equal(np.ascontiguousarray(a[k]).view(np.uint8), np.ascontiguousarray(b[k]).view(np.uint8)), (mode, k)
