@@ -2,10 +2,11 @@
 640x480 frames of the synthetic orbit sequence integrated into a 512^3 volume with a storage wrap, the raycast from the next pose, an ICP
 reduction at full resolution against that prediction, the whole volume extracted.  Run through any implementation M with the function
 names of oracle/oracle.py:
-   - make_full_size_ref.py runs it through oracle/_ref (the reference's own .cu sources compiled for the CPU) -> full_size_ref_v1.json;
+   - make_full_size_ref.py runs it through oracle/_ref (the reference's own .cu sources compiled for the CPU) -> full_size_ref_v1.npz;
    - tests/test_golden_ref.py runs it through the oracle (CPU) and the HIP path (GPU) and compares the digests.
-Inputs are regenerated from kintinuous_amd.synth (deterministic); their digests are part of the file, so a drift of the generator shows up
-as such.  NaNs are canonicalised before hashing (the sign of a NaN is not specified on either side)."""
+The INPUTS (three rendered frames and their poses) are stored in full_size_ref_v1.npz next to the digests: numpy's vectorised sin() and
+BLAS matmul may differ in the last bit between CPUs, so regenerating them on the GPU box would not be reproducible.  NaNs are canonicalised
+before hashing (the sign of a NaN is not specified on either side)."""
 import hashlib
 
 import numpy as np
@@ -27,14 +28,34 @@ def _sorted_points(p):
     return key[np.lexsort(key.T[::-1])]
 
 
-def scenario(M, intr_cls, mat33_inverse, filtered=None):
-    """filtered: optional list of the bilateral-filtered depth frames to start from (the bilateral filter depends on the __expf model in
-    the last bit of a weight; the digests are defined on the ORACLE's filtered frames, which every caller passes in or recomputes)."""
+def make_inputs():
+    """Three frames of the synthetic orbit sequence with their ground-truth poses (run where the fixture is written)."""
     from kintinuous_amd import synth
-    N, size = 512, 6.0
     cam = synth.Camera.scaled(1)
     _, frames, traj, _ = synth.sequence("orbit", 3, cam, 1234)
-    intr = intr_cls(cam.fx, cam.fy, cam.cx, cam.cy)
+    g = {"intr": np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)}
+    for k in range(3):
+        g["depth%d" % k] = frames[k][0]
+        g["R%d" % k] = np.asarray(traj[k][0], np.float32)
+        g["c%d" % k] = np.asarray(traj[k][1], np.float32)
+    g["rgb0"], g["rgb1"] = frames[0][1], frames[1][1]
+    return g
+
+
+class _Cam:
+    pass
+
+
+def scenario(M, g, intr_cls, mat33_inverse, filtered):
+    """g: the stored inputs (make_inputs).  filtered: the bilateral-filtered depth frames to start from (the bilateral filter depends on
+    the __expf model in the last bit of a weight; the digests are defined on the ORACLE's filtered frames, whose digest is an output)."""
+    N, size = 512, 6.0
+    cam = _Cam()
+    cam.rows, cam.cols = g["depth0"].shape
+    fx, fy, cx, cy = [float(v) for v in g["intr"]]
+    frames = [(g["depth0"], g["rgb0"]), (g["depth1"], g["rgb1"]), (g["depth2"], None)]
+    traj = [(g["R%d" % k], g["c%d" % k]) for k in range(3)]
+    intr = intr_cls(fx, fy, cx, cy)
     trunc = max(0.06, 2.1 * size / N)
     wrap = [37, 501, 130]
     out = {"in_depth0": _h(frames[0][0]), "in_rgb1": _h(frames[1][1]), "in_filtered0": _h(filtered[0])}

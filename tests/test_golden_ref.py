@@ -70,7 +70,8 @@ def test_hip_reproduces_reference_golden(ctx, gold):
 # ---- the bench's own configuration (640x480 into 512^3), as digests: tests/golden/full_size_scenario.py ----------------------------
 def _full_size_gold():
     import json
-    return json.load(open(os.path.join(HERE, "golden", "full_size_ref_v1.json")))
+    z = dict(np.load(os.path.join(HERE, "golden", "full_size_ref_v1.npz")))
+    return {k: v for k, v in z.items() if k != "digests"}, json.loads(str(z["digests"]))
 
 
 def _compare_digests(got, want):
@@ -82,7 +83,6 @@ def _compare_digests(got, want):
 def test_oracle_reproduces_reference_full_size_digests(oracle_mod):
     """Two VGA frames into 512^3, raycast, full-resolution ICP reduction, whole-volume extraction: the oracle's outputs hash to what the
     reference's own kernels produced (tests/golden/make_full_size_ref.py)."""
-    from kintinuous_amd import synth
     from oracle.oracle import OIntr
     from full_size_scenario import scenario
 
@@ -93,10 +93,9 @@ def test_oracle_reproduces_reference_full_size_digests(oracle_mod):
         def icp_step(self, *a):
             return oracle_mod.icp_step(*a, 0)
 
-    cam = synth.Camera.scaled(1)
-    _, frames, _, _ = synth.sequence("orbit", 3, cam, 1234)
-    filtered = [oracle_mod.bilateral_filter(d) for d, _ in frames]
-    _compare_digests(scenario(M(), OIntr, oracle_mod.mat33_inverse, filtered), _full_size_gold())
+    g, want = _full_size_gold()
+    filtered = [oracle_mod.bilateral_filter(g["depth%d" % k]) for k in range(3)]
+    _compare_digests(scenario(M(), g, OIntr, oracle_mod.mat33_inverse, filtered), want)
 
 
 @pytest.mark.gpu
@@ -105,11 +104,9 @@ def test_hip_reproduces_reference_full_size_digests(ctx, oracle_mod):
     oracle kernel in between (oracle.mat33_inverse is the host-side 3x3 inverse the reference computes with Eigen before the launch; the
     filtered frames are the HIP bilateral filter's, and their digest is part of the comparison)."""
     from hip_kernels import HipKernels
-    from kintinuous_amd import synth
     from oracle.oracle import OIntr      # a plain (fx, fy, cx, cy) record
     from full_size_scenario import scenario
     H = HipKernels(ctx)
-    cam = synth.Camera.scaled(1)
-    _, frames, _, _ = synth.sequence("orbit", 3, cam, 1234)
-    filtered = [H.bilateral_filter(d) for d, _ in frames]
-    _compare_digests(scenario(H, OIntr, oracle_mod.mat33_inverse, filtered), _full_size_gold())   # (mat33_inverse: host math only)
+    g, want = _full_size_gold()
+    filtered = [H.bilateral_filter(g["depth%d" % k]) for k in range(3)]
+    _compare_digests(scenario(H, g, OIntr, oracle_mod.mat33_inverse, filtered), want)   # (mat33_inverse: host math only)
