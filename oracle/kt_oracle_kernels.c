@@ -1250,7 +1250,9 @@ size_t kto_slice_process(const kto_point* in, size_t n, int weight_cull, float l
         free(pr);
     }
     /* ---- NormalEstimation::computeFeature ---- */
-    const int kk = (size_t)k < nout ? k : (int)nout;
+    int kk = (size_t)k < nout ? k : (int)nout;
+    if (kk > 64) kk = 64;   /* the neighbour list below holds 64 (the reference asks for 20) */
+    if (kk < 1) kk = 1;
 #pragma omp parallel for schedule(static)
     for (long long q = 0; q < (long long)nout; ++q) {
         const float px = cen[6 * q], py = cen[6 * q + 1], pz = cen[6 * q + 2];
