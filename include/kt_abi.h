@@ -283,6 +283,16 @@ int kt_tracker_debug_state(kt_tracker* t, float out29_host[29]);
 /* PMC calibration hook: stream `bytes` of a device buffer with 2- or 4-byte-per-lane coalesced accesses (the widths of the tsdf /
  * colour volume accesses); rmw = 0 reads, 1 reads and writes back.  Used by scripts/pmc_calibrate.py to scale FETCH_SIZE / WRITE_SIZE. */
 int kt_debug_stream(kt_ctx* ctx, void* buf, size_t bytes, int elem_size, int rmw);
+/* PMC calibration on the voxel kernel's own access pattern: a wave owns a 32 x 2 wave-column of an N x N x Z array and walks z, so an
+ * access is two 32-lane rows (64 B at elem_size 2, 128 B at 4).  halves = 2 reads every element once; halves = 1 only the even
+ * wave-columns (elem_size 2: the left 64 bytes of every 128-byte line).  N % 32 == 0, Z % 4 == 0. */
+int kt_debug_stream_rows(kt_ctx* ctx, void* buf, int N, int Z, int elem_size, int halves, int rmw);
+/* issue cost of one instruction kind (csrc/kt_debug.hip lists them) at waves_per_simd resident waves: out_host = {mean, max shader
+ * ticks per wave for the loop, wave-instructions of that kind per wave, launch duration in ms} */
+int kt_debug_valu_rates(kt_ctx* ctx, int kind, int iters, int waves_per_simd, double out_host[4]);
+/* test hook: the voxel kernel's division shortcut (table reciprocal + one correction) against the IEEE division for every finite float
+ * numerator and every divisor 1..256: out_host = {mismatches, float bits of the largest |numerator| among them, mismatches at |n| >= 2^-100} */
+int kt_debug_div_check(kt_ctx* ctx, unsigned int out_host[3]);
 /* test hook: out[v + 32768] = the device's unpack_tsdf(v) for every short v (device.hpp:77-83 restated without a division) */
 int kt_debug_unpack_table(kt_ctx* ctx, float* out_host65536);
 /* test hook: number of floats d, 2^-20 <= |d| <= 2^20, for which the voxel kernel's unwrapped reciprocal chain differs from 1.0f / d */
@@ -295,6 +305,14 @@ int kt_debug_rcp_check(kt_ctx* ctx, unsigned int* mismatches_host);
  * out_host needs room for n points; *n_out receives the count. */
 int kt_slice_process(kt_ctx* ctx, const kt_point_xyzrgb* points_host, size_t n, int weight_cull, float leaf, int k,
                      kt_point_xyzrgbnormal* out_host, size_t* n_out);
+
+/* CloudSliceProcessor::save (backend/CloudSliceProcessor.cpp:180-231), host code, once per run:
+ * kt_host_voxel_grid_normal = the pcl::VoxelGrid<pcl::PointXYZRGBNormal> at `leaf` it applies to the concatenated processed clouds when
+ * extractOverlap && !saveOverlap (:197-218; every field averaged per leaf, rgb re-packed with a zero alpha byte, leaves in key order);
+ * out needs room for n points.  kt_host_save_pcd = pcl::io::savePCDFile(path, cloud, true) (:224-226): PCD v0.7, DATA binary,
+ * FIELDS x y z rgb normal_x normal_y normal_z curvature, 32 bytes per point. */
+int kt_host_voxel_grid_normal(const kt_point_xyzrgbnormal* in, size_t n, float leaf, kt_point_xyzrgbnormal* out, size_t* n_out);
+int kt_host_save_pcd(const char* path, const kt_point_xyzrgbnormal* points, size_t n);
 
 /* Place-recognition tap (KintinuousTracker::addToPlaceRecognition, KintinuousTracker.cpp:917-958): the frames sampled for the
  * loop-closure backend, in order.  The library keeps the sample's metadata (PlaceRecognitionInput::utime / trans / rotation and the

@@ -131,6 +131,9 @@ _PROTOS = {
     "kt_tracker_debug_counts": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_debug_state": (_i, [_vp, _pf]),
     "kt_debug_stream": (_i, [_vp, _vp, _sz, _i, _i]),
+    "kt_debug_stream_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
+    "kt_debug_valu_rates": (_i, [_vp, _i, _i, _i, _pd]),
+    "kt_debug_div_check": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_debug_unpack_table": (_i, [_vp, _pf]),
     "kt_debug_rcp_check": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_num_pr_samples": (_i, [_vp]),
@@ -138,6 +141,8 @@ _PROTOS = {
     "kt_tracker_slice_pr_id": (_i, [_vp, _i, C.POINTER(C.c_int)]),
     "kt_host_place_recognition_movement": (_f, [_pf, _pf, _pf, _pf]),
     "kt_slice_process": (_i, [_vp, _vp, _sz, _i, _f, _i, _vp, C.POINTER(_sz)]),
+    "kt_host_voxel_grid_normal": (_i, [_vp, _sz, _f, _vp, C.POINTER(_sz)]),
+    "kt_host_save_pcd": (_i, [C.c_char_p, _vp, _sz]),
     "kt_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
     "kt_comm_init": (_i, [_vp, _i, _i, C.POINTER(C.c_ubyte), C.POINTER(_vp)]),
     "kt_pose_gather": (_i, [_vp, _vp, _i, _pf]),

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libkt_hip.so")
 BUILD_DIR = os.path.join(os.path.dirname(_HERE), "build")
-SOURCES = ["kt_context.hip", "kt_image.hip", "kt_volume.hip", "kt_track.hip", "kt_tracker.hip", "kt_hostmath.hip", "kt_comm.hip", "kt_slice.hip"]
+SOURCES = ["kt_context.hip", "kt_image.hip", "kt_volume.hip", "kt_track.hip", "kt_tracker.hip", "kt_hostmath.hip", "kt_comm.hip", "kt_slice.hip", "kt_cloud.hip", "kt_debug.hip"]
 # -ffp-contract=off: a*b+c fuses only where __builtin_fmaf is written (bit-parity with the oracle);
 # IEEE division / sqrt are hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,209 @@
+// kt_debug.hip -- measurement hooks that are not part of the data path (scripts/pmc_calibrate.py, scripts/valu_rates.py):
+//   kt_debug_stream_rows   PMC calibration on tsdf23's REAL access pattern: a wave owns a 32 x 2 wave-column and walks z, so every
+//                          access is two 32-lane rows (64 B of tsdf / 128 B of colour each), N^2 elements apart between z-steps;
+//   kt_debug_valu_rates    issue cost of the instruction kinds tsdf23 is made of, at 1..8 waves per SIMD (shader cycles per
+//                          wave-instruction per SIMD), so that the kernel's instruction roof is a measured number.
+#include "kt_internal.hpp"
+
+// One launch reads every element of an N x N x Z array exactly once (halves = 2), or only the columns of the even wave-columns
+// (halves = 1: for 2-byte elements that is the LEFT 64 bytes of every 128-byte line -- if the memory side fetched whole lines the
+// counters would not halve).  The 4 waves of a workgroup take 4 x-neighbouring wave-columns, like tsdf23's task order.
+template <typename T>
+__global__ __launch_bounds__(256) void kt_stream_rows_kernel(T* __restrict__ p, int N, int Z, int halves, int rmw, unsigned int* __restrict__ sink)
+{
+    const int lane = threadIdx.x & 63;
+    const int XG = N / 32, YG = N / 2;
+    const unsigned int plane = (unsigned int)N * (unsigned int)N;
+    unsigned int acc = 0;
+    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < XG * YG; w += gridDim.x * 4) {
+        const int xg = w % XG, yg = w / XG;
+        if (halves == 1 && (xg & 1)) continue;
+        const size_t col = (size_t)(yg * 2 + (lane >> 5)) * N + xg * 32 + (lane & 31);
+        for (int z = 0; z < Z; z += 4) {
+            T v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p[col + (size_t)(z + u) * plane];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc += (unsigned int)v[u];
+                if (rmw) p[col + (size_t)(z + u) * plane] = (T)(v[u] + 1);
+            }
+        }
+    }
+    if (acc == 0x12345678u) *sink = acc;  // keeps the loads alive
+}
+
+extern "C" int kt_debug_stream_rows(kt_ctx* c, void* buf, int N, int Z, int elem_size, int halves, int rmw)
+{
+    KT_ARG(c && buf && (elem_size == 2 || elem_size == 4) && N > 0 && N % 32 == 0 && Z > 0 && Z % 4 == 0 && (halves == 1 || halves == 2));
+    if (elem_size == 2) hipLaunchKernelGGL(kt_stream_rows_kernel<unsigned short>, dim3(2048), dim3(256), 0, c->stream, (unsigned short*)buf, N, Z, halves, rmw, &c->counters[8]);
+    else hipLaunchKernelGGL(kt_stream_rows_kernel<unsigned int>, dim3(2048), dim3(256), 0, c->stream, (unsigned int*)buf, N, Z, halves, rmw, &c->counters[8]);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// ---- VALU / SALU issue rates ----------------------------------------------------------------------------------------------
+// Every wave runs `iters` trips of a loop whose body is 32 instructions of one kind over 8 independent register chains (so the
+// chain latency of ~4 cycles is covered from 2 waves per SIMD on) and reports s_memtime ticks (= shader cycles) for the loop.
+// kinds: 0 v_fma_f32   1 v_pk_fma_f32   2 v_rcp_f32   3 v_rndne_f32 + v_cvt_i32_f32   4 v_fma_f32 with an s_add_u32 between any two
+//        5 v_readlane_b32 (to SGPR) + v_fma_f32 using it   6 v_sqrt_f32   7 v_cndmask_b32 + v_cmp_gt_f32 pairs   8 v_pk_add_f32
+//        9 v_mad_u32_u24   10 v_cvt_f32_ubyte0
+template <int KIND>
+__global__ __launch_bounds__(256) void kt_valu_rate_kernel(int iters, unsigned long long* __restrict__ ticks, float* __restrict__ sink)
+{
+    float a0 = threadIdx.x * 1e-3f + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b0 = a0 + 8, b1 = a0 + 9, b2 = a0 + 10, b3 = a0 + 11, b4 = a0 + 12, b5 = a0 + 13, b6 = a0 + 14, b7 = a0 + 15;
+    const float m = 0.999f, k = 1e-3f;
+    unsigned int s = blockIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (KIND == 0)
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k));
+            else if constexpr (KIND == 1) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3}, p4 = {a4, b4}, p5 = {a5, b5}, p6 = {a6, b6}, p7 = {a7, b7};
+                const f2 mm = {m, m}, kk = {k, k};
+                asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                             "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(mm), "v"(kk));
+                a0 = p0.x; b0 = p0.y; a1 = p1.x; b1 = p1.y; a2 = p2.x; b2 = p2.y; a3 = p3.x; b3 = p3.y;
+                a4 = p4.x; b4 = p4.y; a5 = p5.x; b5 = p5.y; a6 = p6.x; b6 = p6.y; a7 = p7.x; b7 = p7.y;
+            } else if constexpr (KIND == 2)
+                asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                             "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if constexpr (KIND == 3)
+                asm volatile("v_rndne_f32 %0, %0\n v_cvt_i32_f32 %1, %1\n v_rndne_f32 %2, %2\n v_cvt_i32_f32 %3, %3\n"
+                             "v_rndne_f32 %4, %4\n v_cvt_i32_f32 %5, %5\n v_rndne_f32 %6, %6\n v_cvt_i32_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if constexpr (KIND == 4)
+                asm volatile("v_fma_f32 %0, %0, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %1, %1, %9, %10\n s_add_u32 %8, %8, 1\n"
+                             "v_fma_f32 %2, %2, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %3, %3, %9, %10\n s_add_u32 %8, %8, 1\n"
+                             "v_fma_f32 %4, %4, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %5, %5, %9, %10\n s_add_u32 %8, %8, 1\n"
+                             "v_fma_f32 %6, %6, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %7, %7, %9, %10\n s_add_u32 %8, %8, 1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s) : "v"(m), "v"(k) : "scc");
+            else if constexpr (KIND == 5) {
+                unsigned int s0, s1, s2, s3;
+                asm volatile("v_readlane_b32 %8, %0, 3\n v_readlane_b32 %9, %1, 5\n v_readlane_b32 %10, %2, 7\n v_readlane_b32 %11, %3, 9\n"
+                             "s_nop 0\n"
+                             "v_fma_f32 %4, %8, %4, %12\n v_fma_f32 %5, %9, %5, %12\n v_fma_f32 %6, %10, %6, %12\n v_fma_f32 %7, %11, %7, %12\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "v"(k));
+            } else if constexpr (KIND == 6)
+                asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n"
+                             "v_sqrt_f32 %4, %4\n v_sqrt_f32 %5, %5\n v_sqrt_f32 %6, %6\n v_sqrt_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if constexpr (KIND == 7)
+                asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_gt_f32 vcc, %4, %5\n v_cndmask_b32 %6, %6, %7, vcc\n"
+                             "v_cmp_gt_f32 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc\n v_cmp_gt_f32 vcc, %5, %4\n v_cndmask_b32 %7, %7, %6, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
+            else if constexpr (KIND == 8) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3}, p4 = {a4, b4}, p5 = {a5, b5}, p6 = {a6, b6}, p7 = {a7, b7};
+                const f2 kk = {k, k};
+                asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
+                             "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(kk));
+                a0 = p0.x; b0 = p0.y; a1 = p1.x; b1 = p1.y; a2 = p2.x; b2 = p2.y; a3 = p3.x; b3 = p3.y;
+                a4 = p4.x; b4 = p4.y; a5 = p5.x; b5 = p5.y; a6 = p6.x; b6 = p6.y; a7 = p7.x; b7 = p7.y;
+            } else if constexpr (KIND == 9)
+                asm volatile("v_mad_u32_u24 %0, %0, %8, %1\n v_mad_u32_u24 %1, %1, %8, %2\n v_mad_u32_u24 %2, %2, %8, %3\n v_mad_u32_u24 %3, %3, %8, %4\n"
+                             "v_mad_u32_u24 %4, %4, %8, %5\n v_mad_u32_u24 %5, %5, %8, %6\n v_mad_u32_u24 %6, %6, %8, %7\n v_mad_u32_u24 %7, %7, %8, %0\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+            else
+                asm volatile("v_cvt_f32_ubyte0 %0, %0\n v_cvt_f32_ubyte0 %1, %1\n v_cvt_f32_ubyte0 %2, %2\n v_cvt_f32_ubyte0 %3, %3\n"
+                             "v_cvt_f32_ubyte0 %4, %4\n v_cvt_f32_ubyte0 %5, %5\n v_cvt_f32_ubyte0 %6, %6\n v_cvt_f32_ubyte0 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7 + (float)s;
+    if (r == 1.2345678f) *sink = r;
+}
+
+// waves_per_simd blocks of 256 threads per CU (4 waves = one per SIMD each); out_host[0] = mean ticks per wave for the loop,
+// [1] = max, [2] = wave-instructions per wave (iters * 32), [3] = the launch's duration in ms (HIP events)
+extern "C" int kt_debug_valu_rates(kt_ctx* c, int kind, int iters, int waves_per_simd, double out_host[4])
+{
+    KT_ARG(c && out_host && kind >= 0 && kind <= 10 && iters > 0 && waves_per_simd >= 1 && waves_per_simd <= 8);
+    const int blocks = 256 * waves_per_simd;
+    unsigned long long* ticks = nullptr;
+    KT_HIP(hipMalloc((void**)&ticks, sizeof(unsigned long long) * blocks * 4));
+    float* sink = (float*)&c->counters[8];
+#define KT_RATE_CASE(K) case K: hipLaunchKernelGGL(kt_valu_rate_kernel<K>, dim3(blocks), dim3(256), 0, c->stream, iters, ticks, sink); break;
+    hipEvent_t ev[2];
+    KT_HIP(hipEventCreate(&ev[0])); KT_HIP(hipEventCreate(&ev[1]));
+    for (int rep = 0; rep < 2; ++rep) {   // the second launch is the one read back (clocks ramped, code resident)
+        if (rep == 1) KT_HIP(hipEventRecord(ev[0], c->stream));
+        switch (kind) {
+            KT_RATE_CASE(0) KT_RATE_CASE(1) KT_RATE_CASE(2) KT_RATE_CASE(3) KT_RATE_CASE(4) KT_RATE_CASE(5)
+            KT_RATE_CASE(6) KT_RATE_CASE(7) KT_RATE_CASE(8) KT_RATE_CASE(9) KT_RATE_CASE(10)
+        }
+    }
+    KT_HIP(hipEventRecord(ev[1], c->stream));
+#undef KT_RATE_CASE
+    KT_LAUNCH_CHECK();
+    unsigned long long* h = (unsigned long long*)malloc(sizeof(unsigned long long) * blocks * 4);
+    KT_HIP(hipMemcpyAsync(h, ticks, sizeof(unsigned long long) * blocks * 4, hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    double sum = 0, mx = 0;
+    for (int i = 0; i < blocks * 4; ++i) { sum += (double)h[i]; if ((double)h[i] > mx) mx = (double)h[i]; }
+    out_host[0] = sum / (blocks * 4); out_host[1] = mx; out_host[2] = (double)iters * 32;
+    float ms = 0;
+    KT_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    out_host[3] = ms;
+    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    free(h);
+    KT_HIP(hipFree(ticks));
+    return KT_OK;
+}
+
+// ---- exhaustive check of the voxel kernel's division shortcut --------------------------------------------------------------
+// kt_tsdf_consume (KT_TSDF_MARK) forms (F W + tsdf) / (W + 1) as q = n y, q' = fma(fma(-d, q, n), y, q) with y = RN(1 / d):
+// compared here with the IEEE division for EVERY finite float numerator n and every divisor d = 1 .. 256.
+// out[0] = mismatches, out[1] = largest |n| (as float bits) among them, out[2] = mismatches with |n| >= 2^-100
+__global__ __launch_bounds__(256) void kt_div_check_kernel(unsigned int* __restrict__ out)
+{
+    const float d = (float)(blockIdx.y + 1);
+    float y = 1.0f / d;
+    asm volatile("" : "+v"(y));
+    unsigned int bad = 0, bad_big = 0, worst = 0;
+    for (unsigned int hi = blockIdx.x; hi < (1u << 16); hi += gridDim.x) {
+        const unsigned int base = (hi << 16) | (threadIdx.x << 8);
+#pragma unroll 4
+        for (unsigned int lo = 0; lo < 256u; ++lo) {
+            const unsigned int bits = base | lo;
+            if ((bits & 0x7f800000u) == 0x7f800000u) continue;   // inf / NaN
+            const float n = __uint_as_float(bits);
+            float q = n / d;
+            asm volatile("" : "+v"(q));
+            const float q0 = n * y;
+            const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), y, q0);
+            if (__float_as_uint(q1) != __float_as_uint(q)) {
+                ++bad;
+                const unsigned int mag = bits & 0x7fffffffu;
+                if (mag >= 0x0d800000u) ++bad_big;   // 2^-100
+                worst = max(worst, mag);
+            }
+        }
+    }
+    if (bad) { atomicAdd(out, bad); atomicMax(out + 1, worst); }
+    if (bad_big) atomicAdd(out + 2, bad_big);
+}
+extern "C" int kt_debug_div_check(kt_ctx* c, unsigned int out_host[3])
+{
+    KT_ARG(c && out_host);
+    unsigned int* d = nullptr;
+    KT_HIP(hipMalloc((void**)&d, 3 * sizeof(unsigned int)));
+    KT_HIP(hipMemsetAsync(d, 0, 3 * sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(kt_div_check_kernel, dim3(1024, 256), dim3(256), 0, c->stream, d);
+    KT_HIP(hipMemcpyAsync(out_host, d, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    KT_HIP(hipFree(d));
+    return KT_OK;
+}

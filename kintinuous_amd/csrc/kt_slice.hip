@@ -100,10 +100,12 @@ __global__ __launch_bounds__(256) void slice_centroids(const kt_point_xyzrgb* __
         const kt_point_xyzrgb p = pts[src[j]];
         acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += (float)p.r; acc[4] += (float)p.g; acc[5] += (float)p.b;
     }
-    const float cnt = (float)(j - i);
+    // `centroid /= static_cast<float>(count)` on an Eigen::VectorXf: Eigen 3.2 (the reference's, README.md:14-31) evaluates a
+    // floating-point `/= s` as a multiplication by Scalar(1) / s (SelfCwiseBinaryOp.h; true division only from 3.3 on)
+    const float inv_cnt = 1.0f / (float)(j - i);
     const unsigned int q = leaf_of[i] - 1u;   // inclusive scan of the head flags
 #pragma unroll
-    for (int a = 0; a < 6; ++a) cen[(size_t)q * 6 + a] = acc[a] / cnt;
+    for (int a = 0; a < 6; ++a) cen[(size_t)q * 6 + a] = acc[a] * inv_cnt;
     leaf_key[q] = key;
 }
 
@@ -182,7 +184,7 @@ __device__ __forceinline__ int lower_bound(const unsigned int* __restrict__ leaf
 
 // one thread per down-sampled point: kNN over the leaf grid, covariance, normal, curvature
 __global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ cen, const unsigned int* __restrict__ leaf_key, int L, Grid g, int k,
-                                                     int gridded, kt_point_xyzrgbnormal* __restrict__ out)
+                                                     int gridded, const kt_point_xyzrgb* __restrict__ pts, kt_point_xyzrgbnormal* __restrict__ out)
 {
     const int q = blockIdx.x * 128 + threadIdx.x;
     if (q >= L) return;
@@ -234,8 +236,10 @@ __global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ c
     kt_point_xyzrgbnormal o;
     o.x = px; o.y = py; o.z = pz; o.pad0 = 1.0f;
     o.pad1 = 0.0f; o.pad2[0] = 0.0f; o.pad2[1] = 0.0f;
-    // VoxelGrid: r, g, b = static_cast<uint8_t> of the float means; the packed rgb has a zero alpha byte
-    o.r = (unsigned char)cen[(size_t)q * 6 + 3]; o.g = (unsigned char)cen[(size_t)q * 6 + 4]; o.b = (unsigned char)cen[(size_t)q * 6 + 5]; o.a = 0;
+    // VoxelGrid: r, g, b = static_cast<uint8_t> of the float means; the packed rgb has a zero alpha byte -- except in the "leaf size
+    // too small" case, where `output = *input_` keeps every point as it is, its weight byte included
+    o.r = (unsigned char)cen[(size_t)q * 6 + 3]; o.g = (unsigned char)cen[(size_t)q * 6 + 4]; o.b = (unsigned char)cen[(size_t)q * 6 + 5];
+    o.a = gridded ? (unsigned char)0 : pts[q].a;
     if (cnt < 3) {   // NormalEstimation: fewer than 3 neighbours -> NaN normal and curvature
         o.normal_x = o.normal_y = o.normal_z = o.curvature = __builtin_nanf("");
         out[q] = o;
@@ -247,8 +251,9 @@ __global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ c
         acc[0] += x * x; acc[1] += x * y; acc[2] += x * z; acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
         acc[6] += x; acc[7] += y; acc[8] += z;
     }
+    const float inv_cnt = 1.0f / (float)cnt;   // computeMeanAndCovarianceMatrix: `accu /= static_cast<Scalar>(point_count)`, Eigen 3.2 (see slice_centroids)
 #pragma unroll
-    for (int a = 0; a < 9; ++a) acc[a] /= (float)cnt;
+    for (int a = 0; a < 9; ++a) acc[a] *= inv_cnt;
     float cov[9];
     cov[0] = acc[0] - acc[6] * acc[6]; cov[1] = acc[1] - acc[6] * acc[7]; cov[2] = acc[2] - acc[6] * acc[8];
     cov[4] = acc[3] - acc[7] * acc[7]; cov[5] = acc[4] - acc[7] * acc[8]; cov[8] = acc[5] - acc[8] * acc[8];
@@ -351,7 +356,9 @@ extern "C" int kt_slice_process(kt_ctx* c, const kt_point_xyzrgb* points_host, s
     }
     KT_TRY(b.alloc(&d_cen, (size_t)m * 6)); KT_TRY(b.alloc(&d_leafkey, m)); KT_TRY(b.alloc(&d_out, m));
     int L = 0, gridded = 1;
-    if ((long long)g.div_b[0] * g.div_b[1] * g.div_b[2] > 2147483647LL) {
+    // voxel_grid.hpp: dx = static_cast<int64_t>((max_p[0] - min_p[0]) * inverse_leaf_size_[0]) + 1, ...; dx * dy * dz > INT32_MAX
+    if (((long long)((box.mx[0] - box.mn[0]) * g.inv_leaf) + 1) * ((long long)((box.mx[1] - box.mn[1]) * g.inv_leaf) + 1) *
+            ((long long)((box.mx[2] - box.mn[2]) * g.inv_leaf) + 1) > 2147483647LL) {
         // "Leaf size is too small for the input dataset. Integer indices would overflow.": PCL passes the cloud through unfiltered
         hipLaunchKernelGGL(slice_passthrough, dim3(mb), dim3(256), 0, st, d_pts, m, d_cen, d_leafkey);
         KT_LAUNCH_CHECK();
@@ -374,7 +381,7 @@ extern "C" int kt_slice_process(kt_ctx* c, const kt_point_xyzrgb* points_host, s
         L = (int)leaves;
     }
     // ---- NormalEstimation (kNN) + concatenateFields ----
-    hipLaunchKernelGGL(slice_normals, dim3(kt_div_up(L, 128)), dim3(128), 0, st, d_cen, d_leafkey, L, g, k, gridded, d_out);
+    hipLaunchKernelGGL(slice_normals, dim3(kt_div_up(L, 128)), dim3(128), 0, st, d_cen, d_leafkey, L, g, k, gridded, d_pts, d_out);
     KT_LAUNCH_CHECK();
     KT_HIP(hipMemcpyAsync(out_host, d_out, (size_t)L * sizeof(kt_point_xyzrgbnormal), hipMemcpyDeviceToHost, st));
     KT_HIP(hipStreamSynchronize(st));

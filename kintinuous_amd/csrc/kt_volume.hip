@@ -531,6 +531,19 @@ struct kt_tsdf_batch {
 // Needs 32-bit byte offsets: N^3 * 4 < 2^32.
 struct kt_tsdf_bufs { __amdgpu_buffer_rsrc_t vol, col; };
 
+template <bool BUF>
+__device__ __forceinline__ void kt_tsdf_load_voxel(const kt_tsdf23_args& a, const kt_tsdf_bufs& m, kt_tsdf_batch& b, int u, unsigned int col_base, unsigned int plane)
+{
+    if constexpr (BUF) {
+        const unsigned int zoff = (unsigned int)b.sz[u] * plane;   // elements; wave-uniform
+        b.tsdf_raw[u] = __builtin_amdgcn_raw_buffer_load_b16(m.vol, col_base * 2u, zoff * 2u, 0);
+        b.col[u] = __builtin_amdgcn_raw_buffer_load_b32(m.col, col_base * 4u, zoff * 4u, 0);
+    } else {
+        b.tsdf_raw[u] = a.volume[b.off[u]];
+        b.col[u] = *(const unsigned int*)&a.color[b.off[u]];
+    }
+}
+
 // 1 / d, correctly rounded, without the scaling wrapper of the IEEE expansion (v_div_scale x2, v_div_fixup): the refinement chain
 // hipcc emits for 1.0f / d, which is exact as it stands whenever nothing in it can overflow or go denormal.  The caller guarantees
 // 2^-20 <= |d| <= 2^20 (checked once per task at the ends of the z chunk: d is monotone in z); kt_debug_exact_ops compares it
@@ -553,6 +566,17 @@ __device__ __forceinline__ float kt_rcp_exact(float d)
 // outside its conservative interval fails it by construction), which is cheaper than two more compares per step.
 // (Non-temporal volume loads / stores, meant to keep the streamed volume from evicting the pixel records in L2, measured 17% slower
 // on the 512^3 orbit and neutral on the dense 768^3 case.)
+// Variants kept switchable for A/B runs (scripts/exp_variants.sh; measured in profiles/r03_tsdf23_variants_call*.log):
+#ifndef KT_TSDF_DEFER
+#define KT_TSDF_DEFER 1   // 1: the volume words are loaded only for voxels that a cheap bound on the update predicate lets through
+#endif                    //    (0: speculatively for every voxel that projects into the image; -5 % time, -9 % fetched bytes)
+#ifndef KT_TSDF_MARK
+#define KT_TSDF_MARK 1    // 1: the running average's division as a table reciprocal + one correction step (0: the IEEE sequence; -0.5 %)
+#endif
+// (packed fp32 for the projection -- depths and reciprocal chains of two z-steps per v_pk_fma_f32, both image coordinates of a step
+// in one -- was measured with them: 1077 -> 1056 static VALU, launch time unchanged to 0.1 us on both workloads.  On gfx950 a
+// v_pk_fma_f32 occupies the issue port 1.5x as long as a v_fma_f32 (profiles/r03_valu_rates.md), and hipcc spends the rest on moves.)
+
 template <bool COUNT, bool BUF, bool FAST>
 __device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, const kt_tsdf_bufs& m, kt_tsdf_batch& b, int zb, int z_end, bool lane_ok,
                                               unsigned int col_base, unsigned int plane, float v_z, float& v_x, float& v_y, float dvx,
@@ -584,29 +608,44 @@ __device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, const kt_
         v_x += dvx;  // the walk advances on every step, also on skipped ones
         v_y += dvy;
     }
+#if !KT_TSDF_DEFER
 #pragma unroll
     for (int u = 0; u < KT_TSDF_UNROLL; ++u)
-        if (b.in_img[u]) {
-            if constexpr (BUF) {
-                const unsigned int zoff = (unsigned int)b.sz[u] * plane;   // elements; wave-uniform
-                b.tsdf_raw[u] = __builtin_amdgcn_raw_buffer_load_b16(m.vol, col_base * 2u, zoff * 2u, 0);
-                b.col[u] = __builtin_amdgcn_raw_buffer_load_b32(m.col, col_base * 4u, zoff * 4u, 0);
-            } else {
-                b.tsdf_raw[u] = a.volume[b.off[u]];
-                b.col[u] = *(const unsigned int*)&a.color[b.off[u]];
-            }
-        }
+        if (b.in_img[u]) kt_tsdf_load_voxel<BUF>(a, m, b, u, col_base, plane);
+#endif
 }
 
 template <bool COUNT, bool BUF>
-__device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const kt_tsdf_bufs& m, const kt_tsdf_batch& b, float v_g_part_norm,
+__device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const kt_tsdf_bufs& m, kt_tsdf_batch& b, float v_g_part_norm,
                                                 float tranc_dist_inv, unsigned int& n_upd, int brick_xy, unsigned int& n_img,
-                                                unsigned int col_base, unsigned int plane)
+                                                unsigned int col_base, unsigned int plane, const float* __restrict__ s_rcp)
 {
+#if KT_TSDF_DEFER
+    // The update predicate (dp != 0 and sdf >= -trunc, sdf = |dp| - |v|) needs only the pixel record: |v|^2 <= (|dp| + trunc)^2 is
+    // necessary for it (1e-5 of relative slack covers the roundings of both sides: five float operations of <= 2^-24 each), so the
+    // tsdf and colour words are requested only for voxels that pass this bound -- on the 512^3 orbit a quarter of the voxels that
+    // project into the image lie behind the surface and never needed their 6 bytes.
+    bool may[KT_TSDF_UNROLL];
 #pragma unroll
     for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
+        const float s = fabsf(b.rec[u].dp) + a.tranc_dist;
+        may[u] = b.in_img[u] && b.rec[u].dp != 0 && __builtin_fmaf(b.vgz[u], b.vgz[u], v_g_part_norm) <= s * s * 1.00001f;
+    }
+#pragma unroll
+    for (int u = 0; u < KT_TSDF_UNROLL; ++u)
+        if (may[u]) kt_tsdf_load_voxel<BUF>(a, m, b, u, col_base, plane);
+    // (Splitting the record -- 4 bytes of scaled depth first, {weight, rgb} only for these voxels -- was measured too: 83 % / 75 % of
+    // the voxels in the image pass the bound on the two workloads, so nearly every record is fetched anyway and the second array
+    // only adds lines: +8 % fetched bytes, +7 % / +12 % time.)
+#endif
+#pragma unroll
+    for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
+        if (COUNT && b.in_img[u]) ++n_img;   // diagnostics: voxel steps that project into the image
+#if KT_TSDF_DEFER
+        if (!may[u]) continue;
+#else
         if (!b.in_img[u]) continue;
-        if (COUNT) ++n_img;   // diagnostics: voxel steps that project into the image
+#endif
         const float dp = b.rec[u].dp;
         const float Dp_scaled = fabsf(dp);          // a negative scaled depth flags "no colour" (tsdf_volume.cu:520-527, :590-594)
         const bool no_color = dp < 0.0f;
@@ -632,7 +671,17 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
             if (touch) {
                 const float tsdf = is_free ? 1.0f : fminf(1.0f, sdf * tranc_dist_inv);
                 const float tsdf_prev = kt_unpack_tsdf(b.tsdf_raw[u]);
+#if KT_TSDF_MARK
+                // (F W + tsdf) / (W + 1), correctly rounded without the IEEE division sequence: y = RN(1 / (W + 1)) from a 256-entry
+                // table in LDS (built with the division at kernel start), q = RN(n y), one exact residual, one correction (Markstein:
+                // with a correctly rounded y the corrected q is the correctly rounded quotient).  kt_debug_div_check compares it with
+                // the division for every finite float numerator and every divisor 1..256.
+                const float num = __builtin_fmaf(tsdf_prev, weight_prev, tsdf), den = weight_prev + 1.0f, y = s_rcp[c >> 24];
+                const float q0 = num * y;
+                const short packed = kt_pack_tsdf(__builtin_fmaf(__builtin_fmaf(-den, q0, num), y, q0));
+#else
                 const short packed = kt_pack_tsdf(__builtin_fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
+#endif
                 if (packed != b.tsdf_raw[u]) {   // an unchanged word is not written back
                     if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b16(packed, m.vol, col_base * 2u, (unsigned int)b.sz[u] * plane * 2u, 0);
                     else a.volume[b.off[u]] = packed;
@@ -640,8 +689,8 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
                 }                                                                  // that stays was flagged when it was first stored)
             }
         }
-        // weight: min(W + 1, 128) in the top byte, on the whole word: W <= 128 always, so only 128 + 1 has to be undone
-        unsigned int o = min(c + 0x01000000u, c | 0x80000000u);
+        // weight: min(W + 1, 128) in the top byte, on the whole word (saturating add: W = 255 must not wrap)
+        unsigned int o = min(__builtin_elementwise_add_sat(c, 0x01000000u), (c & 0x00ffffffu) | 0x80000000u);   // also for foreign weights above 128
         const unsigned int rgbf = b.rec[u].rgbf;
         // colour update iff (normal valid and not flagged "no colour") or the stored colour is (0, 0, 0)  (tsdf_volume.cu:623).
         // A voxel whose stored colour already equals the pixel's keeps it: with c == rgb the blend is
@@ -693,6 +742,14 @@ __global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_ts
 {
     kt_tsdf23_args a = a_in;
     kt_tsdf_bufs m = {};
+#if KT_TSDF_MARK
+    __shared__ float s_rcp_tab[256];
+    s_rcp_tab[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);   // RN(1 / (W + 1)) for every weight byte W
+    __syncthreads();
+    const float* s_rcp = s_rcp_tab;
+#else
+    const float* s_rcp = nullptr;
+#endif
     if constexpr (BUF) {   // descriptors from kernel arguments only: they stay in SGPRs
         const unsigned int nvox = (unsigned int)a_in.N * (unsigned int)a_in.N * (unsigned int)a_in.N;
         m.vol = __builtin_amdgcn_make_buffer_rsrc((void*)a_in.volume, 0, nvox * 2u, 0x00020000);
@@ -766,7 +823,7 @@ __global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_ts
             kt_tsdf_batch cur;
             if (fast) kt_tsdf_issue<COUNT, BUF, true>(a, m, cur, zb, wz1, lane_ok, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base, r8);
             else kt_tsdf_issue<COUNT, BUF, false>(a, m, cur, zb, wz1, lane_ok, col_base, plane, v_z, v_x, v_y, dvx, dvy, tab_vgz, tab_zs, tab_base, r8);
-            kt_tsdf_consume<COUNT, BUF>(a, m, cur, v_g_part_norm, tranc_dist_inv, n_upd, brick_xy, n_img, col_base, plane);
+            kt_tsdf_consume<COUNT, BUF>(a, m, cur, v_g_part_norm, tranc_dist_inv, n_upd, brick_xy, n_img, col_base, plane, s_rcp);
             if (COUNT) ++n_batches;
         }
         if (COUNT) ++n_tasks_done;

@@ -119,6 +119,9 @@ size_t kto_extract_cloud_slice(const int16_t* volume, const float volume_size[3]
 
 /* ---- f2: the per-slice stage of CloudSliceProcessor (weight cull, VoxelGrid, kNN normals); out48 = 12 floats per point ---- */
 size_t kto_slice_process(const kto_point* in, size_t n, int weight_cull, float leaf, int k, float* out48);
+/* CloudSliceProcessor::save (backend/CloudSliceProcessor.cpp:180-231): the final VoxelGrid<PointXYZRGBNormal> and the binary PCD */
+size_t kto_voxel_grid_normal(const float* in48, size_t n, float leaf, float* out48);
+size_t kto_pcd_binary(const float* pts48, size_t n, unsigned char* out);
 
 /* ---- a7 / a10 host math ---- */
 void kto_mat33_inverse(const kto_mat33* in, kto_mat33* out);            /* Eigen Matrix3f::inverse() (cofactor) */

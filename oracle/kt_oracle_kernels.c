@@ -9,6 +9,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1186,6 +1187,85 @@ static void sp_eigen33(const float mat[9], float* eigenvalue, float v[3])
     v[0] = w[0] / sl; v[1] = w[1] / sl; v[2] = w[2] / sl;
 }
 
+/* ================================================================================================
+ * f1  CloudSliceProcessor::save: the final pcl::VoxelGrid<pcl::PointXYZRGBNormal> over the concatenated processed clouds
+ * (backend/CloudSliceProcessor.cpp:197-218, run when extractOverlap && !saveOverlap) and pcl::io::savePCDFile(file, cloud, true)
+ * (:224-226).  PCL 1.7 filters/impl/voxel_grid.hpp with downsample_all_data_ (the default): every registered field of the point
+ * (x y z rgb normal_x normal_y normal_z curvature, 8 floats) is averaged as a float -- normals are NOT renormalised -- plus r, g, b
+ * as three more floats (the "RGB special case"); the averaged `rgb` float is then overwritten by the packed
+ * (int(r) << 16 | int(g) << 8 | int(b)) (alpha byte 0).  Leaves in key order; points of a leaf summed in input order (std::sort is
+ * unstable: fixed as in kto_slice_process); `centroid /= n` is Eigen 3.2's multiplication by 1 / n.  The output points are value-
+ * initialised PointXYZRGBNormal (data[3] = 1, data_n[3] = 0, the two floats behind curvature 0).  PARITY UNPINNED against PCL itself.
+ * in / out: 48-byte points {x y z 1 | nx ny nz 0 | bgra, curvature, 0, 0}; returns the count (<= n).
+ * ============================================================================================== */
+size_t kto_voxel_grid_normal(const float* in48, size_t n, float leaf, float* out48)
+{
+    if (n == 0) return 0;
+    const float inv_leaf = 1.0f / leaf;
+    float mn[3] = {in48[0], in48[1], in48[2]}, mx[3] = {in48[0], in48[1], in48[2]};
+    for (size_t i = 1; i < n; ++i)
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], in48[12 * i + a]); mx[a] = fmaxf(mx[a], in48[12 * i + a]); }
+    /* "Leaf size is too small for the input dataset": dx * dy * dz of the BOUNDING BOX in leaves must fit an int32 */
+    const long long dx = (long long)((mx[0] - mn[0]) * inv_leaf) + 1, dy = (long long)((mx[1] - mn[1]) * inv_leaf) + 1,
+                    dz = (long long)((mx[2] - mn[2]) * inv_leaf) + 1;
+    if (dx * dy * dz > 2147483647LL) { memcpy(out48, in48, n * 48); return n; }
+    int min_b[3], div_b[3];
+    for (int a = 0; a < 3; ++a) {
+        min_b[a] = (int)floorf(mn[a] * inv_leaf);
+        div_b[a] = (int)floorf(mx[a] * inv_leaf) - min_b[a] + 1;
+    }
+    sp_pair* pr = malloc(n * sizeof(sp_pair));
+    for (size_t i = 0; i < n; ++i) {
+        const float* p = &in48[12 * i];
+        const int i0 = (int)(floorf(p[0] * inv_leaf) - (float)min_b[0]), i1 = (int)(floorf(p[1] * inv_leaf) - (float)min_b[1]),
+                  i2 = (int)(floorf(p[2] * inv_leaf) - (float)min_b[2]);
+        pr[i].key = (unsigned)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]);
+        pr[i].src = (unsigned)i;
+    }
+    qsort(pr, n, sizeof(sp_pair), sp_pair_cmp);
+    size_t nout = 0, i = 0;
+    while (i < n) {
+        size_t j = i;
+        float c[11];
+        for (; j < n && pr[j].key == pr[i].key; ++j) {
+            const float* p = &in48[12 * pr[j].src];
+            const unsigned char* bgra = (const unsigned char*)&p[8];
+            /* field order of POINT_CLOUD_REGISTER_POINT_STRUCT(PointXYZRGBNormal): x y z rgb normal_x normal_y normal_z curvature */
+            const float t[11] = {p[0], p[1], p[2], p[8], p[4], p[5], p[6], p[9], (float)bgra[2], (float)bgra[1], (float)bgra[0]};
+            if (j == i) memcpy(c, t, sizeof(c));
+            else for (int a = 0; a < 11; ++a) c[a] += t[a];
+        }
+        const float inv_cnt = 1.0f / (float)(j - i);
+        for (int a = 0; a < 11; ++a) c[a] *= inv_cnt;
+        float* o = &out48[12 * nout];
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = 1.0f;
+        o[4] = c[4]; o[5] = c[5]; o[6] = c[6]; o[7] = 0.0f;
+        const int rgb = ((int)c[8] << 16) | ((int)c[9] << 8) | (int)c[10];
+        memcpy(&o[8], &rgb, 4);
+        o[9] = c[7]; o[10] = 0.0f; o[11] = 0.0f;
+        ++nout;
+        i = j;
+    }
+    free(pr);
+    return nout;
+}
+
+/* pcl::io::savePCDFile(file, cloud, true) = PCDWriter::writeBinary<PointXYZRGBNormal> (io/impl/pcd_io.hpp, PCL 1.7): the header
+ * generateHeader writes, "DATA binary", then per point the registered fields back to back (32 bytes: x y z rgb normal_x normal_y
+ * normal_z curvature; the struct's padding floats are not fields).  out must hold 512 + 32 n bytes; returns the byte count. */
+size_t kto_pcd_binary(const float* pts48, size_t n, unsigned char* out)
+{
+    const int h = sprintf((char*)out,
+                          "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb normal_x normal_y normal_z curvature\n"
+                          "SIZE 4 4 4 4 4 4 4 4\nTYPE F F F F F F F F\nCOUNT 1 1 1 1 1 1 1 1\nWIDTH %zu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\n"
+                          "POINTS %zu\nDATA binary\n", n, n);
+    unsigned char* o = out + h;
+    static const int field_at[8] = {0, 1, 2, 8, 4, 5, 6, 9};
+    for (size_t i = 0; i < n; ++i)
+        for (int f = 0; f < 8; ++f, o += 4) memcpy(o, &pts48[12 * i + field_at[f]], 4);
+    return (size_t)(o - out);
+}
+
 /* in: n points (32 B, kto_point); out: up to n points of 48 B {x y z 1 | nx ny nz 0 | b g r a, curvature, 0, 0}.  Returns the count. */
 size_t kto_slice_process(const kto_point* in, size_t n, int weight_cull, float leaf, int k, float* out48)
 {
@@ -1208,9 +1288,11 @@ size_t kto_slice_process(const kto_point* in, size_t n, int weight_cull, float l
         div_b[a] = max_b[a] - min_b[a] + 1;
     }
     size_t nout = 0;
+    int passthrough = 0;
     float* cen = NULL;        /* per leaf: x y z r g b */
     int* cell = NULL;         /* per leaf: i j k */
-    const long long cells = (long long)div_b[0] * div_b[1] * div_b[2];
+    /* voxel_grid.hpp: dx = static_cast<int64_t>((max_p[0] - min_p[0]) * inverse_leaf_size_[0]) + 1, ...; dx * dy * dz > INT32_MAX */
+    const long long cells = ((long long)((mx[0] - mn[0]) * inv_leaf) + 1) * ((long long)((mx[1] - mn[1]) * inv_leaf) + 1) * ((long long)((mx[2] - mn[2]) * inv_leaf) + 1);
     if (cells > 2147483647LL) { /* "Leaf size is too small for the input dataset": the cloud passes through unfiltered */
         cen = malloc(m * 6 * sizeof(float)); cell = malloc(m * 3 * sizeof(int));
         for (size_t i = 0; i < m; ++i) {
@@ -1219,6 +1301,7 @@ size_t kto_slice_process(const kto_point* in, size_t n, int weight_cull, float l
             cell[3 * i] = cell[3 * i + 1] = cell[3 * i + 2] = 0;
         }
         nout = m;
+        passthrough = 1;
     } else {
         sp_pair* pr = malloc(m * sizeof(sp_pair));
         for (size_t i = 0; i < m; ++i) {
@@ -1238,8 +1321,10 @@ size_t kto_slice_process(const kto_point* in, size_t n, int weight_cull, float l
                 acc[0] += p->x; acc[1] += p->y; acc[2] += p->z; acc[3] += (float)p->r; acc[4] += (float)p->g; acc[5] += (float)p->b;
                 ++j;
             }
-            const float cnt = (float)(j - i);
-            for (int a = 0; a < 6; ++a) cen[6 * nout + a] = acc[a] / cnt;
+            /* `centroid /= static_cast<float>(n)` on an Eigen::VectorXf: Eigen 3.2 (README.md:14-31: the Ubuntu 14.04 / 15.04 packages)
+             * evaluates a floating-point `/= s` as `*= Scalar(1) / s` (Core/SelfCwiseBinaryOp.h; true division only from Eigen 3.3 on) */
+            const float inv_cnt = 1.0f / (float)(j - i);
+            for (int a = 0; a < 6; ++a) cen[6 * nout + a] = acc[a] * inv_cnt;
             const unsigned key = pr[i].key;
             cell[3 * nout] = (int)(key % (unsigned)div_b[0]);
             cell[3 * nout + 1] = (int)((key / (unsigned)div_b[0]) % (unsigned)div_b[1]);
@@ -1269,9 +1354,11 @@ size_t kto_slice_process(const kto_point* in, size_t n, int weight_cull, float l
         float* o = &out48[12 * q];
         o[0] = px; o[1] = py; o[2] = pz; o[3] = 1.0f;
         o[7] = 0.0f; o[10] = 0.0f; o[11] = 0.0f;
-        /* VoxelGrid: r, g, b = (uint8) of the float means, packed into rgb with a zero alpha byte */
+        /* VoxelGrid: r, g, b = (uint8) of the float means, packed into rgb with a zero alpha byte (`output = *input_` of the
+         * leaf-too-small case keeps the point, its weight byte included) */
         unsigned char* c = (unsigned char*)&o[8];
-        c[0] = (unsigned char)cen[6 * q + 5]; c[1] = (unsigned char)cen[6 * q + 4]; c[2] = (unsigned char)cen[6 * q + 3]; c[3] = 0;
+        c[0] = (unsigned char)cen[6 * q + 5]; c[1] = (unsigned char)cen[6 * q + 4]; c[2] = (unsigned char)cen[6 * q + 3];
+        c[3] = passthrough ? pts[q].a : 0;
         if (cnt < 3) { o[4] = o[5] = o[6] = o[9] = NAN; continue; }
         float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int t = 0; t < cnt; ++t) {
@@ -1279,7 +1366,8 @@ size_t kto_slice_process(const kto_point* in, size_t n, int weight_cull, float l
             acc[0] += x * x; acc[1] += x * y; acc[2] += x * z; acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
             acc[6] += x; acc[7] += y; acc[8] += z;
         }
-        for (int a = 0; a < 9; ++a) acc[a] /= (float)cnt;
+        const float inv_cnt = 1.0f / (float)cnt;   /* `accu /= static_cast<Scalar>(point_count)` (centroid.hpp), Eigen 3.2: see above */
+        for (int a = 0; a < 9; ++a) acc[a] *= inv_cnt;
         float cov[9];
         cov[0] = acc[0] - acc[6] * acc[6]; cov[1] = acc[1] - acc[6] * acc[7]; cov[2] = acc[2] - acc[6] * acc[8];
         cov[4] = acc[3] - acc[7] * acc[7]; cov[5] = acc[4] - acc[7] * acc[8]; cov[8] = acc[5] - acc[8] * acc[8];

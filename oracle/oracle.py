@@ -313,6 +313,26 @@ def slice_process(points, weight_cull: int, leaf: float, k: int = 20) -> np.ndar
     return out[: int(n)]
 
 
+def voxel_grid_normal(points, leaf: float) -> np.ndarray:
+    """CloudSliceProcessor::save's final pcl::VoxelGrid<pcl::PointXYZRGBNormal> (every field averaged, leaves in key order)."""
+    points = np.ascontiguousarray(points)
+    assert points.dtype == NPOINT_DTYPE
+    out = np.zeros(max(len(points), 1), NPOINT_DTYPE)
+    lib().kto_voxel_grid_normal.restype = C.c_size_t
+    n = lib().kto_voxel_grid_normal(_p(points), C.c_size_t(len(points)), C.c_float(leaf), _p(out))
+    return out[: int(n)]
+
+
+def pcd_binary(points) -> bytes:
+    """pcl::io::savePCDFile(file, cloud, true) for pcl::PointXYZRGBNormal: header + 32 bytes per point."""
+    points = np.ascontiguousarray(points)
+    assert points.dtype == NPOINT_DTYPE
+    out = np.zeros(512 + 32 * len(points), np.uint8)
+    lib().kto_pcd_binary.restype = C.c_size_t
+    n = lib().kto_pcd_binary(_p(points), C.c_size_t(len(points)), _p(out))
+    return out[: int(n)].tobytes()
+
+
 # ---- host math -------------------------------------------------------------------------------------
 def mat33_inverse(R) -> np.ndarray:
     o = OMat33()

@@ -17,7 +17,7 @@ if [ "$mode" = build ]; then
     done
     wait
     objs=""
-    for f in kt_context kt_image kt_volume kt_track kt_tracker kt_hostmath kt_comm kt_slice; do
+    for f in kt_context kt_image kt_volume kt_track kt_tracker kt_hostmath kt_comm kt_slice kt_cloud kt_debug; do
       if [ -f $R/build/exp/${f}_$i.o ]; then objs="$objs $R/build/exp/${f}_$i.o"; else objs="$objs $R/build/$f.o"; fi
     done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/kintinuous_amd/libkt_exp_$i.so $objs

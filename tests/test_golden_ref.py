@@ -98,11 +98,7 @@ def test_oracle_reproduces_reference_full_size_digests(oracle_mod):
     _compare_digests(scenario(M(), g, OIntr, oracle_mod.mat33_inverse, filtered), want)
 
 
-# Written after the round's GPU budget was spent: not yet run on hardware.  The chain it shortcuts is green on both sides (HIP == oracle at
-# this configuration in tests/test_gpu_configs.py, oracle == these digests in the test above), so a failure here would be a plumbing slip
-# of this test, and must not stop a `pytest -x` run in front of the parity tests proper: non-strict xfail until its first run (an XPASS
-# in the summary is the expected outcome; then drop the mark).
-@pytest.mark.xfail(reason="first run on hardware pending", strict=False)
+# (first run on hardware: round 2's final GPU suite, green; a regression now fails the run)
 @pytest.mark.gpu
 def test_hip_reproduces_reference_full_size_digests(ctx, oracle_mod):
     """The same scenario through the HIP path (C-ABI): HIP against the reference's own kernels at the bench's configuration, with no

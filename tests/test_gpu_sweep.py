@@ -207,7 +207,7 @@ def test_random_state_integrate_hip(ctx, oracle_mod, seed):
     base = synth.orbit_trajectory(40)
     intr = OIntr(cam.fx, cam.fy, cam.cx, cam.cy)
     trunc = max(0.06 if size == 6.0 else max(0.01, size / 100), 2.1 * size / N)
-    vo, co = random_volume_state(rng, N, reachable=True)
+    vo, co = random_volume_state(rng, N, reachable=bool(seed % 2))   # (the weight update saturates and clamps like tsdf_volume.cu:621 for any byte)
     vh, ch = vo.copy(), co.copy()
     wrap = [int(v) for v in rng.integers(0, N, 3)]
     for k in range(3):

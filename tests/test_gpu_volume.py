@@ -239,3 +239,16 @@ def test_exact_reciprocal_all_floats(ctx):
     bad = C.c_uint(12345)
     abi._chk(abi.lib().kt_debug_rcp_check(ctx.h, C.byref(bad)))
     assert bad.value == 0
+
+
+def test_running_average_division_all_floats(ctx):
+    """tsdf23 forms (F W + tsdf) / (W + 1) as q = n y, q' = fma(fma(-d, q, n), y, q) with y = RN(1 / d) from a table (Markstein's
+    correction).  Compared on the device with the IEEE division for EVERY finite float numerator and every divisor 1..256 (1.1e12
+    pairs): identical wherever |n| >= 2^-100; below that the two may differ in the last bit of a quotient of magnitude < 2^-100, which
+    pack_tsdf (x 32767, truncate) maps to 0 either way."""
+    import ctypes as C
+    from kintinuous_amd import abi
+    out = (C.c_uint * 3)(1, 1, 1)
+    abi._chk(abi.lib().kt_debug_div_check(ctx.h, out))
+    assert out[2] == 0, list(out)
+    assert out[1] < 0x0d800000, hex(out[1])   # every differing numerator is below 2^-100
