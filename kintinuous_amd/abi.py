@@ -617,6 +617,23 @@ def slice_process(ctx: "Ctx", points: np.ndarray, weight_cull: int, leaf: float,
     return out[: n.value]
 
 
+def voxel_grid_normal(points: np.ndarray, leaf: float) -> np.ndarray:
+    """kt_host_voxel_grid_normal: CloudSliceProcessor::save's final pcl::VoxelGrid<pcl::PointXYZRGBNormal> (host code, no GPU)."""
+    points = np.ascontiguousarray(points)
+    assert points.dtype == NPOINT_DTYPE
+    out = np.zeros(max(len(points), 1), NPOINT_DTYPE)
+    n = C.c_size_t(0)
+    _chk(lib().kt_host_voxel_grid_normal(points.ctypes.data_as(C.c_void_p), len(points), float(leaf), out.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return out[: n.value]
+
+
+def save_pcd(path: str, points: np.ndarray) -> None:
+    """kt_host_save_pcd: pcl::io::savePCDFile(path, cloud, true) for pcl::PointXYZRGBNormal records."""
+    points = np.ascontiguousarray(points)
+    assert points.dtype == NPOINT_DTYPE
+    _chk(lib().kt_host_save_pcd(path.encode(), points.ctypes.data_as(C.c_void_p), len(points)))
+
+
 class Comm:
     """The path's single collective through the C-ABI (kt_comm_*: RCCL all-gather of dense poses).  Rank 0 makes the id, `share` hands
     it to the other ranks (bytes -> bytes; identity for one rank)."""

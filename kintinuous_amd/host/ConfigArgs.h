@@ -35,7 +35,10 @@ class ConfigArgs {
                      "  -f             flip colours (RGB <-> BGR)\n"
                      "  -tum           write poses with timestamps in seconds (TUM format; the .poses default)\n"
                      "  -o <prefix>    output prefix (default: the log name)\n"
-                     "  -pcd           write every extracted slice into <prefix>.pcd (binary, x y z rgb)\n"
+                     "  -cw <weight>   weight cull of the slice processor (default 8),  -nos do not keep overlapping points in the saved cloud\n"
+                     "  -pcdraw        debug: the extracted slices as they are into <prefix>.raw.pcd (binary, x y z rgb)\n"
+                     "  -pcd           run the CloudSliceProcessor stage behind the tracker and save <prefix>.pcd as the reference does\n"
+                     "                 (binary pcl::PointXYZRGBNormal: x y z rgb normal_x normal_y normal_z curvature)\n"
                      "  -ppm           write the final model views: <prefix>_model.ppm, _color.ppm, _depth.pgm\n"
                      "  -rank R -world W -comm <file>   one process per GPU (-g): gather the ranks' dense poses at the end (RCCL)\n",
                      argv0.c_str());
@@ -44,7 +47,7 @@ class ConfigArgs {
     std::string calibrationFile, logFile, trajectoryFile, saveFile, vocabFile;
     int gpu, voxelShift, volumeResolution, width, height, totalNumFrames, weightCull, decodeThreads;
     float volumeSize;
-    bool staticMode, dynamicCube, flipColors, extractOverlap, useRGBD, useRGBDICP, disableColorAngleWeight, fastOdometry, help;
+    bool staticMode, dynamicCube, flipColors, extractOverlap, saveOverlap, useRGBD, useRGBDICP, disableColorAngleWeight, fastOdometry, help;
 
   private:
     static bool flag(int argc, char** argv, const char* name)
@@ -81,6 +84,7 @@ class ConfigArgs {
         dynamicCube = flag(argc, argv, "-d");
         flipColors = flag(argc, argv, "-f");
         extractOverlap = !flag(argc, argv, "-no");
+        saveOverlap = !flag(argc, argv, "-nos");   // ConfigArgs.h:153
         useRGBD = flag(argc, argv, "-r");
         useRGBDICP = flag(argc, argv, "-ri");
         disableColorAngleWeight = flag(argc, argv, "-dc");

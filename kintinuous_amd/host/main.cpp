@@ -1,13 +1,15 @@
 // kintinuous_hip -- headless driver of the tracking + fusion path over a .klg log: the part of the reference's
 // `Kintinuous -l log.klg [-c calib] [-s size] [-t shift] [-r|-ri] [-fod] [-sm] ...` run (src/Kintinuous.cpp,
 // MainController.cpp:73-170) that ends at the CloudSlices and the .poses file.  Extra options: -n <N>, -w/-h, -o <prefix>,
-// -ops (compose every frame from the internal.h operators instead of the device-resident tracker), -pcd (write <prefix>.pcd), -ppm (write the model views).
+// -ops (compose every frame from the internal.h operators instead of the device-resident tracker), -pcd (run the CloudSliceProcessor thread
+// behind the tracker and save <prefix>.pcd the way CloudSliceProcessor::save does), -ppm (write the model views).
 #include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <string>
 #include <thread>
 
+#include "CloudSliceProcessor.h"
 #include "TrackerInterface.h"
 
 static Intr loadCalibration(const std::string& file, int width, int height)
@@ -23,10 +25,9 @@ static Intr loadCalibration(const std::string& file, int width, int height)
     return k;
 }
 
-// <prefix>.pcd: every extracted slice appended into one binary PCD in pcl::PointXYZRGB field order (x y z rgb; rgb = the packed
-// b, g, r, a bytes viewed as a float, as pcl::io::savePCDFile(..., true) writes it).  The reference saves the backend's
-// processed cloud (normals + voxel grid, CloudSliceProcessor.cpp:180-231); this is the tracker's raw output in the same container.
-static bool writePcd(const std::string& file, const std::vector<CloudSlice*>& slices)
+// -pcdraw (debug): every extracted slice as the tracker produced it, appended into one binary PCD in pcl::PointXYZRGB field order
+// (x y z rgb) -- the input of the slice processor, for comparing extraction paths point by point
+static bool writeRawPcd(const std::string& file, const std::vector<CloudSlice*>& slices)
 {
     size_t n = 0;
     for (size_t i = 0; i < slices.size(); ++i) n += slices[i]->cloud->size();
@@ -112,12 +113,13 @@ int main(int argc, char** argv)
 {
     const ConfigArgs& args = ConfigArgs::get(argc, argv);
     if (args.help || args.logFile.empty()) { ConfigArgs::usage(argv[0]); return args.help ? 0 : 1; }
-    bool ops = false, pcd = false, ppm = false;
+    bool ops = false, pcd = false, pcdraw = false, ppm = false;
     int rank = 0, world = 0;
     std::string commFile;
     for (int i = 1; i < argc; ++i) {
         ops = ops || std::string(argv[i]) == "-ops";
         pcd = pcd || std::string(argv[i]) == "-pcd";
+        pcdraw = pcdraw || std::string(argv[i]) == "-pcdraw";
         ppm = ppm || std::string(argv[i]) == "-ppm";
         if (i + 1 < argc && std::string(argv[i]) == "-rank") rank = std::atoi(argv[i + 1]);
         if (i + 1 < argc && std::string(argv[i]) == "-world") world = std::atoi(argv[i + 1]);
@@ -132,15 +134,34 @@ int main(int argc, char** argv)
     TrackerInterface tracker(&log, intr, ops);
     if (args.extractOverlap) tracker.enableOverlap();  // MainController.cpp:187-190
 
+    // -pcd: the backend's first thread runs next to the tracker, as in MainController (CloudSliceProcessor.cpp): it takes every slice
+    // at the moment the tracker hands it over and fills its processedCloud on the GPU, on a context and stream of its own
+    ThreadDataPack& pack = ThreadDataPack::get();
+    pack.assignFrontend(tracker.getFrontend());
+    CloudSliceProcessor sliceProcessor;
+    std::thread sliceThread;
+    if (pcd)
+        sliceThread = std::thread([&]() {
+            int idle = 0;
+            while (sliceProcessor.process())
+                if (pack.trackerFinished.getValue() && ++idle > 200) break;   // 10 s without a FINAL slice after the last frame: give up
+        });
+
     const auto t0 = std::chrono::steady_clock::now();
     int frames = 0;
     while (tracker.process()) ++frames;
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    pack.trackerFinished.assignValue(true);
 
     KintinuousTracker* fe = tracker.getFrontend();
     size_t points = 0;
     for (size_t i = 0; i < fe->getCloudSlices().size(); ++i) points += fe->getCloudSlices()[i]->cloud->size();
-    if (pcd && !writePcd(args.saveFile + ".pcd", fe->getCloudSlices())) std::fprintf(stderr, "cannot write %s.pcd\n", args.saveFile.c_str());
+    if (pcdraw && !writeRawPcd(args.saveFile + ".raw.pcd", fe->getCloudSlices())) std::fprintf(stderr, "cannot write %s.raw.pcd\n", args.saveFile.c_str());
+    if (pcd) {
+        sliceThread.join();
+        pack.finalised.assignValue(true);
+        if (!pack.cloudSliceProcessorFinished.getValue() || sliceProcessor.save() < 0) std::fprintf(stderr, "cannot write %s.pcd\n", args.saveFile.c_str());
+    }
     if (ppm) writeViews(fe, args.saveFile);
     const kt::Vector3f cam = fe->getCurrentGlobalCamera();
     std::printf("frames %d  slices %zu  points %zu  last camera %.6f %.6f %.6f  %.1f frames/s (incl. file I/O and uploads)  path %s\n", frames,

@@ -76,17 +76,26 @@ def write_poses(path: str, poses) -> None:
             f.write(" ".join("%g" % v for v in list(t) + list(q)) + "\n")
 
 
+PCD_NORMAL_DTYPE = np.dtype([("xyz", np.float32, 3), ("bgra", np.uint8, 4), ("normal", np.float32, 3), ("curvature", np.float32)])
+
+
 def read_pcd(path: str) -> np.ndarray:
-    """Binary x y z rgb PCD (what `kintinuous_hip -pcd` writes) -> structured array {xyz float32[3], bgra uint8[4]}."""
+    """Binary PCD as `kintinuous_hip` writes it: `-pcdraw` (FIELDS x y z rgb -> {xyz, bgra}) or `-pcd`, the reference's saved cloud
+    (pcl::PointXYZRGBNormal: FIELDS x y z rgb normal_x normal_y normal_z curvature -> PCD_NORMAL_DTYPE)."""
     with open(path, "rb") as f:
-        n = None
+        n, dt = None, None
         while True:
             line = f.readline().decode("ascii").strip()
             if line.startswith("FIELDS"):
-                assert line.split()[1:] == ["x", "y", "z", "rgb"], line
+                fields = line.split()[1:]
+                if fields == ["x", "y", "z", "rgb"]:
+                    dt = np.dtype([("xyz", np.float32, 3), ("bgra", np.uint8, 4)])
+                else:
+                    assert fields == ["x", "y", "z", "rgb", "normal_x", "normal_y", "normal_z", "curvature"], line
+                    dt = PCD_NORMAL_DTYPE
             if line.startswith("POINTS"):
                 n = int(line.split()[1])
             if line.startswith("DATA"):
                 assert line.split()[1] == "binary", line
                 break
-        return np.frombuffer(f.read(16 * n), dtype=np.dtype([("xyz", np.float32, 3), ("bgra", np.uint8, 4)]), count=n)
+        return np.frombuffer(f.read(dt.itemsize * n), dtype=dt, count=n)

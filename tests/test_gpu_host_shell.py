@@ -135,14 +135,14 @@ def test_shifting_log_slices(tmp_path):
     frames = [synth.render(scene, cam, *traj[i]) for i in idx]
     log, calib = _make_log(tmp_path, cam, frames)
     common = ["-l", log, "-c", calib, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "7", "-t", "3"]
-    a = _summary(_run(common + ["-o", str(tmp_path / "dev"), "-pcd"], str(tmp_path)))
-    b = _summary(_run(common + ["-o", str(tmp_path / "ops"), "-ops", "-pcd"], str(tmp_path)))
+    a = _summary(_run(common + ["-o", str(tmp_path / "dev"), "-pcdraw"], str(tmp_path)))
+    b = _summary(_run(common + ["-o", str(tmp_path / "ops"), "-ops", "-pcdraw"], str(tmp_path)))
     assert a == b
     assert a["slices"] >= 5 and a["points"] > 0      # X+ / X- shifts + FINAL
     assert open(tmp_path / "dev.poses").read() == open(tmp_path / "ops.poses").read()
-    # -pcd: every slice point, x y z rgb; both paths extract the same point set (the order inside a slice is free)
+    # -pcdraw: every slice point, x y z rgb; both paths extract the same point set (the order inside a slice is free)
     from kintinuous_amd import klg
-    pa, pb = klg.read_pcd(str(tmp_path / "dev.pcd")), klg.read_pcd(str(tmp_path / "ops.pcd"))
+    pa, pb = klg.read_pcd(str(tmp_path / "dev.raw.pcd")), klg.read_pcd(str(tmp_path / "ops.raw.pcd"))
     assert len(pa) == a["points"] == len(pb)
     key = lambda p: np.sort(np.ascontiguousarray(p).view(np.dtype((np.void, p.dtype.itemsize))).ravel())
     assert np.array_equal(key(pa), key(pb))

@@ -43,9 +43,9 @@ def test_oracle_known_answers(oracle_mod):
         for i in idx:
             acc += kept["xyz"][i]
             col += kept["bgra"][i, :3].astype(np.float32)
-        n = np.float32(len(idx))
-        assert np.array_equal(out["xyz"][q], acc / n)
-        assert np.array_equal(out["bgra"][q, :3], (col / n).astype(np.uint8)) and out["bgra"][q, 3] == 0
+        rn = np.float32(1.0) / np.float32(len(idx))     # Eigen 3.2: `centroid /= n` multiplies by Scalar(1) / n
+        assert np.array_equal(out["xyz"][q], acc * rn)
+        assert np.array_equal(out["bgra"][q, :3], (col * rn).astype(np.uint8)) and out["bgra"][q, 3] == 0
     assert np.all(out["one"] == 1)
     # NormalEstimation: the plane's normal, pointing at the sensor origin, tiny curvature
     nt = np.array([0.2, 0.1, -1.0]) / np.linalg.norm([0.2, 0.1, -1.0])
