@@ -67,7 +67,7 @@ WORKLOADS = {
 }
 
 
-from kintinuous_amd.multistream import aggregate_fps, make_comm, pingpong, stream_seed  # noqa: E402
+from kintinuous_amd.multistream import check_gather, make_comm, make_exchange, pingpong, stream_seed, timed_region  # noqa: E402
 
 
 SLICE_NAMES = {0: "X+", 1: "X-", 2: "Y+", 3: "Y-", 4: "Z+", 5: "Z-", 7: "FINAL"}   # CloudSlice::Dimension
@@ -78,19 +78,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or os.environ.get("KT_BENCH_FORCE_DIST"):   # the env switch exercises the RCCL path on a single GPU
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+    # One communicator per job: the C-ABI's (kt_comm over RCCL) does the pose gather AND the barriers around the timed region; rank 0's
+    # communicator id and the max-over-ranks time travel through a key-value store (no torch process group, no second communicator).
+    exchange = make_exchange(rank, world)
 
     from kintinuous_amd import abi, build as kbuild, synth
     if rank == 0 and kbuild.needs_build():
         kbuild.build()
-    if dist is not None:
-        dist.barrier()
+    exchange.share("built", b"1")   # the other ranks load the library only once rank 0 has (re)built it
 
     cfg_name, scale, N, kw = WORKLOADS[args.workload]
     N = int(os.environ.get("KT_BENCH_N", N))  # experiments only
@@ -135,43 +130,29 @@ def main():
     if not os.environ.get("KT_BENCH_NO_COMM"):
         try:
             with stdout_to_stderr():
-                comm = make_comm(dist, ctx, rank, world)
+                comm = make_comm(exchange, ctx, rank, world)
         except Exception as e:   # no librccl on this host: the single-GPU measurement does not depend on it
             if world > 1:
                 raise
             sys.stderr.write(f"bench: pose gather disabled ({e})\n")
-    for i in range(args.warmup):
-        step(i)
-    ctx.sync()
     # HIP events around the tsdf23 kernel only, on the stream it is launched on: every timed frame when the region is short,
-    # one frame in 8 otherwise (the timing itself then stays off the other 7)
-    trk.enable_profiling(4 if args.steps <= 50 else 1)
-    if dist is not None:
-        import torch
-        dist.barrier()
-        torch.cuda.synchronize()
-    ctx.sync()
-    trk.host_times(reset=True)
-    t0 = time.perf_counter()
-    marks = [t0]
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
-        marks.append(time.perf_counter())   # a call returns once the PREVIOUS frame's pose (and any volume shift) is done
-    pose_bytes = 0
-    if comm is not None:
-        k = min(args.steps, trk.num_poses())
+    # one frame in 8 otherwise (the timing itself then stays off the other 7).
+    def prepare():   # between the warm-up and the first barrier
+        trk.enable_profiling(4 if args.steps <= 50 else 1)
+        trk.host_times(reset=True)
+
+    def gather():   # the single RCCL gather of per-stream poses, inside the timed region
         with stdout_to_stderr():
-            allp = comm.gather_poses(trk, k)  # the single RCCL gather of per-stream poses, inside the timed region
-        pose_bytes = int(allp.size * 4)
-    ctx.sync()
-    if dist is not None:
-        import torch
-        torch.cuda.synchronize()
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    fps = aggregate_fps(dist, args.steps, elapsed, world, device=(f"cuda:{local_rank}" if dist is not None else None))
-    elapsed = world * args.steps / fps
+            return comm.gather_poses(trk, min(args.steps, trk.num_poses()))
+
+    if world > 1 and comm is None:
+        raise RuntimeError("bench: a multi-GPU run needs the pose communicator (librccl)")
+    with stdout_to_stderr() if world > 1 else contextlib.nullcontext():   # (RCCL prints its banner at the first collective)
+        region = timed_region(comm, exchange, world, ctx.sync, step, args.steps, args.warmup, gather if comm is not None else None, prepare)
+    marks, allp = region["marks"], region["gathered"]
+    pose_bytes = int(allp.size * 4) if allp is not None else 0
+    k = allp.shape[1] if allp is not None else 0
+    elapsed = region["elapsed"]   # the slowest rank's
 
     timed_poses = [trk.dense_pose(trk.num_poses() - k + i)[1] for i in range(k)] if comm is not None else []
     first_poses = [trk.dense_pose(i)[1] for i in range(min(trk.num_poses(), args.cpu_frames))]   # frames 0.. of the sequence (warm-up first)
@@ -197,6 +178,20 @@ def main():
 
     # ---- untimed: per-stage breakdown (events around every stage), then the U / S counters of a few frames -----------
     base = args.warmup + args.steps
+    stage_pipe = None
+    if readahead:
+        # the stages of the main stream as the timed frames run them: read-ahead on, the voxel pass from the task plan made ahead of the
+        # frame (events around every stage: each one costs a bubble, which is why this is not done inside the timed region)
+        step(base, announce_next=True)
+        trk.enable_profiling(2)
+        for i in range(base + 1, base + 9):
+            step(i, announce_next=True)
+        stage_pipe = trk.stage_ms()
+        trk.enable_profiling(0)
+        base += 9
+        step(base, announce_next=False)   # consumes the read-ahead that is still outstanding
+        base += 1
+    plan_hits, plan_misses = trk.plan_stats()
     trk.enable_profiling(2)
     for i in range(base, base + 8):
         step(i, announce_next=False)  # serial frames: every stage on the main stream so that each has a duration
@@ -274,7 +269,11 @@ def main():
                      # the same launch with nothing else running (untimed stage pass below):
                      "avg_launch_ms_alone": stage_all["tsdf23"][0],
                      "frac_alone": (bytes_tsdf23 / (stage_all["tsdf23"][0] * 1e-3) / 1e9 / peak) if stage_all["tsdf23"][0] > 0 else None},
+        # every stage alone on the main stream (serial frames, in-stream pre-pass); stage_ms_pipelined: the main stream's stages with the
+        # read-ahead stream running and the voxel pass planned ahead, i.e. as in the timed region (pyramid / resize are not on it there)
         "stage_ms": {k: round(v[0], 4) for k, v in stage_all.items()},
+        "stage_ms_pipelined": ({k: round(v[0], 4) for k, v in stage_pipe.items() if k in ("odometry", "shift", "integrate", "raycast", "tsdf23")} if stage_pipe else None),
+        "planned_frames": {"hits": plan_hits, "misses": plan_misses},
         "host_ms_per_frame": {"process_frame_call": round(1e3 * host_call_s, 4), "of_which_waiting_for_pose": round(1e3 * host_wait_s, 4)},
     }
 
@@ -291,13 +290,11 @@ def main():
         sys.stdout.flush()
     os.dup2(2, 1)   # whatever the libraries still print while shutting down does not reach the driver's stdout
     if comm is not None:
-        assert np.array_equal(allp[rank], np.stack([p.reshape(16) for p in timed_poses])), "the gathered poses are not this rank's"
+        check_gather(allp, rank, np.stack([p.reshape(16) for p in timed_poses]))
         with stdout_to_stderr():
             comm.close()
     trk.close()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 def kt_volume_sha():

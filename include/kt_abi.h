@@ -128,6 +128,19 @@ int kt_icp_step(kt_ctx* ctx, const kt_mat33* Rcurr, const float tcurr[3], const 
                 const kt_mat33* Rprev_inv, const float tprev[3], const kt_intr* intr,
                 const float* vmap_g_prev, const float* nmap_g_prev, int cols, int rows,
                 float dist_thres, float angle_thres, float* A_host, float* b_host, float* residual_host);
+/* ICPOdometry::getIncrementalTransformation as one call (frontend/ICPOdometry.cpp:68-186; SURVEY 8(b) export list): pose in, pose out.
+ * maps[l] = level l of the four pyramids (3 * (rows >> l) planes of (cols >> l) floats; a level with iterations[l] == 0 may be null),
+ * intr = level-0 intrinsics (level l uses intr / 2^l, internal.h:255-259), iterations[l] = Gauss-Newton iterations at level l, run
+ * from level 3 down to 0 (the reference: {10, 5, 4, 0}, fast odometry {0, 10, 5, 0}, ICPOdometry.cpp:44-55).  Every iteration is a
+ * device launch whose epilogue solves the 6x6 system in double (Eigen's pivoted LDLT restated), applies cv::Rodrigues and the
+ * SE(3) update (:127-178) and leaves the pose on the device for the next one: no host round trip until the final read-back.
+ * A_last_host[36] (may be null) = the last iteration's A, row-major symmetric (the reference keeps it as lastA for getCovariance);
+ * residual_host[2] (may be null) = that iteration's {sum residual^2, inlier count}.  Poses are bit-identical to iterating kt_icp_step
+ * + kt_host_ldlt_solve6 + kt_host_pose_update on the host. */
+int kt_icp_track(kt_ctx* ctx, const float* const vmaps_curr[4], const float* const nmaps_curr[4], const float* const vmaps_g_prev[4],
+                 const float* const nmaps_g_prev[4], int cols, int rows, const kt_intr* intr, const kt_mat33* Rprev, const float tprev[3],
+                 const int iterations[4], float dist_thres, float angle_thres, kt_mat33* Rcurr_host, float tcurr_host[3],
+                 float A_last_host[36], float residual_host[2]);
 /* computeRgbResidual  internal.h:519-534 / reduce.cu:798-864 */
 int kt_rgb_residual(kt_ctx* ctx, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
                     const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
@@ -277,6 +290,10 @@ int kt_tracker_last_counts(kt_tracker* t, unsigned long long* U, unsigned long l
 /* diagnostics of the last counted integrate: {U, wave batches of 4 z-steps, active wave-chunks, sum and max of the active
  * waves' durations, sum of their issue and consume phases (10 ns ticks), 0} */
 int kt_tracker_debug_counts(kt_tracker* t, unsigned int out8_host[8]);
+/* Frames whose voxel pass ran from a task plan made ahead of the frame for a predicted pose {hits}, and frames whose pose fell outside
+ * the plan's margins and were fused through the in-stream pre-pass instead {misses} (csrc/kt_volume.hip "planning ahead"; results do
+ * not depend on which of the two happened). */
+int kt_tracker_plan_stats(kt_tracker* t, long long out2_host[2]);
 /* diagnostics: the 29 ICP sums stashed by the last joint RGB-D + ICP iteration (or timing probes in instrumented builds) */
 int kt_tracker_debug_state(kt_tracker* t, float out29_host[29]);
 
@@ -338,6 +355,7 @@ typedef struct kt_comm kt_comm;
 int kt_comm_unique_id(unsigned char id[KT_COMM_ID_BYTES]);
 int kt_comm_init(kt_ctx* ctx, int rank, int nranks, const unsigned char id[KT_COMM_ID_BYTES], kt_comm** out);
 int kt_pose_gather(kt_comm* comm, kt_tracker* t, int k, float* all_poses_host);
+int kt_comm_barrier(kt_comm* comm);   /* returns once every rank has called it (a one-float all-gather) */
 int kt_comm_destroy(kt_comm* comm);
 
 #ifdef __cplusplus

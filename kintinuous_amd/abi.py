@@ -97,6 +97,7 @@ _PROTOS = {
     "kt_rgb_step": (_i, [_vp, _vp, _f, _vp, _f, _f, _vp, _vp, _f, _i, _i, _pf, _pf]),
     "kt_init_volume": (_i, [_vp, _vp, _i]),
     "kt_init_color_volume": (_i, [_vp, _vp, _i]),
+    "kt_icp_track": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _pI, _pM, _pf, _pi, _f, _f, _pM, _pf, _pf, _pf]),
     "kt_integrate_tsdf": (_i, [_vp, _vp, _i, _i, _pI, _pf, _pM, _pf, _f, _vp, _vp, _pi, _vp, _vp, _vp, _i, _i]),
     "kt_raycast": (_i, [_vp, _pI, _pM, _pf, _f, _pf, _vp, _vp, _vp, _i, _i, _pi, _vp, _vp, _i]),
     "kt_clear_volume": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i]),
@@ -130,6 +131,7 @@ _PROTOS = {
     "kt_tracker_last_counts": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "kt_tracker_debug_counts": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_debug_state": (_i, [_vp, _pf]),
+    "kt_tracker_plan_stats": (_i, [_vp, C.POINTER(C.c_longlong)]),
     "kt_debug_stream": (_i, [_vp, _vp, _sz, _i, _i]),
     "kt_debug_stream_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
     "kt_debug_valu_rates": (_i, [_vp, _i, _i, _i, _pd]),
@@ -146,6 +148,7 @@ _PROTOS = {
     "kt_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
     "kt_comm_init": (_i, [_vp, _i, _i, C.POINTER(C.c_ubyte), C.POINTER(_vp)]),
     "kt_pose_gather": (_i, [_vp, _vp, _i, _pf]),
+    "kt_comm_barrier": (_i, [_vp]),
     "kt_comm_destroy": (_i, [_vp]),
     "kt_tracker_host_times": (_i, [_vp, _pd, _i]),
     "kt_tracker_prefetch_frame": (_i, [_vp, _vp, _vp]),
@@ -322,6 +325,19 @@ class Ctx:
                                cols, rows, dist_thres, angle_thres, A, b, r))
         return (np.array(A, dtype=np.float32).reshape(6, 6), np.array(b, dtype=np.float32), np.array(r, dtype=np.float32))
 
+    def icp_track(self, vmaps_curr, nmaps_curr, vmaps_g_prev, nmaps_g_prev, cols, rows, intr: Intr, Rprev, tprev, iterations,
+                  dist_thres, angle_thres):
+        """kt_icp_track: ICPOdometry::getIncrementalTransformation in one call.  maps: lists of 4 DevBuf (None where iterations[l] == 0).
+        Returns (Rcurr, tcurr, A_last[6, 6], residual[2])."""
+        def arr(bufs):
+            return (_vp * 4)(*[(b.ptr if b is not None else None) for b in bufs])
+        Rc = Mat33()
+        tc, A, r = (C.c_float * 3)(), (C.c_float * 36)(), (C.c_float * 2)()
+        it = (C.c_int * 4)(*[int(v) for v in iterations])
+        _chk(lib().kt_icp_track(self.h, arr(vmaps_curr), arr(nmaps_curr), arr(vmaps_g_prev), arr(nmaps_g_prev), cols, rows, C.byref(intr),
+                                C.byref(Mat33.from_np(Rprev)), _fp(tprev), it, dist_thres, angle_thres, C.byref(Rc), tc, A, r))
+        return (np.array(Rc.m, np.float32).reshape(3, 3), np.array(tc, np.float32), np.array(A, np.float32).reshape(6, 6), np.array(r, np.float32))
+
     def rgb_residual(self, min_scale, dIdx, dIdy, last_depth, next_depth, last_image, next_image, cols, rows, corres,
                      max_depth_delta, kt, krkinv) -> Tuple[int, int]:
         sigma, count = C.c_int(0), C.c_int(0)
@@ -394,6 +410,12 @@ class Tracker:
         o = (C.c_double * 2)()
         _chk(lib().kt_tracker_host_times(self.h, o, 1 if reset else 0))
         return float(o[0]), float(o[1])
+
+    def plan_stats(self) -> Tuple[int, int]:
+        """(frames fused from a task plan made ahead of them, frames whose pose fell outside their plan's margins)"""
+        out = (C.c_longlong * 2)()
+        _chk(lib().kt_tracker_plan_stats(self.h, out))
+        return int(out[0]), int(out[1])
 
     def prefetch_frame(self, depth_dev, rgb_dev) -> None:
         """Announce a frame a later process_frame call will receive: its pose-independent stages run on a second stream."""
@@ -653,6 +675,10 @@ class Comm:
         out = np.zeros((self.nranks, k, 16), np.float32)
         _chk(lib().kt_pose_gather(self.h, trk.h, k, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def barrier(self) -> None:
+        """returns once every rank has called it (kt_comm_barrier: a one-float all-gather on the communicator's stream)"""
+        _chk(lib().kt_comm_barrier(self.h))
 
     def close(self) -> None:
         if self.h:

@@ -2,12 +2,26 @@
 // rank) contributes its last k dense poses -- k x 16 floats, row-major [R | currentGlobalCamera], KintinuousTracker.h:151-169 -- to
 // ONE ncclAllGather over RCCL / xGMI, on a dedicated stream so it never queues behind a frame.  64 B - 2 KB messages: latency
 // bound, no ring all-reduce, no data-path collective anywhere else.
-// librccl is opened lazily (dlopen) so that libkt_hip.so loads on hosts without it; the calls go through rccl.h's own prototypes.
+// librccl is opened lazily (dlopen) so that libkt_hip.so loads -- and BUILDS -- on hosts without it: the five entry points used are
+// declared here with the types of RCCL's public C API (nccl.h: ncclUniqueId = 128 opaque bytes, ncclResult_t / ncclDataType_t
+// enums passed as int, ncclComm_t an opaque pointer), so rccl.h is not a build dependency.
 #include "kt_internal.hpp"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <string.h>
+
+extern "C" {
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;     // ncclSuccess = 0
+typedef int ncclDataType_t;   // ncclFloat32 = 7
+}
+enum { ncclSuccess = 0, ncclFloat32 = 7, NCCL_UNIQUE_ID_BYTES = 128 };
+typedef ncclResult_t (*kt_ncclGetUniqueId_t)(ncclUniqueId*);
+typedef ncclResult_t (*kt_ncclCommInitRank_t)(ncclComm_t*, int, ncclUniqueId, int);
+typedef ncclResult_t (*kt_ncclAllGather_t)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+typedef ncclResult_t (*kt_ncclCommDestroy_t)(ncclComm_t);
+typedef const char* (*kt_ncclGetErrorString_t)(ncclResult_t);
 
 struct kt_comm {
     kt_ctx* ctx;
@@ -17,16 +31,17 @@ struct kt_comm {
     int rank, nranks;
     float* send; float* recv;   // device staging, grown on demand
     size_t cap_floats;
+    float* token;               // [1 + nranks] floats for kt_comm_barrier
 };
 
 namespace {
 struct Rccl {
     void* lib;
-    decltype(&ncclGetUniqueId) GetUniqueId;
-    decltype(&ncclCommInitRank) CommInitRank;
-    decltype(&ncclAllGather) AllGather;
-    decltype(&ncclCommDestroy) CommDestroy;
-    decltype(&ncclGetErrorString) GetErrorString;
+    kt_ncclGetUniqueId_t GetUniqueId;
+    kt_ncclCommInitRank_t CommInitRank;
+    kt_ncclAllGather_t AllGather;
+    kt_ncclCommDestroy_t CommDestroy;
+    kt_ncclGetErrorString_t GetErrorString;
 } g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 int rccl_load()
@@ -51,6 +66,8 @@ int rccl_load()
 
 extern "C" {
 
+int kt_comm_destroy(kt_comm* c);
+
 int kt_comm_unique_id(unsigned char id[KT_COMM_ID_BYTES])
 {
     KT_ARG(id);
@@ -74,9 +91,22 @@ int kt_comm_init(kt_ctx* ctx, int rank, int nranks, const unsigned char id[KT_CO
     memcpy(u.internal, id, KT_COMM_ID_BYTES);
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
     if (r != ncclSuccess) { kt_set_error("ncclCommInitRank: %s", g_rccl.GetErrorString(r)); delete c; return KT_ERR_HIP; }
-    KT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    KT_HIP(hipEventCreateWithFlags(&c->poses_ready, hipEventDisableTiming));
+    // (a failure from here on releases what has been built: the communicator, the stream)
+    int s = kt_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreateWithFlags", __FILE__, __LINE__);
+    if (s == KT_OK) s = kt_check(hipEventCreateWithFlags(&c->poses_ready, hipEventDisableTiming), "hipEventCreateWithFlags", __FILE__, __LINE__);
+    if (s == KT_OK) s = kt_check(hipMalloc((void**)&c->token, 2 * sizeof(float) * (size_t)nranks + sizeof(float)), "hipMalloc", __FILE__, __LINE__);
+    if (s != KT_OK) { (void)kt_comm_destroy(c); return s; }
     *out = c;
+    return KT_OK;
+}
+
+// every rank has reached this call: a one-float all-gather on the communicator's stream (bench.py brackets its timed region with it,
+// so a multi-GPU run needs no second communicator for barriers)
+int kt_comm_barrier(kt_comm* c)
+{
+    KT_ARG(c);
+    KT_NCCL(g_rccl.AllGather(c->token, c->token + 1, 1, ncclFloat32, c->comm, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
     return KT_OK;
 }
 
@@ -107,7 +137,7 @@ int kt_comm_destroy(kt_comm* c)
     if (!c) return KT_OK;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
-    (void)hipFree(c->send); (void)hipFree(c->recv);
+    (void)hipFree(c->send); (void)hipFree(c->recv); (void)hipFree(c->token);
     if (c->poses_ready) (void)hipEventDestroy(c->poses_ready);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -33,6 +33,7 @@ struct kt_ctx {
     kt_integrate_scratch* integ;   // integrate scratch (pixel records, z tables, intervals, task list), created on first use
     float* bil_lut;                // bilateral tap weights [27][396] (kt_image.hip), built on first use
     unsigned int red_epoch;  // tag of the last reduction launch (kt_track.hip hand-off granules)
+    void* track_state;       // device kt_track_state of kt_icp_track (kt_track.hip), created on first use
 };
 
 void kt_set_error(const char* fmt, ...);

@@ -67,6 +67,7 @@ int kt_ctx_destroy(kt_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     kt_integrate_scratch_free(c);
     (void)hipFree(c->bil_lut);
+    (void)hipFree(c->track_state);
     (void)hipFree(c->red_partials);
     (void)hipFree(c->red_out);
     (void)hipFree(c->counters);

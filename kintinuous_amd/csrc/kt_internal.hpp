@@ -14,18 +14,51 @@ struct kt_frame_params {
 
 // Per-pixel record of integrate, built once per frame by kt_integrate_prepare: everything tsdf23 gathers per voxel from the frame
 // (scaled depth with the no-colour sign flag, the colour weight derived from |n_z|, rgb, normal-valid) in ONE 16-byte gather.
+#ifndef KT_REC_BYTES
+#define KT_REC_BYTES 16   // 12: no padding word -- a quarter fewer cache lines under the gathers, one more VALU for the address (A/B)
+#endif
+#if KT_REC_BYTES == 16
 struct __attribute__((aligned(16))) kt_pixrec {
+#else
+struct kt_pixrec {
+#endif
     float dp;        // scaleDepth output (negative = "no colour", tsdf_volume.cu:520-527)
     float wrkc;      // (angleColor ? min(1, |n_z| / 0.75) : 1) * 2       tsdf_volume.cu:625
     uint32_t rgbf;   // r | g<<8 | b<<16 | KT_REC_* flags
+#if KT_REC_BYTES == 16
     uint32_t pad;
+#endif
 };
+static_assert(sizeof(kt_pixrec) == KT_REC_BYTES, "pixel record size");
 #define KT_REC_NORMAL_NAN (1u << 24)   // isnan(n_x)
 // computeNmapKernel (maps.cu:96-133) writes only n_x = NaN for an invalid normal: n_z keeps whatever the buffer held, and tsdf23
 // still reads it for the colour weight of a voxel whose colour is (0, 0, 0).  With ONE nmaps_curr_ buffer, as in the reference,
 // that is the n_z of the last frame in which the pixel had a valid normal.  The flag marks such pixels; the tracker, whose
 // frame sets rotate, replaces their wrkc from a per-pixel carry kept in processing order (kt_frame_setup_kernel).
 #define KT_REC_STALE_NZ (1u << 25)
+
+// Checkpoint of tsdf23's incremental walk for one storage column (sx, sy): the reference advances v_x, v_y by repeated float `+=`
+// from z = 0 (tsdf_volume.cu:566-574, quirk A.17: the values are DEFINED by that recurrence), so a task that starts at z = zc needs
+// the walked values there.  zc is wave-uniform at both call sites (kt_tsdf_interval_kernel, kt_frame_setup_kernel).
+__device__ __forceinline__ float2 kt_tsdf_walk_checkpoint(const float* Ri, float tx, float ty, float tz, float cell_x, float cell_y, float cell_z,
+                                                           float fx, float fy, int sx, int sy, int wx, int wy, int N, int zc)
+{
+    int x = sx - wx; if (x < 0) x += N;
+    int y = sy - wy; if (y < 0) y += N;
+    const float v_g_x = __builtin_fmaf((float)x + 0.5f, cell_x, -tx);
+    const float v_g_y = __builtin_fmaf((float)y + 0.5f, cell_y, -ty);
+    const float v_g_z0 = __builtin_fmaf(0 + 0.5f, cell_z, -tz);
+    float v_x = __builtin_fmaf(Ri[2], v_g_z0, __builtin_fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * fx;
+    float v_y = __builtin_fmaf(Ri[5], v_g_z0, __builtin_fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * fy;
+    const float dvx = Ri[2] * cell_z * fx, dvy = Ri[5] * cell_z * fy;
+    int z = 0;
+    for (; z + 16 <= zc; z += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { v_x += dvx; v_y += dvy; }
+    }
+    for (; z < zc; ++z) { v_x += dvx; v_y += dvy; }
+    return make_float2(v_x, v_y);
+}
 
 int kt_bilateral_lut_ensure(kt_ctx* c);
 size_t kt_brick_count(int N);   // flags of the raycast's empty-space bricks for an N^3 volume
@@ -35,7 +68,17 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
                            int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
                            const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev,
                            const void* prepared_rec, const kt_frame_params* fp = nullptr, unsigned char* bricks = nullptr,
-                           const float* prepared_dpmax = nullptr);
+                           const float* prepared_dpmax = nullptr, const struct kt_tsdf_plan* plan = nullptr);
+// One frame's work list for the voxel kernel (kt_volume.hip "planning ahead"): wave-column z-ranges, the compact task list, and the walk
+// checkpoints of the active wave-columns.  kt_integrate_plan fills ranges and tasks for a PREDICTED pose with margins theta (rad) and
+// tau (m) on a stream of the caller's choice; the checkpoints need the frame's own pose (kt_tsdf_walk_checkpoint, set-up kernel).
+struct kt_tsdf_plan { unsigned int* wrange; unsigned int* tasks; unsigned int* task_count; float2* walk0; };
+int kt_tsdf_plan_alloc(kt_tsdf_plan* p, int N);
+void kt_tsdf_plan_free(kt_tsdf_plan* p);
+void kt_tsdf_plan_shape(int N, int* wx, int* wy, int* xg, int* yg);   // wave-column shape and grid (for the checkpoint workgroups)
+int kt_integrate_plan(hipStream_t stream, const kt_tsdf_plan* plan, const void* rec, const float* dpmax, int cols, int rows, const kt_intr* intr,
+                      const float volume_size[3], const kt_mat33* Rinv_pred, const float t_pred[3], float tranc_dist, const int voxel_wrap[3], int N,
+                      float theta, float tau);
 // device z tables {v_g_z[N], z_scaled[N]} of the next integrate call with a non-null fp (filled by the caller's set-up kernel)
 int kt_integrate_tables(kt_ctx* c, int cols, int rows, int N, float** vgz, float** zs);
 size_t kt_integrate_rec_bytes(int cols, int rows);
@@ -53,7 +96,7 @@ int kt_extract_cloud_slice_async(kt_ctx* c, const int16_t* volume, const float v
                                  unsigned int* count_dev);
 int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
                        const float* vmap_g_prev, const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres,
-                       int mode, const kt_track_state* init = nullptr);
+                       int mode, const kt_track_state* init = nullptr, int keep29 = 0);
 int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
                            const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
                            int cols, int rows, kt_dataterm* corres_img, float max_depth_delta, const uint8_t* cand = nullptr,

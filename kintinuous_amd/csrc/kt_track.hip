@@ -301,6 +301,7 @@ struct kt_icp_args {
     unsigned long long* granules; unsigned int epoch;   // inter-workgroup hand-off (kt_reduce29)
     float* out29;              // host path: 29 floats
     int mode;                  // KT_MODE_*
+    int keep29;                // KT_MODE_ICP_SOLVE: also leave the 29 sums in state->icp29 (kt_icp_track's last iteration: the caller's A)
 };
 
 struct kt_icp_row {
@@ -370,6 +371,8 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
             kt_unpack29_d(h, dA, db);
             a.state->last_residual[0] = h[27];
             a.state->last_residual[1] = h[28];
+            if (a.keep29)
+                for (int k = 0; k < 29; ++k) a.state->icp29[k] = h[k];
             if (a.first) {  // ICPOdometry.cpp:70-85: previous pose, its inverse, identity increment
 #pragma unroll
                 for (int k = 0; k < 16; ++k) pr.resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
@@ -425,7 +428,7 @@ extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3
     a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
     a.Rcurr = *Rcurr; a.Rprev_inv = *Rprev_inv;
     for (int k = 0; k < 3; ++k) { a.tcurr[k] = tcurr[k]; a.tprev[k] = tprev[k]; }
-    a.state = nullptr; a.first = 0; a.out29 = c->red_out; a.mode = KT_MODE_HOST;
+    a.state = nullptr; a.first = 0; a.out29 = c->red_out; a.mode = KT_MODE_HOST; a.keep29 = 0;
     int s = kt_icp_launch(c, a);
     if (s != KT_OK) return s;
     KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * KT_RED_SLOTS, hipMemcpyDeviceToHost, c->stream));
@@ -437,13 +440,14 @@ extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3
 
 int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
                        const float* vmap_g_prev, const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres,
-                       int mode, const kt_track_state* init)
+                       int mode, const kt_track_state* init, int keep29)
 {
     kt_icp_args a;
     a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
     a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
     a.state = state; a.out29 = nullptr; a.mode = mode;
     a.first = 0;
+    a.keep29 = keep29;
     if (init) {  // first iteration of a frame (ICP-only path): the starting pose travels in the kernel arguments
         if (mode != KT_MODE_ICP_SOLVE) { kt_set_error("kt_icp_step_device: init needs KT_MODE_ICP_SOLVE"); return KT_ERR_ARG; }
         a.first = 1;
@@ -452,6 +456,57 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
         for (int k = 0; k < 3; ++k) { a.tcurr[k] = init->tcurr[k]; a.tprev[k] = init->tprev[k]; }
     }
     return kt_icp_launch(c, a);
+}
+
+// ICPOdometry::getIncrementalTransformation (ICPOdometry.cpp:68-186) as ONE entry point (SURVEY 8(b) export list): pose in / pose out,
+// every Gauss-Newton iteration of every pyramid level enqueued back to back with the 6x6 solve, Rodrigues and the SE(3) update in
+// the reduction kernel's epilogue (kt_solve_and_update) -- no host round trip per iteration (the reference: 19 x {2 launches,
+// cudaDeviceSynchronize, 116-byte copy, Eigen LDLT on the host}).  The same kernels and the same state machine as the tracker's
+// odometry stage; the tracking state lives in the context.
+extern "C" int kt_icp_track(kt_ctx* c, const float* const vmaps_curr[KT_LEVELS], const float* const nmaps_curr[KT_LEVELS],
+                            const float* const vmaps_g_prev[KT_LEVELS], const float* const nmaps_g_prev[KT_LEVELS], int cols, int rows,
+                            const kt_intr* intr, const kt_mat33* Rprev, const float tprev[3], const int iterations[KT_LEVELS], float dist_thres,
+                            float angle_thres, kt_mat33* Rcurr_out, float tcurr_out[3], float A_last_out[36], float residual_out[2])
+{
+    KT_ARG(c && vmaps_curr && nmaps_curr && vmaps_g_prev && nmaps_g_prev && intr && Rprev && tprev && iterations && Rcurr_out && tcurr_out && cols > 0 && rows > 0);
+    if (!c->track_state) {
+        KT_HIP(hipMalloc((void**)&c->track_state, sizeof(kt_track_state)));
+        KT_HIP(hipMemsetAsync(c->track_state, 0, sizeof(kt_track_state), c->stream));
+    }
+    kt_track_state* st = (kt_track_state*)c->track_state;
+    kt_track_state init;
+    memset(&init, 0, sizeof(init));
+    memcpy(init.Rprev, Rprev->m, sizeof(init.Rprev)); memcpy(init.Rcurr, Rprev->m, sizeof(init.Rcurr));
+    memcpy(init.tprev, tprev, sizeof(init.tprev)); memcpy(init.tcurr, tprev, sizeof(init.tcurr));
+    kt_mat33_inverse(init.Rprev, init.Rprev_inv);  // ICPOdometry.cpp:81
+    int total = 0, done = 0;
+    for (int l = 0; l < KT_LEVELS; ++l) { KT_ARG(iterations[l] >= 0 && (iterations[l] == 0 || (vmaps_curr[l] && nmaps_curr[l] && vmaps_g_prev[l] && nmaps_g_prev[l]))); total += iterations[l]; }
+    for (int l = KT_LEVELS - 1; l >= 0; --l) {
+        const int div = 1 << l;
+        const kt_intr li = {intr->fx / div, intr->fy / div, intr->cx / div, intr->cy / div};   // Intr::operator(), internal.h:255-259
+        for (int it = 0; it < iterations[l]; ++it, ++done)
+            KT_TRY(kt_icp_step_device(c, st, vmaps_curr[l], nmaps_curr[l], &li, vmaps_g_prev[l], nmaps_g_prev[l], cols >> l, rows >> l, dist_thres, angle_thres,
+                                      KT_MODE_ICP_SOLVE, done == 0 ? &init : nullptr, done == total - 1));
+    }
+    if (total == 0) {   // no iterations: the pose stays the previous one
+        *Rcurr_out = *Rprev;
+        for (int k = 0; k < 3; ++k) tcurr_out[k] = tprev[k];
+        if (A_last_out) memset(A_last_out, 0, 36 * sizeof(float));
+        if (residual_out) residual_out[0] = residual_out[1] = 0.0f;
+        return KT_OK;
+    }
+    kt_track_state out;
+    KT_HIP(hipMemcpyAsync(&out, st, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    KT_HIP(hipStreamSynchronize(c->stream));
+    if (out.handoff_timeout) { kt_set_error("kt_icp_track: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
+    memcpy(Rcurr_out->m, out.Rcurr, sizeof(out.Rcurr));
+    memcpy(tcurr_out, out.tcurr, sizeof(out.tcurr));
+    if (A_last_out) {
+        float b[6], r[2];
+        kt_unpack29_host(out.icp29, A_last_out, b, r);
+    }
+    if (residual_out) { residual_out[0] = out.last_residual[0]; residual_out[1] = out.last_residual[1]; }
+    return KT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -797,7 +852,7 @@ int kt_joint_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_cur
     kt_icp_args a;
     a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
     a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
-    a.state = state; a.out29 = nullptr; a.mode = KT_MODE_ICP_STASH; a.first = 0;
+    a.state = state; a.out29 = nullptr; a.mode = KT_MODE_ICP_STASH; a.first = 0; a.keep29 = 0;
     a.granules = kt_second_granules(c);
     a.epoch = kt_next_epoch(c);
     kt_rgb_args r;

@@ -135,6 +135,16 @@ struct kt_tracker {
     // colour weight carried across frames for pixels without a valid normal (KT_REC_STALE_NZ): [carry_sel] = state before the frame
     // in flight, [carry_sel ^ 1] = state after it
     float* wrkc_carry[2]; int carry_sel;
+    // Planning ahead (kt_volume.hip): the voxel kernel's task plan of frame f + 1 is made for a PREDICTED pose on plan_stream as soon as
+    // the frame has been read ahead, i.e. while the odometry of frame f iterates on the main stream (a latency-bound chain that leaves the
+    // compute units idle) -- two frames ahead of the last pose the host has seen.  plan_sel: the slot the frame in flight was enqueued
+    // with, -1 = none (the in-stream pre-pass ran).
+    struct PlanSlot { kt_tsdf_plan plan; hipEvent_t done; long long ordinal; float R[9], t[3], theta, tau; int wrap[3]; };
+    PlanSlot plans[3]; hipStream_t plan_stream;          // (three: frame f + 1 is planned while the voxel kernels of f and f - 1 may still read theirs)
+    int plan_sel; bool plan_enabled; float plan_margin_scale;
+    float hist_R[2][9], hist_gc[2][3]; int hist_n;      // rotation and global camera of the two most recent tracked frames
+    float pred_err_t, pred_err_r;                       // error of the most recent prediction (metres, radians): drives the margins
+    long long plan_hits, plan_misses;
     unsigned char* bricks;             // negative-brick flags of the volume (tsdf23 raises, raycast skips; kt_volume.hip)
     float *vgz_dev, *zs_dev;           // z tables of integrate (kt_integrate_tables)
     PoseMirror* mirror;                // pinned + mapped host memory
@@ -466,6 +476,15 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     t->outstanding = false;
     t->host_wait_s = t->host_call_s = 0.0; t->host_calls = 0;
     KT_TRY(dev_alloc(&t->fp_dev, 1, true));
+    KT_HIP(hipStreamCreateWithFlags(&t->plan_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 3; ++k) {
+        KT_TRY(kt_tsdf_plan_alloc(&t->plans[k].plan, cfg->N));
+        KT_HIP(hipEventCreateWithFlags(&t->plans[k].done, KT_EV_DEVICE));
+        t->plans[k].ordinal = -1;
+    }
+    t->plan_enabled = getenv("KT_NO_PLAN") == nullptr;   // (A/B switch: every frame through the in-stream pre-pass)
+    t->plan_margin_scale = getenv("KT_PLAN_MARGIN_SCALE") ? (float)atof(getenv("KT_PLAN_MARGIN_SCALE")) : 1.0f;   // (tests: 0 makes every plan miss)
+    t->plan_hits = t->plan_misses = 0;
     KT_TRY(dev_alloc(&t->bricks, kt_brick_count(cfg->N) + 16, true));
     for (int k = 0; k < 2; ++k) KT_TRY(dev_alloc(&t->wrkc_carry[k], (size_t)cfg->cols * cfg->rows, true));  // zero: the oracle's calloc'ed normal map
     t->carry_sel = 0;
@@ -519,6 +538,11 @@ int kt_tracker_destroy(kt_tracker* t)
             if (t->ev[par][s][1]) (void)hipEventDestroy(t->ev[par][s][1]);
         }
     (void)hipHostFree(t->mirror);
+    if (t->plan_stream) { (void)hipStreamSynchronize(t->plan_stream); (void)hipStreamDestroy(t->plan_stream); }
+    for (int k = 0; k < 3; ++k) {
+        kt_tsdf_plan_free(&t->plans[k].plan);
+        if (t->plans[k].done) (void)hipEventDestroy(t->plans[k].done);
+    }
     (void)hipFree(t->fp_dev);
     (void)hipFree(t->bricks);
     for (int k = 0; k < 2; ++k) (void)hipFree(t->wrkc_carry[k]);
@@ -545,6 +569,11 @@ int kt_tracker_reset(kt_tracker* t)
     memcpy(t->pr_rot, t->initial_rotation, sizeof(t->pr_rot));
     KT_HIP(hipStreamSynchronize(t->pre_stream));
     t->pending.clear();
+    KT_HIP(hipStreamSynchronize(t->plan_stream));
+    t->plan_sel = -1;
+    for (int k = 0; k < 3; ++k) t->plans[k].ordinal = -1;
+    t->hist_n = 0;
+    t->pred_err_t = t->pred_err_r = 0.0f;
     t->prev_set = -1;
     t->parked = t->cfg.static_mode != 0;
     t->v_wrap_copy[0] = t->v_wrap_copy[1] = t->v_wrap_copy[2] = 0;
@@ -686,7 +715,29 @@ struct kt_setup_args {
     float R[9], t[3];
     float basis[3], voxel[3]; int thresh;
     kt_pixrec* rec; const float* carry_cur; float* carry_next; int npix;
+    // planned frames (kt_volume.hip "planning ahead"): the prediction and margins the plan was made with -- the pose is checked against
+    // them -- and what the checkpoint workgroups need: the plan's wave-column ranges, where the checkpoints go, the walk's constants
+    int carry_groups;
+    const unsigned int* plan_wrange; float2* plan_walk0;
+    float plan_R[9], plan_t[3], plan_theta, plan_tau;
+    int wx, wy, wcx, wcy, XG, YG;        // storage wrap (x, y), wave-column shape and grid
+    float cell_x, cell_y, fx, fy;
 };
+
+// the pose the frame is fused with: the odometry's result, or the previous pose when the RGB-D jump guard discards the increment
+// (RGBDOdometry.cpp:383-387).  A pure function of the tracking state: every workgroup that needs it computes the same bits.
+__device__ __forceinline__ void kt_setup_final_pose(const kt_setup_args& a, float R[9], float tv[3])
+{
+    for (int k = 0; k < 9; ++k) R[k] = a.st->Rcurr[k];
+    for (int k = 0; k < 3; ++k) tv[k] = a.st->tcurr[k];
+    if (a.rgbd_guard) {
+        const float d0 = tv[0] - a.st->tprev[0], d1 = tv[1] - a.st->tprev[1], d2 = tv[2] - a.st->tprev[2];
+        if ((double)__builtin_sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
+            for (int k = 0; k < 9; ++k) R[k] = a.st->Rprev[k];
+            for (int k = 0; k < 3; ++k) tv[k] = a.st->tprev[k];
+        }
+    }
+}
 
 // Workgroup 0 (one wave) is the set-up proper; workgroups 1.. maintain the colour-weight carry of KT_REC_STALE_NZ pixels, 1024 pixels
 // each: a pixel without a valid normal takes the weight the carry holds (and passes it on), every other pixel deposits its own.
@@ -694,6 +745,23 @@ struct kt_setup_args {
 // after a shift) changes nothing.  mode 2 = carry only (first frame).
 __global__ __launch_bounds__(256) void kt_frame_setup_kernel(const kt_setup_args a)
 {
+    if ((int)blockIdx.x > a.carry_groups) {
+        // Checkpoint workgroups of a planned frame, one wave per wave-column of the plan: the walk of v_x, v_y from z = 0 to the
+        // wave-column's first z for its 64 columns, with the pose the odometry has just produced (the plan itself was made for a
+        // prediction; the checkpoints are DEFINED by the frame's own pose, quirk A.17).
+        const int w = ((int)blockIdx.x - 1 - a.carry_groups) * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+        if (w >= a.XG * a.YG) return;
+        const unsigned int r = a.plan_wrange[w];
+        const int zc = (int)(r & 0xffffu);
+        if (zc >= (int)(r >> 16)) return;   // no task in this wave-column
+        const int sx = (w % a.XG) * a.wcx + lane % a.wcx, sy = (w / a.XG) * a.wcy + lane / a.wcx;
+        if (sx >= a.N || sy >= a.N) return;
+        float R[9], tv[3], Rinv[9];
+        kt_setup_final_pose(a, R, tv);
+        kt_mat33_inverse(R, Rinv);
+        a.plan_walk0[(size_t)sy * a.N + sx] = kt_tsdf_walk_checkpoint(Rinv, tv[0], tv[1], tv[2], a.cell_x, a.cell_y, a.cell_z, a.fx, a.fy, sx, sy, a.wx, a.wy, a.N, zc);
+        return;
+    }
     if (blockIdx.x > 0) {
         const int base = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
 #pragma unroll
@@ -712,20 +780,21 @@ __global__ __launch_bounds__(256) void kt_frame_setup_kernel(const kt_setup_args
     float R[9], tv[3];
     int skip = 0;
     if (a.mode == 0) {
-        for (int k = 0; k < 9; ++k) R[k] = a.st->Rcurr[k];
-        for (int k = 0; k < 3; ++k) tv[k] = a.st->tcurr[k];
-        if (a.rgbd_guard) {  // RGBDOdometry.cpp:383-387: an increment of more than 0.3 m is discarded
-            const float d0 = tv[0] - a.st->tprev[0], d1 = tv[1] - a.st->tprev[1], d2 = tv[2] - a.st->tprev[2];
-            if ((double)__builtin_sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
-                for (int k = 0; k < 9; ++k) R[k] = a.st->Rprev[k];
-                for (int k = 0; k < 3; ++k) tv[k] = a.st->tprev[k];
-            }
-        }
+        kt_setup_final_pose(a, R, tv);
         for (int k = 0; k < 3; ++k) {
             const int vt = voxel_trans(tv[k] - a.basis[k], a.voxel[k], a.thresh);
             if (vt >= a.thresh || vt <= -a.thresh) skip = 1;
         }
         if (a.st->handoff_timeout) skip = 1;   // no pose: nothing may be fused with it (complete_frame reports the error)
+        if (a.plan_wrange && !skip) {
+            // The plan is conservative for every pose within plan_theta (rotation) and plan_tau (translation) of the prediction:
+            // |R - R^|_F = 2 sqrt(2) sin(angle / 2) <= sqrt(2) angle.  Outside: skip = 2, the host fuses the frame through the in-stream
+            // pre-pass instead (the enqueued voxel kernel and ray cast do nothing).
+            float dr = 0.0f, dt = 0.0f;
+            for (int k = 0; k < 9; ++k) dr += (R[k] - a.plan_R[k]) * (R[k] - a.plan_R[k]);
+            for (int k = 0; k < 3; ++k) dt += (tv[k] - a.plan_t[k]) * (tv[k] - a.plan_t[k]);
+            if (!(__builtin_sqrtf(dr) <= 1.40f * a.plan_theta && __builtin_sqrtf(dt) <= 0.99f * a.plan_tau)) skip = 2;
+        }
     } else {
         for (int k = 0; k < 9; ++k) R[k] = a.R[k];
         for (int k = 0; k < 3; ++k) tv[k] = a.t[k];
@@ -745,8 +814,8 @@ __global__ __launch_bounds__(256) void kt_frame_setup_kernel(const kt_setup_args
             a.mirror->handoff_timeout = a.st->handoff_timeout;
             __threadfence_system();
             __hip_atomic_store(&a.mirror->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            for (int k = 0; k < 9; ++k) a.st->Rcurr[k] = R[k];
-            for (int k = 0; k < 3; ++k) a.st->tcurr[k] = tv[k];
+            // (the tracking state's pose is left as the odometry wrote it: the checkpoint workgroups of this launch read it, and the
+            // next frame starts from the host's copy of the final pose)
             a.st->fusion_skipped = skip;
         }
     }
@@ -785,14 +854,28 @@ static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv
     a.carry_next = t->wrkc_carry[t->carry_sel ^ 1];
     a.npix = t->cfg.cols * t->cfg.rows;
     const int carry_groups = t->cfg.disable_color_angle ? 0 : (a.npix + 1023) / 1024;   // without the angle weight wrkc is 2 everywhere
-    hipLaunchKernelGGL(kt_frame_setup_kernel, dim3(1 + carry_groups), dim3(256), 0, t->ctx->stream, a);
+    a.carry_groups = carry_groups;
+    a.plan_wrange = nullptr; a.plan_walk0 = nullptr;
+    int walk_groups = 0;
+    if (mode == 0 && t->plan_sel >= 0) {
+        const kt_tracker::PlanSlot& pl = t->plans[t->plan_sel];
+        a.plan_wrange = pl.plan.wrange; a.plan_walk0 = pl.plan.walk0;
+        memcpy(a.plan_R, pl.R, sizeof(a.plan_R)); memcpy(a.plan_t, pl.t, sizeof(a.plan_t));
+        a.plan_theta = pl.theta; a.plan_tau = pl.tau;
+        kt_tsdf_plan_shape(t->N, &a.wcx, &a.wcy, &a.XG, &a.YG);
+        a.wx = t->v_wrap_copy[0] % t->N; a.wy = t->v_wrap_copy[1] % t->N;
+        a.cell_x = t->volume_size[0] / t->N; a.cell_y = t->volume_size[1] / t->N;
+        a.fx = t->intr.fx; a.fy = t->intr.fy;
+        walk_groups = (a.XG * a.YG + 3) / 4;
+    }
+    hipLaunchKernelGGL(kt_frame_setup_kernel, dim3(1 + carry_groups + walk_groups), dim3(256), 0, t->ctx->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
 
 // [H] integrate (:864-876) + [I] raycast (:880-890) + [J] predicted-map pyramid (:892-899, fused into the raycast epilogue), with
 // the pose taken from fp_dev; wrap = the tracker's current v_wrap_copy
-static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, const uint8_t* colors)
+static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, const uint8_t* colors, const kt_tsdf_plan* plan = nullptr)
 {
     kt_ctx* c = t->ctx;
     const int cols = t->cfg.cols, rows = t->cfg.rows, N = t->N;
@@ -807,7 +890,7 @@ static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, con
     tsdf23_hook_arm(t);
     KT_TRY(kt_integrate_tsdf_impl(c, depth_raw, cols, rows, &t->intr, t->volume_size, &dummy_R, dummy_t, t->tranc_dist, t->tsdf,
                                   t->sets[set].scaled, t->v_wrap_copy, t->color, colors, t->sets[set].nmaps[0], !t->cfg.disable_color_angle, N,
-                                  t->counting ? t->upd_dev : nullptr, t->sets[set].rec, t->fp_dev, t->bricks, t->sets[set].dpmax));
+                                  t->counting ? t->upd_dev : nullptr, t->sets[set].rec, t->fp_dev, t->bricks, t->sets[set].dpmax, plan));
     KT_TRY(ev_end(t, ST_INTEGRATE));
     KT_TRY(ev_begin(t, ST_RAYCAST));
     const bool pyr = icp || t->cfg.use_rgbd_icp;
@@ -962,10 +1045,23 @@ static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool specu
         vt[k] = voxel_trans(current_translation[k], t->voxel_size[k], thresh);
         need_shift = need_shift || vt[k] >= thresh || vt[k] <= -thresh;
     }
-    if (speculated && need_shift != (t->mirror->skip != 0)) {
+    if (speculated && need_shift != (t->mirror->skip == 1)) {
         kt_set_error("tracker: host and device disagree on the shift decision");
         return KT_ERR_STATE;
     }
+    // skip == 2: the pose fell outside the margins the frame's task plan was made with -- the device parked the fusion kernels, the
+    // frame is fused below through the in-stream pre-pass
+    const bool plan_missed = speculated && t->mirror->skip == 2;
+    if (speculated && t->plan_sel >= 0) {
+        float dr = 0.0f, dt = 0.0f;
+        const kt_tracker::PlanSlot& pl = t->plans[t->plan_sel];
+        for (int k = 0; k < 9; ++k) dr += (Rcurr[k] - pl.R[k]) * (Rcurr[k] - pl.R[k]);
+        for (int k = 0; k < 3; ++k) dt += (tcurr[k] - pl.t[k]) * (tcurr[k] - pl.t[k]);
+        t->pred_err_r = sqrtf(dr) * 0.70710678f;   // |R - R^|_F ~ sqrt(2) angle
+        t->pred_err_t = sqrtf(dt);
+        if (plan_missed) ++t->plan_misses; else if (!need_shift) ++t->plan_hits;
+    }
+    t->plan_sel = -1;   // whatever is enqueued from here on for this frame runs its own pre-pass
     if (need_shift) {
         const int ov = t->cfg.overlap;
         KT_TRY(ev_begin(t, ST_SHIFT));
@@ -1008,7 +1104,7 @@ static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool specu
         v_wrap_copy_update(t);
         KT_TRY(ev_end(t, ST_SHIFT));
     }
-    if (need_shift || !speculated) {
+    if (need_shift || !speculated || plan_missed) {
         // the fusion the device parked (or that was never enqueued), with the final pose and wrap
         v_wrap_copy_update(t);
         KT_TRY(launch_setup(t, 1, Rcurr, tcurr));
@@ -1017,6 +1113,51 @@ static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool specu
     v_wrap_copy_update(t);
     ++t->global_time;
     push_pose(t, t->out_ts, Rcurr, is_loop);  // [K] :903-909
+    // pose history for the next prediction (rotation and the shift-invariant global camera)
+    memcpy(t->hist_R[0], t->hist_R[1], sizeof(t->hist_R[0])); memcpy(t->hist_gc[0], t->hist_gc[1], sizeof(t->hist_gc[0]));
+    memcpy(t->hist_R[1], Rcurr, sizeof(t->hist_R[1])); memcpy(t->hist_gc[1], t->current_global_camera, sizeof(t->hist_gc[1]));
+    if (t->hist_n < 2) ++t->hist_n;
+    return KT_OK;
+}
+
+// Planning ahead.  Called at the end of process_frame(f) for the frame f + 1 that has been read ahead: the host knows the poses of
+// frames f - 1 and f - 2 (f itself has just been enqueued), predicts the pose of f + 1 by repeating the last motion increment twice
+// (body-frame rotation increment, global-camera translation increment), and enqueues the voxel kernel's pre-pass for that prediction
+// on plan_stream behind the frame's read-ahead -- where it runs next to the odometry iterations of frame f.  Margins: three times the
+// error of the previous prediction on top of a floor, within caps.  The set-up kernel of frame f + 1 checks its pose against them;
+// a volume shift in between invalidates the plan (its storage wrap no longer matches).
+static int plan_ahead(kt_tracker* t, int set, long long ordinal)
+{
+    kt_tracker::PlanSlot& pl = t->plans[ordinal % 3];
+    pl.ordinal = -1;
+    float D[9], D2[9], Rp[9], tp[3];
+    for (int i = 0; i < 3; ++i)       // D = R(f-2)^T R(f-1)
+        for (int j = 0; j < 3; ++j) D[i * 3 + j] = t->hist_R[0][0 * 3 + i] * t->hist_R[1][0 * 3 + j] + t->hist_R[0][1 * 3 + i] * t->hist_R[1][1 * 3 + j] + t->hist_R[0][2 * 3 + i] * t->hist_R[1][2 * 3 + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) D2[i * 3 + j] = D[i * 3 + 0] * D[0 * 3 + j] + D[i * 3 + 1] * D[1 * 3 + j] + D[i * 3 + 2] * D[2 * 3 + j];
+    for (int i = 0; i < 3; ++i)       // R^ = R(f-1) D^2
+        for (int j = 0; j < 3; ++j) Rp[i * 3 + j] = t->Rlast[i * 3 + 0] * D2[0 * 3 + j] + t->Rlast[i * 3 + 1] * D2[1 * 3 + j] + t->Rlast[i * 3 + 2] * D2[2 * 3 + j];
+    float step = 0.0f, turn = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+        const float d = t->hist_gc[1][k] - t->hist_gc[0][k];
+        tp[k] = t->tlast[k] + 2.0f * d;
+        step += d * d;
+    }
+    for (int k = 0; k < 9; ++k) turn += (D[k] - ((k % 4 == 0) ? 1.0f : 0.0f)) * (D[k] - ((k % 4 == 0) ? 1.0f : 0.0f));
+    step = sqrtf(step); turn = sqrtf(turn) * 0.70710678f;
+    if (t->plan_hits + t->plan_misses == 0) { t->pred_err_t = 0.5f * step; t->pred_err_r = 0.5f * turn; }   // nothing observed yet
+    pl.tau = t->plan_margin_scale * fminf(0.020f, 0.0015f + 3.0f * t->pred_err_t);
+    pl.theta = t->plan_margin_scale * fminf(0.02f, 3.0e-4f + 3.0f * t->pred_err_r);
+    kt_mat33 Rinv;
+    kt_mat33_inverse(Rp, Rinv.m);
+    v_wrap_copy_update(t);
+    KT_HIP(hipStreamWaitEvent(t->plan_stream, t->sets[set].ready, 0));
+    KT_TRY(kt_integrate_plan(t->plan_stream, &pl.plan, t->sets[set].rec, t->sets[set].dpmax, t->cfg.cols, t->cfg.rows, &t->intr, t->volume_size, &Rinv, tp,
+                             t->tranc_dist, t->v_wrap_copy, t->N, pl.theta, pl.tau));
+    KT_HIP(hipEventRecord(pl.done, t->plan_stream));
+    memcpy(pl.R, Rp, sizeof(pl.R)); memcpy(pl.t, tp, sizeof(pl.t));
+    memcpy(pl.wrap, t->v_wrap_copy, sizeof(pl.wrap));
+    pl.ordinal = ordinal;
     return KT_OK;
 }
 
@@ -1105,8 +1246,10 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     // [A] pyramid build, KintinuousTracker.cpp:465-479 (+ scaleDepth records): taken from the prefetch stream if this frame
     // was announced with kt_tracker_prefetch_frame, otherwise computed here
     int set = -1;
+    bool read_ahead = false;
     for (size_t i = 0; i < t->pending.size(); ++i)
         if (t->pending[i].depth == depth_raw && t->pending[i].rgb == colors) {
+            read_ahead = true;
             // read-aheads announced before this one were skipped by the caller: their sets return to the pool once written
             for (size_t j = 0; j < i; ++j) KT_HIP(hipStreamWaitEvent(c->stream, t->sets[t->pending[j].set].ready, 0));
             set = t->pending[i].set;
@@ -1188,6 +1331,12 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         return KT_OK;
     }
 
+    // the voxel kernel's task plan, if one was made for this frame while the previous one was tracked and the volume has not
+    // shifted since (plan_ahead)
+    t->plan_sel = -1;
+    v_wrap_copy_update(t);
+    if (read_ahead && t->plans[ordinal % 3].ordinal == ordinal && memcmp(t->plans[ordinal % 3].wrap, t->v_wrap_copy, sizeof(t->v_wrap_copy)) == 0)
+        t->plan_sel = (int)(ordinal % 3);
     // [C] odometry :564-572 -- every Gauss-Newton iteration is enqueued; the pose stays on the device
     KT_TRY(ev_begin(t, ST_ODOMETRY));
     if (icp) KT_TRY(icp_odometry(t));
@@ -1196,14 +1345,20 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     // here, speculatively, on the assumption that the volume does not shift
     v_wrap_copy_update(t);
     if (++t->frame_seq == 0) t->frame_seq = 1;  // 0 is the mirror's initial value
+    // the plan has had the 19 launches above to finish; a join is enqueued only if it has not (a wait packet is a bubble)
+    if (t->plan_sel >= 0 && hipEventQuery(t->plans[t->plan_sel].done) != hipSuccess) KT_HIP(hipStreamWaitEvent(c->stream, t->plans[t->plan_sel].done, 0));
     KT_TRY(launch_setup(t, 0, nullptr, nullptr));
     // -d: the cube may be repositioned once the pose is known, which changes the shift decision -- nothing to speculate on
     t->out_speculated = !t->cfg.dynamic_cube;
-    if (t->out_speculated) KT_TRY(enqueue_fusion(t, set, depth_raw, colors));
+    if (t->out_speculated) KT_TRY(enqueue_fusion(t, set, depth_raw, colors, t->plan_sel >= 0 ? &t->plans[t->plan_sel].plan : nullptr));
     t->outstanding = true;
     t->out_ordinal = ordinal;
     t->gt_utime = timestamp;
     if (!t->out_speculated) KT_TRY(complete_frame(t));   // observe the pose, reposition, shift if needed, enqueue the fusion
+    // the frame that has been read ahead comes next: plan its voxel pass now, for the pose predicted two increments past the last one
+    // the host has seen (-d repositions the cube once the pose is known: nothing to plan for)
+    if (t->plan_enabled && !t->pending.empty() && t->hist_n >= 2 && !t->cfg.dynamic_cube && t->outstanding)
+        KT_TRY(plan_ahead(t, t->pending.front().set, ordinal + 1));
     t->ev_par ^= 1;
     if (t->counting) {  // the counters are read back per frame: finish it before returning
         KT_TRY(complete_frame(t));
@@ -1454,6 +1609,14 @@ int kt_tracker_debug_state(kt_tracker* t, float* out29)
     memcpy(out29, t->state_host->icp29, 29 * sizeof(float));
     return KT_OK;
 }
+int kt_tracker_plan_stats(kt_tracker* t, long long out2[2])
+{
+    KT_ARG(t && out2);
+    KT_TRY(complete_frame(t));
+    out2[0] = t->plan_hits; out2[1] = t->plan_misses;
+    return KT_OK;
+}
+
 int kt_tracker_debug_counts(kt_tracker* t, unsigned int* out4)
 {
     KT_ARG(t && out4);

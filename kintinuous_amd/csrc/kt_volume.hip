@@ -10,6 +10,7 @@
 #include "kt_internal.hpp"
 
 #include <stdlib.h>
+#include <string.h>
 
 thread_local kt_event_hook kt_tsdf23_hook = {{nullptr, nullptr}, false};
 
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(256) void kt_scale_depth_kernel(const uint16_t* __r
         const uint8_t* c = &colors[3 * (y * cols + x)];
         r.rgbf = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | (kt_isnan(nx) ? KT_REC_NORMAL_NAN : 0u) |
                  ((angle_color && kt_isnan(nx)) ? KT_REC_STALE_NZ : 0u);
+#if KT_REC_BYTES == 16
         r.pad = 0;
+#endif
         rec[y * cols + x] = r;
     }
 }
@@ -184,7 +187,6 @@ struct kt_tsdf23_args {
     uchar4* color;
     const float* vgz;
     const float* zs;
-    const unsigned int* interval;  // per storage column: z0 | z1 << 16 (kt_tsdf_interval_kernel)
     const unsigned int* tasks;     // compact list of (wave-column, z-chunk) units that contain work (kt_tsdf_tasks_kernel)
     const unsigned int* task_count;
     const unsigned int* wrange;    // per wave-column: union of its 64 column intervals, z0 | z1 << 16
@@ -202,6 +204,11 @@ struct kt_tsdf23_args {
     const kt_frame_params* fp;  // when set: Ri / t come from the device (kt_frame_params) instead of the fields above
     unsigned char* bricks;      // optional [nb^3], nb = N / 32: set to 1 when a NEGATIVE tsdf is stored into the 32^3 storage brick
     int nb;                     // (raycast skips bricks that hold no negative value, see kt_raycast_kernel)
+    // Planning ahead (kt_integrate_plan): the pre-pass runs on a PREDICTED pose, one frame early and off the frame's critical path.
+    // The pose the frame ends up with may differ from the prediction by a rotation of at most theta and a translation of at most
+    // tau; a voxel's camera coordinates then move by eps <= pm_A * p_z + pm_B (pm_A = 1.01 theta kappa, pm_B = 1.01 tau, kappa =
+    // |p| / p_z at the image corner), and every bound of the pre-pass is widened by that much.  Both 0: the pose is the frame's own.
+    float pm_A, pm_B;
 };
 
 // pose override shared by the two integrate kernels (wave-uniform scalar loads)
@@ -264,8 +271,8 @@ __device__ __forceinline__ int kt_wave_max(int v)
 
 // Pre-pass 1: the conservative z-interval of every voxel column, stored as (z0 | z1 << 16) per storage column (empty = N | 0),
 // and per wave-column the union of its 64 intervals.  grid = (ceil(N / 64), ceil(N / 4)), 256 threads = 2 x 2 wave-columns.
-__global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_args a_in, unsigned int* __restrict__ interval,
-                                                               unsigned int* __restrict__ wrange, float2* __restrict__ walk0)
+__global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_args a_in, unsigned int* __restrict__ wrange,
+                                                               float2* __restrict__ walk0)
 {
     kt_tsdf23_args a = a_in;
     const bool skip = kt_tsdf_pose_from_device(a);
@@ -305,22 +312,27 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
         const float znear = 0.05f;  // below this depth the pixel bounds are not trusted
         const float lo = 0.0f, hi = (float)(N - 1);
         flo = lo; fhi = hi;         // frustum part: p_z >= znear and the four image sides padded by m pixels
-        kt_clip_halfline(az - znear, bz, flo, fhi);
-        const float ul = -0.5f - m - a.intr.cx, uh = (float)a.cols - 0.5f + m - a.intr.cx;
-        const float vl = -0.5f - m - a.intr.cy, vh = (float)a.rows - 0.5f + m - a.intr.cy;
-        kt_clip_halfline(a.intr.fx * ax - ul * az, a.intr.fx * bx - ul * bz, flo, fhi);
-        kt_clip_halfline(uh * az - a.intr.fx * ax, uh * bz - a.intr.fx * bx, flo, fhi);
-        kt_clip_halfline(a.intr.fy * ay - vl * az, a.intr.fy * by - vl * bz, flo, fhi);
-        kt_clip_halfline(vh * az - a.intr.fy * ay, vh * bz - a.intr.fy * by, flo, fhi);
+        // (planned ahead: the frame's own camera coordinates p satisfy |p - p^| <= eps(p^) = pm_A p^_z + pm_B, so an image side
+        // f p_x - u p_z >= 0 is implied by f p^_x - u p^_z + (f + |u|) eps >= 0: the same half-plane with u moved by (f + |u|) pm_A
+        // and the constant (f + |u|) pm_B added)
+        kt_clip_halfline(az - znear + 1.1f * a.pm_B + a.pm_A * znear, bz, flo, fhi);
+        float ul = -0.5f - m - a.intr.cx, uh = (float)a.cols - 0.5f + m - a.intr.cx;
+        float vl = -0.5f - m - a.intr.cy, vh = (float)a.rows - 0.5f + m - a.intr.cy;
+        const float gul = a.intr.fx + fabsf(ul), guh = a.intr.fx + fabsf(uh), gvl = a.intr.fy + fabsf(vl), gvh = a.intr.fy + fabsf(vh);
+        ul -= gul * a.pm_A; uh += guh * a.pm_A; vl -= gvl * a.pm_A; vh += gvh * a.pm_A;
+        kt_clip_halfline(a.intr.fx * ax - ul * az + gul * a.pm_B, a.intr.fx * bx - ul * bz, flo, fhi);
+        kt_clip_halfline(uh * az - a.intr.fx * ax + guh * a.pm_B, uh * bz - a.intr.fx * bx, flo, fhi);
+        kt_clip_halfline(a.intr.fy * ay - vl * az + gvl * a.pm_B, a.intr.fy * by - vl * bz, flo, fhi);
+        kt_clip_halfline(vh * az - a.intr.fy * ay + gvh * a.pm_B, vh * bz - a.intr.fy * by, flo, fhi);
         // near slab: -cell <= p_z <= znear.  There the pixel coordinates are ill-conditioned, so the slab is kept without
         // testing them -- but a voxel that close to the camera plane can only project into the image when it is also within
         // |p_x|, |p_y| <= znear * (image half-size / f) ~ 0.06 m of the optical axis; columns that stay 0.2 m away skip it.
         nlo = lo; nhi = hi;
-        kt_clip_halfline(az + a.cell_z + a.cell_x + a.cell_y, bz, nlo, nhi);
-        kt_clip_halfline(znear - az, -bz, nlo, nhi);
+        kt_clip_halfline(az + a.cell_z + a.cell_x + a.cell_y + 1.1f * a.pm_B, bz, nlo, nhi);
+        kt_clip_halfline(znear + 1.1f * a.pm_B + a.pm_A * znear - az, -bz, nlo, nhi);
         if (nlo <= nhi) {
             const float pxa = ax + nlo * bx, pxb = ax + nhi * bx, pya = ay + nlo * by, pyb = ay + nhi * by;
-            const float rlim = 0.2f;
+            const float rlim = 0.2f + 2.0f * a.pm_B;
             const bool far_x = (pxa > rlim && pxb > rlim) || (pxa < -rlim && pxb < -rlim);
             const bool far_y = (pya > rlim && pyb > rlim) || (pya < -rlim && pyb < -rlim);
             if (far_x || far_y) { nlo = 1e30f; nhi = -1e30f; }
@@ -360,8 +372,10 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
             };
             // Bound of |scaled depth| under the padded bounding box of two pixels from the dilated map of tile size 2^l2: a box at most two
             // tiles wide lies inside the 3 x 3 tiles around the tile of its centre, whose maximum is that entry.  (Wider: the map's maximum.)
-            auto bound = [&](float u0, float v0, float u1, float v1, const float* map, int l2, int mc, int mr) -> float {
-                const float pad = 2.5f, ti = 1.0f / (float)(1 << l2);
+            // (planned ahead: the frame's own pixel lies within (f + |u - c|) eps / (p_z - eps) of the predicted one; the pad of a piece
+            // is taken at its near end, where that is largest)
+            auto bound = [&](float u0, float v0, float u1, float v1, float pad, const float* map, int l2, int mc, int mr) -> float {
+                const float ti = 1.0f / (float)(1 << l2);
                 if (fmaxf(fabsf(u1 - u0), fabsf(v1 - v0)) + 2.0f * pad > (float)(2 << l2)) return Dall;
                 const int tx = min(mc - 1, max(0, (int)floorf(0.5f * (u0 + u1) * ti)));
                 const int ty = min(mr - 1, max(0, (int)floorf(0.5f * (v0 + v1) * ti)));
@@ -371,13 +385,18 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
             // |v(z)|^2 = r2xy + w(z)^2 with w(z) = (z + 0.5) cell_z - t_z linear in z, so the smallest |v| of the piece needs no square root;
             // two voxels of slack in R cover the rounding of z to voxel centres and of this arithmetic.
             auto keep = [&](float z0, float z1, float D, float& top) -> bool {
-                const float R = (D + a.tranc_dist) * 1.001f + 1e-4f + 2.0f * a.cell_z;
+                const float R = (D + a.tranc_dist) * 1.001f + 1e-4f + 2.0f * a.cell_z + a.pm_B;   // (the camera centre moves by <= tau)
                 const float w0 = __builtin_fmaf(z0 + 0.5f, a.cell_z, -a.tz), w1 = __builtin_fmaf(z1 + 0.5f, a.cell_z, -a.tz);
                 const float wmin2 = (w0 <= 0.0f && w1 >= 0.0f) ? 0.0f : fminf(w0 * w0, w1 * w1);
                 const float s2 = R * R - r2xy;
                 if (!(wmin2 <= s2)) return false;
                 top = fminf(z1, (a.tz + __builtin_amdgcn_sqrtf(s2) * 1.00001f) * inv_cell - 0.5f);
                 return true;
+            };
+            const float gpix = fmaxf(a.intr.fx, a.intr.fy) + (float)max(a.cols, a.rows);
+            auto pad_at = [&](float z) -> float {   // 2.5 pixels of rounding + the planning margin at (fractional) z
+                const float pz = az + z * bz, eps = a.pm_A * pz + a.pm_B;
+                return (a.pm_A == 0.0f && a.pm_B == 0.0f) ? 2.5f : 2.5f + gpix * eps * __builtin_amdgcn_rcpf(fmaxf(pz - eps, 1e-3f)) * 1.01f;
             };
             float ua, va, ub, vb;
             pix(flo, ua, va);
@@ -401,7 +420,7 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
                     zc0 = ic == 0 ? flo : flo + dzc * (float)ic;
                     uc0 = ua; vc0 = va;
                     if (ic != 0) pix(zc0, uc0, vc0);
-                    if (keep(zc0, zc1, bound(uc0, vc0, uc1, vc1, s_dp32, 5, tc32, tr32), top)) { found = true; break; }
+                    if (keep(zc0, zc1, bound(uc0, vc0, uc1, vc1, fmaxf(pad_at(zc0), pad_at(zc1)), s_dp32, 5, tc32, tr32), top)) { found = true; break; }
                     zc1 = zc0; uc1 = uc0; vc1 = vc0;
                 }
                 if (!found) break;
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
                     const float zf0 = jf == 0 ? zc0 : zc0 + dzf * (float)jf;
                     float uf0 = uc0, vf0 = vc0;
                     if (jf != 0) pix(zf0, uf0, vf0);
-                    if (keep(zf0, zf1, bound(uf0, vf0, uf1, vf1, s_dpmax, tl2, tcols, trows), top)) { hi_new = top; any = true; break; }
+                    if (keep(zf0, zf1, bound(uf0, vf0, uf1, vf1, fmaxf(pad_at(zf0), pad_at(zf1)), s_dpmax, tl2, tcols, trows), top)) { hi_new = top; any = true; break; }
                     zf1 = zf0; uf1 = uf0; vf1 = vf0;
                 }
                 zc1 = zc0; uc1 = uc0; vc1 = vc0;   // nothing kept in there: scan on below it
@@ -433,30 +452,13 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
             if (z0 >= z1) { z0 = N; z1 = 0; }
         }
     }
-    if (column) interval[(size_t)sy * N + sx] = (unsigned int)z0 | ((unsigned int)z1 << 16);
     const int wz0 = kt_wave_min(z0), wz1 = kt_wave_max(z1);
     const int XG = (N + KT_WX - 1) / KT_WX, YG = (N + KT_WY - 1) / KT_WY;
     if (lane_ == 0 && xg < XG && yg < YG) wrange[(size_t)yg * XG + xg] = (unsigned int)wz0 | ((unsigned int)wz1 << 16);
     // Checkpoint of the incremental walk (quirk A.17: v_x, v_y are DEFINED by repeated float +=) at the wave-column's first z:
     // walked once per column here (wave-uniform trip count), so a voxel task only replays from there to its own chunk.
-    if (wz0 < wz1 && column) {
-        int x = sx - a.wx; if (x < 0) x += N;
-        int y = sy - a.wy; if (y < 0) y += N;
-        const float* Ri = a.Ri.m;
-        const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -a.tx);
-        const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -a.ty);
-        const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
-        float v_x = __builtin_fmaf(Ri[2], v_g_z0, __builtin_fmaf(Ri[0], v_g_x, Ri[1] * v_g_y)) * a.intr.fx;
-        float v_y = __builtin_fmaf(Ri[5], v_g_z0, __builtin_fmaf(Ri[3], v_g_x, Ri[4] * v_g_y)) * a.intr.fy;
-        const float dvx = Ri[2] * a.cell_z * a.intr.fx, dvy = Ri[5] * a.cell_z * a.intr.fy;
-        int z = 0;
-        for (; z + 16 <= wz0; z += 16) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { v_x += dvx; v_y += dvy; }
-        }
-        for (; z < wz0; ++z) { v_x += dvx; v_y += dvy; }
-        walk0[(size_t)sy * N + sx] = make_float2(v_x, v_y);
-    }
+    if (walk0 && wz0 < wz1 && column)   // (a plan made ahead of its frame leaves them to the frame's set-up kernel: they need the frame's own pose)
+        walk0[(size_t)sy * N + sx] = kt_tsdf_walk_checkpoint(a.Ri.m, a.tx, a.ty, a.tz, a.cell_x, a.cell_y, a.cell_z, a.intr.fx, a.intr.fy, sx, sy, a.wx, a.wy, N, wz0);
 }
 
 // Pre-pass 2: compact task list.  One workgroup; thread t owns a contiguous run of wave-columns, counts their chunks, a block-wide
@@ -755,7 +757,8 @@ __global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_ts
         m.vol = __builtin_amdgcn_make_buffer_rsrc((void*)a_in.volume, 0, nvox * 2u, 0x00020000);
         m.col = __builtin_amdgcn_make_buffer_rsrc((void*)a_in.color, 0, nvox * 4u, 0x00020000);
     }
-    (void)kt_tsdf_pose_from_device(a);   // a parked frame has an empty task list
+    // a parked frame does nothing here: its in-stream pre-pass left an empty task list, but a plan made ahead of the frame did not
+    if (kt_tsdf_pose_from_device(a)) return;
     const int N = a.N;
     const int lane = threadIdx.x & 63;
     const unsigned int n_tasks = *a.task_count;
@@ -845,7 +848,6 @@ struct kt_integrate_scratch {
     kt_pixrec* rec = nullptr; size_t rec_px = 0;
     float* vgz = nullptr; float* zs = nullptr; int tabN = 0;
     float* tab_host[2] = {nullptr, nullptr};  // pinned staging of {vgz[N], zs[N]}, double-buffered
-    unsigned int* interval = nullptr;          // N * N column intervals
     unsigned int* wrange = nullptr;            // N * ceil(N / 64) wave-column unions
     float2* walk0 = nullptr;                   // N * N walk checkpoints at the wave-column's first z
     float* dpmax = nullptr;                    // KT_DPT_FLOATS: tile maxima of |scaled depth|, two levels (non-prepared path)
@@ -858,7 +860,7 @@ void kt_integrate_scratch_free(kt_ctx* c)
 {
     kt_integrate_scratch* s = c->integ;
     if (!s) return;
-    (void)hipFree(s->rec); (void)hipFree(s->vgz); (void)hipFree(s->interval); (void)hipFree(s->wrange); (void)hipFree(s->tasks); (void)hipFree(s->walk0); (void)hipFree(s->dpmax);
+    (void)hipFree(s->rec); (void)hipFree(s->vgz); (void)hipFree(s->wrange); (void)hipFree(s->tasks); (void)hipFree(s->walk0); (void)hipFree(s->dpmax);
     (void)hipFree(s->task_count);
     for (int k = 0; k < 2; ++k) (void)hipHostFree(s->tab_host[k]);
     delete s;
@@ -879,10 +881,9 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
     }
     if (s.tabN < N) {
         KT_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(s.vgz); (void)hipFree(s.interval); (void)hipFree(s.wrange); (void)hipFree(s.tasks); (void)hipFree(s.task_count); (void)hipFree(s.walk0);
-        s.vgz = s.zs = nullptr; s.interval = s.wrange = s.tasks = s.task_count = nullptr; s.walk0 = nullptr; s.tabN = 0;
+        (void)hipFree(s.vgz); (void)hipFree(s.wrange); (void)hipFree(s.tasks); (void)hipFree(s.task_count); (void)hipFree(s.walk0);
+        s.vgz = s.zs = nullptr; s.wrange = s.tasks = s.task_count = nullptr; s.walk0 = nullptr; s.tabN = 0;
         const size_t wave_cols = (size_t)kt_div_up(N, KT_WX) * kt_div_up(N, KT_WY);
-        KT_HIP(hipMalloc((void**)&s.interval, sizeof(unsigned int) * (size_t)N * N));
         KT_HIP(hipMalloc((void**)&s.wrange, sizeof(unsigned int) * wave_cols));
         KT_HIP(hipMalloc((void**)&s.walk0, sizeof(float2) * (size_t)N * N));
         KT_HIP(hipMalloc((void**)&s.tasks, sizeof(unsigned int) * wave_cols * kt_div_up(N, KT_TSDF_ZCHUNK)));
@@ -898,12 +899,76 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
     return KT_OK;
 }
 
+// the two pre-pass launches: column intervals (+ wave-column unions, walk checkpoints unless walk0 is null), then the task list
+static int kt_tsdf_prepass(hipStream_t stream, const kt_tsdf23_args& a, unsigned int* wrange, float2* walk0, unsigned int* tasks, unsigned int* task_count)
+{
+    const int N = a.N;
+    const int XG = kt_div_up(N, KT_WX), YG = kt_div_up(N, KT_WY);
+    const size_t maps_lds = a.dpmax && a.dpt_log2 ? sizeof(float) * (size_t)(((kt_div_up(a.cols, 1 << a.dpt_log2) * kt_div_up(a.rows, 1 << a.dpt_log2) + 3) & ~3) + kt_div_up(a.cols, 32) * kt_div_up(a.rows, 32)) : 0;
+    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(kt_div_up(N, 2 * KT_WX), kt_div_up(N, 2 * KT_WY)), dim3(256), maps_lds, stream, a, wrange, walk0);
+    KT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(kt_tsdf_tasks_kernel, dim3(1), dim3(1024), 0, stream, wrange, XG * YG, XG, tasks, task_count);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// ---- planning ahead -------------------------------------------------------------------------------------------------------------
+// The pre-pass above costs 24 us of a 370 us frame and sits between the odometry and the voxel kernel.  Its output only SELECTS work
+// (every kept voxel still runs the reference's exact in-image test), so it may be computed for any pose that is known to be close
+// to the frame's: the tracker predicts the pose of frame k + 1 from those of frames k and k - 1, runs the pre-pass for that
+// prediction on a side stream while the odometry of frame k + 1 iterates, widened by margins (theta, tau) on the rotation and
+// translation error, and the frame's set-up kernel checks the pose the odometry arrived at against those margins: inside them the
+// voxel kernel runs from the plan, outside them the frame is parked and fused through the in-stream pre-pass instead.
+int kt_tsdf_plan_alloc(kt_tsdf_plan* p, int N)
+{
+    const size_t wave_cols = (size_t)kt_div_up(N, KT_WX) * kt_div_up(N, KT_WY);
+    memset(p, 0, sizeof(*p));
+    KT_HIP(hipMalloc((void**)&p->wrange, sizeof(unsigned int) * wave_cols));
+    KT_HIP(hipMalloc((void**)&p->walk0, sizeof(float2) * (size_t)N * N));
+    KT_HIP(hipMalloc((void**)&p->tasks, sizeof(unsigned int) * wave_cols * kt_div_up(N, KT_TSDF_ZCHUNK)));
+    KT_HIP(hipMalloc((void**)&p->task_count, sizeof(unsigned int)));
+    return KT_OK;
+}
+void kt_tsdf_plan_free(kt_tsdf_plan* p)
+{
+    (void)hipFree(p->wrange); (void)hipFree(p->walk0); (void)hipFree(p->tasks); (void)hipFree(p->task_count);
+    memset(p, 0, sizeof(*p));
+}
+void kt_tsdf_plan_shape(int N, int* wx, int* wy, int* xg, int* yg) { *wx = KT_WX; *wy = KT_WY; *xg = kt_div_up(N, KT_WX); *yg = kt_div_up(N, KT_WY); }
+
+int kt_integrate_plan(hipStream_t stream, const kt_tsdf_plan* plan, const void* rec, const float* dpmax, int cols, int rows, const kt_intr* intr,
+                      const float volume_size[3], const kt_mat33* Rinv_pred, const float t_pred[3], float tranc_dist, const int voxel_wrap[3], int N,
+                      float theta, float tau)
+{
+    KT_ARG(plan && rec && intr && volume_size && Rinv_pred && t_pred && voxel_wrap && N > 0 && N <= 1536 && theta >= 0 && tau >= 0);
+    kt_tsdf23_args a;
+    memset(&a, 0, sizeof(a));
+    a.rec = (const kt_pixrec*)rec;
+    a.Ri = *Rinv_pred;
+    a.tx = t_pred[0]; a.ty = t_pred[1]; a.tz = t_pred[2];
+    a.intr = *intr;
+    a.cell_x = volume_size[0] / N; a.cell_y = volume_size[1] / N; a.cell_z = volume_size[2] / N;
+    a.tranc_dist = tranc_dist;
+    a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
+    a.cols = cols; a.rows = rows; a.N = N;
+    a.dpmax = dpmax;
+    a.dpt_log2 = kt_dpt_log2(cols, rows);
+    // |p| / p_z of a point that projects into the (padded) image is at most kappa; eps <= (theta kappa p_z + tau (1 + theta)) / (1 - theta kappa)
+    const float kx = (fmaxf(intr->cx, (float)cols - intr->cx) + 3.0f) / intr->fx, ky = (fmaxf(intr->cy, (float)rows - intr->cy) + 3.0f) / intr->fy;
+    const float kappa = sqrtf(1.0f + kx * kx + ky * ky);
+    KT_ARG(theta * kappa < 0.25f);
+    a.pm_A = 1.01f * theta * kappa / (1.0f - theta * kappa);
+    a.pm_B = 1.01f * tau * (1.0f + theta) / (1.0f - theta * kappa);
+    return kt_tsdf_prepass(stream, a, plan->wrange, nullptr, plan->tasks, plan->task_count);
+}
+
 // shared by the C entry point and the tracker (which wants the update count for the roofline report)
 int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
                            const float volume_size[3], const kt_mat33* Rcurr_inv, const float tcurr[3], float tranc_dist,
                            int16_t* volume, float* depth_raw_scaled, const int voxel_wrap[3], uint8_t* color_volume,
                            const uint8_t* colors, const float* nmap_curr, int angle_color, int N, unsigned int* updated_dev,
-                           const void* prepared_rec, const kt_frame_params* fp, unsigned char* bricks, const float* prepared_dpmax)
+                           const void* prepared_rec, const kt_frame_params* fp, unsigned char* bricks, const float* prepared_dpmax,
+                           const kt_tsdf_plan* plan)
 {
     KT_ARG(c && depth_raw && intr && volume_size && Rcurr_inv && tcurr && volume && depth_raw_scaled && voxel_wrap &&
            color_volume && colors && nmap_curr && N > 0 && cols > 0 && rows > 0);
@@ -958,19 +1023,17 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     a.wx = voxel_wrap[0] % N; a.wy = voxel_wrap[1] % N; a.wz = voxel_wrap[2] % N;
     a.cols = cols; a.rows = rows; a.N = N;
     KT_ARG(N <= 1536);  // 32-bit voxel offsets (N^3 < 2^32) and 16-bit z bounds
-    a.interval = c->integ->interval;
-    a.tasks = c->integ->tasks;
-    a.task_count = c->integ->task_count;
-    a.wrange = c->integ->wrange;
-    a.walk0 = c->integ->walk0;
+    a.pm_A = a.pm_B = 0.0f;
     a.dpmax = prepared_dpmax;
     a.dpt_log2 = kt_dpt_log2(cols, rows);
-    const int XG = kt_div_up(N, KT_WX), YG = kt_div_up(N, KT_WY);
-    const size_t maps_lds = a.dpmax && a.dpt_log2 ? sizeof(float) * (size_t)(((kt_div_up(cols, 1 << a.dpt_log2) * kt_div_up(rows, 1 << a.dpt_log2) + 3) & ~3) + kt_div_up(cols, 32) * kt_div_up(rows, 32)) : 0;
-    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(kt_div_up(N, 2 * KT_WX), kt_div_up(N, 2 * KT_WY)), dim3(256), maps_lds, c->stream, a, c->integ->interval, c->integ->wrange, c->integ->walk0);
-    KT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(kt_tsdf_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, c->integ->wrange, XG * YG, XG, c->integ->tasks, c->integ->task_count);
-    KT_LAUNCH_CHECK();
+    if (plan) {
+        // the task plan was made ahead of the frame (kt_integrate_plan, conservative for every pose within its margins -- the caller
+        // has checked that this frame's pose is) and its walk checkpoints by the frame's set-up kernel: only the voxel kernel is left
+        a.tasks = plan->tasks; a.task_count = plan->task_count; a.wrange = plan->wrange; a.walk0 = plan->walk0;
+    } else {
+        a.tasks = c->integ->tasks; a.task_count = c->integ->task_count; a.wrange = c->integ->wrange; a.walk0 = c->integ->walk0;
+        KT_TRY(kt_tsdf_prepass(c->stream, a, c->integ->wrange, c->integ->walk0, c->integ->tasks, c->integ->task_count));
+    }
     dim3 b(256), g(KT_TSDF_WAVES / 4);
     if (kt_tsdf23_hook.on) KT_HIP(hipEventRecord(kt_tsdf23_hook.ev[0], c->stream));
     const bool buf = N < 1024 && !getenv("KT_TSDF_POINTERS");   // 32-bit byte offsets into the colour volume (N^3 * 4 < 2^32)
@@ -1022,7 +1085,7 @@ extern "C" int kt_integrate_tsdf(kt_ctx* c, const uint16_t* depth_raw, int cols,
                                  const uint8_t* colors, const float* nmap_curr, int angle_color, int N)
 {
     return kt_integrate_tsdf_impl(c, depth_raw, cols, rows, intr, volume_size, Rcurr_inv, tcurr, tranc_dist, volume,
-                                  depth_raw_scaled, voxel_wrap, color_volume, colors, nmap_curr, angle_color, N, nullptr, nullptr, nullptr, nullptr, nullptr);
+                                  depth_raw_scaled, voxel_wrap, color_volume, colors, nmap_curr, angle_color, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 // PMC calibration hooks (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are uncalibrated for narrow accesses): stream a buffer

@@ -40,7 +40,7 @@ class ConfigArgs {
                      "  -pcd           run the CloudSliceProcessor stage behind the tracker and save <prefix>.pcd as the reference does\n"
                      "                 (binary pcl::PointXYZRGBNormal: x y z rgb normal_x normal_y normal_z curvature)\n"
                      "  -ppm           write the final model views: <prefix>_model.ppm, _color.ppm, _depth.pgm\n"
-                     "  -rank R -world W -comm <file>   one process per GPU (-g): gather the ranks' dense poses at the end (RCCL)\n",
+                     "  -rank R -world W -comm <file> [-gk K]   one process per GPU (-g): gather every rank's K most recent dense poses at the end (RCCL; default 1)\n",
                      argv0.c_str());
     }
 

@@ -1,14 +1,17 @@
-// ICPOdometry.h -- projective point-to-plane ICP against the predicted model maps, driven from the host one iteration
-// at a time exactly like the reference (frontend/ICPOdometry.cpp:68-186): icpStep -> 6x6 LDLT solve in double ->
-// Rodrigues -> SE(3) composition.  This is the per-operator path over kt_icp_step (one host sync per iteration);
-// KintinuousTracker's default path runs the same iterations device-resident (kt_tracker_process_frame).  Both produce
-// bit-identical poses (tests/test_gpu_host_shell.py).
+// ICPOdometry.h -- projective point-to-plane ICP against the predicted model maps (frontend/ICPOdometry.cpp:68-186): one call of
+// kt_icp_track -- all 19 Gauss-Newton iterations enqueued back to back, the 6x6 LDLT solve in double, Rodrigues and the SE(3)
+// composition in each reduction kernel's epilogue, pose in / pose out.  (The reference iterates on the host: icpStep, a blocking copy of
+// 29 sums and an Eigen solve per iteration; that loop can still be composed from kt_icp_step + kt_host_ldlt_solve6 +
+// kt_host_pose_update, and gives bit-identical poses: tests/test_gpu_track.py::test_icp_track_matches_the_stepwise_loop.)
+// This is what KintinuousTracker's operator path (-ops) tracks with; its default path runs the same chain inside
+// kt_tracker_process_frame.
 #pragma once
 
 #include <cmath>
 #include <vector>
 
 #include "OdometryProvider.h"
+#include "internal.h"
 
 class ICPOdometry : public OdometryProvider {
   public:
@@ -32,26 +35,18 @@ class ICPOdometry : public OdometryProvider {
     {
         const kt::Matrix3f Rprev = rmats_.back();
         const kt::Vector3f tprev = tvecs_.back();
-        kt::Matrix3f Rcurr = Rprev, Rprev_inv;
+        kt::Matrix3f Rcurr = Rprev;
         kt::Vector3f tcurr = tprev;
-        ktSafeCall(kt_host_mat33_inverse(Rprev.data(), Rprev_inv.data()));
-        double resultRt[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-
-        for (int level_index = LEVELS - 1; level_index >= 0; --level_index) {
-            for (int iter = 0; iter < icp_iterations_[level_index]; ++iter) {
-                float A_icp[36], b_icp[6], residual[2];
-                icpStep(kt::dev(Rcurr), kt::dev(tcurr), vmaps_curr_[level_index],
-                        nmaps_curr_[level_index], kt::dev(Rprev_inv), kt::dev(tprev),
-                        intr(level_index), vmaps_g_prev_[level_index], nmaps_g_prev_[level_index], distThres_, angleThres_, sumDataSE3,
-                        outDataSE3, A_icp, b_icp, residual, 128, 64);
-                double dA[36], db[6], result[6];
-                for (int i = 0; i < 36; ++i) lastA[i] = dA[i] = (double)A_icp[i];
-                for (int i = 0; i < 6; ++i) db[i] = (double)b_icp[i];
-                ktSafeCall(kt_host_ldlt_solve6(dA, db, result));
-                // resultRt = currRt * resultRt;  currentT = [Rprev | tprev] * resultRt^-1   (ICPOdometry.cpp:133-178)
-                ktSafeCall(kt_host_pose_update(result, resultRt, Rprev.data(), tprev.data(), Rcurr.data(), tcurr.data()));
-            }
+        const float *vc[LEVELS], *nc[LEVELS], *vp[LEVELS], *np[LEVELS];
+        for (int l = 0; l < LEVELS; ++l) {
+            vc[l] = vmaps_curr_[l].ptr(); nc[l] = nmaps_curr_[l].ptr();
+            vp[l] = vmaps_g_prev_[l].ptr(); np[l] = nmaps_g_prev_[l].ptr();
         }
+        float A_last[36], residual[2];
+        ktSafeCall(kt_icp_track(::kt::device::context(), vc, nc, vp, np, vmaps_curr_[0].cols(), vmaps_curr_[0].rows() / 3, kt::abi(intr), kt::abi(kt::dev(Rprev)),
+                                kt::abi(kt::dev(tprev)), icp_iterations_, distThres_, angleThres_, reinterpret_cast<kt_mat33*>(Rcurr.data()), tcurr.data(),
+                                A_last, residual));
+        for (int i = 0; i < 36; ++i) lastA[i] = (double)A_last[i];
         trans = tcurr;
         rot = Rcurr;
         return CloudSlice::ICP;
@@ -70,6 +65,5 @@ class ICPOdometry : public OdometryProvider {
     std::vector<DeviceArray2D<float> >& nmaps_curr_;
     Intr& intr;
     double lastA[36];
-    DeviceArray<JtJJtrSE3> sumDataSE3, outDataSE3;
     float distThres_, angleThres_;
 };

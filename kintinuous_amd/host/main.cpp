@@ -3,6 +3,7 @@
 // MainController.cpp:73-170) that ends at the CloudSlices and the .poses file.  Extra options: -n <N>, -w/-h, -o <prefix>,
 // -ops (compose every frame from the internal.h operators instead of the device-resident tracker), -pcd (run the CloudSliceProcessor thread
 // behind the tracker and save <prefix>.pcd the way CloudSliceProcessor::save does), -ppm (write the model views).
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -72,11 +73,30 @@ static void writeViews(KintinuousTracker* fe, const std::string& prefix)
     std::fclose(f);
 }
 
-// -rank R -world W -comm <file>: one process per GPU, each on its own log; after the last frame the ranks exchange their most recent
-// dense poses with the path's single collective (kt_pose_gather: one RCCL all-gather over xGMI).  Rank 0 writes the 128-byte RCCL id
-// to <file> (atomically, via rename); the other ranks wait for it.
-static bool gatherPoses(KintinuousTracker* fe, int rank, int world, const std::string& idFile)
+// -rank R -world W -comm <file> [-gk K]: one process per GPU, each on its own log; after the last frame the ranks exchange their K most
+// recent dense poses (default 1: the final pose) with the path's single collective (kt_pose_gather: one RCCL all-gather over xGMI).
+// EVERY rank contributes the same K -- a collective with unequal counts hangs -- so K comes from the command line, not from the length
+// of the rank's own log, and a rank whose log gave fewer than K poses fails BEFORE it joins the communicator.  Rank 0 writes the
+// 128-byte RCCL id to <file> (atomically, via rename); the other ranks wait for it.  A watchdog ends the process if the rendezvous or
+// the gather does not complete (a rank that died leaves the others inside RCCL for ever): KT_COMM_TIMEOUT_S, default 120.
+static bool gatherPoses(KintinuousTracker* fe, int rank, int world, const std::string& idFile, int k)
 {
+    const int have = kt_tracker_num_poses(fe->handle());
+    if (k < 1 || have < k) {
+        std::fprintf(stderr, "rank %d: %d dense poses, the gather needs %d from every rank (-gk)\n", rank, have, k);
+        return false;
+    }
+    std::atomic<bool> done(false);
+    const char* to = std::getenv("KT_COMM_TIMEOUT_S");
+    const int timeout_s = to ? std::atoi(to) : 120;
+    std::thread watchdog([&done, timeout_s, rank]() {
+        for (int waited = 0; waited < timeout_s * 10 && !done; ++waited) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        if (!done) {
+            std::fprintf(stderr, "rank %d: pose gather did not complete within %d s (another rank missing?)\n", rank, timeout_s);
+            std::_Exit(3);
+        }
+    });
+    struct Join { std::atomic<bool>& d; std::thread& t; ~Join() { d = true; t.join(); } } join{done, watchdog};
     unsigned char id[KT_COMM_ID_BYTES];
     if (rank == 0) {
         ktSafeCall(kt_comm_unique_id(id));
@@ -84,20 +104,18 @@ static bool gatherPoses(KintinuousTracker* fe, int rank, int world, const std::s
         if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0) return false;
         if (std::rename((idFile + ".tmp").c_str(), idFile.c_str()) != 0) return false;
     } else {
-        for (int tries = 0;; ++tries) {
+        for (;;) {   // (bounded by the watchdog)
             FILE* f = std::fopen(idFile.c_str(), "rb");
             if (f) {
                 const size_t got = std::fread(id, 1, sizeof(id), f);
                 std::fclose(f);
                 if (got == sizeof(id)) break;
             }
-            if (tries > 6000) return false;   // 60 s
             std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
     }
     kt_comm* comm = 0;
     ktSafeCall(kt_comm_init(kt::device::context(), rank, world, id, &comm));
-    const int k = std::min(32, kt_tracker_num_poses(fe->handle()));
     std::vector<float> all((size_t)world * k * 16);
     ktSafeCall(kt_pose_gather(comm, fe->handle(), k, all.data()));
     ktSafeCall(kt_comm_destroy(comm));
@@ -114,7 +132,7 @@ int main(int argc, char** argv)
     const ConfigArgs& args = ConfigArgs::get(argc, argv);
     if (args.help || args.logFile.empty()) { ConfigArgs::usage(argv[0]); return args.help ? 0 : 1; }
     bool ops = false, pcd = false, pcdraw = false, ppm = false;
-    int rank = 0, world = 0;
+    int rank = 0, world = 0, gatherCount = 1;
     std::string commFile;
     for (int i = 1; i < argc; ++i) {
         ops = ops || std::string(argv[i]) == "-ops";
@@ -124,6 +142,7 @@ int main(int argc, char** argv)
         if (i + 1 < argc && std::string(argv[i]) == "-rank") rank = std::atoi(argv[i + 1]);
         if (i + 1 < argc && std::string(argv[i]) == "-world") world = std::atoi(argv[i + 1]);
         if (i + 1 < argc && std::string(argv[i]) == "-comm") commFile = argv[i + 1];
+        if (i + 1 < argc && std::string(argv[i]) == "-gk") gatherCount = std::atoi(argv[i + 1]);
     }
 
     Resolution::get(args.width, args.height);
@@ -167,7 +186,7 @@ int main(int argc, char** argv)
     std::printf("frames %d  slices %zu  points %zu  last camera %.6f %.6f %.6f  %.1f frames/s (incl. file I/O and uploads)  path %s\n", frames,
                 fe->getCloudSlices().size(), points, cam(0), cam(1), cam(2), frames / sec, ops ? "operators" : "device-resident");
     if (world > 0 && !ops) {
-        if (commFile.empty() || !gatherPoses(fe, rank, world, commFile)) { std::fprintf(stderr, "pose gather failed (-comm <file> shared by all ranks)\n"); return 1; }
+        if (commFile.empty() || !gatherPoses(fe, rank, world, commFile, gatherCount)) { std::fprintf(stderr, "pose gather failed (-comm <file> shared by all ranks)\n"); return 1; }
     }
     return 0;
 }

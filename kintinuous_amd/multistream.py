@@ -1,6 +1,8 @@
 """Multi-GPU layout of the hot path: independent RGB-D streams, one tracker per GPU (rank), no data-path collective;
-the only exchange is ONE gather of per-stream poses.  The helpers here are backend-agnostic
-(torch.distributed with nccl == RCCL on the GPU box, gloo in the CPU tests)."""
+the only exchange is ONE gather of per-stream poses through the C-ABI's communicator (kt_comm over RCCL).
+bench.py's N-rank protocol lives here (timed_region) so that the CPU test drives the very same control flow with a gloo stand-in for
+the communicator (tests/test_multigpu_gloo.py); rank 0's communicator id and the max-over-ranks time travel through a key-value
+store, so a job holds exactly one communicator."""
 from __future__ import annotations
 
 
@@ -18,36 +20,90 @@ def pingpong(i: int, n: int) -> int:
     return j if j < n else period - j
 
 
-def gather_poses(dist, local_poses, world: int):
-    """All ranks contribute a [k, 16] float32 tensor of row-major 4x4 dense poses ([R | currentGlobalCamera],
-    KintinuousTracker.h:151-169); returns the [world, k, 16] tensor on every rank (one collective)."""
-    import torch
-    assert local_poses.dtype == torch.float32 and local_poses.dim() == 2 and local_poses.shape[1] == 16
-    out = torch.empty((world,) + tuple(local_poses.shape), dtype=torch.float32, device=local_poses.device)
-    dist.all_gather_into_tensor(out.view(-1), local_poses.contiguous().view(-1))
-    return out
+class LocalExchange:
+    """Out-of-band exchange between ranks, one-rank case."""
+
+    def share(self, key: str, data: bytes) -> bytes:
+        return data
+
+    def max(self, key: str, value: float) -> float:
+        return value
 
 
-def make_comm(dist, ctx, rank: int, world: int):
-    """The C-ABI communicator of the pose gather (kt_comm_init over RCCL): rank 0's id travels through torch.distributed's object
-    broadcast when there is more than one rank."""
+class StoreExchange:
+    """Out-of-band exchange of a few small values between the ranks of one job through a torch.distributed TCPStore -- a key-value
+    server, NOT a process group: the job's only communicator is the C-ABI's (kt_comm over RCCL), which needs rank 0's 128-byte id
+    delivered before it exists.  Under torch.distributed.run the launcher's own store (MASTER_ADDR:MASTER_PORT) is used as a client;
+    launched by hand, rank 0 hosts one."""
+
+    def __init__(self, rank: int, world: int, addr: str = None, port: int = None, timeout_s: float = 300.0):
+        import datetime
+        import os
+        from torch.distributed import TCPStore
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(port or os.environ.get("MASTER_PORT", "29533"))
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+        self.rank, self.world = rank, world
+        self.store = TCPStore(addr, port, None if agent else world, is_master=(rank == 0 and not agent), wait_for_workers=False,
+                              timeout=datetime.timedelta(seconds=timeout_s))
+        self.prefix = "kt/%s/" % os.environ.get("TORCHELASTIC_RUN_ID", "job")
+
+    def share(self, key: str, data: bytes) -> bytes:
+        """rank 0's bytes on every rank"""
+        k = self.prefix + key
+        if self.rank == 0:
+            self.store.set(k, data)
+            return data
+        return bytes(self.store.get(k))   # blocks until rank 0 has set it (or the store's timeout)
+
+    def max(self, key: str, value: float) -> float:
+        """the largest of the ranks' values, on every rank"""
+        self.store.set("%s%s/%d" % (self.prefix, key, self.rank), repr(float(value)))
+        return max(float(bytes(self.store.get("%s%s/%d" % (self.prefix, key, r))).decode()) for r in range(self.world))
+
+
+def make_exchange(rank: int, world: int):
+    return StoreExchange(rank, world) if world > 1 else LocalExchange()
+
+
+def make_comm(exchange, ctx, rank: int, world: int):
+    """The C-ABI communicator of the pose gather (kt_comm_init over RCCL): rank 0's id travels through `exchange`."""
     from . import abi
-
-    def share(ident: bytes) -> bytes:
-        if dist is None or world <= 1:
-            return ident
-        box = [ident]
-        dist.broadcast_object_list(box, src=0)
-        return box[0]
-
-    return abi.Comm(ctx, rank, world, share)
+    return abi.Comm(ctx, rank, world, lambda ident: exchange.share("comm_id", ident))
 
 
-def aggregate_fps(dist, steps: int, elapsed_s: float, world: int, device=None) -> float:
-    """Whole-job frames/s: all ranks' frames over the slowest rank's time (max over ranks)."""
-    if dist is None or world <= 1:
-        return world * steps / elapsed_s
-    import torch
-    t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return world * steps / float(t.item())
+def timed_region(comm, exchange, world: int, sync, step, steps: int, warmup: int, gather=None, prepare=None):
+    """bench.py's measurement protocol for one rank of `world` (one independent stream per rank, weak scaling): `warmup` untimed steps;
+    barrier + device sync; EXACTLY `steps` timed steps; the path's single collective (`gather()`, the pose all-gather) inside the
+    region; device sync + barrier; the slowest rank's time defines the rate.  `prepare()` runs between the warm-up and the first
+    barrier (arming profilers, resetting statistics).  `comm` has abi.Comm's interface (barrier / gather_poses
+    / close; None: no collective), `exchange` carries the max over ranks.  Returns {elapsed (max over ranks), local_elapsed, marks,
+    gathered, fps}."""
+    import time
+    for i in range(warmup):
+        step(i)
+    sync()
+    if prepare is not None:
+        prepare()
+    if comm is not None and world > 1:
+        comm.barrier()
+    sync()
+    t0 = time.perf_counter()
+    marks = [t0]
+    for i in range(warmup, warmup + steps):
+        step(i)
+        marks.append(time.perf_counter())
+    gathered = gather() if (gather is not None and comm is not None) else None
+    sync()
+    if comm is not None and world > 1:
+        comm.barrier()
+    local = time.perf_counter() - t0
+    slowest = exchange.max("elapsed", local)
+    return {"elapsed": slowest, "local_elapsed": local, "marks": marks, "gathered": gathered, "fps": world * steps / slowest}
+
+
+def check_gather(gathered, rank: int, mine) -> None:
+    """every rank finds its own poses at its own place in the gathered array"""
+    import numpy as np
+    if not np.array_equal(np.asarray(gathered[rank]), np.asarray(mine)):
+        raise AssertionError("the gathered poses are not this rank's")

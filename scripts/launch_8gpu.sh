@@ -17,7 +17,12 @@ for r in $(seq 0 $((N - 1))); do
   $R/kintinuous_amd/host/bin/kintinuous_hip -l $log -g $r -rank $r -world $N -comm $comm -o /tmp/kt_stream_$r &
   pids+=($!)
 done
+# the ranks meet in ONE collective at the end: if any of them fails first, the others would wait for it inside RCCL -- end them
 rc=0
-for p in "${pids[@]}"; do wait $p || rc=1; done
+left=${#pids[@]}
+while [ $left -gt 0 ]; do
+  if wait -n; then :; else rc=1; kill "${pids[@]}" 2>/dev/null || true; fi
+  left=$((left - 1))
+done
 rm -f $comm
 exit $rc

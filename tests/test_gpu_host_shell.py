@@ -257,8 +257,10 @@ def test_backend_consumer_runs_against_the_shell(ctx, tmp_path):
     assert len(lines) == nslices
     for i, l in enumerate(lines):
         n, dim = trk.slice_info(i)
-        assert int(l[3]) == dim and int(l[5]) == n and int(l[9]) == trk.slice_pr_id(i)
-        # processedCloud = kt_slice_process(cloud): exactly what the Python binding computes from the same slice
+        assert int(l[3]) == dim and int(l[9]) == trk.slice_pr_id(i)
+        # processedCloud = kt_slice_process(cloud): exactly what the Python binding computes from the same slice; and, like the
+        # reference (CloudSliceProcessor.cpp:112-140), the processor leaves the culled, voxel-gridded points in slice->cloud itself
         assert int(l[7]) == len(abi.slice_process(ctx, trk.slice(i)[0], 2, 7.0 / 96))
+        assert int(l[5]) == int(l[7]) <= n
         assert (int(l[7]) > 0) == (n > 0) or int(l[7]) == 0
     trk.close()

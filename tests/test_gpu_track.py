@@ -127,3 +127,40 @@ def test_conversion_semantics(ctx, oracle_mod):
     ctx.bilateral_filter(ctx.upload(d), g0, 64, 64)
     ctx.pyr_down(g0, 64, 64, g1)
     assert np.array_equal(ref, ctx.download(g1, np.uint16, ref.shape))
+
+
+@pytest.mark.parametrize("schedule", [(10, 5, 4, 0), (0, 10, 5, 0), (2, 0, 0, 3), (0, 0, 0, 0)])
+def test_icp_track_matches_the_stepwise_loop(ctx, oracle_mod, small_scene, schedule):
+    """kt_icp_track (SURVEY 8(b) export list: the fused multi-iteration odometry, device-side solve, pose in / pose out) against the
+    loop the reference runs on the host -- kt_icp_step, kt_host_ldlt_solve6, kt_host_pose_update per iteration (ICPOdometry.cpp:88-180):
+    the final pose, the last iteration's A and residual must be identical bit for bit."""
+    from kintinuous_amd import abi
+    from kintinuous_amd.abi import Intr
+    cam, frames, traj = small_scene
+    t0 = np.array([3, 3, 3], np.float32)
+    Rprev = random_rotation(np.random.default_rng(5), 0.02)
+    cur, prev = [], []
+    for l in range(4):
+        vc, nc = _frame_maps(oracle_mod, cam, frames[1][0], l)
+        v0, n0 = _frame_maps(oracle_mod, cam, frames[0][0], l)
+        vg, ng = oracle_mod.transform_maps(v0, n0, Rprev, t0)
+        cur.append((ctx.upload(vc), ctx.upload(nc)))
+        prev.append((ctx.upload(vg), ctx.upload(ng)))
+    dist, ang = 0.10, float(np.float32(np.sin(np.float32(20.0) * np.float32(3.14159254) / np.float32(180.0))))
+    gi = Intr(cam.fx, cam.fy, cam.cx, cam.cy)
+    Rc, tc, A, r = ctx.icp_track([c[0] for c in cur], [c[1] for c in cur], [p[0] for p in prev], [p[1] for p in prev], cam.cols, cam.rows, gi, Rprev, t0,
+                                 schedule, dist, ang)
+    # the same iterations one at a time, with the solve on the host
+    R, t = Rprev.copy(), t0.copy()
+    Rprev_inv = abi.host_mat33_inverse(Rprev)
+    rt = np.eye(4)
+    lastA, lastr = np.zeros((6, 6), np.float32), np.zeros(2, np.float32)
+    for l in (3, 2, 1, 0):
+        for _ in range(schedule[l]):
+            lastA, b, lastr = ctx.icp_step(R, t, cur[l][0], cur[l][1], Rprev_inv, t0, gi.level(l), prev[l][0], prev[l][1], cam.cols >> l, cam.rows >> l, dist, ang)
+            x = abi.host_ldlt_solve6(lastA.astype(np.float64), b.astype(np.float64))
+            rt, R, t = abi.host_pose_update(x, rt, Rprev, t0)
+    assert np.array_equal(Rc.view(np.uint32), np.asarray(R, np.float32).view(np.uint32)) and np.array_equal(tc.view(np.uint32), np.asarray(t, np.float32).view(np.uint32))
+    assert np.array_equal(A.view(np.uint32), lastA.view(np.uint32)) and np.array_equal(r.view(np.uint32), lastr.view(np.uint32))
+    if sum(schedule):
+        assert np.abs(tc - t0).max() > 1e-5 and r[1] > 1000    # it did track something

@@ -445,3 +445,53 @@ def test_slice_downloads_survive_reset_and_destroy(ctx):
     t2, n2, pts2 = run(True)
     assert n2 == n and all(_same_points(a, b) for a, b in zip(pts, pts2))
     t2.close()
+
+
+@pytest.mark.parametrize("mode", ["icp", "rgbd_icp"])
+def test_planned_voxel_pass_is_transparent(ctx, oracle_mod, monkeypatch, mode):
+    """Planning ahead (csrc/kt_volume.hip): with read-ahead the voxel kernel's task plan is made for a PREDICTED pose while the odometry
+    iterates; the set-up kernel accepts it when the pose lands inside the plan's margins and parks the frame for the in-stream pre-pass
+    otherwise.  A shifting sequence through (a) plans that hit, (b) plans forced to miss (margins scaled to 0) and (c) no planning must
+    give the same poses, volumes, colour volumes and slices -- and all three the oracle's."""
+    from kintinuous_amd import abi, synth
+    from oracle import oracle
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("wall")
+    traj = synth.crabwalk_trajectory(420)
+    idx = list(range(0, 40, 2)) + list(range(40, 20, -2))
+    frames = [synth.render(scene, cam, *traj[i]) for i in idx]
+    frames = [(np.ascontiguousarray(d, np.uint16), np.ascontiguousarray(rgb, np.uint8)) for d, rgb in frames]
+    dev = [(ctx.upload(d), ctx.upload(rgb)) for d, rgb in frames]
+    g, o = _cfgs(cam, 96, volume_size=7.0, voxel_shift=3, use_rgbd_icp=int(mode == "rgbd_icp"))
+
+    def run(env):
+        for k in ("KT_NO_PLAN", "KT_PLAN_MARGIN_SCALE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        trk = abi.Tracker(ctx, g)
+        for k in range(len(dev)):
+            if k + 1 < len(dev):
+                trk.prefetch_frame(*dev[k + 1])
+            trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+        out = dict(poses=[trk.dense_pose(i)[1].copy() for i in range(trk.num_poses())], vol=trk.volume().copy(), col=trk.color_volume().copy(),
+                   slices=[trk.slice(i) for i in range(trk.num_slices())], stats=trk.plan_stats(), wrap=[int(v) for v in trk.voxel_wrap()])
+        trk.close()
+        return out
+
+    hit, miss, off = run({}), run({"KT_PLAN_MARGIN_SCALE": "0"}), run({"KT_NO_PLAN": "1"})
+    assert hit["stats"][0] >= len(dev) - 8 and hit["stats"][1] <= 2, hit["stats"]      # (shift frames and the first two are not planned)
+    assert miss["stats"][0] == 0 and miss["stats"][1] >= len(dev) - 8, miss["stats"]
+    assert off["stats"] == (0, 0)
+    assert len(hit["slices"]) >= 3
+    for other in (miss, off):
+        assert len(other["poses"]) == len(hit["poses"]) and all(np.array_equal(a, b) for a, b in zip(other["poses"], hit["poses"]))
+        assert np.array_equal(other["vol"], hit["vol"]) and np.array_equal(other["col"], hit["col"]) and other["wrap"] == hit["wrap"]
+        assert len(other["slices"]) == len(hit["slices"])
+        for (p, d1), (q, d2) in zip(other["slices"], hit["slices"]):
+            assert d1 == d2 and _same_points(p, q)
+    otr = oracle.OracleTracker(o)
+    for k, (d, rgb) in enumerate(frames):
+        otr.process_frame(d, rgb, 33333 * k)
+    assert np.array_equal(hit["vol"], otr.volume()) and np.array_equal(hit["col"], otr.color_volume())
+    otr.close()
