@@ -225,8 +225,8 @@ def main():
     lane_eff = round(sum(u for u, _ in Lok) / max(1, sum(l for _, l in Lok)), 4) if Lok else None
     P = cam.cols * cam.rows
     # algorithmic bytes of the tsdf23 launch (DESIGN.md "integrate"): 12 B per updated voxel (2 B tsdf + 4 B colour/weight,
-    # read and written) + the per-pixel record gathered by the voxels (16 B, counted once per pixel)
-    bytes_tsdf23 = 12.0 * U + 16.0 * P
+    # read and written) + the per-pixel record gathered by the voxels (12 B, counted once per pixel)
+    bytes_tsdf23 = 12.0 * U + 12.0 * P
     if tsdf23_n == 0 or tsdf23_ms <= 0:   # very short runs: no timed frame carried the event pair -> the untimed stage pass's launches
         tsdf23_ms, tsdf23_n = stage_all["tsdf23"][0], 0
     achieved = bytes_tsdf23 / (tsdf23_ms * 1e-3) / 1e9 if tsdf23_ms > 0 else 0.0
@@ -346,7 +346,7 @@ def roofline_stress(ctx, abi, synth):
             Us.append(trk.last_counts()[0])
     trk.close()
     U, P = float(np.mean(Us)), cam.cols * cam.rows
-    b = 12.0 * U + 16.0 * P
+    b = 12.0 * U + 12.0 * P
     achieved = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {"workload": "farwall768: 1280x960 synthetic far-wall sequence, static mode, 768^3 TSDF (BASELINE.json configs[4])", "kernel": "kt_tsdf23_kernel",
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": committed_traffic("farwall768"),

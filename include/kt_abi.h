@@ -322,6 +322,21 @@ int kt_debug_rcp_check(kt_ctx* ctx, unsigned int* mismatches_host);
  * out_host needs room for n points; *n_out receives the count. */
 int kt_slice_process(kt_ctx* ctx, const kt_point_xyzrgb* points_host, size_t n, int weight_cull, float leaf, int k,
                      kt_point_xyzrgbnormal* out_host, size_t* n_out);
+/* The same stage on device-resident points ("slab points are already on device"), asynchronous on the workspace's own
+ * stream (or `hip_stream`), with every intermediate -- the input count, the leaf grid, the output count -- kept on the device:
+ *   kt_slice_ws_create      buffers for up to `capacity` input points, allocated once;
+ *   kt_slice_process_device points_dev[0 .. *n_dev), n_dev a DEVICE word (e.g. the extraction kernel's counter), n_max a host-known
+ *                           upper bound of it; enqueues the stage and returns;
+ *   kt_slice_ws_count       waits for the stream; *n_out = number of output points, which are kt_slice_ws_output(ws)[0 .. *n_out)
+ *                           (device memory, valid until the next call on the workspace).
+ * kt_tracker_enable_slice_stage puts it behind the tracker's own shift path. */
+typedef struct kt_slice_ws kt_slice_ws;
+int kt_slice_ws_create(kt_ctx* ctx, size_t capacity, void* hip_stream, kt_slice_ws** out);
+int kt_slice_ws_destroy(kt_slice_ws* ws);
+void* kt_slice_ws_stream(kt_slice_ws* ws);
+int kt_slice_process_device(kt_slice_ws* ws, const kt_point_xyzrgb* points_dev, const unsigned int* n_dev, size_t n_max, int weight_cull, float leaf, int k);
+int kt_slice_ws_count(kt_slice_ws* ws, size_t* n_out);
+const kt_point_xyzrgbnormal* kt_slice_ws_output(kt_slice_ws* ws);
 
 /* CloudSliceProcessor::save (backend/CloudSliceProcessor.cpp:180-231), host code, once per run:
  * kt_host_voxel_grid_normal = the pcl::VoxelGrid<pcl::PointXYZRGBNormal> at `leaf` it applies to the concatenated processed clouds when
@@ -330,6 +345,14 @@ int kt_slice_process(kt_ctx* ctx, const kt_point_xyzrgb* points_host, size_t n, 
  * FIELDS x y z rgb normal_x normal_y normal_z curvature, 32 bytes per point. */
 int kt_host_voxel_grid_normal(const kt_point_xyzrgbnormal* in, size_t n, float leaf, kt_point_xyzrgbnormal* out, size_t* n_out);
 int kt_host_save_pcd(const char* path, const kt_point_xyzrgbnormal* points, size_t n);
+
+/* The slice stage behind the tracker's own shift path: from this call on every extracted slab also goes through
+ * kt_slice_process_device(weight_cull, leaf = the largest voxel edge, k) on a stream of its own (the slab never leaves the device in
+ * between), and its CloudSlice::processedCloud travels with the slice.  kt_tracker_slice_processed_info: the number of processed points
+ * of slice i, -1 for a slice extracted while the stage was off. */
+int kt_tracker_enable_slice_stage(kt_tracker* t, int on, int weight_cull, int k);
+int kt_tracker_slice_processed_info(kt_tracker* t, int i, long long* n_points);
+int kt_tracker_slice_processed(kt_tracker* t, int i, kt_point_xyzrgbnormal* out);
 
 /* Place-recognition tap (KintinuousTracker::addToPlaceRecognition, KintinuousTracker.cpp:917-958): the frames sampled for the
  * loop-closure backend, in order.  The library keeps the sample's metadata (PlaceRecognitionInput::utime / trans / rotation and the

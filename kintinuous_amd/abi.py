@@ -132,6 +132,9 @@ _PROTOS = {
     "kt_tracker_debug_counts": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_debug_state": (_i, [_vp, _pf]),
     "kt_tracker_plan_stats": (_i, [_vp, C.POINTER(C.c_longlong)]),
+    "kt_tracker_enable_slice_stage": (_i, [_vp, _i, _i, _i]),
+    "kt_tracker_slice_processed_info": (_i, [_vp, _i, C.POINTER(C.c_longlong)]),
+    "kt_tracker_slice_processed": (_i, [_vp, _i, _vp]),
     "kt_debug_stream": (_i, [_vp, _vp, _sz, _i, _i]),
     "kt_debug_stream_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
     "kt_debug_valu_rates": (_i, [_vp, _i, _i, _i, _pd]),
@@ -143,6 +146,12 @@ _PROTOS = {
     "kt_tracker_slice_pr_id": (_i, [_vp, _i, C.POINTER(C.c_int)]),
     "kt_host_place_recognition_movement": (_f, [_pf, _pf, _pf, _pf]),
     "kt_slice_process": (_i, [_vp, _vp, _sz, _i, _f, _i, _vp, C.POINTER(_sz)]),
+    "kt_slice_ws_create": (_i, [_vp, _sz, _vp, C.POINTER(_vp)]),
+    "kt_slice_ws_destroy": (_i, [_vp]),
+    "kt_slice_ws_stream": (_vp, [_vp]),
+    "kt_slice_process_device": (_i, [_vp, _vp, _vp, _sz, _i, _f, _i]),
+    "kt_slice_ws_count": (_i, [_vp, C.POINTER(_sz)]),
+    "kt_slice_ws_output": (_vp, [_vp]),
     "kt_host_voxel_grid_normal": (_i, [_vp, _sz, _f, _vp, C.POINTER(_sz)]),
     "kt_host_save_pcd": (_i, [C.c_char_p, _vp, _sz]),
     "kt_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
@@ -410,6 +419,20 @@ class Tracker:
         o = (C.c_double * 2)()
         _chk(lib().kt_tracker_host_times(self.h, o, 1 if reset else 0))
         return float(o[0]), float(o[1])
+
+    def enable_slice_stage(self, on: bool, weight_cull: int = 8, k: int = 20) -> None:
+        """CloudSliceProcessor's per-slice stage on the device behind every extraction from now on (kt_tracker_enable_slice_stage)."""
+        _chk(lib().kt_tracker_enable_slice_stage(self.h, int(on), int(weight_cull), int(k)))
+
+    def slice_processed(self, i: int):
+        """processedCloud of slice i (NPOINT_DTYPE records), or None for a slice extracted while the stage was off"""
+        n = C.c_longlong(0)
+        _chk(lib().kt_tracker_slice_processed_info(self.h, i, C.byref(n)))
+        if n.value < 0:
+            return None
+        out = np.zeros(max(int(n.value), 1), NPOINT_DTYPE)
+        _chk(lib().kt_tracker_slice_processed(self.h, i, out.ctypes.data_as(C.c_void_p)))
+        return out[: int(n.value)]
 
     def plan_stats(self) -> Tuple[int, int]:
         """(frames fused from a task plan made ahead of them, frames whose pose fell outside their plan's margins)"""

@@ -34,6 +34,7 @@ struct kt_ctx {
     float* bil_lut;                // bilateral tap weights [27][396] (kt_image.hip), built on first use
     unsigned int red_epoch;  // tag of the last reduction launch (kt_track.hip hand-off granules)
     void* track_state;       // device kt_track_state of kt_icp_track (kt_track.hip), created on first use
+    void* slice_ws;          // kt_slice_ws of the host-array kt_slice_process (kt_slice.hip), created on first use
 };
 
 void kt_set_error(const char* fmt, ...);

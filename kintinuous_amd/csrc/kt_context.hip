@@ -66,6 +66,7 @@ int kt_ctx_destroy(kt_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     kt_integrate_scratch_free(c);
+    if (c->slice_ws) (void)kt_slice_ws_destroy((kt_slice_ws*)c->slice_ws);
     (void)hipFree(c->bil_lut);
     (void)hipFree(c->track_state);
     (void)hipFree(c->red_partials);

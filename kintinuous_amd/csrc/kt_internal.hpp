@@ -15,7 +15,7 @@ struct kt_frame_params {
 // Per-pixel record of integrate, built once per frame by kt_integrate_prepare: everything tsdf23 gathers per voxel from the frame
 // (scaled depth with the no-colour sign flag, the colour weight derived from |n_z|, rgb, normal-valid) in ONE 16-byte gather.
 #ifndef KT_REC_BYTES
-#define KT_REC_BYTES 16   // 12: no padding word -- a quarter fewer cache lines under the gathers, one more VALU for the address (A/B)
+#define KT_REC_BYTES 12   // 16 (a padding word, one aligned 16-byte gather): +27 % fetched bytes on the 768^3 case, +8 % on the orbit, +2.5 % / 0 % time (profiles/r03_tsdf23_pmc_variants_call4.log)
 #endif
 #if KT_REC_BYTES == 16
 struct __attribute__((aligned(16))) kt_pixrec {
@@ -111,6 +111,10 @@ int kt_joint_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_cur
 int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corres_img, const float* cloud, float fx, float fy,
                        const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows, int mode,
                        const kt_level_k* next_k);
+
+// kt_slice.hip: a device array of `*n_dev` items (clamped to cap) and its count into (pinned) destination memory, on `st`
+int kt_copy_counted(hipStream_t st, const void* src, void* dst, const unsigned int* n_dev, unsigned int cap, int item_bytes, unsigned int* count_out);
+const unsigned int* kt_slice_ws_leaves_dev(kt_slice_ws* w);   // device word: output count of the workspace's last call
 
 // optional HIP events recorded around the tsdf23 voxel kernel (set by the tracker when profiling)
 struct kt_event_hook { hipEvent_t ev[2]; bool on; };

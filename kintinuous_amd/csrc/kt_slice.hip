@@ -8,46 +8,50 @@
 // Two orders PCL leaves to its implementation are fixed (as in oracle/kt_oracle_kernels.c): the points of a leaf are summed in their
 // original order (a stable sort instead of std::sort), neighbours are ordered by (squared distance, index).
 //
-// Shape on the GPU: cull = flags + scan + scatter; leaf keys; ONE stable radix sort of (key, index) (rocPRIM through hipCUB: the sort is
-// library plumbing, everything arithmetic is written here); one thread per leaf walks its short run in order; after the grid every
-// point owns a distinct leaf cell, so the k nearest neighbours of a point are found by binary-searching the sorted leaf keys of the
-// (2r + 1)^3 cells around its own cell -- all points within r leaf sizes are in there -- with r growing until the k-th neighbour is
-// provably the k-th nearest (distance <= r * leaf), then covariance, smallest eigenvector and curvature in the same thread.
+// Shape on the GPU -- a device-resident stage (kt_slice_process_device): the points stay where the extraction kernel left them, every
+// intermediate (the number of points, the bounding box, the leaf grid, the number of leaves) lives in device memory and is read by the
+// next kernel from there, so the whole stage is ONE uninterrupted run of launches on the workspace's own stream; the host learns the
+// output count from a pinned word behind the last launch.  Steps: bounding box of the points that pass the weight cull; leaf keys (a
+// culled point gets the key 0xffffffff and sorts to the end: the cull needs no compaction pass); ONE stable radix sort of (key, index)
+// pairs and one scan of the run heads (rocPRIM's device-wide primitives, called directly: library plumbing, everything arithmetic is
+// written here); one thread per leaf walks its short run in order; after the grid every point owns a distinct leaf cell, so the k
+// nearest neighbours of a point are found by binary-searching the sorted leaf keys of the (2r + 1)^3 cells around its own cell -- all
+// points within r leaf sizes are in there -- with r growing until the k-th neighbour is provably the k-th nearest (distance <= r *
+// leaf), then covariance, smallest eigenvector and curvature in the same thread.  The workspace (kt_slice_ws) is allocated once for a
+// capacity and reused: no allocation, no copy-back and no synchronisation inside a call.
 #include "kt_internal.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #define KT_SLICE_K_MAX 64
 
 namespace {
 
 struct BBox { float mn[3], mx[3]; };
+struct Grid { int min_b[3], div_b[3]; float inv_leaf, leaf; };
+// what the kernels of one call hand to each other, in device memory
+struct Params { Grid g; int gridded; unsigned int leaves; };
+#define KT_SLICE_CULLED 0xffffffffu   // key of a point that fails the weight cull (or lies past the input's end): sorts behind every leaf
+#define KT_SLICE_BOXES 256
 
-__global__ __launch_bounds__(256) void slice_cull_flags(const kt_point_xyzrgb* __restrict__ in, int n, int weight_cull, unsigned int* __restrict__ keep)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) keep[i] = (!(weight_cull > 0) || (int)in[i].a >= weight_cull) ? 1u : 0u;
-}
+__device__ __forceinline__ bool slice_kept(const kt_point_xyzrgb& p, int weight_cull) { return !(weight_cull > 0) || (int)p.a >= weight_cull; }
 
-__global__ __launch_bounds__(256) void slice_cull_scatter(const kt_point_xyzrgb* __restrict__ in, int n, const unsigned int* __restrict__ keep,
-                                                          const unsigned int* __restrict__ pos, kt_point_xyzrgb* __restrict__ out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && keep[i]) out[pos[i]] = in[i];
-}
-
-// getMinMax3D: per-workgroup partial boxes, folded by one more launch of the same kernel over the partials
-__global__ __launch_bounds__(256) void slice_bbox(const float* __restrict__ xyz, int stride_floats, int n, BBox* __restrict__ partial)
+// getMinMax3D over the points that pass the cull (CloudSliceProcessor.cpp:99-117 runs the cull first): per-workgroup partial boxes
+__global__ __launch_bounds__(256) void slice_bbox(const kt_point_xyzrgb* __restrict__ pts, const unsigned int* __restrict__ n_dev, int n_max, int weight_cull,
+                                                  BBox* __restrict__ partial)
 {
     __shared__ BBox sh[4];
+    const int n = (int)min(*n_dev, (unsigned int)n_max);   // (an extraction counts past its buffer's capacity)
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const kt_point_xyzrgb p = pts[i];
+        if (!slice_kept(p, weight_cull)) continue;
+        const float v[3] = {p.x, p.y, p.z};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float v = xyz[(size_t)i * stride_floats + a], w = xyz[(size_t)i * stride_floats + (stride_floats == 6 ? 3 : 0) + a];
-            mn[a] = fminf(mn[a], v);
-            mx[a] = fmaxf(mx[a], stride_floats == 6 ? w : v);
-        }
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], v[a]); mx[a] = fmaxf(mx[a], v[a]); }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
@@ -64,49 +68,83 @@ __global__ __launch_bounds__(256) void slice_bbox(const float* __restrict__ xyz,
     }
 }
 
-struct Grid { int min_b[3], div_b[3]; float inv_leaf, leaf; };
-
-__global__ __launch_bounds__(256) void slice_keys(const kt_point_xyzrgb* __restrict__ pts, int m, Grid g, unsigned int* __restrict__ keys,
-                                                  unsigned int* __restrict__ src)
+// one wave: fold the partial boxes, derive the leaf grid (voxel_grid.hpp applyFilter: min_b / max_b / div_b, the int32 overflow check)
+__global__ __launch_bounds__(64) void slice_grid(const BBox* __restrict__ partial, float leaf, Params* __restrict__ prm)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    // voxel_grid.hpp: ijk = static_cast<int>(floor(p * inverse_leaf_size) - static_cast<float>(min_b)); idx = ijk . divb_mul
-    const int i0 = (int)(__builtin_floorf(pts[i].x * g.inv_leaf) - (float)g.min_b[0]);
-    const int i1 = (int)(__builtin_floorf(pts[i].y * g.inv_leaf) - (float)g.min_b[1]);
-    const int i2 = (int)(__builtin_floorf(pts[i].z * g.inv_leaf) - (float)g.min_b[2]);
-    keys[i] = (unsigned int)(i0 + i1 * g.div_b[0] + i2 * g.div_b[0] * g.div_b[1]);
-    src[i] = (unsigned int)i;
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = threadIdx.x; i < KT_SLICE_BOXES; i += 64)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], partial[i].mn[a]); mx[a] = fmaxf(mx[a], partial[i].mx[a]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64)); }
+    if (threadIdx.x != 0) return;
+    Params p;
+    p.g.leaf = leaf;
+    p.g.inv_leaf = 1.0f / leaf;
+    p.leaves = 0;
+    long long cells = 1;
+    for (int a = 0; a < 3; ++a) {
+        p.g.min_b[a] = (int)floorf(mn[a] * p.g.inv_leaf);
+        p.g.div_b[a] = (int)floorf(mx[a] * p.g.inv_leaf) - p.g.min_b[a] + 1;
+        // voxel_grid.hpp: dx = static_cast<int64_t>((max_p[0] - min_p[0]) * inverse_leaf_size_[0]) + 1, ...; dx * dy * dz > INT32_MAX
+        cells *= (long long)((mx[a] - mn[a]) * p.g.inv_leaf) + 1;
+    }
+    // "Leaf size is too small for the input dataset. Integer indices would overflow.": PCL passes the cloud through unfiltered
+    p.gridded = !(mn[0] <= mx[0]) || cells <= 2147483647LL;   // (no point kept: nothing to pass through either)
+    *prm = p;
 }
 
-__global__ __launch_bounds__(256) void slice_heads(const unsigned int* __restrict__ keys, int m, unsigned int* __restrict__ head)
+__global__ __launch_bounds__(256) void slice_keys(const kt_point_xyzrgb* __restrict__ pts, const unsigned int* __restrict__ n_dev, int n_max, int weight_cull,
+                                                  const Params* __restrict__ prm, unsigned int* __restrict__ keys, unsigned int* __restrict__ src)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < m) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    if (i >= n_max) return;
+    src[i] = (unsigned int)i;
+    if ((unsigned int)i >= *n_dev) { keys[i] = KT_SLICE_CULLED; return; }
+    const kt_point_xyzrgb p = pts[i];
+    if (!slice_kept(p, weight_cull)) { keys[i] = KT_SLICE_CULLED; return; }
+    const Grid g = prm->g;
+    if (!prm->gridded) { keys[i] = (unsigned int)i; return; }   // every point its own "leaf", in input order
+    // voxel_grid.hpp: ijk = static_cast<int>(floor(p * inverse_leaf_size) - static_cast<float>(min_b)); idx = ijk . divb_mul
+    const int i0 = (int)(__builtin_floorf(p.x * g.inv_leaf) - (float)g.min_b[0]);
+    const int i1 = (int)(__builtin_floorf(p.y * g.inv_leaf) - (float)g.min_b[1]);
+    const int i2 = (int)(__builtin_floorf(p.z * g.inv_leaf) - (float)g.min_b[2]);
+    keys[i] = (unsigned int)(i0 + i1 * g.div_b[0] + i2 * g.div_b[0] * g.div_b[1]);
+}
+
+__global__ __launch_bounds__(256) void slice_heads(const unsigned int* __restrict__ keys, int n_max, unsigned int* __restrict__ head)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_max) head[i] = (keys[i] != KT_SLICE_CULLED && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
 }
 
 // one thread per leaf (= per run of equal keys in the sorted order): the centroid of x, y, z and of r, g, b as floats, summed in run order
 __global__ __launch_bounds__(256) void slice_centroids(const kt_point_xyzrgb* __restrict__ pts, const unsigned int* __restrict__ keys,
                                                        const unsigned int* __restrict__ src, const unsigned int* __restrict__ head,
-                                                       const unsigned int* __restrict__ leaf_of, int m, float* __restrict__ cen,
-                                                       unsigned int* __restrict__ leaf_key)
+                                                       const unsigned int* __restrict__ leaf_of, int n_max, float* __restrict__ cen,
+                                                       unsigned int* __restrict__ leaf_key, unsigned int* __restrict__ leaf_src, Params* __restrict__ prm)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m || !head[i]) return;
+    if (i >= n_max) return;
+    if (i == n_max - 1) prm->leaves = leaf_of[i];   // inclusive scan of the head flags: its last entry is the number of leaves
+    if (!head[i]) return;
     const unsigned int key = keys[i];
     float acc[6] = {0, 0, 0, 0, 0, 0};
     int j = i;
-    for (; j < m && keys[j] == key; ++j) {
+    for (; j < n_max && keys[j] == key; ++j) {
         const kt_point_xyzrgb p = pts[src[j]];
         acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += (float)p.r; acc[4] += (float)p.g; acc[5] += (float)p.b;
     }
     // `centroid /= static_cast<float>(count)` on an Eigen::VectorXf: Eigen 3.2 (the reference's, README.md:14-31) evaluates a
     // floating-point `/= s` as a multiplication by Scalar(1) / s (SelfCwiseBinaryOp.h; true division only from 3.3 on)
     const float inv_cnt = 1.0f / (float)(j - i);
-    const unsigned int q = leaf_of[i] - 1u;   // inclusive scan of the head flags
+    const unsigned int q = leaf_of[i] - 1u;
 #pragma unroll
     for (int a = 0; a < 6; ++a) cen[(size_t)q * 6 + a] = acc[a] * inv_cnt;
     leaf_key[q] = key;
+    leaf_src[q] = src[i];   // the leaf's first point (the pass-through case copies its weight byte)
 }
 
 // ---- pcl::eigen33 / computeRoots (common/impl/eigen.hpp), float ----
@@ -183,11 +221,15 @@ __device__ __forceinline__ int lower_bound(const unsigned int* __restrict__ leaf
 }
 
 // one thread per down-sampled point: kNN over the leaf grid, covariance, normal, curvature
-__global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ cen, const unsigned int* __restrict__ leaf_key, int L, Grid g, int k,
-                                                     int gridded, const kt_point_xyzrgb* __restrict__ pts, kt_point_xyzrgbnormal* __restrict__ out)
+__global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ cen, const unsigned int* __restrict__ leaf_key, const unsigned int* __restrict__ leaf_src,
+                                                     const Params* __restrict__ prm, int k, const kt_point_xyzrgb* __restrict__ pts,
+                                                     kt_point_xyzrgbnormal* __restrict__ out)
 {
     const int q = blockIdx.x * 128 + threadIdx.x;
+    const int L = (int)prm->leaves;
     if (q >= L) return;
+    const Grid g = prm->g;
+    const int gridded = prm->gridded;
     const float px = cen[(size_t)q * 6], py = cen[(size_t)q * 6 + 1], pz = cen[(size_t)q * 6 + 2];
     const int kk = min(k, L);
     float bd[KT_SLICE_K_MAX];
@@ -239,7 +281,7 @@ __global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ c
     // VoxelGrid: r, g, b = static_cast<uint8_t> of the float means; the packed rgb has a zero alpha byte -- except in the "leaf size
     // too small" case, where `output = *input_` keeps every point as it is, its weight byte included
     o.r = (unsigned char)cen[(size_t)q * 6 + 3]; o.g = (unsigned char)cen[(size_t)q * 6 + 4]; o.b = (unsigned char)cen[(size_t)q * 6 + 5];
-    o.a = gridded ? (unsigned char)0 : pts[q].a;
+    o.a = gridded ? (unsigned char)0 : pts[leaf_src[q]].a;
     if (cnt < 3) {   // NormalEstimation: fewer than 3 neighbours -> NaN normal and curvature
         o.normal_x = o.normal_y = o.normal_z = o.curvature = __builtin_nanf("");
         out[q] = o;
@@ -268,123 +310,148 @@ __global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ c
     out[q] = o;
 }
 
-// pass-through rows for the "leaf size too small" case: centroid records straight from the points
-__global__ __launch_bounds__(256) void slice_passthrough(const kt_point_xyzrgb* __restrict__ pts, int m, float* __restrict__ cen, unsigned int* __restrict__ leaf_key)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    cen[(size_t)i * 6] = pts[i].x; cen[(size_t)i * 6 + 1] = pts[i].y; cen[(size_t)i * 6 + 2] = pts[i].z;
-    cen[(size_t)i * 6 + 3] = (float)pts[i].r; cen[(size_t)i * 6 + 4] = (float)pts[i].g; cen[(size_t)i * 6 + 5] = (float)pts[i].b;
-    leaf_key[i] = (unsigned int)i;
-}
-
-struct DevBufs {   // freed on every exit path
-    void* p[16];
-    int n;
-    DevBufs() : n(0) {}
-    ~DevBufs() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
-    template <class T> int alloc(T** out, size_t count)
-    {
-        void* q = nullptr;
-        if (hipMalloc(&q, (count ? count : 1) * sizeof(T)) != hipSuccess) { kt_set_error("kt_slice_process: out of device memory"); return KT_ERR_NOMEM; }
-        p[n++] = q;
-        *out = (T*)q;
-        return KT_OK;
-    }
-};
-
 }  // namespace
 
+// ---- workspace + entry points ---------------------------------------------------------------------------------------------------
+struct kt_slice_ws {
+    kt_ctx* ctx;
+    hipStream_t stream; bool own_stream;
+    size_t cap;
+    unsigned int *keys[2], *src[2], *head, *leafof, *leaf_key, *leaf_src, *n_dev;
+    float* cen;
+    BBox* box;
+    Params* prm;
+    void* tmp; size_t tmp_bytes;
+    kt_point_xyzrgb* in;              // staging for the host-array entry point
+    kt_point_xyzrgbnormal* out;       // device output of the last call (cap points)
+    unsigned int* leaves_host;        // pinned: the output count, written behind the last launch
+};
+
+extern "C" int kt_slice_ws_destroy(kt_slice_ws* w)
+{
+    if (!w) return KT_OK;
+    if (w->stream) (void)hipStreamSynchronize(w->stream);
+    for (int k = 0; k < 2; ++k) { (void)hipFree(w->keys[k]); (void)hipFree(w->src[k]); }
+    (void)hipFree(w->head); (void)hipFree(w->leafof); (void)hipFree(w->leaf_key); (void)hipFree(w->leaf_src); (void)hipFree(w->n_dev);
+    (void)hipFree(w->cen); (void)hipFree(w->box); (void)hipFree(w->prm); (void)hipFree(w->tmp); (void)hipFree(w->in); (void)hipFree(w->out);
+    (void)hipHostFree(w->leaves_host);
+    if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
+    delete w;
+    return KT_OK;
+}
+
+// capacity = the largest number of input points a call may bring; stream = the stream the stage runs on (null: one of its own,
+// so that a backend thread's slices never queue behind -- or in front of -- a frame)
+extern "C" int kt_slice_ws_create(kt_ctx* c, size_t capacity, void* hip_stream, kt_slice_ws** out)
+{
+    KT_ARG(c && out && capacity > 0 && capacity < (1u << 30));
+    kt_slice_ws* w = new kt_slice_ws();
+    memset(w, 0, sizeof(*w));
+    w->ctx = c; w->cap = capacity;
+    int s = KT_OK;
+    auto A = [&](void** p, size_t bytes) { if (s == KT_OK) s = kt_check(hipMalloc(p, bytes), "hipMalloc", __FILE__, __LINE__); };
+    if (hip_stream) w->stream = (hipStream_t)hip_stream;
+    else { s = kt_check(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking), "hipStreamCreateWithFlags", __FILE__, __LINE__); w->own_stream = s == KT_OK; }
+    for (int k = 0; k < 2; ++k) { A((void**)&w->keys[k], capacity * 4); A((void**)&w->src[k], capacity * 4); }
+    A((void**)&w->head, capacity * 4); A((void**)&w->leafof, capacity * 4); A((void**)&w->leaf_key, capacity * 4); A((void**)&w->leaf_src, capacity * 4);
+    A((void**)&w->n_dev, 4); A((void**)&w->cen, capacity * 6 * sizeof(float)); A((void**)&w->box, sizeof(BBox) * KT_SLICE_BOXES); A((void**)&w->prm, sizeof(Params));
+    A((void**)&w->in, capacity * sizeof(kt_point_xyzrgb)); A((void**)&w->out, capacity * sizeof(kt_point_xyzrgbnormal));
+    if (s == KT_OK) {
+        size_t a = 0, b = 0;
+        s = kt_check(rocprim::radix_sort_pairs(nullptr, a, w->keys[0], w->keys[1], w->src[0], w->src[1], (unsigned int)capacity, 0, 32, w->stream), "rocprim::radix_sort_pairs", __FILE__, __LINE__);
+        if (s == KT_OK) s = kt_check(rocprim::inclusive_scan(nullptr, b, w->head, w->leafof, capacity, rocprim::plus<unsigned int>(), w->stream), "rocprim::inclusive_scan", __FILE__, __LINE__);
+        w->tmp_bytes = a > b ? a : b;
+        A(&w->tmp, w->tmp_bytes ? w->tmp_bytes : 16);
+    }
+    if (s == KT_OK) s = kt_check(hipHostMalloc((void**)&w->leaves_host, sizeof(unsigned int), hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__);
+    if (s != KT_OK) { (void)kt_slice_ws_destroy(w); return s; }
+    *out = w;
+    return KT_OK;
+}
+
+extern "C" void* kt_slice_ws_stream(kt_slice_ws* w) { return w ? (void*)w->stream : nullptr; }
+extern "C" const kt_point_xyzrgbnormal* kt_slice_ws_output(kt_slice_ws* w) { return w ? w->out : nullptr; }
+
+// The stage on device-resident points: points_dev[0 .. *n_dev) (n_max = an upper bound of *n_dev known to the host, <= the workspace's
+// capacity; n_dev itself is read on the device, e.g. the extraction kernel's own counter).  Everything is enqueued on the workspace's
+// stream and nothing waits: the result is kt_slice_ws_output(ws)[0 .. *count) once that stream has been synchronised, *count =
+// the pinned word the last copy fills (kt_slice_ws_count).
+extern "C" int kt_slice_process_device(kt_slice_ws* w, const kt_point_xyzrgb* points_dev, const unsigned int* n_dev, size_t n_max, int weight_cull, float leaf, int k)
+{
+    KT_ARG(w && points_dev && n_dev && n_max > 0 && n_max <= w->cap && leaf > 0 && k >= 1 && k <= KT_SLICE_K_MAX);
+    hipStream_t st = w->stream;
+    const int nm = (int)n_max, nb = kt_div_up(nm, 256);
+    hipLaunchKernelGGL(slice_bbox, dim3(KT_SLICE_BOXES), dim3(256), 0, st, points_dev, n_dev, nm, weight_cull, w->box);
+    hipLaunchKernelGGL(slice_grid, dim3(1), dim3(64), 0, st, w->box, leaf, w->prm);
+    hipLaunchKernelGGL(slice_keys, dim3(nb), dim3(256), 0, st, points_dev, n_dev, nm, weight_cull, w->prm, w->keys[0], w->src[0]);
+    KT_LAUNCH_CHECK();
+    size_t tb = w->tmp_bytes;
+    KT_HIP(rocprim::radix_sort_pairs(w->tmp, tb, w->keys[0], w->keys[1], w->src[0], w->src[1], (unsigned int)nm, 0, 32, st));   // stable
+    hipLaunchKernelGGL(slice_heads, dim3(nb), dim3(256), 0, st, w->keys[1], nm, w->head);
+    KT_LAUNCH_CHECK();
+    tb = w->tmp_bytes;
+    KT_HIP(rocprim::inclusive_scan(w->tmp, tb, w->head, w->leafof, (size_t)nm, rocprim::plus<unsigned int>(), st));
+    hipLaunchKernelGGL(slice_centroids, dim3(nb), dim3(256), 0, st, points_dev, w->keys[1], w->src[1], w->head, w->leafof, nm, w->cen, w->leaf_key, w->leaf_src, w->prm);
+    // NormalEstimation (kNN) + concatenateFields: one thread per leaf, the grid sized for the upper bound
+    hipLaunchKernelGGL(slice_normals, dim3(kt_div_up(nm, 128)), dim3(128), 0, st, w->cen, w->leaf_key, w->leaf_src, w->prm, k, points_dev, w->out);
+    KT_LAUNCH_CHECK();
+    KT_HIP(hipMemcpyAsync(w->leaves_host, &w->prm->leaves, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    return KT_OK;
+}
+
+// copy `*n_dev` (clamped to cap) items of `item16` 16-byte words each, and the clamped count itself: how a variable-length device
+// result reaches pinned host memory without the host knowing its length (the tracker's slice download)
+__global__ __launch_bounds__(256) void kt_copy_counted_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const unsigned int* __restrict__ n_dev,
+                                                              unsigned int cap, int item16, unsigned int* __restrict__ count_out)
+{
+    const unsigned int n = min(*n_dev, cap);
+    const size_t total = (size_t)n * item16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;
+}
+int kt_copy_counted(hipStream_t st, const void* src, void* dst, const unsigned int* n_dev, unsigned int cap, int item_bytes, unsigned int* count_out)
+{
+    hipLaunchKernelGGL(kt_copy_counted_kernel, dim3(512), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n_dev, cap, item_bytes / 16, count_out);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+const unsigned int* kt_slice_ws_leaves_dev(kt_slice_ws* w) { return &w->prm->leaves; }
+
+extern "C" int kt_slice_ws_count(kt_slice_ws* w, size_t* n_out)
+{
+    KT_ARG(w && n_out);
+    KT_HIP(hipStreamSynchronize(w->stream));
+    *n_out = (size_t)*w->leaves_host;
+    return KT_OK;
+}
+
+// the host-array form (a CloudSlice's cloud in, its processedCloud out): upload, the device stage, download -- on a workspace the
+// context keeps (grown when a larger slice arrives) and on the context's stream
 extern "C" int kt_slice_process(kt_ctx* c, const kt_point_xyzrgb* points_host, size_t n_in, int weight_cull, float leaf, int k,
                                 kt_point_xyzrgbnormal* out_host, size_t* n_out)
 {
     KT_ARG(c && n_out && (n_in == 0 || (points_host && out_host)) && leaf > 0 && k >= 1 && k <= KT_SLICE_K_MAX && n_in < (1u << 30));
     *n_out = 0;
     if (n_in == 0) return KT_OK;
-    const int n = (int)n_in;
-    hipStream_t st = c->stream;
-    DevBufs b;
-    kt_point_xyzrgb *d_in, *d_pts;
-    unsigned int *d_keep, *d_pos, *d_keys, *d_keys2, *d_src, *d_src2, *d_head, *d_leafof, *d_leafkey;
-    float* d_cen;
-    BBox* d_box;
-    kt_point_xyzrgbnormal* d_out;
-    KT_TRY(b.alloc(&d_in, n)); KT_TRY(b.alloc(&d_pts, n)); KT_TRY(b.alloc(&d_keep, n)); KT_TRY(b.alloc(&d_pos, n));
-    KT_HIP(hipMemcpyAsync(d_in, points_host, (size_t)n * sizeof(kt_point_xyzrgb), hipMemcpyHostToDevice, st));
-    const int nb = kt_div_up(n, 256);
-    // ---- weight cull (CloudSliceProcessor.cpp:99-117), order preserved ----
-    hipLaunchKernelGGL(slice_cull_flags, dim3(nb), dim3(256), 0, st, d_in, n, weight_cull, d_keep);
-    KT_LAUNCH_CHECK();
-    size_t tmp_bytes = 0, need = 0;
-    KT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_keep, d_pos, n, st));
-    tmp_bytes = need;
-    KT_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const unsigned int*)nullptr, (unsigned int*)nullptr, (const unsigned int*)nullptr,
-                                              (unsigned int*)nullptr, n, 0, 32, st));
-    tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
-    KT_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, need, d_keep, d_pos, n, st));
-    tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
-    unsigned char* d_tmp;
-    KT_TRY(b.alloc(&d_tmp, tmp_bytes));
-    KT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_keep, d_pos, n, st));
-    hipLaunchKernelGGL(slice_cull_scatter, dim3(nb), dim3(256), 0, st, d_in, n, d_keep, d_pos, d_pts);
-    KT_LAUNCH_CHECK();
-    unsigned int last_pos = 0, last_keep = 0;
-    KT_HIP(hipMemcpyAsync(&last_pos, d_pos + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-    KT_HIP(hipMemcpyAsync(&last_keep, d_keep + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-    KT_HIP(hipStreamSynchronize(st));
-    const int m = (int)(last_pos + last_keep);
-    if (m == 0) return KT_OK;
-    const int mb = kt_div_up(m, 256);
-    // ---- VoxelGrid::applyFilter ----
-    const int boxes = min(256, mb);
-    KT_TRY(b.alloc(&d_box, boxes + 1));
-    hipLaunchKernelGGL(slice_bbox, dim3(boxes), dim3(256), 0, st, &d_pts->x, 8, m, d_box);
-    KT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(slice_bbox, dim3(1), dim3(256), 0, st, &d_box->mn[0], 6, boxes, d_box + boxes);
-    KT_LAUNCH_CHECK();
-    BBox box;
-    KT_HIP(hipMemcpyAsync(&box, d_box + boxes, sizeof(BBox), hipMemcpyDeviceToHost, st));
-    KT_HIP(hipStreamSynchronize(st));
-    Grid g;
-    g.leaf = leaf;
-    g.inv_leaf = 1.0f / leaf;
-    int max_b[3];
-    for (int a = 0; a < 3; ++a) {
-        g.min_b[a] = (int)floorf(box.mn[a] * g.inv_leaf);
-        max_b[a] = (int)floorf(box.mx[a] * g.inv_leaf);
-        g.div_b[a] = max_b[a] - g.min_b[a] + 1;
+    kt_slice_ws* w = (kt_slice_ws*)c->slice_ws;
+    if (!w || w->cap < n_in || w->stream != c->stream) {
+        if (w) (void)kt_slice_ws_destroy(w);
+        c->slice_ws = nullptr;
+        size_t cap = 1 << 16;
+        while (cap < n_in) cap <<= 1;
+        KT_TRY(kt_slice_ws_create(c, cap, (void*)c->stream, &w));
+        c->slice_ws = w;
     }
-    KT_TRY(b.alloc(&d_cen, (size_t)m * 6)); KT_TRY(b.alloc(&d_leafkey, m)); KT_TRY(b.alloc(&d_out, m));
-    int L = 0, gridded = 1;
-    // voxel_grid.hpp: dx = static_cast<int64_t>((max_p[0] - min_p[0]) * inverse_leaf_size_[0]) + 1, ...; dx * dy * dz > INT32_MAX
-    if (((long long)((box.mx[0] - box.mn[0]) * g.inv_leaf) + 1) * ((long long)((box.mx[1] - box.mn[1]) * g.inv_leaf) + 1) *
-            ((long long)((box.mx[2] - box.mn[2]) * g.inv_leaf) + 1) > 2147483647LL) {
-        // "Leaf size is too small for the input dataset. Integer indices would overflow.": PCL passes the cloud through unfiltered
-        hipLaunchKernelGGL(slice_passthrough, dim3(mb), dim3(256), 0, st, d_pts, m, d_cen, d_leafkey);
-        KT_LAUNCH_CHECK();
-        L = m;
-        gridded = 0;
-    } else {
-        KT_TRY(b.alloc(&d_keys, m)); KT_TRY(b.alloc(&d_keys2, m)); KT_TRY(b.alloc(&d_src, m)); KT_TRY(b.alloc(&d_src2, m));
-        KT_TRY(b.alloc(&d_head, m)); KT_TRY(b.alloc(&d_leafof, m));
-        hipLaunchKernelGGL(slice_keys, dim3(mb), dim3(256), 0, st, d_pts, m, g, d_keys, d_src);
-        KT_LAUNCH_CHECK();
-        KT_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_src, d_src2, m, 0, 32, st));   // stable
-        hipLaunchKernelGGL(slice_heads, dim3(mb), dim3(256), 0, st, d_keys2, m, d_head);
-        KT_LAUNCH_CHECK();
-        KT_HIP(hipcub::DeviceScan::InclusiveSum(d_tmp, tmp_bytes, d_head, d_leafof, m, st));
-        hipLaunchKernelGGL(slice_centroids, dim3(mb), dim3(256), 0, st, d_pts, d_keys2, d_src2, d_head, d_leafof, m, d_cen, d_leafkey);
-        KT_LAUNCH_CHECK();
-        unsigned int leaves = 0;
-        KT_HIP(hipMemcpyAsync(&leaves, d_leafof + (m - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-        KT_HIP(hipStreamSynchronize(st));
-        L = (int)leaves;
+    const unsigned int n32 = (unsigned int)n_in;
+    KT_HIP(hipMemcpyAsync(w->in, points_host, n_in * sizeof(kt_point_xyzrgb), hipMemcpyHostToDevice, w->stream));
+    KT_HIP(hipMemcpyAsync(w->n_dev, &n32, sizeof(n32), hipMemcpyHostToDevice, w->stream));
+    KT_TRY(kt_slice_process_device(w, w->in, w->n_dev, n_in, weight_cull, leaf, k));
+    size_t L = 0;
+    KT_TRY(kt_slice_ws_count(w, &L));
+    if (L) {
+        KT_HIP(hipMemcpyAsync(out_host, w->out, L * sizeof(kt_point_xyzrgbnormal), hipMemcpyDeviceToHost, w->stream));
+        KT_HIP(hipStreamSynchronize(w->stream));
     }
-    // ---- NormalEstimation (kNN) + concatenateFields ----
-    hipLaunchKernelGGL(slice_normals, dim3(kt_div_up(L, 128)), dim3(128), 0, st, d_cen, d_leafkey, L, g, k, gridded, d_pts, d_out);
-    KT_LAUNCH_CHECK();
-    KT_HIP(hipMemcpyAsync(out_host, d_out, (size_t)L * sizeof(kt_point_xyzrgbnormal), hipMemcpyDeviceToHost, st));
-    KT_HIP(hipStreamSynchronize(st));
-    *n_out = (size_t)L;
+    *n_out = L;
     return KT_OK;
 }

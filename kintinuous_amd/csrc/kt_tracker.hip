@@ -21,7 +21,10 @@
 namespace {
 
 struct DensePose { uint64_t ts; float pose[16]; int is_loop; };   // KintinuousTracker.h:151-169
-struct Slice { std::vector<kt_point_xyzrgb> pts; int dim; float R[9], cam[3]; uint64_t ts; int pr_id; };      // CloudSlice.h:28-129 (cloud + dimension)
+struct Slice {      // CloudSlice.h:28-129 (cloud + dimension; processed = CloudSlice::processedCloud when the slice stage is on)
+    std::vector<kt_point_xyzrgb> pts; int dim; float R[9], cam[3]; uint64_t ts; int pr_id;
+    std::vector<kt_point_xyzrgbnormal> processed; bool has_processed = false;
+};
 struct PrSample { uint64_t utime; float trans[3], rot[9]; int pose_index; };   // PlaceRecognitionInput.h:30-56, minus the frame bytes
 
 // Everything computed from the input frame alone (bilateral + pyramids + scaleDepth records): two sets, so the set of frame
@@ -124,6 +127,13 @@ struct kt_tracker {
     SliceJob jobs[2];
     kt_point_xyzrgb* cloud_host[2]; unsigned int* cloud_count_host[2]; hipEvent_t cloud_ev[2];
     int cloud_next;
+    // The CloudSliceProcessor stage behind a shift, on the device (kt_slice.hip; kt_tracker_enable_slice_stage): the extraction then
+    // writes into device memory, and a stream of its own takes the slab from there -- raw points to pinned host memory, the stage, the
+    // processed points to pinned host memory -- while the main stream goes on with the clears and the fusion.
+    bool slice_stage; int slice_cull, slice_k;
+    kt_slice_ws* slice_ws;
+    kt_point_xyzrgb* cloud_dev[2]; unsigned int* cloud_count_dev[2]; hipEvent_t extracted[2];
+    kt_point_xyzrgbnormal* proc_host[2]; unsigned int* proc_count_host[2];
     // place-recognition tap (KintinuousTracker.h:216, 248-249): pose of the last sampled frame, the samples
     float pr_rot[9], pr_trans[3];
     std::vector<PrSample> pr_samples;
@@ -433,6 +443,8 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     }
     t->frames_started = 0;
     t->cloud_next = 0;
+    t->slice_stage = false; t->slice_ws = nullptr;
+    for (int b = 0; b < 2; ++b) { t->cloud_dev[b] = nullptr; t->cloud_count_dev[b] = nullptr; t->extracted[b] = nullptr; t->proc_host[b] = nullptr; t->proc_count_host[b] = nullptr; }
     for (int b = 0; b < 2; ++b) { t->jobs[b].active = false; t->jobs[b].status = hipSuccess; t->cloud_host[b] = nullptr; t->cloud_count_host[b] = nullptr; t->cloud_ev[b] = nullptr; }
     t->frames_observed = 0;
     t->out_ordinal = -1;
@@ -524,7 +536,10 @@ int kt_tracker_destroy(kt_tracker* t)
     for (int b = 0; b < 2; ++b) {
         (void)hipHostFree(t->cloud_host[b]); (void)hipHostFree(t->cloud_count_host[b]);
         if (t->cloud_ev[b]) (void)hipEventDestroy(t->cloud_ev[b]);
+        (void)hipFree(t->cloud_dev[b]); (void)hipFree(t->cloud_count_dev[b]); (void)hipHostFree(t->proc_host[b]); (void)hipHostFree(t->proc_count_host[b]);
+        if (t->extracted[b]) (void)hipEventDestroy(t->extracted[b]);
     }
+    if (t->slice_ws) (void)kt_slice_ws_destroy(t->slice_ws);
     (void)hipFree(t->state_dev); (void)hipHostFree(t->state_host);
     for (int k = 0; k < KT_NSLOTS; ++k) {
         (void)hipFree(t->depth_stage[k]); (void)hipFree(t->rgb_stage[k]);
@@ -930,10 +945,26 @@ static int fetch_slice(kt_tracker* t, const int lo[3], const int hi[3], int dim)
         j.active = false;
         if (j.status != hipSuccess) { kt_set_error("slice download: %s", hipGetErrorString(j.status)); return KT_ERR_HIP; }
     }
-    KT_TRY(kt_extract_cloud_slice_async(c, t->tsdf, t->volume_size, t->cloud_host[b], t->cloud_cap, t->v_wrap_copy, t->color, lo[0], hi[0],
-                                        lo[1], hi[1], lo[2], hi[2], 1, t->voxel_wrap, t->N, &c->counters[1]));
-    KT_HIP(hipMemcpyAsync(t->cloud_count_host[b], &c->counters[1], sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-    KT_HIP(hipEventRecord(t->cloud_ev[b], c->stream));
+    const bool stage = t->slice_stage;
+    if (!stage) {
+        KT_TRY(kt_extract_cloud_slice_async(c, t->tsdf, t->volume_size, t->cloud_host[b], t->cloud_cap, t->v_wrap_copy, t->color, lo[0], hi[0],
+                                            lo[1], hi[1], lo[2], hi[2], 1, t->voxel_wrap, t->N, &c->counters[1]));
+        KT_HIP(hipMemcpyAsync(t->cloud_count_host[b], &c->counters[1], sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        KT_HIP(hipEventRecord(t->cloud_ev[b], c->stream));
+    } else {
+        // the slab stays on the device; everything behind the extraction kernel runs on the slice stage's own stream
+        hipStream_t ss = (hipStream_t)kt_slice_ws_stream(t->slice_ws);
+        KT_TRY(kt_extract_cloud_slice_async(c, t->tsdf, t->volume_size, t->cloud_dev[b], t->cloud_cap, t->v_wrap_copy, t->color, lo[0], hi[0],
+                                            lo[1], hi[1], lo[2], hi[2], 1, t->voxel_wrap, t->N, t->cloud_count_dev[b]));
+        KT_HIP(hipEventRecord(t->extracted[b], c->stream));
+        KT_HIP(hipStreamWaitEvent(ss, t->extracted[b], 0));
+        KT_TRY(kt_copy_counted(ss, t->cloud_dev[b], t->cloud_host[b], t->cloud_count_dev[b], (unsigned int)t->cloud_cap, (int)sizeof(kt_point_xyzrgb), t->cloud_count_host[b]));
+        const float leaf = fmaxf(t->voxel_size[0], fmaxf(t->voxel_size[1], t->voxel_size[2]));   // CloudSliceProcessor.cpp:124-130
+        KT_TRY(kt_slice_process_device(t->slice_ws, t->cloud_dev[b], t->cloud_count_dev[b], t->cloud_cap, t->slice_cull, leaf, t->slice_k));
+        KT_TRY(kt_copy_counted(ss, kt_slice_ws_output(t->slice_ws), t->proc_host[b], kt_slice_ws_leaves_dev(t->slice_ws), (unsigned int)t->cloud_cap,
+                               (int)sizeof(kt_point_xyzrgbnormal), t->proc_count_host[b]));
+        KT_HIP(hipEventRecord(t->cloud_ev[b], ss));
+    }
     t->slices.emplace_back();
     Slice& s = t->slices.back();
     s.dim = dim;
@@ -951,13 +982,21 @@ static int fetch_slice(kt_tracker* t, const int lo[3], const int hi[3], int dim)
     hipEvent_t ev = t->cloud_ev[b];
     hipError_t* status = &j.status;
     const int device = c->device;
-    j.th = std::thread([dst, src, cnt, cap, ev, status, device]() {
+    const kt_point_xyzrgbnormal* psrc = stage ? t->proc_host[b] : nullptr;
+    const unsigned int* pcnt = stage ? t->proc_count_host[b] : nullptr;
+    j.th = std::thread([dst, src, cnt, cap, ev, status, device, psrc, pcnt]() {
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipEventSynchronize(ev);   // the kernel's stores to host memory and the count are complete
         if (e != hipSuccess) { *status = e; return; }
         size_t n = (size_t)*cnt;
         if (n > cap) n = cap;
         dst->pts.assign(src, src + n);
+        if (psrc) {
+            size_t m = (size_t)*pcnt;
+            if (m > cap) m = cap;
+            dst->processed.assign(psrc, psrc + m);
+            dst->has_processed = true;
+        }
     });
     return KT_OK;
 }
@@ -1609,6 +1648,48 @@ int kt_tracker_debug_state(kt_tracker* t, float* out29)
     memcpy(out29, t->state_host->icp29, 29 * sizeof(float));
     return KT_OK;
 }
+/* The CloudSliceProcessor stage (weight cull, voxel grid at the voxel size, k-NN normals: kt_slice_process_device) behind every slab the
+ * tracker extracts from now on, on a stream of its own; the processed points travel with the slice (kt_tracker_slice_processed). */
+int kt_tracker_enable_slice_stage(kt_tracker* t, int on, int weight_cull, int k)
+{
+    KT_ARG(t && (!on || (k >= 1 && k <= 64)));
+    KT_TRY(complete_frame(t));
+    KT_TRY(join_slice_jobs(t));
+    if (on && !t->slice_ws) {
+        KT_TRY(kt_slice_ws_create(t->ctx, t->cloud_cap, nullptr, &t->slice_ws));
+        for (int b = 0; b < 2; ++b) {
+            KT_HIP(hipMalloc((void**)&t->cloud_dev[b], t->cloud_cap * sizeof(kt_point_xyzrgb)));
+            KT_HIP(hipMalloc((void**)&t->cloud_count_dev[b], sizeof(unsigned int)));
+            KT_HIP(hipHostMalloc((void**)&t->proc_host[b], t->cloud_cap * sizeof(kt_point_xyzrgbnormal), hipHostMallocDefault));
+            KT_HIP(hipHostMalloc((void**)&t->proc_count_host[b], sizeof(unsigned int), hipHostMallocDefault));
+            KT_HIP(hipEventCreateWithFlags(&t->extracted[b], KT_EV_DEVICE));
+        }
+    }
+    t->slice_stage = on != 0;
+    t->slice_cull = weight_cull; t->slice_k = k;
+    return KT_OK;
+}
+/* number of processed points of slice i, or -1 when the slice was extracted without the stage */
+int kt_tracker_slice_processed_info(kt_tracker* t, int i, long long* n_points)
+{
+    KT_ARG(t && n_points);
+    KT_TRY(complete_frame(t));
+    KT_ARG(i >= 0 && i < (int)t->slices.size());
+    KT_TRY(join_slice_jobs(t));
+    *n_points = t->slices[i].has_processed ? (long long)t->slices[i].processed.size() : -1;
+    return KT_OK;
+}
+int kt_tracker_slice_processed(kt_tracker* t, int i, kt_point_xyzrgbnormal* out)
+{
+    KT_ARG(t && out);
+    KT_TRY(complete_frame(t));
+    KT_ARG(i >= 0 && i < (int)t->slices.size());
+    KT_TRY(join_slice_jobs(t));
+    KT_ARG(t->slices[i].has_processed);
+    if (!t->slices[i].processed.empty()) memcpy(out, t->slices[i].processed.data(), t->slices[i].processed.size() * sizeof(kt_point_xyzrgbnormal));
+    return KT_OK;
+}
+
 int kt_tracker_plan_stats(kt_tracker* t, long long out2[2])
 {
     KT_ARG(t && out2);

@@ -91,14 +91,20 @@ class CloudSliceProcessor {
             CloudSlice* s = trackerSlices->at(latestPushedCloud);
             // :89-160: weight cull (alpha >= -cw), VoxelGrid with leaf = the largest voxel edge, NormalEstimation k = 20,
             // concatenateFields -> processedCloud
-            s->processedCloud = new CloudSlice::PointCloudNormal(s->cloud->size());
             size_t np = 0;
-            if (s->cloud->size()) {
-                static_assert(sizeof(PointXYZRGBNormal) == sizeof(kt_point_xyzrgbnormal), "processedCloud layout");
-                ktSafeCall(kt_slice_process(context(), s->cloud->data(), s->cloud->size(), ConfigArgs::get().weightCull, leafSize(), 20,
-                                            reinterpret_cast<kt_point_xyzrgbnormal*>(s->processedCloud->data()), &np));
+            if (s->processedCloud) {
+                // the tracker ran the stage on the device right behind the extraction kernel (KintinuousTracker::enableSliceStage):
+                // the slab never left the GPU in between, and nothing is left to do here but the hand-over
+                np = s->processedCloud->size();
+            } else {
+                s->processedCloud = new CloudSlice::PointCloudNormal(s->cloud->size());
+                if (s->cloud->size()) {
+                    static_assert(sizeof(PointXYZRGBNormal) == sizeof(kt_point_xyzrgbnormal), "processedCloud layout");
+                    ktSafeCall(kt_slice_process(context(), s->cloud->data(), s->cloud->size(), ConfigArgs::get().weightCull, leafSize(), 20,
+                                                reinterpret_cast<kt_point_xyzrgbnormal*>(s->processedCloud->data()), &np));
+                }
+                s->processedCloud->resize(np);
             }
-            s->processedCloud->resize(np);
             // the reference culls and down-samples slice->cloud IN PLACE (:112-114, :138-140): later backend threads see the voxel-gridded
             // points there too.  They are the processed cloud without its normals.
             s->cloud->resize(np);

@@ -252,6 +252,15 @@ class KintinuousTracker {
     std::vector<CloudSlice*>& getCloudSlices() { return sharedCloudSlices; }
     CloudSlice* getLiveTsdf() { return liveTsdf; }     // KintinuousTracker.cpp:1065-1073
     CloudSlice* getLiveImage() { return liveImage; }
+    // The backend's CloudSliceProcessor stage (weight cull, voxel grid, 20-NN normals; backend/CloudSliceProcessor.cpp:87-163) on the
+    // device, right behind every slab extraction: slices then reach getCloudSlices() with processedCloud filled.  Device-resident path
+    // only (the operator path hands raw slices over; host/CloudSliceProcessor.h processes those itself).
+    void enableSliceStage(int weightCull)
+    {
+        sliceStage = true;
+        sliceStageCull = weightCull;
+        if (fast) ktSafeCall(kt_tracker_enable_slice_stage(fast, 1, weightCull, 20));
+    }
     void setOverlap(int o)
     {
         overlap = o;
@@ -351,6 +360,8 @@ class KintinuousTracker {
     uint64_t current_utime;
     int nextSlice;
     bool haveTrajectory = false;
+    bool sliceStage = false;
+    int sliceStageCull = 0;
     std::vector<uint64_t> trajectoryTimes;   // -p file, flattened for kt_tracker_load_trajectory
     std::vector<float> trajectoryPoses;
     kt::Matrix3f lastRotation;
@@ -467,6 +478,7 @@ class KintinuousTracker {
         if (fast) return;
         ktSafeCall(kt_tracker_create(kt::device::context(), &config, &fast));
         if (parked) ktSafeCall(kt_tracker_set_parked(fast, 1));
+        if (sliceStage) ktSafeCall(kt_tracker_enable_slice_stage(fast, 1, sliceStageCull, 20));
         if (haveTrajectory)
             ktSafeCall(kt_tracker_load_trajectory(fast, (int)trajectoryTimes.size(), trajectoryTimes.data(), trajectoryPoses.data()));
         if (ConfigArgs::get().saveFile.size()) {
@@ -531,10 +543,20 @@ class KintinuousTracker {
             ktSafeCall(kt_tracker_slice_pose(fast, nextSlice, R.data(), cam.data(), &ts));
             const bool fin = dim == CloudSlice::FINAL;
             PlaceRecognitionInput* pr = (prId >= 0 && prId < PR_BUFFER_SIZE) ? &placeRecognitionBuffer[prId] : 0;
+            // with the slice stage on the device (enableSliceStage) the slice arrives processed: cull, voxel grid and normals ran on the
+            // tracker's slice stream right behind the extraction kernel
+            long long np = -1;
+            ktSafeCall(kt_tracker_slice_processed_info(fast, nextSlice, &np));
+            CloudSlice::PointCloudNormal* processed = 0;
+            if (np >= 0) {
+                processed = new CloudSlice::PointCloudNormal((size_t)np);
+                if (np) ktSafeCall(kt_tracker_slice_processed(fast, nextSlice, reinterpret_cast<kt_point_xyzrgbnormal*>(processed->data())));
+            }
             std::lock_guard<std::mutex> lock(cloudMutex);
             cycledMutex = true;
             sharedCloudSlices.push_back(new CloudSlice(cloud, (CloudSlice::Dimension)dim, lastOdometry, cam, R, ts, fin ? nowMicros() : lagTime,
                                                        fin ? lastRgbImage : 0, 0, 0, fin ? lastDepthData : 0, pr));
+            sharedCloudSlices.back()->processedCloud = processed;
             cloudSignal.notify_all();
         }
         if (global_time_ > before && global_time_ > 1) serveLiveViews();

@@ -131,13 +131,14 @@ int main(int argc, char** argv)
 {
     const ConfigArgs& args = ConfigArgs::get(argc, argv);
     if (args.help || args.logFile.empty()) { ConfigArgs::usage(argv[0]); return args.help ? 0 : 1; }
-    bool ops = false, pcd = false, pcdraw = false, ppm = false;
+    bool ops = false, pcd = false, pcdraw = false, ppm = false, noStage = false;
     int rank = 0, world = 0, gatherCount = 1;
     std::string commFile;
     for (int i = 1; i < argc; ++i) {
         ops = ops || std::string(argv[i]) == "-ops";
         pcd = pcd || std::string(argv[i]) == "-pcd";
         pcdraw = pcdraw || std::string(argv[i]) == "-pcdraw";
+        noStage = noStage || std::string(argv[i]) == "-nostage";   // debug: the slice processor thread calls kt_slice_process itself
         ppm = ppm || std::string(argv[i]) == "-ppm";
         if (i + 1 < argc && std::string(argv[i]) == "-rank") rank = std::atoi(argv[i + 1]);
         if (i + 1 < argc && std::string(argv[i]) == "-world") world = std::atoi(argv[i + 1]);
@@ -157,6 +158,8 @@ int main(int argc, char** argv)
     // at the moment the tracker hands it over and fills its processedCloud on the GPU, on a context and stream of its own
     ThreadDataPack& pack = ThreadDataPack::get();
     pack.assignFrontend(tracker.getFrontend());
+    // the slice stage itself runs on the device behind every extraction (the operator path hands raw slices to the processor instead)
+    if (pcd && !ops && !noStage) tracker.getFrontend()->enableSliceStage(args.weightCull);
     CloudSliceProcessor sliceProcessor;
     std::thread sliceThread;
     if (pcd)

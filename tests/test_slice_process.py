@@ -119,3 +119,66 @@ def test_gpu_plane_and_edge_cases(ctx, oracle_mod):
     want = oracle_mod.slice_process(p[:300], 0, 1e-4)
     assert len(got) == len(want) == 300 and np.array_equal(got["xyz"], want["xyz"])
     assert len(abi.slice_process(ctx, p[:50], 255, 0.05)) == len(oracle_mod.slice_process(p[:50], 255, 0.05))
+
+
+@pytest.mark.gpu
+def test_stage_behind_the_tracker_shift_path(ctx, oracle_mod):
+    """kt_tracker_enable_slice_stage: every extracted slab goes through kt_slice_process_device on the tracker's slice stream -- the
+    slab stays on the device, its length is read from the extraction kernel's own counter -- and the processed points travel with the
+    slice.  They must be what the host-array entry point makes of the same raw slice (bit for bit: same kernels, same input order),
+    hence the oracle's; the raw slices, poses and volumes must not notice the stage."""
+    from kintinuous_amd import abi, synth
+    cam = synth.Camera.small(320, 240)
+    scene = synth.Scene("wall")
+    traj = synth.crabwalk_trajectory(420)
+    frames = [synth.render(scene, cam, *traj[i]) for i in range(50)]
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, 160, cam.fx, cam.fy, cam.cx, cam.cy, 7.0, 6, 2, 0, 0, 0, 0, 0, 0)
+
+    def run(stage):
+        trk = abi.Tracker(ctx, cfg)
+        if stage:
+            trk.enable_slice_stage(True, weight_cull=2)
+        for k, (d, rgb) in enumerate(frames):
+            trk.process_frame_host(d, rgb, 33333 * k)
+        trk.finalise()
+        out = dict(raw=[trk.slice(i) for i in range(trk.num_slices())], proc=[trk.slice_processed(i) for i in range(trk.num_slices())],
+                   pose=trk.pose(), vol=trk.volume().copy())
+        trk.close()
+        return out
+
+    a, b = run(True), run(False)
+    assert len(a["raw"]) == len(b["raw"]) >= 3 and all(p is None for p in b["proc"]) and all(p is not None for p in a["proc"])
+    assert np.array_equal(a["vol"], b["vol"]) and all(np.array_equal(x, y) for x, y in zip(a["pose"], b["pose"]))
+    leaf = 7.0 / 160
+    total = 0
+    for (raw, dim), proc, (raw_b, dim_b) in zip(a["raw"], a["proc"], b["raw"]):
+        assert dim == dim_b and len(raw) == len(raw_b)
+        want = abi.slice_process(ctx, raw, 2, leaf)
+        assert len(proc) == len(want) and proc.tobytes() == want.tobytes()
+        ref = oracle_mod.slice_process(raw.view(oracle_mod.POINT_DTYPE), 2, leaf)
+        assert len(ref) == len(proc) and np.array_equal(ref["xyz"], proc["xyz"]) and np.array_equal(ref["bgra"], proc["bgra"])
+        total += len(proc)
+    assert total > 3000
+
+
+@pytest.mark.gpu
+def test_device_entry_point_counts_on_the_device(ctx, oracle_mod):
+    """kt_slice_process_device with a device-resident count that is smaller than the host's bound, and one larger than the buffer (an
+    extraction that overflowed its capacity): the stage takes min(count, bound) points."""
+    import ctypes as C
+    from kintinuous_amd import abi
+    p = _plane_cloud(5000, seed=9)
+    ws = C.c_void_p()
+    abi._chk(abi.lib().kt_slice_ws_create(ctx.h, 8192, None, C.byref(ws)))
+    pts = ctx.upload(p)
+    for count, bound in ((3000, 5000), (9999, 4000)):
+        n_dev = ctx.upload(np.array([count], np.uint32))
+        abi._chk(abi.lib().kt_slice_process_device(ws, pts.ptr, n_dev.ptr, bound, 100, 0.05, 20))
+        n = C.c_size_t(0)
+        abi._chk(abi.lib().kt_slice_ws_count(ws, C.byref(n)))
+        want = oracle_mod.slice_process(p[: min(count, bound)], 100, 0.05)
+        assert n.value == len(want) > 0
+        got = np.zeros(n.value, abi.NPOINT_DTYPE)
+        abi._chk(abi.lib().kt_download(ctx.h, got.ctypes.data_as(C.c_void_p), abi.lib().kt_slice_ws_output(ws), got.nbytes))
+        assert np.array_equal(got["xyz"], want["xyz"]) and np.array_equal(got["bgra"], want["bgra"])
+    abi._chk(abi.lib().kt_slice_ws_destroy(ws))
