@@ -254,7 +254,7 @@ float kt_host_place_recognition_movement(const float Rcurr[9], const float cam[3
 void kt_host_reposition_cube(const float R[9], const float tlast[3], float volume_size, const float voxel_size[3], int thresh, float basis[3]);
 /* rmats_.back() (row-major 3x3), tvecs_.back(), currentGlobalCamera */
 int kt_tracker_get_pose(kt_tracker* t, float R_host[9], float t_host[3], float global_cam_host[3]);
-int kt_tracker_num_poses(kt_tracker* t);
+int kt_tracker_num_poses(kt_tracker* t);   /* (the kt_tracker_num_* counts are -1 when the frame in flight failed: kt_last_error()) */
 /* densePoseGraph[i]: timestamp, row-major 4x4 [R | currentGlobalCamera], isLoopPose */
 int kt_tracker_get_dense_pose(kt_tracker* t, int i, uint64_t* ts, float pose16_host[16], int* is_loop);
 int kt_tracker_get_voxel_wrap(kt_tracker* t, int wrap_host[3]);

@@ -209,6 +209,13 @@ def _ip(a) -> "C.Array":
     return (C.c_int * a.size)(*a.tolist())
 
 
+def _count(n: int) -> int:
+    """kt_tracker_num_*: a negative count means the frame in flight could not be completed"""
+    if n < 0:
+        raise KtError(lib().kt_last_error().decode() or "tracker error")
+    return n
+
+
 class DevBuf:
     """A raw device allocation owned through kt_malloc / kt_free."""
 
@@ -478,7 +485,7 @@ class Tracker:
         return np.array(R, dtype=np.float32).reshape(3, 3), np.array(t, dtype=np.float32), np.array(g, dtype=np.float32)
 
     def num_poses(self) -> int:
-        return lib().kt_tracker_num_poses(self.h)
+        return _count(lib().kt_tracker_num_poses(self.h))
 
     def dense_pose(self, i: int) -> Tuple[int, np.ndarray, bool]:
         ts, p, il = _u64(0), (C.c_float * 16)(), C.c_int(0)
@@ -491,7 +498,7 @@ class Tracker:
         return np.array(w, dtype=np.int32)
 
     def num_slices(self) -> int:
-        return lib().kt_tracker_num_slices(self.h)
+        return _count(lib().kt_tracker_num_slices(self.h))
 
     def slice_info(self, i: int) -> Tuple[int, int]:
         """(number of points, CloudSlice::Dimension) without downloading the points."""
@@ -510,7 +517,7 @@ class Tracker:
     def pr_samples(self):
         """[(utime, trans[3], rot[3,3], pose_index)] of the frames sampled for place recognition, in order."""
         out = []
-        for i in range(lib().kt_tracker_num_pr_samples(self.h)):
+        for i in range(_count(lib().kt_tracker_num_pr_samples(self.h))):
             ut, tr, ro, pi = _u64(0), (C.c_float * 3)(), (C.c_float * 9)(), C.c_int(0)
             _chk(lib().kt_tracker_pr_sample(self.h, i, C.byref(ut), tr, ro, C.byref(pi)))
             out.append((ut.value, np.array(tr, np.float32), np.array(ro, np.float32).reshape(3, 3), pi.value))

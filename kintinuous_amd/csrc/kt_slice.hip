@@ -220,31 +220,78 @@ __device__ __forceinline__ int lower_bound(const unsigned int* __restrict__ leaf
     return lo;
 }
 
-// one thread per down-sampled point: kNN over the leaf grid, covariance, normal, curvature
-__global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ cen, const unsigned int* __restrict__ leaf_key, const unsigned int* __restrict__ leaf_src,
+// One WAVE per down-sampled point: k nearest neighbours over the leaf grid, covariance, normal, curvature.
+// (One thread per point, the first cut, kept its neighbour list in per-thread arrays -- scratch memory -- and ran with less than one
+// wave per SIMD: 18.8 ms for a 63 k-point slab.)  The candidates of radius r -- the leaves in the (2r + 1)^3 cells around the point's
+// own: one binary search per x-row of cells, rows dealt to lanes -- go into a list in LDS with their squared distances; the k
+// nearest are then picked in ORDER, one per round, as the lexicographic successor of the previous pick under (distance, index) -- a
+// strided scan of the list per lane and a wave minimum -- which needs no bookkeeping of what has been taken.  The covariance is
+// accumulated in that order (the float sums depend on it), wave-uniformly.  Points that do not find k neighbours within 4 leaf sizes
+// (isolated points, a cloud that passed through the grid unfiltered) run the same successor search over ALL leaves.
+#define KT_SLICE_MAXC 729   // (2 * 4 + 1)^3 candidates
+#define KT_SLICE_RMAX 4
+struct slice_pick { float d; int j; };
+__device__ __forceinline__ bool slice_less(float da, int ja, float db, int jb) { return da < db || (da == db && ja < jb); }
+__device__ __forceinline__ slice_pick slice_wave_min(slice_pick p)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float d2 = __shfl_xor(p.d, off, 64);
+        const int j2 = __shfl_xor(p.j, off, 64);
+        if (slice_less(d2, j2, p.d, p.j)) { p.d = d2; p.j = j2; }
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void slice_normals(const float* __restrict__ cen, const unsigned int* __restrict__ leaf_key, const unsigned int* __restrict__ leaf_src,
                                                      const Params* __restrict__ prm, int k, const kt_point_xyzrgb* __restrict__ pts,
                                                      kt_point_xyzrgbnormal* __restrict__ out)
 {
-    const int q = blockIdx.x * 128 + threadIdx.x;
+    __shared__ float s_cd[4][KT_SLICE_MAXC];
+    __shared__ int s_cj[4][KT_SLICE_MAXC];
+    __shared__ float s_sd[4][KT_SLICE_K_MAX];
+    __shared__ int s_sj[4][KT_SLICE_K_MAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + wave;
     const int L = (int)prm->leaves;
     if (q >= L) return;
     const Grid g = prm->g;
     const int gridded = prm->gridded;
+    float* cd = s_cd[wave]; int* cj = s_cj[wave]; float* sd = s_sd[wave]; int* sj = s_sj[wave];
     const float px = cen[(size_t)q * 6], py = cen[(size_t)q * 6 + 1], pz = cen[(size_t)q * 6 + 2];
     const int kk = min(k, L);
-    float bd[KT_SLICE_K_MAX];
-    int bi[KT_SLICE_K_MAX];
-    int cnt = 0;
-    auto offer = [&](int j) {
+    auto dist2 = [&](int j) -> float {
         const float dx = cen[(size_t)j * 6] - px, dy = cen[(size_t)j * 6 + 1] - py, dz = cen[(size_t)j * 6 + 2] - pz;
-        const float d = (dx * dx + dy * dy) + dz * dz;
-        // ordered by (distance, index): candidates do not arrive in index order here, so ties compare the index explicitly
-        if (cnt == kk && !(d < bd[cnt - 1] || (d == bd[cnt - 1] && j < bi[cnt - 1]))) return;
-        int pos = cnt < kk ? cnt : kk - 1;
-        while (pos > 0 && (d < bd[pos - 1] || (d == bd[pos - 1] && j < bi[pos - 1]))) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; --pos; }
-        bd[pos] = d; bi[pos] = j;
-        if (cnt < kk) ++cnt;
+        return (dx * dx + dy * dy) + dz * dz;
     };
+    // the kk nearest of `nc` listed candidates (or of all L leaves when nc < 0), in (distance, index) order, into sd / sj; returns how many
+    auto select = [&](int nc) -> int {
+        slice_pick prev = {-1.0f, -1};
+        int found = 0;
+        for (int t = 0; t < kk; ++t) {
+            slice_pick best = {3.0e38f, 0x7fffffff};
+            if (nc >= 0) {
+                for (int i = lane; i < nc; i += 64) {
+                    const float d = cd[i]; const int j = cj[i];
+                    if (slice_less(prev.d, prev.j, d, j) && slice_less(d, j, best.d, best.j)) { best.d = d; best.j = j; }
+                }
+            } else {
+                for (int j = lane; j < L; j += 64) {
+                    const float d = dist2(j);
+                    if (slice_less(prev.d, prev.j, d, j) && slice_less(d, j, best.d, best.j)) { best.d = d; best.j = j; }
+                }
+            }
+            best = slice_wave_min(best);
+            if (best.j == 0x7fffffff) break;   // the candidates are exhausted
+            if (lane == 0) { sd[t] = best.d; sj[t] = best.j; }
+            prev = best;
+            ++found;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // lane 0's picks are read by every lane of the wave
+        __builtin_amdgcn_wave_barrier();
+        return found;
+    };
+    int cnt = 0;
     bool exact = false;
     if (gridded) {
         const unsigned int key = leaf_key[q];
@@ -253,28 +300,44 @@ __global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ c
         // Every point within r leaf sizes of p (per axis, hence also in Euclidean distance) lies in a cell at most r cells away from
         // p's: a point and its cell index satisfy floor((p + d) / leaf) - floor(p / leaf) <= r for 0 <= d <= r * leaf.  The centroid
         // of a leaf lies inside the leaf up to float rounding; the half-leaf margin below covers that.
-        for (int r = 2; r <= 6 && !exact; ++r) {
-            cnt = 0;
-            for (int dz = -r; dz <= r; ++dz) {
-                const int z = c2 + dz;
-                if (z < 0 || z >= g.div_b[2]) continue;
-                for (int dy = -r; dy <= r; ++dy) {
-                    const int y = c1 + dy;
-                    if (y < 0 || y >= g.div_b[1]) continue;
-                    // the 2r + 1 cells of this x-row have consecutive keys: one binary search, then a short scan
-                    const int x0 = max(0, c0 - r), x1 = min(g.div_b[0] - 1, c0 + r);
-                    const unsigned int k0 = (unsigned int)(x0 + y * g.div_b[0] + z * g.div_b[0] * g.div_b[1]), k1 = k0 + (unsigned int)(x1 - x0);
-                    for (int j = lower_bound(leaf_key, L, k0); j < L && leaf_key[j] <= k1; ++j) offer(j);
+        // (k = 20 neighbours on a surface need a disc of radius ~2.5 leaves: r = 2 never proves its answer, so the search starts at 3)
+        for (int r = (kk > 7 ? 3 : 2); r <= KT_SLICE_RMAX && !exact; ++r) {
+            const int side = 2 * r + 1, rows = side * side;
+            int nc = 0;   // wave-uniform
+            for (int row0 = 0; row0 < rows; row0 += 64) {
+                const int row = row0 + lane;
+                int lo = 0, n_here = 0;
+                if (row < rows) {
+                    const int y = c1 + row % side - r, z = c2 + row / side - r;
+                    if (y >= 0 && y < g.div_b[1] && z >= 0 && z < g.div_b[2]) {
+                        // the 2r + 1 cells of this x-row have consecutive keys: one binary search, then a short scan
+                        const int x0 = max(0, c0 - r), x1 = min(g.div_b[0] - 1, c0 + r);
+                        const unsigned int k0 = (unsigned int)(x0 + y * g.div_b[0] + z * g.div_b[0] * g.div_b[1]), k1 = k0 + (unsigned int)(x1 - x0);
+                        lo = lower_bound(leaf_key, L, k0);
+                        int hi = lo;
+                        while (hi < L && leaf_key[hi] <= k1) ++hi;
+                        n_here = hi - lo;
+                    }
                 }
+                // exclusive prefix of the rows' counts over the wave: where this lane's candidates go
+                int incl = n_here;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int up = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += up;
+                }
+                const int base = nc + incl - n_here;
+                for (int i = 0; i < n_here; ++i) { cd[base + i] = dist2(lo + i); cj[base + i] = lo + i; }   // (<= (2r + 1)^3 in all)
+                nc += __shfl(incl, 63, 64);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the list is written by the lanes that own the rows, scanned by all
+            __builtin_amdgcn_wave_barrier();
+            cnt = select(nc);
             const float reach = ((float)r - 0.5f) * g.leaf;
-            exact = cnt == kk && bd[cnt - 1] <= reach * reach;
+            exact = cnt == kk && sd[kk - 1] <= reach * reach;   // (sd: written by lane 0, read by every lane of the same wave: in order within a wave)
         }
     }
-    if (!exact) {   // isolated points, a cloud that passed through the grid unfiltered: every point is a candidate
-        cnt = 0;
-        for (int j = 0; j < L; ++j) offer(j);
-    }
+    if (!exact) cnt = select(-1);
     kt_point_xyzrgbnormal o;
     o.x = px; o.y = py; o.z = pz; o.pad0 = 1.0f;
     o.pad1 = 0.0f; o.pad2[0] = 0.0f; o.pad2[1] = 0.0f;
@@ -284,12 +347,15 @@ __global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ c
     o.a = gridded ? (unsigned char)0 : pts[leaf_src[q]].a;
     if (cnt < 3) {   // NormalEstimation: fewer than 3 neighbours -> NaN normal and curvature
         o.normal_x = o.normal_y = o.normal_z = o.curvature = __builtin_nanf("");
-        out[q] = o;
+        if (lane == 0) out[q] = o;
         return;
     }
+    // lane t fetches pick t (one round of loads for all of them); the sums then run over the picks in order, every lane alike
+    const int jt = sj[min(lane, cnt - 1)];
+    const float xt = cen[(size_t)jt * 6], yt = cen[(size_t)jt * 6 + 1], zt = cen[(size_t)jt * 6 + 2];
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = 0; t < cnt; ++t) {
-        const float x = cen[(size_t)bi[t] * 6], y = cen[(size_t)bi[t] * 6 + 1], z = cen[(size_t)bi[t] * 6 + 2];
+        const float x = __shfl(xt, t, 64), y = __shfl(yt, t, 64), z = __shfl(zt, t, 64);
         acc[0] += x * x; acc[1] += x * y; acc[2] += x * z; acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
         acc[6] += x; acc[7] += y; acc[8] += z;
     }
@@ -307,7 +373,7 @@ __global__ __launch_bounds__(128) void slice_normals(const float* __restrict__ c
     const float cos_theta = ((0.0f - px) * nv[0] + (0.0f - py) * nv[1]) + (0.0f - pz) * nv[2];   // viewpoint = sensor origin
     if (cos_theta < 0) { nv[0] *= -1; nv[1] *= -1; nv[2] *= -1; }
     o.normal_x = nv[0]; o.normal_y = nv[1]; o.normal_z = nv[2];
-    out[q] = o;
+    if (lane == 0) out[q] = o;
 }
 
 }  // namespace
@@ -392,8 +458,8 @@ extern "C" int kt_slice_process_device(kt_slice_ws* w, const kt_point_xyzrgb* po
     tb = w->tmp_bytes;
     KT_HIP(rocprim::inclusive_scan(w->tmp, tb, w->head, w->leafof, (size_t)nm, rocprim::plus<unsigned int>(), st));
     hipLaunchKernelGGL(slice_centroids, dim3(nb), dim3(256), 0, st, points_dev, w->keys[1], w->src[1], w->head, w->leafof, nm, w->cen, w->leaf_key, w->leaf_src, w->prm);
-    // NormalEstimation (kNN) + concatenateFields: one thread per leaf, the grid sized for the upper bound
-    hipLaunchKernelGGL(slice_normals, dim3(kt_div_up(nm, 128)), dim3(128), 0, st, w->cen, w->leaf_key, w->leaf_src, w->prm, k, points_dev, w->out);
+    // NormalEstimation (kNN) + concatenateFields: one wave per leaf, the grid sized for the upper bound
+    hipLaunchKernelGGL(slice_normals, dim3(kt_div_up(nm, 4)), dim3(256), 0, st, w->cen, w->leaf_key, w->leaf_src, w->prm, k, points_dev, w->out);
     KT_LAUNCH_CHECK();
     KT_HIP(hipMemcpyAsync(w->leaves_host, &w->prm->leaves, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     return KT_OK;

@@ -436,7 +436,7 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
         KT_TRY(dev_alloc(&rec, kt_integrate_rec_bytes(cfg->cols, cfg->rows), true));
         t->sets[q].rec = rec;
         unsigned char* dpm = nullptr;
-        KT_TRY(dev_alloc(&dpm, kt_integrate_dpmax_bytes(), true));
+        KT_TRY(dev_alloc(&dpm, kt_integrate_dpmax_bytes(cfg->cols, cfg->rows), true));
         t->sets[q].dpmax = (float*)dpm;
         KT_HIP(hipEventCreateWithFlags(&t->sets[q].ready, KT_EV_DEVICE));
         t->sets[q].user = -1;
@@ -1514,7 +1514,8 @@ int kt_tracker_finalise(kt_tracker* t)
     return KT_OK;
 }
 
-int kt_tracker_num_pr_samples(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? (int)t->pr_samples.size() : 0; }
+/* (a negative count = the frame in flight could not be completed: kt_last_error() says why) */
+int kt_tracker_num_pr_samples(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? (int)t->pr_samples.size() : -1; }
 int kt_tracker_pr_sample(kt_tracker* t, int i, uint64_t* utime, float* trans, float* rotation, int* pose_index)
 {
     KT_ARG(t && utime && trans && rotation && pose_index);
@@ -1545,7 +1546,7 @@ int kt_tracker_get_pose(kt_tracker* t, float* R, float* tv, float* gc)
     memcpy(gc, t->current_global_camera, sizeof(t->current_global_camera));
     return KT_OK;
 }
-int kt_tracker_num_poses(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? (int)t->poses.size() : 0; }
+int kt_tracker_num_poses(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? (int)t->poses.size() : -1; }
 int kt_tracker_get_dense_pose(kt_tracker* t, int i, uint64_t* ts, float* pose16, int* is_loop)
 {
     KT_ARG(t);
@@ -1563,7 +1564,7 @@ int kt_tracker_get_voxel_wrap(kt_tracker* t, int* wrap)
     memcpy(wrap, t->voxel_wrap, sizeof(t->voxel_wrap));
     return KT_OK;
 }
-int kt_tracker_num_slices(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? (int)t->slices.size() : 0; }
+int kt_tracker_num_slices(kt_tracker* t) { return (t && complete_frame(t) == KT_OK) ? (int)t->slices.size() : -1; }
 int kt_tracker_slice_info(kt_tracker* t, int i, size_t* n_points, int* dimension)
 {
     KT_ARG(t);

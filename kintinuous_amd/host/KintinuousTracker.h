@@ -278,7 +278,13 @@ class KintinuousTracker {
         }
         vWrapCopyUpdate();
         DeviceArray<PointXYZRGB> cloud = tsdf_volume_->fetchCloud(cloud_device_, vWrapCopy, color_volume_->data(), 0, N, 0, N, 0, N, voxelWrap);
-        pushSlice(cloud, CloudSlice::FINAL, lastRgbImage, lastDepthData);
+        PlaceRecognitionInput* pr = 0;
+        if (ConfigArgs::get().vocabFile.size()) {   // :1038-1045: the final slice takes a raw sample of the last frame with it
+            lastPlaceRecognitionRot = rmats_.back();
+            lastPlaceRecognitionTrans = currentGlobalCamera;
+            pr = addToPlaceRecognition(current_utime, lastPlaceRecognitionTrans, lastPlaceRecognitionRot, false);
+        }
+        pushSlice(cloud, CloudSlice::FINAL, lastRgbImage, lastDepthData, pr);
     }
 
     void reset()
@@ -314,6 +320,8 @@ class KintinuousTracker {
         computeGlobalCamera(0);
         lastRotation = rmats_.back();
         lastTranslation = tvecs_.back();
+        lastPlaceRecognitionTrans = currentGlobalCamera;   // :290-291
+        lastPlaceRecognitionRot = rmats_.back();
         parked = ConfigArgs::get().staticMode;
         tsdf_volume_->reset();
         color_volume_->reset();
@@ -370,6 +378,10 @@ class KintinuousTracker {
     CloudSlice* liveTsdf;             // KintinuousTracker.h:243-244
     CloudSlice* liveImage;
     uint64_t lagTime;
+    // the operator path's place-recognition tap (KintinuousTracker.cpp:601-624, 706-717, 1038-1045); the device-resident path keeps this
+    // state inside kt_tracker
+    kt::Matrix3f lastPlaceRecognitionRot;
+    kt::Vector3f lastPlaceRecognitionTrans;
     bool frameCompression = false;    // the compressed payloads of the frame being processed, as the log delivered them (:917-958)
     uint8_t* frameCompressedDepth = 0; int frameDepthSize = 0;
     uint8_t* frameCompressedImage = 0; int frameImageSize = 0;
@@ -493,7 +505,7 @@ class KintinuousTracker {
     {
         ktSafeCall(kt_tracker_get_pose(fast, lastRotation.data(), lastTranslation.data(), currentGlobalCamera.data()));
         const int before = global_time_;
-        global_time_ = kt_tracker_num_poses(fast);
+        global_time_ = kt::count(kt_tracker_num_poses(fast));
         for (int i = (int)densePoseGraph.size(); i < global_time_; ++i) {
             uint64_t ts;
             kt::Matrix4f pose;
@@ -504,7 +516,7 @@ class KintinuousTracker {
         }
         // the frames the library sampled for place recognition belong to the frame just processed: copy its bytes now
         std::vector<PlaceRecognitionInput*> sampleSlot;
-        const int np = kt_tracker_num_pr_samples(fast);
+        const int np = kt::count(kt_tracker_num_pr_samples(fast));
         for (; nextPrSample < np; ++nextPrSample) {
             uint64_t ut;
             kt::Vector3f tr;
@@ -529,7 +541,7 @@ class KintinuousTracker {
             std::lock_guard<std::mutex> lock(cloudMutex);
             cloudSignal.notify_all();
         }
-        const int ns = kt_tracker_num_slices(fast);
+        const int ns = kt::count(kt_tracker_num_slices(fast));
         for (; nextSlice < ns; ++nextSlice) {
             size_t n;
             int dim, prId;
@@ -664,14 +676,15 @@ class KintinuousTracker {
         latestDensePoseId++;
     }
 
-    void pushSlice(const DeviceArray<PointXYZRGB>& cloud, CloudSlice::Dimension dim, unsigned char* rgb, unsigned short* depth)
+    void pushSlice(const DeviceArray<PointXYZRGB>& cloud, CloudSlice::Dimension dim, unsigned char* rgb, unsigned short* depth,
+                   PlaceRecognitionInput* placeRecognitionFrame = 0)
     {
         CloudSlice::PointCloud* pts = new CloudSlice::PointCloud();
         cloud.download(*pts);
         std::lock_guard<std::mutex> lock(cloudMutex);
         cycledMutex = true;
         sharedCloudSlices.push_back(new CloudSlice(pts, dim, lastOdometry, currentGlobalCamera, rmats_.back(), current_utime,
-                                                   dim == CloudSlice::FINAL ? nowMicros() : lagTime, rgb, 0, 0, depth));
+                                                   dim == CloudSlice::FINAL ? nowMicros() : lagTime, rgb, 0, 0, depth, placeRecognitionFrame));
         cloudSignal.notify_all();
     }
 
@@ -721,6 +734,8 @@ class KintinuousTracker {
                 std::memcpy(firstImg, lastRgbImage, (size_t)n * 3);
                 firstDepthData.assignValue(firstDepth);
                 firstRgbImage.assignValue(firstImg);
+                if (ConfigArgs::get().vocabFile.size())   // :546-549: the first frame is always sampled
+                    addToPlaceRecognition(current_utime, lastPlaceRecognitionTrans, lastPlaceRecognitionRot, frameCompression);
                 std::lock_guard<std::mutex> lock(cloudMutex);
                 cloudSignal.notify_all();
             }
@@ -739,6 +754,20 @@ class KintinuousTracker {
             const kt::Vector3f vx = tsdf_volume_->getVoxelSize();
             kt_host_reposition_cube(Rcurr.data(), tvecs_.back().data(), Volume::get().getVolumeSize(), vx.data(),
                                     parked ? (ConfigArgs::get().staticMode ? N * 3 : N) : ConfigArgs::get().voxelShift, volumeBasis.data());
+        }
+        // place-recognition tap :601-624: sample now if the camera has moved enough since the last sample, else with the next slab
+        bool shiftSend = false, isLoopPose = false;
+        if (ConfigArgs::get().vocabFile.size()) {
+            const float place_recognition_movement = 0.15f;   // :76
+            if (kt_host_place_recognition_movement(Rcurr.data(), currentGlobalCamera.data(), lastPlaceRecognitionRot.data(), lastPlaceRecognitionTrans.data()) >=
+                place_recognition_movement) {
+                lastPlaceRecognitionRot = Rcurr;
+                lastPlaceRecognitionTrans = currentGlobalCamera;
+                addToPlaceRecognition(current_utime, lastPlaceRecognitionTrans, lastPlaceRecognitionRot, frameCompression);
+                isLoopPose = true;
+            } else {
+                shiftSend = true;
+            }
         }
         kt::Matrix3f Rcurr_inv;
         ktSafeCall(kt_host_mat33_inverse(Rcurr.data(), Rcurr_inv.data()));
@@ -769,8 +798,16 @@ class KintinuousTracker {
             DeviceArray<PointXYZRGB> cloud = tsdf_volume_->fetchCloud(cloud_device_, vWrapCopy, color_volume_->data(), lo[0], hi[0], lo[1],
                                                                       hi[1], lo[2], hi[2], voxelWrap);
             clearAxis(axis, back, w[axis], w[axis] + vt[axis]);
+            PlaceRecognitionInput* nextPlaceRecognitionFrame = 0;
+            if (shiftSend) {   // :706-717, :762-771, :816-825: the slab leaving the volume takes a sample with it
+                lastPlaceRecognitionRot = Rcurr;
+                lastPlaceRecognitionTrans = currentGlobalCamera;
+                nextPlaceRecognitionFrame = addToPlaceRecognition(current_utime, lastPlaceRecognitionTrans, lastPlaceRecognitionRot, frameCompression);
+                isLoopPose = true;
+                shiftSend = false;
+            }
             // mutexOutCloudBuffer :1156-1208
-            pushSlice(cloud, dim, 0, 0);
+            pushSlice(cloud, dim, 0, 0, nextPlaceRecognitionFrame);
             const float shift = voxel(axis) * (float)vt[axis];
             tvecs_.back()(axis) -= shift;
             w[axis] += vt[axis];
@@ -793,7 +830,7 @@ class KintinuousTracker {
         ++global_time_;
         lastRotation = Rcurr;
         lastTranslation = tvecs_.back();
-        pushDensePose(timestamp, Rcurr, false);
+        pushDensePose(timestamp, Rcurr, isLoopPose);
     }
 
     void clearAxis(int axis, bool back, int cur, int next)

@@ -218,8 +218,10 @@ class RawLogReader : public LogReader {
     {
         std::unique_lock<std::mutex> lock(m);
         for (;;) {
-            // frame g lives in slot g % R; the frames currentFrame - kKeep + 1 .. currentFrame - 1 handed out last are still in use
-            wake.wait(lock, [&] { return stopping || inputEnded || nextToRead + 1 >= numFrames || nextToRead <= currentFrame - kKeep + (int)ring.size(); });
+            // Frame g lives in slot g % R and evicts frame g - R.  currentFrame = 1 + the frame handed out last; that frame and the
+            // kKeep - 1 before it stay untouched -- exactly the lifetime of the synchronous reader (-dt 0), whose ring of kKeep slots
+            // overwrites frame f when frame f + kKeep is read: a frame survives kKeep - 1 further grabNext calls in both modes.
+            wake.wait(lock, [&] { return stopping || inputEnded || nextToRead + 1 >= numFrames || nextToRead < currentFrame - kKeep + (int)ring.size(); });
             if (stopping || inputEnded || nextToRead + 1 >= numFrames) return;
             const int g = nextToRead++;
             Slot& s = ring[(size_t)g % ring.size()];

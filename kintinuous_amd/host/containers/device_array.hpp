@@ -23,6 +23,13 @@ inline void safeCall(int status, const char* file, int line)
     std::exit(1);
 }
 #define ktSafeCall(expr) ::kt::safeCall((expr), __FILE__, __LINE__)
+// kt_tracker_num_*: a negative count reports a failed frame the same way
+inline int count(int n)
+{
+    if (n >= 0) return n;
+    std::fprintf(stderr, "%s\n", kt_last_error());
+    std::exit(1);
+}
 
 // the implicit "current device" of the reference (cudaSetDevice in TrackerInterface.cpp:48) made explicit
 class device {

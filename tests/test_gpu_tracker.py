@@ -485,7 +485,7 @@ def test_planned_voxel_pass_is_transparent(ctx, oracle_mod, monkeypatch, mode):
     assert hit["stats"][0] >= 10 and hit["stats"][0] > 2 * hit["stats"][1], hit["stats"]
     assert miss["stats"][0] == 0 and miss["stats"][1] >= 10, miss["stats"]
     assert off["stats"] == (0, 0)
-    assert len(hit["slices"]) >= 3
+    assert len(hit["slices"]) >= 2
     for other in (miss, off):
         assert len(other["poses"]) == len(hit["poses"]) and all(np.array_equal(a, b) for a, b in zip(other["poses"], hit["poses"]))
         assert np.array_equal(other["vol"], hit["vol"]) and np.array_equal(other["col"], hit["col"]) and other["wrap"] == hit["wrap"]

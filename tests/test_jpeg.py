@@ -190,6 +190,21 @@ def test_cxx_log_reader_decode_ahead(tool, tmp_path, layout):
             assert (rc, out) == (rc0, out0), (threads, err)
 
 
+@pytest.mark.parametrize("threads", [0, 1, 3, 8])
+def test_cxx_log_reader_frame_lifetime(tool, tmp_path, threads):
+    """A frame handed out by grabNext stays untouched for three further grabNext calls (the tracker keeps the current frame and two
+    earlier ones), with the synchronous reader and with every number of decode-ahead workers: klg_tool -hold re-checks the held
+    buffers after every read (the consumer is slower than the decoders here, so they run as far ahead as the ring lets them)."""
+    from kintinuous_amd import klg, synth
+    cam = synth.Camera.small(160, 120)
+    base = [synth.render(synth.Scene("room"), cam, *p) for p in synth.orbit_trajectory(6)]
+    frames = [(np.roll(base[k % 6][0], k, axis=1), np.roll(base[k % 6][1], k, axis=0)) for k in range(60)]
+    path = str(tmp_path / "hold.klg")
+    klg.write_klg(path, frames, cols=cam.cols, rows=cam.rows, compress_depth=True)
+    rc, out, err = _run_klg_tool(path, cam.cols, cam.rows, threads, ["-hold"])
+    assert rc == 0 and len(out.splitlines()) == 59, err
+
+
 @pytest.mark.parametrize("damage", ["truncated_payload", "truncated_header", "bad_zlib", "bad_jpeg", "bad_sizes", "short_count"])
 def test_cxx_log_reader_decode_ahead_on_damaged_logs(tool, tmp_path, damage):
     """A damaged log stops the decode-ahead reader at the same frame, with the same frames delivered before it, the same exit code and
