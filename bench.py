@@ -135,10 +135,10 @@ def main():
             if world > 1:
                 raise
             sys.stderr.write(f"bench: pose gather disabled ({e})\n")
-    # HIP events around the tsdf23 kernel only, on the stream it is launched on: every timed frame when the region is short,
-    # one frame in 8 otherwise (the timing itself then stays off the other 7).
+    # HIP events around the tsdf23 kernel only, on the stream it is launched on: one frame in 4 when the region is short (an event pair is
+    # two marker packets = ~10 us of bubbles in a 340 us frame: on every frame that is 3 % of the rate being measured), one in 8 otherwise.
     def prepare():   # between the warm-up and the first barrier
-        trk.enable_profiling(4 if args.steps <= 50 else 1)
+        trk.enable_profiling(5 if args.steps <= 50 else 1)
         trk.host_times(reset=True)
 
     def gather():   # the single RCCL gather of per-stream poses, inside the timed region
@@ -234,7 +234,7 @@ def main():
     # HBM-side traffic of the same kernel: PMC counters cannot be read from inside the process, so this is the committed rocprofv3
     # measurement of this workload (profiles/, collected and corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes,
     # FETCH_SIZE x 2 after calibration on this access width, WRITE_SIZE x 1, KiB units); null for workloads without one
-    traffic = committed_traffic(args.workload) if N == WORKLOADS[args.workload][2] else None
+    traffic, traffic_ratio = committed_traffic(args.workload) if N == WORKLOADS[args.workload][2] else (None, None)
 
     out = {
         "metric": "RGB-D frames/sec @640x480, 512^3 TSDF" if args.workload == "orbit512" else f"RGB-D frames/sec ({args.workload})",
@@ -260,7 +260,7 @@ def main():
                                 "slowest": [[int(i), round(float(periods[i]), 3)] for i in np.argsort(periods)[::-1][:4]]},
                    "slices_by_direction": slices_by_dim},
         "roofline": {"kernel": "kt_tsdf23_kernel", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
-                     "frac": achieved / peak, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_tsdf23,
+                     "frac": achieved / peak, "traffic": traffic, "traffic_ratio": traffic_ratio, "algorithmic_bytes_per_launch": bytes_tsdf23,
                      "avg_launch_ms": tsdf23_ms, "launches_timed": tsdf23_n, "U_voxels_updated": U, "S_raycast_steps": float(np.mean(Ss)),
                      # lanes the launch spends per updated voxel (first 16 timed frames): 64-lane wave z-steps over wave-columns of 32 x 2
                      # voxel columns, profiles/r02_tsdf23_whatif.md
@@ -304,15 +304,19 @@ def kt_volume_sha():
 
 def committed_traffic(workload):
     """HBM-side traffic of the tsdf23 launch: PMC counters cannot be read from inside the process, so this is the committed rocprofv3
-    measurement of this workload (profiles/r02_pmc_tsdf23_<workload>.json, written by scripts/pmc_traffic.sh: separate --pmc passes,
-    FETCH_SIZE x 2 after calibration on this access width, WRITE_SIZE x 1, as MI355X_MICROARCH.md prescribes).  It is only quoted for
-    the kernel it was measured on: the file records the sha256 of kt_volume.hip, and a stale measurement prints null."""
-    f = os.path.join(ROOT, "profiles", f"r02_pmc_tsdf23_{workload}.json")
+    measurement of this workload (profiles/r03_pmc_tsdf23_<workload>.json, written by scripts/pmc_traffic.sh: separate --pmc passes,
+    FETCH_SIZE x 2 after calibration on the kernel's own access pattern, WRITE_SIZE x 1, as MI355X_MICROARCH.md prescribes).  It is only
+    quoted for the kernel it was measured on: the file records the sha256 of kt_volume.hip, and a stale measurement prints null.
+    Returns (bytes per launch, bytes per launch / algorithmic bytes of the SAME launches): the profiled run covers other frames than
+    the timed region, so the ratio -- not the absolute -- is what compares with this line's algorithmic bytes."""
+    f = os.path.join(ROOT, "profiles", f"r03_pmc_tsdf23_{workload}.json")
     try:
         j = json.load(open(f))
-        return float(j["traffic_bytes_per_launch"]) if j.get("kt_volume_hip_sha16") == kt_volume_sha() else None
+        if j.get("kt_volume_hip_sha16") != kt_volume_sha():
+            return None, None
+        return float(j["traffic_bytes_per_launch"]), (float(j["traffic_ratio"]) if "traffic_ratio" in j else None)
     except Exception:
-        return None
+        return None, None
 
 
 def roofline_stress(ctx, abi, synth):
@@ -349,7 +353,7 @@ def roofline_stress(ctx, abi, synth):
     b = 12.0 * U + 12.0 * P
     achieved = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {"workload": "farwall768: 1280x960 synthetic far-wall sequence, static mode, 768^3 TSDF (BASELINE.json configs[4])", "kernel": "kt_tsdf23_kernel",
-            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": committed_traffic("farwall768"),
+            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": committed_traffic("farwall768")[0], "traffic_ratio": committed_traffic("farwall768")[1],
             "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n, "U_voxels_updated": U, "frame_ms": round(frame_ms, 3)}
 
 

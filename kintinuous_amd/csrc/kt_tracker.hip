@@ -159,7 +159,7 @@ struct kt_tracker {
     float *vgz_dev, *zs_dev;           // z tables of integrate (kt_integrate_tables)
     PoseMirror* mirror;                // pinned + mapped host memory
     unsigned int frame_seq;            // sequence number of the frame in flight (PoseMirror::seq)
-    long long prof_frames;             // frames seen with profiling == 1 (the tsdf23 event pair is recorded on every 8th)
+    long long prof_frames;             // frames seen with profiling == 1 / 5 (the tsdf23 event pair is recorded on every 8th / 4th)
     // profiling / counters (events double-buffered by frame parity: a pair is read one frame after it was recorded)
     double host_wait_s, host_call_s; long long host_calls;   // where the host thread spends a frame (kt_tracker_host_times)
     int profiling; int ev_par;
@@ -321,7 +321,7 @@ static void push_pose(kt_tracker* t, uint64_t ts, const float* R, int is_loop)
 // profiling modes: 0 off; 1 the tsdf23 event pair on every 8th frame (long timed regions: the timing stays off the other 7);
 // 2 every stage of every frame (serial breakdown pass); 4 the tsdf23 pair on EVERY frame (short timed regions)
 static bool prof_all(const kt_tracker* t) { return t->profiling == 2 || t->profiling == 3; }
-static bool prof_tsdf(const kt_tracker* t) { return t->profiling == 1 || t->profiling == 4; }
+static bool prof_tsdf(const kt_tracker* t) { return t->profiling == 1 || t->profiling == 4 || t->profiling == 5; }
 static int ev_begin(kt_tracker* t, int st)
 {
     if (prof_all(t) || (prof_tsdf(t) && st == ST_TSDF23)) {
@@ -339,7 +339,8 @@ static int ev_end(kt_tracker* t, int st)
 }
 static void tsdf23_hook_arm(kt_tracker* t)
 {
-    kt_tsdf23_hook.on = prof_all(t) || t->profiling == 4 || (t->profiling == 1 && (t->prof_frames++ % 8) == 0);
+    // 4: every frame; 1 / 5: every 8th / 4th (an event pair costs two marker packets = ~10 us of bubbles on the main stream)
+    kt_tsdf23_hook.on = prof_all(t) || t->profiling == 4 || (t->profiling == 1 && (t->prof_frames++ % 8) == 0) || (t->profiling == 5 && (t->prof_frames++ % 4) == 0);
     kt_tsdf23_hook.ev[0] = t->ev[t->ev_par][ST_TSDF23][0];
     kt_tsdf23_hook.ev[1] = t->ev[t->ev_par][ST_TSDF23][1];
     if (kt_tsdf23_hook.on) t->ev_rec[t->ev_par][ST_TSDF23] = true;
