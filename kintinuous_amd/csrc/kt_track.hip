@@ -364,22 +364,27 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
     }
     __shared__ float total[KT_RED_SLOTS];
     kt_pose_regs pr;
+    kt_pose_stage ps;
     const bool solve_here = a.mode == KT_MODE_ICP_SOLVE;
-    auto pre = [&]() { if (solve_here && threadIdx.x == 0 && !a.first) pr.load(a.state); };
+    auto pre = [&]() { if (solve_here && !a.first) ps.fetch(a.state); };
     if (!kt_reduce29(fn, a.cols * a.rows, a.granules, a.epoch, total, pre)) return;
+    __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES];
+    __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
+    if (solve_here) {   // ICPOdometry.cpp:127-128: the float sums widened into the double system, one element per lane
+        if (threadIdx.x < 42) sys[threadIdx.x] = (double)total[kt_sys_slot(threadIdx.x)];
+        if (!a.first) ps.park(pose_d, pose_f);
+        __syncthreads();
+        if (threadIdx.x == 0 && !a.first) pr.load(pose_d, pose_f);
+    }
     if (a.mode == KT_MODE_HOST) {
         if (threadIdx.x < KT_RED_SLOTS && (threadIdx.x < 29 || threadIdx.x == KT_RED_SLOTS - 1)) a.out29[threadIdx.x] = total[threadIdx.x];
     } else if (threadIdx.x == 0) {
-        float h[29];
-        for (int k = 0; k < 29; ++k) h[k] = total[k];
         if (a.mode == KT_MODE_ICP_SOLVE) {
             // ICPOdometry.cpp:127-178
-            double dA[36], db[6];
-            kt_unpack29_d(h, dA, db);
-            a.state->last_residual[0] = h[27];
-            a.state->last_residual[1] = h[28];
+            a.state->last_residual[0] = total[27];
+            a.state->last_residual[1] = total[28];
             if (a.keep29)
-                for (int k = 0; k < 29; ++k) a.state->icp29[k] = h[k];
+                for (int k = 0; k < 29; ++k) a.state->icp29[k] = total[k];
             if (a.first) {  // ICPOdometry.cpp:70-85: previous pose, its inverse, identity increment
 #pragma unroll
                 for (int k = 0; k < 16; ++k) pr.resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
@@ -390,12 +395,12 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
                 a.state->handoff_timeout = 0;
             }
             if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
-            kt_solve_and_update(a.state, pr, dA, db);
+            kt_solve_and_update(a.state, pr, sys);
 #ifdef KT_ICP_TIMING
             { const unsigned long long t5 = wall_clock64(); for (int q = 0; q < 7; ++q) a.state->icp29[q] = (float)(kt_ts[q + 0] - kt_ts[0]); a.state->icp29[7] = (float)(t5 - kt_ts[0]); }
 #endif
         } else {  // KT_MODE_ICP_STASH: joint RGB-D + ICP, the rgb kernel's epilogue combines and solves
-            for (int k = 0; k < 29; ++k) a.state->icp29[k] = h[k];
+            for (int k = 0; k < 29; ++k) a.state->icp29[k] = total[k];
             if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
         }
     }
@@ -792,26 +797,32 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_arg
     const kt_rgb_row fn{a, a.state ? a.state->sigma_val : a.sigma};
     __shared__ float total[KT_RED_SLOTS];
     kt_pose_regs pr;
-    auto pre = [&]() { if (a.mode != KT_MODE_HOST && threadIdx.x == 0) pr.load(a.state); };
+    kt_pose_stage ps;
+    auto pre = [&]() { if (a.mode != KT_MODE_HOST) ps.fetch(a.state); };
     if (!kt_reduce29(fn, a.cols * a.rows, a.granules, a.epoch, total, pre)) return;
     if (a.mode == KT_MODE_HOST) {
         if (threadIdx.x < KT_RED_SLOTS && (threadIdx.x < 29 || threadIdx.x == KT_RED_SLOTS - 1)) a.out29[threadIdx.x] = total[threadIdx.x];
-    } else if (threadIdx.x == 0) {
-        float h[29];
-        for (int k = 0; k < 29; ++k) h[k] = total[k];
-        double dA[36], db[6];
-        kt_unpack29_d(h, dA, db);
-        if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
-        if (a.mode == KT_MODE_JOINT_SOLVE) {
-            // RGBDOdometry.cpp:316-321: A = A_rgbd + w*w*A_icp, b = b_rgbd + w*b_icp, w = 10
-            double iA[36], ib[6];
-            kt_unpack29_d(a.state->icp29, iA, ib);
-            const double w = 10;
-            for (int k = 0; k < 36; ++k) dA[k] = dA[k] + w * w * iA[k];
-            for (int k = 0; k < 6; ++k) db[k] = db[k] + w * ib[k];
+    } else {
+        __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES];
+        __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
+        ps.park(pose_d, pose_f);
+        if (threadIdx.x < 42) {
+            const int slot = kt_sys_slot(threadIdx.x);
+            double v = (double)total[slot];
+            if (a.mode == KT_MODE_JOINT_SOLVE) {
+                // RGBDOdometry.cpp:316-321: A = A_rgbd + w*w*A_icp, b = b_rgbd + w*b_icp, w = 10
+                const double w = 10, vi = (double)a.state->icp29[slot];
+                v = threadIdx.x < 36 ? v + w * w * vi : v + w * vi;
+            }
+            sys[threadIdx.x] = v;
         }
-        kt_solve_and_update(a.state, pr, dA, db);
-        kt_update_krk(a.state, a.next_k);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            pr.load(pose_d, pose_f);
+            if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
+            kt_solve_and_update(a.state, pr, sys);
+            kt_update_krk(a.state, a.next_k);
+        }
     }
 }
 
@@ -830,23 +841,26 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
     if (kt_red_publishes()) kt_reduce29_publish2(fi, fr, ai.cols * ai.rows, ai.granules, ar.granules, ar.epoch, rows_icp, rows_rgb);
     if (!kt_red_sweeps()) return;
     kt_pose_regs pr;
-    if (threadIdx.x == 0) pr.load(ar.state);
+    kt_pose_stage ps;
+    ps.fetch(ar.state);
     {
         const unsigned long long* const gs[2] = {ai.granules, ar.granules};
         float* const ts[2] = {total_icp, total};   // the time-out flag lands in total[31]
         kt_reduce29_sweep_n<2>(gs, ar.epoch, ts);
     }
+    __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES];
+    __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
+    ps.park(pose_d, pose_f);
+    if (threadIdx.x < 42) {   // RGBDOdometry.cpp:316-321: A = A_rgbd + w*w*A_icp, b = b_rgbd + w*b_icp, w = 10
+        const int slot = kt_sys_slot(threadIdx.x);
+        const double w = 10, v = (double)total[slot], vi = (double)total_icp[slot];
+        sys[threadIdx.x] = threadIdx.x < 36 ? v + w * w * vi : v + w * vi;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        float h[29], hi[29];
-        for (int k = 0; k < 29; ++k) { h[k] = total[k]; hi[k] = total_icp[k]; }
-        double dA[36], db[6], iA[36], ib[6];
-        kt_unpack29_d(h, dA, db);
-        kt_unpack29_d(hi, iA, ib);
+        pr.load(pose_d, pose_f);
         if (total[KT_RED_SLOTS - 1] != 0.0f) ar.state->handoff_timeout = 1;
-        const double w = 10;
-        for (int k = 0; k < 36; ++k) dA[k] = dA[k] + w * w * iA[k];
-        for (int k = 0; k < 6; ++k) db[k] = db[k] + w * ib[k];
-        kt_solve_and_update(ar.state, pr, dA, db);
+        kt_solve_and_update(ar.state, pr, sys);
         kt_update_krk(ar.state, ar.next_k);
     }
 }

@@ -191,16 +191,28 @@ KT_HD void kt_compute_krk(const double* resultRt, const kt_level_k k, float* krk
 // Pivot-hoisted variant.  Eigen's unblocked LDLT is left-looking: step k only touches column k, so the diagonal entries it pivots on
 // at step k (rows >= k) are still the ORIGINAL ones -- the whole pivot sequence is a selection sort of the original diagonal (first
 // maximum wins, swaps included) and can be decided before any elimination arithmetic.  So: (1) simulate the swaps on the 6
-// diagonal values, (2) gather the symmetrically permuted system from an LDS copy with dynamic addresses, (3) factorise and solve
+// diagonal values, (2) gather the symmetrically permuted system from LDS with dynamic addresses, (3) factorise and solve
 // with compile-time indices and no swaps at all, (4) scatter x back through the permutation.  Every element sees exactly the
-// operations of kt_ldlt_solve6 in the same order; the code is ~40% shorter than with in-loop swaps.  `scratch`: 48 doubles of LDS owned by the calling thread.
-__device__ __forceinline__ void kt_ldlt_solve6_hoisted(const double (&Ain)[36], const double (&bin)[6], double (&x)[6], double* scratch)
+// operations of kt_ldlt_solve6 in the same order; the code is ~40% shorter than with in-loop swaps.
+// The system arrives IN LDS (round 3): 42 lanes of the sweeping workgroup each convert / combine one element (kt_sys_slot), so the
+// solving thread never holds the unpermuted matrix in registers -- with it the RGB-D epilogues (two unpacked systems live at once)
+// spilled 66-84 VGPRs to scratch in the serial tail.  sys: [0, 36) A row-major, [36, 42) b, [42, 48) scratch of the calling thread.
+#define KT_SYS_DOUBLES 48
+// packed index (reduce.cu:401-418: rows i = 0..5, columns j = i..6 in order) of element k of the LDS system
+__device__ __forceinline__ int kt_sys_slot(int k)
+{
+    int i = k / 6, j = k - 6 * i;
+    if (k >= 36) { i = k - 36; j = 6; }
+    else if (i > j) { const int t = i; i = j; j = t; }
+    return i * 7 - (i * (i - 1)) / 2 + (j - i);
+}
+__device__ __forceinline__ void kt_ldlt_solve6_hoisted(double* sys, double (&x)[6])
 {
     // (1) pivot order
     double dg[6];
     int idx[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { dg[i] = Ain[i * 6 + i]; idx[i] = i; }
+    for (int i = 0; i < 6; ++i) { dg[i] = sys[i * 7]; idx[i] = i; }
 #pragma unroll
     for (int K = 0; K < 5; ++K) {
         int p = K;
@@ -220,16 +232,12 @@ __device__ __forceinline__ void kt_ldlt_solve6_hoisted(const double (&Ain)[36], 
             }
     }
     // (2) permuted system A' = P A P^T (lower triangle), b' = P b
-#pragma unroll
-    for (int i = 0; i < 36; ++i) scratch[i] = Ain[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) scratch[36 + i] = bin[i];
     double A[36];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
-        for (int j = 0; j <= i; ++j) A[i * 6 + j] = scratch[idx[i] * 6 + idx[j]];
-        x[i] = scratch[36 + idx[i]];
+        for (int j = 0; j <= i; ++j) A[i * 6 + j] = sys[idx[i] * 6 + idx[j]];
+        x[i] = sys[36 + idx[i]];
     }
     // (3) LDL^T without pivoting, forward / diagonal / backward substitution
 #pragma unroll
@@ -264,9 +272,9 @@ __device__ __forceinline__ void kt_ldlt_solve6_hoisted(const double (&Ain)[36], 
         for (int j = i + 1; j < 6; ++j) x[i] -= A[j * 6 + i] * x[j];
     // (4) x = P^T x'
 #pragma unroll
-    for (int i = 0; i < 6; ++i) scratch[idx[i]] = x[i];
+    for (int i = 0; i < 6; ++i) sys[42 + idx[i]] = x[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) x[i] = scratch[i];
+    for (int i = 0; i < 6; ++i) x[i] = sys[42 + i];
 }
 
 // opt-in timing probes of the reduction tail (build with KT_EXTRA_FLAGS=-DKT_ICP_TIMING; scripts/icp_timing.py)
@@ -277,27 +285,48 @@ __shared__ unsigned long long kt_ts[8];
 #define KT_TS(i) do {} while (0)
 #endif
 
-// the part of the device state one Gauss-Newton step reads, held in registers (loaded early by the sweeping workgroup)
+// the part of the device state one Gauss-Newton step reads, held in registers by the solving thread
 struct kt_pose_regs {
     double resultRt[16];
     float Rprev[9], tprev[3];
-    __device__ __forceinline__ void load(const kt_track_state* st)
+    __device__ __forceinline__ void load(const double* d, const float* f)
     {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) resultRt[k] = st->resultRt[k];
+        for (int k = 0; k < 16; ++k) resultRt[k] = d[k];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rprev[k] = st->Rprev[k];
+        for (int k = 0; k < 9; ++k) Rprev[k] = f[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tprev[k] = st->tprev[k];
+        for (int k = 0; k < 3; ++k) tprev[k] = f[9 + k];
+    }
+};
+// ... fetched EARLY by the sweeping workgroup (before the sweep, so that the latency hides under it), one element per lane of the first
+// 28 -- the solving thread alone would hold 44 VGPRs across the sweep -- and handed over through LDS with the 6x6 system.
+#define KT_POSE_STAGE_DOUBLES 16
+#define KT_POSE_STAGE_FLOATS 12
+struct kt_pose_stage {
+    double d;
+    float f;
+    __device__ __forceinline__ void fetch(const kt_track_state* st)
+    {
+        const int t = threadIdx.x;
+        d = 0.0; f = 0.0f;
+        if (t < 16) d = st->resultRt[t];
+        else if (t < 25) f = st->Rprev[t - 16];
+        else if (t < 28) f = st->tprev[t - 25];
+    }
+    __device__ __forceinline__ void park(double* lds_d, float* lds_f) const   // followed by a __syncthreads() of the caller
+    {
+        const int t = threadIdx.x;
+        if (t < 16) lds_d[t] = d;
+        else if (t < 28) lds_f[t - 16] = f;
     }
 };
 
 // executed by ONE thread in the epilogue of the sweeping workgroup
-__device__ __forceinline__ void kt_solve_and_update(kt_track_state* st, kt_pose_regs& pr, double (&dA)[36], const double (&db)[6])
+__device__ __forceinline__ void kt_solve_and_update(kt_track_state* st, kt_pose_regs& pr, double* sys)
 {
-    __shared__ double solve_scratch[48];
     double x[6];
-    kt_ldlt_solve6_hoisted(dA, db, x, solve_scratch);
+    kt_ldlt_solve6_hoisted(sys, x);
     KT_TS(5);
     float Rcurr[9], tcurr[3];
     kt_pose_update(x, pr.resultRt, pr.Rprev, pr.tprev, Rcurr, tcurr);

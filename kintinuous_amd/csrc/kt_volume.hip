@@ -235,7 +235,7 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
 // Work decomposition of the voxel pass.  A unit of work ("task") is one wave-column -- 64 consecutive storage x of one y --
 // times one chunk of KT_TSDF_ZCHUNK z indices.  Only ~5% of the N^2/64 x N/16 units intersect the view frustum, so:
 //   1. kt_tsdf_interval_kernel   one thread per column: conservative z-interval inside the frustum; per wave-column the union;
-//   2. kt_tsdf_tasks_kernel      one workgroup: prefix sum over the wave-columns -> compact task list (no atomics);
+//   2. kt_tsdf_tasks_kernel      one workgroup: prefix sums over the wave-columns -> compact task list, dealt by cost (no atomics);
 //   3. kt_tsdf23_kernel          a fixed grid of KT_TSDF_WAVES waves strides over the list, so every wave that is launched
 //                                has voxels to update and the SIMDs stay full of loads in flight.
 // A task replays the incremental float walk of v_x / v_y from z = 0 to its first z (quirk A.17: the values are DEFINED by
@@ -255,6 +255,16 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
 // better on the sparse 512^3 orbit but 10% worse on the dense 1280x960 @ 768^3 case, where the 32-byte rows cost more than the lanes.)
 #define KT_WX 32
 #define KT_WY 2
+// cache policy of the voxel kernel's volume accesses (buffer aux bits: 2 = nt).  Measured in round 3 (profiles/r03_experiments.md): nt
+// loads +17 % launch time on the orbit (the words a frame updates were written by the frame before: nt gives up those hits), nt stores
+// within noise on both workloads.
+#ifndef KT_TSDF_LD_AUX
+#define KT_TSDF_LD_AUX 0
+#endif
+#ifndef KT_TSDF_ST_AUX
+#define KT_TSDF_ST_AUX 0
+#endif
+#define KT_TASK_HEAD 16   // words of a task list's head: [0] number of tasks, [1 + k] first task of XCD k (k = 0..8)
 
 __device__ __forceinline__ int kt_wave_min(int v)
 {
@@ -467,56 +477,116 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
         walk0[(size_t)sy * N + sx] = kt_tsdf_walk_checkpoint(a.Ri.m, a.tx, a.ty, a.tz, a.cell_x, a.cell_y, a.cell_z, a.intr.fx, a.intr.fy, sx, sy, a.wx, a.wy, N, wz0);
 }
 
-// Pre-pass 2: compact task list.  One workgroup; thread t owns a contiguous run of wave-columns, counts their chunks, a block-wide
-// exclusive scan places them.  task = yg | xg << 16 | chunk << 24 (wave-column (xg, yg), kt_tsdf_interval_kernel).
-// Inside a run the tasks of two x-neighbouring wave-columns alternate chunk by chunk: the 4 waves of a workgroup then work on
-// (a, c), (b, c), (a, c + 1), (b, c + 1), i.e. on both 64-byte halves of the same 128-byte tsdf lines at the same time.
+// Pre-pass 2: compact task list, dealt by cost.  One workgroup; thread t owns a contiguous run of wave-columns; task = yg | xg << 16 |
+// chunk << 24 (wave-column (xg, yg), kt_tsdf_interval_kernel).  In list order the tasks of two x-neighbouring wave-columns alternate
+// chunk by chunk: the 4 waves of a workgroup then work on (a, c), (b, c), (a, c + 1), (b, c + 1), i.e. on both 64-byte halves of the
+// same 128-byte tsdf lines at the same time.  Head of the list (KT_TASK_HEAD words): [0] number of tasks, [1 + k] first task of XCD k.
+// Until round 3 the list was used in that order, cut into eighths by count.  But the voxel kernel of the 512^3 orbit is ONE task per resident wave, and the eight tasks that
+// share a SIMD differ in cost: the SIMDs of a launch finish +-20 % apart (profiles/r02_tsdf23_whatif.md) and the launch takes as long
+// as the slowest.  A task's cost is, to first order, its number of 4-step batches b (1..4), known here.  So: (1) XCD k takes the k-th
+// eighth of the list by COST, not by count (still a contiguous band of image rows for its L2); (2) inside an XCD the tasks are sorted
+// by b, most expensive first, stably -- position p goes to workgroup (p / 4) % 256, wave p % 4, and dispatch order puts workgroup j on
+// CU j % 32 (a performance assumption, nothing else): every SIMD then gets one task of each cost octile; (3) odd rows of 128 are
+// reversed (snake), so that the SIMD with the most expensive task of one round gets the cheapest of the next.  scripts/lane_model.py
+// (dealing section) models max / mean of the per-SIMD sums: 1.28 list order -> 1.09-1.22; measured (r03 call 10, same box): the
+// orbit launch alone 34.0 -> 31.3 us, the 768^3 launch 0.725 -> 0.699 ms, every parity test unchanged (the order of the tasks cannot
+// change a voxel: each is written by exactly one task).  The sort is stable, so neighbours in list order stay neighbours inside a class.
+// Counting sort without atomics: per-thread counters of the 32 (XCD, b) buckets in LDS, scanned by 16 waves.
 __global__ __launch_bounds__(1024) void kt_tsdf_tasks_kernel(const unsigned int* __restrict__ wrange, int M, int XG,
-                                                             unsigned int* __restrict__ tasks, unsigned int* __restrict__ task_count)
+                                                                      unsigned int* __restrict__ tasks, unsigned int* __restrict__ task_count)
 {
-    __shared__ unsigned int wave_tot[16];
+    constexpr int NB = KT_TSDF_ZCHUNK / KT_TSDF_UNROLL;          // batches of a full task
+    static_assert(NB == 4, "bucket layout assumes 4 batches per task");
+    __shared__ unsigned short cnt[32][1024];
+    __shared__ unsigned int wave_tot[16], btot[32], bbase[33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (((M + 1023) / 1024) + 1) & ~1;   // even: runs start on an even wave-column
+    const int per = (((M + 1023) / 1024) + 1) & ~1;
     const int i0 = min(M, tid * per), i1 = min(M, i0 + per);
-    unsigned int mine = 0;
-    for (int i = i0; i < i1; ++i) {
-        const unsigned int r = wrange[i];
-        const int z0 = (int)(r & 0xffffu), z1 = (int)(r >> 16);
-        if (z0 < z1) mine += (unsigned int)((z1 - 1) / KT_TSDF_ZCHUNK - z0 / KT_TSDF_ZCHUNK + 1);
-    }
-    unsigned int incl = mine;
+    // the thread's tasks in list order: fn(key, batches)
+    auto walk = [&](auto&& fn) {
+        for (int i = i0; i < i1; i += 2) {
+            int c0[2] = {1, 1}, c1[2] = {0, 0}, z0[2] = {0, 0}, z1[2] = {0, 0};
+            unsigned int key[2] = {0, 0};
+            for (int k = 0; k < 2; ++k) {
+                if (i + k >= i1) continue;
+                const unsigned int r = wrange[i + k];
+                z0[k] = (int)(r & 0xffffu); z1[k] = (int)(r >> 16);
+                if (z0[k] < z1[k]) { c0[k] = z0[k] / KT_TSDF_ZCHUNK; c1[k] = (z1[k] - 1) / KT_TSDF_ZCHUNK; }
+                key[k] = (unsigned int)((i + k) / XG) | ((unsigned int)((i + k) % XG) << 16);
+            }
+            const int lo = min(c0[0] <= c1[0] ? c0[0] : INT_MAX, c0[1] <= c1[1] ? c0[1] : INT_MAX);
+            const int hi = max(c0[0] <= c1[0] ? c1[0] : -1, c0[1] <= c1[1] ? c1[1] : -1);
+            for (int c = lo; c <= hi; ++c)
+                for (int k = 0; k < 2; ++k)
+                    if (c >= c0[k] && c <= c1[k]) {
+                        const int za = max(z0[k], c * KT_TSDF_ZCHUNK), zb = min(z1[k], (c + 1) * KT_TSDF_ZCHUNK);
+                        fn(key[k] | ((unsigned int)c << 24), (zb - za + KT_TSDF_UNROLL - 1) / KT_TSDF_UNROLL);
+                    }
+        }
+    };
+    unsigned int mine_w = 0, mine_n = 0;
+    walk([&](unsigned int, int b) { mine_w += (unsigned int)b; ++mine_n; });
+    // block scan of the weights
+    unsigned int incl = mine_w, incl_n = mine_n;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const unsigned int up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
+        const unsigned int up = __shfl_up(incl, off, 64), upn = __shfl_up(incl_n, off, 64);
+        if (lane >= off) { incl += up; incl_n += upn; }
     }
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
-    unsigned int base = 0, total = 0;
+    unsigned int wbase = 0, W = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
         const unsigned int v = wave_tot[w];
-        if (w < wave) base += v;
-        total += v;
+        if (w < wave) wbase += v;
+        W += v;
     }
-    unsigned int pos = base + incl - mine;
-    for (int i = i0; i < i1; i += 2) {
-        int c0[2] = {1, 1}, c1[2] = {0, 0};   // chunk range of the pair's two columns (empty: c0 > c1)
-        unsigned int key[2] = {0, 0};
-        for (int k = 0; k < 2; ++k) {
-            if (i + k >= i1) continue;
-            const unsigned int r = wrange[i + k];
-            const int z0 = (int)(r & 0xffffu), z1 = (int)(r >> 16);
-            if (z0 < z1) { c0[k] = z0 / KT_TSDF_ZCHUNK; c1[k] = (z1 - 1) / KT_TSDF_ZCHUNK; }
-            key[k] = (unsigned int)((i + k) / XG) | ((unsigned int)((i + k) % XG) << 16);
+    const unsigned int w_excl = wbase + incl - mine_w;
+    const unsigned int per_xcd_w = max(1u, (W + 7u) / 8u);
+    for (int b = 0; b < 32; ++b) cnt[b][tid] = 0;
+    {
+        unsigned int rw = w_excl;
+        walk([&](unsigned int, int b) { ++cnt[min(7u, rw / per_xcd_w) * 4u + (unsigned int)(NB - b)][tid]; rw += (unsigned int)b; });
+    }
+    __syncthreads();
+    // exclusive scan of every bucket's 1024 counters: wave w takes buckets w and w + 16, lane l the threads 16 l .. 16 l + 15
+    for (int b = wave; b < 32; b += 16) {
+        unsigned int v[16], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { v[q] = cnt[b][lane * 16 + q]; sum += v[q]; }
+        unsigned int in = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int up = __shfl_up(in, off, 64);
+            if (lane >= off) in += up;
         }
-        const int lo = min(c0[0] <= c1[0] ? c0[0] : INT_MAX, c0[1] <= c1[1] ? c0[1] : INT_MAX);
-        const int hi = max(c0[0] <= c1[0] ? c1[0] : -1, c0[1] <= c1[1] ? c1[1] : -1);
-        for (int c = lo; c <= hi; ++c)
-            for (int k = 0; k < 2; ++k)
-                if (c >= c0[k] && c <= c1[k]) tasks[pos++] = key[k] | ((unsigned int)c << 24);
+        unsigned int run = in - sum;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { cnt[b][lane * 16 + q] = (unsigned short)run; run += v[q]; }
+        if (lane == 63) btot[b] = in;
     }
-    if (tid == 0) *task_count = total;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int run = 0;
+        for (int b = 0; b < 32; ++b) { bbase[b] = run; run += btot[b]; }
+        bbase[32] = run;
+        task_count[0] = run;
+        for (int x = 0; x <= 8; ++x) task_count[1 + x] = x < 8 ? bbase[4 * x] : run;
+    }
+    __syncthreads();
+    {
+        unsigned int rw = w_excl;
+        walk([&](unsigned int key, int b) {
+            const unsigned int x = min(7u, rw / per_xcd_w), bucket = x * 4u + (unsigned int)(NB - b);
+            rw += (unsigned int)b;
+            const unsigned int start = bbase[4 * x], n = bbase[4 * x + 4] - start;
+            unsigned int p = bbase[bucket] - start + cnt[bucket][tid]++;
+            const unsigned int row = p >> 7;
+            if ((row & 1u) && (row + 1u) * 128u <= n) p = row * 128u + (127u - (p & 127u));
+            tasks[start + p] = key;
+        });
+    }
 }
 
 // One in-flight batch of KT_TSDF_UNROLL consecutive z steps of a wave: everything phase A produces for phase B.
@@ -544,8 +614,8 @@ __device__ __forceinline__ void kt_tsdf_load_voxel(const kt_tsdf23_args& a, cons
 {
     if constexpr (BUF) {
         const unsigned int zoff = (unsigned int)b.sz[u] * plane;   // elements; wave-uniform
-        b.tsdf_raw[u] = __builtin_amdgcn_raw_buffer_load_b16(m.vol, col_base * 2u, zoff * 2u, 0);
-        b.col[u] = __builtin_amdgcn_raw_buffer_load_b32(m.col, col_base * 4u, zoff * 4u, 0);
+        b.tsdf_raw[u] = __builtin_amdgcn_raw_buffer_load_b16(m.vol, col_base * 2u, zoff * 2u, KT_TSDF_LD_AUX);
+        b.col[u] = __builtin_amdgcn_raw_buffer_load_b32(m.col, col_base * 4u, zoff * 4u, KT_TSDF_LD_AUX);
     } else {
         b.tsdf_raw[u] = a.volume[b.off[u]];
         b.col[u] = *(const unsigned int*)&a.color[b.off[u]];
@@ -691,7 +761,7 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
                 const short packed = kt_pack_tsdf(__builtin_fmaf(tsdf_prev, weight_prev, tsdf) / (weight_prev + 1.0f));
 #endif
                 if (packed != b.tsdf_raw[u]) {   // an unchanged word is not written back
-                    if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b16(packed, m.vol, col_base * 2u, (unsigned int)b.sz[u] * plane * 2u, 0);
+                    if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b16(packed, m.vol, col_base * 2u, (unsigned int)b.sz[u] * plane * 2u, KT_TSDF_ST_AUX);
                     else a.volume[b.off[u]] = packed;
                     if (a.bricks && packed < 0) a.bricks[b.bz[u] + brick_xy] = 1;  // idempotent byte store, no atomics (a negative value
                 }                                                                  // that stays was flagged when it was first stored)
@@ -735,7 +805,7 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
             }
         }
         if (o != c) {   // a saturated free-space voxel in front of an unchanged pixel costs reads only
-            if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b32(o, m.col, col_base * 4u, (unsigned int)b.sz[u] * plane * 4u, 0);
+            if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b32(o, m.col, col_base * 4u, (unsigned int)b.sz[u] * plane * 4u, KT_TSDF_ST_AUX);
             else *(unsigned int*)&a.color[b.off[u]] = o;
         }
     }
@@ -767,7 +837,6 @@ __global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_ts
     if (kt_tsdf_pose_from_device(a)) return;
     const int N = a.N;
     const int lane = threadIdx.x & 63;
-    const unsigned int n_tasks = *a.task_count;
     const float* Ri = a.Ri.m;
     const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
     const float dvx = Ri[2] * a.cell_z * a.intr.fx;   // Rcurr_inv_0_z_scaled
@@ -777,11 +846,10 @@ __global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_ts
     float r8 = Ri[8];
     asm volatile("" : "+v"(r8));   // keep it in a VGPR: fma(r8, z_scaled, v_z) then takes the broadcast z_scaled straight from its SGPR
     unsigned int n_upd = 0, n_batches = 0, n_tasks_done = 0, n_img = 0;
-    // XCD-aware task order: workgroup b runs on XCD b % 8 (and each XCD has its own L2), so XCD k takes the k-th contiguous eighth of
-    // the list -- a band of y, i.e. a band of image rows whose 16-byte pixel records then stay in that one L2 -- and inside an XCD
-    // consecutive tasks (neighbouring chunks of one wave-column) go to the 4 waves of one workgroup.
-    const unsigned int per_xcd = (n_tasks + 7u) / 8u;
-    const unsigned int t_begin = (blockIdx.x & 7u) * per_xcd, t_end = min(t_begin + per_xcd, n_tasks);
+    // XCD-aware task order: workgroup b runs on XCD b % 8 (and each XCD has its own L2), so XCD k takes the k-th contiguous part of
+    // the list (equal shares of the cost, kt_tsdf_tasks_kernel) -- a band of y, i.e. a band of image rows whose 12-byte pixel records
+    // then stay in that one L2 -- and inside an XCD four consecutive tasks go to the 4 waves of one workgroup.
+    const unsigned int t_begin = a.task_count[1 + (blockIdx.x & 7u)], t_end = a.task_count[2 + (blockIdx.x & 7u)];
     for (unsigned int t = t_begin + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); t < t_end; t += (gridDim.x >> 3) * 4u) {
         const unsigned int task = __builtin_amdgcn_readfirstlane(a.tasks[t]);
         const int yg = (int)(task & 0xffffu), xg = (int)((task >> 16) & 0xffu), chunk = (int)(task >> 24);
@@ -895,7 +963,7 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
         KT_HIP(hipMalloc((void**)&s.wrange, sizeof(unsigned int) * wave_cols));
         KT_HIP(hipMalloc((void**)&s.walk0, sizeof(float2) * (size_t)N * N));
         KT_HIP(hipMalloc((void**)&s.tasks, sizeof(unsigned int) * wave_cols * kt_div_up(N, KT_TSDF_ZCHUNK)));
-        KT_HIP(hipMalloc((void**)&s.task_count, sizeof(unsigned int)));
+        KT_HIP(hipMalloc((void**)&s.task_count, sizeof(unsigned int) * KT_TASK_HEAD));
         KT_HIP(hipMalloc((void**)&s.vgz, sizeof(float) * 2 * N));
         s.zs = s.vgz + N;
         for (int k = 0; k < 2; ++k) {
@@ -934,7 +1002,7 @@ int kt_tsdf_plan_alloc(kt_tsdf_plan* p, int N)
     KT_HIP(hipMalloc((void**)&p->wrange, sizeof(unsigned int) * wave_cols));
     KT_HIP(hipMalloc((void**)&p->walk0, sizeof(float2) * (size_t)N * N));
     KT_HIP(hipMalloc((void**)&p->tasks, sizeof(unsigned int) * wave_cols * kt_div_up(N, KT_TSDF_ZCHUNK)));
-    KT_HIP(hipMalloc((void**)&p->task_count, sizeof(unsigned int)));
+    KT_HIP(hipMalloc((void**)&p->task_count, sizeof(unsigned int) * KT_TASK_HEAD));
     return KT_OK;
 }
 void kt_tsdf_plan_free(kt_tsdf_plan* p)

@@ -58,3 +58,76 @@ for name, m in (("exact hull of the updated voxels per column", upd), ("in-image
     for (WX, WY), ZC, B in itertools.product(((32, 2), (64, 1), (16, 4), (8, 8)), (8, 16), (1, 4)):
         t, n = lane_steps(z0, z1, WX, WY, ZC, B)
         print("  %2dx%d columns, %2d-z tasks, batches of %d: %.2fM lane-steps (U / lane-steps %.0f%%), %d tasks" % (WX, WY, ZC, B, t / 1e6, 100.0 * U / t, n))
+
+
+# ---- dealing of the tasks to the SIMDs (32x2, 16-z tasks, batches of 4, in-image hull + the exact hull as brackets) ----------------
+# kt_tsdf_tasks_kernel's order (wave-columns in index order, the chunks of two x-neighbours interleaved), XCD k takes the k-th eighth,
+# local wave = i % 1024 of the XCD's tasks, workgroup j = local wave / 4 on CU j % 32 (dispatch order; a performance assumption only).
+# cost of a task in "batch units": set-up 0.7 + 1 per batch that updates a voxel, 0.4 per batch that does not (profiles/r02_tsdf23_whatif.md)
+def task_list(z0, z1, m):
+    WX, WY, ZC, B = 32, 2, 16, 4
+    a0 = z0.reshape(N // WY, WY, N // WX, WX).min((1, 3))
+    a1 = z1.reshape(N // WY, WY, N // WX, WX).max((1, 3))
+    anyupd = m.reshape(N // B, B, N // WY, WY, N // WX, WX).any((1, 3, 5))      # [z batch][yg][xg]
+    XG, M = N // WX, (N // WX) * (N // WY)
+    per = ((M + 1023) // 1024 + 1) & ~1
+    out = []
+    for t in range(1024):
+        i0, i1 = min(M, t * per), min(M, t * per + per)
+        for i in range(i0, i1, 2):
+            rng = []
+            for k in (0, 1):
+                yg, xg = divmod(i + k, XG)
+                lo, hi = int(a0[yg, xg]), int(a1[yg, xg])
+                rng.append((yg, xg, lo, hi) if i + k < i1 and lo < hi else None)
+            cs = [c for r in rng if r for c in range(r[2] // ZC, (r[3] - 1) // ZC + 1)]
+            for c in sorted(set(cs)):
+                for r in rng:
+                    if r and r[2] // ZC <= c <= (r[3] - 1) // ZC:
+                        za, zb = max(r[2], c * ZC), min(r[3], (c + 1) * ZC)
+                        nb = -(-(zb - za) // B)
+                        hot = sum(bool(anyupd[min((za + q * B) // B, N // B - 1), r[0], r[1]]) for q in range(nb))
+                        out.append((0.7 + hot + 0.4 * (nb - hot), nb))
+    out = np.array(out)
+    return out[:, 0], out[:, 1]
+
+
+def simd_sums(cost, key, order, split_by_key=False):
+    T = len(cost)
+    sums = np.zeros((8, 128))
+    cum = np.concatenate(([0.0], np.cumsum(key)))
+    cuts = [int(np.searchsorted(cum, cum[-1] * x / 8)) for x in range(9)] if split_by_key else [x * T // 8 for x in range(9)]
+    for x in range(8):
+        idx = order(np.arange(cuts[x], cuts[x + 1]), key)
+        for pos, i in enumerate(idx):
+            lw = pos % 1024
+            sums[x, (lw // 4 % 32) * 4 + lw % 4] += cost[i]
+    return sums.ravel()
+
+
+def by_cost(idx, cost):      # stable: most expensive first, so that round r of the dispatch gets the r-th cost octile
+    return idx[np.argsort(-cost[idx], kind="stable")]
+
+
+def snake(idx, cost):        # sorted, then dealt boustrophedon over the 128 SIMDs of the XCD
+    s = idx[np.argsort(-cost[idx], kind="stable")]
+    out = np.empty_like(s)
+    n = len(s)
+    rows = -(-n // 128)
+    k = 0
+    for r in range(rows):
+        seg = s[r * 128:(r + 1) * 128]
+        out[k:k + len(seg)] = seg if r % 2 == 0 else seg[::-1]
+        k += len(seg)
+    # position p of `out` must land on SIMD (p // 4 % 32) * 4 + p % 4: a permutation of 0..127 per row, the same for every row
+    return out
+
+
+for name, m in (("exact hull", upd), ("in-image hull", inimg)):
+    z0, z1 = hull(m)
+    cost, nb = task_list(z0, z1, upd)
+    for oname, o, key, sp in (("shipped order", lambda i, c: i, cost, False), ("sorted by cost", by_cost, cost, False), ("sorted by cost, snake", snake, cost, False),
+                              ("sorted by batches", by_cost, nb, False), ("sorted by batches, snake", snake, nb, False),
+                              ("XCD split by batches, sorted by batches, snake", snake, nb, True)):
+        s = simd_sums(cost, key, o, sp)
+        print("dealing, %s, %s: %d tasks, SIMD sums mean %.2f p90 %.2f max %.2f (max / mean %.2f)" % (name, oname, len(cost), s.mean(), np.percentile(s, 90), s.max(), s.max() / s.mean()))
