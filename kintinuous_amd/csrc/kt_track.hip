@@ -144,15 +144,26 @@ __device__ __forceinline__ void kt_reduce29_publish2(const RowFnA& fa, const Row
         for (int p = tid; p < kcount * 32; p += KT_RED_THREADS) {
             const int kl = p >> 5, v = p & 31;
             const int i = t0 + v + (kb + kl) * KT_VT_TOTAL;
+            // both rows in stages, the loads of a stage issued together: two exposed memory latencies per pixel instead of four
+            const int ii = min(i, n - 1);
+            const auto term = fb.fetch_term(ii);
+            f3 vcurr, ncurr, vcurr_g, vprev_g, nprev_g;
+            bool inimg;
+            int g;
+            fa.fetch_curr(ii, vcurr, ncurr);
+            typename RowFnB::taps tp;
+            fb.fetch_taps(term, tp);
+            fa.project(vcurr, vcurr_g, inimg, g);
+            fa.fetch_prev(g, vprev_g, nprev_g);
             {
-                float rb[7];   // the short one first: its row is parked in LDS before the long one starts
-                const bool found_b = fb(min(i, n - 1), rb) && i < n;
+                float rb[7];   // the short one first: its row is parked in LDS before the long one's arithmetic starts
+                const bool found_b = fb.finish(term, tp, rb) && i < n;
 #pragma unroll
                 for (int q = 0; q < 7; ++q) rows_b[kl][q][v] = found_b ? rb[q] : 0.0f;
                 rows_b[kl][7][v] = found_b ? 1.0f : 0.0f;
             }
             float ra[7];
-            const bool found_a = fa(min(i, n - 1), ra) && i < n;
+            const bool found_a = fa.finish(ncurr, vcurr_g, vprev_g, nprev_g, inimg, ra) && i < n;
 #pragma unroll
             for (int q = 0; q < 7; ++q) rows_a[kl][q][v] = found_a ? ra[q] : 0.0f;
             rows_a[kl][7][v] = found_a ? 1.0f : 0.0f;
@@ -318,20 +329,32 @@ struct kt_icp_row {
     // search() + getProducts(), reduce.cu:213-277, for pixel i; fills row[7] (zeros when no correspondence), returns found.
     // Branch-free: the reference's early returns become predicates and the gather index of a rejected pixel is clamped to 0, so
     // two calls inlined back to back have all their loads issued together (one exposed latency instead of two).
-    __device__ __forceinline__ bool operator()(int i, float (&row)[7]) const
+    // In four stages, so that a caller with a second row to compute (kt_reduce29_publish2) can put the loads of both behind each other:
+    // fetch_curr -> project -> fetch_prev -> finish.  operator() is the four in sequence.
+    __device__ __forceinline__ void fetch_curr(int i, f3& vcurr, f3& ncurr) const
+    {
+        const int plane = a.cols * a.rows;
+        vcurr = {a.vmap_curr[i], a.vmap_curr[i + plane], a.vmap_curr[i + 2 * plane]};  // y * cols + x == i
+        ncurr = {a.nmap_curr[i], a.nmap_curr[i + plane], a.nmap_curr[i + 2 * plane]};
+    }
+    __device__ __forceinline__ void project(const f3& vcurr, f3& vcurr_g, bool& inimg, int& g) const
     {
         const int cols = a.cols, rows = a.rows;
-        const int plane = cols * rows;
-        const f3 vcurr = {a.vmap_curr[i], a.vmap_curr[i + plane], a.vmap_curr[i + 2 * plane]};  // y * cols + x == i
-        const f3 ncurr = {a.nmap_curr[i], a.nmap_curr[i + plane], a.nmap_curr[i + 2 * plane]};
-        const f3 vcurr_g = kt_add(kt_mul(Rcurr, vcurr), tcurr);
+        vcurr_g = kt_add(kt_mul(Rcurr, vcurr), tcurr);
         const f3 vcurr_cp = kt_mul(Rprev_inv, kt_sub(vcurr_g, tprev));
         const int ux = kt_f2i_rn(vcurr_cp.x * a.intr.fx / vcurr_cp.z + a.intr.cx);
         const int uy = kt_f2i_rn(vcurr_cp.y * a.intr.fy / vcurr_cp.z + a.intr.cy);
-        const bool inimg = !(ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0);
-        const int g = inimg ? uy * cols + ux : 0;
-        const f3 vprev_g = {a.vmap_g_prev[g], a.vmap_g_prev[g + plane], a.vmap_g_prev[g + 2 * plane]};
-        const f3 nprev_g = {a.nmap_g_prev[g], a.nmap_g_prev[g + plane], a.nmap_g_prev[g + 2 * plane]};
+        inimg = !(ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0);
+        g = inimg ? uy * cols + ux : 0;
+    }
+    __device__ __forceinline__ void fetch_prev(int g, f3& vprev_g, f3& nprev_g) const
+    {
+        const int plane = a.cols * a.rows;
+        vprev_g = {a.vmap_g_prev[g], a.vmap_g_prev[g + plane], a.vmap_g_prev[g + 2 * plane]};
+        nprev_g = {a.nmap_g_prev[g], a.nmap_g_prev[g + plane], a.nmap_g_prev[g + 2 * plane]};
+    }
+    __device__ __forceinline__ bool finish(const f3& ncurr, const f3& vcurr_g, const f3& vprev_g, const f3& nprev_g, bool inimg, float (&row)[7]) const
+    {
         const f3 ncurr_g = kt_mul(Rcurr, ncurr);
         const f3 dv = kt_sub(vprev_g, vcurr_g);
         const float dist = __builtin_sqrtf(kt_dot(dv, dv));
@@ -346,6 +369,16 @@ struct kt_icp_row {
         row[3] = found ? sxn.x : 0.0f; row[4] = found ? sxn.y : 0.0f; row[5] = found ? sxn.z : 0.0f;
         row[6] = found ? kt_dot(n_cp, kt_sub(s_cp, d_cp)) : 0.0f;
         return found;
+    }
+    __device__ __forceinline__ bool operator()(int i, float (&row)[7]) const
+    {
+        f3 vcurr, ncurr, vcurr_g, vprev_g, nprev_g;
+        bool inimg;
+        int g;
+        fetch_curr(i, vcurr, ncurr);
+        project(vcurr, vcurr_g, inimg, g);
+        fetch_prev(g, vprev_g, nprev_g);
+        return finish(ncurr, vcurr_g, vprev_g, nprev_g, inimg, row);
     }
 };
 
@@ -600,26 +633,30 @@ __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_re
         corres.diff = 0.f;
         corres.valid = 0;
         corres.pad[0] = corres.pad[1] = corres.pad[2] = 0;
+        // The reference's nested tests (reduce.cu:718-760) as predicates: the loads that do not depend on the pose (candidate flag, depth
+        // and intensity of this pixel) go out together, the two gathers at the projected pixel together behind them -- two exposed memory
+        // latencies per pixel instead of four; the index of a pixel that fails a test is clamped to 0.
+        const float d1 = a.next_depth[k];
+        const uint8_t ni = a.next_image[k];
         const bool candidate = PRE ? a.cand[k] != 0
                                    : kt_residual_candidate(a.next_image, a.dIdx, a.dIdy, a.next_depth, cols, rows, a.min_scale, i, j0);
-        if (candidate) {
+        if (__builtin_amdgcn_ballot_w64(candidate) != 0) {   // wave-uniform: no candidate among these 64 pixels, no arithmetic
             const int y = i, x = j0;
-            const float d1 = a.next_depth[y * cols + x];
             const float xf = (float)x, yf = (float)y;
             const float transformed_d1 = __builtin_fmaf(d1, __builtin_fmaf(K[6], xf, K[7] * yf) + K[8], kt[2]);
             const int u0 = kt_f2i_rn(__builtin_fmaf(d1, __builtin_fmaf(K[0], xf, K[1] * yf) + K[2], kt[0]) / transformed_d1);
             const int v0 = kt_f2i_rn(__builtin_fmaf(d1, __builtin_fmaf(K[3], xf, K[4] * yf) + K[5], kt[1]) / transformed_d1);
-            if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
-                const float d0 = a.last_depth[v0 * cols + u0];
-                const uint8_t li = a.last_image[v0 * cols + u0];
-                if (d0 > 0 && fabsf(transformed_d1 - d0) <= a.max_depth_delta && li != 0) {
-                    corres.zero_x = (int16_t)u0; corres.zero_y = (int16_t)v0;
-                    corres.one_x = (int16_t)x; corres.one_y = (int16_t)y;
-                    corres.diff = (float)a.next_image[y * cols + x] - (float)li;
-                    corres.valid = 1;
-                    cnt += 1;
-                    sig += (unsigned int)kt_f2i_rz(corres.diff * corres.diff);
-                }
+            const bool inimg = candidate && u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows;
+            const int gi = inimg ? v0 * cols + u0 : 0;
+            const float d0 = a.last_depth[gi];
+            const uint8_t li = a.last_image[gi];
+            if (inimg && d0 > 0 && fabsf(transformed_d1 - d0) <= a.max_depth_delta && li != 0) {
+                corres.zero_x = (int16_t)u0; corres.zero_y = (int16_t)v0;
+                corres.one_x = (int16_t)x; corres.one_y = (int16_t)y;
+                corres.diff = (float)ni - (float)li;
+                corres.valid = 1;
+                cnt += 1;
+                sig += (unsigned int)kt_f2i_rz(corres.diff * corres.diff);
             }
         }
         if (PRE && !a.write_all && !candidate) continue;   // still zero from the first iteration of this level in this frame
@@ -762,33 +799,50 @@ struct kt_rgb_args {
 struct kt_rgb_row {
     const kt_rgb_args& a;
     float sigma;
-    // RGBReduction::getProducts, reduce.cu:441-486
-    __device__ __forceinline__ bool operator()(int i, float (&row)[7]) const
+    // RGBReduction::getProducts, reduce.cu:441-486.  Branch-free like kt_icp_row (the reference's early return for an invalid DataTerm
+    // becomes a predicate, the gather indices of an invalid pixel are clamped to 0) and staged: fetch_term -> fetch_taps -> finish.
+    struct taps { float X, Y, Z, gx, gy; };
+    __device__ __forceinline__ kt_dataterm fetch_term(int i) const
+    {
+        const int4 raw = *(const int4*)&a.corres[i];
+        return *(const kt_dataterm*)&raw;
+    }
+    __device__ __forceinline__ void fetch_taps(const kt_dataterm& c, taps& t) const
+    {
+        const bool valid = c.valid != 0;
+        const int zi = valid ? c.zero_y * a.cols + c.zero_x : 0, oi = valid ? c.one_y * a.cols + c.one_x : 0;
+        const float* cp = &a.cloud[3 * zi];
+        t.X = cp[0]; t.Y = cp[1]; t.Z = cp[2];
+        t.gx = (float)a.dIdx[oi]; t.gy = (float)a.dIdy[oi];
+    }
+    __device__ __forceinline__ bool finish(const kt_dataterm& c, const taps& t, float (&row)[7]) const
     {
         const float flt_eps = 1.19209290E-07F;
-#pragma unroll
-        for (int q = 0; q < 7; ++q) row[q] = 0.0f;
-        const int4 raw = *(const int4*)&a.corres[i];
-        const kt_dataterm c = *(const kt_dataterm*)&raw;
-        if (c.valid == 0) return false;
-        const int cols = a.cols;
+        const bool valid = c.valid != 0;
         float w = sigma + fabsf(c.diff);
         w = w > flt_eps ? 1.0f / w : 1.0f;
         if (sigma == -1) w = 1;
-        row[6] = -w * c.diff;
-        const float* cp = &a.cloud[3 * (c.zero_y * cols + c.zero_x)];
-        const float X = cp[0], Y = cp[1], Z = cp[2];
+        const float r6 = -w * c.diff;
+        const float X = t.X, Y = t.Y, Z = t.Z;
         const float invz = (float)(1.0 / (double)Z);
-        const float dI_dx_val = w * a.sobel_scale * (float)a.dIdx[c.one_y * cols + c.one_x];
-        const float dI_dy_val = w * a.sobel_scale * (float)a.dIdy[c.one_y * cols + c.one_x];
+        const float dI_dx_val = w * a.sobel_scale * t.gx;
+        const float dI_dy_val = w * a.sobel_scale * t.gy;
         const float v0 = dI_dx_val * a.fx * invz;
         const float v1 = dI_dy_val * a.fy * invz;
         const float v2 = -__builtin_fmaf(v0, X, v1 * Y) * invz;
-        row[0] = v0; row[1] = v1; row[2] = v2;
-        row[3] = __builtin_fmaf(Y, v2, -(Z * v1));   // -Z*v1 + Y*v2 is canonicalised to Y*v2 - Z*v1 before contraction (oracle/_ref)
-        row[4] = __builtin_fmaf(Z, v0, -(X * v2));
-        row[5] = __builtin_fmaf(X, v1, -(Y * v0));   // likewise: X*v1 - Y*v0
-        return true;
+        row[0] = valid ? v0 : 0.0f; row[1] = valid ? v1 : 0.0f; row[2] = valid ? v2 : 0.0f;
+        row[3] = valid ? __builtin_fmaf(Y, v2, -(Z * v1)) : 0.0f;   // -Z*v1 + Y*v2 is canonicalised to Y*v2 - Z*v1 before contraction (oracle/_ref)
+        row[4] = valid ? __builtin_fmaf(Z, v0, -(X * v2)) : 0.0f;
+        row[5] = valid ? __builtin_fmaf(X, v1, -(Y * v0)) : 0.0f;   // likewise: X*v1 - Y*v0
+        row[6] = valid ? r6 : 0.0f;
+        return valid;
+    }
+    __device__ __forceinline__ bool operator()(int i, float (&row)[7]) const
+    {
+        const kt_dataterm c = fetch_term(i);
+        taps t;
+        fetch_taps(c, t);
+        return finish(c, t, row);
     }
 };
 
