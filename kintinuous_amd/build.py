@@ -81,7 +81,7 @@ def build_host(force: bool = False) -> str:
         return HOST_BIN
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
     # the .klg colour decoder on its own (no HIP dependency): used by the CPU tests
-    for src, out, libs in (("jpeg_tool.cpp", JPEG_TOOL, []), ("klg_tool.cpp", KLG_TOOL, ["-lz", "-pthread"])):
+    for src, out, libs in (("jpeg_tool.cpp", JPEG_TOOL, ["-lz"]), ("klg_tool.cpp", KLG_TOOL, ["-lz", "-pthread"])):
         r = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", os.path.join(HOST_DIR, src), "-o", out] + libs, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{src} build failed:\n{r.stderr}")

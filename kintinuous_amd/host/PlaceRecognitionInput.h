@@ -1,8 +1,9 @@
 // PlaceRecognitionInput.h -- one frame sampled for the loop-closure backend (frontend/PlaceRecognitionInput.h:27-214): the image and
 // depth bytes as the log delivered them (raw, or zlib depth + JPEG colour), the frame's time stamps and the camera pose of the sample.
-// compress(): the depth goes through zlib's compress2 at Z_BEST_SPEED exactly as in the reference; the colour image is handed to
-// cvEncodeImage there, which is OpenCV's business in the backend's thread and not restated -- here the raw image is kept and
-// `imageIsRaw` says so.  decompressImgTo / decompressDepthTo undo what the log (or compress()) did.
+// compress(): the depth goes through zlib's compress2 at Z_BEST_SPEED and the colour image through a baseline JPEG encoder at quality
+// 90, like the reference's cvEncodeImage(".jpg", ..., {CV_IMWRITE_JPEG_QUALITY, 90}) (JpegEncoder.h restates libjpeg's default
+// compression path: the bytes are libjpeg-turbo's, tests/test_jpeg.py) -- sequentially here, on two boost threads there.  A sample that
+// still holds raw pixels says so in `imageIsRaw`.  decompressImgTo / decompressDepthTo undo what the log (or compress()) did.
 #pragma once
 
 #include <stdint.h>
@@ -12,6 +13,7 @@
 
 #include "ConfigArgs.h"
 #include "JpegDecoder.h"
+#include "JpegEncoder.h"
 #include "LinearAlgebra.h"
 #include "Resolution.h"
 
@@ -41,6 +43,17 @@ class PlaceRecognitionInput {
         delete[] depthMap;
         depthMap = (unsigned short*)tmp;
         depthSize = (int)compressed_size;
+        if (imageIsRaw && rgbImage) {  // encodeJpeg, :208-224
+            std::vector<unsigned char> jpg;
+            if (kt::jpeg::encodeBGR(rgbImage, Resolution::get().cols(), Resolution::get().rows(), 90, jpg)) {
+                unsigned char* img = new unsigned char[jpg.size()];
+                std::memcpy(img, jpg.data(), jpg.size());
+                delete[] rgbImage;
+                rgbImage = img;
+                imageSize = (int)jpg.size();
+                imageIsRaw = false;
+            }
+        }
         isCompressed = true;
     }
     void decompressImgTo(unsigned char* target)  // :120-133

@@ -2,7 +2,8 @@
 independent numpy restatement of libjpeg's default decode path (kintinuous_amd/jpeg_ref.py): byte-identical output for every
 stream layout the encoder can produce; the integer IDCT path within 2 grey levels of a double-precision decode; decent PSNR
 against the source image.  Pinned against the real library as well: Pillow (libjpeg-turbo, the decoder OpenCV's cvDecodeImage
-wraps too) decodes our encoder's streams AND its own to exactly the bytes the C++ decoder produces."""
+wraps too) decodes our encoder's streams AND its own to exactly the bytes the C++ decoder produces.  The other direction too: the C++
+encoder behind PlaceRecognitionInput::compress() (host/JpegEncoder.h) writes exactly the bytes libjpeg-turbo's encoder writes."""
 import os
 import subprocess
 
@@ -158,6 +159,60 @@ def test_decoder_matches_libjpeg(tool, tmp_path, name, sub):
         pil = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
         got = _cxx_decode(tool, data, w, h, tmp_path, name=f"s{k}")
         assert np.array_equal(got, pil[..., ::-1]), (k, int((got != pil[..., ::-1]).sum()))
+
+
+def _encoder_images():
+    rng = np.random.default_rng(3)
+    out = dict(_images())
+    out["noise48x32"] = rng.integers(0, 256, (32, 48, 3), dtype=np.uint8)           # whole MCUs
+    out["noise17x9"] = rng.integers(0, 256, (9, 17, 3), dtype=np.uint8)             # dummy luma blocks right and below
+    out["noise24x40"] = rng.integers(0, 256, (40, 24, 3), dtype=np.uint8)           # odd number of luma block columns
+    out["pixel"] = rng.integers(0, 256, (1, 1, 3), dtype=np.uint8)
+    out["white"] = np.full((33, 31, 3), 255, np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("name", ["render", "noise", "ramp", "noise48x32", "noise17x9", "noise24x40", "pixel", "white"])
+def test_encoder_matches_libjpeg(tool, tmp_path, name):
+    """PlaceRecognitionInput::compress()'s JPEG half (host/JpegEncoder.h, the stand-in for cvEncodeImage(".jpg", quality 90)) against
+    libjpeg-turbo's own encoder through Pillow: the same BYTES -- markers, tables, entropy-coded data -- at the reference's quality and
+    at both ends of the scale, for MCU-aligned and ragged sizes (edge replication, dummy blocks)."""
+    import io
+    Image = _pillow()
+    bgr = np.ascontiguousarray(_encoder_images()[name])
+    h, w = bgr.shape[:2]
+    src = tmp_path / "in.bgr"
+    src.write_bytes(bgr.tobytes())
+    for q in (90, 50, 100, 5):
+        dst = tmp_path / f"q{q}.jpg"
+        r = subprocess.run([tool, "-e", str(src), str(w), str(h), str(q), str(dst)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(bgr[..., ::-1]), "RGB").save(buf, format="JPEG", quality=q, subsampling=2)
+        assert dst.read_bytes() == buf.getvalue(), (name, q)
+
+
+def test_place_recognition_input_compress_round_trip(tool, tmp_path):
+    """frontend/PlaceRecognitionInput.h:72-140 through the shell's class: compress() leaves zlib depth + a quality-90 JPEG (the bytes
+    libjpeg writes), decompressDepthTo returns the depth exactly, decompressImgTo what libjpeg decodes from that JPEG."""
+    import io
+    Image = _pillow()
+    from kintinuous_amd import synth
+    cam = synth.Camera.small(160, 120)
+    _, rgb = synth.render(synth.Scene("room"), cam, *synth.orbit_trajectory(2)[0])
+    bgr = np.ascontiguousarray(rgb)
+    h, w = bgr.shape[:2]
+    src, jpg, back = tmp_path / "in.bgr", tmp_path / "pr.jpg", tmp_path / "pr.bgr"
+    src.write_bytes(bgr.tobytes())
+    r = subprocess.run([tool, "-pr", str(src), str(w), str(h), str(jpg), str(back)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, (r.returncode, r.stderr)      # 3 = flags or the depth round trip wrong
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(bgr[..., ::-1]), "RGB").save(buf, format="JPEG", quality=90, subsampling=2)
+    assert jpg.read_bytes() == buf.getvalue()
+    pil = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+    got = np.frombuffer(back.read_bytes(), np.uint8).reshape(h, w, 3)
+    assert np.array_equal(got, pil[..., ::-1])
+    assert len(jpg.read_bytes()) < bgr.size // 4
 
 
 def _run_klg_tool(path, cols, rows, threads, extra=()):
