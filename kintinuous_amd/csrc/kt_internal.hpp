@@ -75,7 +75,7 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
 struct kt_tsdf_plan { unsigned int* wrange; unsigned int* tasks; unsigned int* task_count; float2* walk0; };
 int kt_tsdf_plan_alloc(kt_tsdf_plan* p, int N);
 void kt_tsdf_plan_free(kt_tsdf_plan* p);
-void kt_tsdf_plan_shape(int N, int* wx, int* wy, int* xg, int* yg);   // wave-column shape and grid (for the checkpoint workgroups)
+void kt_tsdf_plan_shape(int cols, int rows, int N, int* wx, int* wy, int* xg, int* yg);   // wave-column shape and grid of these launches (for the checkpoint workgroups)
 int kt_integrate_plan(hipStream_t stream, const kt_tsdf_plan* plan, const void* rec, const float* dpmax, int cols, int rows, const kt_intr* intr,
                       const float volume_size[3], const kt_mat33* Rinv_pred, const float t_pred[3], float tranc_dist, const int voxel_wrap[3], int N,
                       float theta, float tau);

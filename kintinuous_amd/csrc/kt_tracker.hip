@@ -792,7 +792,12 @@ __global__ __launch_bounds__(256) void kt_frame_setup_kernel(const kt_setup_args
         }
         return;
     }
-    if (threadIdx.x >= 64 || a.mode == 2) return;
+    // Two waves of workgroup 0 do the set-up proper, each from its own copy of the (cheap, deterministic) pose arithmetic: wave 0 writes
+    // what the device-side consumers read and walks the z tables; wave 1 tells the host -- its system-scope fence costs 2-3 us and would
+    // otherwise sit in front of the walk.
+    if (threadIdx.x >= 128 || a.mode == 2) return;
+    const int role = (int)(threadIdx.x >> 6);
+    if (role == 1 && a.mode != 0) return;
     float R[9], tv[3];
     int skip = 0;
     if (a.mode == 0) {
@@ -815,14 +820,9 @@ __global__ __launch_bounds__(256) void kt_frame_setup_kernel(const kt_setup_args
         for (int k = 0; k < 9; ++k) R[k] = a.R[k];
         for (int k = 0; k < 3; ++k) tv[k] = a.t[k];
     }
-    float Rinv[9];
-    kt_mat33_inverse(R, Rinv);
-    const int lane = threadIdx.x;
-    if (lane == 0) {
-        for (int k = 0; k < 9; ++k) { a.fp->R[k] = R[k]; a.fp->Rinv[k] = Rinv[k]; }
-        for (int k = 0; k < 3; ++k) a.fp->t[k] = tv[k];
-        a.fp->skip = skip;
-        if (a.mode == 0) {
+    const int lane = threadIdx.x & 63;
+    if (role == 1) {
+        if (lane == 0) {
             // what the host needs: the final pose and whether the fusion kernels run -- straight into its memory
             for (int k = 0; k < 9; ++k) a.mirror->R[k] = R[k];
             for (int k = 0; k < 3; ++k) a.mirror->t[k] = tv[k];
@@ -830,10 +830,18 @@ __global__ __launch_bounds__(256) void kt_frame_setup_kernel(const kt_setup_args
             a.mirror->handoff_timeout = a.st->handoff_timeout;
             __threadfence_system();
             __hip_atomic_store(&a.mirror->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            // (the tracking state's pose is left as the odometry wrote it: the checkpoint workgroups of this launch read it, and the
-            // next frame starts from the host's copy of the final pose)
-            a.st->fusion_skipped = skip;
         }
+        return;
+    }
+    float Rinv[9];
+    kt_mat33_inverse(R, Rinv);
+    if (lane == 2) {
+        for (int k = 0; k < 9; ++k) { a.fp->R[k] = R[k]; a.fp->Rinv[k] = Rinv[k]; }
+        for (int k = 0; k < 3; ++k) a.fp->t[k] = tv[k];
+        a.fp->skip = skip;
+        // (the tracking state's pose is left as the odometry wrote it: the checkpoint workgroups of this launch read it, and the
+        // next frame starts from the host's copy of the final pose)
+        if (a.mode == 0) a.st->fusion_skipped = skip;
     }
     // lane 0 walks v_g_z, lane 1 walks z_scaled: the same dependent float adds as tsdf23's z loop (tsdf_volume.cu:560-640),
     // 16 at a time in registers so the chain runs at add latency
@@ -878,7 +886,7 @@ static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv
         a.plan_wrange = pl.plan.wrange; a.plan_walk0 = pl.plan.walk0;
         memcpy(a.plan_R, pl.R, sizeof(a.plan_R)); memcpy(a.plan_t, pl.t, sizeof(a.plan_t));
         a.plan_theta = pl.theta; a.plan_tau = pl.tau;
-        kt_tsdf_plan_shape(t->N, &a.wcx, &a.wcy, &a.XG, &a.YG);
+        kt_tsdf_plan_shape(t->cfg.cols, t->cfg.rows, t->N, &a.wcx, &a.wcy, &a.XG, &a.YG);
         a.wx = t->v_wrap_copy[0] % t->N; a.wy = t->v_wrap_copy[1] % t->N;
         a.cell_x = t->volume_size[0] / t->N; a.cell_y = t->volume_size[1] / t->N;
         a.fx = t->intr.fx; a.fy = t->intr.fy;

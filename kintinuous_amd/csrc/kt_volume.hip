@@ -209,6 +209,7 @@ struct kt_tsdf23_args {
     // tau; a voxel's camera coordinates then move by eps <= pm_A * p_z + pm_B (pm_A = 1.01 theta kappa, pm_B = 1.01 tau, kappa =
     // |p| / p_z at the image corner), and every bound of the pre-pass is widened by that much.  Both 0: the pose is the frame's own.
     float pm_A, pm_B;
+    int wcl;                       // log2 of the wave-column's width in x: 5 = 32 x 2 columns, 4 = 16 x 4 (kt_tsdf_wcl)
 };
 
 // pose override shared by the two integrate kernels (wave-uniform scalar loads)
@@ -250,11 +251,23 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
 #ifndef KT_TSDF_WAVES
 #define KT_TSDF_WAVES 8192
 #endif
-// shape of a wave-column: 32 consecutive storage x of 2 consecutive y.  (64 x 1 wastes a third of the lanes at the left / right
-// frustum faces; 32 x 2 halves that and still moves 64 B of tsdf + 128 B of colour per row and access; 16 x 4 is another 5%
-// better on the sparse 512^3 orbit but 10% worse on the dense 1280x960 @ 768^3 case, where the 32-byte rows cost more than the lanes.)
-#define KT_WX 32
-#define KT_WY 2
+// Shape of a wave-column: 2^wcl consecutive storage x of 64 / 2^wcl consecutive y, a property of the launch (kt_tsdf23_args::wcl).
+// 64 x 1 wastes a third of the lanes at the left / right frustum faces; 32 x 2 halves that and still moves 64 B of tsdf + 128 B of
+// colour per row and access; 16 x 4 follows the frustum faces and depth discontinuities closer still (lane efficiency 0.59 -> 0.64 on
+// the 512^3 orbit: launch 31.0 -> 29.0 us) but its 32-byte rows cost the dense 1280x960 @ 768^3 case 4.6 % (0.720 -> 0.753 ms).
+// kt_tsdf_wcl picks per launch (rule and measurements: profiles/r03_experiments.md); KT_TSDF_WCX=16|32 in the environment overrides.
+static size_t kt_tsdf_max_wave_cols(int N)   // wave-columns of an N^3 volume under either shape
+{
+    const size_t a = (size_t)kt_div_up(N, 32) * kt_div_up(N, 2), b = (size_t)kt_div_up(N, 16) * kt_div_up(N, 4);
+    return a > b ? a : b;
+}
+static int kt_tsdf_wcl(int cols, int rows, int N)
+{
+    static const int forced = []() { const char* e = getenv("KT_TSDF_WCX"); const int v = e ? atoi(e) : 0; return v == 16 ? 4 : (v == 32 ? 5 : 0); }();
+    if (forced) return forced;
+    // pixels per voxel column: few -> the volume is sparse in the image (interval ends dominate) -> squarer wave-columns
+    return (double)cols * rows <= 1.5 * (double)N * N ? 4 : 5;
+}
 // cache policy of the voxel kernel's volume accesses (buffer aux bits: 2 = nt).  Measured in round 3 (profiles/r03_experiments.md): nt
 // loads +17 % launch time on the orbit (the words a frame updates were written by the frame before: nt gives up those hits), nt stores
 // within noise on both workloads.
@@ -290,8 +303,9 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
     // a workgroup covers 2 x 2 wave-columns
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
     const int xg = blockIdx.x * 2 + (wave_ & 1), yg = blockIdx.y * 2 + (wave_ >> 1);
-    const int sx = xg * KT_WX + (lane_ & (KT_WX - 1));
-    const int sy = yg * KT_WY + (lane_ / KT_WX);
+    const int WX = 1 << a.wcl, WY = 64 >> a.wcl;
+    const int sx = xg * WX + (lane_ & (WX - 1));
+    const int sy = yg * WY + (lane_ >> a.wcl);
     const bool column = sx < N && sy < N;
     // dynamic LDS, sized to the two maps of this image (19 + 1.2 KB at 640x480): with the 40 KB of the largest case allocated
     // statically only three workgroups fit a CU and the 1024 workgroups of a 512^3 launch need two rounds
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
         }
     }
     const int wz0 = kt_wave_min(z0), wz1 = kt_wave_max(z1);
-    const int XG = (N + KT_WX - 1) / KT_WX, YG = (N + KT_WY - 1) / KT_WY;
+    const int XG = (N + WX - 1) / WX, YG = (N + WY - 1) / WY;
     if (lane_ == 0 && xg < XG && yg < YG) wrange[(size_t)yg * XG + xg] = (unsigned int)wz0 | ((unsigned int)wz1 << 16);
     // Checkpoint of the incremental walk (quirk A.17: v_x, v_y are DEFINED by repeated float +=) at the wave-column's first z:
     // walked once per column here (wave-uniform trip count), so a voxel task only replays from there to its own chunk.
@@ -836,6 +850,7 @@ __global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_ts
     // a parked frame does nothing here: its in-stream pre-pass left an empty task list, but a plan made ahead of the frame did not
     if (kt_tsdf_pose_from_device(a)) return;
     const int N = a.N;
+    const int WX = 1 << a.wcl, WY = 64 >> a.wcl;
     const int lane = threadIdx.x & 63;
     const float* Ri = a.Ri.m;
     const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -a.tz);
@@ -853,11 +868,11 @@ __global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_ts
     for (unsigned int t = t_begin + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); t < t_end; t += (gridDim.x >> 3) * 4u) {
         const unsigned int task = __builtin_amdgcn_readfirstlane(a.tasks[t]);
         const int yg = (int)(task & 0xffffu), xg = (int)((task >> 16) & 0xffu), chunk = (int)(task >> 24);
-        const int sx = xg * KT_WX + (lane & (KT_WX - 1));
-        const int sy = min(yg * KT_WY + (lane / KT_WX), N - 1);   // a row past the volume (odd N) only repeats the last one, never live
-        const bool lane_ok = sx < N && yg * KT_WY + (lane / KT_WX) < N;
+        const int sx = xg * WX + (lane & (WX - 1));
+        const int sy = min(yg * WY + (lane >> a.wcl), N - 1);   // a row past the volume (odd N) only repeats the last one, never live
+        const bool lane_ok = sx < N && yg * WY + (lane >> a.wcl) < N;
         // the wave-column's union of column intervals, cut to this chunk (wave-uniform)
-        const unsigned int wr = __builtin_amdgcn_readfirstlane(a.wrange[(size_t)yg * ((N + KT_WX - 1) / KT_WX) + xg]);
+        const unsigned int wr = __builtin_amdgcn_readfirstlane(a.wrange[(size_t)yg * ((N + WX - 1) / WX) + xg]);
         const int zc = (int)(wr & 0xffffu);
         const int wz0 = max(zc, chunk * KT_TSDF_ZCHUNK), wz1 = min((int)(wr >> 16), (chunk + 1) * KT_TSDF_ZCHUNK);
         if (wz0 >= wz1) continue;
@@ -959,7 +974,7 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
         KT_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(s.vgz); (void)hipFree(s.wrange); (void)hipFree(s.tasks); (void)hipFree(s.task_count); (void)hipFree(s.walk0);
         s.vgz = s.zs = nullptr; s.wrange = s.tasks = s.task_count = nullptr; s.walk0 = nullptr; s.tabN = 0;
-        const size_t wave_cols = (size_t)kt_div_up(N, KT_WX) * kt_div_up(N, KT_WY);
+        const size_t wave_cols = kt_tsdf_max_wave_cols(N);
         KT_HIP(hipMalloc((void**)&s.wrange, sizeof(unsigned int) * wave_cols));
         KT_HIP(hipMalloc((void**)&s.walk0, sizeof(float2) * (size_t)N * N));
         KT_HIP(hipMalloc((void**)&s.tasks, sizeof(unsigned int) * wave_cols * kt_div_up(N, KT_TSDF_ZCHUNK)));
@@ -979,9 +994,10 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
 static int kt_tsdf_prepass(hipStream_t stream, const kt_tsdf23_args& a, unsigned int* wrange, float2* walk0, unsigned int* tasks, unsigned int* task_count)
 {
     const int N = a.N;
-    const int XG = kt_div_up(N, KT_WX), YG = kt_div_up(N, KT_WY);
+    const int WX = 1 << a.wcl, WY = 64 >> a.wcl;
+    const int XG = kt_div_up(N, WX), YG = kt_div_up(N, WY);
     const size_t maps_lds = a.dpmax && a.dpt_log2 ? sizeof(float) * (size_t)(((kt_div_up(a.cols, 1 << a.dpt_log2) * kt_div_up(a.rows, 1 << a.dpt_log2) + 3) & ~3) + kt_div_up(a.cols, 32) * kt_div_up(a.rows, 32)) : 0;
-    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(kt_div_up(N, 2 * KT_WX), kt_div_up(N, 2 * KT_WY)), dim3(256), maps_lds, stream, a, wrange, walk0);
+    hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(kt_div_up(N, 2 * WX), kt_div_up(N, 2 * WY)), dim3(256), maps_lds, stream, a, wrange, walk0);
     KT_LAUNCH_CHECK();
     hipLaunchKernelGGL(kt_tsdf_tasks_kernel, dim3(1), dim3(1024), 0, stream, wrange, XG * YG, XG, tasks, task_count);
     KT_LAUNCH_CHECK();
@@ -997,7 +1013,7 @@ static int kt_tsdf_prepass(hipStream_t stream, const kt_tsdf23_args& a, unsigned
 // voxel kernel runs from the plan, outside them the frame is parked and fused through the in-stream pre-pass instead.
 int kt_tsdf_plan_alloc(kt_tsdf_plan* p, int N)
 {
-    const size_t wave_cols = (size_t)kt_div_up(N, KT_WX) * kt_div_up(N, KT_WY);
+    const size_t wave_cols = kt_tsdf_max_wave_cols(N);
     memset(p, 0, sizeof(*p));
     KT_HIP(hipMalloc((void**)&p->wrange, sizeof(unsigned int) * wave_cols));
     KT_HIP(hipMalloc((void**)&p->walk0, sizeof(float2) * (size_t)N * N));
@@ -1010,7 +1026,11 @@ void kt_tsdf_plan_free(kt_tsdf_plan* p)
     (void)hipFree(p->wrange); (void)hipFree(p->walk0); (void)hipFree(p->tasks); (void)hipFree(p->task_count);
     memset(p, 0, sizeof(*p));
 }
-void kt_tsdf_plan_shape(int N, int* wx, int* wy, int* xg, int* yg) { *wx = KT_WX; *wy = KT_WY; *xg = kt_div_up(N, KT_WX); *yg = kt_div_up(N, KT_WY); }
+void kt_tsdf_plan_shape(int cols, int rows, int N, int* wx, int* wy, int* xg, int* yg)
+{
+    const int wcl = kt_tsdf_wcl(cols, rows, N);
+    *wx = 1 << wcl; *wy = 64 >> wcl; *xg = kt_div_up(N, *wx); *yg = kt_div_up(N, *wy);
+}
 
 int kt_integrate_plan(hipStream_t stream, const kt_tsdf_plan* plan, const void* rec, const float* dpmax, int cols, int rows, const kt_intr* intr,
                       const float volume_size[3], const kt_mat33* Rinv_pred, const float t_pred[3], float tranc_dist, const int voxel_wrap[3], int N,
@@ -1029,6 +1049,7 @@ int kt_integrate_plan(hipStream_t stream, const kt_tsdf_plan* plan, const void* 
     a.cols = cols; a.rows = rows; a.N = N;
     a.dpmax = dpmax;
     a.dpt_log2 = kt_dpt_log2(cols, rows);
+    a.wcl = kt_tsdf_wcl(cols, rows, N);
     // |p| / p_z of a point that projects into the (padded) image is at most kappa; eps <= (theta kappa p_z + tau (1 + theta)) / (1 - theta kappa)
     const float kx = (fmaxf(intr->cx, (float)cols - intr->cx) + 3.0f) / intr->fx, ky = (fmaxf(intr->cy, (float)rows - intr->cy) + 3.0f) / intr->fy;
     const float kappa = sqrtf(1.0f + kx * kx + ky * ky);
@@ -1102,6 +1123,7 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     a.pm_A = a.pm_B = 0.0f;
     a.dpmax = prepared_dpmax;
     a.dpt_log2 = kt_dpt_log2(cols, rows);
+    a.wcl = kt_tsdf_wcl(cols, rows, N);
     if (plan) {
         // the task plan was made ahead of the frame (kt_integrate_plan, conservative for every pose within its margins -- the caller
         // has checked that this frame's pose is) and its walk checkpoints by the frame's set-up kernel: only the voxel kernel is left
@@ -1305,6 +1327,8 @@ struct kt_rc {
         gx = (px < vx) ? (gx - 1) : gx;
         gy = (py < vy) ? (gy - 1) : gy;
         gz = (pz < vz) ? (gz - 1) : gz;
+        // (a short form of these divisions by a launch constant -- reciprocal + two residual corrections, verified exhaustively per
+        // divisor -- was measured in round 3: no difference in the kernel's time; profiles/r03_experiments.md)
         float fa = __builtin_fmaf(-((float)gx + 0.5f), a.cx_, px) / a.cx_;
         float fb = __builtin_fmaf(-((float)gy + 0.5f), a.cy_, py) / a.cy_;
         float fc = __builtin_fmaf(-((float)gz + 0.5f), a.cz_, pz) / a.cz_;
