@@ -61,6 +61,22 @@ struct f3 { float x, y, z; };
 __device__ __forceinline__ float kt_nan() { return __int_as_float(0x7fffffff); }  // limits.hpp quiet_NaN
 __device__ __forceinline__ bool kt_isnan(float x) { return x != x; }
 
+// a * b + c and a * b with a, b < 2^24 (low 32 bits of the 48-bit product): v_mad_u32_u24 / v_mul_u32_u24 run at full
+// rate, a 32 x 32 multiply (v_mul_lo_u32, v_mad_u64_u32) at a quarter of it.  As inline assembly: given the mul24 intrinsic LLVM proves
+// the operands small and turns it back into a generic 32-bit multiply, which it then selects as v_mad_u64_u32 / v_mul_lo_u32.
+__device__ __forceinline__ unsigned int kt_mad24(unsigned int a, unsigned int b, unsigned int c)
+{
+    unsigned int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned int kt_mul24(unsigned int a, unsigned int b)
+{
+    unsigned int r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // v_cvt_i32_f32: truncates, saturates, NaN -> 0  (== CUDA cvt.r*i.s32.f32 after the rounding step)
 __device__ __forceinline__ int kt_cvt_i32(float x)
 {

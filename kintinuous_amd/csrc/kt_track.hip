@@ -345,7 +345,7 @@ struct kt_icp_row {
         const int ux = kt_f2i_rn(vcurr_cp.x * a.intr.fx / vcurr_cp.z + a.intr.cx);
         const int uy = kt_f2i_rn(vcurr_cp.y * a.intr.fy / vcurr_cp.z + a.intr.cy);
         inimg = !(ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0);
-        g = inimg ? uy * cols + ux : 0;
+        g = inimg ? (int)kt_mad24((unsigned int)uy, (unsigned int)cols, (unsigned int)ux) : 0;   // (uy, ux < 2^24 inside the image)
     }
     __device__ __forceinline__ void fetch_prev(int g, f3& vprev_g, f3& nprev_g) const
     {

@@ -693,7 +693,9 @@ __device__ __forceinline__ void kt_tsdf_issue(const kt_tsdf23_args& a, const kt_
         int sz = zz + a.wz; if (sz >= N) sz -= N;
         b.bz[u] = (sz >> KT_BRICK_LOG2) * a.nb * a.nb;
         // coo_x, coo_y < 2^24 inside the image: the 24-bit multiply is exact there (and full rate, unlike v_mul_lo_u32)
-        const unsigned int pix = b.in_img[u] ? __umul24((unsigned int)coo_y, (unsigned int)a.cols) + (unsigned int)coo_x : 0u;
+        const unsigned int pix = b.in_img[u] ? kt_mad24((unsigned int)coo_y, (unsigned int)a.cols, (unsigned int)coo_x) : 0u;
+        // (the gather through a buffer descriptor -- offset by one more 24-bit multiply instead of the 64-bit v_mad_u64_u32 of this address
+        // -- was measured in round 3: launch time unchanged, 14 more spilled SGPRs)
         b.rec[u] = a.rec[pix];
         if constexpr (BUF) b.sz[u] = sz;
         else b.off[u] = col_base + (unsigned int)sz * plane;
@@ -1282,12 +1284,14 @@ struct kt_raycast_args {
 struct kt_rc {
     const kt_raycast_args& a;
     float rcx, rcy, rcz;   // RN(1 / cell) per axis, for voxel_fast
-    __device__ __forceinline__ size_t index(int x, int y, int z) const
+    // storage element of logical voxel (x, y, z).  32-bit, and every product through the 24-bit multiplier (v_mad_u32_u24, full rate; a
+    // 32 x 32 multiply is quarter rate on CDNA): kt_raycast_impl requires N <= 1536, so Z N + Y < N^2 < 2^24 and the result < N^3 < 2^32.
+    __device__ __forceinline__ unsigned int index(int x, int y, int z) const
     {
         int X = x + a.wx; if (X >= a.N) X -= a.N;
         int Y = y + a.wy; if (Y >= a.N) Y -= a.N;
         int Z = z + a.wz; if (Z >= a.N) Z -= a.N;
-        return (size_t)X + (size_t)Y * a.N + (size_t)Z * a.N * a.N;
+        return kt_mad24(kt_mad24((unsigned int)Z, (unsigned int)a.N, (unsigned int)Y), (unsigned int)a.N, (unsigned int)X);
     }
     __device__ __forceinline__ void voxel(float px, float py, float pz, int& gx, int& gy, int& gz) const
     {
@@ -1340,12 +1344,12 @@ struct kt_rc {
             int xx = gx + d + a.wx; if (xx >= N) xx -= N;
             int yy = gy + d + a.wy; if (yy >= N) yy -= N;
             int zz = gz + d + a.wz; if (zz >= N) zz -= N;
-            X[d] = (unsigned int)xx; Y[d] = (unsigned int)yy * (unsigned int)N; Z[d] = (unsigned int)zz * (unsigned int)N * (unsigned int)N;
+            X[d] = (unsigned int)xx; Y[d] = kt_mul24((unsigned int)yy, (unsigned int)N); Z[d] = kt_mul24(kt_mul24((unsigned int)zz, (unsigned int)N), (unsigned int)N);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int dx = (k >> 2) & 1, dy = (k >> 1) & 1, dz = k & 1;
-            const size_t i = (size_t)Z[dz] + Y[dy] + X[dx];
+            const unsigned int i = Z[dz] + Y[dy] + X[dx];
             if (CH < 0) r[k] = kt_unpack_tsdf(a.volume[i]);
             else {
                 const uchar4 c = a.color[i];
@@ -1507,7 +1511,7 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
                         int bx = kt_cvt_i32(cx) + awx; bx -= (bx >= a.nb) ? a.nb : 0;
                         int by = kt_cvt_i32(cy) + awy; by -= (by >= a.nb) ? a.nb : 0;
                         int bz = kt_cvt_i32(cz) + awz; bz -= (bz >= a.nb) ? a.nb : 0;
-                        if (s_bricks[(bz * a.nb + by) * a.nb + bx] == 0) {
+                        if (s_bricks[kt_mad24(kt_mad24((unsigned int)bz, (unsigned int)a.nb, (unsigned int)by), (unsigned int)a.nb, (unsigned int)bx)] == 0) {
                             // ray time from this sample to the (margin-shrunk) far face of the cell
                             const float dx = ((vdx > 0 ? hix : lox) - qx) * ivx, dy = ((vdy > 0 ? hiy : loy) - qy) * ivy,
                                         dz = ((vdz > 0 ? hiz : loz) - qz) * ivz;
@@ -1547,10 +1551,12 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
                     // getVoxel: floor(RN(p / cell)), via p * RN(1 / cell) when provably identical (see kt_rc::voxel_fast)
                     float qx = px * rcx, qy = py * rcy, qz = pz * rcz;
                     float flx = __builtin_floorf(qx), fly = __builtin_floorf(qy), flz = __builtin_floorf(qz);
+                    // every fraction farther than 2e-4 from an integer, every |q| < 1024: two max3 and two compares (a NaN coordinate
+                    // slips through the max, and floor(NaN) converts to voxel 0 on either path)
                     const float fx = qx - flx, fy = qy - fly, fz = qz - flz;
-                    const float lo = 2e-4f, hi = 1.0f - 2e-4f;
-                    const bool safe = fx > lo && fx < hi && fy > lo && fy < hi && fz > lo && fz < hi &&
-                                      fabsf(qx) < 1024.f && fabsf(qy) < 1024.f && fabsf(qz) < 1024.f;
+                    const float off = __builtin_fmaxf(__builtin_fmaxf(fabsf(fx - 0.5f), fabsf(fy - 0.5f)), fabsf(fz - 0.5f));
+                    const float big = __builtin_fmaxf(__builtin_fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
+                    const bool safe = off < 0.5f - 2e-4f && big < 1024.f;
                     if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
                         if (!safe) {
                             flx = __builtin_floorf(px / a.cx_);
@@ -1563,7 +1569,8 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
                     unsigned int X = ux + (unsigned int)a.wx; X -= (X >= uN) ? uN : 0u;
                     unsigned int Y = uy + (unsigned int)a.wy; Y -= (Y >= uN) ? uN : 0u;
                     unsigned int Z = uz + (unsigned int)a.wz; Z -= (Z >= uN) ? uN : 0u;
-                    gi[k] = inb[k] ? (Z * uN + Y) * uN + X : 0u;
+                    const unsigned int gidx = kt_mad24(kt_mad24(Z, uN, Y), uN, X);   // (garbage outside the volume: masked)
+                    gi[k] = inb[k] ? gidx : 0u;
                     t += a.time_step;
                 }
                 short v[KT_RC_BATCH];
