@@ -70,6 +70,13 @@ __device__ __forceinline__ unsigned int kt_mad24(unsigned int a, unsigned int b,
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// ... with a wave-uniform b (taken from its SGPR)
+__device__ __forceinline__ unsigned int kt_mad24u(unsigned int a, unsigned int b, unsigned int c)
+{
+    unsigned int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ unsigned int kt_mul24(unsigned int a, unsigned int b)
 {
     unsigned int r;

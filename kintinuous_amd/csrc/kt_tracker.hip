@@ -14,6 +14,9 @@
 #include <array>
 #include <deque>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <map>
 #include <thread>
 #include <vector>
@@ -123,8 +126,16 @@ struct kt_tracker {
     // Slice download off the frame's critical path.  The extraction kernel writes the points into pinned host memory (two buffers,
     // alternating), the count follows by an asynchronous copy and an event; a helper thread waits for the event and copies the n points
     // into the slice while the main thread has long gone on enqueueing the clears and the fusion.  Getters join (join_slice_jobs).
-    struct SliceJob { std::thread th; bool active; size_t slice; hipError_t status; };
+    // ONE worker thread per tracker, started at creation (where it also pays HIP's per-thread set-up): a thread per shift put its
+    // creation and, worse, its first hipSetDevice -- which takes the runtime's lock for up to a millisecond -- into the shift frame
+    // (frame period of the first shift of a run: 1.44 ms against 0.47-0.56 later; r03 call 16).
+    struct SliceJob { bool active; bool done; size_t slice; hipError_t status; };
     SliceJob jobs[2];
+    std::thread worker;
+    std::mutex wmu;
+    std::condition_variable wcv, wdone;
+    std::deque<std::function<void()>> wq;
+    bool wstop;
     kt_point_xyzrgb* cloud_host[2]; unsigned int* cloud_count_host[2]; hipEvent_t cloud_ev[2];
     int cloud_next;
     // The CloudSliceProcessor stage behind a shift, on the device (kt_slice.hip; kt_tracker_enable_slice_stage): the extraction then
@@ -446,7 +457,25 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     t->cloud_next = 0;
     t->slice_stage = false; t->slice_ws = nullptr;
     for (int b = 0; b < 2; ++b) { t->cloud_dev[b] = nullptr; t->cloud_count_dev[b] = nullptr; t->extracted[b] = nullptr; t->proc_host[b] = nullptr; t->proc_count_host[b] = nullptr; }
-    for (int b = 0; b < 2; ++b) { t->jobs[b].active = false; t->jobs[b].status = hipSuccess; t->cloud_host[b] = nullptr; t->cloud_count_host[b] = nullptr; t->cloud_ev[b] = nullptr; }
+    for (int b = 0; b < 2; ++b) { t->jobs[b].active = false; t->jobs[b].done = true; t->jobs[b].status = hipSuccess; t->cloud_host[b] = nullptr; t->cloud_count_host[b] = nullptr; t->cloud_ev[b] = nullptr; }
+    t->wstop = false;
+    {
+        const int device = ctx->device;
+        t->worker = std::thread([t, device]() {
+            (void)hipSetDevice(device);
+            std::unique_lock<std::mutex> lk(t->wmu);
+            for (;;) {
+                t->wcv.wait(lk, [t]() { return t->wstop || !t->wq.empty(); });
+                if (t->wq.empty()) return;   // stop requested and nothing left to do
+                std::function<void()> job = std::move(t->wq.front());
+                t->wq.pop_front();
+                lk.unlock();
+                job();
+                lk.lock();
+                t->wdone.notify_all();
+            }
+        });
+    }
     t->frames_observed = 0;
     t->out_ordinal = -1;
     KT_HIP(hipEventCreateWithFlags(&t->guard_ev, KT_EV_DEVICE));
@@ -514,6 +543,11 @@ int kt_tracker_destroy(kt_tracker* t)
     if (!t) return KT_OK;
     (void)hipStreamSynchronize(t->ctx->stream);
     (void)join_slice_jobs(t);
+    if (t->worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(t->wmu); t->wstop = true; }
+        t->wcv.notify_all();
+        t->worker.join();
+    }
     (void)hipFree(t->tsdf); (void)hipFree(t->color);
     for (int l = 0; l < KT_LEVELS; ++l) {
         for (int q = 0; q < KT_NSETS; ++q) { (void)hipFree(t->sets[q].depths[l]); (void)hipFree(t->sets[q].vmaps[l]); (void)hipFree(t->sets[q].nmaps[l]); }
@@ -934,7 +968,7 @@ static int join_slice_jobs(kt_tracker* t)
     for (int b = 0; b < 2; ++b) {
         kt_tracker::SliceJob& j = t->jobs[b];
         if (!j.active) continue;
-        if (j.th.joinable()) j.th.join();
+        { std::unique_lock<std::mutex> lk(t->wmu); t->wdone.wait(lk, [&j]() { return j.done; }); }
         j.active = false;
         if (j.status != hipSuccess) { kt_set_error("slice download: %s", hipGetErrorString(j.status)); rc = KT_ERR_HIP; }
     }
@@ -950,7 +984,7 @@ static int fetch_slice(kt_tracker* t, const int lo[3], const int hi[3], int dim)
     t->cloud_next ^= 1;
     kt_tracker::SliceJob& j = t->jobs[b];
     if (j.active) {   // the download that used this buffer two slices ago
-        if (j.th.joinable()) j.th.join();
+        { std::unique_lock<std::mutex> lk(t->wmu); t->wdone.wait(lk, [&j]() { return j.done; }); }
         j.active = false;
         if (j.status != hipSuccess) { kt_set_error("slice download: %s", hipGetErrorString(j.status)); return KT_ERR_HIP; }
     }
@@ -990,23 +1024,32 @@ static int fetch_slice(kt_tracker* t, const int lo[3], const int hi[3], int dim)
     const size_t cap = t->cloud_cap;
     hipEvent_t ev = t->cloud_ev[b];
     hipError_t* status = &j.status;
-    const int device = c->device;
     const kt_point_xyzrgbnormal* psrc = stage ? t->proc_host[b] : nullptr;
     const unsigned int* pcnt = stage ? t->proc_count_host[b] : nullptr;
-    j.th = std::thread([dst, src, cnt, cap, ev, status, device, psrc, pcnt]() {
-        hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipEventSynchronize(ev);   // the kernel's stores to host memory and the count are complete
-        if (e != hipSuccess) { *status = e; return; }
-        size_t n = (size_t)*cnt;
-        if (n > cap) n = cap;
-        dst->pts.assign(src, src + n);
-        if (psrc) {
-            size_t m = (size_t)*pcnt;
-            if (m > cap) m = cap;
-            dst->processed.assign(psrc, psrc + m);
-            dst->has_processed = true;
-        }
-    });
+    bool* done = &j.done;
+    std::mutex* mu = &t->wmu;
+    j.done = false;
+    {
+        std::lock_guard<std::mutex> lk(t->wmu);
+        t->wq.emplace_back([dst, src, cnt, cap, ev, status, psrc, pcnt, done, mu]() {
+            const hipError_t e = hipEventSynchronize(ev);   // the kernel's stores to host memory and the count are complete
+            if (e != hipSuccess) *status = e;
+            else {
+                size_t n = (size_t)*cnt;
+                if (n > cap) n = cap;
+                dst->pts.assign(src, src + n);
+                if (psrc) {
+                    size_t m = (size_t)*pcnt;
+                    if (m > cap) m = cap;
+                    dst->processed.assign(psrc, psrc + m);
+                    dst->has_processed = true;
+                }
+            }
+            std::lock_guard<std::mutex> lk2(*mu);
+            *done = true;
+        });
+    }
+    t->wcv.notify_one();
     return KT_OK;
 }
 

@@ -1310,9 +1310,7 @@ struct kt_rc {
         const float lo = 2e-4f, hi = 1.0f - 2e-4f;
         const bool safe = fx > lo && fx < hi && fy > lo && fy < hi && fz > lo && fz < hi &&
                           fabsf(qx) < 1024.f && fabsf(qy) < 1024.f && fabsf(qz) < 1024.f;
-        if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
-            if (!safe) { qx = px / a.cx_; qy = py / a.cy_; qz = pz / a.cz_; }
-        }
+        if (!safe) { qx = px / a.cx_; qy = py / a.cy_; qz = pz / a.cz_; }
         gx = kt_f2i_rd(qx); gy = kt_f2i_rd(qy); gz = kt_f2i_rd(qz);
     }
     // interpolateTrilineary / ...Color / ...Heat bodies, ray_caster.cu:160-296.  CH < 0: tsdf.
@@ -1557,19 +1555,17 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
                     const float off = __builtin_fmaxf(__builtin_fmaxf(fabsf(fx - 0.5f), fabsf(fy - 0.5f)), fabsf(fz - 0.5f));
                     const float big = __builtin_fmaxf(__builtin_fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
                     const bool safe = off < 0.5f - 2e-4f && big < 1024.f;
-                    if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
-                        if (!safe) {
-                            flx = __builtin_floorf(px / a.cx_);
-                            fly = __builtin_floorf(py / a.cy_);
-                            flz = __builtin_floorf(pz / a.cz_);
-                        }
+                    if (!safe) {   // (the compiler skips the block when no lane of the wave needs it)
+                        flx = __builtin_floorf(px / a.cx_);
+                        fly = __builtin_floorf(py / a.cy_);
+                        flz = __builtin_floorf(pz / a.cz_);
                     }
                     const unsigned int ux = (unsigned int)kt_cvt_i32(flx), uy = (unsigned int)kt_cvt_i32(fly), uz = (unsigned int)kt_cvt_i32(flz);
                     inb[k] = ux < uN && uy < uN && uz < uN;  // checkInds (negative indices wrap to huge unsigned values)
                     unsigned int X = ux + (unsigned int)a.wx; X -= (X >= uN) ? uN : 0u;
                     unsigned int Y = uy + (unsigned int)a.wy; Y -= (Y >= uN) ? uN : 0u;
                     unsigned int Z = uz + (unsigned int)a.wz; Z -= (Z >= uN) ? uN : 0u;
-                    const unsigned int gidx = kt_mad24(kt_mad24(Z, uN, Y), uN, X);   // (garbage outside the volume: masked)
+                    const unsigned int gidx = kt_mad24u(kt_mad24u(Z, uN, Y), uN, X);   // (garbage outside the volume: masked)
                     gi[k] = inb[k] ? gidx : 0u;
                     t += a.time_step;
                 }

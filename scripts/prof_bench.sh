@@ -1,4 +1,8 @@
+# rocprofv3 kernel trace of the default bench workload: prof_bench.sh [tag]  ->  gpurun_out/prof_<tag>/ + gpurun_out/prof_<tag>_bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r01_v12 -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_r01_v12_bench.log 2>&1
-tail -1 $GRAFT_REPO_ROOT/gpurun_out/prof_r01_v12_bench.log | cut -c1-200
-find $GRAFT_REPO_ROOT/gpurun_out/prof_r01_v12 -name "*kernel_stats.csv" | head -2
+R=$GRAFT_REPO_ROOT; T=${1:-r03_final}
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$T -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $R/gpurun_out/prof_${T}_bench.log 2>&1
+tail -1 $R/gpurun_out/prof_${T}_bench.log > $R/gpurun_out/prof_${T}_bench.json
+cut -c1-200 $R/gpurun_out/prof_${T}_bench.json
+cp "$(find $R/gpurun_out/prof_$T -name '*kernel_stats.csv' | head -1)" $R/gpurun_out/prof_${T}_kernel_stats.csv
+head -24 $R/gpurun_out/prof_${T}_kernel_stats.csv | cut -c1-160
