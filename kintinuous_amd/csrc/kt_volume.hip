@@ -505,16 +505,24 @@ __global__ __launch_bounds__(256) void kt_tsdf_interval_kernel(const kt_tsdf23_a
 // (dealing section) models max / mean of the per-SIMD sums: 1.28 list order -> 1.09-1.22; measured (r03 call 10, same box): the
 // orbit launch alone 34.0 -> 31.3 us, the 768^3 launch 0.725 -> 0.699 ms, every parity test unchanged (the order of the tasks cannot
 // change a voxel: each is written by exactly one task).  The sort is stable, so neighbours in list order stay neighbours inside a class.
-// Counting sort without atomics: per-thread counters of the 32 (XCD, b) buckets in LDS, scanned by 16 waves.
+// Counting sort without atomics and without memory traffic per task: a thread's whole run of wave-columns goes to ONE XCD (the one its
+// exclusive cost prefix falls into -- 1/1024 of the list is fine as a granule), so a thread needs four class counters, in registers; one
+// block scan of {cost, 4 class counts} gives every thread its offset inside each class of its XCD.  Two walks over the thread's
+// wave-columns (count, place).  Measured around it in round 3 (profiles/r03_experiments.md): 32 counters per thread in LDS touched per
+// task (27 us against 20 for this one and 8 for the unsorted list); the counts taken in the interval kernel + a one-workgroup scan + one
+// wave per pair placing its tasks by ballot ranks (three launches, 41 us of plan-stream work in all): both slower for the frame, because
+// whatever runs on the plan stream sits on CUs next to the odometry chain, whose 256 one-per-CU workgroups then run a second round.
 __global__ __launch_bounds__(1024) void kt_tsdf_tasks_kernel(const unsigned int* __restrict__ wrange, int M, int XG,
-                                                                      unsigned int* __restrict__ tasks, unsigned int* __restrict__ task_count)
+                                                             unsigned int* __restrict__ tasks, unsigned int* __restrict__ task_count)
 {
     constexpr int NB = KT_TSDF_ZCHUNK / KT_TSDF_UNROLL;          // batches of a full task
-    static_assert(NB == 4, "bucket layout assumes 4 batches per task");
-    __shared__ unsigned short cnt[32][1024];
-    __shared__ unsigned int wave_tot[16], btot[32], bbase[33];
+    static_assert(NB == 4, "class layout assumes 4 batches per task");
+    __shared__ unsigned int wave_tot[5][16];
+    __shared__ unsigned char xs[1024];           // XCD of every thread's run
+    __shared__ unsigned int cbase[4][9];         // exclusive class-count prefix at the first thread of XCD x (x = 8: totals)
+    __shared__ unsigned int bbase[33];           // first list position of bucket 4 x + class
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (((M + 1023) / 1024) + 1) & ~1;
+    const int per = (((M + 1023) / 1024) + 1) & ~1;               // even: runs start on an even wave-column
     const int i0 = min(M, tid * per), i1 = min(M, i0 + per);
     // the thread's tasks in list order: fn(key, batches)
     auto walk = [&](auto&& fn) {
@@ -538,69 +546,85 @@ __global__ __launch_bounds__(1024) void kt_tsdf_tasks_kernel(const unsigned int*
                     }
         }
     };
-    unsigned int mine_w = 0, mine_n = 0;
-    walk([&](unsigned int, int b) { mine_w += (unsigned int)b; ++mine_n; });
-    // block scan of the weights
-    unsigned int incl = mine_w, incl_n = mine_n;
+    // walk 1: cost and class counts (class q = NB - batches: 0 = most expensive)
+    unsigned int mine[5] = {0, 0, 0, 0, 0};
+    walk([&](unsigned int, int b) {
+        mine[0] += (unsigned int)b;
+        mine[1] += b == 4 ? 1u : 0u; mine[2] += b == 3 ? 1u : 0u; mine[3] += b == 2 ? 1u : 0u; mine[4] += b == 1 ? 1u : 0u;
+    });
+    unsigned int incl[5];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) incl[v] = mine[v];
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const unsigned int up = __shfl_up(incl, off, 64), upn = __shfl_up(incl_n, off, 64);
-        if (lane >= off) { incl += up; incl_n += upn; }
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    unsigned int wbase = 0, W = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        const unsigned int v = wave_tot[w];
-        if (w < wave) wbase += v;
-        W += v;
+        for (int v = 0; v < 5; ++v) {
+            const unsigned int up = __shfl_up(incl[v], off, 64);
+            if (lane >= off) incl[v] += up;
+        }
     }
-    const unsigned int w_excl = wbase + incl - mine_w;
-    const unsigned int per_xcd_w = max(1u, (W + 7u) / 8u);
-    for (int b = 0; b < 32; ++b) cnt[b][tid] = 0;
+    if (lane == 63) {
+#pragma unroll
+        for (int v = 0; v < 5; ++v) wave_tot[v][wave] = incl[v];
+    }
+    __syncthreads();
+    unsigned int excl[5], total[5];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        unsigned int base = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const unsigned int t = wave_tot[v][w];
+            if (w < wave) base += t;
+            tot += t;
+        }
+        excl[v] = base + incl[v] - mine[v];
+        total[v] = tot;
+    }
+    const unsigned int per_xcd_w = max(1u, (total[0] + 7u) / 8u);
+    const int my_x = (int)min(7u, excl[0] / per_xcd_w);
+    xs[tid] = (unsigned char)my_x;
+    __syncthreads();
     {
-        unsigned int rw = w_excl;
-        walk([&](unsigned int, int b) { ++cnt[min(7u, rw / per_xcd_w) * 4u + (unsigned int)(NB - b)][tid]; rw += (unsigned int)b; });
+        const int prev_x = tid == 0 ? -1 : (int)xs[tid - 1];
+        for (int x = prev_x + 1; x <= my_x; ++x) {     // (XCDs no run falls into get an empty part)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cbase[q][x] = excl[1 + q];
+        }
+        if (tid == 1023)
+            for (int x = my_x + 1; x <= 8; ++x) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cbase[q][x] = total[1 + q];
+            }
     }
     __syncthreads();
-    // exclusive scan of every bucket's 1024 counters: wave w takes buckets w and w + 16, lane l the threads 16 l .. 16 l + 15
-    for (int b = wave; b < 32; b += 16) {
-        unsigned int v[16], sum = 0;
+    if (tid < 64) {   // bucket sizes in (XCD, class) order -> exclusive scan over 32 lanes
+        const int x = (tid & 31) >> 2, q = tid & 3;
+        const unsigned int size = tid < 32 ? cbase[q][x + 1] - cbase[q][x] : 0u;
+        unsigned int in = size;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { v[q] = cnt[b][lane * 16 + q]; sum += v[q]; }
-        unsigned int in = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
+        for (int off = 1; off < 32; off <<= 1) {
             const unsigned int up = __shfl_up(in, off, 64);
             if (lane >= off) in += up;
         }
-        unsigned int run = in - sum;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { cnt[b][lane * 16 + q] = (unsigned short)run; run += v[q]; }
-        if (lane == 63) btot[b] = in;
+        if (tid < 32) bbase[tid] = in - size;
+        if (tid == 31) { bbase[32] = in; task_count[0] = in; task_count[9] = in; }
+        if (tid < 32 && q == 0) task_count[1 + x] = in - size;
     }
     __syncthreads();
-    if (tid == 0) {
-        unsigned int run = 0;
-        for (int b = 0; b < 32; ++b) { bbase[b] = run; run += btot[b]; }
-        bbase[32] = run;
-        task_count[0] = run;
-        for (int x = 0; x <= 8; ++x) task_count[1 + x] = x < 8 ? bbase[4 * x] : run;
-    }
-    __syncthreads();
-    {
-        unsigned int rw = w_excl;
-        walk([&](unsigned int key, int b) {
-            const unsigned int x = min(7u, rw / per_xcd_w), bucket = x * 4u + (unsigned int)(NB - b);
-            rw += (unsigned int)b;
-            const unsigned int start = bbase[4 * x], n = bbase[4 * x + 4] - start;
-            unsigned int p = bbase[bucket] - start + cnt[bucket][tid]++;
-            const unsigned int row = p >> 7;
-            if ((row & 1u) && (row + 1u) * 128u <= n) p = row * 128u + (127u - (p & 127u));
-            tasks[start + p] = key;
-        });
-    }
+    // walk 2: place.  Position inside the XCD's part = the bucket's start + the thread's offset in its class + a running count.
+    const unsigned int start = bbase[4 * my_x], n = bbase[4 * my_x + 4] - start;
+    unsigned int off0 = bbase[4 * my_x + 0] - start + (excl[1] - cbase[0][my_x]);
+    unsigned int off1 = bbase[4 * my_x + 1] - start + (excl[2] - cbase[1][my_x]);
+    unsigned int off2 = bbase[4 * my_x + 2] - start + (excl[3] - cbase[2][my_x]);
+    unsigned int off3 = bbase[4 * my_x + 3] - start + (excl[4] - cbase[3][my_x]);
+    walk([&](unsigned int key, int b) {
+        unsigned int p = b == 4 ? off0 : (b == 3 ? off1 : (b == 2 ? off2 : off3));
+        off0 += b == 4 ? 1u : 0u; off1 += b == 3 ? 1u : 0u; off2 += b == 2 ? 1u : 0u; off3 += b == 1 ? 1u : 0u;
+        const unsigned int row = p >> 7;
+        if ((row & 1u) && (row + 1u) * 128u <= n) p = row * 128u + (127u - (p & 127u));
+        tasks[start + p] = key;
+    });
 }
 
 // One in-flight batch of KT_TSDF_UNROLL consecutive z steps of a wave: everything phase A produces for phase B.
