@@ -1211,10 +1211,10 @@ static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool specu
     return KT_OK;
 }
 
-// Planning ahead.  Called at the end of process_frame(f) for the frame f + 1 that has been read ahead: the host knows the poses of
-// frames f - 1 and f - 2 (f itself has just been enqueued), predicts the pose of f + 1 by repeating the last motion increment twice
+// Planning ahead.  Called in process_frame(f), before f's odometry is enqueued, for the frame f + 1 that has been read ahead: the host
+// knows the poses of frames f - 1 and f - 2, predicts the pose of f + 1 by repeating the last motion increment twice
 // (body-frame rotation increment, global-camera translation increment), and enqueues the voxel kernel's pre-pass for that prediction
-// on plan_stream behind the frame's read-ahead -- where it runs next to the odometry iterations of frame f.  Margins: three times the
+// on plan_stream behind the frame's read-ahead -- where it runs next to the fusion kernels of frame f - 1.  Margins: three times the
 // error of the previous prediction on top of a floor, within caps.  The set-up kernel of frame f + 1 checks its pose against them;
 // a volume shift in between invalidates the plan (its storage wrap no longer matches).
 static int plan_ahead(kt_tracker* t, int set, long long ordinal)
@@ -1428,6 +1428,13 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     v_wrap_copy_update(t);
     if (read_ahead && t->plans[ordinal % 3].ordinal == ordinal && memcmp(t->plans[ordinal % 3].wrap, t->v_wrap_copy, sizeof(t->v_wrap_copy)) == 0)
         t->plan_sel = (int)(ordinal % 3);
+    // The frame that has been read ahead comes next: plan its voxel pass now, for the pose predicted two increments past the last one
+    // the host has seen (-d repositions the cube once the pose is known: nothing to plan for).  NOW = before this frame's odometry is
+    // enqueued: the GPU is still in the previous frame's voxel kernel and ray cast, which do not mind a few small workgroups next to
+    // them; enqueued after the odometry (the first cut) the pre-pass ran next to the iterations, each of whose 256 workgroups needs a
+    // whole CU, and cost them 10 us per frame.
+    if (t->plan_enabled && !t->pending.empty() && t->hist_n >= 2 && !t->cfg.dynamic_cube)
+        KT_TRY(plan_ahead(t, t->pending.front().set, ordinal + 1));
     // [C] odometry :564-572 -- every Gauss-Newton iteration is enqueued; the pose stays on the device
     KT_TRY(ev_begin(t, ST_ODOMETRY));
     if (icp) KT_TRY(icp_odometry(t));
@@ -1446,10 +1453,6 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     t->out_ordinal = ordinal;
     t->gt_utime = timestamp;
     if (!t->out_speculated) KT_TRY(complete_frame(t));   // observe the pose, reposition, shift if needed, enqueue the fusion
-    // the frame that has been read ahead comes next: plan its voxel pass now, for the pose predicted two increments past the last one
-    // the host has seen (-d repositions the cube once the pose is known: nothing to plan for)
-    if (t->plan_enabled && !t->pending.empty() && t->hist_n >= 2 && !t->cfg.dynamic_cube && t->outstanding)
-        KT_TRY(plan_ahead(t, t->pending.front().set, ordinal + 1));
     t->ev_par ^= 1;
     if (t->counting) {  // the counters are read back per frame: finish it before returning
         KT_TRY(complete_frame(t));
