@@ -535,7 +535,18 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     memset(t->mirror, 0, sizeof(PoseMirror));
     t->frame_seq = 0;
     t->prof_frames = 0;
-    return kt_tracker_reset(t);
+    KT_TRY(kt_tracker_reset(t));
+    // The kernels of the shift path run for the first time HERE, on the empty volume (a one-voxel extraction, one plane of zeros
+    // cleared to zero), not in the middle of the first shift frame: a kernel's first launch pays the runtime's lazy set-up for it.
+    {
+        const int zero[3] = {0, 0, 0};
+        KT_TRY(kt_extract_cloud_slice_async(ctx, t->tsdf, t->volume_size, t->cloud_host[0], t->cloud_cap, zero, t->color, 0, 1, 0, 1, 0, 1, 1, zero, t->N,
+                                            &ctx->counters[1]));
+        KT_TRY(kt_clear_volume(ctx, t->tsdf, 2, t->N, 0, 0, 0, 0));
+        KT_TRY(kt_clear_volume(ctx, t->color, 4, t->N, 0, 0, 0, 0));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return KT_OK;
 }
 
 int kt_tracker_destroy(kt_tracker* t)
@@ -1720,6 +1731,12 @@ int kt_tracker_enable_slice_stage(kt_tracker* t, int on, int weight_cull, int k)
             KT_HIP(hipHostMalloc((void**)&t->proc_count_host[b], sizeof(unsigned int), hipHostMallocDefault));
             KT_HIP(hipEventCreateWithFlags(&t->extracted[b], KT_EV_DEVICE));
         }
+        // the stage's kernels (the library sort needs scratch memory, which the runtime allocates at a kernel's first launch) run once
+        // here, on an empty slab, so that the first shift does not pay for it
+        KT_HIP(hipMemsetAsync(t->cloud_count_dev[0], 0, sizeof(unsigned int), (hipStream_t)kt_slice_ws_stream(t->slice_ws)));
+        const float leaf = fmaxf(t->voxel_size[0], fmaxf(t->voxel_size[1], t->voxel_size[2]));
+        KT_TRY(kt_slice_process_device(t->slice_ws, t->cloud_dev[0], t->cloud_count_dev[0], t->cloud_cap, weight_cull, leaf, k));
+        KT_HIP(hipStreamSynchronize((hipStream_t)kt_slice_ws_stream(t->slice_ws)));
     }
     t->slice_stage = on != 0;
     t->slice_cull = weight_cull; t->slice_k = k;

@@ -1877,9 +1877,12 @@ __global__ __launch_bounds__(256) void kt_extract_kernel(const kt_extract_args a
 {
     const long long total = (long long)a.nx * a.ny * a.nz;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // (up to three points per thread, one per axis.  Indexed by the AXIS, a compile-time constant in the unrolled loops, never by a
+    // running count: a dynamically indexed array lives in scratch memory, and the first launch of a scratch-using kernel on a queue makes
+    // the runtime allocate it -- 1 ms in the middle of the first shift frame of a process.)
     float4 pts[3];
     uint32_t cols[3];
-    int local = 0;
+    bool found[3] = {false, false, false};
     if (tid < total) {
         const int ix = (int)(tid % a.nx);
         const int iy = (int)((tid / a.nx) % a.ny);
@@ -1908,17 +1911,18 @@ __global__ __launch_bounds__(256) void kt_extract_kernel(const kt_extract_args a
                     const float d_inv = 1.f / (fabsf(F) + fabsf(Fn));
                     // dz: the other product is the contracted one (LLVM operand order on extract.cu:224, pinned by oracle/_ref)
                     p[axis] = (axis == 2 ? __builtin_fmaf(Vn, fabsf(F), V[axis] * fabsf(Fn)) : __builtin_fmaf(V[axis], fabsf(Fn), Vn * fabsf(F))) * d_inv;
-                    pts[local] = make_float4(p[0], p[1], p[2], 0.f);
+                    pts[axis] = make_float4(p[0], p[1], p[2], 0.f);
                     // colour of the NEIGHBOUR voxel, alpha = weight of the base voxel; the point's byte order is
                     // b,g,r,a with ptr->b = colour.x and ptr->r = colour.z (store_point_type, quirk A.14)
-                    cols[local] = (uint32_t)cn.x | ((uint32_t)cn.y << 8) | ((uint32_t)cn.z << 16) | ((uint32_t)W << 24);
-                    ++local;
+                    cols[axis] = (uint32_t)cn.x | ((uint32_t)cn.y << 8) | ((uint32_t)cn.z << 16) | ((uint32_t)W << 24);
+                    found[axis] = true;
                 }
             }
         }
     }
     // wave compaction: exclusive prefix of `local` over the 64 lanes
     const int lane = threadIdx.x & 63;
+    const int local = (int)found[0] + (int)found[1] + (int)found[2];
     int incl = local;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -1930,9 +1934,10 @@ __global__ __launch_bounds__(256) void kt_extract_kernel(const kt_extract_args a
     unsigned int base = 0;
     if (lane == 0) base = atomicAdd(a.count, (unsigned int)wave_total);
     base = __shfl(base, 0, 64);
-    const unsigned int offs = base + (unsigned int)(incl - local);
-    for (int l = 0; l < local; ++l) {
-        const unsigned int o = offs + l;
+    unsigned int o = base + (unsigned int)(incl - local);   // the thread's points in axis order, as before
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        if (!found[l]) continue;
         if (o < a.out_cap) {
             // store_point_type  extract.cu:307-317
             float4 lo, hi;
@@ -1947,6 +1952,7 @@ __global__ __launch_bounds__(256) void kt_extract_kernel(const kt_extract_args a
             dst[0] = lo;
             dst[1] = hi;
         }
+        ++o;
     }
 }
 
