@@ -1,5 +1,5 @@
 """Per-kernel resource table of libkt_hip.so's device code: compiles every .hip to gfx950 assembly (-S, device only) with the build's
-flags and reads the .amdhsa metadata.   python scripts/isa_summary.py > profiles/r01_isa_summary.md   (no GPU needed)"""
+flags and reads the .amdhsa metadata.   python scripts/isa_summary.py > profiles/r03_isa_summary.md   (no GPU needed)"""
 import os
 import re
 import subprocess
