@@ -268,7 +268,11 @@ def main():
                      # in the timed region the kernel shares the GPU with the read-ahead stream (next frame's bilateral / pyramid);
                      # the same launch with nothing else running (untimed stage pass below):
                      "avg_launch_ms_alone": stage_all["tsdf23"][0],
-                     "frac_alone": (bytes_tsdf23 / (stage_all["tsdf23"][0] * 1e-3) / 1e9 / peak) if stage_all["tsdf23"][0] > 0 else None},
+                     "frac_alone": (bytes_tsdf23 / (stage_all["tsdf23"][0] * 1e-3) / 1e9 / peak) if stage_all["tsdf23"][0] > 0 else None,
+                     # the whole integrate stage of the pipelined frame by SURVEY 8(d)'s stage formula (12 U + 25 P: the voxel words, the raw
+                     # depth, the scaled depth and the pixel records written and read once) over the stage's time on the main stream
+                     "stage_frac": (((12.0 * U + 25.0 * cam.cols * cam.rows) / (stage_pipe["integrate"][0] * 1e-3) / 1e9 / peak)
+                                    if stage_pipe and stage_pipe.get("integrate", (0,))[0] > 0 else None)},
         # every stage alone on the main stream (serial frames, in-stream pre-pass); stage_ms_pipelined: the main stream's stages with the
         # read-ahead stream running and the voxel pass planned ahead, i.e. as in the timed region (pyramid / resize are not on it there)
         "stage_ms": {k: round(v[0], 4) for k, v in stage_all.items()},
