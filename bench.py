@@ -234,7 +234,8 @@ def main():
     # HBM-side traffic of the same kernel: PMC counters cannot be read from inside the process, so this is the committed rocprofv3
     # measurement of this workload (profiles/, collected and corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes,
     # FETCH_SIZE x 2 after calibration on this access width, WRITE_SIZE x 1, KiB units); null for workloads without one
-    traffic, traffic_ratio = committed_traffic(args.workload) if N == WORKLOADS[args.workload][2] else (None, None)
+    traffic, traffic_ratio, traffic_source = committed_traffic(args.workload) if N == WORKLOADS[args.workload][2] else (None, None, None)
+    voxel_kernel = abi.lib().kt_debug_tsdf_kernel().decode()
 
     out = {
         "metric": "RGB-D frames/sec @640x480, 512^3 TSDF" if args.workload == "orbit512" else f"RGB-D frames/sec ({args.workload})",
@@ -259,8 +260,10 @@ def main():
                                 # the slowest calls (index in the timed region, ms): shift frames and whatever else stalls the caller
                                 "slowest": [[int(i), round(float(periods[i]), 3)] for i in np.argsort(periods)[::-1][:4]]},
                    "slices_by_direction": slices_by_dim},
-        "roofline": {"kernel": "kt_tsdf23_kernel", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
-                     "frac": achieved / peak, "traffic": traffic, "traffic_ratio": traffic_ratio, "algorithmic_bytes_per_launch": bytes_tsdf23,
+        "roofline": {"kernel": voxel_kernel, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
+                     "frac": achieved / peak, "traffic": traffic, "traffic_ratio": traffic_ratio,
+                     # not measured by this run: the committed rocprofv3 PMC passes of the same workload and the same kt_volume.hip
+                     "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_tsdf23,
                      "avg_launch_ms": tsdf23_ms, "launches_timed": tsdf23_n, "U_voxels_updated": U, "S_raycast_steps": float(np.mean(Ss)),
                      # lanes the launch spends per updated voxel (first 16 timed frames): 64-lane wave z-steps over wave-columns of 32 x 2
                      # voxel columns, profiles/r02_tsdf23_whatif.md
@@ -283,6 +286,14 @@ def main():
 
     if rank == 0 and world == 1 and args.workload == "orbit512" and not args.no_stress and not args.host_frames:
         out["roofline_stress"] = roofline_stress(ctx, abi, synth)
+        out["roofline_stress"]["kernel"] = voxel_kernel
+
+    # every rank checks its row of the gather and leaves the communicator TOGETHER, before rank 0 alone spends seconds on the CPU
+    # baseline (a rank destroying its communicator while a peer still holds one is the first thing to hang on real hardware)
+    if comm is not None:
+        check_gather(allp, rank, np.stack([p.reshape(16) for p in timed_poses]))
+        with stdout_to_stderr():
+            comm.close()
 
     if rank == 0 and not args.no_cpu_baseline:
         # the oracle needs cpu_frames + 2 frames of the same sequence whatever --steps / --warmup are
@@ -293,10 +304,6 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     os.dup2(2, 1)   # whatever the libraries still print while shutting down does not reach the driver's stdout
-    if comm is not None:
-        check_gather(allp, rank, np.stack([p.reshape(16) for p in timed_poses]))
-        with stdout_to_stderr():
-            comm.close()
     trk.close()
     ctx.close()
 
@@ -308,19 +315,21 @@ def kt_volume_sha():
 
 def committed_traffic(workload):
     """HBM-side traffic of the tsdf23 launch: PMC counters cannot be read from inside the process, so this is the committed rocprofv3
-    measurement of this workload (profiles/r03_pmc_tsdf23_<workload>.json, written by scripts/pmc_traffic.sh: separate --pmc passes,
+    measurement of this workload (profiles/r04_pmc_tsdf23_<workload>.json, written by scripts/pmc_traffic.sh: separate --pmc passes,
     FETCH_SIZE x 2 after calibration on the kernel's own access pattern, WRITE_SIZE x 1, as MI355X_MICROARCH.md prescribes).  It is only
     quoted for the kernel it was measured on: the file records the sha256 of kt_volume.hip, and a stale measurement prints null.
-    Returns (bytes per launch, bytes per launch / algorithmic bytes of the SAME launches): the profiled run covers other frames than
+    Returns (bytes per launch, bytes per launch / algorithmic bytes of the SAME launches, the file): the profiled run covers other frames than
     the timed region, so the ratio -- not the absolute -- is what compares with this line's algorithmic bytes."""
-    f = os.path.join(ROOT, "profiles", f"r03_pmc_tsdf23_{workload}.json")
-    try:
-        j = json.load(open(f))
-        if j.get("kt_volume_hip_sha16") != kt_volume_sha():
-            return None, None
-        return float(j["traffic_bytes_per_launch"]), (float(j["traffic_ratio"]) if "traffic_ratio" in j else None)
-    except Exception:
-        return None, None
+    for rnd in ("r04", "r03"):
+        f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_tsdf23_{workload}.json")
+        try:
+            j = json.load(open(f))
+            if j.get("kt_volume_hip_sha16") != kt_volume_sha():
+                continue
+            return float(j["traffic_bytes_per_launch"]), (float(j["traffic_ratio"]) if "traffic_ratio" in j else None), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None, None
 
 
 def roofline_stress(ctx, abi, synth):
@@ -358,6 +367,7 @@ def roofline_stress(ctx, abi, synth):
     achieved = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {"workload": "farwall768: 1280x960 synthetic far-wall sequence, static mode, 768^3 TSDF (BASELINE.json configs[4])", "kernel": "kt_tsdf23_kernel",
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": committed_traffic("farwall768")[0], "traffic_ratio": committed_traffic("farwall768")[1],
+            "traffic_source": committed_traffic("farwall768")[2],
             "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n, "U_voxels_updated": U, "frame_ms": round(frame_ms, 3)}
 
 

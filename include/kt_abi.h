@@ -306,8 +306,22 @@ int kt_debug_stream(kt_ctx* ctx, void* buf, size_t bytes, int elem_size, int rmw
  * wave-columns (elem_size 2: the left 64 bytes of every 128-byte line).  N % 32 == 0, Z % 4 == 0. */
 int kt_debug_stream_rows(kt_ctx* ctx, void* buf, int N, int Z, int elem_size, int halves, int rmw);
 /* issue cost of one instruction kind (csrc/kt_debug.hip lists them) at waves_per_simd resident waves: out_host = {mean, max shader
- * ticks per wave for the loop, wave-instructions of that kind per wave, launch duration in ms} */
-int kt_debug_valu_rates(kt_ctx* ctx, int kind, int iters, int waves_per_simd, double out_host[4]);
+ * ticks per wave for the loop, wave-instructions per wave, launch duration in ms, shader clock in MHz while the loop ran (s_memtime
+ * against the 100 MHz s_memrealtime), first wave in .. last wave out in us, VALU per wave, SALU per wave} */
+int kt_debug_valu_rates(kt_ctx* ctx, int kind, int iters, int waves_per_simd, double out_host[8]);
+/* test hooks of the voxel pass planned ahead of its frame (csrc/kt_tracker.hip plan_ahead; tests/test_gpu_tracker.py):
+ * kt_tracker_debug_pose_log: enable >= 0 switches the log of the poses the frames' set-up kernels saw (12 floats per frame: R row-major,
+ * t; before that frame's own shift) on or off; out12n / n_frames, when given, receive it.
+ * kt_tracker_debug_plan_truth: poses12n (from the log of an identical earlier run) replace the motion extrapolation as the prediction
+ * of every frame they cover; the prediction is then offset by a rotation of fr * theta about a random axis and by ft * tau along a random
+ * direction (theta, tau = the plan's margins; fixed to theta_fixed / tau_fixed when those are > 0).  A plan whose frame lands at
+ * fr, ft < 0.99 of its margins must be accepted and give the same volume as no plan; beyond 1 it must be rejected. */
+int kt_tracker_debug_pose_log(kt_tracker* trk, int enable, float* out12n, int max_frames, int* n_frames);
+int kt_tracker_debug_plan_truth(kt_tracker* trk, const float* poses12n, int n_frames, float fr, float ft, float theta_fixed, float tau_fixed, unsigned int seed);
+/* test / A-B hook: selects the voxel kernel of kt_integrate_tsdf and the tracker for N < 1024: 1 = kt_tsdf23_lean_kernel (round 4), 0 = the
+ * round-3 kernel, -1 = back to the default (KT_TSDF_LEAN in the environment, else the build's).  Both store the same bits. */
+int kt_debug_tsdf_lean(int on);
+const char* kt_debug_tsdf_kernel(void);   /* name of the voxel kernel the next N < 1024 launch uses (bench.py reports it) */
 /* test hook: the voxel kernel's division shortcut (table reciprocal + one correction) against the IEEE division for every finite float
  * numerator and every divisor 1..256: out_host = {mismatches, float bits of the largest |numerator| among them, mismatches at |n| >= 2^-100} */
 int kt_debug_div_check(kt_ctx* ctx, unsigned int out_host[3]);

@@ -138,6 +138,10 @@ _PROTOS = {
     "kt_debug_stream": (_i, [_vp, _vp, _sz, _i, _i]),
     "kt_debug_stream_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
     "kt_debug_valu_rates": (_i, [_vp, _i, _i, _i, _pd]),
+    "kt_tracker_debug_pose_log": (_i, [_vp, _i, _pf, _i, C.POINTER(C.c_int)]),
+    "kt_tracker_debug_plan_truth": (_i, [_vp, _pf, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint]),
+    "kt_debug_tsdf_lean": (_i, [_i]),
+    "kt_debug_tsdf_kernel": (C.c_char_p, []),
     "kt_debug_div_check": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_debug_unpack_table": (_i, [_vp, _pf]),
     "kt_debug_rcp_check": (_i, [_vp, C.POINTER(C.c_uint)]),
@@ -440,6 +444,23 @@ class Tracker:
         out = np.zeros(max(int(n.value), 1), NPOINT_DTYPE)
         _chk(lib().kt_tracker_slice_processed(self.h, i, out.ctypes.data_as(C.c_void_p)))
         return out[: int(n.value)]
+
+    def pose_log(self, enable: Optional[bool] = None, fetch: bool = False):
+        """test hook: switch the log of the poses the frames' set-up kernels saw on / off; fetch=True returns it as float32 [n, 12]"""
+        if not fetch:
+            _chk(lib().kt_tracker_debug_pose_log(self.h, -1 if enable is None else int(enable), None, 0, None))
+            return None
+        n = C.c_int(0)
+        _chk(lib().kt_tracker_debug_pose_log(self.h, -1 if enable is None else int(enable), None, 0, C.byref(n)))
+        out = np.zeros((n.value, 12), np.float32)
+        if n.value:
+            _chk(lib().kt_tracker_debug_pose_log(self.h, -1, out.ctypes.data_as(_pf), n.value, None))
+        return out
+
+    def plan_truth(self, poses12, fr: float, ft: float, theta_fixed: float = 0.0, tau_fixed: float = 0.0, seed: int = 1) -> None:
+        """test hook: poses of an identical earlier run as the plan's predictions, offset by fr * theta / ft * tau (kt_tracker_debug_plan_truth)"""
+        p = np.ascontiguousarray(poses12, np.float32).reshape(-1, 12)
+        _chk(lib().kt_tracker_debug_plan_truth(self.h, p.ctypes.data_as(_pf), len(p), fr, ft, theta_fixed, tau_fixed, seed))
 
     def plan_stats(self) -> Tuple[int, int]:
         """(frames fused from a task plan made ahead of them, frames whose pose fell outside their plan's margins)"""

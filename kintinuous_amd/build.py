@@ -70,13 +70,14 @@ HOST_BIN = os.path.join(HOST_DIR, "bin", "kintinuous_hip")
 JPEG_TOOL = os.path.join(HOST_DIR, "bin", "jpeg_tool")
 KLG_TOOL = os.path.join(HOST_DIR, "bin", "klg_tool")
 CONSUMER_TEST = os.path.join(HOST_DIR, "bin", "consumer_test")
+CONTROLLER_TEST = os.path.join(HOST_DIR, "bin", "controller_test")
 
 
 def build_host(force: bool = False) -> str:
     """g++ build of the C++ host shell's headless driver (kintinuous_amd/host/main.cpp) against libkt_hip.so."""
     deps = [os.path.join(dp, f) for dp, _, fs in os.walk(HOST_DIR) for f in fs if f.endswith((".h", ".hpp", ".cpp"))]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "kt_abi.h"))
-    outs = (HOST_BIN, JPEG_TOOL, KLG_TOOL, CONSUMER_TEST)
+    outs = (HOST_BIN, JPEG_TOOL, KLG_TOOL, CONSUMER_TEST, CONTROLLER_TEST)
     if not force and all(os.path.exists(o) for o in outs) and all(os.path.getmtime(d) <= min(os.path.getmtime(o) for o in outs) for d in deps):
         return HOST_BIN
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
@@ -96,6 +97,12 @@ def build_host(force: bool = False) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"consumer_test build failed:\n{r.stderr}")
+    # MainController minus the GUI (setup / mainLoop / complete / save) against the shell's ThreadObjects: compiling it is half the test
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", os.path.dirname(_HERE), os.path.join(HOST_DIR, "controller_test.cpp"), "-o", CONTROLLER_TEST,
+           "-L", _HERE, "-lkt_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/../..", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"controller_test build failed:\n{r.stderr}")
     return HOST_BIN
 
 

@@ -47,7 +47,12 @@ extern "C" int kt_debug_stream_rows(kt_ctx* c, void* buf, int N, int Z, int elem
 // chain latency of ~4 cycles is covered from 2 waves per SIMD on) and reports s_memtime ticks (= shader cycles) for the loop.
 // kinds: 0 v_fma_f32   1 v_pk_fma_f32   2 v_rcp_f32   3 v_rndne_f32 + v_cvt_i32_f32   4 v_fma_f32 with an s_add_u32 between any two
 //        5 v_readlane_b32 (to SGPR) + v_fma_f32 using it   6 v_sqrt_f32   7 v_cndmask_b32 + v_cmp_gt_f32 pairs   8 v_pk_add_f32
-//        9 v_mad_u32_u24   10 v_cvt_f32_ubyte0
+//        9 v_mad_u32_u24   10 v_cvt_f32_ubyte0   11 s_add_u32 only (4 independent chains)   12 two v_fma_f32 per s_add_u32
+//        13 one v_fma_f32 per two s_add_u32   14 v_cmp_gt_f32 to an SGPR pair + s_and_b64 on it (a predicate step)
+//        15 s_and_saveexec_b64 / s_or_b64 exec around one v_fma_f32 (an exec region)
+// Round 4: every wave also stamps s_memrealtime (the constant 100 MHz counter) at both ends, so that the shader clock UNDER THIS LOAD
+// is a measured number (ticks / real time) instead of the 2.4 GHz of the data sheet.
+#define KT_RATE_KINDS 34
 template <int KIND>
 __global__ __launch_bounds__(256) void kt_valu_rate_kernel(int iters, unsigned long long* __restrict__ ticks, float* __restrict__ sink)
 {
@@ -55,7 +60,11 @@ __global__ __launch_bounds__(256) void kt_valu_rate_kernel(int iters, unsigned l
     float b0 = a0 + 8, b1 = a0 + 9, b2 = a0 + 10, b3 = a0 + 11, b4 = a0 + 12, b5 = a0 + 13, b6 = a0 + 14, b7 = a0 + 15;
     const float m = 0.999f, k = 1e-3f;
     unsigned int s = blockIdx.x;
+    unsigned int s1 = s + 1, s2 = s + 2, s3 = s + 3;
+    unsigned long long m0 = 0, m1 = 0;
+    unsigned long long q0 = threadIdx.x, q1 = q0 + 1, q2 = q0 + 2, q3 = q0 + 3;   // 64-bit chains (v_mad_u64_u32)
     __syncthreads();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -114,26 +123,131 @@ __global__ __launch_bounds__(256) void kt_valu_rate_kernel(int iters, unsigned l
                 asm volatile("v_mad_u32_u24 %0, %0, %8, %1\n v_mad_u32_u24 %1, %1, %8, %2\n v_mad_u32_u24 %2, %2, %8, %3\n v_mad_u32_u24 %3, %3, %8, %4\n"
                              "v_mad_u32_u24 %4, %4, %8, %5\n v_mad_u32_u24 %5, %5, %8, %6\n v_mad_u32_u24 %6, %6, %8, %7\n v_mad_u32_u24 %7, %7, %8, %0\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
-            else
+            else if constexpr (KIND == 10)
                 asm volatile("v_cvt_f32_ubyte0 %0, %0\n v_cvt_f32_ubyte0 %1, %1\n v_cvt_f32_ubyte0 %2, %2\n v_cvt_f32_ubyte0 %3, %3\n"
                              "v_cvt_f32_ubyte0 %4, %4\n v_cvt_f32_ubyte0 %5, %5\n v_cvt_f32_ubyte0 %6, %6\n v_cvt_f32_ubyte0 %7, %7\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if constexpr (KIND == 11)
+                asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
+                             "s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
+                             : "+s"(s), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+            else if constexpr (KIND == 12)   // 8 VALU + 4 SALU
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n s_add_u32 %8, %8, 1\n"
+                             "v_fma_f32 %2, %2, %12, %13\n v_fma_f32 %3, %3, %12, %13\n s_add_u32 %9, %9, 1\n"
+                             "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n s_add_u32 %10, %10, 1\n"
+                             "v_fma_f32 %6, %6, %12, %13\n v_fma_f32 %7, %7, %12, %13\n s_add_u32 %11, %11, 1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s), "+s"(s1), "+s"(s2), "+s"(s3)
+                             : "v"(m), "v"(k) : "scc");
+            else if constexpr (KIND == 13)   // 4 VALU + 8 SALU
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n s_add_u32 %4, %4, 1\n s_add_u32 %5, %5, 1\n"
+                             "v_fma_f32 %1, %1, %8, %9\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n"
+                             "v_fma_f32 %2, %2, %8, %9\n s_add_u32 %4, %4, 1\n s_add_u32 %5, %5, 1\n"
+                             "v_fma_f32 %3, %3, %8, %9\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(m), "v"(k) : "scc");
+            else if constexpr (KIND == 14)   // 4 VALU + 4 SALU: compare into an SGPR pair, fold it into a mask
+                asm volatile("v_cmp_gt_f32 vcc, %0, %1\n s_and_b64 %4, %4, vcc\n v_cmp_gt_f32 vcc, %1, %2\n s_or_b64 %5, %5, vcc\n"
+                             "v_cmp_gt_f32 vcc, %2, %3\n s_and_b64 %4, %4, vcc\n v_cmp_gt_f32 vcc, %3, %0\n s_or_b64 %5, %5, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(m0), "+s"(m1) : : "vcc", "scc");
+            else if constexpr (KIND == 16)   // v_add_f32
+                asm volatile("v_add_f32 %0, %0, %9\n v_add_f32 %1, %1, %9\n v_add_f32 %2, %2, %9\n v_add_f32 %3, %3, %9\n"
+                             "v_add_f32 %4, %4, %9\n v_add_f32 %5, %5, %9\n v_add_f32 %6, %6, %9\n v_add_f32 %7, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 17)   // v_mul_f32
+                asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                             "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 18)   // v_max_f32
+                asm volatile("v_max_f32 %0, %0, %9\n v_max_f32 %1, %1, %9\n v_max_f32 %2, %2, %9\n v_max_f32 %3, %3, %9\n"
+                             "v_max_f32 %4, %4, %9\n v_max_f32 %5, %5, %9\n v_max_f32 %6, %6, %9\n v_max_f32 %7, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 19)   // v_add_u32
+                asm volatile("v_add_u32 %0, %0, %9\n v_add_u32 %1, %1, %9\n v_add_u32 %2, %2, %9\n v_add_u32 %3, %3, %9\n"
+                             "v_add_u32 %4, %4, %9\n v_add_u32 %5, %5, %9\n v_add_u32 %6, %6, %9\n v_add_u32 %7, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 20)   // v_and_b32
+                asm volatile("v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n"
+                             "v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 21)   // v_lshlrev_b32
+                asm volatile("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3\n"
+                             "v_lshlrev_b32 %4, 1, %4\n v_lshlrev_b32 %5, 1, %5\n v_lshlrev_b32 %6, 1, %6\n v_lshlrev_b32 %7, 1, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 22)   // v_mov_b32
+                asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n"
+                             "v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 23)   // v_cndmask_b32 (vcc fixed)
+                asm volatile("v_cndmask_b32 %0, %0, %9, vcc\n v_cndmask_b32 %1, %1, %9, vcc\n v_cndmask_b32 %2, %2, %9, vcc\n v_cndmask_b32 %3, %3, %9, vcc\n"
+                             "v_cndmask_b32 %4, %4, %9, vcc\n v_cndmask_b32 %5, %5, %9, vcc\n v_cndmask_b32 %6, %6, %9, vcc\n v_cndmask_b32 %7, %7, %9, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 24)   // v_cmp_gt_f32 only
+                asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cmp_gt_f32 vcc, %1, %2\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %3, %4\n"
+                             "v_cmp_gt_f32 vcc, %4, %5\n v_cmp_gt_f32 vcc, %5, %6\n v_cmp_gt_f32 vcc, %6, %7\n v_cmp_gt_f32 vcc, %7, %0\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 25)   // v_cvt_f32_u32
+                asm volatile("v_cvt_f32_u32 %0, %0\n v_cvt_f32_u32 %1, %1\n v_cvt_f32_u32 %2, %2\n v_cvt_f32_u32 %3, %3\n"
+                             "v_cvt_f32_u32 %4, %4\n v_cvt_f32_u32 %5, %5\n v_cvt_f32_u32 %6, %6\n v_cvt_f32_u32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 26)   // v_med3_i32
+                asm volatile("v_med3_i32 %0, %0, %8, %9\n v_med3_i32 %1, %1, %8, %9\n v_med3_i32 %2, %2, %8, %9\n v_med3_i32 %3, %3, %8, %9\n"
+                             "v_med3_i32 %4, %4, %8, %9\n v_med3_i32 %5, %5, %8, %9\n v_med3_i32 %6, %6, %8, %9\n v_med3_i32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 27)   // v_mul_u32_u24
+                asm volatile("v_mul_u32_u24 %0, %0, %9\n v_mul_u32_u24 %1, %1, %9\n v_mul_u32_u24 %2, %2, %9\n v_mul_u32_u24 %3, %3, %9\n"
+                             "v_mul_u32_u24 %4, %4, %9\n v_mul_u32_u24 %5, %5, %9\n v_mul_u32_u24 %6, %6, %9\n v_mul_u32_u24 %7, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 28)   // v_lshl_add_u32
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %9\n v_lshl_add_u32 %1, %1, 1, %9\n v_lshl_add_u32 %2, %2, 1, %9\n v_lshl_add_u32 %3, %3, 1, %9\n"
+                             "v_lshl_add_u32 %4, %4, 1, %9\n v_lshl_add_u32 %5, %5, 1, %9\n v_lshl_add_u32 %6, %6, 1, %9\n v_lshl_add_u32 %7, %7, 1, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 29)   // v_mad_u64_u32 (pair dst)
+                asm volatile("v_mad_u64_u32 %0, vcc, %4, 12, %0\n v_mad_u64_u32 %1, vcc, %5, 12, %1\n v_mad_u64_u32 %2, vcc, %6, 12, %2\n v_mad_u64_u32 %3, vcc, %7, 12, %3\n"
+                             "v_mad_u64_u32 %0, vcc, %5, 12, %0\n v_mad_u64_u32 %1, vcc, %6, 12, %1\n v_mad_u64_u32 %2, vcc, %7, 12, %2\n v_mad_u64_u32 %3, vcc, %4, 12, %3\n"
+                             : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(a4), "v"(a5), "v"(a6), "v"(a7) : "vcc");
+            else if constexpr (KIND == 30)   // v_bfe_u32
+                asm volatile("v_bfe_u32 %0, %0, 8, 8\n v_bfe_u32 %1, %1, 8, 8\n v_bfe_u32 %2, %2, 8, 8\n v_bfe_u32 %3, %3, 8, 8\n"
+                             "v_bfe_u32 %4, %4, 8, 8\n v_bfe_u32 %5, %5, 8, 8\n v_bfe_u32 %6, %6, 8, 8\n v_bfe_u32 %7, %7, 8, 8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 31)   // v_min_u32
+                asm volatile("v_min_u32 %0, %0, %9\n v_min_u32 %1, %1, %9\n v_min_u32 %2, %2, %9\n v_min_u32 %3, %3, %9\n"
+                             "v_min_u32 %4, %4, %9\n v_min_u32 %5, %5, %9\n v_min_u32 %6, %6, %9\n v_min_u32 %7, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 32)   // v_sub_f32 |abs| (VOP3)
+                asm volatile("v_sub_f32 %0, |%0|, %9\n v_sub_f32 %1, |%1|, %9\n v_sub_f32 %2, |%2|, %9\n v_sub_f32 %3, |%3|, %9\n"
+                             "v_sub_f32 %4, |%4|, %9\n v_sub_f32 %5, |%5|, %9\n v_sub_f32 %6, |%6|, %9\n v_sub_f32 %7, |%7|, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(m0) : "vcc");
+            else if constexpr (KIND == 33)   // v_cmp_lt_u32 to SGPR pair (VOP3)
+                asm volatile("v_cmp_lt_u32 %8, %0, %1\n v_cmp_lt_u32 %8, %1, %2\n v_cmp_lt_u32 %8, %2, %3\n v_cmp_lt_u32 %8, %3, %4\n"
+                             "v_cmp_lt_u32 %8, %4, %5\n v_cmp_lt_u32 %8, %5, %6\n v_cmp_lt_u32 %8, %6, %7\n v_cmp_lt_u32 %8, %7, %0\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) , "+s"(m0) : "v"(m), "v"(k) : "vcc");
+            else if constexpr (KIND == 15)   // 4 VALU + 8 SALU: an exec region around every VALU
+                asm volatile("s_and_saveexec_b64 %4, %5\n v_fma_f32 %0, %0, %6, %7\n s_or_b64 exec, exec, %4\n"
+                             "s_and_saveexec_b64 %4, %5\n v_fma_f32 %1, %1, %6, %7\n s_or_b64 exec, exec, %4\n"
+                             "s_and_saveexec_b64 %4, %5\n v_fma_f32 %2, %2, %6, %7\n s_or_b64 exec, exec, %4\n"
+                             "s_and_saveexec_b64 %4, %5\n v_fma_f32 %3, %3, %6, %7\n s_or_b64 exec, exec, %4\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&s"(m0) : "s"(~0ull), "v"(m), "v"(k) : "scc");
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
-    if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
-    const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7 + (float)s;
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* o = ticks + 4 * (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6));
+        o[0] = t0; o[1] = t1; o[2] = r0; o[3] = r1;
+    }
+    const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7 + (float)(s + s1 + s2 + s3) + (float)(m0 ^ m1) + (float)(q0 + q1 + q2 + q3);
     if (r == 1.2345678f) *sink = r;
 }
 
 // waves_per_simd blocks of 256 threads per CU (4 waves = one per SIMD each); out_host[0] = mean ticks per wave for the loop,
-// [1] = max, [2] = wave-instructions per wave (iters * 32), [3] = the launch's duration in ms (HIP events)
-extern "C" int kt_debug_valu_rates(kt_ctx* c, int kind, int iters, int waves_per_simd, double out_host[4])
+// [1] = max, [2] = wave-instructions per wave (the kind's body x 4 x iters), [3] = the launch's duration in ms (HIP events),
+// [4] = shader clock in MHz while the loop ran (sum of s_memtime ticks / sum of s_memrealtime ticks x 100 MHz over the waves),
+// [5] = first wave in .. last wave out in us of real time, [6] = VALU per wave, [7] = SALU per wave
+extern "C" int kt_debug_valu_rates(kt_ctx* c, int kind, int iters, int waves_per_simd, double out_host[8])
 {
-    KT_ARG(c && out_host && kind >= 0 && kind <= 10 && iters > 0 && waves_per_simd >= 1 && waves_per_simd <= 8);
+    KT_ARG(c && out_host && kind >= 0 && kind < KT_RATE_KINDS && iters > 0 && waves_per_simd >= 1 && waves_per_simd <= 8);
     const int blocks = 256 * waves_per_simd;
     unsigned long long* ticks = nullptr;
-    KT_HIP(hipMalloc((void**)&ticks, sizeof(unsigned long long) * blocks * 4));
+    KT_HIP(hipMalloc((void**)&ticks, sizeof(unsigned long long) * blocks * 16));
     float* sink = (float*)&c->counters[8];
 #define KT_RATE_CASE(K) case K: hipLaunchKernelGGL(kt_valu_rate_kernel<K>, dim3(blocks), dim3(256), 0, c->stream, iters, ticks, sink); break;
     hipEvent_t ev[2];
@@ -143,20 +257,36 @@ extern "C" int kt_debug_valu_rates(kt_ctx* c, int kind, int iters, int waves_per
         switch (kind) {
             KT_RATE_CASE(0) KT_RATE_CASE(1) KT_RATE_CASE(2) KT_RATE_CASE(3) KT_RATE_CASE(4) KT_RATE_CASE(5)
             KT_RATE_CASE(6) KT_RATE_CASE(7) KT_RATE_CASE(8) KT_RATE_CASE(9) KT_RATE_CASE(10)
+            KT_RATE_CASE(11) KT_RATE_CASE(12) KT_RATE_CASE(13) KT_RATE_CASE(14) KT_RATE_CASE(15)
+            KT_RATE_CASE(16) KT_RATE_CASE(17) KT_RATE_CASE(18) KT_RATE_CASE(19) KT_RATE_CASE(20) KT_RATE_CASE(21) KT_RATE_CASE(22) KT_RATE_CASE(23) KT_RATE_CASE(24) KT_RATE_CASE(25) KT_RATE_CASE(26) KT_RATE_CASE(27) KT_RATE_CASE(28) KT_RATE_CASE(29) KT_RATE_CASE(30) KT_RATE_CASE(31) KT_RATE_CASE(32) KT_RATE_CASE(33)
         }
     }
     KT_HIP(hipEventRecord(ev[1], c->stream));
 #undef KT_RATE_CASE
     KT_LAUNCH_CHECK();
-    unsigned long long* h = (unsigned long long*)malloc(sizeof(unsigned long long) * blocks * 4);
-    KT_HIP(hipMemcpyAsync(h, ticks, sizeof(unsigned long long) * blocks * 4, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long* h = (unsigned long long*)malloc(sizeof(unsigned long long) * blocks * 16);
+    KT_HIP(hipMemcpyAsync(h, ticks, sizeof(unsigned long long) * blocks * 16, hipMemcpyDeviceToHost, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
-    double sum = 0, mx = 0;
-    for (int i = 0; i < blocks * 4; ++i) { sum += (double)h[i]; if ((double)h[i] > mx) mx = (double)h[i]; }
-    out_host[0] = sum / (blocks * 4); out_host[1] = mx; out_host[2] = (double)iters * 32;
+    double sum = 0, mx = 0, rsum = 0;
+    unsigned long long rmin = ~0ull, rmax = 0;
+    for (int i = 0; i < blocks * 4; ++i) {
+        const double d = (double)(h[4 * i + 1] - h[4 * i]);
+        sum += d; if (d > mx) mx = d;
+        rsum += (double)(h[4 * i + 3] - h[4 * i + 2]);
+        if (h[4 * i + 2] < rmin) rmin = h[4 * i + 2];
+        if (h[4 * i + 3] > rmax) rmax = h[4 * i + 3];
+    }
+    // instructions of the kind's asm body per trip of the inner r loop: {VALU, SALU}
+    static const int body[KT_RATE_KINDS][2] = {{8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 8}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0},
+                                               {0, 8}, {8, 4}, {4, 8}, {4, 4}, {4, 8}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}};
+    out_host[0] = sum / (blocks * 4); out_host[1] = mx; out_host[2] = (double)iters * 4 * (body[kind][0] + body[kind][1]);
     float ms = 0;
     KT_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
     out_host[3] = ms;
+    out_host[4] = rsum > 0 ? sum / rsum * 100.0 : 0.0;
+    out_host[5] = (double)(rmax - rmin) / 100.0;
+    out_host[6] = (double)iters * 4 * body[kind][0];
+    out_host[7] = (double)iters * 4 * body[kind][1];
     (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
     free(h);
     KT_HIP(hipFree(ticks));

@@ -76,6 +76,7 @@ struct kt_tsdf_plan { unsigned int* wrange; unsigned int* tasks; unsigned int* t
 int kt_tsdf_plan_alloc(kt_tsdf_plan* p, int N);
 void kt_tsdf_plan_free(kt_tsdf_plan* p);
 void kt_tsdf_plan_shape(int cols, int rows, int N, int* wx, int* wy, int* xg, int* yg);   // wave-column shape and grid of these launches (for the checkpoint workgroups)
+#define KT_NO_PLAN (-1)   // kt_integrate_plan: no plan can be made for these margins (not an error: the caller takes the in-stream pre-pass)
 int kt_integrate_plan(hipStream_t stream, const kt_tsdf_plan* plan, const void* rec, const float* dpmax, int cols, int rows, const kt_intr* intr,
                       const float volume_size[3], const kt_mat33* Rinv_pred, const float t_pred[3], float tranc_dist, const int voxel_wrap[3], int N,
                       float theta, float tau);

@@ -160,9 +160,16 @@ struct kt_tracker {
     // the frame has been read ahead, i.e. while the odometry of frame f iterates on the main stream (a latency-bound chain that leaves the
     // compute units idle) -- two frames ahead of the last pose the host has seen.  plan_sel: the slot the frame in flight was enqueued
     // with, -1 = none (the in-stream pre-pass ran).
-    struct PlanSlot { kt_tsdf_plan plan; hipEvent_t done; long long ordinal; float R[9], t[3], theta, tau; int wrap[3]; };
+    // a plan belongs to ONE read-ahead frame: the frame set it was built from and the frame's buffers identify it (the ordinal alone does
+    // not: the caller may skip a read-ahead, and the pre-pass intervals depend on that frame's depth)
+    struct PlanSlot { kt_tsdf_plan plan; hipEvent_t done; long long ordinal; float R[9], t[3], theta, tau; int wrap[3]; int set; const uint16_t* depth; const uint8_t* rgb; };
     PlanSlot plans[3]; hipStream_t plan_stream;          // (three: frame f + 1 is planned while the voxel kernels of f and f - 1 may still read theirs)
     int plan_sel; bool plan_enabled; float plan_margin_scale;
+    // test hooks (kt_tracker_debug_plan_*): the pose every frame WILL arrive at, taken from an identical earlier run, as the prediction;
+    // an offset of fr * theta about a random axis and ft * tau along a random direction on top of the prediction; fixed margins; a log
+    // of the poses the set-up kernels saw
+    std::vector<float> plan_truth; float plan_fr = 0.0f, plan_ft = 0.0f, plan_theta_fixed = 0.0f, plan_tau_fixed = 0.0f; bool plan_perturb = false;
+    unsigned int plan_rng = 0x9e3779b9u; std::vector<float> pose_log; bool pose_log_on = false;
     float hist_R[2][9], hist_gc[2][3]; int hist_n;      // rotation and global camera of the two most recent tracked frames
     float pred_err_t, pred_err_r;                       // error of the most recent prediction (metres, radians): drives the margins
     long long plan_hits, plan_misses;
@@ -522,7 +529,7 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     for (int k = 0; k < 3; ++k) {
         KT_TRY(kt_tsdf_plan_alloc(&t->plans[k].plan, cfg->N));
         KT_HIP(hipEventCreateWithFlags(&t->plans[k].done, KT_EV_DEVICE));
-        t->plans[k].ordinal = -1;
+        t->plans[k].ordinal = -1; t->plans[k].set = -1; t->plans[k].depth = nullptr; t->plans[k].rgb = nullptr;
     }
     t->plan_enabled = getenv("KT_NO_PLAN") == nullptr;   // (A/B switch: every frame through the in-stream pre-pass)
     t->plan_margin_scale = getenv("KT_PLAN_MARGIN_SCALE") ? (float)atof(getenv("KT_PLAN_MARGIN_SCALE")) : 1.0f;   // (tests: 0 makes every plan miss)
@@ -632,7 +639,7 @@ int kt_tracker_reset(kt_tracker* t)
     t->pending.clear();
     KT_HIP(hipStreamSynchronize(t->plan_stream));
     t->plan_sel = -1;
-    for (int k = 0; k < 3; ++k) t->plans[k].ordinal = -1;
+    for (int k = 0; k < 3; ++k) { t->plans[k].ordinal = -1; t->plans[k].set = -1; }
     t->hist_n = 0;
     t->pred_err_t = t->pred_err_r = 0.0f;
     t->prev_set = -1;
@@ -1228,10 +1235,40 @@ static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool specu
 // on plan_stream behind the frame's read-ahead -- where it runs next to the fusion kernels of frame f - 1.  Margins: three times the
 // error of the previous prediction on top of a floor, within caps.  The set-up kernel of frame f + 1 checks its pose against them;
 // a volume shift in between invalidates the plan (its storage wrap no longer matches).
-static int plan_ahead(kt_tracker* t, int set, long long ordinal)
+// A frame set that leaves the pending list WITHOUT being processed (a skipped or dropped read-ahead) takes its plan with it: the slot is
+// invalidated, and whatever recycles the set -- the main stream or the read-ahead stream -- first waits for the plan's kernels, which read
+// the set's pixel records and tile maxima on plan_stream.
+static int drop_plans_of_set(kt_tracker* t, int set)
 {
+    for (int k = 0; k < 3; ++k) {
+        kt_tracker::PlanSlot& pl = t->plans[k];
+        if (pl.ordinal < 0 || pl.set != set) continue;
+        KT_HIP(hipStreamWaitEvent(t->ctx->stream, pl.done, 0));
+        KT_HIP(hipStreamWaitEvent(t->pre_stream, pl.done, 0));
+        pl.ordinal = -1; pl.set = -1;
+    }
+    return KT_OK;
+}
+
+static float plan_rand(kt_tracker* t)   // uniform in (-1, 1), deterministic per tracker
+{
+    t->plan_rng = t->plan_rng * 1664525u + 1013904223u;
+    return (float)((t->plan_rng >> 8) & 0xffffffu) * (2.0f / 16777216.0f) - 1.0f;
+}
+static void plan_rand_unit(kt_tracker* t, float v[3])
+{
+    for (;;) {
+        v[0] = plan_rand(t); v[1] = plan_rand(t); v[2] = plan_rand(t);
+        const float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        if (n2 > 0.01f && n2 <= 1.0f) { const float s = 1.0f / sqrtf(n2); v[0] *= s; v[1] *= s; v[2] *= s; return; }
+    }
+}
+
+static int plan_ahead(kt_tracker* t, const Pending& next, long long ordinal)
+{
+    const int set = next.set;
     kt_tracker::PlanSlot& pl = t->plans[ordinal % 3];
-    pl.ordinal = -1;
+    pl.ordinal = -1; pl.set = -1;
     float D[9], D2[9], Rp[9], tp[3];
     for (int i = 0; i < 3; ++i)       // D = R(f-2)^T R(f-1)
         for (int j = 0; j < 3; ++j) D[i * 3 + j] = t->hist_R[0][0 * 3 + i] * t->hist_R[1][0 * 3 + j] + t->hist_R[0][1 * 3 + i] * t->hist_R[1][1 * 3 + j] + t->hist_R[0][2 * 3 + i] * t->hist_R[1][2 * 3 + j];
@@ -1250,15 +1287,38 @@ static int plan_ahead(kt_tracker* t, int set, long long ordinal)
     if (t->plan_hits + t->plan_misses == 0) { t->pred_err_t = 0.5f * step; t->pred_err_r = 0.5f * turn; }   // nothing observed yet
     pl.tau = t->plan_margin_scale * fminf(0.020f, 0.0015f + 3.0f * t->pred_err_t);
     pl.theta = t->plan_margin_scale * fminf(0.02f, 3.0e-4f + 3.0f * t->pred_err_r);
+    // ---- test hooks: where a plan can actually fail is a pose that lands just inside its margins
+    if (t->plan_theta_fixed > 0.0f) pl.theta = t->plan_theta_fixed;
+    if (t->plan_tau_fixed > 0.0f) pl.tau = t->plan_tau_fixed;
+    if ((size_t)(ordinal + 1) * 12 <= t->plan_truth.size()) {   // the pose frame `ordinal` arrived at in an identical earlier run
+        memcpy(Rp, &t->plan_truth[(size_t)ordinal * 12], sizeof(Rp));
+        memcpy(tp, &t->plan_truth[(size_t)ordinal * 12 + 9], sizeof(tp));
+    }
+    if (t->plan_perturb) {   // prediction := prediction (+) a rotation of fr * theta about a random axis, + ft * tau along a random direction
+        float ax[3], dir[3], K[9], Rd[9], Rn[9];
+        plan_rand_unit(t, ax); plan_rand_unit(t, dir);
+        const float phi = t->plan_fr * pl.theta, sn = sinf(phi), cs = cosf(phi);
+        const float Kx[9] = {0, -ax[2], ax[1], ax[2], 0, -ax[0], -ax[1], ax[0], 0};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) K[i * 3 + j] = Kx[i * 3 + 0] * Kx[0 * 3 + j] + Kx[i * 3 + 1] * Kx[1 * 3 + j] + Kx[i * 3 + 2] * Kx[2 * 3 + j];
+        for (int k = 0; k < 9; ++k) Rd[k] = ((k % 4 == 0) ? 1.0f : 0.0f) + sn * Kx[k] + (1.0f - cs) * K[k];   // Rodrigues
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = Rp[i * 3 + 0] * Rd[0 * 3 + j] + Rp[i * 3 + 1] * Rd[1 * 3 + j] + Rp[i * 3 + 2] * Rd[2 * 3 + j];
+        memcpy(Rp, Rn, sizeof(Rp));
+        for (int k = 0; k < 3; ++k) tp[k] += dir[k] * t->plan_ft * pl.tau;
+    }
     kt_mat33 Rinv;
     kt_mat33_inverse(Rp, Rinv.m);
     v_wrap_copy_update(t);
     KT_HIP(hipStreamWaitEvent(t->plan_stream, t->sets[set].ready, 0));
-    KT_TRY(kt_integrate_plan(t->plan_stream, &pl.plan, t->sets[set].rec, t->sets[set].dpmax, t->cfg.cols, t->cfg.rows, &t->intr, t->volume_size, &Rinv, tp,
-                             t->tranc_dist, t->v_wrap_copy, t->N, pl.theta, pl.tau));
+    const int made = kt_integrate_plan(t->plan_stream, &pl.plan, t->sets[set].rec, t->sets[set].dpmax, t->cfg.cols, t->cfg.rows, &t->intr, t->volume_size, &Rinv, tp,
+                                       t->tranc_dist, t->v_wrap_copy, t->N, pl.theta, pl.tau);
+    if (made == KT_NO_PLAN) return KT_OK;   // margins too wide for this camera: planning is an optimisation, the frame takes the in-stream pre-pass
+    KT_TRY(made);
     KT_HIP(hipEventRecord(pl.done, t->plan_stream));
     memcpy(pl.R, Rp, sizeof(pl.R)); memcpy(pl.t, tp, sizeof(pl.t));
     memcpy(pl.wrap, t->v_wrap_copy, sizeof(pl.wrap));
+    pl.set = set; pl.depth = next.depth; pl.rgb = next.rgb;
     pl.ordinal = ordinal;
     return KT_OK;
 }
@@ -1296,6 +1356,11 @@ static int complete_frame(kt_tracker* t)
     float Rcurr[9], tcurr[3];
     memcpy(Rcurr, t->mirror->R, sizeof(Rcurr));
     memcpy(tcurr, t->mirror->t, sizeof(tcurr));
+    if (t->pose_log_on) {   // test hook: the pose the set-up kernel of frame out_ordinal saw (before any shift of this frame)
+        if (t->pose_log.size() < (size_t)(t->out_ordinal + 1) * 12) t->pose_log.resize((size_t)(t->out_ordinal + 1) * 12, 0.0f);
+        memcpy(&t->pose_log[(size_t)t->out_ordinal * 12], Rcurr, sizeof(Rcurr));
+        memcpy(&t->pose_log[(size_t)t->out_ordinal * 12 + 9], tcurr, sizeof(tcurr));
+    }
     return finish_pose(t, Rcurr, tcurr, t->out_speculated);
 }
 
@@ -1335,6 +1400,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         for (size_t i = 0; i < t->pending.size(); ++i)
             if (t->pending[i].depth == depth_raw && t->pending[i].rgb == colors) {
                 KT_HIP(hipStreamWaitEvent(c->stream, t->sets[t->pending[i].set].ready, 0));
+                KT_TRY(drop_plans_of_set(t, t->pending[i].set));
                 t->pending.erase(t->pending.begin() + i);
                 break;
             }
@@ -1353,7 +1419,10 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         if (t->pending[i].depth == depth_raw && t->pending[i].rgb == colors) {
             read_ahead = true;
             // read-aheads announced before this one were skipped by the caller: their sets return to the pool once written
-            for (size_t j = 0; j < i; ++j) KT_HIP(hipStreamWaitEvent(c->stream, t->sets[t->pending[j].set].ready, 0));
+            for (size_t j = 0; j < i; ++j) {
+                KT_HIP(hipStreamWaitEvent(c->stream, t->sets[t->pending[j].set].ready, 0));
+                KT_TRY(drop_plans_of_set(t, t->pending[j].set));
+            }
             set = t->pending[i].set;
             t->pending.erase(t->pending.begin(), t->pending.begin() + i + 1);
             // a read-ahead that has already retired needs no device-side join (a wait packet is a 3-5 us bubble in front of the odometry)
@@ -1366,6 +1435,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         if (set < 0) {  // both spare sets hold read-aheads the caller is not consuming: give up the older one
             set = t->pending.front().set;
             KT_HIP(hipStreamWaitEvent(c->stream, t->sets[set].ready, 0));
+            KT_TRY(drop_plans_of_set(t, set));
             t->pending.erase(t->pending.begin());
         }
         t->last_assigned = set;
@@ -1437,15 +1507,21 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     // shifted since (plan_ahead)
     t->plan_sel = -1;
     v_wrap_copy_update(t);
-    if (read_ahead && t->plans[ordinal % 3].ordinal == ordinal && memcmp(t->plans[ordinal % 3].wrap, t->v_wrap_copy, sizeof(t->v_wrap_copy)) == 0)
-        t->plan_sel = (int)(ordinal % 3);
+    {
+        const kt_tracker::PlanSlot& pl = t->plans[ordinal % 3];
+        // the plan of THIS frame: made for this ordinal, from this frame's set and buffers (a caller may process another read-ahead
+        // than the one that was planned for), for the storage wrap that still holds
+        if (read_ahead && pl.ordinal == ordinal && pl.set == set && pl.depth == depth_raw && pl.rgb == colors &&
+            memcmp(pl.wrap, t->v_wrap_copy, sizeof(t->v_wrap_copy)) == 0)
+            t->plan_sel = (int)(ordinal % 3);
+    }
     // The frame that has been read ahead comes next: plan its voxel pass now, for the pose predicted two increments past the last one
     // the host has seen (-d repositions the cube once the pose is known: nothing to plan for).  NOW = before this frame's odometry is
     // enqueued: the GPU is still in the previous frame's voxel kernel and ray cast, which do not mind a few small workgroups next to
     // them; enqueued after the odometry (the first cut) the pre-pass ran next to the iterations, each of whose 256 workgroups needs a
     // whole CU, and cost them 10 us per frame.
     if (t->plan_enabled && !t->pending.empty() && t->hist_n >= 2 && !t->cfg.dynamic_cube)
-        KT_TRY(plan_ahead(t, t->pending.front().set, ordinal + 1));
+        KT_TRY(plan_ahead(t, t->pending.front(), ordinal + 1));
     // [C] odometry :564-572 -- every Gauss-Newton iteration is enqueued; the pose stays on the device
     KT_TRY(ev_begin(t, ST_ODOMETRY));
     if (icp) KT_TRY(icp_odometry(t));
@@ -1770,6 +1846,29 @@ int kt_tracker_plan_stats(kt_tracker* t, long long out2[2])
     out2[0] = t->plan_hits; out2[1] = t->plan_misses;
     return KT_OK;
 }
+/* test hooks of the planned-ahead voxel pass (tests/test_gpu_tracker.py::test_plan_margins_*): */
+int kt_tracker_debug_pose_log(kt_tracker* t, int enable, float* out12n, int max_frames, int* n_frames)
+{
+    KT_ARG(t);
+    if (enable >= 0) t->pose_log_on = enable != 0;
+    if (out12n || n_frames) {
+        KT_TRY(complete_frame(t));
+        const int n = (int)(t->pose_log.size() / 12);
+        if (n_frames) *n_frames = n;
+        if (out12n) memcpy(out12n, t->pose_log.data(), sizeof(float) * 12 * (size_t)(n < max_frames ? n : max_frames));
+    }
+    return KT_OK;
+}
+int kt_tracker_debug_plan_truth(kt_tracker* t, const float* poses12n, int n_frames, float fr, float ft, float theta_fixed, float tau_fixed, unsigned int seed)
+{
+    KT_ARG(t && n_frames >= 0 && (poses12n || n_frames == 0) && fr >= 0 && ft >= 0 && theta_fixed >= 0 && tau_fixed >= 0);
+    t->plan_truth.assign(poses12n, poses12n + (size_t)n_frames * 12);
+    t->plan_fr = fr; t->plan_ft = ft; t->plan_perturb = fr > 0.0f || ft > 0.0f;
+    t->plan_theta_fixed = theta_fixed; t->plan_tau_fixed = tau_fixed;
+    t->plan_rng = seed * 2654435761u + 0x9e3779b9u;
+    return KT_OK;
+}
+
 
 int kt_tracker_debug_counts(kt_tracker* t, unsigned int* out4)
 {

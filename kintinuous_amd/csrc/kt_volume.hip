@@ -855,6 +855,9 @@ __device__ __forceinline__ void kt_tsdf_consume(const kt_tsdf23_args& a, const k
 #ifndef KT_TSDF_OCC
 #define KT_TSDF_OCC 8   // waves per SIMD the register budget is cut for
 #endif
+#ifndef KT_TSDF_LEAN_DEFAULT
+#define KT_TSDF_LEAN_DEFAULT 1   // 1: kt_tsdf23_lean_kernel (round 4) is the voxel kernel of every N < 1024 launch unless KT_TSDF_LEAN=0
+#endif
 template <bool COUNT, bool BUF>
 __global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_tsdf23_args a_in)
 {
@@ -948,6 +951,314 @@ __global__ __launch_bounds__(256, KT_TSDF_OCC) void kt_tsdf23_kernel(const kt_ts
     }
     if (COUNT) {
         // wave-level sum, one atomic per wave and counter; [1] = wave batches, [2] = tasks with work (diagnostics)
+        for (int off = 32; off > 0; off >>= 1) { n_upd += __shfl_down(n_upd, off, 64); n_img += __shfl_down(n_img, off, 64); }
+        if (lane == 0) {
+            if (n_upd) atomicAdd(a.updated, n_upd);
+            if (n_batches) atomicAdd(a.updated + 1, n_batches);
+            if (n_tasks_done) atomicAdd(a.updated + 2, n_tasks_done);
+            if (n_img) atomicAdd(a.updated + 3, n_img);
+        }
+    }
+}
+
+
+// ---- round 4: the voxel kernel with its scalar half cut (KT_TSDF_LEAN=0 in the environment selects the kernel above) -----------------
+// Round 3's counters: 100 VALU + 65 SALU + 4 VMEM wave-instructions per wave z-step, 38 spilled SGPRs.  The scalar half was bookkeeping:
+// exec-mask regions around every predicate of the consume phase, the wave-uniform z arithmetic (table index, storage wrap, plane
+// offsets x 2 and x 4, brick row) repeated per step, the kernel's 60 argument SGPRs, v_readlane broadcasts of the z tables.  Here:
+//   * the per-z quantities {v_g_z, z_scaled, element offset of the storage plane, brick plane} of ALL z are built once per workgroup in
+//     LDS (16 bytes per z) and fetched with ONE uniform ds_read_b128 per step -- the LDS pipe was idle, the scalar unit and the
+//     v_readlane / s_nop pairs were not;
+//   * the voxel's buffer offset is a VGPR add (no SGPR plane offset, no s_mul / s_lshl per access);
+//   * the update predicate is evaluated ONCE, before the volume words are requested (round 3 evaluated a cheap necessary bound first
+//     and the predicate again after the loads): tsdf = min(1, sdf / trunc) is exactly 1 on the free-space side whatever the last bit
+//     of the square root, so the same guard band as before decides who takes the correctly rounded root, and the loads go out only
+//     for voxels that WILL be updated;
+//   * predicates are combined with non-short-circuit logic, the pixel index is computed unconditionally and selected;
+//   * the kernel takes a cut-down argument block (kt_tsdf_lean_args: what the loop needs, nothing of the pre-pass).
+// Stored bits are those of the kernel above (same expressions, same guard bands); tests/test_gpu_volume.py runs both.
+struct kt_tsdf_ztab { float vgz, zs; unsigned int zoff2; int bz; };   // per z: walk tables, byte offset of the storage plane in the tsdf volume, brick plane index
+struct kt_tsdf_lean_args {
+    const kt_pixrec* rec;
+    int16_t* volume;
+    uchar4* color;
+    const float* vgz;
+    const float* zs;
+    const unsigned int* tasks;
+    const unsigned int* task_count;
+    const unsigned int* wrange;
+    const float2* walk0;
+    unsigned int* updated;
+    const kt_frame_params* fp;
+    unsigned char* bricks;
+    kt_mat33 Ri;
+    float tx, ty, tz;
+    kt_intr intr;
+    float cell_x, cell_y, cell_z;
+    float tranc_dist;
+    int wx, wy, wz;
+    int cols, rows, N;
+    int nb, wcl;
+};
+
+// Issue cost on gfx950 (profiles/r04_valu_rates.md, 8 waves per SIMD, measured clock): v_fma / v_mul / v_add / v_sub_f32, v_add_u32,
+// v_and_b32, v_mov_b32 take ~2.5 cycles per wave-instruction; EVERYTHING else -- compares, v_cndmask, min / max, shifts, every
+// conversion, v_rndne, 24-bit multiplies, v_mad_u64_u32 -- ~4.2, v_rcp / v_sqrt 8.2.  The lean kernel is VALU-issue bound, so its inner loop
+// trades the second kind for the first wherever the value is provably the same:
+//   * round-to-nearest-even to an integer = add 1.5 * 2^23 (one v_add_f32; exact for |x| < 2^22) and read the integer off the mantissa,
+//     instead of v_rndne_f32 + v_cvt_i32_f32;
+//   * byte offsets come from the z table and are ADDED to a loop-invariant column offset; x 2 for the colour volume is an add too;
+//   * byte -> float by v_cvt_f32_ubyteN + v_mul_f32 instead of the 24-bit integer multiply + conversion hipcc selects.
+#define KT_RNE_MAGIC 12582912.0f       // 1.5 * 2^23: ulp = 1, so x + MAGIC rounds x to the nearest integer, ties to even
+#define KT_RNE_MAGIC_BITS 0x4B400000u
+template <int N>
+__device__ __forceinline__ float kt_ubyte_f32(unsigned int v)   // (float)((v >> 8 N) & 0xff) as ONE conversion (and nothing the compiler can fold into an integer multiply)
+{
+    float r;
+    if constexpr (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(v));
+    else if constexpr (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(v));
+    else if constexpr (N == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(v));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ unsigned int kt_twice(unsigned int x)   // 2 x as v_add_u32 (hipcc would select the shift, which issues at half the rate)
+{
+    unsigned int r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ float kt_min1(float x)   // min(1, x) as one v_min_f32 (fminf costs a canonicalising v_max_f32 on top; x is never NaN here)
+{
+    float r;
+    asm("v_min_f32 %0, 1.0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+template <bool COUNT, bool FAST>
+__device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, const kt_tsdf_bufs& m, const kt_tsdf_ztab* __restrict__ s_tab,
+                                                   const float* __restrict__ s_rcp, int zb, int rem, unsigned int col_base2, int brick_xy,
+                                                   float v_z, float& v_x, float& v_y, float dvx, float dvy, float r8, float v_g_part_norm,
+                                                   float tranc_dist_inv, unsigned int& n_upd, unsigned int& n_img)
+{
+    kt_pixrec rec[KT_TSDF_UNROLL];
+    bool in_img[KT_TSDF_UNROLL];
+    float r2[KT_TSDF_UNROLL];
+    unsigned int toff[KT_TSDF_UNROLL];   // byte offset of the voxel in the tsdf volume (the colour volume: twice that)
+    // ---- phase A: project the 4 voxels, gather their pixel records
+#pragma unroll
+    for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
+        const kt_tsdf_ztab e = s_tab[zb + u];   // wave-uniform address: one broadcast ds_read_b128
+        const float d = __builtin_fmaf(r8, e.zs, v_z);
+        const float inv_z = FAST ? kt_rcp_exact(d) : 1.0f / d;
+        const float px = __builtin_fmaf(v_x, inv_z, a.intr.cx), py = __builtin_fmaf(v_y, inv_z, a.intr.cy);
+        unsigned int coo_x, coo_y;
+        if constexpr (FAST) {
+            // __float2int_rn off the mantissa: for |p| < 2^22 the sum is exactly MAGIC + rne(p); a larger |p|, an infinity or a NaN (none of
+            // which the FAST path can produce: |1 / d| <= 2^20 and the walk is finite) leaves a word that fails the unsigned in-image test
+            coo_x = __float_as_uint(px + KT_RNE_MAGIC) - KT_RNE_MAGIC_BITS;
+            coo_y = __float_as_uint(py + KT_RNE_MAGIC) - KT_RNE_MAGIC_BITS;
+        } else {
+            coo_x = (unsigned int)kt_f2i_rn(px);
+            coo_y = (unsigned int)kt_f2i_rn(py);
+        }
+        // the last batch of a task may reach past the chunk (whose next z belong to another task): those steps see an image of 0 rows
+        const unsigned int rows_u = u < rem ? (unsigned int)a.rows : 0u;   // wave-uniform
+        bool in = (coo_x < (unsigned int)a.cols) & (coo_y < rows_u);   // 0 <= coo < size as ONE unsigned compare per axis
+        if constexpr (!FAST) in = in & !(inv_z < 0);   // FAST: the sign of d is constant over the task and part of the task's lane mask
+        in_img[u] = in;
+        unsigned int pix = kt_mad24(coo_y, (unsigned int)a.cols, coo_x);   // exact inside the image; selected away outside
+        pix = in ? pix : 0u;
+        rec[u] = a.rec[pix];
+        r2[u] = __builtin_fmaf(e.vgz, e.vgz, v_g_part_norm);
+        toff[u] = col_base2 + e.zoff2;
+        v_x += dvx;  // the walk advances on every step, also on skipped ones
+        v_y += dvy;
+    }
+    // ---- phase B: the update predicate (dp != 0 and sdf >= -trunc), the new tsdf sample, the volume words of the voxels that pass
+    bool upd[KT_TSDF_UNROLL];
+    float tv[KT_TSDF_UNROLL];
+    unsigned int raw[KT_TSDF_UNROLL];   // the packed tsdf, zero-extended (one register each: packing two per register would wait for the loads here)
+    unsigned int col[KT_TSDF_UNROLL];
+#pragma unroll
+    for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
+        const float Dp_scaled = fabsf(rec[u].dp);   // a negative scaled depth flags "no colour" (tsdf_volume.cu:520-527, :590-594)
+        // v_sqrt_f32 (<= 1 ulp) gives t = sdf / trunc to within 2e-5.  t > 1.001: free space, min(1, t) is exactly 1 whatever the last bit
+        // of the root.  t < -1.001: sdf < -trunc, no update.  In between (the truncation band and a hair around its edges) the correctly
+        // rounded root runs, behind a wave-uniform branch.
+        float sdf = Dp_scaled - __builtin_amdgcn_sqrtf(r2[u]);
+        const float t = sdf * tranc_dist_inv;
+        const bool live = in_img[u] & (rec[u].dp != 0);
+        const bool band = live & (t <= 1.001f) & (t >= -1.001f);   // NaN (never: r2 >= 0) falls out
+        if (__builtin_amdgcn_ballot_w64(band) != 0) {
+            asm volatile("; exact sqrt" ::: "memory");  // a real branch: if-converted, the 16-instruction correctly rounded sqrt runs for every voxel
+            if (band) sdf = Dp_scaled - __builtin_sqrtf(r2[u]);
+        }
+        upd[u] = live & (sdf >= -a.tranc_dist);   // free space: sdf > 1.001 trunc; behind the band: sdf < -1.001 trunc -- the approximate root decides both
+        tv[u] = kt_min1(sdf * tranc_dist_inv);
+        if (COUNT && in_img[u]) ++n_img;
+        if (upd[u]) {
+            raw[u] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.vol, toff[u], 0, KT_TSDF_LD_AUX);
+            col[u] = __builtin_amdgcn_raw_buffer_load_b32(m.col, kt_twice(toff[u]), 0, KT_TSDF_LD_AUX);
+        }
+    }
+    // ---- phase C: running averages, stores (only of words that changed)
+#pragma unroll
+    for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
+        if (!upd[u]) continue;
+        if (COUNT) ++n_upd;
+        const unsigned int c = col[u];
+        const float weight_prev = kt_ubyte_f32<3>(c);
+        // a voxel that already holds F = 1 (raw 32767) and sees tsdf = 1: (1 * W + 1) / (W + 1) == 1 exactly, the stored value stays
+        const bool touch = !((tv[u] == 1.0f) & (raw[u] == (unsigned int)KT_DIVISOR));
+        if (touch) {
+            const float tsdf_prev = kt_unpack_tsdf((short)raw[u]);
+            // (F W + tsdf) / (W + 1), correctly rounded: y = RN(1 / (W + 1)) from the LDS table, q = RN(n y), one exact residual, one
+            // correction (Markstein); kt_debug_div_check compares it with the division for every finite numerator and divisor 1..256
+            const float num = __builtin_fmaf(tsdf_prev, weight_prev, tv[u]), den = weight_prev + 1.0f;
+            const float y = *(const float*)((const char*)s_rcp + ((c >> 22) & 0x3fcu));   // s_rcp[c >> 24]
+            const float q0 = num * y;
+            const short packed = kt_pack_tsdf(__builtin_fmaf(__builtin_fmaf(-den, q0, num), y, q0));
+            if ((unsigned int)(unsigned short)packed != raw[u]) {   // an unchanged word is not written back
+                __builtin_amdgcn_raw_buffer_store_b16(packed, m.vol, toff[u], 0, KT_TSDF_ST_AUX);
+                if (a.bricks && packed < 0) a.bricks[s_tab[zb + u].bz + brick_xy] = 1;  // idempotent byte store (rare: the table is re-read here)
+            }
+        }
+        // weight: min(W + 1, 128) in the top byte, on the whole word (saturating add: W = 255 must not wrap)
+        unsigned int o = min(__builtin_elementwise_add_sat(c, 0x01000000u), (c & 0x00ffffffu) | 0x80000000u);
+        const unsigned int rgbf = rec[u].rgbf;
+        // colour update iff (normal valid and not flagged "no colour") or the stored colour is (0, 0, 0)  (tsdf_volume.cu:623); a voxel
+        // whose stored colour already equals the pixel's keeps it (see kt_tsdf_consume)
+        const bool blend = ((((rgbf & KT_REC_NORMAL_NAN) == 0) & (rec[u].dp > 0.0f)) | ((c & 0xffffffu) == 0)) & (((c ^ rgbf) & 0xffffffu) != 0);
+        if (blend) {
+            const float Wrkc = rec[u].wrkc;
+            const float den = weight_prev + Wrkc;
+            // numerators c_prev * W + Wrkc * c_new: the SECOND product is the fused one (oracle/_ref pins it at a .5 tie of the quotient)
+            // (the products c_prev * W are exact in float: two integers below 256)
+            const float nx = __builtin_fmaf(Wrkc, kt_ubyte_f32<0>(rgbf), kt_ubyte_f32<0>(c) * weight_prev);
+            const float ny = __builtin_fmaf(Wrkc, kt_ubyte_f32<1>(rgbf), kt_ubyte_f32<1>(c) * weight_prev);
+            const float nz = __builtin_fmaf(Wrkc, kt_ubyte_f32<2>(rgbf), kt_ubyte_f32<2>(c) * weight_prev);
+            const float rden = __builtin_amdgcn_rcpf(den);
+            // candidates k = the integer nearest n * rden, formed as MAGIC + k in one FMA (any integer next to the quotient will do: the
+            // residual test below is what licenses it)
+            float yx = __builtin_fmaf(nx, rden, KT_RNE_MAGIC), yy = __builtin_fmaf(ny, rden, KT_RNE_MAGIC), yz = __builtin_fmaf(nz, rden, KT_RNE_MAGIC);
+            const float kx = yx - KT_RNE_MAGIC, ky = yy - KT_RNE_MAGIC, kz = yz - KT_RNE_MAGIC;
+            const float lim = 0.4999f * den;
+            // candidate accepted when the FMA residual |n - k den| < 0.4999 den (then the exact quotient rounds to k); false for NaN
+            const bool safe = (fabsf(__builtin_fmaf(-kx, den, nx)) < lim) & (fabsf(__builtin_fmaf(-ky, den, ny)) < lim) &
+                              (fabsf(__builtin_fmaf(-kz, den, nz)) < lim);
+            if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
+                asm volatile("; exact blend" ::: "memory");
+                if (!safe) {
+                    yx = (float)min(255, max(0, kt_f2i_rn(nx / den))) + KT_RNE_MAGIC;
+                    yy = (float)min(255, max(0, kt_f2i_rn(ny / den))) + KT_RNE_MAGIC;
+                    yz = (float)min(255, max(0, kt_f2i_rn(nz / den))) + KT_RNE_MAGIC;
+                }
+            }
+            // k in 0..255 sits in the low byte of MAGIC + k
+            o = (o & 0xff000000u) | (__float_as_uint(yx) & 0xffu) | ((__float_as_uint(yy) & 0xffu) << 8) | ((__float_as_uint(yz) & 0xffu) << 16);
+        }
+        if (o != c) __builtin_amdgcn_raw_buffer_store_b32(o, m.col, kt_twice(toff[u]), 0, KT_TSDF_ST_AUX);   // a saturated free-space voxel in front of an unchanged pixel costs reads only
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_kernel(const kt_tsdf_lean_args a_in)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char kt_tsdf_lds[];
+    float* s_rcp = (float*)kt_tsdf_lds;                                   // [256] RN(1 / (W + 1)) for every weight byte W
+    kt_tsdf_ztab* s_tab = (kt_tsdf_ztab*)(kt_tsdf_lds + 1024);            // [N + KT_TSDF_UNROLL]
+    const kt_tsdf_lean_args& a = a_in;
+    // a parked frame does nothing here: its in-stream pre-pass left an empty task list, but a plan made ahead of the frame did not
+    if (a.fp && a.fp->skip != 0) return;
+    const int N = a.N;
+    float Ri[9], tx, ty, tz;   // the pose: from the device (kt_frame_params, written by the frame's set-up kernel) or from the arguments
+    if (a.fp) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ri[k] = a.fp->Rinv[k];
+        tx = a.fp->t[0]; ty = a.fp->t[1]; tz = a.fp->t[2];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ri[k] = a.Ri.m[k];
+        tx = a.tx; ty = a.ty; tz = a.tz;
+    }
+    const unsigned int plane = (unsigned int)N * (unsigned int)N;
+    s_rcp[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
+    for (int z = threadIdx.x; z < N + KT_TSDF_UNROLL; z += 256) {
+        const int zz = min(z, N - 1);   // entries past the volume are only ever read by masked-off steps; they repeat the last one
+        int sz = zz + a.wz; if (sz >= N) sz -= N;
+        kt_tsdf_ztab e;
+        e.vgz = a.vgz[zz]; e.zs = a.zs[zz];
+        e.zoff2 = (unsigned int)sz * plane * 2u;
+        e.bz = (sz >> KT_BRICK_LOG2) * a.nb * a.nb;
+        s_tab[z] = e;
+    }
+    __syncthreads();
+    kt_tsdf_bufs m;
+    {
+        const unsigned int nvox = (unsigned int)a_in.N * (unsigned int)a_in.N * (unsigned int)a_in.N;
+        m.vol = __builtin_amdgcn_make_buffer_rsrc((void*)a_in.volume, 0, nvox * 2u, 0x00020000);
+        m.col = __builtin_amdgcn_make_buffer_rsrc((void*)a_in.color, 0, nvox * 4u, 0x00020000);
+    }
+    const int WX = 1 << a.wcl, WY = 64 >> a.wcl;
+    const int lane = threadIdx.x & 63;
+    const float v_g_z0 = __builtin_fmaf(0 + 0.5f, a.cell_z, -tz);
+    const float dvx = Ri[2] * a.cell_z * a.intr.fx;   // Rcurr_inv_0_z_scaled
+    const float dvy = Ri[5] * a.cell_z * a.intr.fy;   // Rcurr_inv_1_z_scaled
+    const float tranc_dist_inv = 1.0f / a.tranc_dist;
+    const float r8 = Ri[8];
+    unsigned int n_upd = 0, n_batches = 0, n_tasks_done = 0, n_img = 0;
+    // XCD-aware task order (see kt_tsdf23_kernel): XCD k takes the k-th contiguous part of the list
+    const unsigned int t_begin = a.task_count[1 + (blockIdx.x & 7u)], t_end = a.task_count[2 + (blockIdx.x & 7u)];
+    for (unsigned int t = t_begin + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); t < t_end; t += (gridDim.x >> 3) * 4u) {
+        const unsigned int task = __builtin_amdgcn_readfirstlane(a.tasks[t]);
+        const int yg = (int)(task & 0xffffu), xg = (int)((task >> 16) & 0xffu), chunk = (int)(task >> 24);
+        const int sx = xg * WX + (lane & (WX - 1));
+        const int sy = min(yg * WY + (lane >> a.wcl), N - 1);   // a row past the volume (odd N) only repeats the last one, never live
+        const bool lane_ok = (sx < N) & (yg * WY + (lane >> a.wcl) < N);
+        const unsigned int wr = __builtin_amdgcn_readfirstlane(a.wrange[(size_t)yg * ((N + WX - 1) / WX) + xg]);
+        const int zc = (int)(wr & 0xffffu);
+        const int wz0 = max(zc, chunk * KT_TSDF_ZCHUNK), wz1 = min((int)(wr >> 16), (chunk + 1) * KT_TSDF_ZCHUNK);
+        if (wz0 >= wz1) continue;
+        int x = sx - a.wx; if (x < 0) x += N;
+        int y = sy - a.wy; if (y < 0) y += N;
+        const float v_g_x = __builtin_fmaf((float)x + 0.5f, a.cell_x, -tx);
+        const float v_g_y = __builtin_fmaf((float)y + 0.5f, a.cell_y, -ty);
+        const float v_g_part_norm = __builtin_fmaf(v_g_x, v_g_x, v_g_y * v_g_y);
+        const float v_z = __builtin_fmaf(Ri[8], v_g_z0, __builtin_fmaf(Ri[6], v_g_x, Ri[7] * v_g_y));
+        // the reference's walk (tsdf_volume.cu:566-571, 634-640): resume from the wave-column's checkpoint and advance to this task's first z
+        const float2 cp = a.walk0[(size_t)sy * N + min(sx, N - 1)];
+        float v_x = cp.x, v_y = cp.y;
+        {
+            int z = zc;
+            for (; z + 16 <= wz0; z += 16) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { v_x += dvx; v_y += dvy; }
+            }
+            for (; z < wz0; ++z) { v_x += dvx; v_y += dvy; }
+        }
+        const unsigned int col_base = (unsigned int)min(sx, N - 1) + (unsigned int)sy * (unsigned int)N;
+        const int brick_xy = (sy >> KT_BRICK_LOG2) * a.nb + (min(sx, N - 1) >> KT_BRICK_LOG2);
+        // d(z) = fma(R8, z_scaled(z), v_z) is monotone in z: when its values at the two ends of the task are of one sign and in
+        // [2^-20, 2^20] in magnitude, every reciprocal of the task may use the unwrapped refinement chain (kt_rcp_exact), and
+        // "inv_z < 0" is the sign of d at either end: it joins the task's lane mask.  Otherwise the task takes the division.
+        const int z_last = min(wz0 + ((wz1 - wz0 + KT_TSDF_UNROLL - 1) & ~(KT_TSDF_UNROLL - 1)) - 1, N - 1);
+        const float d_a = __builtin_fmaf(r8, s_tab[wz0].zs, v_z), d_b = __builtin_fmaf(r8, s_tab[z_last].zs, v_z);
+        const bool d_ok = fminf(fabsf(d_a), fabsf(d_b)) >= 0x1p-20f && fmaxf(fabsf(d_a), fabsf(d_b)) <= 0x1p20f && (d_a < 0) == (d_b < 0);
+        const bool fast = __builtin_amdgcn_ballot_w64(!d_ok) == 0;
+        if (fast) {
+            if (lane_ok & (d_a > 0)) {   // lanes behind the camera plane (1 / d < 0) never pass the in-image test
+                for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
+                    kt_tsdf_batch_lean<COUNT, true>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
+                }
+            }
+        } else if (lane_ok) {
+            for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
+                kt_tsdf_batch_lean<COUNT, false>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
+            }
+        }
+        if (COUNT) { n_batches += (unsigned int)((wz1 - wz0 + KT_TSDF_UNROLL - 1) / KT_TSDF_UNROLL); ++n_tasks_done; }
+    }
+    if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { n_upd += __shfl_down(n_upd, off, 64); n_img += __shfl_down(n_img, off, 64); }
         if (lane == 0) {
             if (n_upd) atomicAdd(a.updated, n_upd);
@@ -1079,11 +1390,21 @@ int kt_integrate_plan(hipStream_t stream, const kt_tsdf_plan* plan, const void* 
     // |p| / p_z of a point that projects into the (padded) image is at most kappa; eps <= (theta kappa p_z + tau (1 + theta)) / (1 - theta kappa)
     const float kx = (fmaxf(intr->cx, (float)cols - intr->cx) + 3.0f) / intr->fx, ky = (fmaxf(intr->cy, (float)rows - intr->cy) + 3.0f) / intr->fy;
     const float kappa = sqrtf(1.0f + kx * kx + ky * ky);
-    KT_ARG(theta * kappa < 0.25f);
+    if (!(theta * kappa < 0.25f)) return KT_NO_PLAN;   // the margin algebra needs theta kappa << 1: no plan, not an error (the caller falls back to the in-stream pre-pass)
     a.pm_A = 1.01f * theta * kappa / (1.0f - theta * kappa);
     a.pm_B = 1.01f * tau * (1.0f + theta) / (1.0f - theta * kappa);
     return kt_tsdf_prepass(stream, a, plan->wrange, nullptr, plan->tasks, plan->task_count);
 }
+
+// test / A-B hook: which voxel kernel the N < 1024 launches use (-1: KT_TSDF_LEAN in the environment, else the build's default)
+static int kt_tsdf_lean_override = -1;
+extern "C" int kt_debug_tsdf_lean(int on) { kt_tsdf_lean_override = on < 0 ? -1 : (on != 0); return KT_OK; }
+static bool kt_tsdf_lean_selected()
+{
+    static const bool lean_env = []() { const char* e = getenv("KT_TSDF_LEAN"); return e ? atoi(e) != 0 : KT_TSDF_LEAN_DEFAULT != 0; }();
+    return kt_tsdf_lean_override < 0 ? lean_env : kt_tsdf_lean_override != 0;
+}
+extern "C" const char* kt_debug_tsdf_kernel(void) { return kt_tsdf_lean_selected() ? "kt_tsdf23_lean_kernel" : "kt_tsdf23_kernel"; }
 
 // shared by the C entry point and the tracker (which wants the update count for the roofline report)
 int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
@@ -1161,7 +1482,16 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
     dim3 b(256), g(KT_TSDF_WAVES / 4);
     if (kt_tsdf23_hook.on) KT_HIP(hipEventRecord(kt_tsdf23_hook.ev[0], c->stream));
     const bool buf = N < 1024 && !getenv("KT_TSDF_POINTERS");   // 32-bit byte offsets into the colour volume (N^3 * 4 < 2^32)
-    if (updated_dev) {
+    if (buf && kt_tsdf_lean_selected()) {   // round 4: the kernel with the scalar half cut (same stored bits; KT_TSDF_LEAN=0 selects the round-3 kernel)
+        kt_tsdf_lean_args l;
+        l.rec = a.rec; l.volume = a.volume; l.color = a.color; l.vgz = a.vgz; l.zs = a.zs; l.tasks = a.tasks; l.task_count = a.task_count;
+        l.wrange = a.wrange; l.walk0 = a.walk0; l.updated = a.updated; l.fp = a.fp; l.bricks = a.bricks; l.Ri = a.Ri;
+        l.tx = a.tx; l.ty = a.ty; l.tz = a.tz; l.intr = a.intr; l.cell_x = a.cell_x; l.cell_y = a.cell_y; l.cell_z = a.cell_z;
+        l.tranc_dist = a.tranc_dist; l.wx = a.wx; l.wy = a.wy; l.wz = a.wz; l.cols = a.cols; l.rows = a.rows; l.N = a.N; l.nb = a.nb; l.wcl = a.wcl;
+        const size_t lds = 1024 + sizeof(kt_tsdf_ztab) * (size_t)(N + KT_TSDF_UNROLL);
+        if (updated_dev) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<true>), g, b, lds, c->stream, l);
+        else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<false>), g, b, lds, c->stream, l);
+    } else if (updated_dev) {
         if (buf) hipLaunchKernelGGL((kt_tsdf23_kernel<true, true>), g, b, 0, c->stream, a);
         else hipLaunchKernelGGL((kt_tsdf23_kernel<true, false>), g, b, 0, c->stream, a);
     } else {

@@ -4,8 +4,8 @@
 // kt_slice_process on the GPU instead of three PCL passes on the CPU -- and, at the end of a run, writes what the reference's save()
 // writes: the concatenated processed clouds, voxel-gridded once more unless overlaps are kept, as a binary PCD of
 // pcl::PointXYZRGBNormal (kt_host_voxel_grid_normal / kt_host_save_pcd).
-// ThreadDataPack below carries the fields of utils/ThreadDataPack.h this thread reads and writes; the rest of that singleton (mesh,
-// loop-closure and deformation state) belongs to backend threads that are not part of this path.
+// A ThreadObject like the reference's: a controller starts it with std::thread(&ThreadObject::start, processor); it ends itself once it
+// has taken over the FINAL slice (the tracker thread keeps waking it until then, TrackerInterface.cpp:66-69).
 #pragma once
 
 #include <atomic>
@@ -19,38 +19,12 @@
 
 #include "ConfigArgs.h"
 #include "KintinuousTracker.h"
+#include "ThreadObject.h"
 #include "Volume.h"
 
-class ThreadDataPack {
+class CloudSliceProcessor : public ThreadObject {
   public:
-    static ThreadDataPack& get()
-    {
-        static ThreadDataPack instance;
-        return instance;
-    }
-    void assignFrontend(KintinuousTracker* frontend) { tracker = frontend; }
-    void reset()
-    {
-        if (cloudSlices.size()) delete cloudSlices.at(0);   // the FIRST slice is the processor's own; the others belong to the tracker
-        cloudSlices.clear();
-        latestPoseId.assignValue(0);
-        trackerFinished.assignValue(false);
-        cloudSliceProcessorFinished.assignValue(false);
-        finalised.assignValue(false);
-    }
-
-    KintinuousTracker* tracker;
-    std::vector<CloudSlice*> cloudSlices;
-    ThreadMutexObject<int> latestPoseId;
-    ThreadMutexObject<bool> trackerFinished, cloudSliceProcessorFinished, finalised;
-
-  private:
-    ThreadDataPack() : tracker(0), latestPoseId(0), trackerFinished(false), cloudSliceProcessorFinished(false), finalised(false) {}
-};
-
-class CloudSliceProcessor {
-  public:
-    CloudSliceProcessor() : threadPack(ThreadDataPack::get()), lagTime(0), ctx(0) { reset(); }
+    CloudSliceProcessor() : ThreadObject("CloudSliceProcessorThread"), ctx(0) { reset(); }
     virtual ~CloudSliceProcessor()
     {
         if (ctx) kt_ctx_destroy(ctx);
@@ -62,10 +36,40 @@ class CloudSliceProcessor {
         cycledMutex = false;
     }
 
-    // one turn of ThreadObject::run()'s loop (CloudSliceProcessor.cpp:38-178); false once the FINAL slice has been taken over.
-    // wait_ms bounds the wait on cloudSignal (the reference waits without a bound, :42; its main thread wakes it at shutdown).
-    bool process(int wait_ms = 50)
+    // :180-231.  Returns the number of points written (the reference prints it), or -1 when the file cannot be written.
+    long long save()
     {
+        if (!(threadPack.finalised.getValue() && threadPack.cloudSlices.size() > 1)) return -1;   // assert(finalised && cloudSlices.size() > 1), :182
+        CloudSlice::PointCloudNormal fullCloud;
+        const int latestPoseIdCopy = threadPack.latestPoseId.getValue();
+        for (int i = 1; i < latestPoseIdCopy; i++)
+            fullCloud.insert(fullCloud.end(), threadPack.cloudSlices.at(i)->processedCloud->begin(), threadPack.cloudSlices.at(i)->processedCloud->end());
+        if (ConfigArgs::get().extractOverlap && !ConfigArgs::get().saveOverlap && fullCloud.size()) {
+            CloudSlice::PointCloudNormal tempCloud(fullCloud.size());
+            size_t kept = 0;
+            ktSafeCall(kt_host_voxel_grid_normal(reinterpret_cast<const kt_point_xyzrgbnormal*>(fullCloud.data()), fullCloud.size(), leafSize(),
+                                                 reinterpret_cast<kt_point_xyzrgbnormal*>(tempCloud.data()), &kept));
+            tempCloud.resize(kept);
+            fullCloud.swap(tempCloud);
+        }
+        std::printf("Saving %zu points... ", fullCloud.size());
+        std::fflush(stdout);
+        const std::string filePCD = ConfigArgs::get().saveFile + ".pcd";
+        if (kt_host_save_pcd(filePCD.c_str(), reinterpret_cast<const kt_point_xyzrgbnormal*>(fullCloud.data()), fullCloud.size()) != KT_OK) {
+            std::printf("failed: %s\n", kt_last_error());
+            return -1;
+        }
+        std::printf("PCD saved\n");
+        return (long long)fullCloud.size();
+    }
+
+  private:
+    // one turn of ThreadObject::run()'s loop (CloudSliceProcessor.cpp:38-178); false once the FINAL slice has been taken over.
+    // The wait on cloudSignal is bounded at 50 ms (the reference waits without a bound, :42, and relies on the tracker's per-frame
+    // notify and on the end-of-run wake-ups of TrackerInterface.cpp:66-69; so does this, the bound only covers a lost wake-up).
+    bool inline process()
+    {
+        const int wait_ms = 50;
         std::unique_lock<std::mutex> lock(threadPack.tracker->cloudMutex);
         threadPack.tracker->cloudSignal.wait_for(lock, std::chrono::milliseconds(wait_ms));
         std::vector<CloudSlice*>* trackerSlices = &threadPack.tracker->getCloudSlices();
@@ -79,7 +83,7 @@ class CloudSliceProcessor {
             kt::Matrix3f lastRotation = threadPack.tracker->getLastRotation();
             kt::Vector3f lastTranslation = threadPack.tracker->getLastTranslation();
             threadPack.cloudSlices.push_back(new CloudSlice(new CloudSlice::PointCloud(), CloudSlice::FIRST, CloudSlice::FAIL, lastTranslation,
-                                                            lastRotation, initTime, 0, 0, 0, 0, 0, &threadPack.tracker->placeRecognitionBuffer[0]));
+                                                            lastRotation, initTime, Stopwatch::getCurrentSystemTime(), 0, 0, 0, 0, &threadPack.tracker->placeRecognitionBuffer[0]));
             threadPack.cloudSlices.back()->processedCloud = new CloudSlice::PointCloudNormal();
             threadPack.latestPoseId.assignAndNotifyAll((int)threadPack.cloudSlices.size());
         }
@@ -119,7 +123,7 @@ class CloudSliceProcessor {
             threadPack.latestPoseId.assignAndNotifyAll((int)threadPack.cloudSlices.size());
             latestPushedCloud++;
         }
-        if (latestPushedCloud) lagTime.assignValue(trackerSlices->at(latestPushedCloud - 1)->lagTime);
+        if (latestPushedCloud) lagTime.assignValue(Stopwatch::getCurrentSystemTime() - trackerSlices->at(latestPushedCloud - 1)->lagTime);   // :165-168
         if (threadPack.cloudSlices.size() && threadPack.cloudSlices.back()->dimension == CloudSlice::FINAL) {
             threadPack.cloudSliceProcessorFinished.assignAndNotifyAll(true);
             lagTime.assignValue(0);
@@ -128,37 +132,6 @@ class CloudSliceProcessor {
         return true;
     }
 
-    // :180-231.  Returns the number of points written (the reference prints it), or -1 when the file cannot be written.
-    long long save()
-    {
-        if (threadPack.cloudSlices.size() <= 1) return -1;   // assert(... cloudSlices.size() > 1)
-        CloudSlice::PointCloudNormal fullCloud;
-        const int latestPoseIdCopy = threadPack.latestPoseId.getValue();
-        for (int i = 1; i < latestPoseIdCopy; i++)
-            fullCloud.insert(fullCloud.end(), threadPack.cloudSlices.at(i)->processedCloud->begin(), threadPack.cloudSlices.at(i)->processedCloud->end());
-        if (ConfigArgs::get().extractOverlap && !ConfigArgs::get().saveOverlap && fullCloud.size()) {
-            CloudSlice::PointCloudNormal tempCloud(fullCloud.size());
-            size_t kept = 0;
-            ktSafeCall(kt_host_voxel_grid_normal(reinterpret_cast<const kt_point_xyzrgbnormal*>(fullCloud.data()), fullCloud.size(), leafSize(),
-                                                 reinterpret_cast<kt_point_xyzrgbnormal*>(tempCloud.data()), &kept));
-            tempCloud.resize(kept);
-            fullCloud.swap(tempCloud);
-        }
-        std::printf("Saving %zu points... ", fullCloud.size());
-        std::fflush(stdout);
-        const std::string filePCD = ConfigArgs::get().saveFile + ".pcd";
-        if (kt_host_save_pcd(filePCD.c_str(), reinterpret_cast<const kt_point_xyzrgbnormal*>(fullCloud.data()), fullCloud.size()) != KT_OK) {
-            std::printf("failed: %s\n", kt_last_error());
-            return -1;
-        }
-        std::printf("PCD saved\n");
-        return (long long)fullCloud.size();
-    }
-
-    ThreadDataPack& threadPack;
-    ThreadMutexObject<uint64_t> lagTime;
-
-  private:
     static float leafSize()
     {
         const float3& v = Volume::get().getVoxelSizeMeters();

@@ -115,8 +115,6 @@ class KintinuousTracker {
         // the odometry provider, KintinuousTracker.cpp:128-178: a trajectory file wins over the odometry flags
         if (args.trajectoryFile.size()) {
             loadTrajectory(args.trajectoryFile);
-            for (size_t k = 0; k < trajectoryTimes.size(); ++k)
-                kt_host_trajectory_pose(&trajectoryPoses[k * 7], camera_trajectory[trajectoryTimes[k]].data());
             groundTruth = new GroundTruthOdometry(tvecs_, rmats_, camera_trajectory, odom_utime);
             odometryProvider = groundTruth;
             lastOdometry = CloudSlice::GROUNDTRUTH;
@@ -267,6 +265,48 @@ class KintinuousTracker {
         config.overlap = o;
         if (fast) { kt_tracker_destroy(fast); fast = 0; }
     }
+
+    // KintinuousTracker::loadTrajectory (KintinuousTracker.cpp:216-260): lines "utime,x,y,z,qx,qy,qz,qw"; the poses themselves are
+    // built inside the library (kt_tracker_load_trajectory)
+    void loadTrajectory(const std::string& filename)
+    {
+        FILE* f = std::fopen(filename.c_str(), "r");
+        if (!f) {
+            std::fprintf(stderr, "cannot open trajectory file %s\n", filename.c_str());
+            std::exit(1);
+        }
+        haveTrajectory = true;
+        // the reference fills a map keyed by utime (camera_trajectory[utime] = T, :253): loading a file again -- the constructor does it
+        // for -p, MainController::setup does it once more (MainController.cpp:112-116) -- replaces the entries.  So does this.
+        trajectoryTimes.clear();
+        trajectoryPoses.clear();
+        char line[512];
+        double trajSum = 0.0;
+        bool first = true;
+        float lastT[3] = {0, 0, 0};
+        while (std::fgets(line, sizeof(line), f)) {
+            unsigned long long utime;
+            float v[7];
+            if (std::sscanf(line, "%llu,%f,%f,%f,%f,%f,%f,%f", &utime, &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) != 8) continue;
+            if (!first) {
+                const float d[3] = {v[0] - lastT[0], v[1] - lastT[1], v[2] - lastT[2]};
+                trajSum += std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            }
+            first = false;
+            for (int k = 0; k < 3; ++k) lastT[k] = v[k];
+            trajectoryTimes.push_back(utime);
+            trajectoryPoses.insert(trajectoryPoses.end(), v, v + 7);
+        }
+        std::fclose(f);
+        std::printf("Done loading ground truth, length: %g\n", trajSum);
+        if (operatorPath) {
+            for (size_t k = 0; k < trajectoryTimes.size(); ++k)
+                kt_host_trajectory_pose(&trajectoryPoses[k * 7], camera_trajectory[trajectoryTimes[k]].data());
+        } else if (fast) {
+            ktSafeCall(kt_tracker_load_trajectory(fast, (int)trajectoryTimes.size(), trajectoryTimes.data(), trajectoryPoses.data()));
+        }
+    }
+
 
     void finalise()
     {
@@ -579,37 +619,6 @@ class KintinuousTracker {
         int dim;
         ktSafeCall(kt_tracker_slice_info(fast, kt_tracker_num_slices(fast) - 1, &n, &dim));
         return dim == CloudSlice::FINAL;
-    }
-
-    // KintinuousTracker::loadTrajectory (KintinuousTracker.cpp:216-260): lines "utime,x,y,z,qx,qy,qz,qw"; the poses themselves are
-    // built inside the library (kt_tracker_load_trajectory)
-    void loadTrajectory(const std::string& filename)
-    {
-        FILE* f = std::fopen(filename.c_str(), "r");
-        if (!f) {
-            std::fprintf(stderr, "cannot open trajectory file %s\n", filename.c_str());
-            std::exit(1);
-        }
-        haveTrajectory = true;
-        char line[512];
-        double trajSum = 0.0;
-        bool first = true;
-        float lastT[3] = {0, 0, 0};
-        while (std::fgets(line, sizeof(line), f)) {
-            unsigned long long utime;
-            float v[7];
-            if (std::sscanf(line, "%llu,%f,%f,%f,%f,%f,%f,%f", &utime, &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) != 8) continue;
-            if (!first) {
-                const float d[3] = {v[0] - lastT[0], v[1] - lastT[1], v[2] - lastT[2]};
-                trajSum += std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-            }
-            first = false;
-            for (int k = 0; k < 3; ++k) lastT[k] = v[k];
-            trajectoryTimes.push_back(utime);
-            trajectoryPoses.insert(trajectoryPoses.end(), v, v + 7);
-        }
-        std::fclose(f);
-        std::printf("Done loading ground truth, length: %g\n", trajSum);
     }
 
     // <saveFile>.poses, KintinuousTracker.cpp:199-218

@@ -28,13 +28,11 @@ int main(int argc, char** argv)
     pack.tracker->tsdfRequest.assignValue(true);     // the GUI's "draw the live TSDF" switch (PangoVis)
     pack.tracker->liveViewsEnabled = true;
 
-    std::thread consumer([&]() {
-        int idle = 0;
-        while (processor.process()) {
-            if (pack.trackerFinished.getValue() && ++idle > 200) break;   // 10 s after the tracker has finished without a FINAL slice: give up
-        }
-    });
-    while (tracker.process()) {}
+    pack.limit.assignValue(false);   // the GUI's 30 Hz throttle (ThreadDataPack::limit) off: play the log as fast as it tracks
+    // MainController::mainLoop (MainController.cpp:142-150): every component runs ThreadObject::start on a thread of its own
+    std::thread consumer(&ThreadObject::start, static_cast<ThreadObject*>(&processor));
+    std::thread producer(&ThreadObject::start, static_cast<ThreadObject*>(&tracker));
+    producer.join();   // ends after finalise() and the hand-shake on cloudSliceProcessorFinished (TrackerInterface.cpp:57-71)
     pack.trackerFinished.assignValue(true);
     consumer.join();
 

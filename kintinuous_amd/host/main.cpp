@@ -161,29 +161,29 @@ int main(int argc, char** argv)
     // the slice stage itself runs on the device behind every extraction (the operator path hands raw slices to the processor instead)
     if (pcd && !ops && !noStage) tracker.getFrontend()->enableSliceStage(args.weightCull);
     CloudSliceProcessor sliceProcessor;
+    pack.limit.assignValue(false);   // the GUI's 30 Hz throttle (ThreadDataPack::limit) off: play the log as fast as it tracks
+    // Components run as in MainController::mainLoop (MainController.cpp:142-150): ThreadObject::start on a thread each.  Without -pcd no
+    // slice processor runs; it is then marked finished up front, the way MainController::setup marks absent components (:121-141), so
+    // that the tracker's end-of-log hand-shake (TrackerInterface.cpp:66-69) has nothing to wait for.
     std::thread sliceThread;
-    if (pcd)
-        sliceThread = std::thread([&]() {
-            int idle = 0;
-            while (sliceProcessor.process())
-                if (pack.trackerFinished.getValue() && ++idle > 200) break;   // 10 s without a FINAL slice after the last frame: give up
-        });
+    if (pcd) sliceThread = std::thread(&ThreadObject::start, static_cast<ThreadObject*>(&sliceProcessor));
+    else pack.cloudSliceProcessorFinished.assignValue(true);
 
     const auto t0 = std::chrono::steady_clock::now();
-    int frames = 0;
-    while (tracker.process()) ++frames;
+    std::thread trackerThread(&ThreadObject::start, static_cast<ThreadObject*>(&tracker));
+    trackerThread.join();
+    const int frames = tracker.getCurrentFrame();
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     pack.trackerFinished.assignValue(true);
+    if (pcd) sliceThread.join();   // the slices are the processor's until it has ended (it rewrites slice->cloud in place)
 
     KintinuousTracker* fe = tracker.getFrontend();
-    size_t points = 0;
+    // -pcdraw is the extraction as the tracker produced it: only meaningful without -pcd, whose processor down-samples slice->cloud in place
+    if (pcdraw && !pcd && !writeRawPcd(args.saveFile + ".raw.pcd", fe->getCloudSlices())) std::fprintf(stderr, "cannot write %s.raw.pcd\n", args.saveFile.c_str());
+    if (pcdraw && pcd) std::fprintf(stderr, "-pcdraw ignored with -pcd (the slice processor rewrites the slices in place)\n");
+    size_t points = 0;   // with -pcd: the down-sampled slices (the processor has ended); without: the raw extraction
     for (size_t i = 0; i < fe->getCloudSlices().size(); ++i) points += fe->getCloudSlices()[i]->cloud->size();
-    if (pcdraw && !writeRawPcd(args.saveFile + ".raw.pcd", fe->getCloudSlices())) std::fprintf(stderr, "cannot write %s.raw.pcd\n", args.saveFile.c_str());
-    if (pcd) {
-        sliceThread.join();
-        pack.finalised.assignValue(true);
-        if (!pack.cloudSliceProcessorFinished.getValue() || sliceProcessor.save() < 0) std::fprintf(stderr, "cannot write %s.pcd\n", args.saveFile.c_str());
-    }
+    if (pcd && (!pack.cloudSliceProcessorFinished.getValue() || sliceProcessor.save() < 0)) std::fprintf(stderr, "cannot write %s.pcd\n", args.saveFile.c_str());
     if (ppm) writeViews(fe, args.saveFile);
     const kt::Vector3f cam = fe->getCurrentGlobalCamera();
     std::printf("frames %d  slices %zu  points %zu  last camera %.6f %.6f %.6f  %.1f frames/s (incl. file I/O and uploads)  path %s\n", frames,

@@ -17,6 +17,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Round 4: two voxel kernels store the same bits (kt_tsdf23_lean_kernel and the round-3 kt_tsdf23_kernel; kt_debug_tsdf_lean selects):
+# every GPU test of these modules runs once per kernel.
+VOXEL_KERNEL_MODULES = {"test_gpu_volume", "test_gpu_sweep", "test_golden_ref", "test_golden", "test_gpu_fullsize"}
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__.split(".")[-1] in VOXEL_KERNEL_MODULES and metafunc.definition.get_closest_marker("gpu"):
+        if "voxel_kernel" not in metafunc.fixturenames:
+            metafunc.fixturenames.append("voxel_kernel")
+        metafunc.parametrize("voxel_kernel", ["lean", "r3"], indirect=True)
+
+
+@pytest.fixture
+def voxel_kernel(request, ktlib):
+    from kintinuous_amd import abi
+    abi._chk(ktlib.kt_debug_tsdf_lean(1 if request.param == "lean" else 0))
+    yield request.param
+    abi._chk(ktlib.kt_debug_tsdf_lean(-1))
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle

@@ -22,6 +22,17 @@ def _run(args, cwd):
     return r.stdout
 
 
+def _controller(args, cwd):
+    exe = os.path.join(ROOT, "kintinuous_amd", "host", "bin", "controller_test")
+    assert os.path.exists(exe), "controller_test not built: run __graft_entry__.build()"
+    r = subprocess.run([exe] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("controller ")]
+    assert r.returncode == 0 and line, r.stdout + r.stderr
+    tok = line[-1].split()
+    return {k: tok[tok.index(k) + 1] for k in ("frames", "slices", "consumed", "saved", "finished")}, r.stdout
+
+
+
 def _summary(out):
     tok = [l for l in out.splitlines() if l.startswith("frames ")][-1].split()
     return {"frames": int(tok[1]), "slices": int(tok[3]), "points": int(tok[5])}
@@ -172,6 +183,12 @@ def test_ground_truth_trajectory_cli(ctx, tmp_path):
     assert out["slices"] == 1
     P = _poses(tmp_path / "gt.poses")
     assert len(P) == len(keep) - 1                     # the first frame writes no line, the dropped frame none either
+    # MainController::setup calls trackerInterface->loadTrajectory once more on top of the constructor's (MainController.cpp:112-116):
+    # the controller stand-in does, and must write the same file
+    gotc, outc = _controller(["-l", log, "-c", calib, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "6", "-p", tfile, "-o",
+                              str(tmp_path / "gtc")], str(tmp_path))
+    assert "Load trajectory:" in outc and gotc["finished"] == "1"
+    assert open(str(tmp_path / "gt.poses"), "rb").read() == open(str(tmp_path / "gtc.poses"), "rb").read()
 
     cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
     trk = abi.Tracker(ctx, cfg)
@@ -236,7 +253,8 @@ def test_backend_consumer_runs_against_the_shell(ctx, tmp_path):
     args = ["-l", log, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "7", "-t", "3", "-v", "vocab.yml.gz", "-cw", "2"]
     r = subprocess.run([exe] + args, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    head = r.stdout.splitlines()[0].split()
+    head = [l for l in r.stdout.splitlines() if l.startswith("consumed ")][0].split()   # (the ThreadObjects announce themselves first)
+    assert "TrackerInterfaceThread started" in r.stdout and "CloudSliceProcessorThread ended" in r.stdout
     got = {k: head[head.index(k) + 1] for k in ("consumed", "finished", "first_utime", "pr", "loops", "poses", "latest", "first_frame")}
     # the same run through the C-ABI tracker.  consumer_test derives its intrinsics from the image size like MainController's default
     k = (528.0 * cam.cols / 640.0, 528.0 * cam.rows / 480.0, 320.0 * cam.cols / 640.0, 240.0 * cam.rows / 480.0)
@@ -253,7 +271,7 @@ def test_backend_consumer_runs_against_the_shell(ctx, tmp_path):
     assert int(got["first_utime"]) == 0 and got["first_frame"] == "1"
     live = head[head.index("live") + 1: head.index("live") + 3]
     assert int(live[0]) > 1000 and live[1] == "1"                                       # getLiveTsdf / getLiveImage were served
-    lines = [l.split() for l in r.stdout.splitlines()[1:]]
+    lines = [l.split() for l in r.stdout.splitlines() if l.startswith("slice ")]
     assert len(lines) == nslices
     for i, l in enumerate(lines):
         n, dim = trk.slice_info(i)
@@ -264,3 +282,41 @@ def test_backend_consumer_runs_against_the_shell(ctx, tmp_path):
         assert int(l[5]) == int(l[7]) <= n
         assert (int(l[7]) > 0) == (n > 0) or int(l[7]) == 0
     trk.close()
+
+
+def test_main_controller_runs_against_the_shell(tmp_path):
+    """host/controller_test.cpp is MainController::setup / mainLoop / complete / save (MainController.cpp:93-183, 235-265) minus the GUI,
+    compiled against the shell's TrackerInterface and CloudSliceProcessor AS ThreadObjects (start / stop / running, endRequested,
+    loadTrajectory, the pauseCapture / finalised / cloudSliceProcessorFinished hand-shake, the limit throttle).  It must end by itself at
+    the end of the log, write the same .poses as kintinuous_hip and a .pcd with the same points; -end K (the GUI's End button) must stop
+    the run early through endRequested and still finalise and save; -limit must hold the tracker to 30 frames per second."""
+    from kintinuous_amd import klg, synth
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("wall")
+    traj = synth.crabwalk_trajectory(420)
+    frames = [synth.render(scene, cam, *traj[i]) for i in range(0, 48, 2)]
+    log, calib = _make_log(tmp_path, cam, frames)
+    common = ["-l", log, "-c", calib, "-n", "96", "-w", str(cam.cols), "-h", str(cam.rows), "-s", "7", "-t", "3"]
+    a = _summary(_run(common + ["-o", str(tmp_path / "drv"), "-pcd"], str(tmp_path)))
+    got, out = _controller(common + ["-o", str(tmp_path / "ctl"), "-stage"], str(tmp_path))
+    assert "TrackerInterfaceThread started" in out and "TrackerInterfaceThread ended" in out and "CloudSliceProcessorThread ended" in out
+    assert got["finished"] == "1" and int(got["frames"]) == a["frames"] == len(frames) and int(got["slices"]) == a["slices"] >= 3
+    assert int(got["consumed"]) == a["slices"] + 1                       # + the processor's own FIRST slice
+    assert open(str(tmp_path / "drv.poses"), "rb").read() == open(str(tmp_path / "ctl.poses"), "rb").read()
+    pa, pb = klg.read_pcd(str(tmp_path / "drv.pcd")), klg.read_pcd(str(tmp_path / "ctl.pcd"))
+    assert len(pa) == len(pb) == int(got["saved"]) > 1000
+    # (extraction order inside a slice is free, so a leaf's float sum may differ in its last bits between two runs: tests/test_pcd.py)
+    assert np.abs(pa["xyz"] - pb["xyz"]).max() <= 2e-6 * max(1.0, float(np.abs(pa["xyz"]).max()))
+    # the processor thread doing the per-slice stage itself (kt_slice_process on its own context) gives the same cloud
+    got2, _ = _controller(common + ["-o", str(tmp_path / "ctl2")], str(tmp_path))
+    assert got2["saved"] == got["saved"] and got2["consumed"] == got["consumed"]
+    # the End button: endRequested after 8 frames -> finalise, hand-shake, save; fewer frames than the log holds
+    got3, _ = _controller(common + ["-o", str(tmp_path / "ctl3"), "-end", "8"], str(tmp_path))
+    assert got3["finished"] == "1" and 8 <= int(got3["frames"]) < len(frames) and int(got3["saved"]) > 0
+    P = _poses(str(tmp_path / "ctl3.poses"))
+    assert len(P) == int(got3["frames"]) - 1 and np.array_equal(P, _poses(str(tmp_path / "ctl.poses"))[:len(P)])   # (the first frame writes no line)
+    # the 30 Hz throttle (ThreadDataPack::limit, TrackerInterface.cpp:106-110)
+    import time
+    t0 = time.time()
+    got4, _ = _controller(common + ["-o", str(tmp_path / "ctl4"), "-end", "6", "-limit"], str(tmp_path))
+    assert got4["finished"] == "1" and time.time() - t0 >= 6 * 0.0333

@@ -497,3 +497,128 @@ def test_planned_voxel_pass_is_transparent(ctx, oracle_mod, monkeypatch, mode):
         otr.process_frame(d, rgb, 33333 * k)
     assert np.array_equal(hit["vol"], otr.volume()) and np.array_equal(hit["col"], otr.color_volume())
     otr.close()
+
+
+def test_plan_is_bound_to_its_frame(ctx, monkeypatch):
+    """A task plan is made from ONE read-ahead frame's depth (its pixel records and tile maxima) and may only serve that frame.  The
+    caller is allowed to skip a read-ahead: announce A and B, process B.  The plan made for "the next frame" (A) must not be used for
+    B -- its column intervals would end where A's surfaces end -- and the skipped set must not be rewritten under the plan's kernels.
+    B is A's view with every surface 0.4 m farther away, so a plan from A's depth cuts B's updates short; the result must equal a run
+    without planning."""
+    from kintinuous_amd import abi, synth
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("room")
+    traj = synth.orbit_trajectory(12)
+    frames = [synth.render(scene, cam, R, c) for (R, c) in traj]
+    frames = [(np.ascontiguousarray(d, np.uint16), np.ascontiguousarray(rgb, np.uint8)) for d, rgb in frames]
+    far = [(np.where(d > 0, d + 400, 0).astype(np.uint16), rgb) for d, rgb in frames]
+    dev = [(ctx.upload(d), ctx.upload(rgb)) for d, rgb in frames]
+    dev_far = [(ctx.upload(d), ctx.upload(rgb)) for d, rgb in far]
+    g, _ = _cfgs(cam, 96)
+
+    def run(env):
+        monkeypatch.delenv("KT_NO_PLAN", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        trk = abi.Tracker(ctx, g)
+        for k in range(6):   # history for the motion model, plans that hit
+            trk.prefetch_frame(*dev[k + 1])
+            trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+        # frame 6 (A) is read ahead and has been planned for; now announce a SECOND frame (B) and process that one
+        trk.prefetch_frame(*dev_far[7])
+        trk.process_frame(dev_far[7][0], dev_far[7][1], 33333 * 6)     # ... skipping A
+        trk.prefetch_frame(*dev[8])
+        trk.process_frame(dev[7][0], dev[7][1], 33333 * 7)             # an unannounced frame while frame 8 is pending (and planned for)
+        trk.prefetch_frame(*dev[9])
+        trk.process_frame(dev[8][0], dev[8][1], 33333 * 8)             # back to the regular order
+        trk.process_frame(dev[9][0], dev[9][1], 33333 * 9)
+        out = dict(vol=trk.volume().copy(), col=trk.color_volume().copy(), poses=[trk.dense_pose(i)[1].copy() for i in range(trk.num_poses())],
+                   stats=trk.plan_stats())
+        trk.close()
+        return out
+
+    plan, off = run({}), run({"KT_NO_PLAN": "1"})
+    assert plan["stats"][0] >= 1 and off["stats"] == (0, 0), plan["stats"]
+    assert len(plan["poses"]) == len(off["poses"]) and all(np.array_equal(a, b) for a, b in zip(plan["poses"], off["poses"]))
+    assert np.array_equal(plan["vol"], off["vol"]) and np.array_equal(plan["col"], off["col"])
+
+
+def _plan_edge_runs(ctx, cam, frames, N, kw, cases, theta_tau):
+    """Run A (no plans) logs the pose every frame arrives at; runs B use those poses, offset by (fr theta, ft tau), as the plans'
+    predictions.  Returns {case: (hits, misses, equal)}."""
+    from kintinuous_amd import abi
+    g, _ = _cfgs(cam, N, **kw)
+    dev = [(ctx.upload(np.ascontiguousarray(d, np.uint16)), ctx.upload(np.ascontiguousarray(c, np.uint8))) for d, c in frames]
+
+    def play(trk):
+        for k in range(len(dev)):
+            if k + 1 < len(dev):
+                trk.prefetch_frame(*dev[k + 1])
+            trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+
+    os.environ["KT_NO_PLAN"] = "1"
+    try:
+        ref = abi.Tracker(ctx, g)
+    finally:
+        del os.environ["KT_NO_PLAN"]
+    ref.pose_log(True)
+    play(ref)
+    truth = ref.pose_log(fetch=True)
+    assert len(truth) == len(frames)
+    vol, col, wrap, nsl = ref.volume().copy(), ref.color_volume().copy(), ref.voxel_wrap().copy(), ref.num_slices()
+    ref.close()
+    out = {}
+    for (fr, ft) in cases:
+        for (theta, tau) in theta_tau:
+            trk = abi.Tracker(ctx, g)
+            trk.plan_truth(truth, fr, ft, theta, tau, seed=int(1000 * fr + 10 * ft) + 1)
+            play(trk)
+            hits, misses = trk.plan_stats()
+            equal = bool(np.array_equal(trk.voxel_wrap(), wrap) and trk.num_slices() == nsl and np.array_equal(trk.volume(), vol) and
+                         np.array_equal(trk.color_volume(), col))
+            trk.close()
+            out[(fr, ft, theta, tau)] = (hits, misses, equal)
+    return out
+
+
+import os  # noqa: E402
+
+
+@pytest.mark.parametrize("size", ["small", "orbit512", "farwall768"])
+def test_plan_margins_hold_at_their_edge(ctx, size):
+    """The one mechanism whose failure is silent: a plan that is too tight DROPS voxels (skipped iterations do not run at all).  The
+    pre-pass is widened for a pose within theta (rotation) and tau (translation) of the prediction; here every frame's pose lands at
+    0.9 / 0.98 of BOTH margins in a random direction (the prediction is the frame's real pose from an identical run, offset by exactly
+    that much) -- the plans must be accepted and the volumes must equal those of a run without plans, byte for byte; at 1.05 of either
+    margin the set-up kernel must reject the plan (and the fall-back gives the same volumes).  Margins: small realistic ones and the
+    caps (20 mrad, 20 mm)."""
+    from kintinuous_amd import synth
+    if size == "small":
+        cam = synth.Camera.small(160, 120)
+        traj = synth.crabwalk_trajectory(420)
+        frames = [synth.render(synth.Scene("wall"), cam, *traj[i]) for i in list(range(0, 40, 2)) + list(range(40, 20, -2))]
+        N, kw = 96, dict(volume_size=7.0, voxel_shift=3)
+        margins = [(1.0e-3, 3.0e-3), (0.02, 0.02)]
+    elif size == "orbit512":
+        cam = synth.Camera()
+        _, frames, _, kw = synth.sequence("orbit", 24, cam)   # through the orbit's first shift
+        N = 512
+        margins = [(2.0e-3, 4.0e-3)]
+    else:
+        cam = synth.Camera.scaled(2)
+        _, frames, _, kw = synth.sequence("farwall", 8, cam)
+        kw = dict(kw, static_mode=1)
+        N = 768
+        margins = [(2.0e-3, 4.0e-3)]
+    accept = [(0.9, 0.9), (0.9, 0.98), (0.98, 0.9), (0.98, 0.98)]
+    reject = [(1.05, 0.5), (0.5, 1.05)]
+    res = _plan_edge_runs(ctx, cam, frames, N, kw, accept + reject, margins)
+    # planned frames: all but the first three (no motion history yet), minus the frames that shift the volume and the frame behind
+    # each shift (its plan was made for the old storage wrap)
+    floor = {"small": 8, "orbit512": len(frames) - 3 - 6, "farwall768": len(frames) - 3 - 1}[size]
+    for key, (hits, misses, equal) in res.items():
+        assert equal, (key, hits, misses)
+        if key[:2] in accept:
+            assert hits >= floor and misses == 0, (key, hits, misses)     # every plan that was tried was accepted
+        else:
+            assert hits == 0 and misses >= floor, (key, hits, misses)     # ... and rejected
