@@ -52,7 +52,7 @@ extern "C" int kt_debug_stream_rows(kt_ctx* c, void* buf, int N, int Z, int elem
 //        15 s_and_saveexec_b64 / s_or_b64 exec around one v_fma_f32 (an exec region)
 // Round 4: every wave also stamps s_memrealtime (the constant 100 MHz counter) at both ends, so that the shader clock UNDER THIS LOAD
 // is a measured number (ticks / real time) instead of the 2.4 GHz of the data sheet.
-#define KT_RATE_KINDS 34
+#define KT_RATE_KINDS 50
 template <int KIND>
 __global__ __launch_bounds__(256) void kt_valu_rate_kernel(int iters, unsigned long long* __restrict__ ticks, float* __restrict__ sink)
 {
@@ -220,6 +220,70 @@ __global__ __launch_bounds__(256) void kt_valu_rate_kernel(int iters, unsigned l
                 asm volatile("v_cmp_lt_u32 %8, %0, %1\n v_cmp_lt_u32 %8, %1, %2\n v_cmp_lt_u32 %8, %2, %3\n v_cmp_lt_u32 %8, %3, %4\n"
                              "v_cmp_lt_u32 %8, %4, %5\n v_cmp_lt_u32 %8, %5, %6\n v_cmp_lt_u32 %8, %6, %7\n v_cmp_lt_u32 %8, %7, %0\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) , "+s"(m0) : "v"(m), "v"(k) : "vcc");
+            else if constexpr (KIND == 34)   // v_sub_u32
+                asm volatile("v_sub_u32 %0, %0, %9\n v_sub_u32 %1, %1, %9\n v_sub_u32 %2, %2, %9\n v_sub_u32 %3, %3, %9\n"
+                             "v_sub_u32 %4, %4, %9\n v_sub_u32 %5, %5, %9\n v_sub_u32 %6, %6, %9\n v_sub_u32 %7, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 35)   // v_or_b32
+                asm volatile("v_or_b32 %0, %0, %8\n v_or_b32 %1, %1, %8\n v_or_b32 %2, %2, %8\n v_or_b32 %3, %3, %8\n"
+                             "v_or_b32 %4, %4, %8\n v_or_b32 %5, %5, %8\n v_or_b32 %6, %6, %8\n v_or_b32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 36)   // v_xor_b32
+                asm volatile("v_xor_b32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n"
+                             "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 37)   // v_min_f32
+                asm volatile("v_min_f32 %0, %0, %9\n v_min_f32 %1, %1, %9\n v_min_f32 %2, %2, %9\n v_min_f32 %3, %3, %9\n"
+                             "v_min_f32 %4, %4, %9\n v_min_f32 %5, %5, %9\n v_min_f32 %6, %6, %9\n v_min_f32 %7, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 38)   // v_cvt_i32_f32
+                asm volatile("v_cvt_i32_f32 %0, %0\n v_cvt_i32_f32 %1, %1\n v_cvt_i32_f32 %2, %2\n v_cvt_i32_f32 %3, %3\n"
+                             "v_cvt_i32_f32 %4, %4\n v_cvt_i32_f32 %5, %5\n v_cvt_i32_f32 %6, %6\n v_cvt_i32_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 39)   // v_rndne_f32
+                asm volatile("v_rndne_f32 %0, %0\n v_rndne_f32 %1, %1\n v_rndne_f32 %2, %2\n v_rndne_f32 %3, %3\n"
+                             "v_rndne_f32 %4, %4\n v_rndne_f32 %5, %5\n v_rndne_f32 %6, %6\n v_rndne_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 40)   // v_perm_b32
+                asm volatile("v_perm_b32 %0, %0, %8, %9\n v_perm_b32 %1, %1, %8, %9\n v_perm_b32 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n"
+                             "v_perm_b32 %4, %4, %8, %9\n v_perm_b32 %5, %5, %8, %9\n v_perm_b32 %6, %6, %8, %9\n v_perm_b32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 41)   // v_bfi_b32
+                asm volatile("v_bfi_b32 %0, %8, %0, %9\n v_bfi_b32 %1, %8, %1, %9\n v_bfi_b32 %2, %8, %2, %9\n v_bfi_b32 %3, %8, %3, %9\n"
+                             "v_bfi_b32 %4, %8, %4, %9\n v_bfi_b32 %5, %8, %5, %9\n v_bfi_b32 %6, %8, %6, %9\n v_bfi_b32 %7, %8, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 42)   // v_and_or_b32
+                asm volatile("v_and_or_b32 %0, %0, %8, %9\n v_and_or_b32 %1, %1, %8, %9\n v_and_or_b32 %2, %2, %8, %9\n v_and_or_b32 %3, %3, %8, %9\n"
+                             "v_and_or_b32 %4, %4, %8, %9\n v_and_or_b32 %5, %5, %8, %9\n v_and_or_b32 %6, %6, %8, %9\n v_and_or_b32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 43)   // v_or3_b32
+                asm volatile("v_or3_b32 %0, %0, %8, %9\n v_or3_b32 %1, %1, %8, %9\n v_or3_b32 %2, %2, %8, %9\n v_or3_b32 %3, %3, %8, %9\n"
+                             "v_or3_b32 %4, %4, %8, %9\n v_or3_b32 %5, %5, %8, %9\n v_or3_b32 %6, %6, %8, %9\n v_or3_b32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 44)   // v_add3_u32
+                asm volatile("v_add3_u32 %0, %0, %8, %9\n v_add3_u32 %1, %1, %8, %9\n v_add3_u32 %2, %2, %8, %9\n v_add3_u32 %3, %3, %8, %9\n"
+                             "v_add3_u32 %4, %4, %8, %9\n v_add3_u32 %5, %5, %8, %9\n v_add3_u32 %6, %6, %8, %9\n v_add3_u32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 45)   // v_lshl_or_b32
+                asm volatile("v_lshl_or_b32 %0, %0, 1, %9\n v_lshl_or_b32 %1, %1, 1, %9\n v_lshl_or_b32 %2, %2, 1, %9\n v_lshl_or_b32 %3, %3, 1, %9\n"
+                             "v_lshl_or_b32 %4, %4, 1, %9\n v_lshl_or_b32 %5, %5, 1, %9\n v_lshl_or_b32 %6, %6, 1, %9\n v_lshl_or_b32 %7, %7, 1, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 46)   // v_floor_f32
+                asm volatile("v_floor_f32 %0, %0\n v_floor_f32 %1, %1\n v_floor_f32 %2, %2\n v_floor_f32 %3, %3\n"
+                             "v_floor_f32 %4, %4\n v_floor_f32 %5, %5\n v_floor_f32 %6, %6\n v_floor_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 47)   // v_cvt_u32_f32
+                asm volatile("v_cvt_u32_f32 %0, %0\n v_cvt_u32_f32 %1, %1\n v_cvt_u32_f32 %2, %2\n v_cvt_u32_f32 %3, %3\n"
+                             "v_cvt_u32_f32 %4, %4\n v_cvt_u32_f32 %5, %5\n v_cvt_u32_f32 %6, %6\n v_cvt_u32_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 48)   // v_subrev_f32
+                asm volatile("v_subrev_f32 %0, %9, %0\n v_subrev_f32 %1, %9, %1\n v_subrev_f32 %2, %9, %2\n v_subrev_f32 %3, %9, %3\n"
+                             "v_subrev_f32 %4, %9, %4\n v_subrev_f32 %5, %9, %5\n v_subrev_f32 %6, %9, %6\n v_subrev_f32 %7, %9, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
+            else if constexpr (KIND == 49)   // v_fma_f32 with SGPR operand
+                asm volatile("v_fma_f32 %0, %0, %10, %9\n v_fma_f32 %1, %1, %10, %9\n v_fma_f32 %2, %2, %10, %9\n v_fma_f32 %3, %3, %10, %9\n"
+                             "v_fma_f32 %4, %4, %10, %9\n v_fma_f32 %5, %5, %10, %9\n v_fma_f32 %6, %6, %10, %9\n v_fma_f32 %7, %7, %10, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k), "s"(s) : "vcc");
             else if constexpr (KIND == 15)   // 4 VALU + 8 SALU: an exec region around every VALU
                 asm volatile("s_and_saveexec_b64 %4, %5\n v_fma_f32 %0, %0, %6, %7\n s_or_b64 exec, exec, %4\n"
                              "s_and_saveexec_b64 %4, %5\n v_fma_f32 %1, %1, %6, %7\n s_or_b64 exec, exec, %4\n"
@@ -259,6 +323,7 @@ extern "C" int kt_debug_valu_rates(kt_ctx* c, int kind, int iters, int waves_per
             KT_RATE_CASE(6) KT_RATE_CASE(7) KT_RATE_CASE(8) KT_RATE_CASE(9) KT_RATE_CASE(10)
             KT_RATE_CASE(11) KT_RATE_CASE(12) KT_RATE_CASE(13) KT_RATE_CASE(14) KT_RATE_CASE(15)
             KT_RATE_CASE(16) KT_RATE_CASE(17) KT_RATE_CASE(18) KT_RATE_CASE(19) KT_RATE_CASE(20) KT_RATE_CASE(21) KT_RATE_CASE(22) KT_RATE_CASE(23) KT_RATE_CASE(24) KT_RATE_CASE(25) KT_RATE_CASE(26) KT_RATE_CASE(27) KT_RATE_CASE(28) KT_RATE_CASE(29) KT_RATE_CASE(30) KT_RATE_CASE(31) KT_RATE_CASE(32) KT_RATE_CASE(33)
+            KT_RATE_CASE(34) KT_RATE_CASE(35) KT_RATE_CASE(36) KT_RATE_CASE(37) KT_RATE_CASE(38) KT_RATE_CASE(39) KT_RATE_CASE(40) KT_RATE_CASE(41) KT_RATE_CASE(42) KT_RATE_CASE(43) KT_RATE_CASE(44) KT_RATE_CASE(45) KT_RATE_CASE(46) KT_RATE_CASE(47) KT_RATE_CASE(48) KT_RATE_CASE(49)
         }
     }
     KT_HIP(hipEventRecord(ev[1], c->stream));
@@ -278,7 +343,7 @@ extern "C" int kt_debug_valu_rates(kt_ctx* c, int kind, int iters, int waves_per
     }
     // instructions of the kind's asm body per trip of the inner r loop: {VALU, SALU}
     static const int body[KT_RATE_KINDS][2] = {{8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 8}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0},
-                                               {0, 8}, {8, 4}, {4, 8}, {4, 4}, {4, 8}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}};
+                                               {0, 8}, {8, 4}, {4, 8}, {4, 4}, {4, 8}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}, {8, 0}};
     out_host[0] = sum / (blocks * 4); out_host[1] = mx; out_host[2] = (double)iters * 4 * (body[kind][0] + body[kind][1]);
     float ms = 0;
     KT_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));

@@ -148,6 +148,44 @@ __global__ __launch_bounds__(256) void slice_centroids(const kt_point_xyzrgb* __
 }
 
 // ---- pcl::eigen33 / computeRoots (common/impl/eigen.hpp), float ----
+// sin / cos / atan2 of pcl::computeRoots, on the small domain the stage needs (atan2(y >= 0, x) in [0, pi], sin / cos on [0, pi / 3]):
+// the Cephes single-precision kernels, the SAME operations in the SAME order as oracle/kt_oracle_kernels.c (sp_atan01, sp_atan2_pos,
+// sp_sincos), every fused multiply-add written out -- the device library's atan2f / sinf / cosf differ from libm in the last bits,
+// which made the normals the one output of the stage that was only close to the oracle's (1e-4) instead of equal.
+__device__ __forceinline__ float sp_atan01(float a)
+{
+    float y0 = 0.0f, x = a;
+    if (a > 0.4142135623730950f) { y0 = 0.78539816339744830962f; x = (a - 1.0f) / (a + 1.0f); }
+    const float z = x * x;
+    float p = __builtin_fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = __builtin_fmaf(p, z, 1.99777106478e-1f);
+    p = __builtin_fmaf(p, z, -3.33329491539e-1f);
+    return y0 + __builtin_fmaf(p * z, x, x);
+}
+__device__ __forceinline__ float sp_atan2_pos(float y, float x)
+{
+    const float ax = fabsf(x);
+    const float hi = ax > y ? ax : y, lo = ax > y ? y : ax;
+    if (!(hi > 0.0f)) return 0.0f;
+    float r = sp_atan01(lo / hi);
+    if (y > ax) r = 1.57079632679489661923f - r;
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    return r;
+}
+__device__ __forceinline__ void sp_sincos(float t, float& s, float& c)
+{
+    const bool swap = t > 0.78539816339744830962f;
+    const float x = swap ? 1.57079632679489661923f - t : t;
+    const float z = x * x;
+    float ps = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(ps * z, x, x);
+    float pc = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    s = swap ? cs : sn;
+    c = swap ? sn : cs;
+}
 __device__ __forceinline__ void roots2(float b, float c, float (&r)[3])
 {
     r[0] = 0.f;
@@ -171,8 +209,9 @@ __device__ __forceinline__ void roots3(const float (&m)[9], float (&r)[3])
     float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
     if (q > 0.0f) q = 0.0f;
     const float rho = __builtin_sqrtf(-a_over_3);
-    const float theta = atan2f(__builtin_sqrtf(-q), half_b) * s_inv3;
-    const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+    const float theta = sp_atan2_pos(__builtin_sqrtf(-q), half_b) * s_inv3;
+    float cos_theta, sin_theta;
+    sp_sincos(theta, sin_theta, cos_theta);
     r[0] = c2_over_3 + 2.0f * rho * cos_theta;
     r[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     r[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
@@ -229,7 +268,7 @@ __device__ __forceinline__ int lower_bound(const unsigned int* __restrict__ leaf
 // accumulated in that order (the float sums depend on it), wave-uniformly.  Points that do not find k neighbours within 4 leaf sizes
 // (isolated points, a cloud that passed through the grid unfiltered) run the same successor search over ALL leaves.
 #define KT_SLICE_MAXC 729   // (2 * 4 + 1)^3 candidates
-#define KT_SLICE_RMAX 4
+#define KT_SLICE_RMAX 16
 struct slice_pick { float d; int j; };
 __device__ __forceinline__ bool slice_less(float da, int ja, float db, int jb) { return da < db || (da == db && ja < jb); }
 __device__ __forceinline__ slice_pick slice_wave_min(slice_pick p)
@@ -264,8 +303,9 @@ __global__ __launch_bounds__(256) void slice_normals(const float* __restrict__ c
         const float dx = cen[(size_t)j * 6] - px, dy = cen[(size_t)j * 6 + 1] - py, dz = cen[(size_t)j * 6 + 2] - pz;
         return (dx * dx + dy * dy) + dz * dz;
     };
-    // the kk nearest of `nc` listed candidates (or of all L leaves when nc < 0), in (distance, index) order, into sd / sj; returns how many
-    auto select = [&](int nc) -> int {
+    // the kk nearest of `nc` listed candidates (or, when nc < 0, of the leaves [jlo, jhi)), in (distance, index) order, into sd / sj;
+    // returns how many
+    auto select = [&](int nc, int jlo = 0, int jhi = 0) -> int {
         slice_pick prev = {-1.0f, -1};
         int found = 0;
         for (int t = 0; t < kk; ++t) {
@@ -276,7 +316,7 @@ __global__ __launch_bounds__(256) void slice_normals(const float* __restrict__ c
                     if (slice_less(prev.d, prev.j, d, j) && slice_less(d, j, best.d, best.j)) { best.d = d; best.j = j; }
                 }
             } else {
-                for (int j = lane; j < L; j += 64) {
+                for (int j = jlo + lane; j < jhi; j += 64) {
                     const float d = dist2(j);
                     if (slice_less(prev.d, prev.j, d, j) && slice_less(d, j, best.d, best.j)) { best.d = d; best.j = j; }
                 }
@@ -301,21 +341,26 @@ __global__ __launch_bounds__(256) void slice_normals(const float* __restrict__ c
         // p's: a point and its cell index satisfy floor((p + d) / leaf) - floor(p / leaf) <= r for 0 <= d <= r * leaf.  The centroid
         // of a leaf lies inside the leaf up to float rounding; the half-leaf margin below covers that.
         // (k = 20 neighbours on a surface need a disc of radius ~2.5 leaves: r = 2 never proves its answer, so the search starts at 3)
-        for (int r = (kk > 7 ? 3 : 2); r <= KT_SLICE_RMAX && !exact; ++r) {
+        // radii tried in turn: 3 (2 for small k), 4, then 8 and 16 -- at the edge of a 15-voxel shift slab a 20-neighbour disc is cut in
+        // half (a quarter of a slab's points), and the missing neighbours lie further along the strip; a radius whose cells hold more
+        // than KT_SLICE_MAXC leaves (a dense cloud) is given up for the windowed search below
+        bool overflow = false;
+        for (int r = (kk > 7 ? 3 : 2); r <= KT_SLICE_RMAX && !exact && !overflow; r = r < 4 ? r + 1 : 2 * r) {
             const int side = 2 * r + 1, rows = side * side;
             int nc = 0;   // wave-uniform
-            for (int row0 = 0; row0 < rows; row0 += 64) {
+            for (int row0 = 0; row0 < rows && !overflow; row0 += 64) {
                 const int row = row0 + lane;
                 int lo = 0, n_here = 0;
                 if (row < rows) {
                     const int y = c1 + row % side - r, z = c2 + row / side - r;
                     if (y >= 0 && y < g.div_b[1] && z >= 0 && z < g.div_b[2]) {
-                        // the 2r + 1 cells of this x-row have consecutive keys: one binary search, then a short scan
+                        // the 2r + 1 cells of this x-row have consecutive keys: one binary search for each end
                         const int x0 = max(0, c0 - r), x1 = min(g.div_b[0] - 1, c0 + r);
                         const unsigned int k0 = (unsigned int)(x0 + y * g.div_b[0] + z * g.div_b[0] * g.div_b[1]), k1 = k0 + (unsigned int)(x1 - x0);
                         lo = lower_bound(leaf_key, L, k0);
                         int hi = lo;
-                        while (hi < L && leaf_key[hi] <= k1) ++hi;
+                        if (r <= 4) { while (hi < L && leaf_key[hi] <= k1) ++hi; }   // a short scan ...
+                        else hi = lower_bound(leaf_key, L, k1 + 1u);                 // ... or a second search when the row is long
                         n_here = hi - lo;
                     }
                 }
@@ -327,9 +372,12 @@ __global__ __launch_bounds__(256) void slice_normals(const float* __restrict__ c
                     if (lane >= off) incl += up;
                 }
                 const int base = nc + incl - n_here;
-                for (int i = 0; i < n_here; ++i) { cd[base + i] = dist2(lo + i); cj[base + i] = lo + i; }   // (<= (2r + 1)^3 in all)
-                nc += __shfl(incl, 63, 64);
+                const int total = nc + __shfl(incl, 63, 64);
+                if (total > KT_SLICE_MAXC) { overflow = true; break; }   // (wave-uniform)
+                for (int i = 0; i < n_here; ++i) { cd[base + i] = dist2(lo + i); cj[base + i] = lo + i; }
+                nc = total;
             }
+            if (overflow) break;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the list is written by the lanes that own the rows, scanned by all
             __builtin_amdgcn_wave_barrier();
             cnt = select(nc);
@@ -337,7 +385,24 @@ __global__ __launch_bounds__(256) void slice_normals(const float* __restrict__ c
             exact = cnt == kk && sd[kk - 1] <= reach * reach;   // (sd: written by lane 0, read by every lane of the same wave: in order within a wave)
         }
     }
-    if (!exact) cnt = select(-1);
+    // Points the cell search cannot settle used to fall back on ALL leaves -- 20 passes over 50 000 of them, most of the stage's time
+    // until round 4.  What is left after the larger radii above: the keys are sorted z-major, so the leaves within R cells of the
+    // point's z are one contiguous run of the list: the same successor search over that run, R = 8, 16, ... until the k-th neighbour is
+    // provably the k-th nearest (every point within (R - 1/2) leaf sizes lies inside the window) or the window is the whole list.
+    if (!exact && gridded) {
+        const int c2 = (int)(leaf_key[q] / ((unsigned int)g.div_b[0] * (unsigned int)g.div_b[1]));
+        const unsigned int plane_cells = (unsigned int)g.div_b[0] * (unsigned int)g.div_b[1];
+        for (int R = 8; !exact; R *= 2) {
+            const int zlo = max(0, c2 - R), zhi = min(g.div_b[2] - 1, c2 + R);
+            const bool all = zlo == 0 && zhi == g.div_b[2] - 1;
+            const int jlo = all ? 0 : lower_bound(leaf_key, L, (unsigned int)zlo * plane_cells);
+            const int jhi = (all || zhi == g.div_b[2] - 1) ? L : lower_bound(leaf_key, L, (unsigned int)(zhi + 1) * plane_cells);
+            cnt = select(-1, jlo, jhi);
+            const float reach = ((float)R - 0.5f) * g.leaf;
+            exact = all || (cnt == kk && sd[kk - 1] <= reach * reach);
+        }
+    }
+    if (!exact) cnt = select(-1, 0, L);
     kt_point_xyzrgbnormal o;
     o.x = px; o.y = py; o.z = pz; o.pad0 = 1.0f;
     o.pad1 = 0.0f; o.pad2[0] = 0.0f; o.pad2[1] = 0.0f;

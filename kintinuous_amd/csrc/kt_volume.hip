@@ -627,6 +627,178 @@ __global__ __launch_bounds__(1024) void kt_tsdf_tasks_kernel(const unsigned int*
     });
 }
 
+// Round 4: the same list without a serial walk per thread (kt_tsdf_tasks_kernel above: two walks over a thread's run of wave-columns, and
+// the active wave-columns are a contiguous band, so 15 % of the threads walked all the tasks: 20-22 us in ONE workgroup).  Two launches:
+//   kt_tsdf_tasks_scan_kernel (one workgroup)
+//     (1) the class counts {cost, n4, n3, n2, n1} of a PAIR of x-neighbouring wave-columns follow from its two z-ranges in O(1) -- the
+//         interior chunks of a column are full (4 batches), only its first and last chunk can be shorter -- so counting needs no loop;
+//     (2) their exclusive prefixes over all pairs (list order) go to memory behind the list's head: any wave can then place any pair;
+//     (3) the XCD of a pair is where its cost prefix falls (granule = one pair; the serial form's granule was a thread's run);
+//   kt_tsdf_tasks_place_kernel (one WAVE per pair, the whole GPU)
+//     (4) one lane per (chunk, column) slot of the pair in list order, ranks inside a class from ballots.
+// Same order rules as above: XCD parts by cost, inside a part stable by class (most batches first), odd rows of 128 reversed.
+// Layout of the list's head buffer (KT_TASK_HEAD_WORDS(pairs) words): [0, 16) the head proper, [16, 52) cbase[4][9], [52, 85) bbase[33],
+// [85] share of an XCD, [96 + v (P + 1) + i] exclusive prefix of quantity v over pairs.
+#define KT_TASK_CBASE 16
+#define KT_TASK_BBASE 52
+#define KT_TASK_SHARE 85
+#define KT_TASK_PREF 96
+static size_t kt_task_head_words(int N) { return KT_TASK_PREF + 5 * ((kt_tsdf_max_wave_cols(N) + 1) / 2 + 1); }
+__device__ __forceinline__ void kt_task_counts(unsigned int r, unsigned int (&cnt)[5])
+{
+    const int z0 = (int)(r & 0xffffu), z1 = (int)(r >> 16);
+    if (z0 >= z1) return;
+    const int c0 = z0 / KT_TSDF_ZCHUNK, c1 = (z1 - 1) / KT_TSDF_ZCHUNK;
+    const int bf = (min(z1, (c0 + 1) * KT_TSDF_ZCHUNK) - z0 + KT_TSDF_UNROLL - 1) / KT_TSDF_UNROLL;   // first chunk (the only one if c0 == c1)
+    cnt[0] += (unsigned int)bf; cnt[5 - bf] += 1u;
+    if (c1 > c0) {
+        const int bl = (z1 - c1 * KT_TSDF_ZCHUNK + KT_TSDF_UNROLL - 1) / KT_TSDF_UNROLL;
+        cnt[0] += (unsigned int)bl + 4u * (unsigned int)(c1 - c0 - 1); cnt[5 - bl] += 1u; cnt[1] += (unsigned int)(c1 - c0 - 1);
+    }
+}
+__device__ __forceinline__ void kt_pair_counts(const unsigned int* __restrict__ wrange, int M, int i, unsigned int (&cnt)[5])
+{
+#pragma unroll
+    for (int v = 0; v < 5; ++v) cnt[v] = 0;
+    kt_task_counts(wrange[2 * i], cnt);
+    if (2 * i + 1 < M) kt_task_counts(wrange[2 * i + 1], cnt);
+}
+__global__ __launch_bounds__(1024) void kt_tsdf_tasks_scan_kernel(const unsigned int* __restrict__ wrange, int M, unsigned int* __restrict__ head)
+{
+    static_assert(KT_TSDF_ZCHUNK / KT_TSDF_UNROLL == 4, "class layout assumes 4 batches per task");
+    __shared__ unsigned int wave_tot[5][16];
+    __shared__ unsigned int cbase[4][9];         // class-count prefix at the first pair of XCD x (x = 8: totals)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = (M + 1) >> 1;
+    const int S = P + 1;
+    unsigned int* const pref = head + KT_TASK_PREF;
+    // contiguous pairs per thread, thread sums, block scan
+    const int pp = (P + 1023) / 1024;
+    const int i0 = min(P, tid * pp), i1 = min(P, i0 + pp);
+    unsigned int mine[5] = {0, 0, 0, 0, 0};
+    for (int i = i0; i < i1; ++i) {
+        unsigned int cnt[5];
+        kt_pair_counts(wrange, M, i, cnt);
+#pragma unroll
+        for (int v = 0; v < 5; ++v) mine[v] += cnt[v];
+    }
+    unsigned int incl[5];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) incl[v] = mine[v];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const unsigned int up = __shfl_up(incl[v], off, 64);
+            if (lane >= off) incl[v] += up;
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int v = 0; v < 5; ++v) wave_tot[v][wave] = incl[v];
+    }
+    __syncthreads();
+    unsigned int run[5], total[5];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        unsigned int base = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const unsigned int t = wave_tot[v][w];
+            if (w < wave) base += t;
+            tot += t;
+        }
+        run[v] = base + incl[v] - mine[v];
+        total[v] = tot;
+    }
+    const unsigned int per_xcd = max(1u, (total[0] + 7u) / 8u);
+    // per-pair prefixes out; XCD parts: pair i belongs to XCD min(7, cost prefix / share), and the first pair of every XCD leaves the
+    // class prefixes there (cbase).  The XCD of the pair in front of a thread's run follows from that pair's own counts.
+    int x_prev = -1;
+    if (i0 > 0 && i0 < P) {
+        unsigned int cnt[5];
+        kt_pair_counts(wrange, M, i0 - 1, cnt);
+        x_prev = (int)min(7u, (run[0] - cnt[0]) / per_xcd);
+    }
+    for (int i = i0; i < i1; ++i) {
+        const int x_here = (int)min(7u, run[0] / per_xcd);
+        for (int x = x_prev + 1; x <= x_here; ++x) {   // (XCDs no pair falls into get an empty part)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cbase[q][x] = run[1 + q];
+        }
+        x_prev = x_here;
+        unsigned int cnt[5];
+        kt_pair_counts(wrange, M, i, cnt);
+#pragma unroll
+        for (int v = 0; v < 5; ++v) { pref[v * S + i] = run[v]; run[v] += cnt[v]; }
+    }
+    if (i1 == P && i0 < P) {   // the thread that owns the last pair closes the table
+        for (int x = x_prev + 1; x <= 8; ++x) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cbase[q][x] = total[1 + q];
+        }
+#pragma unroll
+        for (int v = 0; v < 5; ++v) pref[v * S + P] = total[v];
+        head[KT_TASK_SHARE] = per_xcd;
+    }
+    __syncthreads();
+    if (tid < 64) {   // bucket sizes in (XCD, class) order -> exclusive scan over 32 lanes
+        const int x = (tid & 31) >> 2, q = tid & 3;
+        const unsigned int size = tid < 32 ? cbase[q][x + 1] - cbase[q][x] : 0u;
+        unsigned int in = size;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const unsigned int up = __shfl_up(in, off, 64);
+            if (lane >= off) in += up;
+        }
+        if (tid < 32) head[KT_TASK_BBASE + tid] = in - size;
+        if (tid == 31) { head[KT_TASK_BBASE + 32] = in; head[0] = in; head[9] = in; }
+        if (tid < 32 && q == 0) head[1 + x] = in - size;
+    }
+    if (tid < 36) head[KT_TASK_CBASE + tid] = cbase[tid / 9][tid % 9];
+}
+__global__ __launch_bounds__(256) void kt_tsdf_tasks_place_kernel(const unsigned int* __restrict__ wrange, int M, int XG, const unsigned int* __restrict__ head,
+                                                                   unsigned int* __restrict__ tasks)
+{
+    const int lane = threadIdx.x & 63;
+    const int P = (M + 1) >> 1, S = P + 1;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= P) return;
+    const unsigned int* const pref = head + KT_TASK_PREF;
+    const unsigned int pc = pref[pair];
+    if (pref[pair + 1] == pc) return;   // no task in this pair (wave-uniform)
+    const int x = (int)min(7u, pc / head[KT_TASK_SHARE]);
+    const unsigned int start = head[KT_TASK_BBASE + 4 * x], n = head[KT_TASK_BBASE + 4 * x + 4] - start;
+    unsigned int running[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) running[q] = head[KT_TASK_BBASE + 4 * x + q] - start + (pref[(1 + q) * S + pair] - head[KT_TASK_CBASE + q * 9 + x]);
+    const int k = lane & 1, wc = 2 * pair + k;
+    const unsigned int r = wc < M ? wrange[wc] : (unsigned int)KT_TSDF_ZCHUNK;   // (an odd M leaves the last pair half empty: z0 > z1)
+    const int z0 = (int)(r & 0xffffu), z1 = (int)(r >> 16);
+    const bool some = z0 < z1;
+    const int c0 = some ? z0 / KT_TSDF_ZCHUNK : INT_MAX, c1 = some ? (z1 - 1) / KT_TSDF_ZCHUNK : -1;
+    const int lo = kt_wave_min(c0), hi = kt_wave_max(c1);
+    const unsigned int key = (unsigned int)(wc / XG) | ((unsigned int)(wc % XG) << 16);
+    for (int cb = lo; cb <= hi; cb += 32) {
+        const int c = cb + (lane >> 1);
+        const bool valid = c >= c0 && c <= c1;
+        const int za = max(z0, c * KT_TSDF_ZCHUNK), zb = min(z1, (c + 1) * KT_TSDF_ZCHUNK);
+        const int b = valid ? (zb - za + KT_TSDF_UNROLL - 1) / KT_TSDF_UNROLL : 0;
+        unsigned int p = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(b == 4 - q);
+            if (b == 4 - q) p = running[q] + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+            running[q] += (unsigned int)__builtin_popcountll(m);
+        }
+        if (valid) {
+            const unsigned int row = p >> 7;
+            if ((row & 1u) && (row + 1u) * 128u <= n) p = row * 128u + (127u - (p & 127u));
+            tasks[start + p] = key | ((unsigned int)c << 24);
+        }
+    }
+}
+
 // One in-flight batch of KT_TSDF_UNROLL consecutive z steps of a wave: everything phase A produces for phase B.
 struct kt_tsdf_batch {
     bool in_img[KT_TSDF_UNROLL];
@@ -1044,19 +1216,24 @@ __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, c
     bool in_img[KT_TSDF_UNROLL];
     float r2[KT_TSDF_UNROLL];
     unsigned int toff[KT_TSDF_UNROLL];   // byte offset of the voxel in the tsdf volume (the colour volume: twice that)
+    // loop constants the fast VALU operations read live in VGPRs: an SGPR operand halves the issue rate of v_fma / v_add_f32
+    // (profiles/r04_valu_rates.md: 4.2 cycles against 2.4)
+    float2 cxy = make_float2(a.intr.cx, a.intr.cy);
+    float magic = KT_RNE_MAGIC;
+    asm volatile("" : "+v"(cxy.x), "+v"(cxy.y), "+v"(magic), "+v"(r8));
     // ---- phase A: project the 4 voxels, gather their pixel records
 #pragma unroll
     for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
         const kt_tsdf_ztab e = s_tab[zb + u];   // wave-uniform address: one broadcast ds_read_b128
         const float d = __builtin_fmaf(r8, e.zs, v_z);
         const float inv_z = FAST ? kt_rcp_exact(d) : 1.0f / d;
-        const float px = __builtin_fmaf(v_x, inv_z, a.intr.cx), py = __builtin_fmaf(v_y, inv_z, a.intr.cy);
+        const float px = __builtin_fmaf(v_x, inv_z, cxy.x), py = __builtin_fmaf(v_y, inv_z, cxy.y);
         unsigned int coo_x, coo_y;
         if constexpr (FAST) {
             // __float2int_rn off the mantissa: for |p| < 2^22 the sum is exactly MAGIC + rne(p); a larger |p|, an infinity or a NaN (none of
             // which the FAST path can produce: |1 / d| <= 2^20 and the walk is finite) leaves a word that fails the unsigned in-image test
-            coo_x = __float_as_uint(px + KT_RNE_MAGIC) - KT_RNE_MAGIC_BITS;
-            coo_y = __float_as_uint(py + KT_RNE_MAGIC) - KT_RNE_MAGIC_BITS;
+            coo_x = __float_as_uint(px + magic) - KT_RNE_MAGIC_BITS;
+            coo_y = __float_as_uint(py + magic) - KT_RNE_MAGIC_BITS;
         } else {
             coo_x = (unsigned int)kt_f2i_rn(px);
             coo_y = (unsigned int)kt_f2i_rn(py);
@@ -1315,7 +1492,7 @@ static int kt_integrate_scratch_reserve(kt_ctx* c, size_t px, int N)
         KT_HIP(hipMalloc((void**)&s.wrange, sizeof(unsigned int) * wave_cols));
         KT_HIP(hipMalloc((void**)&s.walk0, sizeof(float2) * (size_t)N * N));
         KT_HIP(hipMalloc((void**)&s.tasks, sizeof(unsigned int) * wave_cols * kt_div_up(N, KT_TSDF_ZCHUNK)));
-        KT_HIP(hipMalloc((void**)&s.task_count, sizeof(unsigned int) * KT_TASK_HEAD));
+        KT_HIP(hipMalloc((void**)&s.task_count, sizeof(unsigned int) * kt_task_head_words(N)));
         KT_HIP(hipMalloc((void**)&s.vgz, sizeof(float) * 2 * N));
         s.zs = s.vgz + N;
         for (int k = 0; k < 2; ++k) {
@@ -1336,7 +1513,12 @@ static int kt_tsdf_prepass(hipStream_t stream, const kt_tsdf23_args& a, unsigned
     const size_t maps_lds = a.dpmax && a.dpt_log2 ? sizeof(float) * (size_t)(((kt_div_up(a.cols, 1 << a.dpt_log2) * kt_div_up(a.rows, 1 << a.dpt_log2) + 3) & ~3) + kt_div_up(a.cols, 32) * kt_div_up(a.rows, 32)) : 0;
     hipLaunchKernelGGL(kt_tsdf_interval_kernel, dim3(kt_div_up(N, 2 * WX), kt_div_up(N, 2 * WY)), dim3(256), maps_lds, stream, a, wrange, walk0);
     KT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(kt_tsdf_tasks_kernel, dim3(1), dim3(1024), 0, stream, wrange, XG * YG, XG, tasks, task_count);
+    static const bool serial = getenv("KT_TSDF_TASKS_SERIAL") != nullptr;   // (A/B switch: round 3's one-workgroup list kernel)
+    if (!serial) {
+        hipLaunchKernelGGL(kt_tsdf_tasks_scan_kernel, dim3(1), dim3(1024), 0, stream, wrange, XG * YG, task_count);
+        hipLaunchKernelGGL(kt_tsdf_tasks_place_kernel, dim3(kt_div_up((XG * YG + 1) / 2, 4)), dim3(256), 0, stream, wrange, XG * YG, XG, task_count, tasks);
+    } else
+        hipLaunchKernelGGL(kt_tsdf_tasks_kernel, dim3(1), dim3(1024), 0, stream, wrange, XG * YG, XG, tasks, task_count);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
@@ -1355,7 +1537,7 @@ int kt_tsdf_plan_alloc(kt_tsdf_plan* p, int N)
     KT_HIP(hipMalloc((void**)&p->wrange, sizeof(unsigned int) * wave_cols));
     KT_HIP(hipMalloc((void**)&p->walk0, sizeof(float2) * (size_t)N * N));
     KT_HIP(hipMalloc((void**)&p->tasks, sizeof(unsigned int) * wave_cols * kt_div_up(N, KT_TSDF_ZCHUNK)));
-    KT_HIP(hipMalloc((void**)&p->task_count, sizeof(unsigned int) * KT_TASK_HEAD));
+    KT_HIP(hipMalloc((void**)&p->task_count, sizeof(unsigned int) * kt_task_head_words(N)));
     return KT_OK;
 }
 void kt_tsdf_plan_free(kt_tsdf_plan* p)

@@ -1,6 +1,7 @@
 // EigenAdapters.h -- conversions between the shell's plain linear-algebra structs (LinearAlgebra.h) and the Eigen / PCL types the
 // reference's backend passes around.  Compiled only where those libraries exist; this build image has
-// neither, so nothing here is exercised by the tests -- every function is a memory-layout identity (the structs were laid out to match:
+// neither -- tests/test_host_logic.py::test_eigen_adapters_type_check compiles and runs every function against stand-in headers with
+// the shapes of those types (tests/stubs/).  Every function is a memory-layout identity (the structs were laid out to match:
 // row-major 3x3 floats, 3 floats, 32-byte PointXYZRGB, 48-byte PointXYZRGBNormal).
 #pragma once
 

@@ -36,9 +36,11 @@ class StoreExchange:
     delivered before it exists.  Under torch.distributed.run the launcher's own store (MASTER_ADDR:MASTER_PORT) is used as a client;
     launched by hand, rank 0 hosts one."""
 
-    def __init__(self, rank: int, world: int, addr: str = None, port: int = None, timeout_s: float = 300.0):
+    def __init__(self, rank: int, world: int, addr: str = None, port: int = None, timeout_s: float = None):
         import datetime
         import os
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("KT_EXCHANGE_TIMEOUT_S", "300"))
         from torch.distributed import TCPStore
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = int(port or os.environ.get("MASTER_PORT", "29533"))
@@ -47,19 +49,34 @@ class StoreExchange:
         self.store = TCPStore(addr, port, None if agent else world, is_master=(rank == 0 and not agent), wait_for_workers=False,
                               timeout=datetime.timedelta(seconds=timeout_s))
         self.prefix = "kt/%s/" % os.environ.get("TORCHELASTIC_RUN_ID", "job")
+        self.generation = {}   # per key: how often it has been exchanged (every rank calls in the same order, so the counts agree)
+
+    def _key(self, key: str) -> str:
+        """a fresh store key per exchange of `key`: the store never forgets, and a second timed_region in one job must not read the
+        first one's values"""
+        g = self.generation.get(key, 0)
+        self.generation[key] = g + 1
+        return "%s%s#%d" % (self.prefix, key, g)
+
+    def _get(self, k: str, who: str) -> bytes:
+        try:
+            return bytes(self.store.get(k))   # blocks until the key exists or the store's timeout expires
+        except Exception as e:   # noqa: BLE001 -- a rank that died before it published must end the job with a message, not a hang
+            raise RuntimeError("multistream: %s never arrived in the key-value store (key %s): a rank of the job is gone? (%s)" % (who, k, e)) from e
 
     def share(self, key: str, data: bytes) -> bytes:
         """rank 0's bytes on every rank"""
-        k = self.prefix + key
+        k = self._key(key)
         if self.rank == 0:
             self.store.set(k, data)
             return data
-        return bytes(self.store.get(k))   # blocks until rank 0 has set it (or the store's timeout)
+        return self._get(k, "rank 0's '%s'" % key)
 
     def max(self, key: str, value: float) -> float:
         """the largest of the ranks' values, on every rank"""
-        self.store.set("%s%s/%d" % (self.prefix, key, self.rank), repr(float(value)))
-        return max(float(bytes(self.store.get("%s%s/%d" % (self.prefix, key, r))).decode()) for r in range(self.world))
+        k = self._key(key)
+        self.store.set("%s/%d" % (k, self.rank), repr(float(value)))
+        return max(float(self._get("%s/%d" % (k, r), "rank %d's '%s'" % (r, key)).decode()) for r in range(self.world))
 
 
 def make_exchange(rank: int, world: int):

@@ -1126,6 +1126,46 @@ static int sp_pair_cmp(const void* a, const void* b)
     if (x->key != y->key) return x->key < y->key ? -1 : 1;
     return x->src < y->src ? -1 : (x->src > y->src);
 }
+/* sin / cos / atan2 of pcl::computeRoots (common/impl/eigen.hpp), restated: the C library's and the device library's versions differ
+ * from each other in the last bits, and a normal is only as reproducible as they are.  The stage needs them on a small domain --
+ * atan2(y >= 0, x) in [0, pi], then sin / cos of a third of that, in [0, pi / 3] -- so both sides (this file and csrc/kt_slice.hip,
+ * the same operations in the same order, every fused multiply-add written out) use the Cephes single-precision kernels:
+ * atanf on [0, tan(pi / 8)] with one reduction step, sinf / cosf on [0, pi / 4] with the complement for the rest.  Absolute error
+ * ~1e-7, like the libraries'; PCL itself (libm) is not reproduced to the bit by either -- f2 is "parity unpinned" by necessity. */
+static float sp_atan01(float a)   /* atan(a), 0 <= a <= 1 */
+{
+    float y0 = 0.0f, x = a;
+    if (a > 0.4142135623730950f) { y0 = 0.78539816339744830962f; x = (a - 1.0f) / (a + 1.0f); }   /* tan(pi / 8) */
+    const float z = x * x;
+    float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    return y0 + fmaf(p * z, x, x);
+}
+static float sp_atan2_pos(float y, float x)   /* atan2f(y, x) for y >= 0 */
+{
+    const float ax = fabsf(x);
+    const float hi = ax > y ? ax : y, lo = ax > y ? y : ax;
+    if (!(hi > 0.0f)) return 0.0f;                       /* atan2(0, 0) = 0; atan2(0, x < 0) = pi is the lo == 0, x < 0 case below */
+    float r = sp_atan01(lo / hi);
+    if (y > ax) r = 1.57079632679489661923f - r;
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    return r;
+}
+static void sp_sincos(float t, float* s, float* c)   /* 0 <= t <= pi / 3 (+ a few ulp) */
+{
+    const int swap = t > 0.78539816339744830962f;
+    const float x = swap ? 1.57079632679489661923f - t : t;
+    const float z = x * x;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float sn = fmaf(ps * z, x, x);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    const float cs = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    *s = swap ? cs : sn;
+    *c = swap ? sn : cs;
+}
 static void sp_compute_roots2(float b, float c, float r[3])
 {
     r[0] = 0.f;
@@ -1149,8 +1189,9 @@ static void sp_compute_roots(const float m[9], float r[3])
     float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
     if (q > 0.0f) q = 0.0f;
     const float rho = sqrtf(-a_over_3);
-    const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
-    const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+    const float theta = sp_atan2_pos(sqrtf(-q), half_b) * s_inv3;
+    float cos_theta, sin_theta;
+    sp_sincos(theta, &sin_theta, &cos_theta);
     r[0] = c2_over_3 + 2.0f * rho * cos_theta;
     r[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     r[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

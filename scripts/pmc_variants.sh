@@ -8,7 +8,7 @@ run() {  # label lib counter workload steps
   python - <<PY
 import csv, glob
 fs = glob.glob("$R/gpurun_out/pmcv/*/*counter_collection.csv")
-vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(fs[0])) if "tsdf23_kernel<false" in r["Kernel_Name"] and r["Counter_Name"] == "$3"] if fs else []
+vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(fs[0])) if "tsdf23" in r["Kernel_Name"] and "<false" in r["Kernel_Name"] and r["Counter_Name"] == "$3"] if fs else []
 print("PMC %-40s %-11s %-10s launches %3d  mean %.1f KiB  (x1024: %.2f MB)" % ("$1", "$4", "$3", len(vals), sum(vals) / max(1, len(vals)), sum(vals) / max(1, len(vals)) * 1024 / 1e6))
 PY
 }

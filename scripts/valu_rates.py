@@ -11,7 +11,8 @@ KINDS = ["v_fma_f32", "v_pk_fma_f32", "v_rcp_f32", "v_rndne_f32 / v_cvt_i32_f32"
          "v_sqrt_f32", "v_cmp_gt_f32 / v_cndmask_b32", "v_pk_add_f32", "v_mad_u32_u24", "v_cvt_f32_ubyte0",
          "s_add_u32 only", "2 v_fma_f32 : 1 s_add_u32", "1 v_fma_f32 : 2 s_add_u32", "v_cmp -> SGPR pair + s_and_b64 (1 : 1)",
          "s_and_saveexec / v_fma / s_or exec (1 : 2)"] + \
-        ['v_add_f32', 'v_mul_f32', 'v_max_f32', 'v_add_u32', 'v_and_b32', 'v_lshlrev_b32', 'v_mov_b32', 'v_cndmask_b32 (vcc fixed)', 'v_cmp_gt_f32 only', 'v_cvt_f32_u32', 'v_med3_i32', 'v_mul_u32_u24', 'v_lshl_add_u32', 'v_mad_u64_u32 (pair dst)', 'v_bfe_u32', 'v_min_u32', 'v_sub_f32 |abs| (VOP3)', 'v_cmp_lt_u32 to SGPR pair (VOP3)']
+        ['v_add_f32', 'v_mul_f32', 'v_max_f32', 'v_add_u32', 'v_and_b32', 'v_lshlrev_b32', 'v_mov_b32', 'v_cndmask_b32 (vcc fixed)', 'v_cmp_gt_f32 only', 'v_cvt_f32_u32', 'v_med3_i32', 'v_mul_u32_u24', 'v_lshl_add_u32', 'v_mad_u64_u32 (pair dst)', 'v_bfe_u32', 'v_min_u32', 'v_sub_f32 |abs| (VOP3)', 'v_cmp_lt_u32 to SGPR pair (VOP3)'] + \
+        ['v_sub_u32', 'v_or_b32', 'v_xor_b32', 'v_min_f32', 'v_cvt_i32_f32', 'v_rndne_f32', 'v_perm_b32', 'v_bfi_b32', 'v_and_or_b32', 'v_or3_b32', 'v_add3_u32', 'v_lshl_or_b32', 'v_floor_f32', 'v_cvt_u32_f32', 'v_subrev_f32', 'v_fma_f32 with SGPR operand']
 ctx = abi.Ctx(0)
 out = (C.c_double * 8)()
 print("# Issue cost per wave-instruction and SIMD, shader clock measured under the load (round 4)\n")

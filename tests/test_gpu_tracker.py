@@ -622,3 +622,4 @@ def test_plan_margins_hold_at_their_edge(ctx, size):
             assert hits >= floor and misses == 0, (key, hits, misses)     # every plan that was tried was accepted
         else:
             assert hits == 0 and misses >= floor, (key, hits, misses)     # ... and rejected
+

@@ -212,3 +212,19 @@ def test_rgbd_and_ground_truth_host_math_known_answers():
     R, t = abi.host_ground_truth_pose(A, A, last[:9], last[9:])
     assert np.allclose(R, last[:9].reshape(3, 3), atol=1e-6) and np.allclose(t, last[9:], atol=1e-6)
 
+
+
+def test_eigen_adapters_type_check(tmp_path):
+    """host/EigenAdapters.h (the conversions to the Eigen / PCL types the reference's backend passes around, KintinuousTracker.h:59-80)
+    sits behind __has_include and had never been through a compiler: this image has neither library.  tests/stubs/ holds stand-in
+    headers with the SHAPES of the types it touches (fixed-size matrices with a storage order, Map, pcl::PointCloud, the two point
+    layouts); the adapters are compiled against them and every one is run once (header-only, no GPU)."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "eigen_adapters_check")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "tests", "stubs"), "-I", os.path.join(ROOT, "kintinuous_amd", "host"),
+                        "-I", ROOT, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "stubs", "eigen_adapters_check.cpp"), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "eigen adapters ok" in r.stdout, (r.returncode, r.stdout, r.stderr)

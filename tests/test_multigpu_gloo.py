@@ -49,12 +49,16 @@ WORKER = textwrap.dedent("""
     trk = OracleTracker(OTrackerConfig(cam.cols, cam.rows, 32, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0))
     comm = GlooComm(exchange, rank, world)
     steps, warmup, prepared = 3, 1, []
+    slow = [1]                                                    # the rank whose time must define the rate
+    die = int(os.environ.get("KT_TEST_DIE_RANK", "-1"))
 
     def step(i):
         d, rgb = frames[pingpong(i, len(frames))]
         trk.process_frame(d, rgb, 33333 * i)
-        if i >= warmup and rank == 1:
-            time.sleep(0.05)                                      # rank 1 is the slow one: its time must define the rate
+        if i >= warmup and rank == slow[0]:
+            time.sleep(0.05)
+        if rank == die and i == warmup + 1:
+            os._exit(3)                                           # a rank that dies inside the timed region, before the gather
 
     region = timed_region(comm, exchange, world, lambda: None, step, steps, warmup, lambda: comm.gather_poses(trk, steps), lambda: prepared.append(1))
     assert prepared == [1] and comm.barriers == 2                # one barrier on each side of the timed region
@@ -62,31 +66,86 @@ WORKER = textwrap.dedent("""
     assert allp.shape == (world, steps, 16) and len(region["marks"]) == steps + 1
     mine = np.stack([trk.dense_pose(trk.num_poses() - steps + i)[1].reshape(16) for i in range(steps)])
     check_gather(allp, rank, mine)
-    assert not np.array_equal(allp[1 - rank][-1], mine[-1])      # different scenes (seeds) -> different tracked poses
-    # max over ranks: both ranks report the slow rank's time
+    other = (rank + 1) %% world
+    assert not np.array_equal(allp[other][-1], mine[-1])         # different scenes (seeds) -> different tracked poses
+    # max over ranks: every rank reports the slow rank's time
     assert region["elapsed"] >= region["local_elapsed"] - 1e-9 and region["elapsed"] >= 0.15
     slowest = exchange.max("check", region["local_elapsed"])
     assert abs(slowest - region["elapsed"]) < 1e-9
     assert abs(region["fps"] - world * steps / region["elapsed"]) < 1e-9
     try:
-        check_gather(allp, 1 - rank, mine)
+        check_gather(allp, other, mine)
         raise SystemExit("check_gather accepted another rank's poses")
     except AssertionError:
         pass
+    # a SECOND timed region in the same job: the exchange must not hand back the first region's values (keys carry a generation).
+    # Now rank 0 is the slow one, and slower than rank 1 was.
+    slow[0] = 0
+    def step2(i):
+        d, rgb = frames[pingpong(i, len(frames))]
+        trk.process_frame(d, rgb, 33333 * (i + 10))
+        if i >= warmup and rank == 0:
+            time.sleep(0.12)
+    region2 = timed_region(comm, exchange, world, lambda: None, step2, steps, warmup, lambda: comm.gather_poses(trk, steps), None)
+    assert region2["elapsed"] >= 0.36 and region2["elapsed"] >= region2["local_elapsed"] - 1e-9, (region2["elapsed"], region["elapsed"])
+    assert exchange.generation["elapsed"] == 2 and exchange.generation["built"] == 1
     comm.close()
     trk.close()
     open(os.path.join(%r, "rank%%d.ok" %% rank), "w").write("ok")
 """)
 
 
-def test_two_rank_bench_protocol(tmp_path):
+def _launch(tmp_path, world, port, extra_env=None, timeout=600):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % (ROOT, str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(extra_env or {}))
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_two_rank_bench_protocol(tmp_path):
+    r = _launch(tmp_path, 2, 29517)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_four_rank_bench_protocol(tmp_path):
+    r = _launch(tmp_path, 4, 29518)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert all((tmp_path / ("rank%d.ok" % k)).exists() for k in range(4))
+
+
+def test_a_rank_that_dies_ends_the_job(tmp_path):
+    """Rank 2 of 4 dies inside the timed region, before the gather.  The others sit in the collective (or in the key-value store waiting
+    for its time): the job must END with an error within a bounded time -- the launcher takes the survivors down -- not hang, and no
+    rank may report success."""
+    import time
+    t0 = time.time()
+    r = _launch(tmp_path, 4, 29519, extra_env={"KT_TEST_DIE_RANK": "2", "KT_EXCHANGE_TIMEOUT_S": "30"}, timeout=300)
+    assert r.returncode != 0
+    assert time.time() - t0 < 240
+    assert not any((tmp_path / ("rank%d.ok" % k)).exists() for k in range(4))
+
+
+def test_store_exchange_keys_carry_a_generation():
+    """two exchanges of the same key in one job use different store keys (a stale value can not be read back); a missing rank raises"""
+    import threading
+    from kintinuous_amd.multistream import StoreExchange
+    port = 29520
+    out = {}
+
+    def rank(r):
+        ex = StoreExchange(r, 2, "127.0.0.1", port, timeout_s=20)
+        a = ex.max("elapsed", 1.0 + r)
+        b = ex.max("elapsed", 0.25 - 0.125 * r)       # smaller than anything of the first round
+        c = ex.share("id", b"x" if r == 0 else b"")
+        out[r] = (a, b, c, dict(ex.generation), ex)   # (rank 0 hosts the store: it must outlive rank 1's last read)
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert out[0][:3] == (2.0, 0.25, b"x") and out[1][:3] == (2.0, 0.25, b"x")
+    assert out[0][3] == {"elapsed": 2, "id": 1}
 
 
 def test_one_rank_exchange_is_local():
@@ -97,3 +156,12 @@ def test_one_rank_exchange_is_local():
     region = timed_region(None, ex, 1, lambda: calls.append("sync"), lambda i: calls.append(i), 3, 2)
     assert calls[:3] == [0, 1, "sync"] and [c for c in calls if c != "sync"] == [0, 1, 2, 3, 4] and region["gathered"] is None
     assert abs(region["fps"] - 3 / region["elapsed"]) < 1e-9
+
+
+def test_store_exchange_reports_a_missing_rank():
+    """a rank that never publishes its value makes the others raise after the store's timeout (bench.py then exits non-zero)"""
+    import pytest
+    from kintinuous_amd.multistream import StoreExchange
+    ex = StoreExchange(0, 2, "127.0.0.1", 29521, timeout_s=2)
+    with pytest.raises(RuntimeError, match="rank 1's 'elapsed' never arrived"):
+        ex.max("elapsed", 1.0)
