@@ -1206,7 +1206,7 @@ __device__ __forceinline__ float kt_min1(float x)   // min(1, x) as one v_min_f3
     return r;
 }
 
-template <bool COUNT, bool FAST>
+template <bool COUNT, bool FAST, bool NT>
 __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, const kt_tsdf_bufs& m, const kt_tsdf_ztab* __restrict__ s_tab,
                                                    const float* __restrict__ s_rcp, int zb, int rem, unsigned int col_base2, int brick_xy,
                                                    float v_z, float& v_x, float& v_y, float dvx, float dvy, float r8, float v_g_part_norm,
@@ -1274,8 +1274,8 @@ __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, c
         tv[u] = kt_min1(sdf * tranc_dist_inv);
         if (COUNT && in_img[u]) ++n_img;
         if (upd[u]) {
-            raw[u] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.vol, toff[u], 0, KT_TSDF_LD_AUX);
-            col[u] = __builtin_amdgcn_raw_buffer_load_b32(m.col, kt_twice(toff[u]), 0, KT_TSDF_LD_AUX);
+            raw[u] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.vol, toff[u], 0, NT ? 2 : KT_TSDF_LD_AUX);
+            col[u] = __builtin_amdgcn_raw_buffer_load_b32(m.col, kt_twice(toff[u]), 0, NT ? 2 : KT_TSDF_LD_AUX);
         }
     }
     // ---- phase C: running averages, stores (only of words that changed)
@@ -1296,7 +1296,7 @@ __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, c
             const float q0 = num * y;
             const short packed = kt_pack_tsdf(__builtin_fmaf(__builtin_fmaf(-den, q0, num), y, q0));
             if ((unsigned int)(unsigned short)packed != raw[u]) {   // an unchanged word is not written back
-                __builtin_amdgcn_raw_buffer_store_b16(packed, m.vol, toff[u], 0, KT_TSDF_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b16(packed, m.vol, toff[u], 0, NT ? 2 : KT_TSDF_ST_AUX);
                 if (a.bricks && packed < 0) a.bricks[s_tab[zb + u].bz + brick_xy] = 1;  // idempotent byte store (rare: the table is re-read here)
             }
         }
@@ -1334,11 +1334,16 @@ __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, c
             // k in 0..255 sits in the low byte of MAGIC + k
             o = (o & 0xff000000u) | (__float_as_uint(yx) & 0xffu) | ((__float_as_uint(yy) & 0xffu) << 8) | ((__float_as_uint(yz) & 0xffu) << 16);
         }
-        if (o != c) __builtin_amdgcn_raw_buffer_store_b32(o, m.col, kt_twice(toff[u]), 0, KT_TSDF_ST_AUX);   // a saturated free-space voxel in front of an unchanged pixel costs reads only
+        if (o != c) __builtin_amdgcn_raw_buffer_store_b32(o, m.col, kt_twice(toff[u]), 0, NT ? 2 : KT_TSDF_ST_AUX);   // a saturated free-space voxel in front of an unchanged pixel costs reads only
     }
 }
 
-template <bool COUNT>
+// NT: the volume words are loaded and stored with the non-temporal policy (buffer aux bit 1).  A launch property: on a dense view the
+// updated voxels (816 MB at 1280x960 into 768^3) stream through the caches once per frame, and marking them non-temporal keeps the pixel
+// records -- which ARE re-read, by every z-step of every column -- in the L2s: 21 % fewer bytes fetched at the same launch time
+// (profiles/r04_experiments.md).  On a sparse view the words a frame updates (20 MB) are still cached from the frame before, and
+// non-temporal accesses give those hits up (orbit: 47 us against 32).
+template <bool COUNT, bool NT>
 __global__ __launch_bounds__(256, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_kernel(const kt_tsdf_lean_args a_in)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kt_tsdf_lds[];
@@ -1425,12 +1430,12 @@ __global__ __launch_bounds__(256, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_k
         if (fast) {
             if (lane_ok & (d_a > 0)) {   // lanes behind the camera plane (1 / d < 0) never pass the in-image test
                 for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
-                    kt_tsdf_batch_lean<COUNT, true>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
+                    kt_tsdf_batch_lean<COUNT, true, NT>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
                 }
             }
         } else if (lane_ok) {
             for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
-                kt_tsdf_batch_lean<COUNT, false>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
+                kt_tsdf_batch_lean<COUNT, false, NT>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
             }
         }
         if (COUNT) { n_batches += (unsigned int)((wz1 - wz0 + KT_TSDF_UNROLL - 1) / KT_TSDF_UNROLL); ++n_tasks_done; }
@@ -1671,8 +1676,11 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
         l.tx = a.tx; l.ty = a.ty; l.tz = a.tz; l.intr = a.intr; l.cell_x = a.cell_x; l.cell_y = a.cell_y; l.cell_z = a.cell_z;
         l.tranc_dist = a.tranc_dist; l.wx = a.wx; l.wy = a.wy; l.wz = a.wz; l.cols = a.cols; l.rows = a.rows; l.N = a.N; l.nb = a.nb; l.wcl = a.wcl;
         const size_t lds = 1024 + sizeof(kt_tsdf_ztab) * (size_t)(N + KT_TSDF_UNROLL);
-        if (updated_dev) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<true>), g, b, lds, c->stream, l);
-        else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<false>), g, b, lds, c->stream, l);
+        // dense view (the rule that picks the 32 x 2 wave-column shape): the volume words stream, non-temporal; KT_TSDF_NT=0|1 overrides
+        static const int nt_env = []() { const char* e = getenv("KT_TSDF_NT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+        const bool nt = nt_env >= 0 ? nt_env != 0 : a.wcl == 5;
+        if (updated_dev) { if (nt) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<true, true>), g, b, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<true, false>), g, b, lds, c->stream, l); }
+        else { if (nt) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<false, true>), g, b, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<false, false>), g, b, lds, c->stream, l); }
     } else if (updated_dev) {
         if (buf) hipLaunchKernelGGL((kt_tsdf23_kernel<true, true>), g, b, 0, c->stream, a);
         else hipLaunchKernelGGL((kt_tsdf23_kernel<true, false>), g, b, 0, c->stream, a);
