@@ -135,10 +135,11 @@ def main():
             if world > 1:
                 raise
             sys.stderr.write(f"bench: pose gather disabled ({e})\n")
-    # HIP events around the tsdf23 kernel only, on the stream it is launched on: one frame in 4 when the region is short (an event pair is
-    # two marker packets = ~10 us of bubbles in a 340 us frame: on every frame that is 3 % of the rate being measured), one in 8 otherwise.
+    # HIP events around the tsdf23 kernel only, on the stream it is launched on: one frame in 2 when the region is very short (the driver's
+    # 20 frames: 10 samples), one in 4 up to 50 frames (an event pair is two marker packets = ~10 us of bubbles in a 340 us frame: on every
+    # frame that is 3 % of the rate being measured), one in 8 otherwise.
     def prepare():   # between the warm-up and the first barrier
-        trk.enable_profiling(5 if args.steps <= 50 else 1)
+        trk.enable_profiling(6 if args.steps <= 30 else (5 if args.steps <= 50 else 1))
         trk.host_times(reset=True)
 
     def gather():   # the single RCCL gather of per-stream poses, inside the timed region

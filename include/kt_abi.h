@@ -273,7 +273,7 @@ float* kt_tracker_nmap_g_prev(kt_tracker* t, int level);
 /* vmap_curr_color: the raycast's uchar4 colour + weight image of the last frame (input of kt_generate_image) */
 uint8_t* kt_tracker_vmap_curr_color(kt_tracker* t);
 float kt_tracker_trunc_dist(kt_tracker* t);
-/* profiling: on = 0 off, 2 = all stages, 1 / 5 / 4 = only the tsdf23 voxel kernel, on every 8th / every 4th / every frame (an event
+/* profiling: on = 0 off, 2 = all stages, 1 / 5 / 6 / 4 = only the tsdf23 voxel kernel, on every 8th / 4th / 2nd / every frame (an event
  * pair is two marker packets on the main stream, ~10 us of bubbles: timing every frame lowers the frame rate it is measured next to).
  * kt_tracker_stage_ms returns the MEAN milliseconds per frame since profiling was enabled (hipEvent pairs on
  * the context stream) for: 0 pyramid, 1 odometry, 2 shift, 3 integrate (scaleDepth + tsdf23), 4 raycast,

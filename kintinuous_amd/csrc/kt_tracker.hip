@@ -339,7 +339,7 @@ static void push_pose(kt_tracker* t, uint64_t ts, const float* R, int is_loop)
 // profiling modes: 0 off; 1 the tsdf23 event pair on every 8th frame (long timed regions: the timing stays off the other 7);
 // 2 every stage of every frame (serial breakdown pass); 4 the tsdf23 pair on EVERY frame (short timed regions)
 static bool prof_all(const kt_tracker* t) { return t->profiling == 2 || t->profiling == 3; }
-static bool prof_tsdf(const kt_tracker* t) { return t->profiling == 1 || t->profiling == 4 || t->profiling == 5; }
+static bool prof_tsdf(const kt_tracker* t) { return t->profiling == 1 || t->profiling == 4 || t->profiling == 5 || t->profiling == 6; }
 static int ev_begin(kt_tracker* t, int st)
 {
     if (prof_all(t) || (prof_tsdf(t) && st == ST_TSDF23)) {
@@ -358,7 +358,8 @@ static int ev_end(kt_tracker* t, int st)
 static void tsdf23_hook_arm(kt_tracker* t)
 {
     // 4: every frame; 1 / 5: every 8th / 4th (an event pair costs two marker packets = ~10 us of bubbles on the main stream)
-    kt_tsdf23_hook.on = prof_all(t) || t->profiling == 4 || (t->profiling == 1 && (t->prof_frames++ % 8) == 0) || (t->profiling == 5 && (t->prof_frames++ % 4) == 0);
+    kt_tsdf23_hook.on = prof_all(t) || t->profiling == 4 || (t->profiling == 1 && (t->prof_frames++ % 8) == 0) || (t->profiling == 5 && (t->prof_frames++ % 4) == 0) ||
+                        (t->profiling == 6 && (t->prof_frames++ % 2) == 0);   // 6: every second frame (the driver's 20-frame region: 10 samples)
     kt_tsdf23_hook.ev[0] = t->ev[t->ev_par][ST_TSDF23][0];
     kt_tsdf23_hook.ev[1] = t->ev[t->ev_par][ST_TSDF23][1];
     if (kt_tsdf23_hook.on) t->ev_rec[t->ev_par][ST_TSDF23] = true;
