@@ -325,6 +325,12 @@ const char* kt_debug_tsdf_kernel(void);   /* name of the voxel kernel the next N
 /* test hook: the voxel kernel's division shortcut (table reciprocal + one correction) against the IEEE division for every finite float
  * numerator and every divisor 1..256: out_host = {mismatches, float bits of the largest |numerator| among them, mismatches at |n| >= 2^-100} */
 int kt_debug_div_check(kt_ctx* ctx, unsigned int out_host[3]);
+/* test hook: the Gauss-Newton tail of the reduction kernels (6x6 pivoted LDL^T in double, cv::Rodrigues, the pose composition;
+ * ICPOdometry.cpp:127-178) in its two device forms -- one thread, and spread over the lanes of a wave (the one the kernels run) -- on n
+ * caller-supplied systems.  cases_host: n records {float packed[32] (reduce.cu:401-418 order), float packed2[32], double resultRt[16],
+ * float Rprev[9], float tprev[3], int joint, int pad[3]}; serial_out_host / wave_out_host: n device state records each; layout_out =
+ * {sizeof(state record), offsets of resultRt (16 doubles), Rcurr (9 floats), tcurr (3 floats), sizeof(case record)} (n = 0: layout only). */
+int kt_debug_solve_check(kt_ctx* ctx, int n, const void* cases_host, void* serial_out_host, void* wave_out_host, int layout_out[5]);
 /* test hook: out[v + 32768] = the device's unpack_tsdf(v) for every short v (device.hpp:77-83 restated without a division) */
 int kt_debug_unpack_table(kt_ctx* ctx, float* out_host65536);
 /* test hook: number of floats d, 2^-20 <= |d| <= 2^20, for which the voxel kernel's unwrapped reciprocal chain differs from 1.0f / d */

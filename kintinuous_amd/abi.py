@@ -143,6 +143,7 @@ _PROTOS = {
     "kt_debug_tsdf_lean": (_i, [_i]),
     "kt_debug_tsdf_kernel": (C.c_char_p, []),
     "kt_debug_div_check": (_i, [_vp, C.POINTER(C.c_uint)]),
+    "kt_debug_solve_check": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     "kt_debug_unpack_table": (_i, [_vp, _pf]),
     "kt_debug_rcp_check": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_num_pr_samples": (_i, [_vp]),
@@ -191,6 +192,8 @@ def lib() -> C.CDLL:
             raise KtError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` first")
         l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in _PROTOS.items():
+            if name.startswith("kt_debug_") and os.environ.get("KT_HIP_LIB") and not hasattr(l, name):
+                continue   # an A/B build of an older tree may lack a newer test hook (never the tree's own library)
             fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args

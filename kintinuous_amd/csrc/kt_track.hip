@@ -396,46 +396,54 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
         fn.tprev = {a.tprev[0], a.tprev[1], a.tprev[2]};
     }
     __shared__ float total[KT_RED_SLOTS];
-    kt_pose_regs pr;
     kt_pose_stage ps;
     const bool solve_here = a.mode == KT_MODE_ICP_SOLVE;
     auto pre = [&]() { if (solve_here && !a.first) ps.fetch(a.state); };
     if (!kt_reduce29(fn, a.cols * a.rows, a.granules, a.epoch, total, pre)) return;
-    __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES];
+    __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES], tail_work[KT_TAIL_WORK_DOUBLES];
     __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
     if (solve_here) {   // ICPOdometry.cpp:127-128: the float sums widened into the double system, one element per lane
         if (threadIdx.x < 42) sys[threadIdx.x] = (double)total[kt_sys_slot(threadIdx.x)];
         if (!a.first) ps.park(pose_d, pose_f);
+        else if (threadIdx.x == 64) {   // ICPOdometry.cpp:70-85: identity increment, the previous pose from the kernel arguments
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pose_d[k] = (k % 5 == 0) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) pose_f[k] = a.Rcurr.m[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pose_f[9 + k] = a.tprev[k];
+        }
         __syncthreads();
-        if (threadIdx.x == 0 && !a.first) pr.load(pose_d, pose_f);
     }
     if (a.mode == KT_MODE_HOST) {
         if (threadIdx.x < KT_RED_SLOTS && (threadIdx.x < 29 || threadIdx.x == KT_RED_SLOTS - 1)) a.out29[threadIdx.x] = total[threadIdx.x];
-    } else if (threadIdx.x == 0) {
-        if (a.mode == KT_MODE_ICP_SOLVE) {
-            // ICPOdometry.cpp:127-178
+    } else if (a.mode == KT_MODE_ICP_SOLVE) {
+        // ICPOdometry.cpp:127-178: the solve and the pose update on the lanes of the first wave (kt_solve_and_update_wave); the
+        // bookkeeping stores on a lane of the second
+        if (threadIdx.x == 64) {
             a.state->last_residual[0] = total[27];
             a.state->last_residual[1] = total[28];
             if (a.keep29)
                 for (int k = 0; k < 29; ++k) a.state->icp29[k] = total[k];
-            if (a.first) {  // ICPOdometry.cpp:70-85: previous pose, its inverse, identity increment
+            if (a.first) {  // ICPOdometry.cpp:70-85: previous pose and its inverse
 #pragma unroll
-                for (int k = 0; k < 16; ++k) pr.resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+                for (int k = 0; k < 9; ++k) { a.state->Rprev[k] = a.Rcurr.m[k]; a.state->Rprev_inv[k] = a.Rprev_inv.m[k]; }
 #pragma unroll
-                for (int k = 0; k < 9; ++k) { pr.Rprev[k] = a.Rcurr.m[k]; a.state->Rprev[k] = a.Rcurr.m[k]; a.state->Rprev_inv[k] = a.Rprev_inv.m[k]; }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { pr.tprev[k] = a.tprev[k]; a.state->tprev[k] = a.tprev[k]; }
-                a.state->handoff_timeout = 0;
+                for (int k = 0; k < 3; ++k) a.state->tprev[k] = a.tprev[k];
+                a.state->handoff_timeout = total[KT_RED_SLOTS - 1] != 0.0f ? 1 : 0;
+            } else if (total[KT_RED_SLOTS - 1] != 0.0f) {
+                a.state->handoff_timeout = 1;
             }
-            if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
-            kt_solve_and_update(a.state, pr, sys);
-#ifdef KT_ICP_TIMING
-            { const unsigned long long t5 = wall_clock64(); for (int q = 0; q < 7; ++q) a.state->icp29[q] = (float)(kt_ts[q + 0] - kt_ts[0]); a.state->icp29[7] = (float)(t5 - kt_ts[0]); }
-#endif
-        } else {  // KT_MODE_ICP_STASH: joint RGB-D + ICP, the rgb kernel's epilogue combines and solves
-            for (int k = 0; k < 29; ++k) a.state->icp29[k] = total[k];
-            if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
         }
+        if (threadIdx.x < 64) {
+            kt_solve_and_update_wave(a.state, sys, pose_d, pose_f, tail_work);
+#ifdef KT_ICP_TIMING
+            if (threadIdx.x == 0) { const unsigned long long t5 = wall_clock64(); for (int q = 0; q < 7; ++q) a.state->icp29[q] = (float)(kt_ts[q + 0] - kt_ts[0]); a.state->icp29[7] = (float)(t5 - kt_ts[0]); }
+#endif
+        }
+    } else if (threadIdx.x == 0) {  // KT_MODE_ICP_STASH: joint RGB-D + ICP, the rgb kernel's epilogue combines and solves
+        for (int k = 0; k < 29; ++k) a.state->icp29[k] = total[k];
+        if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
     }
 }
 
@@ -850,14 +858,13 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_arg
 {
     const kt_rgb_row fn{a, a.state ? a.state->sigma_val : a.sigma};
     __shared__ float total[KT_RED_SLOTS];
-    kt_pose_regs pr;
     kt_pose_stage ps;
     auto pre = [&]() { if (a.mode != KT_MODE_HOST) ps.fetch(a.state); };
     if (!kt_reduce29(fn, a.cols * a.rows, a.granules, a.epoch, total, pre)) return;
     if (a.mode == KT_MODE_HOST) {
         if (threadIdx.x < KT_RED_SLOTS && (threadIdx.x < 29 || threadIdx.x == KT_RED_SLOTS - 1)) a.out29[threadIdx.x] = total[threadIdx.x];
     } else {
-        __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES];
+        __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES], tail_work[KT_TAIL_WORK_DOUBLES];
         __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
         ps.park(pose_d, pose_f);
         if (threadIdx.x < 42) {
@@ -871,11 +878,11 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_arg
             sys[threadIdx.x] = v;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            pr.load(pose_d, pose_f);
-            if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
-            kt_solve_and_update(a.state, pr, sys);
-            kt_update_krk(a.state, a.next_k);
+        if (threadIdx.x == 64 && total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
+        if (threadIdx.x < 64) {
+            kt_solve_and_update_wave(a.state, sys, pose_d, pose_f, tail_work);
+            __builtin_amdgcn_wave_barrier();
+            if (threadIdx.x == 0) kt_compute_krk(pose_d, a.next_k, a.state->krkinv, a.state->kt);
         }
     }
 }
@@ -894,7 +901,6 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
     __shared__ float total_icp[KT_RED_SLOTS], total[KT_RED_SLOTS];
     if (kt_red_publishes()) kt_reduce29_publish2(fi, fr, ai.cols * ai.rows, ai.granules, ar.granules, ar.epoch, rows_icp, rows_rgb);
     if (!kt_red_sweeps()) return;
-    kt_pose_regs pr;
     kt_pose_stage ps;
     ps.fetch(ar.state);
     {
@@ -902,7 +908,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
         float* const ts[2] = {total_icp, total};   // the time-out flag lands in total[31]
         kt_reduce29_sweep_n<2>(gs, ar.epoch, ts);
     }
-    __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES];
+    __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES], tail_work[KT_TAIL_WORK_DOUBLES];
     __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
     ps.park(pose_d, pose_f);
     if (threadIdx.x < 42) {   // RGBDOdometry.cpp:316-321: A = A_rgbd + w*w*A_icp, b = b_rgbd + w*b_icp, w = 10
@@ -911,11 +917,11 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
         sys[threadIdx.x] = threadIdx.x < 36 ? v + w * w * vi : v + w * vi;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        pr.load(pose_d, pose_f);
-        if (total[KT_RED_SLOTS - 1] != 0.0f) ar.state->handoff_timeout = 1;
-        kt_solve_and_update(ar.state, pr, sys);
-        kt_update_krk(ar.state, ar.next_k);
+    if (threadIdx.x == 64 && total[KT_RED_SLOTS - 1] != 0.0f) ar.state->handoff_timeout = 1;
+    if (threadIdx.x < 64) {
+        kt_solve_and_update_wave(ar.state, sys, pose_d, pose_f, tail_work);
+        __builtin_amdgcn_wave_barrier();
+        if (threadIdx.x == 0) kt_compute_krk(pose_d, ar.next_k, ar.state->krkinv, ar.state->kt);
     }
 }
 
@@ -970,4 +976,69 @@ int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corr
     hipLaunchKernelGGL(kt_rgb_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// test hook: the serial tail (kt_solve_and_update, one thread) and the lane-parallel one (kt_solve_and_update_wave) on the same systems
+// ------------------------------------------------------------------------------------------------
+struct kt_solve_case {
+    float packed[32];    // the 29 sums in reduce.cu:401-418 order (27 of them the upper triangle of [A | b])
+    float packed2[32];   // joint != 0: the ICP sums of the joint solve (A = A_rgbd + 100 A_icp, b = b_rgbd + 10 b_icp)
+    double resultRt[16];
+    float posef[12];     // Rprev[9], tprev[3]
+    int joint, pad[3];
+};
+
+__global__ __launch_bounds__(64) void kt_solve_check_kernel(const kt_solve_case* __restrict__ cases, kt_track_state* serial_out, kt_track_state* wave_out)
+{
+    __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES], tail_work[KT_TAIL_WORK_DOUBLES];
+    __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
+    const kt_solve_case& cs = cases[blockIdx.x];
+    if (threadIdx.x < 42) {
+        const int slot = kt_sys_slot(threadIdx.x);
+        double v = (double)cs.packed[slot];
+        if (cs.joint) {
+            const double w = 10, vi = (double)cs.packed2[slot];
+            v = threadIdx.x < 36 ? v + w * w * vi : v + w * vi;
+        }
+        sys[threadIdx.x] = v;
+    }
+    if (threadIdx.x < 16) pose_d[threadIdx.x] = cs.resultRt[threadIdx.x];
+    if (threadIdx.x < 12) pose_f[threadIdx.x] = cs.posef[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        kt_pose_regs pr;
+        pr.load(pose_d, pose_f);
+        kt_solve_and_update(&serial_out[blockIdx.x], pr, sys);
+    }
+    __syncthreads();
+    kt_solve_and_update_wave(&wave_out[blockIdx.x], sys, pose_d, pose_f, tail_work);
+}
+
+extern "C" int kt_debug_solve_check(kt_ctx* c, int n, const void* cases_host, void* serial_out_host, void* wave_out_host, int layout_out[5])
+{
+    KT_ARG(c && layout_out);
+    layout_out[0] = (int)sizeof(kt_track_state); layout_out[1] = (int)offsetof(kt_track_state, resultRt);
+    layout_out[2] = (int)offsetof(kt_track_state, Rcurr); layout_out[3] = (int)offsetof(kt_track_state, tcurr);
+    layout_out[4] = (int)sizeof(kt_solve_case);
+    if (n <= 0) return KT_OK;
+    KT_ARG(cases_host && serial_out_host && wave_out_host);
+    kt_solve_case* cases = nullptr;
+    kt_track_state* out = nullptr;
+    KT_HIP(hipMalloc((void**)&cases, sizeof(kt_solve_case) * (size_t)n));
+    if (hipMalloc((void**)&out, sizeof(kt_track_state) * 2 * (size_t)n) != hipSuccess) { (void)hipFree(cases); kt_set_error("kt_debug_solve_check: out of memory"); return KT_ERR_HIP; }
+    int status = KT_OK;
+    if (hipMemcpyAsync(cases, cases_host, sizeof(kt_solve_case) * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemsetAsync(out, 0, sizeof(kt_track_state) * 2 * (size_t)n, c->stream) != hipSuccess) status = KT_ERR_HIP;
+    if (status == KT_OK) {
+        hipLaunchKernelGGL(kt_solve_check_kernel, dim3(n), dim3(64), 0, c->stream, cases, out, out + n);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(serial_out_host, out, sizeof(kt_track_state) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(wave_out_host, out + n, sizeof(kt_track_state) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) status = KT_ERR_HIP;
+    }
+    (void)hipFree(cases);
+    (void)hipFree(out);
+    if (status != KT_OK) kt_set_error("kt_debug_solve_check: HIP error");
+    return status;
 }

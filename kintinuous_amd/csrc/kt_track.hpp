@@ -303,6 +303,7 @@ struct kt_pose_regs {
 // 28 -- the solving thread alone would hold 44 VGPRs across the sweep -- and handed over through LDS with the 6x6 system.
 #define KT_POSE_STAGE_DOUBLES 16
 #define KT_POSE_STAGE_FLOATS 12
+#define KT_TAIL_WORK_DOUBLES 36   // LDS scratch of kt_solve_and_update_wave: the 6 x 6 factor (its transpose is read back), then the float increment
 struct kt_pose_stage {
     double d;
     float f;
@@ -339,4 +340,193 @@ __device__ __forceinline__ void kt_solve_and_update(kt_track_state* st, kt_pose_
     for (int k = 0; k < 3; ++k) st->tcurr[k] = tcurr[k];
 }
 __device__ __forceinline__ void kt_update_krk(kt_track_state* st, const kt_level_k k) { kt_compute_krk(st->resultRt, k, st->krkinv, st->kt); }
+
+// ------------------------------------------------------------------------------------------------
+// The same tail spread over the LANES of one wave (round 4).  The serial form above is ~1300 executed instructions of one thread, and a
+// lone wave issues a dependent f64 operation only every 6-8 cycles: 3.7 us per Gauss-Newton iteration whatever the rest of the chip does
+// (profiles/r04_experiments.md: not instruction fetch -- a second pass over the same code takes 3.4 us).  Its cost is its instruction
+// count, so the arithmetic goes sideways:
+//   * LDL^T: lane r owns row r of the permuted system.  Eigen's unblocked algorithm is left-looking, so at step K every lane i >= K forms
+//     A[i][K] - sum_j (A[i][j] A[K][j]) D[j] for its own row -- lane K's result is the pivot d_K -- with row K and the pivots broadcast by
+//     v_readlane, and ONE division per step serves the five rows below (6 divisions instead of 21, 45 multiply-subtract terms instead of 105);
+//   * forward substitution by lanes (x[i] -= L[i][j] x[j], j ascending: x[j] is final when it is needed); backward substitution is
+//     serial by construction (x[i] subtracts L[j][i] x[j] for j ASCENDING, and its first operand is the one that is ready last): the
+//     products are formed once per column, the subtractions by the lane that owns x[i];
+//   * Rodrigues row i, the row-i-times-column-j products of the 4 x 4 composition and the nine + three elements of the float pose each on
+//     their own lane; the state leaves in three store instructions.
+// Every element sees exactly the operations of kt_ldlt_solve6 / kt_pose_update in the same order (the bit-exact trajectory tests and
+// kt_debug_solve_check -- both forms on the same systems, ties, zeros, NaNs -- compare them).
+// Called by all 64 lanes of ONE wave with wave-uniform arguments.  sys: [0, 36) A row-major, [36, 42) b, [42, 48) scratch; pose_d:
+// resultRt[16]; pose_f: Rprev[9], tprev[3]; work: 64 doubles of LDS scratch.  On return pose_d holds the new resultRt (for kt_compute_krk).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double kt_lane_bcast(double v, int src)   // src: wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, double* sys, double* pose_d, const float* pose_f, double* work)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const int r = min(lane, 5);   // lanes past the sixth repeat the last row (their results are never used)
+    // (1) pivot order: the selection sort of the original diagonal (see kt_ldlt_solve6_hoisted), the same on every lane
+    double dg[6];
+    int idx[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { dg[i] = sys[i * 7]; idx[i] = i; }
+#pragma unroll
+    for (int K = 0; K < 5; ++K) {
+        int p = K;
+        double big = fabs(dg[K]);
+#pragma unroll
+        for (int i = K + 1; i < 6; ++i) {
+            const double v = fabs(dg[i]);
+            if (v > big) { big = v; p = i; }
+        }
+        p = __builtin_amdgcn_readfirstlane(p);
+#pragma unroll
+        for (int c = K + 1; c < 6; ++c)
+            if (p == c) {
+                asm volatile("; pivot swap" ::: "memory");
+                const double t = dg[K]; dg[K] = dg[c]; dg[c] = t;
+                const int ti = idx[K]; idx[K] = idx[c]; idx[c] = ti;
+            }
+    }
+    // (2) row r of A' = P A P^T and b' = P b
+    int my = idx[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) my = (r == i) ? idx[i] : my;
+    double a[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a[c] = sys[my * 6 + idx[c]];
+    double x = sys[36 + my];
+    // (3) LDL^T, left-looking; D[] and the broadcast row are wave-uniform
+    double D[6];
+#pragma unroll
+    for (int K = 0; K < 6; ++K) {
+        double s = a[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) s -= a[j] * kt_lane_bcast(a[j], K) * D[j];
+        const double d = kt_lane_bcast(s, K);
+        D[K] = d;
+        if (K < 5) {
+            const double q = (d != 0.0) ? s / d : s;
+            a[K] = (lane > K) ? q : s;
+        } else {
+            a[K] = s;
+        }
+    }
+    // the columns of L for the backward substitution: T[i][j], read back as c[j] = L[j][r]
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 6) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) work[lane * 6 + c] = a[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (4) forward substitution
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const double xj = kt_lane_bcast(x, j);
+        const double y = x - a[j] * xj;
+        x = (lane > j) ? y : x;
+    }
+    // (5) D^-1 as a pseudo-inverse
+    double maxd = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (fabs(D[i]) > maxd) maxd = fabs(D[i]);
+    double tol = maxd * DBL_EPSILON;
+    if (tol < 1.0 / DBL_MAX) tol = 1.0 / DBL_MAX;
+    double mine = D[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) mine = (r == i) ? D[i] : mine;
+    x = (fabs(mine) > tol) ? x / mine : 0.0;
+    // (6) backward substitution: x[i] -= L[j][i] x[j], j ascending
+    double cl[6];
+#pragma unroll
+    for (int j = 1; j < 6; ++j) cl[j] = work[j * 6 + r];
+    double X[6], P[6];
+    X[5] = kt_lane_bcast(x, 5);
+#pragma unroll
+    for (int s = 4; s >= 0; --s) {
+        P[s + 1] = cl[s + 1] * X[s + 1];
+        double y = x;
+#pragma unroll
+        for (int j = s + 1; j < 6; ++j) y -= P[j];
+        x = (lane == s) ? y : x;
+        X[s] = kt_lane_bcast(x, s);
+    }
+    // (7) x = P^T x': X[i] belongs to the unknown idx[i]
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 6) sys[42 + my] = x;
+    __builtin_amdgcn_wave_barrier();
+    double xs[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xs[i] = sys[42 + i];
+    KT_TS(5);
+    // (8) cv::Rodrigues (kt_rodrigues), row i of [R | t] on the lanes of row i; i == 3: (0, 0, 0, 1)
+    const int pi = (lane >> 2) & 3, pj = lane & 3;
+    double crow[4];
+    {
+        const double theta = sqrt(xs[3] * xs[3] + xs[4] * xs[4] + xs[5] * xs[5]);
+        if (theta < DBL_EPSILON) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) crow[k] = (pi == k) ? 1.0 : 0.0;
+        } else {
+            const double c = cos(theta), sn = sin(theta), c1 = 1. - c, itheta = 1. / theta;
+            const double rx = xs[3] * itheta, ry = xs[4] * itheta, rz = xs[5] * itheta;
+            const double rv[3] = {rx, ry, rz};
+            const double ri = (pi == 0) ? rx : ((pi == 1) ? ry : rz);
+            const double cI1 = c * 1.0, cI0 = c * 0.0;
+            // r_x = {0, -rz, ry;  rz, 0, -rx;  -ry, rx, 0}
+            const double rxk[3] = {(pi == 0) ? 0.0 : ((pi == 1) ? rz : -ry), (pi == 0) ? -rz : ((pi == 1) ? 0.0 : rx), (pi == 0) ? ry : ((pi == 1) ? -rx : 0.0)};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double rrt = ri * rv[k];   // (kt_rodrigues forms r_min * r_max: the same product)
+                crow[k] = ((pi == k) ? cI1 : cI0) + c1 * rrt + sn * rxk[k];
+            }
+        }
+        crow[3] = (pi == 0) ? xs[0] : ((pi == 1) ? xs[1] : xs[2]);
+        if (pi == 3) { crow[0] = 0.0; crow[1] = 0.0; crow[2] = 0.0; crow[3] = 1.0; }
+    }
+    // (9) resultRt = [R | t] * resultRt: element (pi, pj) on lane 4 pi + pj
+    double prod = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) prod += crow[k] * pose_d[k * 4 + pj];
+    __builtin_amdgcn_wave_barrier();
+    float* fw = (float*)work;   // [0, 16): the new increment in float
+    if (lane < 16) {
+        st->resultRt[lane] = prod;
+        pose_d[lane] = prod;
+        fw[lane] = (float)prod;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (10) T_curr = T_prev * inverse([R | t]) in float (kt_pose_update): lanes 0..8 the rotation, 9..11 the translation
+    float rot[9], trans[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rot[i * 3 + j] = fw[i * 4 + j];
+        trans[i] = fw[i * 4 + 3];
+    }
+    float tinv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tinv[i] = -((rot[0 * 3 + i] * trans[0] + rot[1 * 3 + i] * trans[1]) + rot[2 * 3 + i] * trans[2]);
+    const bool is_t = lane >= 9;
+    const int l12 = min(lane, 11);
+    const int oi = is_t ? l12 - 9 : (l12 * 11) >> 5, oj = l12 - 3 * oi;   // (lanes 9..11: oj unused)
+    float B[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float rjk = (oj == 0) ? rot[0 * 3 + k] : ((oj == 1) ? rot[1 * 3 + k] : rot[2 * 3 + k]);   // rinv[k][j] = rot[j][k]
+        B[k] = is_t ? tinv[k] : rjk;
+    }
+    const float p0 = pose_f[oi * 3 + 0], p1 = pose_f[oi * 3 + 1], p2 = pose_f[oi * 3 + 2];
+    float v = (p0 * B[0] + p1 * B[1]) + p2 * B[2];
+    const float vt = v + pose_f[9 + oi];
+    v = is_t ? vt : v;
+    if (lane < 12) (&st->Rcurr[0])[lane] = v;   // Rcurr[9] and tcurr[3] are adjacent in kt_track_state
+    KT_TS(6);
+}
+static_assert(offsetof(kt_track_state, tcurr) == offsetof(kt_track_state, Rcurr) + 9 * sizeof(float), "Rcurr / tcurr adjacency");
 #endif
