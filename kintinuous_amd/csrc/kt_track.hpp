@@ -359,6 +359,11 @@ __device__ __forceinline__ void kt_update_krk(kt_track_state* st, const kt_level
 // Called by all 64 lanes of ONE wave with wave-uniform arguments.  sys: [0, 36) A row-major, [36, 42) b, [42, 48) scratch; pose_d:
 // resultRt[16]; pose_f: Rprev[9], tprev[3]; work: 64 doubles of LDS scratch.  On return pose_d holds the new resultRt (for kt_compute_krk).
 // ------------------------------------------------------------------------------------------------
+#ifdef KT_TAIL_MARK   // analysis builds: section markers in the ISA (scripts/isa_summary.py counts the instructions between them)
+#define KT_MARK(n) asm volatile("; TAILSEC " #n ::: "memory")
+#else
+#define KT_MARK(n) do {} while (0)
+#endif
 __device__ __forceinline__ double kt_lane_bcast(double v, int src)   // src: wave-uniform
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -368,68 +373,88 @@ __device__ __forceinline__ double kt_lane_bcast(double v, int src)   // src: wav
 __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, double* sys, double* pose_d, const float* pose_f, double* work)
 {
     const int lane = (int)(threadIdx.x & 63u);
-    const int r = min(lane, 5);   // lanes past the sixth repeat the last row (their results are never used)
-    // (1) pivot order: the selection sort of the original diagonal (see kt_ldlt_solve6_hoisted), the same on every lane
+    const int r = min(lane, 5);   // lanes past the sixth repeat row 5 (their results are never used)
+    KT_MARK(1);
+    // (1) pivot order.  Lane l keeps ORIGINAL row l; what is permuted is its logical position pos (the row of A' = P A P^T it stands
+    // for) and the order idx[] in which everybody walks the columns.  The order is the selection sort of the original diagonal (see
+    // kt_ldlt_solve6_hoisted).  Without ties it is simply the rank of |A[l][l]| -- counted by the lanes, no swaps; with a tie or a NaN on
+    // the diagonal the swap history decides, and the serial emulation runs (wave-uniform branch).
     double dg[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dg[i] = fabs(sys[i * 7]);
+    const double mydg = fabs(sys[r * 7]);
+    int n_gt = 0, n_ge = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { n_gt += (dg[i] > mydg) ? 1 : 0; n_ge += (dg[i] >= mydg) ? 1 : 0; }
+    int pos = n_gt;
     int idx[6];
+    if (__builtin_amdgcn_ballot_w64(n_ge != n_gt + 1) == 0) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { dg[i] = sys[i * 7]; idx[i] = i; }
+        for (int c = 0; c < 6; ++c) idx[c] = __builtin_ctzll(__builtin_amdgcn_ballot_w64((n_gt == c) & (lane < 6)) | (1ull << 63));
+    } else {
+        asm volatile("; pivot order with ties" ::: "memory");
 #pragma unroll
-    for (int K = 0; K < 5; ++K) {
-        int p = K;
-        double big = fabs(dg[K]);
+        for (int i = 0; i < 6; ++i) idx[i] = i;
 #pragma unroll
-        for (int i = K + 1; i < 6; ++i) {
-            const double v = fabs(dg[i]);
-            if (v > big) { big = v; p = i; }
+        for (int K = 0; K < 5; ++K) {
+            int p = K;
+            double big = dg[K];
+#pragma unroll
+            for (int i = K + 1; i < 6; ++i)
+                if (dg[i] > big) { big = dg[i]; p = i; }
+            p = __builtin_amdgcn_readfirstlane(p);
+#pragma unroll
+            for (int c = K + 1; c < 6; ++c)
+                if (p == c) {
+                    asm volatile("; pivot swap" ::: "memory");
+                    const double t = dg[K]; dg[K] = dg[c]; dg[c] = t;
+                    const int ti = idx[K]; idx[K] = idx[c]; idx[c] = ti;
+                }
         }
-        p = __builtin_amdgcn_readfirstlane(p);
+        pos = 0;
 #pragma unroll
-        for (int c = K + 1; c < 6; ++c)
-            if (p == c) {
-                asm volatile("; pivot swap" ::: "memory");
-                const double t = dg[K]; dg[K] = dg[c]; dg[c] = t;
-                const int ti = idx[K]; idx[K] = idx[c]; idx[c] = ti;
-            }
+        for (int i = 0; i < 6; ++i) { idx[i] = __builtin_amdgcn_readfirstlane(idx[i]); pos = (idx[i] == r) ? i : pos; }
     }
-    // (2) row r of A' = P A P^T and b' = P b
-    int my = idx[0];
-#pragma unroll
-    for (int i = 1; i < 6; ++i) my = (r == i) ? idx[i] : my;
+    KT_MARK(2);
+    // (2) row l with its columns in pivot order, and b[l]
     double a[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) a[c] = sys[my * 6 + idx[c]];
-    double x = sys[36 + my];
-    // (3) LDL^T, left-looking; D[] and the broadcast row are wave-uniform
+    for (int c = 0; c < 6; ++c) a[c] = sys[r * 6 + idx[c]];
+    double x = sys[36 + r];
+    KT_MARK(3);
+    // (3) LDL^T, left-looking; D[] and the broadcast row are wave-uniform.  Step K: the lane at position K owns the pivot.
     double D[6];
 #pragma unroll
     for (int K = 0; K < 6; ++K) {
         double s = a[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) s -= a[j] * kt_lane_bcast(a[j], K) * D[j];
-        const double d = kt_lane_bcast(s, K);
+        for (int j = 0; j < K; ++j) s -= a[j] * kt_lane_bcast(a[j], idx[K]) * D[j];
+        const double d = kt_lane_bcast(s, idx[K]);
         D[K] = d;
         if (K < 5) {
             const double q = (d != 0.0) ? s / d : s;
-            a[K] = (lane > K) ? q : s;
+            a[K] = (pos > K) ? q : s;
         } else {
             a[K] = s;
         }
     }
-    // the columns of L for the backward substitution: T[i][j], read back as c[j] = L[j][r]
+    KT_MARK(31);
+    // the factor by positions, for the backward substitution (its columns) and the lane's own pivot: T[pos][c]
     __builtin_amdgcn_wave_barrier();
     if (lane < 6) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) work[lane * 6 + c] = a[c];
+        for (int c = 0; c < 6; ++c) work[pos * 6 + c] = a[c];
     }
     __builtin_amdgcn_wave_barrier();
+    KT_MARK(4);
     // (4) forward substitution
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const double xj = kt_lane_bcast(x, j);
+        const double xj = kt_lane_bcast(x, idx[j]);
         const double y = x - a[j] * xj;
-        x = (lane > j) ? y : x;
+        x = (pos > j) ? y : x;
     }
+    KT_MARK(5);
     // (5) D^-1 as a pseudo-inverse
     double maxd = 0;
 #pragma unroll
@@ -437,33 +462,34 @@ __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, dou
         if (fabs(D[i]) > maxd) maxd = fabs(D[i]);
     double tol = maxd * DBL_EPSILON;
     if (tol < 1.0 / DBL_MAX) tol = 1.0 / DBL_MAX;
-    double mine = D[0];
-#pragma unroll
-    for (int i = 1; i < 6; ++i) mine = (r == i) ? D[i] : mine;
+    const double mine = work[pos * 7];
     x = (fabs(mine) > tol) ? x / mine : 0.0;
+    KT_MARK(6);
     // (6) backward substitution: x[i] -= L[j][i] x[j], j ascending
     double cl[6];
 #pragma unroll
-    for (int j = 1; j < 6; ++j) cl[j] = work[j * 6 + r];
+    for (int j = 1; j < 6; ++j) cl[j] = work[j * 6 + pos];
     double X[6], P[6];
-    X[5] = kt_lane_bcast(x, 5);
+    X[5] = kt_lane_bcast(x, idx[5]);
 #pragma unroll
     for (int s = 4; s >= 0; --s) {
         P[s + 1] = cl[s + 1] * X[s + 1];
         double y = x;
 #pragma unroll
         for (int j = s + 1; j < 6; ++j) y -= P[j];
-        x = (lane == s) ? y : x;
-        X[s] = kt_lane_bcast(x, s);
+        x = (pos == s) ? y : x;
+        if (s > 0) X[s] = kt_lane_bcast(x, idx[s]);
     }
-    // (7) x = P^T x': X[i] belongs to the unknown idx[i]
+    KT_MARK(7);
+    // (7) lane l holds the unknown l: no permutation to undo
     __builtin_amdgcn_wave_barrier();
-    if (lane < 6) sys[42 + my] = x;
+    if (lane < 6) sys[42 + lane] = x;
     __builtin_amdgcn_wave_barrier();
     double xs[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) xs[i] = sys[42 + i];
     KT_TS(5);
+    KT_MARK(8);
     // (8) cv::Rodrigues (kt_rodrigues), row i of [R | t] on the lanes of row i; i == 3: (0, 0, 0, 1)
     const int pi = (lane >> 2) & 3, pj = lane & 3;
     double crow[4];
@@ -489,6 +515,7 @@ __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, dou
         crow[3] = (pi == 0) ? xs[0] : ((pi == 1) ? xs[1] : xs[2]);
         if (pi == 3) { crow[0] = 0.0; crow[1] = 0.0; crow[2] = 0.0; crow[3] = 1.0; }
     }
+    KT_MARK(9);
     // (9) resultRt = [R | t] * resultRt: element (pi, pj) on lane 4 pi + pj
     double prod = 0;
 #pragma unroll
@@ -501,6 +528,7 @@ __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, dou
         fw[lane] = (float)prod;
     }
     __builtin_amdgcn_wave_barrier();
+    KT_MARK(10);
     // (10) T_curr = T_prev * inverse([R | t]) in float (kt_pose_update): lanes 0..8 the rotation, 9..11 the translation
     float rot[9], trans[3];
 #pragma unroll
@@ -526,6 +554,7 @@ __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, dou
     const float vt = v + pose_f[9 + oi];
     v = is_t ? vt : v;
     if (lane < 12) (&st->Rcurr[0])[lane] = v;   // Rcurr[9] and tcurr[3] are adjacent in kt_track_state
+    KT_MARK(11);
     KT_TS(6);
 }
 static_assert(offsetof(kt_track_state, tcurr) == offsetof(kt_track_state, Rcurr) + 9 * sizeof(float), "Rcurr / tcurr adjacency");
