@@ -299,6 +299,8 @@ static unsigned int kt_next_epoch(kt_ctx* c)
 // the residual kernel's granules live behind the two [32][256] kt_reduce29 blocks in the same buffer
 static unsigned long long* kt_residual_granules(kt_ctx* c) { return (unsigned long long*)c->red_partials + 64 * KT_RED_BLOCKS; }
 // second kt_reduce29 granule block, for kernels that run two reductions (kt_joint_kernel)
+// ... and behind those the plain per-workgroup words of the device-path residual launch ([2][256] unsigned int)
+static unsigned int* kt_residual_partials(kt_ctx* c) { return (unsigned int*)((unsigned long long*)c->red_partials + 64 * KT_RED_BLOCKS + 1024); }
 static unsigned long long* kt_second_granules(kt_ctx* c) { return (unsigned long long*)c->red_partials + 32 * KT_RED_BLOCKS; }
 
 // ------------------------------------------------------------------------------------------------
@@ -577,7 +579,8 @@ struct kt_residual_args {
     kt_track_state* state;   // device path: krkinv / kt read from the state, sigma written back
     int cols, rows;
     int* out2;               // host path: {count, sigma} written by the sweeping workgroup
-    unsigned long long* granules; unsigned int epoch;   // [2][gridDim.x] {epoch, value} hand-off granules (as in kt_reduce29)
+    unsigned long long* granules; unsigned int epoch;   // host path: [2][gridDim.x] {epoch, value} hand-off granules (as in kt_reduce29)
+    unsigned int* partials;  // device path: [2][KT_RES_MAX_BLOCKS] plain per-workgroup sums, read by the next launch (kt_residual_sigma)
     const uint8_t* cand;     // tracker path: the pose-independent half of the per-pixel test, precomputed per frame (kt_residual_candidates_kernel)
     int write_all;           // with cand: 0 = only candidates are stored (the other DataTerms were zeroed by an earlier iteration of this frame)
 };
@@ -620,6 +623,7 @@ int kt_rgb_residual_candidates(kt_ctx* c, float min_scale, const int16_t* dIdx, 
 
 #define KT_RES_THREADS 1024
 #define KT_RES_MAX_BLOCKS 256   // <= 4 granules per sweeping lane and sum
+static int kt_residual_blocks(int cols, int rows) { const int g = kt_div_up(cols * rows, KT_RES_THREADS); return g > KT_RES_MAX_BLOCKS ? KT_RES_MAX_BLOCKS : g; }
 template <bool PRE>
 __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_residual_args a)
 {
@@ -686,10 +690,18 @@ __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_re
         unsigned int t = 0;
 #pragma unroll
         for (int w = 0; w < KT_RES_THREADS / 64; ++w) t += wsum[threadIdx.x][w];
+        if (a.state) {
+            // device path (round 4): the pair goes out as plain words and the launch ENDS here -- no sweep.  The consumer is the next
+            // launch on the stream (kt_rgb_kernel / kt_joint_kernel), whose kernel boundary makes the words visible; each of its waves adds
+            // the <= 256 pairs up itself while its first loads are in flight (kt_residual_sigma): one cross-XCD polling round trip and a
+            // serial tail less per Gauss-Newton iteration (5.5 -> 3.5 us).
+            a.partials[threadIdx.x * KT_RES_MAX_BLOCKS + blockIdx.x] = t;
+            return;
+        }
         __hip_atomic_store(&a.granules[threadIdx.x * gridDim.x + blockIdx.x], ((unsigned long long)a.epoch << 32) | t, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (blockIdx.x != gridDim.x - 1 || threadIdx.x >= 64) return;
+    if (a.state || blockIdx.x != gridDim.x - 1 || threadIdx.x >= 64) return;
     // sweeping wave: lane l reads granules l, l + 64, l + 128, l + 192 of both sums -- all eight loads in flight together -- until
     // every tag carries this launch's epoch
     unsigned int tot[2] = {0, 0};
@@ -726,19 +738,34 @@ __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_re
     }
     const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
     if (lane == 0) {
-        const int count = (int)tot[0], sigma = (int)tot[1];
-        if (a.state) {
-            // RGBDOdometry.cpp:253 (quirk): sigmaVal = sqrt(count) unless sigma / count == 0
-            a.state->sigma_val = __builtin_sqrtf(((float)sigma / (float)count == 0) ? 1.0f : (float)count);
-            a.state->rgb_count = count;
-            a.state->rgb_sigma = sigma;
-            if (!all_ok) a.state->handoff_timeout = 1;
-        } else {
-            a.out2[0] = count;
-            a.out2[1] = sigma;
-            a.out2[2] = all_ok ? 0 : 1;
-        }
+        a.out2[0] = (int)tot[0];
+        a.out2[1] = (int)tot[1];
+        a.out2[2] = all_ok ? 0 : 1;
     }
+}
+
+// {count, sum diff^2} of the residual launch in front of this one, summed by every wave for itself from the workgroups' plain words
+// (integer sums: any order), and RGBDOdometry.cpp:253's sigmaVal from them (quirk A.11: sqrt(count) unless sigma / count == 0)
+__device__ __forceinline__ float kt_residual_sigma(const unsigned int* __restrict__ partials, int blocks, int& count_out, int& sigma_out)
+{
+    const unsigned int lane = threadIdx.x & 63u;
+    unsigned int tot[2] = {0, 0};
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+        for (int q = 0; q < KT_RES_MAX_BLOCKS / 64; ++q) {
+            const unsigned int g = lane + 64u * q;
+            const unsigned int v = partials[which * KT_RES_MAX_BLOCKS + min(g, (unsigned int)blocks - 1u)];
+            tot[which] += g < (unsigned int)blocks ? v : 0u;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tot[0] += __shfl_xor(tot[0], off, 64);
+        tot[1] += __shfl_xor(tot[1], off, 64);
+    }
+    count_out = (int)tot[0];
+    sigma_out = (int)tot[1];
+    return __builtin_sqrtf(((float)sigma_out / (float)count_out == 0) ? 1.0f : (float)count_out);
 }
 
 extern "C" int kt_rgb_residual(kt_ctx* c, float min_scale, const int16_t* dIdx, const int16_t* dIdy, const float* last_depth,
@@ -754,7 +781,7 @@ extern "C" int kt_rgb_residual(kt_ctx* c, float min_scale, const int16_t* dIdx, 
     a.last_image = last_image; a.next_image = next_image; a.corres = corres_img; a.max_depth_delta = max_depth_delta;
     for (int k = 0; k < 3; ++k) a.kt_[k] = kt[k];
     a.krkinv = *krkinv; a.state = nullptr; a.cols = cols; a.rows = rows; a.out2 = out2;
-    a.granules = kt_residual_granules(c); a.epoch = kt_next_epoch(c);
+    a.granules = kt_residual_granules(c); a.epoch = kt_next_epoch(c); a.partials = nullptr;
     a.cand = nullptr; a.write_all = 1;
     int g = kt_div_up(cols * rows, KT_RES_THREADS);
     if (g > KT_RES_MAX_BLOCKS) g = KT_RES_MAX_BLOCKS;
@@ -776,10 +803,9 @@ int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, co
     a.min_scale = min_scale; a.dIdx = dIdx; a.dIdy = dIdy; a.last_depth = last_depth; a.next_depth = next_depth;
     a.last_image = last_image; a.next_image = next_image; a.corres = corres_img; a.max_depth_delta = max_depth_delta;
     a.state = state; a.cols = cols; a.rows = rows; a.out2 = (int*)&c->counters[4];
-    a.granules = kt_residual_granules(c); a.epoch = kt_next_epoch(c);
+    a.granules = nullptr; a.epoch = 0; a.partials = kt_residual_partials(c);
     a.cand = cand; a.write_all = write_all;
-    int g = kt_div_up(cols * rows, KT_RES_THREADS);
-    if (g > KT_RES_MAX_BLOCKS) g = KT_RES_MAX_BLOCKS;
+    const int g = kt_residual_blocks(cols, rows);
     if (cand) hipLaunchKernelGGL(kt_residual_kernel<true>, dim3(g), dim3(KT_RES_THREADS), 0, c->stream, a);
     else hipLaunchKernelGGL(kt_residual_kernel<false>, dim3(g), dim3(KT_RES_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
@@ -802,6 +828,7 @@ struct kt_rgb_args {
     float* out29;
     int mode;              // KT_MODE_HOST, KT_MODE_RGB_SOLVE, KT_MODE_JOINT_SOLVE
     kt_level_k next_k;     // intrinsics of the level the NEXT iteration runs at (for K R K^-1, K t)
+    const unsigned int* res_partials; int res_blocks;   // device path: the residual launch's per-workgroup {count, sum diff^2} words
 };
 
 struct kt_rgb_row {
@@ -856,7 +883,8 @@ struct kt_rgb_row {
 
 __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_args a)
 {
-    const kt_rgb_row fn{a, a.state ? a.state->sigma_val : a.sigma};
+    int res_count = 0, res_sigma = 0;
+    const kt_rgb_row fn{a, a.state ? kt_residual_sigma(a.res_partials, a.res_blocks, res_count, res_sigma) : a.sigma};
     __shared__ float total[KT_RED_SLOTS];
     kt_pose_stage ps;
     auto pre = [&]() { if (a.mode != KT_MODE_HOST) ps.fetch(a.state); };
@@ -878,7 +906,10 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_arg
             sys[threadIdx.x] = v;
         }
         __syncthreads();
-        if (threadIdx.x == 64 && total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
+        if (threadIdx.x == 64) {
+            if (total[KT_RED_SLOTS - 1] != 0.0f) a.state->handoff_timeout = 1;
+            a.state->sigma_val = fn.sigma; a.state->rgb_count = res_count; a.state->rgb_sigma = res_sigma;   // (kept for observers)
+        }
         if (threadIdx.x < 64) {
             kt_solve_and_update_wave(a.state, sys, pose_d, pose_f, tail_work);
             __builtin_amdgcn_wave_barrier();
@@ -896,7 +927,8 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
     for (int k = 0; k < 9; ++k) { fi.Rcurr.m[k] = ai.state->Rcurr[k]; fi.Rprev_inv.m[k] = ai.state->Rprev_inv[k]; }
     fi.tcurr = {ai.state->tcurr[0], ai.state->tcurr[1], ai.state->tcurr[2]};
     fi.tprev = {ai.state->tprev[0], ai.state->tprev[1], ai.state->tprev[2]};
-    const kt_rgb_row fr{ar, ar.state->sigma_val};
+    int res_count = 0, res_sigma = 0;
+    const kt_rgb_row fr{ar, kt_residual_sigma(ar.res_partials, ar.res_blocks, res_count, res_sigma)};
     __shared__ kt_rows_t rows_icp[KT_KBATCH], rows_rgb[KT_KBATCH];   // 2 x 40 KB
     __shared__ float total_icp[KT_RED_SLOTS], total[KT_RED_SLOTS];
     if (kt_red_publishes()) kt_reduce29_publish2(fi, fr, ai.cols * ai.rows, ai.granules, ar.granules, ar.epoch, rows_icp, rows_rgb);
@@ -917,7 +949,10 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
         sys[threadIdx.x] = threadIdx.x < 36 ? v + w * w * vi : v + w * vi;
     }
     __syncthreads();
-    if (threadIdx.x == 64 && total[KT_RED_SLOTS - 1] != 0.0f) ar.state->handoff_timeout = 1;
+    if (threadIdx.x == 64) {
+        if (total[KT_RED_SLOTS - 1] != 0.0f) ar.state->handoff_timeout = 1;
+        ar.state->sigma_val = fr.sigma; ar.state->rgb_count = res_count; ar.state->rgb_sigma = res_sigma;   // (kept for observers)
+    }
     if (threadIdx.x < 64) {
         kt_solve_and_update_wave(ar.state, sys, pose_d, pose_f, tail_work);
         __builtin_amdgcn_wave_barrier();
@@ -941,6 +976,7 @@ int kt_joint_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_cur
     r.sobel_scale = sobel_scale; r.cols = cols; r.rows = rows; r.state = state;
     r.granules = (unsigned long long*)c->red_partials; r.epoch = a.epoch; r.out29 = nullptr; r.mode = KT_MODE_JOINT_SOLVE;
     r.next_k = *next_k;
+    r.res_partials = kt_residual_partials(c); r.res_blocks = kt_residual_blocks(cols, rows);
     hipLaunchKernelGGL(kt_joint_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a, r);
     KT_LAUNCH_CHECK();
     return KT_OK;
@@ -955,6 +991,7 @@ extern "C" int kt_rgb_step(kt_ctx* c, const kt_dataterm* corres_img, float sigma
     a.corres = corres_img; a.sigma = sigma; a.cloud = cloud; a.fx = fx; a.fy = fy; a.dIdx = dIdx; a.dIdy = dIdy;
     a.sobel_scale = sobel_scale; a.cols = cols; a.rows = rows; a.state = nullptr;
     a.granules = (unsigned long long*)c->red_partials; a.epoch = kt_next_epoch(c); a.out29 = c->red_out; a.mode = KT_MODE_HOST;
+    a.res_partials = nullptr; a.res_blocks = 0;
     hipLaunchKernelGGL(kt_rgb_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * KT_RED_SLOTS, hipMemcpyDeviceToHost, c->stream));
@@ -973,6 +1010,7 @@ int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corr
     a.sobel_scale = sobel_scale; a.cols = cols; a.rows = rows; a.state = state;
     a.granules = (unsigned long long*)c->red_partials; a.epoch = kt_next_epoch(c); a.out29 = nullptr; a.mode = mode;
     a.next_k = *next_k;
+    a.res_partials = kt_residual_partials(c); a.res_blocks = kt_residual_blocks(cols, rows);
     hipLaunchKernelGGL(kt_rgb_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
