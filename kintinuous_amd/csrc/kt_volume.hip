@@ -1343,38 +1343,85 @@ __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, c
 // records -- which ARE re-read, by every z-step of every column -- in the L2s: 21 % fewer bytes fetched at the same launch time
 // (profiles/r04_experiments.md).  On a sparse view the words a frame updates (20 MB) are still cached from the frame before, and
 // non-temporal accesses give those hits up (orbit: 47 us against 32).
-template <bool COUNT, bool NT>
+#ifdef KT_TSDF_TIMELINE   // analysis builds (scripts/tsdf_timeline.py): per wave {hw id, entry, tables ready, first batch, ..., exit} in 10 ns ticks
+#define KT_TL_WORDS 16
+__device__ unsigned long long kt_tsdf_tl[KT_TSDF_WAVES * KT_TL_WORDS];
+#define KT_TL(i) do { if ((threadIdx.x & 63) == 0 && tl_n < KT_TL_WORDS) tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define KT_TL(i) do {} while (0)
+#endif
+// FP: the pose and the parked flag come from the device (kt_frame_params, the tracker) -- a compile-time property so that the start-up
+// has no pointer test in front of its loads.
+template <bool COUNT, bool NT, bool FP>
 __global__ __launch_bounds__(256, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_kernel(const kt_tsdf_lean_args a_in)
 {
+#ifdef KT_TSDF_TIMELINE
+    unsigned long long* tl = &kt_tsdf_tl[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * KT_TL_WORDS];
+    int tl_n = 0;
+    if ((threadIdx.x & 63) == 0) { unsigned int hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); tl[tl_n++] = hw; for (int q = 1; q < KT_TL_WORDS; ++q) tl[q] = 0; }
+    KT_TL(1);
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char kt_tsdf_lds[];
     float* s_rcp = (float*)kt_tsdf_lds;                                   // [256] RN(1 / (W + 1)) for every weight byte W
     kt_tsdf_ztab* s_tab = (kt_tsdf_ztab*)(kt_tsdf_lds + 1024);            // [N + KT_TSDF_UNROLL]
     const kt_tsdf_lean_args& a = a_in;
-    // a parked frame does nothing here: its in-stream pre-pass left an empty task list, but a plan made ahead of the frame did not
-    if (a.fp && a.fp->skip != 0) return;
+    // Start-up, in as few dependent memory round trips as the data allow (the in-kernel timeline of round 4, profiles/r04_experiments.md:
+    // a wave spent 2.2 us before its tables were ready -- the parked-frame flag was tested BEFORE anything else was requested -- and 3.5 us
+    // more on task_count -> task word -> {wave-column range, walk checkpoint}; every wave of a one-task-per-wave launch is in that phase
+    // at the same time, so nothing hides it).  Now: trip 1 = {parked flag, pose, this XCD's part of the list, this thread's table entries},
+    // trip 2 = the wave's first task word, under the table's LDS writes and the barrier; trip 3 = range + checkpoint.
     const int N = a.N;
+    const unsigned int xcd = blockIdx.x & 7u;
+    int parked = 0;
     float Ri[9], tx, ty, tz;   // the pose: from the device (kt_frame_params, written by the frame's set-up kernel) or from the arguments
-    if (a.fp) {
+    if constexpr (FP) {
+        // t[3], Rinv[9] and skip are 13 consecutive words of kt_frame_params: requested together, one wait
+        struct fp_tail { float t[3], Rinv[9]; int skip; };
+        static_assert(offsetof(kt_frame_params, skip) == offsetof(kt_frame_params, t) + 12 * sizeof(float), "kt_frame_params tail");
+        const fp_tail ft = *(const fp_tail*)&a.fp->t[0];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Ri[k] = a.fp->Rinv[k];
-        tx = a.fp->t[0]; ty = a.fp->t[1]; tz = a.fp->t[2];
+        for (int k = 0; k < 9; ++k) Ri[k] = ft.Rinv[k];
+        tx = ft.t[0]; ty = ft.t[1]; tz = ft.t[2];
+        parked = ft.skip;
     } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Ri[k] = a.Ri.m[k];
         tx = a.tx; ty = a.ty; tz = a.tz;
     }
+    // XCD-aware task order (see kt_tsdf23_kernel): XCD k takes the k-th contiguous part of the list.
+    // A parked frame does nothing here (its in-stream pre-pass left an empty task list, but a plan made ahead of the frame did not): its
+    // part of the list is taken as empty.  Deliberately NOT an early return: a branch on the flag in front of everything else is what
+    // made the flag's round trip the first of five.
+    const uint2 t_part = *(const uint2*)&a.task_count[1 + xcd];   // (4-byte aligned: two adjacent words, one request)
+    const unsigned int t_begin = t_part.x, t_end = parked != 0 ? t_part.x : t_part.y;
+    constexpr int KT_TAB_PASSES = (1023 + KT_TSDF_UNROLL + 255) / 256;   // N < 1024 on this path
+    float tab_vgz[KT_TAB_PASSES], tab_zs[KT_TAB_PASSES];
+#pragma unroll
+    for (int i = 0; i < KT_TAB_PASSES; ++i) {
+        const int z = (int)threadIdx.x + 256 * i;
+        const int zz = min(z, N - 1);   // entries past the volume are only ever read by masked-off steps; they repeat the last one
+        tab_vgz[i] = a.vgz[zz]; tab_zs[i] = a.zs[zz];
+    }
+    const unsigned int t_stride = (gridDim.x >> 3) * 4u;
+    unsigned int t = t_begin + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);
+    unsigned int task_word = t < t_end ? a.tasks[t] : 0u;
     const unsigned int plane = (unsigned int)N * (unsigned int)N;
     s_rcp[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
-    for (int z = threadIdx.x; z < N + KT_TSDF_UNROLL; z += 256) {
-        const int zz = min(z, N - 1);   // entries past the volume are only ever read by masked-off steps; they repeat the last one
-        int sz = zz + a.wz; if (sz >= N) sz -= N;
-        kt_tsdf_ztab e;
-        e.vgz = a.vgz[zz]; e.zs = a.zs[zz];
-        e.zoff2 = (unsigned int)sz * plane * 2u;
-        e.bz = (sz >> KT_BRICK_LOG2) * a.nb * a.nb;
-        s_tab[z] = e;
+#pragma unroll
+    for (int i = 0; i < KT_TAB_PASSES; ++i) {
+        const int z = (int)threadIdx.x + 256 * i;
+        if (z < N + KT_TSDF_UNROLL) {
+            const int zz = min(z, N - 1);
+            int sz = zz + a.wz; if (sz >= N) sz -= N;
+            kt_tsdf_ztab e;
+            e.vgz = tab_vgz[i]; e.zs = tab_zs[i];
+            e.zoff2 = (unsigned int)sz * plane * 2u;
+            e.bz = (sz >> KT_BRICK_LOG2) * a.nb * a.nb;
+            s_tab[z] = e;
+        }
     }
     __syncthreads();
+    KT_TL(2);
     kt_tsdf_bufs m;
     {
         const unsigned int nvox = (unsigned int)a_in.N * (unsigned int)a_in.N * (unsigned int)a_in.N;
@@ -1389,10 +1436,8 @@ __global__ __launch_bounds__(256, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_k
     const float tranc_dist_inv = 1.0f / a.tranc_dist;
     const float r8 = Ri[8];
     unsigned int n_upd = 0, n_batches = 0, n_tasks_done = 0, n_img = 0;
-    // XCD-aware task order (see kt_tsdf23_kernel): XCD k takes the k-th contiguous part of the list
-    const unsigned int t_begin = a.task_count[1 + (blockIdx.x & 7u)], t_end = a.task_count[2 + (blockIdx.x & 7u)];
-    for (unsigned int t = t_begin + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); t < t_end; t += (gridDim.x >> 3) * 4u) {
-        const unsigned int task = __builtin_amdgcn_readfirstlane(a.tasks[t]);
+    for (; t < t_end; t += t_stride, task_word = t < t_end ? a.tasks[t] : 0u) {
+        const unsigned int task = __builtin_amdgcn_readfirstlane(task_word);
         const int yg = (int)(task & 0xffffu), xg = (int)((task >> 16) & 0xffu), chunk = (int)(task >> 24);
         const int sx = xg * WX + (lane & (WX - 1));
         const int sy = min(yg * WY + (lane >> a.wcl), N - 1);   // a row past the volume (odd N) only repeats the last one, never live
@@ -1427,10 +1472,12 @@ __global__ __launch_bounds__(256, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_k
         const float d_a = __builtin_fmaf(r8, s_tab[wz0].zs, v_z), d_b = __builtin_fmaf(r8, s_tab[z_last].zs, v_z);
         const bool d_ok = fminf(fabsf(d_a), fabsf(d_b)) >= 0x1p-20f && fmaxf(fabsf(d_a), fabsf(d_b)) <= 0x1p20f && (d_a < 0) == (d_b < 0);
         const bool fast = __builtin_amdgcn_ballot_w64(!d_ok) == 0;
+        KT_TL(3);
         if (fast) {
             if (lane_ok & (d_a > 0)) {   // lanes behind the camera plane (1 / d < 0) never pass the in-image test
                 for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
                     kt_tsdf_batch_lean<COUNT, true, NT>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
+                    KT_TL(4);
                 }
             }
         } else if (lane_ok) {
@@ -1440,6 +1487,7 @@ __global__ __launch_bounds__(256, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_k
         }
         if (COUNT) { n_batches += (unsigned int)((wz1 - wz0 + KT_TSDF_UNROLL - 1) / KT_TSDF_UNROLL); ++n_tasks_done; }
     }
+    KT_TL(9);
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { n_upd += __shfl_down(n_upd, off, 64); n_img += __shfl_down(n_img, off, 64); }
         if (lane == 0) {
@@ -1591,6 +1639,19 @@ static bool kt_tsdf_lean_selected()
     static const bool lean_env = []() { const char* e = getenv("KT_TSDF_LEAN"); return e ? atoi(e) != 0 : KT_TSDF_LEAN_DEFAULT != 0; }();
     return kt_tsdf_lean_override < 0 ? lean_env : kt_tsdf_lean_override != 0;
 }
+extern "C" int kt_debug_tsdf_timeline(kt_ctx* c, unsigned long long* out_host, int max_words)
+{
+    KT_ARG(c && out_host && max_words > 0);
+#ifdef KT_TSDF_TIMELINE
+    KT_HIP(hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)KT_TSDF_WAVES * KT_TL_WORDS;
+    KT_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(kt_tsdf_tl), sizeof(unsigned long long) * (n < (size_t)max_words ? n : (size_t)max_words)));
+    return (int)KT_TL_WORDS;   // (> 0: words per wave)
+#else
+    kt_set_error("kt_debug_tsdf_timeline: the library was not built with -DKT_TSDF_TIMELINE");
+    return -KT_ERR_STATE;
+#endif
+}
 extern "C" const char* kt_debug_tsdf_kernel(void) { return kt_tsdf_lean_selected() ? "kt_tsdf23_lean_kernel" : "kt_tsdf23_kernel"; }
 
 // shared by the C entry point and the tracker (which wants the update count for the roofline report)
@@ -1679,8 +1740,10 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
         // dense view (the rule that picks the 32 x 2 wave-column shape): the volume words stream, non-temporal; KT_TSDF_NT=0|1 overrides
         static const int nt_env = []() { const char* e = getenv("KT_TSDF_NT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
         const bool nt = nt_env >= 0 ? nt_env != 0 : a.wcl == 5;
-        if (updated_dev) { if (nt) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<true, true>), g, b, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<true, false>), g, b, lds, c->stream, l); }
-        else { if (nt) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<false, true>), g, b, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<false, false>), g, b, lds, c->stream, l); }
+#define KT_LEAN_LAUNCH(C, T) do { if (l.fp) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, true>), g, b, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, false>), g, b, lds, c->stream, l); } while (0)
+        if (updated_dev) { if (nt) KT_LEAN_LAUNCH(true, true); else KT_LEAN_LAUNCH(true, false); }
+        else { if (nt) KT_LEAN_LAUNCH(false, true); else KT_LEAN_LAUNCH(false, false); }
+#undef KT_LEAN_LAUNCH
     } else if (updated_dev) {
         if (buf) hipLaunchKernelGGL((kt_tsdf23_kernel<true, true>), g, b, 0, c->stream, a);
         else hipLaunchKernelGGL((kt_tsdf23_kernel<true, false>), g, b, 0, c->stream, a);
