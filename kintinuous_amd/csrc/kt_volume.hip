@@ -248,6 +248,9 @@ __device__ __forceinline__ void kt_clip_halfline(float alpha, float beta, float&
 #ifndef KT_TSDF_UNROLL
 #define KT_TSDF_UNROLL 4
 #endif
+#ifndef KT_TSDF_WPB
+#define KT_TSDF_WPB 4         // waves per workgroup of the lean voxel kernel (its z table is per workgroup)
+#endif
 #ifndef KT_TSDF_WAVES
 #define KT_TSDF_WAVES 8192
 #endif
@@ -1353,10 +1356,10 @@ __device__ unsigned long long kt_tsdf_tl[KT_TSDF_WAVES * KT_TL_WORDS];
 // FP: the pose and the parked flag come from the device (kt_frame_params, the tracker) -- a compile-time property so that the start-up
 // has no pointer test in front of its loads.
 template <bool COUNT, bool NT, bool FP>
-__global__ __launch_bounds__(256, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_kernel(const kt_tsdf_lean_args a_in)
+__global__ __launch_bounds__(64 * KT_TSDF_WPB, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_kernel(const kt_tsdf_lean_args a_in)
 {
 #ifdef KT_TSDF_TIMELINE
-    unsigned long long* tl = &kt_tsdf_tl[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * KT_TL_WORDS];
+    unsigned long long* tl = &kt_tsdf_tl[(size_t)(blockIdx.x * KT_TSDF_WPB + (threadIdx.x >> 6)) * KT_TL_WORDS];
     int tl_n = 0;
     if ((threadIdx.x & 63) == 0) { unsigned int hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); tl[tl_n++] = hw; for (int q = 1; q < KT_TL_WORDS; ++q) tl[q] = 0; }
     KT_TL(1);
@@ -1394,22 +1397,23 @@ __global__ __launch_bounds__(256, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_k
     // made the flag's round trip the first of five.
     const uint2 t_part = *(const uint2*)&a.task_count[1 + xcd];   // (4-byte aligned: two adjacent words, one request)
     const unsigned int t_begin = t_part.x, t_end = parked != 0 ? t_part.x : t_part.y;
-    constexpr int KT_TAB_PASSES = (1023 + KT_TSDF_UNROLL + 255) / 256;   // N < 1024 on this path
+    constexpr int KT_TB = 64 * KT_TSDF_WPB;
+    constexpr int KT_TAB_PASSES = (1023 + KT_TSDF_UNROLL + KT_TB - 1) / KT_TB;   // N < 1024 on this path
     float tab_vgz[KT_TAB_PASSES], tab_zs[KT_TAB_PASSES];
 #pragma unroll
     for (int i = 0; i < KT_TAB_PASSES; ++i) {
-        const int z = (int)threadIdx.x + 256 * i;
+        const int z = (int)threadIdx.x + KT_TB * i;
         const int zz = min(z, N - 1);   // entries past the volume are only ever read by masked-off steps; they repeat the last one
         tab_vgz[i] = a.vgz[zz]; tab_zs[i] = a.zs[zz];
     }
-    const unsigned int t_stride = (gridDim.x >> 3) * 4u;
-    unsigned int t = t_begin + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);
+    const unsigned int t_stride = (gridDim.x >> 3) * (unsigned int)KT_TSDF_WPB;
+    unsigned int t = t_begin + (blockIdx.x >> 3) * (unsigned int)KT_TSDF_WPB + (threadIdx.x >> 6);
     unsigned int task_word = t < t_end ? a.tasks[t] : 0u;
     const unsigned int plane = (unsigned int)N * (unsigned int)N;
-    s_rcp[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
+    for (int w = (int)threadIdx.x; w < 256; w += KT_TB) s_rcp[w] = 1.0f / (float)(w + 1);
 #pragma unroll
     for (int i = 0; i < KT_TAB_PASSES; ++i) {
-        const int z = (int)threadIdx.x + 256 * i;
+        const int z = (int)threadIdx.x + KT_TB * i;
         if (z < N + KT_TSDF_UNROLL) {
             const int zz = min(z, N - 1);
             int sz = zz + a.wz; if (sz >= N) sz -= N;
@@ -1740,7 +1744,8 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
         // dense view (the rule that picks the 32 x 2 wave-column shape): the volume words stream, non-temporal; KT_TSDF_NT=0|1 overrides
         static const int nt_env = []() { const char* e = getenv("KT_TSDF_NT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
         const bool nt = nt_env >= 0 ? nt_env != 0 : a.wcl == 5;
-#define KT_LEAN_LAUNCH(C, T) do { if (l.fp) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, true>), g, b, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, false>), g, b, lds, c->stream, l); } while (0)
+        const dim3 lb(64 * KT_TSDF_WPB), lg(KT_TSDF_WAVES / KT_TSDF_WPB);
+#define KT_LEAN_LAUNCH(C, T) do { if (l.fp) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, true>), lg, lb, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, false>), lg, lb, lds, c->stream, l); } while (0)
         if (updated_dev) { if (nt) KT_LEAN_LAUNCH(true, true); else KT_LEAN_LAUNCH(true, false); }
         else { if (nt) KT_LEAN_LAUNCH(false, true); else KT_LEAN_LAUNCH(false, false); }
 #undef KT_LEAN_LAUNCH

@@ -48,10 +48,16 @@ for b in range(4):
         print("batch %d:" % (b + 1), int(ok.sum()), "waves,", pct((ht[ok, 3 + b] - ht[ok, 2 + b]) * 0.01))
 last = np.array([r[r > 0][-1] for r in st])
 print("wave exit:", pct(us(last)))
+ent = st[:, 0]
+q = np.percentile(ent[has_task], [25, 50, 75])
+for lo, hi, name in [(-1, q[0], "first"), (q[0], q[1], "second"), (q[1], q[2], "third"), (q[2], 1 << 62, "last")]:
+    sel = has_task & (ent > lo) & (ent <= hi)
+    print("waves of the %s entry quartile: entry %.2f-%.2f us, exit" % (name, us(ent[sel].min()), us(ent[sel].max())), pct(us(last[sel])))
 print("wave lifetime (with a task):", pct((last[has_task] - st[has_task, 0]) * 0.01), "mean %.2f" % ((last[has_task] - st[has_task, 0]).mean() * 0.01))
 # HW_ID (gfx9): wave_id [3:0], simd_id [5:4], pipe [7:6], cu_id [11:8], sh_id [12], se_id [15:13] (gfx950: se 3 bits?), ... ; group by the bits that identify a SIMD
 simd_key = hw & 0xFFF0 | ((hw >> 16) & 0xF) << 16   # everything but the wave slot (best effort; XCC id lives elsewhere: waves of a workgroup share it)
-xcd = (np.arange(W) // 4) % 8                       # workgroup -> XCD round robin
+WPB = int(os.environ.get('KT_TL_WPB', '4'))
+xcd = (np.arange(W) // WPB) % 8                     # workgroup -> XCD round robin
 key = simd_key.astype(np.int64) * 8 + xcd
 fin = {}
 for k_, e in zip(key, last):
