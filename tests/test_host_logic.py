@@ -228,3 +228,22 @@ def test_eigen_adapters_type_check(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "eigen adapters ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_thread_object_protocol(tmp_path):
+    """host/ThreadObject.h, ThreadMutexObject.h and ThreadDataPack.h without a GPU: start / running / stop / restart, a loop that ends by
+    itself, a consumer woken by the tracker's signal, the end-of-run hand-shake (tests/stubs/thread_object_check.cpp).  The shell's
+    headers call into the C-ABI, so the program links libkt_hip.so -- it never creates a context."""
+    import subprocess
+    from kintinuous_amd import build
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(build.OUT):
+        pytest.skip("libkt_hip.so not built")
+    exe = str(tmp_path / "thread_object_check")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-I", os.path.join(ROOT, "kintinuous_amd", "host"), "-I", ROOT,
+                        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "stubs", "thread_object_check.cpp"), "-o", exe,
+                        "-L", os.path.dirname(build.OUT), "-lkt_hip", "-lz", "-Wl,-rpath," + os.path.dirname(build.OUT), "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "thread object ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
