@@ -291,12 +291,14 @@ __global__ __launch_bounds__(256) void slice_normals(const float* __restrict__ c
     __shared__ float s_sd[4][KT_SLICE_K_MAX];
     __shared__ int s_sj[4][KT_SLICE_K_MAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + wave;
     const int L = (int)prm->leaves;
-    if (q >= L) return;
     const Grid g = prm->g;
     const int gridded = prm->gridded;
     float* cd = s_cd[wave]; int* cj = s_cj[wave]; float* sd = s_sd[wave]; int* sj = s_sj[wave];
+    // one wave per leaf, a bounded grid striding over the leaves: the number of leaves is known on the device only, and a grid sized for
+    // the host's upper bound (the whole extraction buffer in the tracker: 230 k workgroups, nearly all of them empty) is work for the
+    // dispatcher on a stream that runs next to the frame path (advisor, round 3)
+    for (int q = blockIdx.x * 4 + wave; q < L; q += gridDim.x * 4) {
     const float px = cen[(size_t)q * 6], py = cen[(size_t)q * 6 + 1], pz = cen[(size_t)q * 6 + 2];
     const int kk = min(k, L);
     auto dist2 = [&](int j) -> float {
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(256) void slice_normals(const float* __restrict__ c
     if (cnt < 3) {   // NormalEstimation: fewer than 3 neighbours -> NaN normal and curvature
         o.normal_x = o.normal_y = o.normal_z = o.curvature = __builtin_nanf("");
         if (lane == 0) out[q] = o;
-        return;
+        continue;
     }
     // lane t fetches pick t (one round of loads for all of them); the sums then run over the picks in order, every lane alike
     const int jt = sj[min(lane, cnt - 1)];
@@ -439,6 +441,7 @@ __global__ __launch_bounds__(256) void slice_normals(const float* __restrict__ c
     if (cos_theta < 0) { nv[0] *= -1; nv[1] *= -1; nv[2] *= -1; }
     o.normal_x = nv[0]; o.normal_y = nv[1]; o.normal_z = nv[2];
     if (lane == 0) out[q] = o;
+    }
 }
 
 }  // namespace
@@ -523,8 +526,8 @@ extern "C" int kt_slice_process_device(kt_slice_ws* w, const kt_point_xyzrgb* po
     tb = w->tmp_bytes;
     KT_HIP(rocprim::inclusive_scan(w->tmp, tb, w->head, w->leafof, (size_t)nm, rocprim::plus<unsigned int>(), st));
     hipLaunchKernelGGL(slice_centroids, dim3(nb), dim3(256), 0, st, points_dev, w->keys[1], w->src[1], w->head, w->leafof, nm, w->cen, w->leaf_key, w->leaf_src, w->prm);
-    // NormalEstimation (kNN) + concatenateFields: one wave per leaf, the grid sized for the upper bound
-    hipLaunchKernelGGL(slice_normals, dim3(kt_div_up(nm, 4)), dim3(256), 0, st, w->cen, w->leaf_key, w->leaf_src, w->prm, k, points_dev, w->out);
+    // NormalEstimation (kNN) + concatenateFields: one wave per leaf, a bounded grid striding over the leaves
+    hipLaunchKernelGGL(slice_normals, dim3(kt_div_up(nm, 4) < 4096 ? kt_div_up(nm, 4) : 4096), dim3(256), 0, st, w->cen, w->leaf_key, w->leaf_src, w->prm, k, points_dev, w->out);
     KT_LAUNCH_CHECK();
     KT_HIP(hipMemcpyAsync(w->leaves_host, &w->prm->leaves, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     return KT_OK;
