@@ -957,6 +957,9 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
         kt_solve_and_update_wave(ar.state, sys, pose_d, pose_f, tail_work);
         __builtin_amdgcn_wave_barrier();
         if (threadIdx.x == 0) kt_compute_krk(pose_d, ar.next_k, ar.state->krkinv, ar.state->kt);
+#ifdef KT_ICP_TIMING
+        if (threadIdx.x == 0) { const unsigned long long t7 = wall_clock64(); for (int q = 0; q < 7; ++q) ar.state->icp29[q] = (float)(kt_ts[q + 0] - kt_ts[0]); ar.state->icp29[7] = (float)(t7 - kt_ts[0]); }
+#endif
     }
 }
 
