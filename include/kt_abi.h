@@ -325,6 +325,9 @@ const char* kt_debug_tsdf_kernel(void);   /* name of the voxel kernel the next N
 /* test hook: the voxel kernel's division shortcut (table reciprocal + one correction) against the IEEE division for every finite float
  * numerator and every divisor 1..256: out_host = {mismatches, float bits of the largest |numerator| among them, mismatches at |n| >= 2^-100} */
 int kt_debug_div_check(kt_ctx* ctx, unsigned int out_host[3]);
+/* analysis hook (builds with -DKT_ICP_TIMING only; otherwise KT_ERR_STATE): per workgroup of the last reduction launch, 100 MHz stamps:
+ * [0, 256) pixel loop entered, [256, 512) loop done, [512, 768) granules published */
+int kt_debug_icp_wg_times(kt_ctx* ctx, unsigned long long* out768_host);
 /* analysis hook (builds with -DKT_TSDF_TIMELINE only; otherwise a negative status): per wave of the last voxel-kernel launch
  * {HW_ID, 100 MHz stamps: entry, tables ready, then per task: set up, after every batch; exit}; returns the words per wave */
 int kt_debug_tsdf_timeline(kt_ctx* ctx, unsigned long long* out_host, int max_words);

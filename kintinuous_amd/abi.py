@@ -143,6 +143,7 @@ _PROTOS = {
     "kt_debug_tsdf_lean": (_i, [_i]),
     "kt_debug_tsdf_kernel": (C.c_char_p, []),
     "kt_debug_div_check": (_i, [_vp, C.POINTER(C.c_uint)]),
+    "kt_debug_icp_wg_times": (_i, [_vp, C.POINTER(C.c_ulonglong)]),
     "kt_debug_tsdf_timeline": (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),
     "kt_debug_solve_check": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     "kt_debug_unpack_table": (_i, [_vp, _pf]),

@@ -63,6 +63,12 @@ __device__ __constant__ unsigned char KT_PB[28] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3,
 // granules stored; RowFn(i, row[7]) -> found computes one pixel.  kt_reduce29_sweep: the last workgroup gathers the grid sums into
 // total[0..28] (LDS).  kt_reduce29 = both, returning true (workgroup-uniformly) in the sweeping workgroup.
 struct kt_no_prefetch { __device__ __forceinline__ void operator()() const {} };
+// Place of workgroup wg's (= CUDA block wg / 4, warp wg % 4) granule of product `comp`: the four warps of a block are 64 granules apart,
+// so that the sweeping wave's q-th load -- lane b takes warp q of block b -- reads 512 CONTIGUOUS bytes (four full lines).  Round 3 kept
+// a block's four granules adjacent: each of the four loads then touched all sixteen lines of the product, and the sweep -- agent-scope
+// loads go past the L2 -- is paid per line request, not per byte (profiles/r04_experiments.md: one set 2.2 us, two sets 4.0 us, with
+// every granule already published when the sweep began).
+__device__ __forceinline__ int kt_granule_index(int comp, int wg) { return comp * KT_RED_BLOCKS + (wg & 3) * (KT_RED_BLOCKS / 4) + (wg >> 2); }
 typedef float kt_rows_t[8][32];   // LDS staging rows[k][component][vt], KT_KBATCH of them
 
 template <typename RowFn>
@@ -118,7 +124,7 @@ __device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsi
     // warp tree: the 32 lanes of a half-wave hold product `comp` of the 32 virtual threads of this CUDA warp
     const float wsum = kt_warp32_sum(acc);
     if (comp < 29 && vt == 0)
-        __hip_atomic_store(&granules[comp * KT_RED_BLOCKS + blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum),
+        __hip_atomic_store(&granules[kt_granule_index(comp, blockIdx.x)], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     KT_TS(2);
 }
@@ -185,9 +191,9 @@ __device__ __forceinline__ void kt_reduce29_publish2(const RowFnA& fa, const Row
     KT_TS(1);
     const float wsum_a = kt_warp32_sum(acc_a), wsum_b = kt_warp32_sum(acc_b);
     if (comp < 29 && vt == 0) {
-        __hip_atomic_store(&granules_a[comp * KT_RED_BLOCKS + blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum_a),
+        __hip_atomic_store(&granules_a[kt_granule_index(comp, blockIdx.x)], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum_a),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&granules_b[comp * KT_RED_BLOCKS + blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum_b),
+        __hip_atomic_store(&granules_b[kt_granule_index(comp, blockIdx.x)], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum_b),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     KT_TS(2);
@@ -208,7 +214,7 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(const unsigned long long* co
     // lanes 4..31 zero; offsets 16, 8, 4 add zeros, offset 2 gives s0+s2 and s1+s3, offset 1 adds them.  Then
     // reduceSum<<<1, 512>>> (reduce.cu:166-184): threads 0..63 hold 0 + in[b]; warps 0 and 1 fold with the 32-lane tree, the rest
     // is zero; the final first-warp tree reduces to s0 + s1.  Wave w handles products w and w + 16; lane = CUDA block b, whose 4
-    // warp sums are the granules 4b..4b+3.  Each wave re-reads its granules until all of them carry this launch's epoch (bounded:
+    // warp sums are the granules kt_granule_index(c, 4b + q), q = 0..3: 64 granules apart, so that load q of a wave is one contiguous run.  Each wave re-reads its granules until all of them carry this launch's epoch (bounded:
     // a hand-off that never completes raises slot 31 of total[], which the callers report as an error).
     {
         const int w = tid >> 6, lane = tid & 63;
@@ -221,9 +227,9 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(const unsigned long long* co
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int c = min(w + 16 * r, 28);   // waves 13..15 re-read product 28 in their second slot (result unused)
-                    const unsigned long long* pp = &granules[s][c * KT_RED_BLOCKS + 4 * lane];
+                    const unsigned long long* pp = &granules[s][c * KT_RED_BLOCKS + lane];   // kt_granule_index(c, 4 lane + q) = pp + 64 q
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) g[s][r][q] = __hip_atomic_load(pp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int q = 0; q < 4; ++q) g[s][r][q] = __hip_atomic_load(pp + q * (KT_RED_BLOCKS / 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             ok = true;
 #pragma unroll
@@ -1082,4 +1088,19 @@ extern "C" int kt_debug_solve_check(kt_ctx* c, int n, const void* cases_host, vo
     (void)hipFree(out);
     if (status != KT_OK) kt_set_error("kt_debug_solve_check: HIP error");
     return status;
+}
+
+// analysis hook (builds with -DKT_ICP_TIMING): when every workgroup of the LAST reduction launch entered its pixel loop, left it and had
+// published its granules (100 MHz ticks; scripts/icp_timing.py)
+extern "C" int kt_debug_icp_wg_times(kt_ctx* c, unsigned long long* out768_host)
+{
+    KT_ARG(c && out768_host);
+#ifdef KT_ICP_TIMING
+    KT_HIP(hipStreamSynchronize(c->stream));
+    KT_HIP(hipMemcpyFromSymbol(out768_host, HIP_SYMBOL(kt_wg_ts), sizeof(unsigned long long) * 768));
+    return KT_OK;
+#else
+    kt_set_error("kt_debug_icp_wg_times: the library was not built with -DKT_ICP_TIMING");
+    return KT_ERR_STATE;
+#endif
 }

@@ -279,8 +279,9 @@ __device__ __forceinline__ void kt_ldlt_solve6_hoisted(double* sys, double (&x)[
 
 // opt-in timing probes of the reduction tail (build with KT_EXTRA_FLAGS=-DKT_ICP_TIMING; scripts/icp_timing.py)
 #ifdef KT_ICP_TIMING
-#define KT_TS(i) do { if (threadIdx.x == 0) kt_ts[i] = wall_clock64(); } while (0)
+#define KT_TS(i) do { if (threadIdx.x == 0) { kt_ts[i] = wall_clock64(); if ((i) <= 2) kt_wg_ts[(i) * 256 + (blockIdx.x & 255)] = kt_ts[i]; } } while (0)
 __shared__ unsigned long long kt_ts[8];
+__device__ unsigned long long kt_wg_ts[3 * 256];   // per workgroup of the last reduction launch: loop entered, loop done, granules published (100 MHz ticks)
 #else
 #define KT_TS(i) do {} while (0)
 #endif
