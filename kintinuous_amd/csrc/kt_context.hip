@@ -51,7 +51,7 @@ int kt_ctx_create(int device, kt_ctx** out)
     KT_HIP(hipMalloc((void**)&c->red_partials, sizeof(double) * 32 * c->red_max_blocks));
     KT_HIP(hipMalloc((void**)&c->red_out, sizeof(float) * 64));
     KT_HIP(hipMalloc((void**)&c->counters, sizeof(unsigned int) * 16));
-    KT_HIP(hipMemsetAsync(c->red_partials, 0, sizeof(double) * 32 * c->red_max_blocks, c->stream));
+    KT_HIP(hipMemsetAsync(c->red_partials, 0xff, sizeof(double) * 32 * c->red_max_blocks, c->stream));   // the reduction granules' sentinel (kt_track.hip)
     KT_HIP(hipMemsetAsync(c->counters, 0, sizeof(unsigned int) * 16, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
     KT_HIP(hipHostMalloc((void**)&c->red_out_host, sizeof(float) * 64, hipHostMallocDefault));

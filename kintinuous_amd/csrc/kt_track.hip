@@ -19,11 +19,10 @@
 //            compiled by clang with -ffp-contract=fast, pins that);
 //   tree:    lanes are laid out c-major, so each 32-lane half-wave holds one product of the 32 vts = one CUDA warp:
 //            ds_swizzle(xor 16) + DPP row_shl 8/4/2/1 reproduces warpReduceSum;
-//   hand-off: the data is the flag (cdna_hip_programming.md G16 form R2): each warp sum goes out as ONE aligned 8-byte
-//            {epoch, value} granule, stored write-through at agent scope; the last workgroup of the grid sweeps the 29 x 256
-//            granules with agent-scope loads until every tag carries this launch's epoch, folds blocks and the final
-//            tree and, in the device-resident path, solves the 6x6 system and updates the pose.  No ticket, no fence,
-//            no zeroing between launches (epochs never repeat within a context; the buffer is zeroed at creation).
+//   hand-off: the data is the flag (cdna_hip_programming.md G16 form R2): two warp sums go out as ONE aligned 8-byte granule, stored
+//            write-through at agent scope; the last workgroup of the grid sweeps the 15 x 256 granules with agent-scope loads until
+//            none of them is the sentinel, hands them back as sentinels, folds blocks and the final tree and, in the
+//            device-resident path, solves the 6x6 system and updates the pose.  No ticket, no fence, no epoch.
 #include "kt_internal.hpp"
 
 #include <string.h>
@@ -63,17 +62,31 @@ __device__ __constant__ unsigned char KT_PB[28] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3,
 // granules stored; RowFn(i, row[7]) -> found computes one pixel.  kt_reduce29_sweep: the last workgroup gathers the grid sums into
 // total[0..28] (LDS).  kt_reduce29 = both, returning true (workgroup-uniformly) in the sweeping workgroup.
 struct kt_no_prefetch { __device__ __forceinline__ void operator()() const {} };
-// Place of workgroup wg's (= CUDA block wg / 4, warp wg % 4) granule of product `comp`: the four warps of a block are 64 granules apart,
-// so that the sweeping wave's q-th load -- lane b takes warp q of block b -- reads 512 CONTIGUOUS bytes (four full lines).  Round 3 kept
-// a block's four granules adjacent: each of the four loads then touched all sixteen lines of the product, and the sweep -- agent-scope
-// loads go past the L2 -- is paid per line request, not per byte (profiles/r04_experiments.md: one set 2.2 us, two sets 4.0 us, with
-// every granule already published when the sweep began).
-__device__ __forceinline__ int kt_granule_index(int comp, int wg) { return comp * KT_RED_BLOCKS + (wg & 3) * (KT_RED_BLOCKS / 4) + (wg >> 2); }
+// Hand-off granules (round 4, third form).  ONE aligned 8-byte word carries TWO of a workgroup's 29 warp sums -- products 2p and 2p + 1,
+// which the two half-waves of wave p hold -- and "the data is the flag": a granule is valid when it is not the SENTINEL (all ones: two
+// NaNs of a payload no arithmetic produces; a publisher that did hold 0xffffffff stores 0xfffffffe).  The sweeping wave writes the
+// sentinel back into every granule it has consumed; the next launch that publishes into the buffer is behind this one on the stream,
+// so the kernel boundary orders the two.  (Rounds 2-3 tagged every 4-byte sum with a 4-byte epoch: twice the lines for the sweep to
+// fetch, and the sweep -- agent-scope loads go past the L2, one compute unit issues all of them -- is paid per LINE REQUEST:
+// profiles/r04_experiments.md.)  Place of workgroup wg's (= CUDA block wg / 4, warp wg % 4) granule of pair p: the four warps of a block
+// are 64 granules apart, so that the sweeping wave's q-th load -- lane b takes warp q of block b -- reads 512 contiguous bytes.
+#define KT_RED_PAIRS 15
+#define KT_GRANULE_SENTINEL 0xffffffffffffffffull
+__device__ __forceinline__ int kt_granule_index(int pair, int wg) { return pair * KT_RED_BLOCKS + (wg & 3) * (KT_RED_BLOCKS / 4) + (wg >> 2); }
+// lane 0 of every wave p < 15 publishes {sum of product 2p (lanes 0..31), sum of product 2p + 1 (lanes 32..63)}
+__device__ __forceinline__ void kt_publish_pair(unsigned long long* __restrict__ granules, float wsum)
+{
+    unsigned int lo = __float_as_uint(wsum), hi = (unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(wsum), 32);
+    lo = lo == 0xffffffffu ? 0xfffffffeu : lo;
+    const int pair = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0 && pair < KT_RED_PAIRS)
+        __hip_atomic_store(&granules[kt_granule_index(pair, blockIdx.x)], ((unsigned long long)hi << 32) | (unsigned long long)lo, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
 typedef float kt_rows_t[8][32];   // LDS staging rows[k][component][vt], KT_KBATCH of them
 
 template <typename RowFn>
-__device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsigned long long* __restrict__ granules, unsigned int epoch,
-                                                    kt_rows_t* rows)
+__device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsigned long long* __restrict__ granules, kt_rows_t* rows)
 {
     KT_TS(0);
     const int tid = threadIdx.x;
@@ -122,10 +135,8 @@ __device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsi
     }
     KT_TS(1);
     // warp tree: the 32 lanes of a half-wave hold product `comp` of the 32 virtual threads of this CUDA warp
-    const float wsum = kt_warp32_sum(acc);
-    if (comp < 29 && vt == 0)
-        __hip_atomic_store(&granules[kt_granule_index(comp, blockIdx.x)], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float wsum = kt_warp32_sum(acc);   // (threads of a product past the 29th hold 0)
+    kt_publish_pair(granules, wsum);
     KT_TS(2);
 }
 
@@ -134,8 +145,7 @@ __device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsi
 // kt_reduce29_publish calls; only the waiting is shared.
 template <typename RowFnA, typename RowFnB>
 __device__ __forceinline__ void kt_reduce29_publish2(const RowFnA& fa, const RowFnB& fb, int n, unsigned long long* __restrict__ granules_a,
-                                                     unsigned long long* __restrict__ granules_b, unsigned int epoch, kt_rows_t* rows_a,
-                                                     kt_rows_t* rows_b)
+                                                     unsigned long long* __restrict__ granules_b, kt_rows_t* rows_a, kt_rows_t* rows_b)
 {
     KT_TS(0);
     const int tid = threadIdx.x;
@@ -190,20 +200,15 @@ __device__ __forceinline__ void kt_reduce29_publish2(const RowFnA& fa, const Row
     }
     KT_TS(1);
     const float wsum_a = kt_warp32_sum(acc_a), wsum_b = kt_warp32_sum(acc_b);
-    if (comp < 29 && vt == 0) {
-        __hip_atomic_store(&granules_a[kt_granule_index(comp, blockIdx.x)], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum_a),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&granules_b[kt_granule_index(comp, blockIdx.x)], ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(wsum_b),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    kt_publish_pair(granules_a, wsum_a);
+    kt_publish_pair(granules_b, wsum_b);
     KT_TS(2);
 }
 
-// NS reductions published by the same launch (same epoch) are swept together: every wave issues the loads of all its granules --
-// 2 products x 4 warp sums x NS sets -- before it looks at any of them, so the sweep costs one memory round trip, not one per set.
+// NS reductions published by the same launch are swept together: every wave issues the loads of all its granules -- 4 warp pairs x NS
+// sets -- before it looks at any of them, so the sweep costs one memory round trip, not one per set.
 template <int NS>
-__device__ __forceinline__ void kt_reduce29_sweep_n(const unsigned long long* const (&granules)[NS], unsigned int epoch,
-                                                    float* const (&total)[NS])
+__device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&granules)[NS], float* const (&total)[NS])
 {
     const int tid = threadIdx.x;
     KT_TS(3);
@@ -213,51 +218,56 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(const unsigned long long* co
     // The sweeping workgroup.  blockReduceSum second stage (reduce.cu:131-164) per CUDA block b: lanes 0..3 hold the warp sums,
     // lanes 4..31 zero; offsets 16, 8, 4 add zeros, offset 2 gives s0+s2 and s1+s3, offset 1 adds them.  Then
     // reduceSum<<<1, 512>>> (reduce.cu:166-184): threads 0..63 hold 0 + in[b]; warps 0 and 1 fold with the 32-lane tree, the rest
-    // is zero; the final first-warp tree reduces to s0 + s1.  Wave w handles products w and w + 16; lane = CUDA block b, whose 4
-    // warp sums are the granules kt_granule_index(c, 4b + q), q = 0..3: 64 granules apart, so that load q of a wave is one contiguous run.  Each wave re-reads its granules until all of them carry this launch's epoch (bounded:
-    // a hand-off that never completes raises slot 31 of total[], which the callers report as an error).
+    // is zero; the final first-warp tree reduces to s0 + s1.  Wave w < 15 handles the pair of products (2w, 2w + 1); lane = CUDA block b,
+    // whose 4 warp pairs are the granules kt_granule_index(w, 4b + q), q = 0..3: 64 granules apart, so that load q of a wave is one
+    // contiguous run.  Each wave re-reads its granules until none of them is the sentinel (bounded: a hand-off that never completes
+    // raises slot 31 of total[], which the callers report as an error), then hands them back as sentinels for the next launch.
     {
         const int w = tid >> 6, lane = tid & 63;
-        unsigned long long g[NS][2][4];
-        bool ok;
-        unsigned int spins = 0;
-        for (;;) {
+        if (w < KT_RED_PAIRS) {   // (wave-uniform)
+            unsigned long long g[NS][4];
+            bool ok;
+            unsigned int spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const unsigned long long* pp = &granules[s][w * KT_RED_BLOCKS + lane];   // kt_granule_index(w, 4 lane + q) = pp + 64 q
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[s][q] = __hip_atomic_load(pp + q * (KT_RED_BLOCKS / 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                ok = true;
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ok = ok && g[s][q] != KT_GRANULE_SENTINEL;
+                if (__all(ok) || ++spins > (1u << 22)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const bool all_ok = __all(ok);
+            if (all_ok) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        __hip_atomic_store(&granules[s][w * KT_RED_BLOCKS + lane + q * (KT_RED_BLOCKS / 4)], KT_GRANULE_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const int c = min(w + 16 * r, 28);   // waves 13..15 re-read product 28 in their second slot (result unused)
-                    const unsigned long long* pp = &granules[s][c * KT_RED_BLOCKS + lane];   // kt_granule_index(c, 4 lane + q) = pp + 64 q
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[s][r][q] = __hip_atomic_load(pp + q * (KT_RED_BLOCKS / 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int c = 2 * w + r;
+                    const float s0 = __uint_as_float((unsigned int)(g[s][0] >> (32 * r))) + 0.0f;
+                    const float s1 = __uint_as_float((unsigned int)(g[s][1] >> (32 * r))) + 0.0f;
+                    const float s2 = __uint_as_float((unsigned int)(g[s][2] >> (32 * r))) + 0.0f;
+                    const float s3 = __uint_as_float((unsigned int)(g[s][3] >> (32 * r))) + 0.0f;
+                    const float blk = (s0 + s2) + (s1 + s3);
+                    const float tr = kt_warp32_sum(0.0f + blk);
+                    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tr), 0));
+                    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tr), 32));
+                    if (lane == 0 && c < 29) total[s][c] = (lo + 0.0f) + (hi + 0.0f);
                 }
-            ok = true;
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ok = ok && (unsigned int)(g[s][r][q] >> 32) == epoch;
-            if (__all(ok) || ++spins > (1u << 22)) break;
-            __builtin_amdgcn_s_sleep(1);
+            if (lane == 0 && !all_ok) atomicOr(&timed_out, 1u);
         }
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int c = w + 16 * r;
-                const float s0 = __uint_as_float((unsigned int)g[s][r][0]) + 0.0f;
-                const float s1 = __uint_as_float((unsigned int)g[s][r][1]) + 0.0f;
-                const float s2 = __uint_as_float((unsigned int)g[s][r][2]) + 0.0f;
-                const float s3 = __uint_as_float((unsigned int)g[s][r][3]) + 0.0f;
-                const float blk = (s0 + s2) + (s1 + s3);
-                const float tr = kt_warp32_sum(0.0f + blk);
-                const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tr), 0));
-                const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tr), 32));
-                if (lane == 0 && c < 29) total[s][c] = (lo + 0.0f) + (hi + 0.0f);
-            }
-        const bool all_ok = __all(ok);
-        if (lane == 0 && !all_ok) atomicOr(&timed_out, 1u);
     }
     __syncthreads();
     if (tid == 0) total[NS - 1][KT_RED_SLOTS - 1] = timed_out ? 1.0f : 0.0f;  // slot 31: the hand-off never completed (reported by the callers)
@@ -265,11 +275,11 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(const unsigned long long* co
     KT_TS(4);
 }
 
-__device__ __forceinline__ void kt_reduce29_sweep(const unsigned long long* __restrict__ granules, unsigned int epoch, float (&total)[KT_RED_SLOTS])
+__device__ __forceinline__ void kt_reduce29_sweep(unsigned long long* __restrict__ granules, float (&total)[KT_RED_SLOTS])
 {
-    const unsigned long long* const gs[1] = {granules};
+    unsigned long long* const gs[1] = {granules};
     float* const ts[1] = {total};
-    kt_reduce29_sweep_n<1>(gs, epoch, ts);
+    kt_reduce29_sweep_n<1>(gs, ts);
 }
 
 // `pre` runs in the sweeping workgroup between its publish and the sweep: the place to issue loads the epilogue will need
@@ -282,22 +292,23 @@ __device__ __forceinline__ bool kt_red_publishes() { return true; }
 __device__ __forceinline__ bool kt_red_sweeps() { return blockIdx.x == KT_RED_GRID - 1; }
 
 template <typename RowFn, typename PreFn = kt_no_prefetch>
-__device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, unsigned long long* __restrict__ granules, unsigned int epoch,
-                                            float (&total)[KT_RED_SLOTS], const PreFn& pre = PreFn())
+__device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, unsigned long long* __restrict__ granules, float (&total)[KT_RED_SLOTS],
+                                            const PreFn& pre = PreFn())
 {
     __shared__ kt_rows_t rows[KT_KBATCH];
-    if (kt_red_publishes()) kt_reduce29_publish(fn, n, granules, epoch, rows);
+    if (kt_red_publishes()) kt_reduce29_publish(fn, n, granules, rows);
     if (!kt_red_sweeps()) return false;
     pre();
-    kt_reduce29_sweep(granules, epoch, total);
+    kt_reduce29_sweep(granules, total);
     return true;
 }
 
-// epoch of the next reduction launch on this context: never 0 (the zeroed buffer's tag), never repeated between two zeroings
+// epoch of the next launch on this context (the host form of the residual launch still tags its granules with it): never 0, never
+// repeated between two refills of the buffer (all ones: the reduction granules' sentinel, and a tag no epoch takes for 2^32 launches)
 static unsigned int kt_next_epoch(kt_ctx* c)
 {
     if (++c->red_epoch == 0) {
-        (void)hipMemsetAsync(c->red_partials, 0, sizeof(double) * 32 * c->red_max_blocks, c->stream);
+        (void)hipMemsetAsync(c->red_partials, 0xff, sizeof(double) * 32 * c->red_max_blocks, c->stream);
         c->red_epoch = 1;
     }
     return c->red_epoch;
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
     kt_pose_stage ps;
     const bool solve_here = a.mode == KT_MODE_ICP_SOLVE;
     auto pre = [&]() { if (solve_here && !a.first) ps.fetch(a.state); };
-    if (!kt_reduce29(fn, a.cols * a.rows, a.granules, a.epoch, total, pre)) return;
+    if (!kt_reduce29(fn, a.cols * a.rows, a.granules, total, pre)) return;
     __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES], tail_work[KT_TAIL_WORK_DOUBLES];
     __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
     if (solve_here) {   // ICPOdometry.cpp:127-128: the float sums widened into the double system, one element per lane
@@ -894,7 +905,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_arg
     __shared__ float total[KT_RED_SLOTS];
     kt_pose_stage ps;
     auto pre = [&]() { if (a.mode != KT_MODE_HOST) ps.fetch(a.state); };
-    if (!kt_reduce29(fn, a.cols * a.rows, a.granules, a.epoch, total, pre)) return;
+    if (!kt_reduce29(fn, a.cols * a.rows, a.granules, total, pre)) return;
     if (a.mode == KT_MODE_HOST) {
         if (threadIdx.x < KT_RED_SLOTS && (threadIdx.x < 29 || threadIdx.x == KT_RED_SLOTS - 1)) a.out29[threadIdx.x] = total[threadIdx.x];
     } else {
@@ -937,14 +948,14 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
     const kt_rgb_row fr{ar, kt_residual_sigma(ar.res_partials, ar.res_blocks, res_count, res_sigma)};
     __shared__ kt_rows_t rows_icp[KT_KBATCH], rows_rgb[KT_KBATCH];   // 2 x 40 KB
     __shared__ float total_icp[KT_RED_SLOTS], total[KT_RED_SLOTS];
-    if (kt_red_publishes()) kt_reduce29_publish2(fi, fr, ai.cols * ai.rows, ai.granules, ar.granules, ar.epoch, rows_icp, rows_rgb);
+    if (kt_red_publishes()) kt_reduce29_publish2(fi, fr, ai.cols * ai.rows, ai.granules, ar.granules, rows_icp, rows_rgb);
     if (!kt_red_sweeps()) return;
     kt_pose_stage ps;
     ps.fetch(ar.state);
     {
-        const unsigned long long* const gs[2] = {ai.granules, ar.granules};
+        unsigned long long* const gs[2] = {ai.granules, ar.granules};
         float* const ts[2] = {total_icp, total};   // the time-out flag lands in total[31]
-        kt_reduce29_sweep_n<2>(gs, ar.epoch, ts);
+        kt_reduce29_sweep_n<2>(gs, ts);
     }
     __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES], tail_work[KT_TAIL_WORK_DOUBLES];
     __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
