@@ -23,7 +23,7 @@ struct kt_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
-    // scratch for reductions: hand-off granules (u64[32][256] {epoch, value}) + final (float[32])
+    // scratch for reductions: hand-off granules (two sets of u64[15][256] {sum 2p, sum 2p + 1}, all ones = empty; kt_track.hip) + final (float[32])
     double* red_partials;
     float* red_out;        // device, 32 floats
     float* red_out_host;   // pinned host mirror
@@ -32,7 +32,7 @@ struct kt_ctx {
     int red_max_blocks;
     kt_integrate_scratch* integ;   // integrate scratch (pixel records, z tables, intervals, task list), created on first use
     float* bil_lut;                // bilateral tap weights [27][396] (kt_image.hip), built on first use
-    unsigned int red_epoch;  // tag of the last reduction launch (kt_track.hip hand-off granules)
+    unsigned int red_epoch;  // launch counter; the tag of the host-form residual launch's granules (kt_track.hip)
     void* track_state;       // device kt_track_state of kt_icp_track (kt_track.hip), created on first use
     void* slice_ws;          // kt_slice_ws of the host-array kt_slice_process (kt_slice.hip), created on first use
 };
