@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- RGB-D frames/s of the per-frame tracking + fusion hot path on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under torch.distributed.run,
-one rank per GPU.  A "step" is ONE frame through KintinuousTracker::processFrame (pyramid build, 19 ICP Gauss-Newton
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 one rank per GPU under torch.distributed.run -- started by
+the caller (RANK / WORLD_SIZE in the environment; WORLD_SIZE must equal --gpus) or, when the command is run bare, by bench.py itself,
+which re-executes under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (resolve_launch).  A "step" is ONE frame through KintinuousTracker::processFrame (pyramid build, 19 ICP Gauss-Newton
 iterations solved on the device, shift check, TSDF integrate, raycast, predicted-map pyramid) with the frame already
 resident in HBM.  Workload at every N: BASELINE.json configs[1] -- 640x480 synthetic orbit, ICP-only tracking, 512^3
 TSDF -- one independent stream per GPU (seed 1234 + rank), poses gathered once with an RCCL all_gather (weak scaling).
@@ -44,7 +45,10 @@ def stdout_to_stderr():
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs (= ranks = independent streams) of the job; default: WORLD_SIZE, else 1")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="resolve the launch (re-exec under torch.distributed.run if needed), meet the other ranks in the key-value store, print "
+                         "{n_gpus, ranks} on rank 0 and exit: no GPU is touched (tests/test_host_logic.py)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="orbit512", choices=["orbit512", "orbit256", "crabwalk512", "farwall768"])
@@ -73,11 +77,50 @@ from kintinuous_amd.multistream import check_gather, make_comm, make_exchange, p
 SLICE_NAMES = {0: "X+", 1: "X-", 2: "Y+", 3: "Y-", 4: "Z+", 5: "Z-", 7: "FINAL"}   # CloudSlice::Dimension
 
 
+def resolve_launch(gpus, environ):
+    """How `--gpus` and the launcher's environment combine (`--gpus` was parsed and never read, so a bare `bench.py --gpus 8`
+    ran ONE stream).  Returns ("run", rank, local_rank, world) when this process is a rank of the job, or ("exec", world) when it must
+    replace itself by torch.distributed.run with `world` ranks.  A launcher's WORLD_SIZE that disagrees with --gpus is an error: the JSON
+    line's n_gpus must equal --gpus in every launch form."""
+    launched = "WORLD_SIZE" in environ and "RANK" in environ
+    if launched:
+        world = int(environ["WORLD_SIZE"])
+        if gpus is not None and gpus != world:
+            raise SystemExit(f"bench: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
+        return ("run", int(environ["RANK"]), int(environ.get("LOCAL_RANK", environ["RANK"])), world)
+    if gpus is None or gpus == 1:
+        return ("run", 0, 0, 1)
+    if gpus < 1:
+        raise SystemExit(f"bench: --gpus {gpus}")
+    return ("exec", gpus)
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    how = resolve_launch(args.gpus, os.environ)
+    if how[0] == "exec":   # a bare `python bench.py --gpus N`: become the N-rank job the driver's torchrun line would have started
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={how[1]}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execvpe(cmd[0], cmd, env)
+    _, rank, local_rank, world = how
+    if args.launch_check:
+        ex = make_exchange(rank, world)
+        ex.share("built", b"1")
+        top = ex.max("rank", float(rank))
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "highest_rank_seen": int(top), "gpus_flag": args.gpus}))
+        return
     # One communicator per job: the C-ABI's (kt_comm over RCCL) does the pose gather AND the barriers around the timed region; rank 0's
     # communicator id and the max-over-ranks time travel through a key-value store (no torch process group, no second communicator).
     exchange = make_exchange(rank, world)

@@ -148,6 +148,7 @@ _PROTOS = {
     "kt_debug_solve_check": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     "kt_debug_unpack_table": (_i, [_vp, _pf]),
     "kt_debug_rcp_check": (_i, [_vp, C.POINTER(C.c_uint)]),
+    "kt_debug_handoff_fault": (_i, [_vp, _i, _i, C.c_uint, C.POINTER(C.c_uint)]),
     "kt_tracker_num_pr_samples": (_i, [_vp]),
     "kt_tracker_pr_sample": (_i, [_vp, _i, C.POINTER(_u64), _pf, _pf, C.POINTER(C.c_int)]),
     "kt_tracker_slice_pr_id": (_i, [_vp, _i, C.POINTER(C.c_int)]),

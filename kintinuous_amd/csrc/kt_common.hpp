@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "../../include/kt_abi.h"
+#include "kt_debug.h"   // test / analysis hooks (not part of the boundary)
 
 #define KT_DIVISOR 32767                 // internal.h:237
 #define KT_RGB_VIEW_ANGLE_WEIGHT 0.75f   // internal.h:241
@@ -32,6 +33,7 @@ struct kt_ctx {
     int red_max_blocks;
     kt_integrate_scratch* integ;   // integrate scratch (pixel records, z tables, intervals, task list), created on first use
     float* bil_lut;                // bilateral tap weights [27][396] (kt_image.hip), built on first use
+    int fault_skip, fault_count;   // test hook kt_debug_handoff_fault: after fault_skip more ICP reduction launches, fault_count launches lose a publisher
     unsigned int red_epoch;  // launch counter; the tag of the host-form residual launch's granules (kt_track.hip)
     void* track_state;       // device kt_track_state of kt_icp_track (kt_track.hip), created on first use
     void* slice_ws;          // kt_slice_ws of the host-array kt_slice_process (kt_slice.hip), created on first use

@@ -95,6 +95,7 @@ int kt_extract_cloud_slice_async(kt_ctx* c, const int16_t* volume, const float v
                                  size_t output_capacity, const int voxel_wrap[3], const uint8_t* color_volume, int minX, int maxX,
                                  int minY, int maxY, int minZ, int maxZ, int subsample, const int real_voxel_wrap[3], int N,
                                  unsigned int* count_dev);
+int kt_refill_granules(kt_ctx* c);   // kt_track.hip: every hand-off granule back to the sentinel, on the context's stream
 int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
                        const float* vmap_g_prev, const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres,
                        int mode, const kt_track_state* init = nullptr, int keep29 = 0);

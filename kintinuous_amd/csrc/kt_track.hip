@@ -207,6 +207,9 @@ __device__ __forceinline__ void kt_reduce29_publish2(const RowFnA& fa, const Row
 
 // NS reductions published by the same launch are swept together: every wave issues the loads of all its granules -- 4 warp pairs x NS
 // sets -- before it looks at any of them, so the sweep costs one memory round trip, not one per set.
+// bound of the sweep's spin (a test hook lowers it: kt_debug_handoff_fault); read once per sweep, next to the first granule loads
+__device__ unsigned int kt_sweep_spin_limit = 1u << 22;
+
 template <int NS>
 __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&granules)[NS], float* const (&total)[NS])
 {
@@ -228,6 +231,7 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&
             unsigned long long g[NS][4];
             bool ok;
             unsigned int spins = 0;
+            const unsigned int spin_limit = *(volatile const unsigned int*)&kt_sweep_spin_limit;
             for (;;) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -240,7 +244,7 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) ok = ok && g[s][q] != KT_GRANULE_SENTINEL;
-                if (__all(ok) || ++spins > (1u << 22)) break;
+                if (__all(ok) || ++spins > spin_limit) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             const bool all_ok = __all(ok);
@@ -303,12 +307,24 @@ __device__ __forceinline__ bool kt_reduce29(const RowFn& fn, int n, unsigned lon
     return true;
 }
 
-// epoch of the next launch on this context (the host form of the residual launch still tags its granules with it): never 0, never
-// repeated between two refills of the buffer (all ones: the reduction granules' sentinel, and a tag no epoch takes for 2^32 launches)
+// Every granule back to the sentinel, on the context's stream (ordered behind everything enqueued so far).  A sweep that gave up leaves
+// the buffer in an undefined state: it hands nothing back, and the publishers it did not wait for store AFTER it has looked -- values the
+// NEXT launch's sweep could take for its own (advisor, round 4; with the epoch tags of rounds 2-3 a stale granule could not be mistaken).
+// So EVERY path that reports a time-out to its caller refills before the next reduction launch: kt_icp_step / kt_rgb_step /
+// kt_rgb_residual / kt_icp_track here, complete_frame and kt_tracker_reset in kt_tracker.hip (tests/test_gpu_track.py forces one).
+int kt_refill_granules(kt_ctx* c)
+{
+    KT_HIP(hipMemsetAsync(c->red_partials, 0xff, sizeof(double) * 32 * c->red_max_blocks, c->stream));
+    return KT_OK;
+}
+
+// epoch of the next launch on this context (only the host form of the residual launch still tags its granules with it): never 0, never
+// all ones -- the buffer's fill pattern, which a never-written residual granule would otherwise share with launch 2^32 - 1 --, never
+// repeated between two refills of the buffer
 static unsigned int kt_next_epoch(kt_ctx* c)
 {
-    if (++c->red_epoch == 0) {
-        (void)hipMemsetAsync(c->red_partials, 0xff, sizeof(double) * 32 * c->red_max_blocks, c->stream);
+    if (++c->red_epoch >= 0xffffffffu) {
+        (void)kt_refill_granules(c);
         c->red_epoch = 1;
     }
     return c->red_epoch;
@@ -335,7 +351,7 @@ struct kt_icp_args {
     kt_track_state* state;     // nullptr on the host path
     int first;                 // device path, first iteration of a frame: the pose comes from the fields above (== previous pose) and
                                // the epilogue initialises *state (no host-to-device copy of the state per frame)
-    unsigned long long* granules; unsigned int epoch;   // inter-workgroup hand-off (kt_reduce29)
+    unsigned long long* granules; unsigned int fault;   // inter-workgroup hand-off (kt_reduce29); fault: test hook, below
     float* out29;              // host path: 29 floats
     int mode;                  // KT_MODE_*
     int keep29;                // KT_MODE_ICP_SOLVE: also leave the 29 sums in state->icp29 (kt_icp_track's last iteration: the caller's A)
@@ -403,6 +419,7 @@ struct kt_icp_row {
 
 __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_args a)
 {
+    if (a.fault && blockIdx.x == 0) return;   // test hook (kt_debug_handoff_fault): a publisher that never arrives -> the sweep must give up
     kt_icp_row fn{a};
     if (a.state && !a.first) {
         // pose produced by the previous iteration's epilogue (kernel boundary orders the accesses)
@@ -469,7 +486,9 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
 int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
 {
     a.granules = (unsigned long long*)c->red_partials;
-    a.epoch = kt_next_epoch(c);
+    a.fault = 0;
+    if (c->fault_skip > 0) --c->fault_skip;
+    else if (c->fault_count > 0) { --c->fault_count; a.fault = 1; }
     hipLaunchKernelGGL(kt_icp_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
@@ -505,7 +524,7 @@ extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3
     if (s != KT_OK) return s;
     KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * KT_RED_SLOTS, hipMemcpyDeviceToHost, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
-    if (c->red_out_host[KT_RED_SLOTS - 1] != 0.0f) { kt_set_error("icpStep: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
+    if (c->red_out_host[KT_RED_SLOTS - 1] != 0.0f) { (void)kt_refill_granules(c); kt_set_error("icpStep: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
     kt_unpack29_host(c->red_out_host, A_host, b_host, residual_host);
     return KT_OK;
 }
@@ -570,7 +589,7 @@ extern "C" int kt_icp_track(kt_ctx* c, const float* const vmaps_curr[KT_LEVELS],
     kt_track_state out;
     KT_HIP(hipMemcpyAsync(&out, st, sizeof(out), hipMemcpyDeviceToHost, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
-    if (out.handoff_timeout) { kt_set_error("kt_icp_track: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
+    if (out.handoff_timeout) { (void)kt_refill_granules(c); kt_set_error("kt_icp_track: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
     memcpy(Rcurr_out->m, out.Rcurr, sizeof(out.Rcurr));
     memcpy(tcurr_out, out.tcurr, sizeof(out.tcurr));
     if (A_last_out) {
@@ -727,6 +746,7 @@ __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_re
         const unsigned int G = gridDim.x;
         unsigned long long v[2][4];
         unsigned int spins = 0;
+        const unsigned int spin_limit = *(volatile const unsigned int*)&kt_sweep_spin_limit;
         for (;;) {
 #pragma unroll
             for (int which = 0; which < 2; ++which)
@@ -740,7 +760,7 @@ __global__ __launch_bounds__(KT_RES_THREADS) void kt_residual_kernel(const kt_re
             for (int which = 0; which < 2; ++which)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ok = ok && (unsigned int)(v[which][q] >> 32) == a.epoch;
-            if (__all(ok) || ++spins > (1u << 22)) break;
+            if (__all(ok) || ++spins > spin_limit) break;
             __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
@@ -806,7 +826,7 @@ extern "C" int kt_rgb_residual(kt_ctx* c, float min_scale, const int16_t* dIdx, 
     KT_LAUNCH_CHECK();
     KT_HIP(hipMemcpyAsync(c->int_out_host, out2, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
-    if (c->int_out_host[2]) { kt_set_error("computeRgbResidual: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
+    if (c->int_out_host[2]) { (void)kt_refill_granules(c); kt_set_error("computeRgbResidual: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
     *count_host = c->int_out_host[0];
     *sigma_sum_host = c->int_out_host[1];
     return KT_OK;
@@ -841,7 +861,7 @@ struct kt_rgb_args {
     float sobel_scale;
     int cols, rows;
     kt_track_state* state;
-    unsigned long long* granules; unsigned int epoch;
+    unsigned long long* granules;
     float* out29;
     int mode;              // KT_MODE_HOST, KT_MODE_RGB_SOLVE, KT_MODE_JOINT_SOLVE
     kt_level_k next_k;     // intrinsics of the level the NEXT iteration runs at (for K R K^-1, K t)
@@ -990,11 +1010,11 @@ int kt_joint_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_cur
     a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
     a.state = state; a.out29 = nullptr; a.mode = KT_MODE_ICP_STASH; a.first = 0; a.keep29 = 0;
     a.granules = kt_second_granules(c);
-    a.epoch = kt_next_epoch(c);
+    a.fault = 0;
     kt_rgb_args r;
     r.corres = corres_img; r.sigma = 0.f; r.cloud = cloud; r.fx = intr->fx; r.fy = intr->fy; r.dIdx = dIdx; r.dIdy = dIdy;
     r.sobel_scale = sobel_scale; r.cols = cols; r.rows = rows; r.state = state;
-    r.granules = (unsigned long long*)c->red_partials; r.epoch = a.epoch; r.out29 = nullptr; r.mode = KT_MODE_JOINT_SOLVE;
+    r.granules = (unsigned long long*)c->red_partials; r.out29 = nullptr; r.mode = KT_MODE_JOINT_SOLVE;
     r.next_k = *next_k;
     r.res_partials = kt_residual_partials(c); r.res_blocks = kt_residual_blocks(cols, rows);
     hipLaunchKernelGGL(kt_joint_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a, r);
@@ -1010,13 +1030,13 @@ extern "C" int kt_rgb_step(kt_ctx* c, const kt_dataterm* corres_img, float sigma
     kt_rgb_args a;
     a.corres = corres_img; a.sigma = sigma; a.cloud = cloud; a.fx = fx; a.fy = fy; a.dIdx = dIdx; a.dIdy = dIdy;
     a.sobel_scale = sobel_scale; a.cols = cols; a.rows = rows; a.state = nullptr;
-    a.granules = (unsigned long long*)c->red_partials; a.epoch = kt_next_epoch(c); a.out29 = c->red_out; a.mode = KT_MODE_HOST;
+    a.granules = (unsigned long long*)c->red_partials; a.out29 = c->red_out; a.mode = KT_MODE_HOST;
     a.res_partials = nullptr; a.res_blocks = 0;
     hipLaunchKernelGGL(kt_rgb_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * KT_RED_SLOTS, hipMemcpyDeviceToHost, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
-    if (c->red_out_host[KT_RED_SLOTS - 1] != 0.0f) { kt_set_error("rgbStep: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
+    if (c->red_out_host[KT_RED_SLOTS - 1] != 0.0f) { (void)kt_refill_granules(c); kt_set_error("rgbStep: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
     kt_unpack29_host(c->red_out_host, A_host, b_host, nullptr);
     return KT_OK;
 }
@@ -1028,7 +1048,7 @@ int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corr
     kt_rgb_args a;
     a.corres = corres_img; a.sigma = 0.f; a.cloud = cloud; a.fx = fx; a.fy = fy; a.dIdx = dIdx; a.dIdy = dIdy;
     a.sobel_scale = sobel_scale; a.cols = cols; a.rows = rows; a.state = state;
-    a.granules = (unsigned long long*)c->red_partials; a.epoch = kt_next_epoch(c); a.out29 = nullptr; a.mode = mode;
+    a.granules = (unsigned long long*)c->red_partials; a.out29 = nullptr; a.mode = mode;
     a.next_k = *next_k;
     a.res_partials = kt_residual_partials(c); a.res_blocks = kt_residual_blocks(cols, rows);
     hipLaunchKernelGGL(kt_rgb_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
@@ -1114,4 +1134,36 @@ extern "C" int kt_debug_icp_wg_times(kt_ctx* c, unsigned long long* out768_host)
     kt_set_error("kt_debug_icp_wg_times: the library was not built with -DKT_ICP_TIMING");
     return KT_ERR_STATE;
 #endif
+}
+
+
+// ---- test hook: a reduction launch that loses a publisher ---------------------------------------------------------------------------
+// After `skip` more ICP reduction launches on this context, `count` launches run without workgroup 0 (it returns at once), so their
+// sweeps give up after spin_limit looks (0 = leave the limit alone; the product's is 2^22) and report the time-out.  dirty_out, when
+// given, receives the number of reduction granules that are NOT the sentinel once everything enqueued on the context's stream has
+// retired: 0 after any launch whose sweep completed, and 0 after a REPORTED time-out (the reporting path refills the buffer).
+__global__ void kt_granules_dirty_kernel(const unsigned long long* __restrict__ g, int n, unsigned int* __restrict__ out)
+{
+    unsigned int dirty = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dirty += g[i] != KT_GRANULE_SENTINEL;
+    if (dirty) atomicAdd(out, dirty);
+}
+extern "C" int kt_debug_handoff_fault(kt_ctx* c, int skip, int count, unsigned int spin_limit, unsigned int* dirty_out)
+{
+    KT_ARG(c && skip >= 0 && count >= 0);
+    c->fault_skip = skip; c->fault_count = count;
+    if (spin_limit) KT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(kt_sweep_spin_limit), &spin_limit, sizeof(spin_limit), 0, hipMemcpyHostToDevice, c->stream));
+    if (dirty_out) {
+        unsigned int* d = nullptr;
+        KT_HIP(hipMalloc((void**)&d, sizeof(unsigned int)));
+        KT_HIP(hipMemsetAsync(d, 0, sizeof(unsigned int), c->stream));
+        // the two [15][256] kt_reduce29 sets (the second one starts at 32 * KT_RED_BLOCKS: kt_second_granules)
+        for (int set = 0; set < 2; ++set)
+            hipLaunchKernelGGL(kt_granules_dirty_kernel, dim3(4), dim3(256), 0, c->stream, (const unsigned long long*)c->red_partials + set * 32 * KT_RED_BLOCKS,
+                               KT_RED_PAIRS * KT_RED_BLOCKS, d);
+        KT_HIP(hipMemcpyAsync(dirty_out, d, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        KT_HIP(hipStreamSynchronize(c->stream));
+        KT_HIP(hipFree(d));
+    }
+    return KT_OK;
 }

@@ -358,7 +358,7 @@ __device__ __forceinline__ void kt_update_krk(kt_track_state* st, const kt_level
 // Every element sees exactly the operations of kt_ldlt_solve6 / kt_pose_update in the same order (the bit-exact trajectory tests and
 // kt_debug_solve_check -- both forms on the same systems, ties, zeros, NaNs -- compare them).
 // Called by all 64 lanes of ONE wave with wave-uniform arguments.  sys: [0, 36) A row-major, [36, 42) b, [42, 48) scratch; pose_d:
-// resultRt[16]; pose_f: Rprev[9], tprev[3]; work: 64 doubles of LDS scratch.  On return pose_d holds the new resultRt (for kt_compute_krk).
+// resultRt[16]; pose_f: Rprev[9], tprev[3]; work: KT_TAIL_WORK_DOUBLES (36) doubles of LDS scratch.  On return pose_d holds the new resultRt (for kt_compute_krk).
 // ------------------------------------------------------------------------------------------------
 #ifdef KT_TAIL_MARK   // analysis builds: section markers in the ISA (scripts/isa_summary.py counts the instructions between them)
 #define KT_MARK(n) asm volatile("; TAILSEC " #n ::: "memory")

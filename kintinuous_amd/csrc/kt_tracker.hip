@@ -624,6 +624,7 @@ int kt_tracker_reset(kt_tracker* t)
     // KintinuousTracker::reset :262-354
     KT_ARG(t);
     t->outstanding = false;
+    KT_TRY(kt_refill_granules(t->ctx));   // whatever a failed or abandoned frame left in the hand-off buffer
     KT_HIP(hipStreamSynchronize(t->ctx->stream));
     t->global_time = 0;
     memcpy(t->Rlast, t->initial_rotation, sizeof(t->Rlast));
@@ -1353,7 +1354,13 @@ static int complete_frame(kt_tracker* t)
     }
     if (t->out_ordinal + 1 > t->frames_observed) t->frames_observed = t->out_ordinal + 1;
     ev_collect(t);
-    if (t->mirror->handoff_timeout) { kt_set_error("odometry: inter-workgroup hand-off timed out"); return KT_ERR_STATE; }
+    if (t->mirror->handoff_timeout) {
+        // the granule buffer is in an undefined state (kt_track.hip: kt_refill_granules): refill it behind everything enqueued so far,
+        // before the caller's next frame (or its reset) launches another reduction
+        (void)kt_refill_granules(c);
+        kt_set_error("odometry: inter-workgroup hand-off timed out");
+        return KT_ERR_STATE;
+    }
     float Rcurr[9], tcurr[3];
     memcpy(Rcurr, t->mirror->R, sizeof(Rcurr));
     memcpy(tcurr, t->mirror->t, sizeof(tcurr));

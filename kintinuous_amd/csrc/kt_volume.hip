@@ -1395,7 +1395,8 @@ __global__ __launch_bounds__(64 * KT_TSDF_WPB, COUNT ? 6 : KT_TSDF_OCC) void kt_
     // A parked frame does nothing here (its in-stream pre-pass left an empty task list, but a plan made ahead of the frame did not): its
     // part of the list is taken as empty.  Deliberately NOT an early return: a branch on the flag in front of everything else is what
     // made the flag's round trip the first of five.
-    const uint2 t_part = *(const uint2*)&a.task_count[1 + xcd];   // (4-byte aligned: two adjacent words, one request)
+    uint2 t_part;   // two adjacent words, only 4-byte aligned (odd word index for even xcd): copied, not read through a uint2 lvalue
+    __builtin_memcpy(&t_part, &a.task_count[1 + xcd], sizeof(t_part));
     const unsigned int t_begin = t_part.x, t_end = parked != 0 ? t_part.x : t_part.y;
     constexpr int KT_TB = 64 * KT_TSDF_WPB;
     constexpr int KT_TAB_PASSES = (1023 + KT_TSDF_UNROLL + KT_TB - 1) / KT_TB;   // N < 1024 on this path

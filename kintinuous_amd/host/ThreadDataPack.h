@@ -1,3 +1,6 @@
+// STAND-IN for the reference's own header (utils/ThreadDataPack.h): in an integration the reference's file is used as it is and this
+// one is deleted.  Interface glue for the shell's tests, not product code -- do not grow it.
+//
 // ThreadDataPack.h -- the singleton the reference's threads talk through (utils/ThreadDataPack.h:34-165), cut to the fields the
 // tracking + fusion path and its first consumer read and write: the tracker pointer, the slices taken over by CloudSliceProcessor,
 // latestPoseId and the hand-shake flags of the end of a run (pauseCapture, finalised, cloudSliceProcessorFinished), the 30 Hz

@@ -1,3 +1,6 @@
+// STAND-IN for the reference's own header (utils/ThreadObject.h): in an integration the reference's file is used as it is and this
+// one is deleted.  It exists so that the shell and its tests build without boost; it is interface glue, not product code -- do not grow it.
+//
 // ThreadObject.h -- the base of every thread of the reference (utils/ThreadObject.h:26-97), restated on std:: primitives: start() runs
 // process() until it returns false or stop() raises haltSignal; running() tells a controller whether the loop is still alive;
 // threadPack is the shared ThreadDataPack; lagTime is what the GUI shows as "lag".  A controller starts one as
@@ -5,7 +8,7 @@
 #pragma once
 
 #include <assert.h>
-#include <iostream>
+#include <stdio.h>
 #include <string>
 
 #include "Stopwatch.h"
@@ -45,11 +48,22 @@ class ThreadObject {
   protected:
     void run()
     {
-        std::cout << threadIdentifier << " started" << std::endl;
+        announce(" started\n");
         isRunning.assignValue(true);
         while (process() && !haltSignal.getValue()) Stopwatch::get().sendAll();
         isRunning.assignValue(false);
-        std::cout << threadIdentifier << " ended" << std::endl;
+        announce(" ended\n");
+    }
+
+    // The reference's words (utils/ThreadObject.h:73-85), but each announcement leaves as ONE write: several ThreadObjects start at the
+    // same moment and an unsynchronised std::cout interleaved them ("...Thread startedTracker...").
+    void announce(const char* what)
+    {
+        std::string line = threadIdentifier + what;
+        flockfile(stdout);                    // one locked stdio operation: ordered with every other printf / std::cout of the process
+        fputs(line.c_str(), stdout);
+        fflush(stdout);
+        funlockfile(stdout);
     }
 
     virtual bool process()

@@ -8,6 +8,7 @@
 
 #include <unistd.h>
 #include <algorithm>
+#include <cstdio>
 
 #include "KintinuousTracker.h"
 #include "RawLogReader.h"
@@ -34,6 +35,8 @@ class TrackerInterface : public ThreadObject {
     int getCurrentFrame() const { return currentFrame; }   // (shell addition: frames handed to the frontend so far)
 
     ThreadMutexObject<bool> endRequested;
+    ThreadMutexObject<bool> handshakeTimedOut;   // (shell addition) the end-of-run hand-shake below gave up
+    int handshakeSeconds = 20;
 
   private:
     // one turn of ThreadObject::run()'s loop (TrackerInterface.cpp:44-137)
@@ -56,9 +59,21 @@ class TrackerInterface : public ThreadObject {
             threadPack.finalised.assignValue(true);
             finalise();
             // the FINAL slice is out: keep waking the slice processor until it has taken it over (:66-69)
-            while (!threadPack.cloudSliceProcessorFinished.getValueWait()) {
-                std::lock_guard<std::mutex> lock(frontend->cloudMutex);
-                frontend->cloudSignal.notify_all();
+            // (the reference loops for ever, napping 33 ms before every look; here the flag is looked at first -- a run without a processor
+            // thread, or one that has finished already, pays no nap -- and the loop gives up after handshakeSeconds: a processor that
+            // is stuck or was never started must not hang join())
+            const uint64_t waitStart = Stopwatch::getCurrentSystemTime();
+            while (!threadPack.cloudSliceProcessorFinished.getValue()) {
+                {
+                    std::lock_guard<std::mutex> lock(frontend->cloudMutex);
+                    frontend->cloudSignal.notify_all();
+                }
+                if (Stopwatch::getCurrentSystemTime() - waitStart > (uint64_t)handshakeSeconds * 1000000ull) {
+                    std::fprintf(stderr, "TrackerInterface: the slice processor did not take the FINAL slice over within %d s\n", handshakeSeconds);
+                    handshakeTimedOut.assignValue(true);
+                    break;
+                }
+                usleep(2000);
             }
             return shouldEnd ? false : returnVal;
         }

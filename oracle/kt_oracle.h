@@ -180,6 +180,10 @@ void kto_tracker_stage_seconds(const kto_tracker* t, double out[6]);
 /* statistics of the last frame: U (integrate updates), S (raycast steps) */
 void kto_tracker_last_counts(const kto_tracker* t, long long* U, long long* S);
 
+/* test access to the shared atan2 / sin / cos restatement of the per-slice stage (kt_oracle_kernels.c: sp_atan2_pos, sp_sincos) */
+float kto_test_sp_atan2_pos(float y, float x);
+void kto_test_sp_sincos(float t, float* s, float* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1166,6 +1166,10 @@ static void sp_sincos(float t, float* s, float* c)   /* 0 <= t <= pi / 3 (+ a fe
     *s = swap ? cs : sn;
     *c = swap ? sn : cs;
 }
+/* test access (tests/test_oracle_kat.py pins the three against libm: a wrong coefficient or reduction would otherwise pass on both sides,
+ * HIP and oracle sharing this restatement) */
+float kto_test_sp_atan2_pos(float y, float x) { return sp_atan2_pos(y, x); }
+void kto_test_sp_sincos(float t, float* s, float* c) { sp_sincos(t, s, c); }
 static void sp_compute_roots2(float b, float c, float r[3])
 {
     r[0] = 0.f;

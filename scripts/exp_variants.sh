@@ -5,7 +5,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mode=$1; shift
 if [ "$mode" = build ]; then
-  mkdir -p $R/build/exp
+  mkdir -p $R/build/exp $R/exp
   i=0
   for flags in "$@"; do
     i=$((i+1))
@@ -20,16 +20,16 @@ if [ "$mode" = build ]; then
     for f in kt_context kt_image kt_volume kt_track kt_tracker kt_hostmath kt_comm kt_slice kt_cloud kt_debug; do
       if [ -f $R/build/exp/${f}_$i.o ]; then objs="$objs $R/build/exp/${f}_$i.o"; else objs="$objs $R/build/$f.o"; fi
     done
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/kintinuous_amd/libkt_exp_$i.so $objs
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/exp/libkt_exp_$i.so $objs
     echo "$i: $flags" 
-  done > $R/kintinuous_amd/exp_variants.txt
-  cat $R/kintinuous_amd/exp_variants.txt
+  done > $R/exp/variants.txt
+  cat $R/exp/variants.txt
 else
   W=${1:-orbit512}; S=${2:-40}
   echo "== $W"
   python $R/bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline --no-readahead 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('base', d['roofline']['avg_launch_ms'], d['value'], d['stage_ms'])"
   while read line; do
     i=${line%%:*}
-    KT_HIP_LIB=$R/kintinuous_amd/libkt_exp_$i.so python $R/bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline --no-readahead 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$line', d['roofline']['avg_launch_ms'], d['value'], d['stage_ms'])" || echo "$line FAILED"
-  done < $R/kintinuous_amd/exp_variants.txt
+    KT_HIP_LIB=$R/exp/libkt_exp_$i.so python $R/bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline --no-readahead 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$line', d['roofline']['avg_launch_ms'], d['value'], d['stage_ms'])" || echo "$line FAILED"
+  done < $R/exp/variants.txt
 fi

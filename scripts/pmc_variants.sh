@@ -1,4 +1,4 @@
-# HBM-side traffic of kt_tsdf23_kernel for the tree's library and every variant of kintinuous_amd/exp_variants.txt: FETCH_SIZE (all) and
+# HBM-side traffic of kt_tsdf23_kernel for the tree's library and every variant of exp/variants.txt: FETCH_SIZE (all) and
 # WRITE_SIZE (tree + non-what-if variants), one --pmc pass each, kernel-trace only.  Prints KiB per launch (mean) per {lib, workload}.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -18,7 +18,7 @@ for w in orbit512 farwall768; do
   run tree "" WRITE_SIZE $w $S
   while read line; do
     i=${line%%:*}
-    run "variant $line" $R/kintinuous_amd/libkt_exp_$i.so FETCH_SIZE $w $S
-    case "$line" in *WHATIF*) ;; *) run "variant $line" $R/kintinuous_amd/libkt_exp_$i.so WRITE_SIZE $w $S;; esac
-  done < $R/kintinuous_amd/exp_variants.txt
+    run "variant $line" $R/exp/libkt_exp_$i.so FETCH_SIZE $w $S
+    case "$line" in *WHATIF*) ;; *) run "variant $line" $R/exp/libkt_exp_$i.so WRITE_SIZE $w $S;; esac
+  done < $R/exp/variants.txt
 done

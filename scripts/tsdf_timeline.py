@@ -1,6 +1,6 @@
 """In-kernel timeline of the voxel kernel (kt_tsdf23_lean_kernel), orbit512, one launch: when waves enter, how long the table fill and a
 task's set-up take, how long each batch takes, when SIMDs / XCDs finish.  Needs a library built with -DKT_TSDF_TIMELINE
-(scripts/exp_variants.sh build "-DKT_TSDF_TIMELINE"; KT_HIP_LIB=kintinuous_amd/libkt_exp_1.so)."""
+(scripts/exp_variants.sh build "-DKT_TSDF_TIMELINE"; KT_HIP_LIB=exp/libkt_exp_1.so)."""
 import ctypes as C
 import os
 import sys

@@ -1,4 +1,4 @@
-# A/B of the libkt_exp_<i>.so variants built by `scripts/exp_variants.sh build ...` (kintinuous_amd/exp_variants.txt) against the tree's
+# A/B of the libkt_exp_<i>.so variants built by `scripts/exp_variants.sh build ...` (exp/variants.txt) against the tree's
 # library, in one GPU call: parity verdict (volume / sweep / golden tests through KT_HIP_LIB) and tsdf23 launch times on both workloads.
 #   gpurun --timeout 900 -- 'bash scripts/variants_ab.sh [steps]'
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -15,5 +15,5 @@ one() {   # $1 = label, $2 = library path or empty
 while read line; do
   i=${line%%:*}
   case "$line" in *WHATIF*) continue;; esac
-  one "variant $line" $PWD/kintinuous_amd/libkt_exp_$i.so
-done < kintinuous_amd/exp_variants.txt
+  one "variant $line" $PWD/exp/libkt_exp_$i.so
+done < exp/variants.txt

@@ -17,6 +17,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Order of a run (round 5).  The driver runs the GPU suite with -x: a failure hides everything behind it, so the kernel-parity evidence goes
+# FIRST (reference-made goldens, the BASELINE configs, then per-kernel modules) and the process-level tests -- child processes, threads,
+# files: the only tests whose outcome can depend on scheduling -- go LAST.  Unknown modules keep their place in the middle.
+_ORDER = ["test_golden_ref", "test_golden", "test_gpu_configs", "test_gpu_fullsize", "test_gpu_image", "test_gpu_track", "test_gpu_solve",
+          "test_gpu_volume", "test_gpu_sweep", "test_gpu_tol", "test_gpu_tracker", "test_slice_process", "test_pcd", "test_jpeg", "test_gpu_comm"]
+_LAST = ["test_gpu_bench_cli", "test_gpu_host_shell"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = item.module.__name__.split(".")[-1]
+        if name in _LAST:
+            return 1000 + _LAST.index(name)
+        return _ORDER.index(name) if name in _ORDER else len(_ORDER)
+    items.sort(key=rank)          # stable: the order inside a module is kept
+
+
 # Round 4: two voxel kernels store the same bits (kt_tsdf23_lean_kernel and the round-3 kt_tsdf23_kernel; kt_debug_tsdf_lean selects):
 # every GPU test of these modules runs once per kernel.
 VOXEL_KERNEL_MODULES = {"test_gpu_volume", "test_gpu_sweep", "test_golden_ref", "test_golden", "test_gpu_fullsize"}

@@ -53,6 +53,9 @@ def main():
     out = scenario(ref, g, OIntr)
     assert int(out["rgb_sigma_count"][1]) > 50 and len(out["cloud"]) > 300 and np.isfinite(out["ray_vmap"][: int(g["rows"])]).sum() > 500
     assert float(out["icp_r"][1]) > 1000
+    # the z + 1 wrap of the last plane is exercised: the rotated volume has a wall's worth of crossings between logical N - 1 and 0, and
+    # the extraction of its top slab holds at least that many points more than a wrap-less extraction could
+    assert int(out["zwrap_shift_crossings"][1]) > 100 and len(out["cloud_zwrap_top"]) >= int(out["zwrap_shift_crossings"][1])
     path = os.path.join(HERE, "golden_ref_v1.npz")
     np.savez_compressed(path, **{f"in_{k}": v for k, v in g.items()}, **{f"out_{k}": v for k, v in out.items()})
     print(path, os.path.getsize(path), "bytes;", len(out), "outputs")

@@ -12,6 +12,18 @@ def _sorted_points(p):
     return key[order]
 
 
+def z_wrap_rotation(vol, col, wrap_z):
+    """(k, n): rolling the STORAGE arrays by k planes along z puts the pair of logical planes with the most dz zero crossings (n of them)
+    at logical (N - 1, 0)."""
+    N = vol.shape[0]
+    L = np.roll(vol, -wrap_z, axis=0).astype(np.int32)                 # logical z order
+    ok = (np.roll(col[..., 3], -wrap_z, axis=0) != 0) & (L != 32767)
+    cross = ok[:-1] & ok[1:] & (((L[:-1] > 0) & (L[1:] < 0)) | ((L[:-1] < 0) & (L[1:] > 0)))
+    n = cross.reshape(N - 1, -1).sum(axis=1)
+    zbest = int(np.argmax(n))
+    return (N - 1 - zbest) % N, int(n[zbest])
+
+
 def scenario(M, g, intr_cls):
     cols, rows = int(g["cols"]), int(g["rows"])
     fx, fy, cx, cy = [float(x) for x in g["intr"]]
@@ -50,6 +62,16 @@ def scenario(M, g, intr_cls):
     out["cloud"] = _sorted_points(pts)
     pts = M.extract_cloud_slice(vol, [size] * 3, 200000, wrap, col, 0, N, 0, N, N - 13, N, 1, [int(w) for w in g["real_wrap"]])
     out["cloud_zminus"] = _sorted_points(pts)
+    # extract.cu's dz neighbour of the LAST logical plane is fetched through the storage index, i.e. it wraps to logical plane 0
+    # (oracle: kto_extract_cloud_slice).  The fused scene has no surface there, so the volume is rotated along z
+    # until its busiest pair of planes (z, z + 1) -- the far wall -- sits at (N - 1, 0): those crossings exist only through the wrap.
+    zr = z_wrap_rotation(vol, col, wrap[2])
+    out["zwrap_shift_crossings"] = np.array(zr, np.int64)
+    vol_r, col_r = np.roll(vol, zr[0], axis=0), np.roll(col, zr[0], axis=0)
+    pts = M.extract_cloud_slice(vol_r, [size] * 3, 200000, wrap, col_r, 0, N, 0, N, 0, N, 1, [int(w) for w in g["real_wrap"]])
+    out["cloud_zwrap"] = _sorted_points(pts)
+    pts = M.extract_cloud_slice(vol_r, [size] * 3, 200000, wrap, col_r, 0, N, 0, N, N - 3, N, 1, [int(w) for w in g["real_wrap"]])
+    out["cloud_zwrap_top"] = _sorted_points(pts)
     cv, cc = vol.copy(), col.copy()
     M.clear_volume(cv, 0, False, 20, 36)   # 17-plane X slab: the launch-geometry quirk leaves one plane
     M.clear_volume(cc, 2, True, 5, -9)

@@ -6,11 +6,20 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "kt_abi.h")).read()
+def _names(path):
+    src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(kt_[a-z0-9_]+)\s*\(", src)
-    return sorted(set(names))
+    return sorted(set(re.findall(r"\b(kt_[a-z0-9_]+)\s*\(", src)))
+
+
+def _declared():
+    """The boundary: include/kt_abi.h."""
+    return _names(os.path.join(ROOT, "include", "kt_abi.h"))
+
+
+def _declared_debug():
+    """Test / analysis hooks, kept OUT of the boundary header: kintinuous_amd/csrc/kt_debug.h."""
+    return _names(os.path.join(ROOT, "kintinuous_amd", "csrc", "kt_debug.h"))
 
 
 def test_header_symbols_are_exported():
@@ -19,13 +28,14 @@ def test_header_symbols_are_exported():
     lib = ctypes.CDLL(abi.LIB_PATH)
     declared = _declared()
     assert len(declared) > 55
-    missing = [n for n in declared if not hasattr(lib, n)]
+    missing = [n for n in declared + _declared_debug() if not hasattr(lib, n)]
     assert not missing, missing
+    assert not [n for n in declared if "debug" in n]          # the product header declares no test hook
 
 
 def test_binding_matches_header():
     from kintinuous_amd import abi
-    declared = set(_declared())
+    declared = set(_declared()) | set(_declared_debug())
     bound = set(abi.ABI_SYMBOLS)
     assert bound <= declared, sorted(bound - declared)
     assert declared - bound == set(), sorted(declared - bound)

@@ -164,3 +164,97 @@ def test_icp_track_matches_the_stepwise_loop(ctx, oracle_mod, small_scene, sched
     assert np.array_equal(A.view(np.uint32), lastA.view(np.uint32)) and np.array_equal(r.view(np.uint32), lastr.view(np.uint32))
     if sum(schedule):
         assert np.abs(tc - t0).max() > 1e-5 and r[1] > 1000    # it did track something
+
+
+def _handoff_fault(ctx, skip, count, spin_limit=0, want_dirty=True):
+    import ctypes as C
+    from kintinuous_amd import abi
+    dirty = C.c_uint(0)
+    abi._chk(abi.lib().kt_debug_handoff_fault(ctx.h, skip, count, spin_limit, C.byref(dirty) if want_dirty else None))
+    return dirty.value
+
+
+def test_a_reported_handoff_timeout_leaves_a_clean_buffer(ctx, oracle_mod, small_scene):
+    """Advisor, round 4: the sentinel hand-off ("the data is the flag") has no tag to tell a stale granule from a fresh one, so a sweep
+    that gives up -- it hands nothing back, and the publishers it did not wait for store after it has looked -- must not leave the buffer
+    to the next launch as it is.  kt_debug_handoff_fault makes ONE reduction launch lose a publishing workgroup (its sweep gives up after
+    a lowered number of looks).  The call must report the time-out, the buffer must be all sentinels again once the stream has drained
+    (every reporting path refills it: kt_refill_granules), and the next calls must give the reference-order sums bit for bit."""
+    from kintinuous_amd import abi
+    from kintinuous_amd.abi import Intr
+    from oracle.oracle import OIntr
+    cam, frames, traj = small_scene
+    vc, nc = _frame_maps(oracle_mod, cam, frames[1][0], 0)
+    v0, n0 = _frame_maps(oracle_mod, cam, frames[0][0], 0)
+    t0 = np.array([3, 3, 3], np.float32)
+    vg, ng = oracle_mod.transform_maps(v0, n0, np.eye(3), t0)
+    rows, cols = vc.shape[0] // 3, vc.shape[1]
+    R = np.eye(3, dtype=np.float32)
+    dist, ang = 0.10, 0.342
+    oi, gi = OIntr(cam.fx, cam.fy, cam.cx, cam.cy), Intr(cam.fx, cam.fy, cam.cx, cam.cy)
+    Af, bf, rf = oracle_mod.icp_step(R, t0, vc, nc, R, t0, oi, vg, ng, dist, ang, order=0)
+    dev = [ctx.upload(x) for x in (vc, nc, vg, ng)]
+    step = lambda: ctx.icp_step(R, t0, dev[0], dev[1], R, t0, gi, dev[2], dev[3], cols, rows, dist, ang)
+    A, b, r = step()
+    assert np.array_equal(A, Af) and np.array_equal(b, bf) and np.array_equal(r, rf)
+    assert _handoff_fault(ctx, 0, 0) == 0                                  # a completed sweep hands every granule back
+    try:
+        _handoff_fault(ctx, 0, 1, spin_limit=64, want_dirty=False)
+        with pytest.raises(abi.KtError, match="timed out"):
+            step()
+        assert _handoff_fault(ctx, 0, 0) == 0, "a reported time-out must refill the hand-off buffer"
+        for _ in range(3):
+            A, b, r = step()
+            assert np.array_equal(A, Af) and np.array_equal(b, bf) and np.array_equal(r, rf)
+        # the same through the device-resident chain (kt_icp_track): the LAST of its launches loses the publisher
+        pyr = lambda depth: [_frame_maps(oracle_mod, cam, depth, l) for l in range(4)]
+        cur, prev = pyr(frames[1][0]), pyr(frames[0][0])
+        vcs, ncs = [ctx.upload(v) for v, _ in cur], [ctx.upload(n) for _, n in cur]
+        g = [oracle_mod.transform_maps(v, n, np.eye(3), t0) for v, n in prev]
+        vgs, ngs = [ctx.upload(v) for v, _ in g], [ctx.upload(n) for _, n in g]
+        its = [4, 3, 2, 0]
+        track = lambda: ctx.icp_track(vcs, ncs, vgs, ngs, cols, rows, gi, R, t0, its, dist, ang)
+        good = track()
+        _handoff_fault(ctx, sum(its) - 1, 1, want_dirty=False)
+        with pytest.raises(abi.KtError, match="timed out"):
+            track()
+        assert _handoff_fault(ctx, 0, 0) == 0
+        again = track()
+        for x, y in zip(good, again):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    finally:
+        _handoff_fault(ctx, 0, 0, spin_limit=1 << 22, want_dirty=False)
+
+
+def test_tracker_recovers_from_a_handoff_timeout(ctx, small_scene):
+    """The tracker's form of the same: the last odometry launch of a frame times out -> the frame's getter reports it, nothing is fused with
+    the pose-less frame, the buffer is clean, and after kt_tracker_reset the sequence gives the poses and the volume of an undisturbed run."""
+    from kintinuous_amd import abi
+    cam, frames, traj = small_scene
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
+    trk = abi.Tracker(ctx, cfg)
+
+    def run():
+        poses = []
+        for k, (d, rgb) in enumerate(frames[:5]):
+            trk.process_frame_host(d, rgb, 33333 * k)
+            poses.append(np.concatenate([x.ravel() for x in trk.pose()]))
+        return np.array(poses), trk.volume().copy(), trk.color_volume().copy()
+
+    try:
+        P0, V0, C0 = run()
+        trk.reset()
+        for k in range(2):
+            trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
+        trk.pose()
+        _handoff_fault(ctx, 18, 1, spin_limit=64, want_dirty=False)        # frame 2: 10 + 5 + 4 launches, the last one faulted
+        trk.process_frame_host(frames[2][0], frames[2][1], 33333 * 2)
+        with pytest.raises(abi.KtError, match="timed out"):
+            trk.pose()
+        assert _handoff_fault(ctx, 0, 0) == 0
+        trk.reset()
+        P1, V1, C1 = run()
+        assert np.array_equal(P0, P1) and np.array_equal(V0, V1) and np.array_equal(C0, C1)
+    finally:
+        _handoff_fault(ctx, 0, 0, spin_limit=1 << 22, want_dirty=False)
+        trk.close()

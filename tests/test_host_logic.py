@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_synth_is_deterministic_and_sane():
     from kintinuous_amd import synth
@@ -247,3 +249,54 @@ def test_thread_object_protocol(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "thread object ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kt_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_gpus_flag_resolves_the_launch():
+    """`python bench.py --gpus N` means N ranks in every launch form (the flag was parsed and never read): bare -> re-exec under
+    torch.distributed.run; under a launcher -> WORLD_SIZE must agree; no flag -> the launcher's world, else one rank."""
+    b = _bench_module()
+    assert b.resolve_launch(None, {}) == ("run", 0, 0, 1)
+    assert b.resolve_launch(1, {}) == ("run", 0, 0, 1)
+    assert b.resolve_launch(8, {}) == ("exec", 8)
+    env = {"WORLD_SIZE": "4", "RANK": "2", "LOCAL_RANK": "2"}
+    assert b.resolve_launch(4, env) == ("run", 2, 2, 4) and b.resolve_launch(None, env) == ("run", 2, 2, 4)
+    with pytest.raises(SystemExit):
+        b.resolve_launch(8, env)
+    with pytest.raises(SystemExit):
+        b.resolve_launch(1, env)
+    with pytest.raises(SystemExit):
+        b.resolve_launch(0, {})
+
+
+@pytest.mark.parametrize("form", ["bare", "torchrun"])
+def test_bench_gpus_2_starts_two_ranks(form, tmp_path):
+    """Both launch forms of `bench.py --gpus 2` end up as a two-rank job whose ranks meet in the key-value store (--launch-check stops there:
+    no GPU is touched); rank 0's stdout is ONE JSON line with n_gpus == --gpus."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    if form == "bare":
+        cmd = [sys.executable, bench, "--gpus", "2", "--steps", "3", "--warmup", "1", "--launch-check"]
+    else:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               bench, "--gpus", "2", "--steps", "3", "--warmup", "1", "--launch-check"]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 == j["gpus_flag"] and j["highest_rank_seen"] == 1

@@ -379,3 +379,35 @@ def test_place_recognition_tap_known_answer(oracle_mod):
         trk.process_frame(d, rgb, int(stamps[k]))
     assert [k for k in range(trk.num_poses()) if trk.dense_pose(k)[2]] == [0] and trk.pr_samples() == []
     trk.close()
+
+
+def test_slice_stage_trig_restatement_is_pinned_to_libm(oracle_mod):
+    """Advisor, round 4: HIP (csrc/kt_slice.hip) and the oracle share ONE hand-written atan2 / sin / cos (Cephes kernels, every FMA written
+    out) so that the per-slice normals compare bit for bit -- which proves only that both sides run the same code.  This pins the shared
+    restatement itself: against libm's double-precision atan2 / sin / cos it must stay within a few units in the last place on the whole
+    domain the stage uses (atan2(y >= 0, x) in [0, pi]; sin / cos on [0, pi / 3]), so a wrong coefficient or range reduction fails here."""
+    import ctypes as C
+    import math
+    l = oracle_mod.lib()
+    f = l.kto_test_sp_atan2_pos
+    f.restype, f.argtypes = C.c_float, [C.c_float, C.c_float]
+    g = l.kto_test_sp_sincos
+    g.restype, g.argtypes = None, [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    rng = np.random.default_rng(7)
+    ys = (np.abs(rng.normal(size=40000)) * 10.0 ** rng.uniform(-6, 3, 40000)).astype(np.float32)
+    xs = (rng.normal(size=40000) * 10.0 ** rng.uniform(-6, 3, 40000)).astype(np.float32)
+    ys[:200], xs[200:400] = 0.0, 0.0                            # the axes; (0, 0) is defined as 0 below
+    worst = 0.0
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        r, t = f(y, x), math.atan2(y, x)
+        assert 0.0 <= r <= 3.1415928
+        worst = max(worst, abs(r - t) / float(np.spacing(np.float32(max(t, 1e-30)))))
+    assert worst <= 4.0, worst                                   # measured 3.03
+    assert f(0.0, 0.0) == 0.0 and abs(f(0.0, -1.0) - math.pi) < 3e-7 and f(0.0, 2.0) == 0.0 and abs(f(3.0, 0.0) - math.pi / 2) < 2e-7
+    s, c = C.c_float(), C.c_float()
+    ws = wc = 0.0
+    for t in np.linspace(0.0, math.pi / 3 + 1e-6, 40001).astype(np.float32).tolist():
+        g(t, C.byref(s), C.byref(c))
+        ws = max(ws, abs(s.value - math.sin(t)) / float(np.spacing(np.float32(max(math.sin(t), 1e-30)))))
+        wc = max(wc, abs(c.value - math.cos(t)) / float(np.spacing(np.float32(math.cos(t)))))
+    assert ws <= 2.5 and wc <= 2.5, (ws, wc)                     # measured 1.75 / 1.56
