@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--host-frames", action="store_true",
                     help="frames start in host memory (pinned staging copy + PCIe upload inside the timed region): the PCIe-inclusive rate, not the headline")
     ap.add_argument("--cpu-frames", type=int, default=31, help="frames of the CPU baseline sample (about 3 s wall = 100 core-seconds on 32 threads)")
+    ap.add_argument("--contract", default="bit-exact", choices=["bit-exact", "survey-8c"],
+                    help="arithmetic contract of the voxel kernel in the timed frames: bit-exact (kt_tsdf23_lean_kernel; the default and the one every parity "
+                         "test holds) or survey-8c (kt_tsdf23_tol_kernel: SURVEY.md 8(c)'s parity policy, counted by tests/test_gpu_tol.py)")
     ap.add_argument("--no-stress", action="store_true", help="skip the roofline_stress block (BASELINE.json configs[4]: 1280x960 @ 768^3, 3 frames)")
     return ap.parse_args()
 
@@ -142,6 +145,8 @@ def main():
     d.update(kw)
 
     ctx = abi.Ctx(local_rank)
+    if args.contract == "survey-8c":
+        abi._chk(abi.lib().kt_debug_tsdf_contract(1))
     cfg = abi.TrackerConfig(cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, d["volume_size"], d["voxel_shift"], d["overlap"], d["static_mode"],
                             d["use_rgbd"], d["use_rgbd_icp"], d["fast_odometry"], d["disable_color_angle"], 0)
     trk = abi.Tracker(ctx, cfg)
@@ -264,6 +269,29 @@ def main():
     trk.enable_counts(False)
     if trk.num_poses() != args.warmup + args.steps:
         sys.stderr.write(f"bench: the counting replay produced {trk.num_poses()} poses for {args.warmup + args.steps} frames\n")
+    # A/B of the voxel kernel's two contracts on this workload (untimed, alone, serial frames; after every other measurement: the volume the
+    # tolerant kernel leaves behind is not used again).  Never the headline: `roofline` above is the contract the timed frames ran.
+    contract_ab = None
+    if abi.lib().kt_debug_tsdf_kernel().decode() == "kt_tsdf23_lean_kernel" and rank == 0 and world == 1 and args.warmup + args.steps >= 20:
+        n_ab = min(args.warmup + args.steps, 60)
+        def alone_ms(tol):
+            abi._chk(abi.lib().kt_debug_tsdf_contract(1 if tol else 0))
+            trk.reset()
+            for i in range(n_ab - 16):
+                step(i, announce_next=False)
+            trk.pose()
+            trk.enable_profiling(2)
+            for i in range(n_ab - 16, n_ab):
+                step(i, announce_next=False)
+            trk.pose()
+            ms_ = trk.stage_ms()["tsdf23"][0]
+            trk.enable_profiling(0)
+            return ms_
+        try:
+            ab = [alone_ms(False), alone_ms(True), alone_ms(False), alone_ms(True)]
+        finally:
+            abi._chk(abi.lib().kt_debug_tsdf_contract(-1))
+        contract_ab = {"frames": [n_ab - 16, n_ab], "bit_exact_alone_ms": [round(ab[0], 5), round(ab[2], 5)], "survey8c_alone_ms": [round(ab[1], 5), round(ab[3], 5)]}
     U = float(np.mean(Us))
     Lok = [x for x in Ls if x]
     lane_eff = round(sum(u for u, _ in Lok) / max(1, sum(l for _, l in Lok)), 4) if Lok else None
@@ -304,7 +332,7 @@ def main():
                                 # the slowest calls (index in the timed region, ms): shift frames and whatever else stalls the caller
                                 "slowest": [[int(i), round(float(periods[i]), 3)] for i in np.argsort(periods)[::-1][:4]]},
                    "slices_by_direction": slices_by_dim},
-        "roofline": {"kernel": voxel_kernel, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
+        "roofline": {"kernel": voxel_kernel, "contract": "survey-8c" if voxel_kernel == "kt_tsdf23_tol_kernel" else "bit-exact", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                      "frac": achieved / peak, "traffic": traffic, "traffic_ratio": traffic_ratio,
                      # not measured by this run: the committed rocprofv3 PMC passes of the same workload and the same kt_volume.hip
                      "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_tsdf23,
@@ -312,6 +340,8 @@ def main():
                      # lanes the launch spends per updated voxel (first 16 timed frames): 64-lane wave z-steps over wave-columns of 32 x 2
                      # voxel columns, profiles/r02_tsdf23_whatif.md
                      "lane_efficiency": lane_eff,
+                     # the same launch (alone, frames [a, b) of the sequence) under the two contracts, alternating; informational
+                     "contract_ab": contract_ab,
                      # in the timed region the kernel shares the GPU with the read-ahead stream (next frame's bilateral / pyramid);
                      # the same launch with nothing else running (untimed stage pass below):
                      "avg_launch_ms_alone": stage_all["tsdf23"][0],
@@ -378,28 +408,66 @@ def committed_traffic(workload):
 
 def roofline_stress(ctx, abi, synth):
     """BASELINE.json configs[4] / SURVEY 8(d) config 5, the roofline showcase: 1280x960 depth into a 768^3 volume in static mode (the
-    camera 0.45 m outside the near face, far wall at 6.2 m), 8 warm-up + 4 timed frames, HIP events around every tsdf23 launch."""
+    camera 0.45 m outside the near face, far wall at 6.2 m), 8 warm-up + 4 timed frames, HIP events around every tsdf23 launch.
+    Three measurements of the SAME launch, each labelled (the headline `roofline.frac` is an in-region figure, this
+    block's `frac` was an alone figure and did not say so):
+      frac_alone / avg_launch_ms_alone : frames pushed one at a time, nothing else on the GPU (`frac` = this one, as in rounds 2-4);
+      frac_pipelined / avg_launch_ms_pipelined : frames pushed with one frame of read-ahead, as the headline's timed region runs them
+          (the 1280x960 bilateral / pyramid / scaleDepth of the NEXT frame share the GPU with the voxel kernel);
+      survey8c : the same two under the voxel kernel's second contract (kt_tsdf23_tol_kernel) -- an A/B of the contracts, never the headline."""
     N, cam = 768, synth.Camera.scaled(2)
     _, frames, _, kw = synth.sequence("farwall", 5, cam)
     cfg = abi.TrackerConfig(cam.cols, cam.rows, N, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 1, 0, 0, 0, 0, 0)
     trk = abi.Tracker(ctx, cfg)
     dev = [(ctx.upload(a), ctx.upload(b)) for a, b in frames]
     WARM, TIMED = 8, 4   # (round 4: 8 warm-up frames instead of 2 -- the first launches into the freshly cleared 2.7 GB of volumes run 8 % slower)
-    seq = [pingpong(k, len(dev)) for k in range(WARM + TIMED + 1)]
-    for k in range(WARM):
-        trk.process_frame(dev[seq[k]][0], dev[seq[k]][1], 33333 * k)
-    ctx.sync()
-    trk.enable_profiling(4)
-    t0 = time.perf_counter()
-    for k in range(WARM, WARM + TIMED):
-        trk.process_frame(dev[seq[k]][0], dev[seq[k]][1], 33333 * k)
-    trk.pose()
-    ctx.sync()
-    frame_ms = 1e3 * (time.perf_counter() - t0) / TIMED
-    trk.process_frame(dev[seq[WARM + TIMED]][0], dev[seq[WARM + TIMED]][1], 33333 * (WARM + TIMED))   # harvest the last event pair
-    ctx.sync()
-    ms, n = trk.stage_ms()["tsdf23"]
-    trk.enable_profiling(0)
+    seq = [pingpong(k, len(dev)) for k in range(WARM + 16)]
+
+    def run(readahead, timed=TIMED):
+        """-> (mean tsdf23 launch ms, launches, frame ms) over `timed` frames after WARM; the tracker is reset first.  A frame whose plan is
+        rejected is parked: the event pair then sits around an EMPTY launch (3.5 us) and the real one, re-issued by the host, is not
+        timed -- such pairs (plan_stats misses inside the window) are taken out of the mean instead of flattering it."""
+        TIMED = timed
+        trk.reset()
+        push = lambda k: trk.process_frame(dev[seq[k]][0], dev[seq[k]][1], 33333 * k)
+        ahead = lambda k: trk.prefetch_frame(dev[seq[k]][0], dev[seq[k]][1])
+        for k in range(WARM):
+            if readahead:
+                ahead(k + 1)
+            push(k)
+        trk.pose()
+        ctx.sync()
+        misses0 = trk.plan_stats()[1]
+        trk.enable_profiling(4)
+        t0 = time.perf_counter()
+        for k in range(WARM, WARM + TIMED):
+            if readahead:
+                ahead(k + 1)
+            push(k)
+        trk.pose()
+        ctx.sync()
+        frame_ms = 1e3 * (time.perf_counter() - t0) / TIMED
+        if readahead:
+            ahead(WARM + TIMED + 1)
+        push(WARM + TIMED)   # harvest the last event pair
+        trk.pose()
+        ctx.sync()
+        ms, n = trk.stage_ms()["tsdf23"]
+        trk.enable_profiling(0)
+        parked = trk.plan_stats()[1] - misses0
+        if 0 < parked < n:
+            ms, n = (ms * n - parked * 0.0035) / (n - parked), n - parked
+        return ms, n, frame_ms
+
+    ms, n, frame_ms = run(False)
+    ms_p, n_p, frame_ms_p = run(True, 12)
+    tol = None
+    if abi.lib().kt_debug_tsdf_kernel().decode() == "kt_tsdf23_lean_kernel":   # the A/B of the contracts (skipped when the run itself is under survey-8c)
+        abi._chk(abi.lib().kt_debug_tsdf_contract(1))
+        try:
+            tol = (run(False), run(True, 12))
+        finally:
+            abi._chk(abi.lib().kt_debug_tsdf_contract(-1))
     trk.reset()
     trk.enable_counts(True)
     Us = []
@@ -410,11 +478,20 @@ def roofline_stress(ctx, abi, synth):
     trk.close()
     U, P = float(np.mean(Us)), cam.cols * cam.rows
     b = 12.0 * U + 12.0 * P
+    frac = lambda t: (b / (t * 1e-3) / 1e9 / 8000.0) if t > 0 else None
     achieved = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    return {"workload": "farwall768: 1280x960 synthetic far-wall sequence, static mode, 768^3 TSDF (BASELINE.json configs[4])", "kernel": "kt_tsdf23_kernel",
-            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": committed_traffic("farwall768")[0], "traffic_ratio": committed_traffic("farwall768")[1],
-            "traffic_source": committed_traffic("farwall768")[2],
-            "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n, "U_voxels_updated": U, "frame_ms": round(frame_ms, 3)}
+    traffic = committed_traffic("farwall768")
+    out = {"workload": "farwall768: 1280x960 synthetic far-wall sequence, static mode, 768^3 TSDF (BASELINE.json configs[4])", "kernel": "kt_tsdf23_kernel",
+           "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+           "frac_is": "alone: frames one at a time, no read-ahead stream next to the launch (frac_pipelined = with it, as the headline's region)",
+           "frac_alone": frac(ms), "avg_launch_ms_alone": ms,
+           "frac_pipelined": frac(ms_p), "avg_launch_ms_pipelined": ms_p, "launches_timed_pipelined": n_p, "frame_ms_pipelined": round(frame_ms_p, 3),
+           "traffic": traffic[0], "traffic_ratio": traffic[1], "traffic_source": traffic[2],
+           "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n, "U_voxels_updated": U, "frame_ms": round(frame_ms, 3)}
+    if tol:
+        out["survey8c"] = {"kernel": "kt_tsdf23_tol_kernel", "frac_alone": frac(tol[0][0]), "avg_launch_ms_alone": tol[0][0],
+                           "frac_pipelined": frac(tol[1][0]), "avg_launch_ms_pipelined": tol[1][0]}
+    return out
 
 
 def cpu_baseline(cam, N, d, frames, nframes, gpu_poses=()):

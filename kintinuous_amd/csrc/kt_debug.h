@@ -39,6 +39,9 @@ int kt_tracker_debug_plan_truth(kt_tracker* trk, const float* poses12n, int n_fr
 /* test / A-B hook: selects the voxel kernel of kt_integrate_tsdf and the tracker for N < 1024: 1 = kt_tsdf23_lean_kernel (round 4), 0 = the
  * round-3 kernel, -1 = back to the default (KT_TSDF_LEAN in the environment, else the build's).  Both store the same bits. */
 int kt_debug_tsdf_lean(int on);
+/* the arithmetic contract of the lean voxel kernel: 0 = bit-exact (default), 1 = "survey-8c" (kt_tsdf23_tol_kernel: SURVEY.md 8(c)'s parity
+ * policy -- tsdf shorts within 1, colour bytes within 1 at near-ties, weights and voxel / pixel indices exact), -1 = environment / default */
+int kt_debug_tsdf_contract(int tol);
 const char* kt_debug_tsdf_kernel(void);   /* name of the voxel kernel the next N < 1024 launch uses (bench.py reports it) */
 /* test hook: the voxel kernel's division shortcut (table reciprocal + one correction) against the IEEE division for every finite float
  * numerator and every divisor 1..256: out_host = {mismatches, float bits of the largest |numerator| among them, mismatches at |n| >= 2^-100} */
@@ -63,6 +66,9 @@ int kt_debug_rcp_check(kt_ctx* ctx, unsigned int* mismatches_host);
  * their hand-off sweep gives up after spin_limit looks (0: unchanged) and the caller is told KT_ERR_STATE; dirty_out (optional) = number
  * of reduction granules that are not the sentinel once the context's stream has drained (0 = the buffer is clean for the next launch) */
 int kt_debug_handoff_fault(kt_ctx* ctx, int skip, int count, unsigned int spin_limit, unsigned int* dirty_out);
+/* host arithmetic behind the ICP row's threshold tests (csrc/kt_track.hip: kt_icp_set_thresholds): the largest float X with
+ * sqrtf(X) <= T (strict = 0) or sqrtf(X) < T (strict = 1), -1 when there is none */
+float kt_debug_sq_threshold(float T, int strict);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,8 @@
 #include "kt_internal.hpp"
 
 #include <string.h>
+#include <float.h>
+#include <math.h>
 
 // ------------------------------------------------------------------------------------------------
 // block / grid reduction
@@ -345,6 +347,10 @@ struct kt_icp_args {
     kt_intr intr;
     int cols, rows;
     float dist_thres, angle_thres;
+    // the two thresholds on the SQUARES (kt_icp_set_thresholds): sqrtf is correctly rounded and monotone, so "sqrtf(x) <= T" is "x <= X" for
+    // the largest float X whose root is <= T, and "sqrtf(x) < A" is "x <= X'" for the largest float whose root is < A -- found once per
+    // launch on the host, instead of two 16-instruction IEEE square roots per pixel (reduce.cu:247-253)
+    float dist2_le, sine2_le;
     // pose: either immediate (host path) or read from the device state (device-resident path)
     kt_mat33 Rcurr; float tcurr[3];
     kt_mat33 Rprev_inv; float tprev[3];
@@ -392,10 +398,10 @@ struct kt_icp_row {
     {
         const f3 ncurr_g = kt_mul(Rcurr, ncurr);
         const f3 dv = kt_sub(vprev_g, vcurr_g);
-        const float dist = __builtin_sqrtf(kt_dot(dv, dv));
+        const float dist2 = kt_dot(dv, dv);                       // dist = sqrtf(dist2) <= dist_thres   <=>  dist2 <= dist2_le
         const f3 cr = kt_cross(ncurr_g, nprev_g);
-        const float sine = __builtin_sqrtf(kt_dot(cr, cr));
-        const bool found = inimg && (sine < a.angle_thres && dist <= a.dist_thres && !kt_isnan(ncurr.x) && !kt_isnan(nprev_g.x));
+        const float sine2 = kt_dot(cr, cr);                       // sine = sqrtf(sine2) < angle_thres   <=>  sine2 <= sine2_le
+        const bool found = inimg && (sine2 <= a.sine2_le && dist2 <= a.dist2_le && !kt_isnan(ncurr.x) && !kt_isnan(nprev_g.x));
         const f3 s_cp = kt_mul(Rprev_inv, kt_sub(vcurr_g, tprev));
         const f3 d_cp = kt_mul(Rprev_inv, kt_sub(vprev_g, tprev));
         const f3 n_cp = kt_mul(Rprev_inv, nprev_g);
@@ -416,6 +422,29 @@ struct kt_icp_row {
         return finish(ncurr, vcurr_g, vprev_g, nprev_g, inimg, row);
     }
 };
+
+// X = the largest float with sqrtf(X) <= T (strict = 0) or sqrtf(X) < T (strict = 1); -1 when no x >= 0 qualifies (then "x <= X" is false for
+// every sum of squares, and for NaN, as the comparison of the root was).  sqrtf on the host is the correctly rounded IEEE root, like the
+// device's __builtin_sqrtf it replaces; a NaN threshold makes every comparison false on both sides.  tests/test_host_logic.py walks the
+// neighbours of X for a spread of thresholds.
+extern "C" float kt_debug_sq_threshold(float T, int strict)
+{
+    if (!(T >= 0.0f) || (strict && !(T > 0.0f))) return -1.0f;
+    if (T == INFINITY) return strict ? FLT_MAX : INFINITY;
+    const auto ok = [&](float x) { const float r = sqrtf(x); return strict ? r < T : r <= T; };
+    float x = T * T;
+    if (x == INFINITY) x = FLT_MAX;
+    while (x > 0.0f && !ok(x)) x = nextafterf(x, -INFINITY);
+    if (!ok(x)) return -1.0f;   // (strict, T the smallest denormal: not even 0 ... sqrtf(0) = 0 < T holds, so this cannot happen; kept for clarity)
+    while (x < FLT_MAX && ok(nextafterf(x, INFINITY))) x = nextafterf(x, INFINITY);
+    return x;
+}
+static void kt_icp_set_thresholds(kt_icp_args& a, float dist_thres, float angle_thres)
+{
+    a.dist_thres = dist_thres; a.angle_thres = angle_thres;
+    a.dist2_le = kt_debug_sq_threshold(dist_thres, 0);
+    a.sine2_le = kt_debug_sq_threshold(angle_thres, 1);
+}
 
 __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_args a)
 {
@@ -516,7 +545,7 @@ extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3
     KT_ARG(cols > 0 && rows > 0);
     kt_icp_args a;
     a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
-    a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
+    a.intr = *intr; a.cols = cols; a.rows = rows; kt_icp_set_thresholds(a, dist_thres, angle_thres);
     a.Rcurr = *Rcurr; a.Rprev_inv = *Rprev_inv;
     for (int k = 0; k < 3; ++k) { a.tcurr[k] = tcurr[k]; a.tprev[k] = tprev[k]; }
     a.state = nullptr; a.first = 0; a.out29 = c->red_out; a.mode = KT_MODE_HOST; a.keep29 = 0;
@@ -535,7 +564,7 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
 {
     kt_icp_args a;
     a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
-    a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
+    a.intr = *intr; a.cols = cols; a.rows = rows; kt_icp_set_thresholds(a, dist_thres, angle_thres);
     a.state = state; a.out29 = nullptr; a.mode = mode;
     a.first = 0;
     a.keep29 = keep29;
@@ -1007,7 +1036,7 @@ int kt_joint_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_cur
 {
     kt_icp_args a;
     a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
-    a.intr = *intr; a.cols = cols; a.rows = rows; a.dist_thres = dist_thres; a.angle_thres = angle_thres;
+    a.intr = *intr; a.cols = cols; a.rows = rows; kt_icp_set_thresholds(a, dist_thres, angle_thres);
     a.state = state; a.out29 = nullptr; a.mode = KT_MODE_ICP_STASH; a.first = 0; a.keep29 = 0;
     a.granules = kt_second_granules(c);
     a.fault = 0;

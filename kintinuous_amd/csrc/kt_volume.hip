@@ -1209,7 +1209,15 @@ __device__ __forceinline__ float kt_min1(float x)   // min(1, x) as one v_min_f3
     return r;
 }
 
-template <bool COUNT, bool FAST, bool NT>
+// TOL: the second, explicitly named arithmetic contract of the voxel kernel ("survey-8c": SURVEY.md 8(c)'s parity policy and north_star's
+// 1e-4 on floats instead of every stored bit; VERDICT r4 item 2 iii).  What it drops: the correctly rounded square root inside the
+// truncation band (v_sqrt_f32, <= 1 ulp, everywhere), the Markstein correction of the running average (q = n * RN(1 / d): <= 1 ulp),
+// the residual test of the colour blend (k = rint(n * v_rcp_f32(den)): wrong only next to a .5 tie).  What it keeps: the projection's
+// exact reciprocal (the PIXEL a voxel reads must not change: "bit-exact on voxel indices"), every predicate, weight and store rule.
+// Consequences, counted by tests/test_gpu_tol.py against the bit-exact kernel at BASELINE configs 2 / 3 / 5: tsdf shorts differ by at
+// most 1 on a small fraction of the touched voxels, colour bytes by at most 1 at near-ties, weights never.  The bit-exact kernel stays
+// the default of the library, of every parity test and of bench.py's headline.
+template <bool COUNT, bool FAST, bool NT, bool TOL = false>
 __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, const kt_tsdf_bufs& m, const kt_tsdf_ztab* __restrict__ s_tab,
                                                    const float* __restrict__ s_rcp, int zb, int rem, unsigned int col_base2, int brick_xy,
                                                    float v_z, float& v_x, float& v_y, float dvx, float dvy, float r8, float v_g_part_norm,
@@ -1268,10 +1276,12 @@ __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, c
         float sdf = Dp_scaled - __builtin_amdgcn_sqrtf(r2[u]);
         const float t = sdf * tranc_dist_inv;
         const bool live = in_img[u] & (rec[u].dp != 0);
-        const bool band = live & (t <= 1.001f) & (t >= -1.001f);   // NaN (never: r2 >= 0) falls out
-        if (__builtin_amdgcn_ballot_w64(band) != 0) {
-            asm volatile("; exact sqrt" ::: "memory");  // a real branch: if-converted, the 16-instruction correctly rounded sqrt runs for every voxel
-            if (band) sdf = Dp_scaled - __builtin_sqrtf(r2[u]);
+        if constexpr (!TOL) {
+            const bool band = live & (t <= 1.001f) & (t >= -1.001f);   // NaN (never: r2 >= 0) falls out
+            if (__builtin_amdgcn_ballot_w64(band) != 0) {
+                asm volatile("; exact sqrt" ::: "memory");  // a real branch: if-converted, the 16-instruction correctly rounded sqrt runs for every voxel
+                if (band) sdf = Dp_scaled - __builtin_sqrtf(r2[u]);
+            }
         }
         upd[u] = live & (sdf >= -a.tranc_dist);   // free space: sdf > 1.001 trunc; behind the band: sdf < -1.001 trunc -- the approximate root decides both
         tv[u] = kt_min1(sdf * tranc_dist_inv);
@@ -1297,7 +1307,8 @@ __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, c
             const float num = __builtin_fmaf(tsdf_prev, weight_prev, tv[u]), den = weight_prev + 1.0f;
             const float y = *(const float*)((const char*)s_rcp + ((c >> 22) & 0x3fcu));   // s_rcp[c >> 24]
             const float q0 = num * y;
-            const short packed = kt_pack_tsdf(__builtin_fmaf(__builtin_fmaf(-den, q0, num), y, q0));
+            const short packed = kt_pack_tsdf(TOL ? q0 : __builtin_fmaf(__builtin_fmaf(-den, q0, num), y, q0));
+            (void)den;
             if ((unsigned int)(unsigned short)packed != raw[u]) {   // an unchanged word is not written back
                 __builtin_amdgcn_raw_buffer_store_b16(packed, m.vol, toff[u], 0, NT ? 2 : KT_TSDF_ST_AUX);
                 if (a.bricks && packed < 0) a.bricks[s_tab[zb + u].bz + brick_xy] = 1;  // idempotent byte store (rare: the table is re-read here)
@@ -1321,19 +1332,24 @@ __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, c
             // candidates k = the integer nearest n * rden, formed as MAGIC + k in one FMA (any integer next to the quotient will do: the
             // residual test below is what licenses it)
             float yx = __builtin_fmaf(nx, rden, KT_RNE_MAGIC), yy = __builtin_fmaf(ny, rden, KT_RNE_MAGIC), yz = __builtin_fmaf(nz, rden, KT_RNE_MAGIC);
-            const float kx = yx - KT_RNE_MAGIC, ky = yy - KT_RNE_MAGIC, kz = yz - KT_RNE_MAGIC;
-            const float lim = 0.4999f * den;
-            // candidate accepted when the FMA residual |n - k den| < 0.4999 den (then the exact quotient rounds to k); false for NaN
-            const bool safe = (fabsf(__builtin_fmaf(-kx, den, nx)) < lim) & (fabsf(__builtin_fmaf(-ky, den, ny)) < lim) &
-                              (fabsf(__builtin_fmaf(-kz, den, nz)) < lim);
-            if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
-                asm volatile("; exact blend" ::: "memory");
-                if (!safe) {
-                    yx = (float)min(255, max(0, kt_f2i_rn(nx / den))) + KT_RNE_MAGIC;
-                    yy = (float)min(255, max(0, kt_f2i_rn(ny / den))) + KT_RNE_MAGIC;
-                    yz = (float)min(255, max(0, kt_f2i_rn(nz / den))) + KT_RNE_MAGIC;
+            if constexpr (!TOL) {
+                const float kx = yx - KT_RNE_MAGIC, ky = yy - KT_RNE_MAGIC, kz = yz - KT_RNE_MAGIC;
+                const float lim = 0.4999f * den;
+                // candidate accepted when the FMA residual |n - k den| < 0.4999 den (then the exact quotient rounds to k); false for NaN
+                const bool safe = (fabsf(__builtin_fmaf(-kx, den, nx)) < lim) & (fabsf(__builtin_fmaf(-ky, den, ny)) < lim) &
+                                  (fabsf(__builtin_fmaf(-kz, den, nz)) < lim);
+                if (__builtin_amdgcn_ballot_w64(!safe) != 0) {
+                    asm volatile("; exact blend" ::: "memory");
+                    if (!safe) {
+                        yx = (float)min(255, max(0, kt_f2i_rn(nx / den))) + KT_RNE_MAGIC;
+                        yy = (float)min(255, max(0, kt_f2i_rn(ny / den))) + KT_RNE_MAGIC;
+                        yz = (float)min(255, max(0, kt_f2i_rn(nz / den))) + KT_RNE_MAGIC;
+                    }
                 }
             }
+            // (TOL: the candidates are taken as they are.  Quotients lie in [0, 255], so a candidate is 0..255 or, next to 255.5, never 256:
+            // n <= 255 den.  den = 0 -- weight 0 and Wrkc 0 -- makes n * rden = 0 * inf the default NaN, whose low byte is 0: what the exact
+            // kernel's rn(NaN) stores too.)
             // k in 0..255 sits in the low byte of MAGIC + k
             o = (o & 0xff000000u) | (__float_as_uint(yx) & 0xffu) | ((__float_as_uint(yy) & 0xffu) << 8) | ((__float_as_uint(yz) & 0xffu) << 16);
         }
@@ -1355,8 +1371,8 @@ __device__ unsigned long long kt_tsdf_tl[KT_TSDF_WAVES * KT_TL_WORDS];
 #endif
 // FP: the pose and the parked flag come from the device (kt_frame_params, the tracker) -- a compile-time property so that the start-up
 // has no pointer test in front of its loads.
-template <bool COUNT, bool NT, bool FP>
-__global__ __launch_bounds__(64 * KT_TSDF_WPB, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_kernel(const kt_tsdf_lean_args a_in)
+template <bool COUNT, bool NT, bool FP, bool TOL>
+__device__ __forceinline__ void kt_tsdf23_lean_body(const kt_tsdf_lean_args& a_in)
 {
 #ifdef KT_TSDF_TIMELINE
     unsigned long long* tl = &kt_tsdf_tl[(size_t)(blockIdx.x * KT_TSDF_WPB + (threadIdx.x >> 6)) * KT_TL_WORDS];
@@ -1481,13 +1497,13 @@ __global__ __launch_bounds__(64 * KT_TSDF_WPB, COUNT ? 6 : KT_TSDF_OCC) void kt_
         if (fast) {
             if (lane_ok & (d_a > 0)) {   // lanes behind the camera plane (1 / d < 0) never pass the in-image test
                 for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
-                    kt_tsdf_batch_lean<COUNT, true, NT>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
+                    kt_tsdf_batch_lean<COUNT, true, NT, TOL>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
                     KT_TL(4);
                 }
             }
         } else if (lane_ok) {
             for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
-                kt_tsdf_batch_lean<COUNT, false, NT>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
+                kt_tsdf_batch_lean<COUNT, false, NT, TOL>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
             }
         }
         if (COUNT) { n_batches += (unsigned int)((wz1 - wz0 + KT_TSDF_UNROLL - 1) / KT_TSDF_UNROLL); ++n_tasks_done; }
@@ -1502,6 +1518,17 @@ __global__ __launch_bounds__(64 * KT_TSDF_WPB, COUNT ? 6 : KT_TSDF_OCC) void kt_
             if (n_img) atomicAdd(a.updated + 3, n_img);
         }
     }
+}
+// the two contracts as two kernels, so that a profile names the one that ran
+template <bool COUNT, bool NT, bool FP>
+__global__ __launch_bounds__(64 * KT_TSDF_WPB, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_kernel(const kt_tsdf_lean_args a_in)
+{
+    kt_tsdf23_lean_body<COUNT, NT, FP, false>(a_in);
+}
+template <bool COUNT, bool NT, bool FP>
+__global__ __launch_bounds__(64 * KT_TSDF_WPB, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_tol_kernel(const kt_tsdf_lean_args a_in)
+{
+    kt_tsdf23_lean_body<COUNT, NT, FP, true>(a_in);
 }
 
 // scratch owned by the context for integrate (pixel records, z tables, intervals, task list), grown on demand
@@ -1657,7 +1684,19 @@ extern "C" int kt_debug_tsdf_timeline(kt_ctx* c, unsigned long long* out_host, i
     return -KT_ERR_STATE;
 #endif
 }
-extern "C" const char* kt_debug_tsdf_kernel(void) { return kt_tsdf_lean_selected() ? "kt_tsdf23_lean_kernel" : "kt_tsdf23_kernel"; }
+// which arithmetic contract the lean voxel kernel runs under: 0 = bit-exact (the default), 1 = survey-8c (kt_tsdf23_tol_kernel, above);
+// -1 = back to the environment's (KT_TSDF_CONTRACT=survey8c) or the default.  Only the lean kernel has the second contract.
+static int kt_tsdf_contract_override = -1;
+extern "C" int kt_debug_tsdf_contract(int tol) { kt_tsdf_contract_override = tol < 0 ? -1 : (tol != 0); return KT_OK; }
+static bool kt_tsdf_tol_selected()
+{
+    static const bool env = []() { const char* e = getenv("KT_TSDF_CONTRACT"); return e && (!strcmp(e, "survey8c") || !strcmp(e, "survey-8c") || !strcmp(e, "tol")); }();
+    return kt_tsdf_lean_selected() && (kt_tsdf_contract_override < 0 ? env : kt_tsdf_contract_override != 0);
+}
+extern "C" const char* kt_debug_tsdf_kernel(void)
+{
+    return kt_tsdf_lean_selected() ? (kt_tsdf_tol_selected() ? "kt_tsdf23_tol_kernel" : "kt_tsdf23_lean_kernel") : "kt_tsdf23_kernel";
+}
 
 // shared by the C entry point and the tracker (which wants the update count for the roofline report)
 int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int rows, const kt_intr* intr,
@@ -1746,7 +1785,10 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
         static const int nt_env = []() { const char* e = getenv("KT_TSDF_NT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
         const bool nt = nt_env >= 0 ? nt_env != 0 : a.wcl == 5;
         const dim3 lb(64 * KT_TSDF_WPB), lg(KT_TSDF_WAVES / KT_TSDF_WPB);
-#define KT_LEAN_LAUNCH(C, T) do { if (l.fp) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, true>), lg, lb, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, false>), lg, lb, lds, c->stream, l); } while (0)
+        const bool tol = kt_tsdf_tol_selected();
+#define KT_LEAN_LAUNCH(C, T) do { \
+            if (tol) { if (l.fp) hipLaunchKernelGGL((kt_tsdf23_tol_kernel<C, T, true>), lg, lb, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_tol_kernel<C, T, false>), lg, lb, lds, c->stream, l); } \
+            else { if (l.fp) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, true>), lg, lb, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, false>), lg, lb, lds, c->stream, l); } } while (0)
         if (updated_dev) { if (nt) KT_LEAN_LAUNCH(true, true); else KT_LEAN_LAUNCH(true, false); }
         else { if (nt) KT_LEAN_LAUNCH(false, true); else KT_LEAN_LAUNCH(false, false); }
 #undef KT_LEAN_LAUNCH

@@ -300,3 +300,33 @@ def test_bench_gpus_2_starts_two_ranks(form, tmp_path):
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 == j["gpus_flag"] and j["highest_rank_seen"] == 1
+
+
+def test_squared_thresholds_of_the_icp_row_are_equivalent_to_the_roots():
+    """csrc/kt_track.hip compares the SQUARES dist^2 / sine^2 with thresholds found once on the host instead of taking two correctly rounded
+    square roots per pixel (reduce.cu:247-253: `sine < angleThres && dist <= distThres`).  Equivalence, checked where it can fail -- at the
+    threshold's neighbours: for X = kt_debug_sq_threshold(T, strict), every float x within 64 ulps of X satisfies
+    (sqrtf(x) <= T) == (x <= X)   [strict: (sqrtf(x) < T) == (x <= X)], and the corner cases (0, denormals, huge, inf, NaN, negative)."""
+    import ctypes as C
+    from kintinuous_amd import abi, build
+    build.build()
+    l = C.CDLL(abi.LIB_PATH)
+    f = l.kt_debug_sq_threshold
+    f.restype, f.argtypes = C.c_float, [C.c_float, C.c_int]
+    rng = np.random.default_rng(11)
+    Ts = np.concatenate([np.float32([0.10, 0.34202015, 0.05, 1.0, 2.0, 1e-3, 3.0e-20, 1e19, 0.5, 0.70710677, 1.1754944e-38, 1e-45, 3.4e38]),
+                         (10.0 ** rng.uniform(-18, 18, 400)).astype(np.float32), rng.uniform(0.0, 1.0, 400).astype(np.float32)])
+    for T in Ts.tolist():
+        T = float(np.float32(T))
+        for strict in (0, 1):
+            X = np.float32(f(T, strict))
+            assert X >= 0
+            bits = int(X.view(np.uint32))
+            lo, hi = max(0, bits - 64), min(0x7f7fffff, bits + 64)
+            xs = np.arange(lo, hi + 1, dtype=np.uint32).view(np.float32)
+            roots = np.sqrt(xs)                                  # numpy's float32 sqrt is the correctly rounded IEEE root
+            want = (roots < np.float32(T)) if strict else (roots <= np.float32(T))
+            assert np.array_equal(want, xs <= X), (T, strict, X)
+    assert f(0.0, 0) == 0.0 and f(0.0, 1) == -1.0                # sqrtf(x) <= 0 only at 0; sqrtf(x) < 0 never
+    assert f(-1.0, 0) == -1.0 and f(float("nan"), 0) == -1.0 and f(float("nan"), 1) == -1.0
+    assert f(float("inf"), 0) == float("inf") and np.float32(f(float("inf"), 1)) == np.finfo(np.float32).max
