@@ -47,73 +47,80 @@ struct kt_integrate_tables {  // incremental z walk of tsdf23 (quirk A.17), iden
     float* zs;       // z_scaled after z increments
 };
 
+// One workgroup = a 32-pixel-wide strip of `passes` x 8 rows.  With tile_raw set (the tracker's read-ahead path) passes x 8 is the tile edge T of
+// the depth-range map (8, 16 or 32: kt_dpt_log2), so a workgroup covers 32 / T whole tiles and leaves their raw maxima of |scaled depth| --
+// round 4 spent a launch of its own on them (kt_tile_max_kernel: 5 us of launch latency on the read-ahead stream).
 __global__ __launch_bounds__(256) void kt_scale_depth_kernel(const uint16_t* __restrict__ depth, float* __restrict__ scaled,
                                                              kt_pixrec* __restrict__ rec, const uint8_t* __restrict__ colors,
                                                              const float* __restrict__ nmap, int cols, int rows, kt_intr intr,
-                                                             int angle_color)
+                                                             int angle_color, int passes, float* __restrict__ tile_raw, int tl2, int tcols)
 {
-    int x = threadIdx.x + blockIdx.x * blockDim.x;
-    int y = threadIdx.y + blockIdx.y * blockDim.y;
-    if (x >= cols || y >= rows) return;
-    int Dp = depth[y * cols + x];
-    float xl = ((float)x - intr.cx) / intr.fx;
-    float yl = ((float)y - intr.cy) / intr.fy;
-    float lambda = __builtin_sqrtf(__builtin_fmaf(xl, xl, yl * yl) + 1);
-    float out;
-    if (angle_color) {
-        const int ky = 7, kx = 7;
-        int ty = min(y - ky / 2 + ky, rows - 1);
-        int tx = min(x - kx / 2 + kx, cols - 1);
-        int count = 0;
-        for (int cy = max(y - ky / 2, 0); cy < ty; ++cy)
-            for (int cx = max(x - kx / 2, 0); cx < tx; ++cx)
-                if (abs(Dp - (int)depth[cy * cols + cx]) > 200 || Dp == 0) count++;
-        out = (count > 5) ? (float)(-Dp) * lambda / 1000.f : (float)Dp * lambda / 1000.f;
-    } else
-        out = (float)Dp * lambda / 1000.f;
-    scaled[y * cols + x] = out;
-    if (rec) {
-        float nx = nmap[y * cols + x];
-        float nz = nmap[(y + 2 * rows) * cols + x];
-        if (nz < 0) nz = -nz;
-        kt_pixrec r;
-        r.dp = out;
-        r.wrkc = (angle_color ? fminf(1.0f, nz / KT_RGB_VIEW_ANGLE_WEIGHT) : 1.0f) * 2.0f;
-        const uint8_t* c = &colors[3 * (y * cols + x)];
-        r.rgbf = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | (kt_isnan(nx) ? KT_REC_NORMAL_NAN : 0u) |
-                 ((angle_color && kt_isnan(nx)) ? KT_REC_STALE_NZ : 0u);
+    __shared__ unsigned int s_tile[4];   // raw maxima of the strip's tiles, as the bit patterns of non-negative floats (ordered like them)
+    if (tile_raw) {
+        if (threadIdx.y == 0 && threadIdx.x < 4) s_tile[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    const int x = threadIdx.x + blockIdx.x * blockDim.x;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int y = threadIdx.y + (blockIdx.y * passes + pass) * blockDim.y;
+        float out = 0.0f;
+        if (x < cols && y < rows) {
+            int Dp = depth[y * cols + x];
+            float xl = ((float)x - intr.cx) / intr.fx;
+            float yl = ((float)y - intr.cy) / intr.fy;
+            float lambda = __builtin_sqrtf(__builtin_fmaf(xl, xl, yl * yl) + 1);
+            if (angle_color) {
+                const int ky = 7, kx = 7;
+                int ty = min(y - ky / 2 + ky, rows - 1);
+                int tx = min(x - kx / 2 + kx, cols - 1);
+                int count = 0;
+                for (int cy = max(y - ky / 2, 0); cy < ty; ++cy)
+                    for (int cx = max(x - kx / 2, 0); cx < tx; ++cx)
+                        if (abs(Dp - (int)depth[cy * cols + cx]) > 200 || Dp == 0) count++;
+                out = (count > 5) ? (float)(-Dp) * lambda / 1000.f : (float)Dp * lambda / 1000.f;
+            } else
+                out = (float)Dp * lambda / 1000.f;
+            scaled[y * cols + x] = out;
+            if (rec) {
+                float nx = nmap[y * cols + x];
+                float nz = nmap[(y + 2 * rows) * cols + x];
+                if (nz < 0) nz = -nz;
+                kt_pixrec r;
+                r.dp = out;
+                r.wrkc = (angle_color ? fminf(1.0f, nz / KT_RGB_VIEW_ANGLE_WEIGHT) : 1.0f) * 2.0f;
+                const uint8_t* c = &colors[3 * (y * cols + x)];
+                r.rgbf = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | (kt_isnan(nx) ? KT_REC_NORMAL_NAN : 0u) |
+                         ((angle_color && kt_isnan(nx)) ? KT_REC_STALE_NZ : 0u);
 #if KT_REC_BYTES == 16
-        r.pad = 0;
+                r.pad = 0;
 #endif
-        rec[y * cols + x] = r;
+                rec[y * cols + x] = r;
+            }
+        }
+        if (tile_raw) {
+            // a wave is two rows of 32 pixels; a tile takes 2^tl2 consecutive lanes of each: fold them, then one LDS atomic per tile and row
+            float m = fabsf(out);   // (0 outside the image)
+            for (int off = 1; off < (1 << tl2) && off < 32; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            if ((threadIdx.x & ((1 << tl2) - 1)) == 0) atomicMax(&s_tile[threadIdx.x >> tl2], __float_as_uint(m));
+        }
+    }
+    if (tile_raw) {
+        __syncthreads();
+        const int g = threadIdx.x, tx = (blockIdx.x * 32 >> tl2) + g;
+        if (threadIdx.y == 0 && g < (32 >> tl2) && tx < tcols) tile_raw[blockIdx.y * tcols + tx] = __uint_as_float(s_tile[g]);
     }
 }
 
 // Coarse map of the largest |scaled depth| per T x T pixel tile: lets the interval pre-pass bound, per voxel column, how far
 // from the camera an update is still possible (sdf >= -trunc needs |v| <= Dp + trunc).  One wave per tile.  T = 8, 16 or 32: the
 // smallest that keeps the map within KT_DPT_MAX_TILES entries (it is staged in LDS by the interval kernel): 8 at 640x480, 16 at 1280x960.
+// The raw maxima come out of kt_scale_depth_kernel itself (round 5).
 #define KT_DPT_MAX_TILES 8192
 static int kt_dpt_log2(int cols, int rows)
 {
     for (int l = 3; l <= 5; ++l)
         if (kt_div_up(cols, 1 << l) * kt_div_up(rows, 1 << l) <= KT_DPT_MAX_TILES && kt_div_up(cols, 32) * kt_div_up(rows, 32) <= 2048) return l;
     return 0;   // too many tiles even at 32 x 32: no depth-range prune
-}
-__global__ __launch_bounds__(256) void kt_tile_max_kernel(const kt_pixrec* __restrict__ rec, int cols, int rows, float* __restrict__ dpmax, int tl2, int tcols,
-                                                          int ntiles)
-{
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (tile >= ntiles) return;
-    const int T = 1 << tl2;
-    const int x0 = (tile % tcols) * T, y0 = (tile / tcols) * T;
-    float m = 0.0f;
-    for (int i = lane; i < T * T; i += 64) {
-        const int x = x0 + (i & (T - 1)), y = y0 + (i >> tl2);
-        if (x < cols && y < rows) m = fmaxf(m, fabsf(rec[y * cols + x].dp));
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if (lane == 0) dpmax[tile] = m;
 }
 // What the interval pre-pass looks up is the DILATED map: entry (tx, ty) = the largest raw maximum of the 3 x 3 tiles around it, so that a
 // piece of a column whose padded pixel bounding box is at most two tiles wide is bounded by the ONE entry under its centre.  Layout of the
@@ -122,24 +129,26 @@ __global__ __launch_bounds__(256) void kt_tile_max_kernel(const kt_pixrec* __res
 #define KT_DPT_COARSE_TILES 2048
 #define KT_DPT_RAW (KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES + 1)
 #define KT_DPT_FLOATS (KT_DPT_RAW + KT_DPT_MAX_TILES)
-__global__ __launch_bounds__(256) void kt_tile_dilate_kernel(float* __restrict__ dpmax, int tcols, int trows)
+// ONE workgroup finishes the map from the raw fine maxima (round 4: a dilation launch and a coarse launch, 5 us of launch latency each):
+// raw fine map into LDS; its 3 x 3 dilation out; raw 32 x 32 pixel maxima from the LDS copy, their dilation and the overall maximum out.
+__global__ __launch_bounds__(1024) void kt_tile_finish_kernel(float* __restrict__ dpmax, int tl2, int tcols, int trows, int tc32, int tr32)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= tcols * trows) return;
-    const int tx = i % tcols, ty = i / tcols;
-    float v = 0.0f;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int x = tx + dx, y = ty + dy;
-            if (x >= 0 && x < tcols && y >= 0 && y < trows) v = fmaxf(v, dpmax[KT_DPT_RAW + y * tcols + x]);
-        }
-    dpmax[i] = v;
-}
-// one workgroup: raw 32 x 32 pixel maxima into LDS, their dilation and the overall maximum out
-__global__ __launch_bounds__(1024) void kt_tile_max_coarse_kernel(float* __restrict__ dpmax, int tl2, int tcols, int trows, int tc32, int tr32)
-{
+    __shared__ float raw[KT_DPT_MAX_TILES];
     __shared__ float raw32[KT_DPT_COARSE_TILES];
     __shared__ float wmax[16];
+    const int n = tcols * trows;
+    for (int i = threadIdx.x; i < n; i += 1024) raw[i] = dpmax[KT_DPT_RAW + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int tx = i % tcols, ty = i / tcols;
+        float v = 0.0f;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = tx + dx, y = ty + dy;
+                if (x >= 0 && x < tcols && y >= 0 && y < trows) v = fmaxf(v, raw[y * tcols + x]);
+            }
+        dpmax[i] = v;
+    }
     const int f = 5 - tl2;
     float all = 0.0f;
     for (int i = threadIdx.x; i < tc32 * tr32; i += 1024) {
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(1024) void kt_tile_max_coarse_kernel(float* __restr
         for (int dy = 0; dy < (1 << f); ++dy)
             for (int dx = 0; dx < (1 << f); ++dx) {
                 const int tx = (cx << f) + dx, ty = (cy << f) + dy;
-                if (tx < tcols && ty < trows) v = fmaxf(v, dpmax[KT_DPT_RAW + ty * tcols + tx]);
+                if (tx < tcols && ty < trows) v = fmaxf(v, raw[ty * tcols + tx]);
             }
         raw32[i] = v;
         all = fmaxf(all, v);
@@ -173,12 +182,17 @@ __global__ __launch_bounds__(1024) void kt_tile_max_coarse_kernel(float* __restr
         dpmax[KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES] = all;
     }
 }
-static void kt_launch_tile_max(kt_ctx* c, const kt_pixrec* rec, int cols, int rows, float* dpmax, int tl2)
+// scaleDepth + the pixel records and, when a depth-range map is wanted, its raw tile maxima from the same launch and the finishing launch
+static void kt_launch_scale_depth(kt_ctx* c, const uint16_t* depth_raw, float* depth_raw_scaled, kt_pixrec* rec, const uint8_t* colors, const float* nmap_curr,
+                                  int cols, int rows, const kt_intr& intr, int angle_color, float* dpmax)
 {
-    const int tcols = kt_div_up(cols, 1 << tl2), trows = kt_div_up(rows, 1 << tl2), ntiles = tcols * trows;
-    hipLaunchKernelGGL(kt_tile_max_kernel, dim3(kt_div_up(ntiles, 4)), dim3(256), 0, c->stream, rec, cols, rows, dpmax + KT_DPT_RAW, tl2, tcols, ntiles);
-    hipLaunchKernelGGL(kt_tile_dilate_kernel, dim3(kt_div_up(ntiles, 256)), dim3(256), 0, c->stream, dpmax, tcols, trows);
-    hipLaunchKernelGGL(kt_tile_max_coarse_kernel, dim3(1), dim3(1024), 0, c->stream, dpmax, tl2, tcols, trows, kt_div_up(cols, 32), kt_div_up(rows, 32));
+    const int tl2 = (dpmax && rec) ? kt_dpt_log2(cols, rows) : 0;
+    const int passes = tl2 ? (1 << tl2) / 8 : 1;
+    const int tcols = tl2 ? kt_div_up(cols, 1 << tl2) : 0, trows = tl2 ? kt_div_up(rows, 1 << tl2) : 0;
+    dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8 * passes));
+    hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, rec, colors, nmap_curr, cols, rows, intr, angle_color, passes,
+                       tl2 ? dpmax + KT_DPT_RAW : nullptr, tl2, tcols);
+    if (tl2) hipLaunchKernelGGL(kt_tile_finish_kernel, dim3(1), dim3(1024), 0, c->stream, dpmax, tl2, tcols, trows, kt_div_up(cols, 32), kt_div_up(rows, 32));
 }
 
 struct kt_tsdf23_args {
@@ -191,7 +205,7 @@ struct kt_tsdf23_args {
     const unsigned int* task_count;
     const unsigned int* wrange;    // per wave-column: union of its 64 column intervals, z0 | z1 << 16
     const float2* walk0;           // per column: (v_x, v_y) of the reference walk at z = the wave-column's first z
-    const float* dpmax;            // [ceil(rows / T)][ceil(cols / T)] largest |scaled depth| per pixel tile (kt_tile_max_kernel), or null
+    const float* dpmax;            // [ceil(rows / T)][ceil(cols / T)] largest |scaled depth| per pixel tile (kt_scale_depth_kernel + kt_tile_finish_kernel), or null
     int dpt_log2;                  // log2 T (kt_dpt_log2)
     unsigned int* updated;  // optional counter (U of SURVEY 8d)
     kt_mat33 Ri;            // Rcurr_inv
@@ -1729,16 +1743,9 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
         KT_HIP(hipMemcpyAsync(sc.zs, th + sc.tabN, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
     }
     if (!prepared_rec) {  // scaleDepth + per-pixel records (a caller that ran kt_integrate_prepare ahead of time passes them in)
-        dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8));
-        hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, c->integ->rec, colors, nmap_curr,
-                           cols, rows, *intr, angle_color);
+        kt_launch_scale_depth(c, depth_raw, depth_raw_scaled, c->integ->rec, colors, nmap_curr, cols, rows, *intr, angle_color, c->integ->dpmax);
         KT_LAUNCH_CHECK();
-        prepared_dpmax = nullptr;
-        if (kt_dpt_log2(cols, rows)) {
-            kt_launch_tile_max(c, c->integ->rec, cols, rows, c->integ->dpmax, kt_dpt_log2(cols, rows));
-            KT_LAUNCH_CHECK();
-            prepared_dpmax = c->integ->dpmax;
-        }
+        prepared_dpmax = kt_dpt_log2(cols, rows) ? c->integ->dpmax : nullptr;
     }
     kt_tsdf23_args a;
     a.rec = prepared_rec ? (const kt_pixrec*)prepared_rec : c->integ->rec;
@@ -1823,14 +1830,8 @@ size_t kt_integrate_dpmax_bytes(int, int) { return sizeof(float) * (size_t)KT_DP
 int kt_integrate_prepare(kt_ctx* c, const uint16_t* depth_raw, const uint8_t* colors, const float* nmap_curr, int cols, int rows,
                          const kt_intr* intr, int angle_color, float* depth_raw_scaled, void* rec, float* dpmax)
 {
-    dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8));
-    hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, (kt_pixrec*)rec, colors, nmap_curr, cols, rows,
-                       *intr, angle_color);
+    kt_launch_scale_depth(c, depth_raw, depth_raw_scaled, (kt_pixrec*)rec, colors, nmap_curr, cols, rows, *intr, angle_color, dpmax);
     KT_LAUNCH_CHECK();
-    if (dpmax && kt_dpt_log2(cols, rows)) {
-        kt_launch_tile_max(c, (const kt_pixrec*)rec, cols, rows, dpmax, kt_dpt_log2(cols, rows));
-        KT_LAUNCH_CHECK();
-    }
     return KT_OK;
 }
 
@@ -1968,47 +1969,46 @@ struct kt_rc {
         if (!safe) { qx = px / a.cx_; qy = py / a.cy_; qz = pz / a.cz_; }
         gx = kt_f2i_rd(qx); gy = kt_f2i_rd(qy); gz = kt_f2i_rd(qz);
     }
-    // interpolateTrilineary / ...Color / ...Heat bodies, ray_caster.cu:160-296.  CH < 0: tsdf.
-    template <int CH>
-    __device__ __forceinline__ bool trilinear(float px, float py, float pz, float& out) const
+    // interpolateTrilineary / ...Color / ...Heat bodies, ray_caster.cu:160-296, ONE AXIS AT A TIME (round 5).  Everything such a call derives
+    // from a coordinate -- its voxel floor(p / cell), the in-volume test, the lower tap after the half-cell comparison, the fraction and the two
+    // wrapped storage offsets -- depends on that coordinate alone, and a hit evaluates 12 interpolations at points that share coordinates: the
+    // four colour channels sit at ONE point, and each of the six normal taps (ray_caster.cu:389-409) moves ONE coordinate of that point by a
+    // cell.  15 axis evaluations instead of 36, each with the reference's expressions (the voxel through kt_rc::voxel_fast's rule, applied
+    // per axis: floor(p * RN(1 / cell)) where provably equal to floor(RN(p / cell)), the division otherwise).
+    struct axis_t {
+        int gpre;            // floor(p / cell): getVoxel's coordinate
+        bool ok;             // 0 < gpre < N - 1 (ray_caster.cu:166-173)
+        float f;             // (p - (g + 0.5) cell) / cell for the lower tap g
+        unsigned int o[2];   // storage offset contributions of taps g and g + 1 along this axis (wrapped; x: 1, y: N, z: N^2)
+    };
+    template <int AX>
+    __device__ __forceinline__ axis_t axis(float p) const
     {
-        int gx, gy, gz;
-        voxel_fast(px, py, pz, gx, gy, gz);   // == voxel(): only floor(p / cell) is used
-        const int N = a.N;
-        if (gx <= 0 || gx >= N - 1) return false;
-        if (gy <= 0 || gy >= N - 1) return false;
-        if (gz <= 0 || gz >= N - 1) return false;
-        float vx = ((float)gx + 0.5f) * a.cx_;
-        float vy = ((float)gy + 0.5f) * a.cy_;
-        float vz = ((float)gz + 0.5f) * a.cz_;
-        gx = (px < vx) ? (gx - 1) : gx;
-        gy = (py < vy) ? (gy - 1) : gy;
-        gz = (pz < vz) ? (gz - 1) : gz;
-        // (a short form of these divisions by a launch constant -- reciprocal + two residual corrections, verified exhaustively per
+        const float cell = AX == 0 ? a.cx_ : AX == 1 ? a.cy_ : a.cz_, rcell = AX == 0 ? rcx : AX == 1 ? rcy : rcz;
+        const int w = AX == 0 ? a.wx : AX == 1 ? a.wy : a.wz, N = a.N;
+        float q = p * rcell;
+        const float fr = q - __builtin_floorf(q);
+        const bool safe = fr > 2e-4f && fr < 1.0f - 2e-4f && fabsf(q) < 1024.f;
+        if (!safe) q = p / cell;   // (wave-uniform skip when every lane is safe)
+        axis_t r;
+        int g = kt_f2i_rd(q);
+        r.gpre = g;
+        r.ok = !(g <= 0 || g >= N - 1);
+        const float v = ((float)g + 0.5f) * cell;
+        g = (p < v) ? (g - 1) : g;
+        // (a short form of this division by a launch constant -- reciprocal + two residual corrections, verified exhaustively per
         // divisor -- was measured in round 3: no difference in the kernel's time; profiles/r03_experiments.md)
-        float fa = __builtin_fmaf(-((float)gx + 0.5f), a.cx_, px) / a.cx_;
-        float fb = __builtin_fmaf(-((float)gy + 0.5f), a.cy_, py) / a.cy_;
-        float fc = __builtin_fmaf(-((float)gz + 0.5f), a.cz_, pz) / a.cz_;
-        float r[8];
-        // the 8 taps share 2 wrapped coordinates per axis (32-bit partial offsets: kt_raycast_impl requires N <= 1536)
-        unsigned int X[2], Y[2], Z[2];
+        r.f = __builtin_fmaf(-((float)g + 0.5f), cell, p) / cell;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-            int xx = gx + d + a.wx; if (xx >= N) xx -= N;
-            int yy = gy + d + a.wy; if (yy >= N) yy -= N;
-            int zz = gz + d + a.wz; if (zz >= N) zz -= N;
-            X[d] = (unsigned int)xx; Y[d] = kt_mul24((unsigned int)yy, (unsigned int)N); Z[d] = kt_mul24(kt_mul24((unsigned int)zz, (unsigned int)N), (unsigned int)N);
+            int t = g + d + w; if (t >= N) t -= N;
+            r.o[d] = AX == 0 ? (unsigned int)t : AX == 1 ? kt_mul24((unsigned int)t, (unsigned int)N) : kt_mul24(kt_mul24((unsigned int)t, (unsigned int)N), (unsigned int)N);
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int dx = (k >> 2) & 1, dy = (k >> 1) & 1, dz = k & 1;
-            const unsigned int i = Z[dz] + Y[dy] + X[dx];
-            if (CH < 0) r[k] = kt_unpack_tsdf(a.volume[i]);
-            else {
-                const uchar4 c = a.color[i];
-                r[k] = (float)(CH == 0 ? c.x : CH == 1 ? c.y : CH == 2 ? c.z : c.w);
-            }
-        }
+        return r;
+    }
+    // the 8-tap blend of interpolateTrilineary (ray_caster.cu:185-194), taps r[k] with k = 4 dx + 2 dy + dz
+    static __device__ __forceinline__ float blend(const float (&r)[8], float fa, float fb, float fc)
+    {
         const float ia = 1 - fa, ib = 1 - fb, ic = 1 - fc;
         float res = __builtin_fmaf(r[0] * ia * ib, ic, r[1] * ia * ib * fc);
         res = __builtin_fmaf(r[2] * ia * fb, ic, res);
@@ -2017,13 +2017,29 @@ struct kt_rc {
         res = __builtin_fmaf(r[5] * fa * ib, fc, res);
         res = __builtin_fmaf(r[6] * fa * fb, ic, res);
         res = __builtin_fmaf(r[7] * fa * fb, fc, res);
-        out = res;
-        return true;
+        return res;
     }
-    __device__ __forceinline__ float tsdf_at(float px, float py, float pz) const
+    // interpolateTrilineary at the point whose axes are (ax, ay, az); NaN where the reference returns "outside" (ray_caster.cu:166-173)
+    __device__ __forceinline__ float tsdf_at(const axis_t& ax, const axis_t& ay, const axis_t& az) const
     {
-        float r;
-        return trilinear<-1>(px, py, pz, r) ? r : kt_nan();
+        if (!(ax.ok && ay.ok && az.ok)) return kt_nan();
+        float r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = kt_unpack_tsdf(a.volume[az.o[k & 1] + ay.o[(k >> 1) & 1] + ax.o[(k >> 2) & 1]]);
+        return blend(r, ax.f, ay.f, az.f);
+    }
+    // interpolateTrilinearyColor for the four channels of one point (ray_caster.cu:372-378): each uchar4 tap is loaded once
+    __device__ __forceinline__ uchar4 colour_at(const axis_t& ax, const axis_t& ay, const axis_t& az) const
+    {
+        if (!(ax.ok && ay.ok && az.ok)) return make_uchar4(0, 0, 0, 0);
+        uchar4 c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = a.color[az.o[k & 1] + ay.o[(k >> 1) & 1] + ax.o[(k >> 2) & 1]];
+        float r0[8], r1[8], r2[8], r3[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { r0[k] = (float)c[k].x; r1[k] = (float)c[k].y; r2[k] = (float)c[k].z; r3[k] = (float)c[k].w; }
+        return make_uchar4(kt_f2u8_rz(blend(r0, ax.f, ay.f, az.f)), kt_f2u8_rz(blend(r1, ax.f, ay.f, az.f)), kt_f2u8_rz(blend(r2, ax.f, ay.f, az.f)),
+                           kt_f2u8_rz(blend(r3, ax.f, ay.f, az.f)));
     }
 };
 
@@ -2247,26 +2263,23 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
                 time_curr = t_cross;
                 const float tn = time_curr + a.time_step;
                 const float px = __builtin_fmaf(rd.x, tn, rs.x), py = __builtin_fmaf(rd.y, tn, rs.y), pz = __builtin_fmaf(rd.z, tn, rs.z);
-                const float Ftdt = rc.tsdf_at(px, py, pz);
+                const float Ftdt = rc.tsdf_at(rc.axis<0>(px), rc.axis<1>(py), rc.axis<2>(pz));
                 if (!kt_isnan(Ftdt)) {
                     const float qx = __builtin_fmaf(rd.x, time_curr, rs.x), qy = __builtin_fmaf(rd.y, time_curr, rs.y), qz = __builtin_fmaf(rd.z, time_curr, rs.z);
-                    const float Ft = rc.tsdf_at(qx, qy, qz);
+                    const kt_rc::axis_t qax = rc.axis<0>(qx), qay = rc.axis<1>(qy), qaz = rc.axis<2>(qz);
+                    const float Ft = rc.tsdf_at(qax, qay, qaz);
                     if (!kt_isnan(Ft)) {
                         const float Ts = time_curr - a.time_step * Ft / (Ftdt - Ft);
                         vfx = __builtin_fmaf(rd.x, Ts, rs.x); vfy = __builtin_fmaf(rd.y, Ts, rs.y); vfz = __builtin_fmaf(rd.z, Ts, rs.z);
                         hit = true;
                         out_vx = vfx;
-                        int hx, hy, hz;
-                        rc.voxel(qx, qy, qz, hx, hy, hz);
-                        float col;
-                        colr.x = rc.trilinear<0>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
-                        colr.y = rc.trilinear<1>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
-                        colr.z = rc.trilinear<2>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
-                        colr.w = rc.trilinear<3>(vfx, vfy, vfz, col) ? kt_f2u8_rz(col) : 0;
+                        const int hx = qax.gpre, hy = qay.gpre, hz = qaz.gpre;   // getVoxel(ray_start + ray_dir * time_curr), ray_caster.cu:380
+                        const kt_rc::axis_t cax = rc.axis<0>(vfx), cay = rc.axis<1>(vfy), caz = rc.axis<2>(vfz);
+                        colr = rc.colour_at(cax, cay, caz);
                         if (hx > 1 && hy > 1 && hz > 1 && hx < N - 2 && hy < N - 2 && hz < N - 2) {
-                            const float Fx1 = rc.tsdf_at(vfx + a.cx_, vfy, vfz), Fx2 = rc.tsdf_at(vfx - a.cx_, vfy, vfz);
-                            const float Fy1 = rc.tsdf_at(vfx, vfy + a.cy_, vfz), Fy2 = rc.tsdf_at(vfx, vfy - a.cy_, vfz);
-                            const float Fz1 = rc.tsdf_at(vfx, vfy, vfz + a.cz_), Fz2 = rc.tsdf_at(vfx, vfy, vfz - a.cz_);
+                            const float Fx1 = rc.tsdf_at(rc.axis<0>(vfx + a.cx_), cay, caz), Fx2 = rc.tsdf_at(rc.axis<0>(vfx - a.cx_), cay, caz);
+                            const float Fy1 = rc.tsdf_at(cax, rc.axis<1>(vfy + a.cy_), caz), Fy2 = rc.tsdf_at(cax, rc.axis<1>(vfy - a.cy_), caz);
+                            const float Fz1 = rc.tsdf_at(cax, cay, rc.axis<2>(vfz + a.cz_)), Fz2 = rc.tsdf_at(cax, cay, rc.axis<2>(vfz - a.cz_));
                             const f3 n = kt_normalized({Fx1 - Fx2, Fy1 - Fy2, Fz1 - Fz2});
                             nx = n.x; ny = n.y; nz = n.z;
                             has_normal = true;
