@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--contract", default="bit-exact", choices=["bit-exact", "survey-8c"],
                     help="arithmetic contract of the voxel kernel in the timed frames: bit-exact (kt_tsdf23_lean_kernel; the default and the one every parity "
                          "test holds) or survey-8c (kt_tsdf23_tol_kernel: SURVEY.md 8(c)'s parity policy, counted by tests/test_gpu_tol.py)")
+    ap.add_argument("--no-contract-ab", action="store_true", help="skip the untimed A/B of the voxel kernel's two contracts (profiling runs: keeps their launches out of the kernel statistics)")
     ap.add_argument("--no-stress", action="store_true", help="skip the roofline_stress block (BASELINE.json configs[4]: 1280x960 @ 768^3, 3 frames)")
     return ap.parse_args()
 
@@ -272,7 +273,7 @@ def main():
     # A/B of the voxel kernel's two contracts on this workload (untimed, alone, serial frames; after every other measurement: the volume the
     # tolerant kernel leaves behind is not used again).  Never the headline: `roofline` above is the contract the timed frames ran.
     contract_ab = None
-    if abi.lib().kt_debug_tsdf_kernel().decode() == "kt_tsdf23_lean_kernel" and rank == 0 and world == 1 and args.warmup + args.steps >= 20:
+    if abi.lib().kt_debug_tsdf_kernel().decode() == "kt_tsdf23_lean_kernel" and rank == 0 and world == 1 and args.warmup + args.steps >= 20 and not args.no_contract_ab:
         n_ab = min(args.warmup + args.steps, 60)
         def alone_ms(tol):
             abi._chk(abi.lib().kt_debug_tsdf_contract(1 if tol else 0))
@@ -369,7 +370,7 @@ def main():
         with stdout_to_stderr():
             comm.close()
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # (rank 0 at N = 1 only: the contract's cpu_baseline leg)
         # the oracle needs cpu_frames + 2 frames of the same sequence whatever --steps / --warmup are
         cframes = frames if len(frames) >= args.cpu_frames + 2 else synth.sequence(cfg_name, args.cpu_frames + 2, cam, seed)[1]
         out["cpu_baseline"] = cpu_baseline(cam, N, d, cframes, args.cpu_frames, first_poses)
@@ -389,12 +390,12 @@ def kt_volume_sha():
 
 def committed_traffic(workload):
     """HBM-side traffic of the tsdf23 launch: PMC counters cannot be read from inside the process, so this is the committed rocprofv3
-    measurement of this workload (profiles/r04_pmc_tsdf23_<workload>.json, written by scripts/pmc_traffic.sh: separate --pmc passes,
+    measurement of this workload (profiles/r05_pmc_tsdf23_<workload>.json, written by scripts/pmc_traffic.sh: separate --pmc passes,
     FETCH_SIZE x 2 after calibration on the kernel's own access pattern, WRITE_SIZE x 1, as MI355X_MICROARCH.md prescribes).  It is only
     quoted for the kernel it was measured on: the file records the sha256 of kt_volume.hip, and a stale measurement prints null.
     Returns (bytes per launch, bytes per launch / algorithmic bytes of the SAME launches, the file): the profiled run covers other frames than
     the timed region, so the ratio -- not the absolute -- is what compares with this line's algorithmic bytes."""
-    for rnd in ("r04", "r03"):
+    for rnd in ("r05", "r04", "r03"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_tsdf23_{workload}.json")
         try:
             j = json.load(open(f))

@@ -2075,7 +2075,9 @@ __device__ __forceinline__ void kt_tile_resize(const float* __restrict__ src, fl
     }
 }
 
-#define KT_RC_BATCH 4
+#ifndef KT_RC_BATCH
+#define KT_RC_BATCH 6   // samples issued together per march iteration (round 5 A/B: 2: 57.2 us, 4: 52.6, 6: 51.4, 8: 52.2 serial stage at VGA; 255 / 243 / 244 us at 1280x960 for 4 / 6 / 8)
+#endif
 #define KT_RC_MAX_BRICKS 32768   // brick flags staged in LDS (N <= 1024)
 
 // Empty-space skipping (SKIP).  The march only ever reacts to a sign change between two consecutive samples (+ -> - is the hit,

@@ -11,7 +11,7 @@ R=$GRAFT_REPO_ROOT
 run() { # name, counters...
   n=$1; shift
   rm -rf $R/gpurun_out/pmci_${T}_$n
-  KT_TSDF_LEAN=$L rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmci_${T}_$n -- python $R/bench.py --workload $W --steps $S --warmup 2 --no-cpu-baseline --no-readahead --no-stress > $R/gpurun_out/pmci_${T}_$n.log 2>&1 || { echo "pass $n FAILED"; tail -3 $R/gpurun_out/pmci_${T}_$n.log; }
+  KT_TSDF_LEAN=$L rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmci_${T}_$n -- python $R/bench.py --workload $W --steps $S --warmup 2 --no-cpu-baseline --no-contract-ab --no-readahead --no-stress > $R/gpurun_out/pmci_${T}_$n.log 2>&1 || { echo "pass $n FAILED"; tail -3 $R/gpurun_out/pmci_${T}_$n.log; }
 }
 P=${PASSES:-sq sq2 grbm tcc}
 want() { case " $P " in *" $1 "*) return 0;; esac; return 1; }

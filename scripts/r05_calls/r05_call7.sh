@@ -1,0 +1,7 @@
+# round 5, call 7: the overlapped ICP chain (KT_ICP_OVERLAP=1): parity of the tracker / config suites, then A/B of the frame rate
+cd $GRAFT_REPO_ROOT
+KT_ICP_OVERLAP=1 timeout 600 python -m pytest tests/test_gpu_tracker.py tests/test_gpu_configs.py tests/test_gpu_track.py -m gpu -x -q > gpurun_out/r05_c7_tests.log 2>&1; grep -E "passed|failed|^E |Timeout" gpurun_out/r05_c7_tests.log | head
+for v in 0 1 0 1; do KT_ICP_OVERLAP=$v timeout 300 python bench.py --no-cpu-baseline --no-stress --no-contract-ab 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('overlap $v fps', round(d['value'],1), 'pipelined', d['stage_ms_pipelined'], 'serial', d['stage_ms']['odometry'], 'err', d['config']['pose_err_m_at_end'])"; done
+KT_ICP_OVERLAP=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress --no-contract-ab 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('overlap 1 driver-style fps', round(d['value'],1), d['stage_ms_pipelined'])"
