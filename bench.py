@@ -7,7 +7,9 @@ which re-executes under `python -m torch.distributed.run --nnodes=1 --nproc-per-
 iterations solved on the device, shift check, TSDF integrate, raycast, predicted-map pyramid) with the frame already
 resident in HBM.  Workload at every N: BASELINE.json configs[1] -- 640x480 synthetic orbit, ICP-only tracking, 512^3
 TSDF -- one independent stream per GPU (seed 1234 + rank), poses gathered once with an RCCL all_gather (weak scaling).
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  `roofline` = the voxel kernel (tsdf::integrate) of the timed frames, HIP events on its launch stream, against 8 TB/s; `roofline.contract`
+names the arithmetic contract those frames ran under (bit-exact unless --contract says otherwise), `roofline.contract_ab` the same launch alone under both contracts;
+`roofline_stress` = BASELINE configs[4] with `frac_alone`, `frac_pipelined` and `survey8c` labelled; `cpu_baseline` = the oracle on this host's cores (N = 1 only).
 """
 import argparse
 import json
