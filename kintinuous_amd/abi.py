@@ -144,6 +144,7 @@ _PROTOS = {
     "kt_debug_tsdf_kernel": (C.c_char_p, []),
     "kt_debug_tsdf_contract": (_i, [_i]),
     "kt_debug_sq_threshold": (_f, [_f, _i]),
+    "kt_debug_icp_levels": (_i, [_i]),
     "kt_debug_div_check": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_debug_icp_wg_times": (_i, [_vp, C.POINTER(C.c_ulonglong)]),
     "kt_debug_tsdf_timeline": (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),

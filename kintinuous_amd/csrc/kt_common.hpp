@@ -34,6 +34,8 @@ struct kt_ctx {
     kt_integrate_scratch* integ;   // integrate scratch (pixel records, z tables, intervals, task list), created on first use
     float* bil_lut;                // bilateral tap weights [27][396] (kt_image.hip), built on first use
     int fault_skip, fault_count;   // test hook kt_debug_handoff_fault: after fault_skip more ICP reduction launches, fault_count launches lose a publisher
+    unsigned long long* pose_gran;   // device, 16 x {float, seq}: the in-kernel pose hand-over of kt_icp_level_kernel (kt_track.hip)
+    unsigned int odo_seq;            // its sequence counter
     unsigned int red_epoch;  // launch counter; the tag of the host-form residual launch's granules (kt_track.hip)
     void* track_state;       // device kt_track_state of kt_icp_track (kt_track.hip), created on first use
     void* slice_ws;          // kt_slice_ws of the host-array kt_slice_process (kt_slice.hip), created on first use

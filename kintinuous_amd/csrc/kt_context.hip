@@ -53,6 +53,8 @@ int kt_ctx_create(int device, kt_ctx** out)
     KT_HIP(hipMalloc((void**)&c->counters, sizeof(unsigned int) * 16));
     KT_HIP(hipMemsetAsync(c->red_partials, 0xff, sizeof(double) * 32 * c->red_max_blocks, c->stream));   // the reduction granules' sentinel (kt_track.hip)
     KT_HIP(hipMemsetAsync(c->counters, 0, sizeof(unsigned int) * 16, c->stream));
+    KT_HIP(hipMalloc((void**)&c->pose_gran, 256));
+    KT_HIP(hipMemsetAsync(c->pose_gran, 0, 256, c->stream));
     KT_HIP(hipStreamSynchronize(c->stream));
     KT_HIP(hipHostMalloc((void**)&c->red_out_host, sizeof(float) * 64, hipHostMallocDefault));
     KT_HIP(hipHostMalloc((void**)&c->int_out_host, sizeof(int) * 16, hipHostMallocDefault));
@@ -70,6 +72,7 @@ int kt_ctx_destroy(kt_ctx* c)
     (void)hipFree(c->bil_lut);
     (void)hipFree(c->track_state);
     (void)hipFree(c->red_partials);
+    (void)hipFree(c->pose_gran);
     (void)hipFree(c->red_out);
     (void)hipFree(c->counters);
     (void)hipHostFree(c->red_out_host);

@@ -99,6 +99,9 @@ int kt_refill_granules(kt_ctx* c);   // kt_track.hip: every hand-off granule bac
 int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
                        const float* vmap_g_prev, const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres,
                        int mode, const kt_track_state* init = nullptr, int keep29 = 0);
+int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr, const float* vmap_g_prev,
+                        const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres, const kt_track_state* frame, int first, int n_iter);
+bool kt_icp_levels_selected();   // kt_track.hip: KT_ICP_LEVELS / kt_debug_icp_levels
 int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
                            const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
                            int cols, int rows, kt_dataterm* corres_img, float max_depth_delta, const uint8_t* cand = nullptr,

@@ -26,6 +26,7 @@
 #include "kt_internal.hpp"
 
 #include <string.h>
+#include <stdlib.h>
 #include <float.h>
 #include <math.h>
 
@@ -361,12 +362,19 @@ struct kt_icp_args {
     float* out29;              // host path: 29 floats
     int mode;                  // KT_MODE_*
     int keep29;                // KT_MODE_ICP_SOLVE: also leave the 29 sums in state->icp29 (kt_icp_track's last iteration: the caller's A)
+    // kt_icp_level_kernel (round 5): n_iter Gauss-Newton iterations of ONE pyramid level in ONE launch.  The pose goes from an iteration's
+    // solving workgroup to the others as 12 granules {float, seq} tagged seq0 + iteration; Rcurr / tcurr then carry the frame's PREVIOUS pose
+    // (also the starting pose of the frame's first launch), Rprev_inv / tprev as always.
+    int n_iter; unsigned int seq0; unsigned long long* pose_gran; unsigned long long* granules2;
 };
 
 struct kt_icp_row {
     const kt_icp_args& a;
     kt_mat33 Rcurr, Rprev_inv;
     f3 tcurr, tprev;
+    // kt_icp_level_kernel: the current frame's vertex / normal of pixel pf_i, requested before the pose of the previous iteration arrived
+    int pf_i = -1;
+    f3 pf_v = {0.f, 0.f, 0.f}, pf_n = {0.f, 0.f, 0.f};
     // search() + getProducts(), reduce.cu:213-277, for pixel i; fills row[7] (zeros when no correspondence), returns found.
     // Branch-free: the reference's early returns become predicates and the gather index of a rejected pixel is clamped to 0, so
     // two calls inlined back to back have all their loads issued together (one exposed latency instead of two).
@@ -416,7 +424,8 @@ struct kt_icp_row {
         f3 vcurr, ncurr, vcurr_g, vprev_g, nprev_g;
         bool inimg;
         int g;
-        fetch_curr(i, vcurr, ncurr);
+        if (i == pf_i) { vcurr = pf_v; ncurr = pf_n; }
+        else fetch_curr(i, vcurr, ncurr);
         project(vcurr, vcurr_g, inimg, g);
         fetch_prev(g, vprev_g, nprev_g);
         return finish(ncurr, vcurr_g, vprev_g, nprev_g, inimg, row);
@@ -512,13 +521,110 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Several iterations of a level in one launch (round 5).  Of a stream-ordered iteration's 9 us, 1.45 are the kernel boundary and ~0.7 the
+// first loads of the next launch; here the 256 workgroups stay resident for all iterations of the level: after publishing its reduction
+// granules a workgroup requests the current-frame values of its first pixel for the NEXT iteration (they do not depend on the pose) and
+// polls the 12 pose granules the solving workgroup publishes at the end of its tail -- measured hand-over latency 0.6-0.7 us
+// (profiles/r05_icp_overlap/).  The solving workgroup (the last one, as in kt_icp_kernel) keeps the accumulated increment in LDS from one
+// iteration to the next and takes its own pose from LDS.  Consecutive iterations use the two granule sets in turn.  The arithmetic of an
+// iteration is kt_icp_kernel's, operation for operation (same row functor, same reduction, same tail).
+// Unlike two kernels on two streams (the overlapped chain that was measured and dropped), one kernel cannot starve itself: all of its
+// workgroups are dispatched before any of them waits for more than the first pose.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_icp_args a)
+{
+    if (a.fault && blockIdx.x == 0) return;   // test hook (kt_debug_handoff_fault)
+    __shared__ float total[KT_RED_SLOTS];
+    __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES], tail_work[KT_TAIL_WORK_DOUBLES];
+    __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
+    __shared__ float s_pose[13];   // the pose of the iteration about to run (+ [12] != 0: it never came)
+    const bool sweeper = kt_red_sweeps();
+    kt_icp_row fn{a};
+    fn.Rprev_inv = a.Rprev_inv;
+    fn.tprev = {a.tprev[0], a.tprev[1], a.tprev[2]};
+    if (a.first) {   // ICPOdometry.cpp:70-85: the frame starts from the previous pose
+        fn.Rcurr = a.Rcurr;
+        fn.tcurr = {a.tprev[0], a.tprev[1], a.tprev[2]};
+    } else {         // the pose the previous launch left (the kernel boundary orders the accesses)
+        for (int k = 0; k < 9; ++k) fn.Rcurr.m[k] = a.state->Rcurr[k];
+        fn.tcurr = {a.state->tcurr[0], a.state->tcurr[1], a.state->tcurr[2]};
+    }
+    if (sweeper) {   // the solving workgroup's carry: the accumulated increment and the frame's previous pose
+        if (threadIdx.x < 16) pose_d[threadIdx.x] = a.first ? ((threadIdx.x % 5 == 0) ? 1.0 : 0.0) : a.state->resultRt[threadIdx.x];
+        else if (threadIdx.x < 25) pose_f[threadIdx.x - 16] = a.Rcurr.m[threadIdx.x - 16];
+        else if (threadIdx.x < 28) pose_f[threadIdx.x - 16] = a.tprev[threadIdx.x - 25];
+    }
+    const int n = a.cols * a.rows;
+    // the first pixel this thread is asked for in every iteration (kt_reduce29_publish: p = tid of batch 0)
+    const int t0 = blockIdx.x * 32, nk_blk = (n - t0 + KT_VT_TOTAL - 1) / KT_VT_TOTAL;
+    const int pf_i = ((int)threadIdx.x < min(KT_KBATCH, nk_blk) * 32) ? min(t0 + ((int)threadIdx.x & 31) + ((int)threadIdx.x >> 5) * KT_VT_TOTAL, n - 1) : -1;
+    for (int it = 0; it < a.n_iter; ++it) {
+        unsigned long long* const gran = (it & 1) ? a.granules2 : a.granules;
+        if (it > 0) {
+            fn.pf_i = -1;
+            if (!sweeper) {
+                if (pf_i >= 0) { fn.fetch_curr(pf_i, fn.pf_v, fn.pf_n); fn.pf_i = pf_i; }   // in flight while the pose is awaited
+                if (threadIdx.x < 64) {
+                    const int lane = (int)threadIdx.x;
+                    const unsigned int want = a.seq0 + (unsigned int)it - 1u;
+                    const unsigned int spin_limit = min(*(volatile const unsigned int*)&kt_sweep_spin_limit, 1u << 20);
+                    unsigned long long g = 0;
+                    unsigned int spins = 0;
+                    bool ok;
+                    for (;;) {
+                        if (lane < 12) g = __hip_atomic_load(&a.pose_gran[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = lane >= 12 || (unsigned int)(g >> 32) == want;
+                        if (__all(ok) || ++spins > spin_limit) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    const bool got = __all(ok);
+                    if (lane < 12) s_pose[lane] = __uint_as_float((unsigned int)g);
+                    if (lane == 12) { s_pose[12] = got ? 0.0f : 1.0f; if (!got) a.state->handoff_timeout = 1; }   // (reported by complete_frame)
+                }
+            }
+            __syncthreads();   // (the solving workgroup: its tail wrote s_pose)
+            for (int k = 0; k < 9; ++k) fn.Rcurr.m[k] = s_pose[k];
+            fn.tcurr = {s_pose[9], s_pose[10], s_pose[11]};
+        }
+        __shared__ kt_rows_t rows[KT_KBATCH];
+        kt_reduce29_publish(fn, n, gran, rows);
+        if (!sweeper) continue;
+        kt_reduce29_sweep(gran, total);
+        // ICPOdometry.cpp:127-178, as kt_icp_kernel's KT_MODE_ICP_SOLVE epilogue
+        if (threadIdx.x < 42) sys[threadIdx.x] = (double)total[kt_sys_slot(threadIdx.x)];
+        __syncthreads();
+        if (threadIdx.x == 64) {
+            a.state->last_residual[0] = total[27];
+            a.state->last_residual[1] = total[28];
+            if (a.first && it == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { a.state->Rprev[k] = a.Rcurr.m[k]; a.state->Rprev_inv[k] = a.Rprev_inv.m[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a.state->tprev[k] = a.tprev[k];
+                a.state->handoff_timeout = total[KT_RED_SLOTS - 1] != 0.0f ? 1 : 0;
+            } else if (total[KT_RED_SLOTS - 1] != 0.0f) {
+                a.state->handoff_timeout = 1;
+            }
+        }
+        if (threadIdx.x < 64) kt_solve_and_update_wave(a.state, sys, pose_d, pose_f, tail_work, a.pose_gran, a.seq0 + (unsigned int)it, s_pose);
+    }
+}
+
 int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
 {
     a.granules = (unsigned long long*)c->red_partials;
     a.fault = 0;
     if (c->fault_skip > 0) --c->fault_skip;
     else if (c->fault_count > 0) { --c->fault_count; a.fault = 1; }
-    hipLaunchKernelGGL(kt_icp_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
+    if (a.n_iter > 0) {
+        a.granules2 = kt_second_granules(c);
+        a.pose_gran = c->pose_gran;
+        hipLaunchKernelGGL(kt_icp_level_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
+    } else {
+        hipLaunchKernelGGL(kt_icp_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
+    }
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
@@ -549,6 +655,7 @@ extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3
     a.Rcurr = *Rcurr; a.Rprev_inv = *Rprev_inv;
     for (int k = 0; k < 3; ++k) { a.tcurr[k] = tcurr[k]; a.tprev[k] = tprev[k]; }
     a.state = nullptr; a.first = 0; a.out29 = c->red_out; a.mode = KT_MODE_HOST; a.keep29 = 0;
+    a.n_iter = 0; a.seq0 = 0; a.pose_gran = nullptr; a.granules2 = nullptr;
     int s = kt_icp_launch(c, a);
     if (s != KT_OK) return s;
     KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * KT_RED_SLOTS, hipMemcpyDeviceToHost, c->stream));
@@ -563,6 +670,7 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
                        int mode, const kt_track_state* init, int keep29)
 {
     kt_icp_args a;
+    a.n_iter = 0; a.seq0 = 0; a.pose_gran = nullptr; a.granules2 = nullptr;
     a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
     a.intr = *intr; a.cols = cols; a.rows = rows; kt_icp_set_thresholds(a, dist_thres, angle_thres);
     a.state = state; a.out29 = nullptr; a.mode = mode;
@@ -575,6 +683,25 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
         memcpy(a.Rprev_inv.m, init->Rprev_inv, sizeof(a.Rprev_inv.m));
         for (int k = 0; k < 3; ++k) { a.tcurr[k] = init->tcurr[k]; a.tprev[k] = init->tprev[k]; }
     }
+    return kt_icp_launch(c, a);
+}
+
+// n_iter iterations of one pyramid level in one launch (kt_icp_level_kernel).  frame: Rprev, tprev, Rprev_inv of the frame (the init record of the
+// stepwise form); first: the frame's first launch (the starting pose is the previous pose, the state is initialised).
+int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr, const float* vmap_g_prev,
+                        const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres, const kt_track_state* frame, int first, int n_iter)
+{
+    if (n_iter <= 0) return KT_OK;
+    kt_icp_args a;
+    a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
+    a.intr = *intr; a.cols = cols; a.rows = rows; kt_icp_set_thresholds(a, dist_thres, angle_thres);
+    a.state = state; a.out29 = nullptr; a.mode = KT_MODE_ICP_SOLVE; a.first = first ? 1 : 0; a.keep29 = 0;
+    memcpy(a.Rcurr.m, frame->Rprev, sizeof(a.Rcurr.m));
+    memcpy(a.Rprev_inv.m, frame->Rprev_inv, sizeof(a.Rprev_inv.m));
+    for (int k = 0; k < 3; ++k) { a.tcurr[k] = frame->tprev[k]; a.tprev[k] = frame->tprev[k]; }
+    a.n_iter = n_iter;
+    a.seq0 = c->odo_seq + 1u;
+    c->odo_seq += (unsigned int)n_iter;
     return kt_icp_launch(c, a);
 }
 
@@ -1195,4 +1322,32 @@ extern "C" int kt_debug_handoff_fault(kt_ctx* c, int skip, int count, unsigned i
         KT_HIP(hipFree(d));
     }
     return KT_OK;
+}
+
+
+// which form the tracker's ICP-only odometry takes: one launch per iteration (0) or one per pyramid level (1); read when a tracker is created
+#ifndef KT_ICP_LEVELS_DEFAULT
+#define KT_ICP_LEVELS_DEFAULT 1
+#endif
+static int kt_icp_levels_override = -1;
+extern "C" int kt_debug_icp_levels(int on) { kt_icp_levels_override = on < 0 ? -1 : (on != 0); return KT_OK; }
+// The level kernel's workgroups wait for each other INSIDE the launch (a pose needs every workgroup's granules), so all KT_RED_GRID of them must
+// be resident at once: a device (or a partition of one) that cannot hold the whole grid would run the first wave of workgroups into their bounded
+// waits.  Checked once per process against the occupancy the runtime reports; such a device keeps the launch per iteration.
+static bool kt_icp_levels_fit()
+{
+    static const bool fit = []() {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kt_icp_level_kernel, KT_RED_THREADS, 0) != hipSuccess) return false;
+        return (long long)cus * per_cu >= KT_RED_GRID;
+    }();
+    return fit;
+}
+bool kt_icp_levels_selected()
+{
+    const char* e = getenv("KT_ICP_LEVELS");
+    const bool env = e ? atoi(e) != 0 : KT_ICP_LEVELS_DEFAULT != 0;
+    return (kt_icp_levels_override < 0 ? env : kt_icp_levels_override != 0) && kt_icp_levels_fit();
 }

@@ -371,7 +371,10 @@ __device__ __forceinline__ double kt_lane_bcast(double v, int src)   // src: wav
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, double* sys, double* pose_d, const float* pose_f, double* work)
+// gran != nullptr (kt_icp_level_kernel: several iterations in one launch): the new pose also leaves as 12 tagged granules {float, seq} for the
+// other workgroups, which poll them ("the data is the flag", as in kt_reduce29), and as 12 floats in LDS (pose_lds) for this workgroup itself.
+__device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, double* sys, double* pose_d, const float* pose_f, double* work,
+                                                         unsigned long long* gran = nullptr, unsigned int seq = 0, float* pose_lds = nullptr)
 {
     const int lane = (int)(threadIdx.x & 63u);
     const int r = min(lane, 5);   // lanes past the sixth repeat row 5 (their results are never used)
@@ -555,6 +558,10 @@ __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, dou
     const float vt = v + pose_f[9 + oi];
     v = is_t ? vt : v;
     if (lane < 12) (&st->Rcurr[0])[lane] = v;   // Rcurr[9] and tcurr[3] are adjacent in kt_track_state
+    if (gran && lane < 12) {
+        __hip_atomic_store(&gran[lane], ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pose_lds[lane] = v;
+    }
     KT_MARK(11);
     KT_TS(6);
 }

@@ -163,6 +163,7 @@ struct kt_tracker {
     // a plan belongs to ONE read-ahead frame: the frame set it was built from and the frame's buffers identify it (the ordinal alone does
     // not: the caller may skip a read-ahead, and the pre-pass intervals depend on that frame's depth)
     struct PlanSlot { kt_tsdf_plan plan; hipEvent_t done; long long ordinal; float R[9], t[3], theta, tau; int wrap[3]; int set; const uint16_t* depth; const uint8_t* rgb; };
+    bool icp_levels;   // ICP-only odometry: one launch per pyramid level (kt_icp_level_kernel) instead of one per iteration
     PlanSlot plans[3]; hipStream_t plan_stream;          // (three: frame f + 1 is planned while the voxel kernels of f and f - 1 may still read theirs)
     int plan_sel; bool plan_enabled; float plan_margin_scale;
     // test hooks (kt_tracker_debug_plan_*): the pose every frame WILL arrive at, taken from an identical earlier run, as the prediction;
@@ -527,6 +528,7 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     t->host_wait_s = t->host_call_s = 0.0; t->host_calls = 0;
     KT_TRY(dev_alloc(&t->fp_dev, 1, true));
     KT_HIP(hipStreamCreateWithFlags(&t->plan_stream, hipStreamNonBlocking));
+    t->icp_levels = kt_icp_levels_selected();
     for (int k = 0; k < 3; ++k) {
         KT_TRY(kt_tsdf_plan_alloc(&t->plans[k].plan, cfg->N));
         KT_HIP(hipEventCreateWithFlags(&t->plans[k].done, KT_EV_DEVICE));
@@ -701,6 +703,16 @@ static int icp_odometry(kt_tracker* t)
     memcpy(init.tcurr, t->tlast, sizeof(init.tcurr));
     kt_mat33_inverse(init.Rprev, init.Rprev_inv);  // ICPOdometry.cpp:81
     bool first = true;
+    if (t->icp_levels) {   // one launch per level: the iterations of a level hand the pose over inside the kernel (kt_track.hip: kt_icp_level_kernel)
+        for (int l = KT_LEVELS - 1; l >= 0; --l) {
+            if (iters[l] <= 0) continue;
+            const kt_intr li = lvl_intr(t->intr, l);
+            KT_TRY(kt_icp_level_device(t->ctx, t->state_dev, t->vmaps_curr[l], t->nmaps_curr[l], &li, t->vmaps_g_prev[l], t->nmaps_g_prev[l], lvl_cols(t, l),
+                                       lvl_rows(t, l), dist_thres, angle_thres, &init, first ? 1 : 0, iters[l]));
+            first = false;
+        }
+        return odometry_end(t);
+    }
     for (int l = KT_LEVELS - 1; l >= 0; --l) {
         const kt_intr li = lvl_intr(t->intr, l);
         for (int it = 0; it < iters[l]; ++it) {

@@ -226,13 +226,20 @@ def test_a_reported_handoff_timeout_leaves_a_clean_buffer(ctx, oracle_mod, small
         _handoff_fault(ctx, 0, 0, spin_limit=1 << 22, want_dirty=False)
 
 
-def test_tracker_recovers_from_a_handoff_timeout(ctx, small_scene):
+@pytest.mark.parametrize("levels", [1, 0])
+def test_tracker_recovers_from_a_handoff_timeout(ctx, small_scene, levels):
     """The tracker's form of the same: the last odometry launch of a frame times out -> the frame's getter reports it, nothing is fused with
-    the pose-less frame, the buffer is clean, and after kt_tracker_reset the sequence gives the poses and the volume of an undisturbed run."""
+    the pose-less frame, the buffer is clean, and after kt_tracker_reset the sequence gives the poses and the volume of an undisturbed run.
+    Both forms of the ICP chain: one launch per pyramid level (kt_icp_level_kernel: 3 launches per frame, every iteration of the faulted
+    launch loses the publisher) and one launch per iteration (19)."""
     from kintinuous_amd import abi
     cam, frames, traj = small_scene
     cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
-    trk = abi.Tracker(ctx, cfg)
+    abi._chk(abi.lib().kt_debug_icp_levels(levels))
+    try:
+        trk = abi.Tracker(ctx, cfg)
+    finally:
+        abi._chk(abi.lib().kt_debug_icp_levels(-1))
 
     def run():
         poses = []
@@ -247,7 +254,7 @@ def test_tracker_recovers_from_a_handoff_timeout(ctx, small_scene):
         for k in range(2):
             trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
         trk.pose()
-        _handoff_fault(ctx, 18, 1, spin_limit=64, want_dirty=False)        # frame 2: 10 + 5 + 4 launches, the last one faulted
+        _handoff_fault(ctx, 2 if levels else 18, 1, spin_limit=64, want_dirty=False)   # frame 2: its last launch (of 3, or of 10 + 5 + 4) faulted
         trk.process_frame_host(frames[2][0], frames[2][1], 33333 * 2)
         with pytest.raises(abi.KtError, match="timed out"):
             trk.pose()

@@ -623,3 +623,26 @@ def test_plan_margins_hold_at_their_edge(ctx, size):
         else:
             assert hits == 0 and misses >= floor, (key, hits, misses)     # ... and rejected
 
+
+
+def test_icp_chain_per_level_equals_per_iteration(ctx, small_scene):
+    """The tracker's ICP-only odometry as one launch per pyramid level (kt_icp_level_kernel: the iterations of a level hand the pose over
+    inside the kernel) and as one launch per iteration (kt_icp_kernel x 19) are the same arithmetic: every pose and both volumes bit-equal."""
+    from kintinuous_amd import abi
+    cam, frames, traj = small_scene
+    g, _ = _cfgs(cam, 96)
+    out = []
+    for levels in (0, 1):
+        abi._chk(abi.lib().kt_debug_icp_levels(levels))
+        try:
+            trk = abi.Tracker(ctx, g)
+        finally:
+            abi._chk(abi.lib().kt_debug_icp_levels(-1))
+        poses = []
+        for k, (d, rgb) in enumerate(frames):
+            trk.process_frame_host(d, rgb, 33333 * k)
+            poses.append(np.concatenate([x.ravel() for x in trk.pose()]))
+        out.append((np.array(poses), trk.volume().copy(), trk.color_volume().copy()))
+        trk.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
