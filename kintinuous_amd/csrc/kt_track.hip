@@ -533,7 +533,11 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
 // Unlike two kernels on two streams (the overlapped chain that was measured and dropped), one kernel cannot starve itself: all of its
 // workgroups are dispatched before any of them waits for more than the first pose.
 // ------------------------------------------------------------------------------------------------
+#ifdef KT_ICP_LEVEL_WAVES   // A/B builds: waves per SIMD the register budget is cut for (8: 64 VGPRs = two workgroups per compute unit)
+__global__ __launch_bounds__(KT_RED_THREADS, KT_ICP_LEVEL_WAVES) void kt_icp_level_kernel(const kt_icp_args a)
+#else
 __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_icp_args a)
+#endif
 {
     if (a.fault && blockIdx.x == 0) return;   // test hook (kt_debug_handoff_fault)
     __shared__ float total[KT_RED_SLOTS];
@@ -585,8 +589,10 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
                 }
             }
             __syncthreads();   // (the solving workgroup: its tail wrote s_pose)
-            for (int k = 0; k < 9; ++k) fn.Rcurr.m[k] = s_pose[k];
-            fn.tcurr = {s_pose[9], s_pose[10], s_pose[11]};
+            // (wave-uniform values: into scalar registers, where kt_icp_kernel's arguments live too -- as per-lane copies they cost 12 VGPRs)
+            const auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+            for (int k = 0; k < 9; ++k) fn.Rcurr.m[k] = uni(s_pose[k]);
+            fn.tcurr = {uni(s_pose[9]), uni(s_pose[10]), uni(s_pose[11])};
         }
         __shared__ kt_rows_t rows[KT_KBATCH];
         kt_reduce29_publish(fn, n, gran, rows);
