@@ -145,6 +145,7 @@ _PROTOS = {
     "kt_debug_tsdf_contract": (_i, [_i]),
     "kt_debug_sq_threshold": (_f, [_f, _i]),
     "kt_debug_icp_levels": (_i, [_i]),
+    "kt_tracker_debug_icp_levels": (_i, [_vp]),
     "kt_debug_div_check": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_debug_icp_wg_times": (_i, [_vp, C.POINTER(C.c_ulonglong)]),
     "kt_debug_tsdf_timeline": (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),
@@ -425,6 +426,12 @@ class Tracker:
         if self.h:
             lib().kt_tracker_destroy(self.h)
             self.h = None
+
+    def __del__(self):   # (a tracker left open would keep later ones off the level form of the ICP chain: kt_tracker_create)
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def reset(self) -> None:
         _chk(lib().kt_tracker_reset(self.h))

@@ -69,6 +69,7 @@ int kt_debug_handoff_fault(kt_ctx* ctx, int skip, int count, unsigned int spin_l
 /* A/B hook: trackers created from now on run their ICP-only odometry as one launch per pyramid level (csrc/kt_track.hip: kt_icp_level_kernel) -- 1 --
  * or as one launch per iteration -- 0; -1 = KT_ICP_LEVELS in the environment, else the build's default.  Both give the same bits. */
 int kt_debug_icp_levels(int on);
+int kt_tracker_debug_icp_levels(kt_tracker* trk);   /* 1: the tracker's last frame ran its ICP chain in the level form (only while it is the process's only live tracker) */
 /* host arithmetic behind the ICP row's threshold tests (csrc/kt_track.hip: kt_icp_set_thresholds): the largest float X with
  * sqrtf(X) <= T (strict = 0) or sqrtf(X) < T (strict = 1), -1 when there is none */
 float kt_debug_sq_threshold(float T, int strict);

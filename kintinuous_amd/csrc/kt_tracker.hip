@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <atomic>
 #include <map>
 #include <thread>
 #include <vector>
@@ -67,6 +68,7 @@ enum { ST_PYRAMID = 0, ST_ODOMETRY, ST_SHIFT, ST_INTEGRATE, ST_RAYCAST, ST_RESIZ
 
 }  // namespace
 
+static std::atomic<int> kt_live_trackers{0};   // live trackers of this process: the level form of the ICP chain needs to be alone (kt_tracker_create)
 struct kt_tracker {
     kt_ctx* ctx;
     kt_tracker_config cfg;
@@ -163,7 +165,8 @@ struct kt_tracker {
     // a plan belongs to ONE read-ahead frame: the frame set it was built from and the frame's buffers identify it (the ordinal alone does
     // not: the caller may skip a read-ahead, and the pre-pass intervals depend on that frame's depth)
     struct PlanSlot { kt_tsdf_plan plan; hipEvent_t done; long long ordinal; float R[9], t[3], theta, tau; int wrap[3]; int set; const uint16_t* depth; const uint8_t* rgb; };
-    bool icp_levels;   // ICP-only odometry: one launch per pyramid level (kt_icp_level_kernel) instead of one per iteration
+    bool icp_levels;   // ICP-only odometry: one launch per pyramid level (kt_icp_level_kernel) instead of one per iteration, while this tracker is alone
+    bool last_icp_levels;   // ... and whether the last frame's chain took that form
     PlanSlot plans[3]; hipStream_t plan_stream;          // (three: frame f + 1 is planned while the voxel kernels of f and f - 1 may still read theirs)
     int plan_sel; bool plan_enabled; float plan_margin_scale;
     // test hooks (kt_tracker_debug_plan_*): the pose every frame WILL arrive at, taken from an identical earlier run, as the prediction;
@@ -528,7 +531,14 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     t->host_wait_s = t->host_call_s = 0.0; t->host_calls = 0;
     KT_TRY(dev_alloc(&t->fp_dev, 1, true));
     KT_HIP(hipStreamCreateWithFlags(&t->plan_stream, hipStreamNonBlocking));
+    // The level form is used only while this is the ONLY live tracker of the process (decided per frame, icp_odometry): its workgroups wait for
+    // each other inside a launch and need the whole machine, so anything that keeps compute units busy next to it for long -- a second tracker
+    // fed from the same host (scripts/multistream_one_gpu.py) -- can keep its last workgroup out until the bounded waits give up.  The
+    // tracker's own side streams are finite per frame and its main-stream kernels are ordered behind the launch.  Processes that share ONE GPU
+    // must set KT_ICP_LEVELS=0 themselves.
     t->icp_levels = kt_icp_levels_selected();
+    t->last_icp_levels = false;
+    kt_live_trackers.fetch_add(1);
     for (int k = 0; k < 3; ++k) {
         KT_TRY(kt_tsdf_plan_alloc(&t->plans[k].plan, cfg->N));
         KT_HIP(hipEventCreateWithFlags(&t->plans[k].done, KT_EV_DEVICE));
@@ -562,6 +572,7 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
 int kt_tracker_destroy(kt_tracker* t)
 {
     if (!t) return KT_OK;
+    kt_live_trackers.fetch_sub(1);
     (void)hipStreamSynchronize(t->ctx->stream);
     (void)join_slice_jobs(t);
     if (t->worker.joinable()) {
@@ -703,7 +714,8 @@ static int icp_odometry(kt_tracker* t)
     memcpy(init.tcurr, t->tlast, sizeof(init.tcurr));
     kt_mat33_inverse(init.Rprev, init.Rprev_inv);  // ICPOdometry.cpp:81
     bool first = true;
-    if (t->icp_levels) {   // one launch per level: the iterations of a level hand the pose over inside the kernel (kt_track.hip: kt_icp_level_kernel)
+    t->last_icp_levels = t->icp_levels && kt_live_trackers.load() == 1;
+    if (t->last_icp_levels) {   // one launch per level: the iterations of a level hand the pose over inside the kernel (kt_track.hip: kt_icp_level_kernel)
         for (int l = KT_LEVELS - 1; l >= 0; --l) {
             if (iters[l] <= 0) continue;
             const kt_intr li = lvl_intr(t->intr, l);
@@ -1918,3 +1930,5 @@ int kt_tracker_export_poses_device(kt_tracker* t, int k, float* dst_dev)
 }
 
 }  // extern "C"
+
+extern "C" int kt_tracker_debug_icp_levels(kt_tracker* t) { return t && t->last_icp_levels ? 1 : 0; }

@@ -646,3 +646,39 @@ def test_icp_chain_per_level_equals_per_iteration(ctx, small_scene):
         trk.close()
     assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_the_level_form_needs_to_be_alone(ctx, small_scene):
+    """kt_icp_level_kernel's workgroups wait for each other inside a launch and need the whole machine: a second tracker fed next to it can keep
+    its last workgroup out until the bounded waits give up.  So the form is chosen per frame: only while the tracker is the process's only live
+    one.  Two trackers fed alternately (their frames overlap on the GPU) both run the launch per iteration and give the same poses, bit for bit,
+    as a lone tracker in the level form."""
+    import os
+    from kintinuous_amd import abi
+    if os.environ.get("KT_ICP_LEVELS") == "0":
+        pytest.skip("the environment switches the level form off")
+    cam, frames, traj = small_scene
+    g, _ = _cfgs(cam, 96)
+    form = lambda t: abi.lib().kt_tracker_debug_icp_levels(t.h)
+    last = lambda t: np.concatenate([x.ravel() for x in t.pose()]).view(np.uint32)
+    probe = abi.Tracker(ctx, g)   # alone, unless an earlier test of this process left a tracker open
+    for k in range(2):
+        probe.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
+    probe.pose()
+    alone = form(probe) == 1
+    probe.close()
+    if not alone:
+        pytest.skip("another tracker is alive in this process")
+    a = abi.Tracker(ctx, g)
+    b = abi.Tracker(ctx, g)
+    for k, (d, rgb) in enumerate(frames):
+        a.process_frame_host(d, rgb, 33333 * k)
+        b.process_frame_host(d, rgb, 33333 * k)
+    pa, pb = last(a), last(b)
+    assert form(a) == 0 and form(b) == 0 and np.array_equal(pa, pb)
+    a.close()
+    b.reset()
+    for k, (d, rgb) in enumerate(frames):
+        b.process_frame_host(d, rgb, 33333 * k)
+    assert form(b) == 1 and np.array_equal(last(b), pa)
+    b.close()
