@@ -1,4 +1,5 @@
 import os, sys, ctypes as C
+os.environ.setdefault("KT_ICP_LEVELS", "0")   # the probes live in kt_icp_kernel (one launch per iteration), not in the level kernel
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from kintinuous_amd import abi, synth
