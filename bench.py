@@ -336,7 +336,10 @@ def main():
                                 "slowest": [[int(i), round(float(periods[i]), 3)] for i in np.argsort(periods)[::-1][:4]]},
                    "slices_by_direction": slices_by_dim},
         "roofline": {"kernel": voxel_kernel, "contract": "survey-8c" if voxel_kernel == "kt_tsdf23_tol_kernel" else "bit-exact", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
-                     "frac": achieved / peak, "traffic": traffic, "traffic_ratio": traffic_ratio,
+                     "frac": achieved / peak,
+                     "frac_is": "the launch inside the timed region, next to the read-ahead and plan streams (since round 5 they run beside the fusion kernels: the "
+                                "odometry of a pyramid level is one resident launch); frac_alone = the same launch with nothing else on the GPU",
+                     "traffic": traffic, "traffic_ratio": traffic_ratio,
                      # not measured by this run: the committed rocprofv3 PMC passes of the same workload and the same kt_volume.hip
                      "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_tsdf23,
                      "avg_launch_ms": tsdf23_ms, "launches_timed": tsdf23_n, "U_voxels_updated": U, "S_raycast_steps": float(np.mean(Ss)),
