@@ -330,3 +330,25 @@ def test_squared_thresholds_of_the_icp_row_are_equivalent_to_the_roots():
     assert f(0.0, 0) == 0.0 and f(0.0, 1) == -1.0                # sqrtf(x) <= 0 only at 0; sqrtf(x) < 0 never
     assert f(-1.0, 0) == -1.0 and f(float("nan"), 0) == -1.0 and f(float("nan"), 1) == -1.0
     assert f(float("inf"), 0) == float("inf") and np.float32(f(float("inf"), 1)) == np.finfo(np.float32).max
+
+
+def test_kernel_stats_splitter_moves_the_counting_rows(tmp_path):
+    """scripts/split_kernel_stats.py: the counting variants of bench.py's untimed replay (`<true, ...>` template rows) go below a separator row and
+    out of the percentages, the frame's own launches keep their order and sum to 100 %."""
+    import csv
+    import subprocess
+    import sys
+    src, dst = tmp_path / "in.csv", tmp_path / "out.csv"
+    rows = [["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"],
+            ["void kt_raycast_kernel<true, true, true>(kt_raycast_args)", "10", "2600000", "260000", "50.0", "1", "2", "0"],
+            ["kt_icp_level_kernel(kt_icp_args)", "30", "1500000", "50000", "28.8", "1", "2", "0"],
+            ["void kt_tsdf23_lean_kernel<false, false, true>(kt_tsdf_lean_args)", "10", "500000", "50000", "9.6", "1", "2", "0"],
+            ["void kt_tsdf23_lean_kernel<true, false, true>(kt_tsdf_lean_args)", "10", "600000", "60000", "11.5", "1", "2", "0"]]
+    with open(src, "w", newline="") as f:
+        csv.writer(f).writerows(rows)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "split_kernel_stats.py"), str(src), str(dst)])
+    out = list(csv.reader(open(dst)))
+    names = [r[0] for r in out[1:]]
+    assert names[0].startswith("kt_icp_level_kernel") and names[1].startswith("void kt_tsdf23_lean_kernel<false")
+    assert names[2].startswith("# BELOW") and all("<true," in n for n in names[3:]) and len(names) == 5
+    assert abs(sum(float(r[4]) for r in out[1:3]) - 100.0) < 1e-3 and all(r[4] == "" for r in out[4:])
