@@ -77,6 +77,11 @@ WORKLOADS = {
 }
 
 
+# which BASELINE.json config a workload is (every line used to say configs[1])
+BASELINE_CONFIG = {"orbit512": "BASELINE.json configs[1]", "crabwalk512": "BASELINE.json configs[2]", "farwall768": "BASELINE.json configs[4]",
+                   "orbit256": "configs[0]-sized volume; not a BASELINE bench line"}
+
+
 from kintinuous_amd.multistream import check_gather, make_comm, make_exchange, pingpong, stream_seed, timed_region  # noqa: E402
 
 
@@ -217,6 +222,7 @@ def main():
         _, sdim = trk.slice_info(si)
         slices_by_dim[SLICE_NAMES.get(sdim, str(sdim))] = slices_by_dim.get(SLICE_NAMES.get(sdim, str(sdim)), 0) + 1
     host_call_s, host_wait_s = trk.host_times()
+    fallbacks = trk.odometry_fallbacks()
     stage = trk.stage_ms()
     tsdf23_ms, tsdf23_n = stage["tsdf23"]
     # tracking must still be healthy at the end of the timed region (not a degenerate run)
@@ -326,10 +332,13 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {cam.cols}x{cam.rows} synthetic {cfg_name} sequence, {'ICP+RGB-D' if d['use_rgbd_icp'] else 'ICP-only'} tracking, "
-                               f"{N}^3 TSDF, " + ("inputs in HOST memory (PCIe-inclusive)" if args.host_frames else "inputs resident in HBM") + ", 1 stream per GPU (BASELINE.json configs[1])"
+                               f"{N}^3 TSDF, " + ("inputs in HOST memory (PCIe-inclusive)" if args.host_frames else "inputs resident in HBM") + ", 1 stream per GPU (" + BASELINE_CONFIG[args.workload] + ")"
                                + (", log playback with 1 frame of read-ahead" if readahead else ", no read-ahead"),
                    "volume": N, "cols": cam.cols, "rows": cam.rows, "unique_frames": nuniq, "pose_err_m_at_end": pose_err,
                    "pose_gather_bytes": pose_bytes,
+                   # the side streams wait for the ray cast of the frame in flight instead of running beside its voxel kernel (KT_SIDE_GATE;
+                   # default: dense views only); frames whose odometry was re-run stepwise after a hand-off time-out (0 on an undisturbed GPU)
+                   "side_gate": int(abi.lib().kt_tracker_debug_side_gate(trk.h)), "odometry_fallbacks": fallbacks,
                    "frame_ms": {"p50": round(float(np.percentile(periods, 50)), 4), "p99": round(float(np.percentile(periods, 99)), 4),
                                 "max": round(float(periods.max()), 4),
                                 # the slowest calls (index in the timed region, ms): shift frames and whatever else stalls the caller
@@ -465,6 +474,7 @@ def roofline_stress(ctx, abi, synth):
             ms, n = (ms * n - parked * 0.0035) / (n - parked), n - parked
         return ms, n, frame_ms
 
+    side_gate = int(abi.lib().kt_tracker_debug_side_gate(trk.h))
     ms, n, frame_ms = run(False)
     ms_p, n_p, frame_ms_p = run(True, 12)
     tol = None
@@ -493,7 +503,8 @@ def roofline_stress(ctx, abi, synth):
            "frac_alone": frac(ms), "avg_launch_ms_alone": ms,
            "frac_pipelined": frac(ms_p), "avg_launch_ms_pipelined": ms_p, "launches_timed_pipelined": n_p, "frame_ms_pipelined": round(frame_ms_p, 3),
            "traffic": traffic[0], "traffic_ratio": traffic[1], "traffic_source": traffic[2],
-           "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n, "U_voxels_updated": U, "frame_ms": round(frame_ms, 3)}
+           "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n, "U_voxels_updated": U, "frame_ms": round(frame_ms, 3),
+           "side_gate": side_gate}
     if tol:
         out["survey8c"] = {"kernel": "kt_tsdf23_tol_kernel", "frac_alone": frac(tol[0][0]), "avg_launch_ms_alone": tol[0][0],
                            "frac_pipelined": frac(tol[1][0]), "avg_launch_ms_pipelined": tol[1][0]}

@@ -292,6 +292,11 @@ int kt_tracker_last_counts(kt_tracker* t, unsigned long long* U, unsigned long l
  * the plan's margins and were fused through the in-stream pre-pass instead {misses} (csrc/kt_volume.hip "planning ahead"; results do
  * not depend on which of the two happened). */
 int kt_tracker_plan_stats(kt_tracker* t, long long out2_host[2]);
+/* Frames whose odometry was run a second time, one launch per iteration, because an inter-workgroup hand-off of the first attempt gave up
+ * (csrc/kt_track.hip: kt_icp_level_kernel needs its whole grid resident; another process on the same GPU can keep a workgroup out).  The
+ * reference's icpStep is stream-ordered and cannot fail this way (reduce.cu:347-419); here the frame is re-run inside the call that observes
+ * it, with the same bits, and only counted.  0 on an undisturbed GPU. */
+int kt_tracker_odometry_fallbacks(kt_tracker* t, long long* out_host);
 
 
 /* The per-slice stage of the backend's CloudSliceProcessor (backend/CloudSliceProcessor.cpp:87-163), the consumer right behind every

@@ -132,6 +132,9 @@ _PROTOS = {
     "kt_tracker_debug_counts": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_tracker_debug_state": (_i, [_vp, _pf]),
     "kt_tracker_plan_stats": (_i, [_vp, C.POINTER(C.c_longlong)]),
+    "kt_tracker_odometry_fallbacks": (_i, [_vp, C.POINTER(C.c_longlong)]),
+    "kt_debug_wait_limit": (_i, [_vp, C.c_uint]),
+    "kt_tracker_debug_side_gate": (_i, [_vp]),
     "kt_tracker_enable_slice_stage": (_i, [_vp, _i, _i, _i]),
     "kt_tracker_slice_processed_info": (_i, [_vp, _i, C.POINTER(C.c_longlong)]),
     "kt_tracker_slice_processed": (_i, [_vp, _i, _vp]),
@@ -483,6 +486,12 @@ class Tracker:
         out = (C.c_longlong * 2)()
         _chk(lib().kt_tracker_plan_stats(self.h, out))
         return int(out[0]), int(out[1])
+
+    def odometry_fallbacks(self) -> int:
+        """frames whose odometry was re-run in the stepwise form after a hand-off time-out (kt_tracker_odometry_fallbacks)"""
+        out = C.c_longlong(0)
+        _chk(lib().kt_tracker_odometry_fallbacks(self.h, C.byref(out)))
+        return int(out.value)
 
     def prefetch_frame(self, depth_dev, rgb_dev) -> None:
         """Announce a frame a later process_frame call will receive: its pose-independent stages run on a second stream."""

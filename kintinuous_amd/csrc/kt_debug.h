@@ -66,10 +66,14 @@ int kt_debug_rcp_check(kt_ctx* ctx, unsigned int* mismatches_host);
  * their hand-off sweep gives up after spin_limit looks (0: unchanged) and the caller is told KT_ERR_STATE; dirty_out (optional) = number
  * of reduction granules that are not the sentinel once the context's stream has drained (0 = the buffer is clean for the next launch) */
 int kt_debug_handoff_fault(kt_ctx* ctx, int skip, int count, unsigned int spin_limit, unsigned int* dirty_out);
+/* test / tuning hook: the time bound of the hand-off waits (sweep; the level kernel's pose wait takes twice as long) in ticks of the 100 MHz
+ * clock; 0 = the default, 5 000 000 = 50 ms */
+int kt_debug_wait_limit(kt_ctx* ctx, unsigned int ticks_100mhz);
 /* A/B hook: trackers created from now on run their ICP-only odometry as one launch per pyramid level (csrc/kt_track.hip: kt_icp_level_kernel) -- 1 --
  * or as one launch per iteration -- 0; -1 = KT_ICP_LEVELS in the environment, else the build's default.  Both give the same bits. */
 int kt_debug_icp_levels(int on);
 int kt_tracker_debug_icp_levels(kt_tracker* trk);   /* 1: the tracker's last frame ran its ICP chain in the level form (only while it is the process's only live tracker) */
+int kt_tracker_debug_side_gate(kt_tracker* trk);    /* 1: the tracker's read-ahead waits for the ray cast of the frame in flight (KT_SIDE_GATE; csrc/kt_tracker.hip) */
 /* host arithmetic behind the ICP row's threshold tests (csrc/kt_track.hip: kt_icp_set_thresholds): the largest float X with
  * sqrtf(X) <= T (strict = 0) or sqrtf(X) < T (strict = 1), -1 when there is none */
 float kt_debug_sq_threshold(float T, int strict);

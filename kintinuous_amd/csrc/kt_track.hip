@@ -69,12 +69,21 @@ struct kt_no_prefetch { __device__ __forceinline__ void operator()() const {} };
 // which the two half-waves of wave p hold -- and "the data is the flag": a granule is valid when it is not the SENTINEL (all ones: two
 // NaNs of a payload no arithmetic produces; a publisher that did hold 0xffffffff stores 0xfffffffe).  The sweeping wave writes the
 // sentinel back into every granule it has consumed; the next launch that publishes into the buffer is behind this one on the stream,
-// so the kernel boundary orders the two.  (Rounds 2-3 tagged every 4-byte sum with a 4-byte epoch: twice the lines for the sweep to
+// so the kernel boundary orders the two -- ALWAYS: a launch that runs several iterations (kt_icp_level_kernel) gives every iteration a
+// granule set of its own (kt_level_granules), so a hand-back and the next publish into the same word are never inside one launch
+// (advisor, round 5: two sets used in turn left that pair ordered only by a causal chain of relaxed accesses).
+// (Rounds 2-3 tagged every 4-byte sum with a 4-byte epoch: twice the lines for the sweep to
 // fetch, and the sweep -- agent-scope loads go past the L2, one compute unit issues all of them -- is paid per LINE REQUEST:
 // profiles/r04_experiments.md.)  Place of workgroup wg's (= CUDA block wg / 4, warp wg % 4) granule of pair p: the four warps of a block
 // are 64 granules apart, so that the sweeping wave's q-th load -- lane b takes warp q of block b -- reads 512 contiguous bytes.
 #define KT_RED_PAIRS 15
 #define KT_GRANULE_SENTINEL 0xffffffffffffffffull
+// kt_icp_level_kernel: one granule set per iteration of a launch, behind everything else in the context's hand-off buffer (u64 indices;
+// [0, 8192) and [8192, 16384): the two kt_reduce29 sets, 16384..: the residual launch's words, kt_residual_granules / kt_residual_partials)
+#define KT_LEVEL_SETS 16
+#define KT_LEVEL_SET_STRIDE 4096      // >= KT_RED_PAIRS * KT_RED_BLOCKS = 3840
+#define KT_LEVEL_SET_BASE 32768
+#define KT_POSE_ABORT 15              // pose_gran[15]: {0, seq} of the iteration whose sweep gave up (same 128-byte line as the 12 pose granules)
 __device__ __forceinline__ int kt_granule_index(int pair, int wg) { return pair * KT_RED_BLOCKS + (wg & 3) * (KT_RED_BLOCKS / 4) + (wg >> 2); }
 // lane 0 of every wave p < 15 publishes {sum of product 2p (lanes 0..31), sum of product 2p + 1 (lanes 32..63)}
 __device__ __forceinline__ void kt_publish_pair(unsigned long long* __restrict__ granules, float wsum)
@@ -212,6 +221,12 @@ __device__ __forceinline__ void kt_reduce29_publish2(const RowFnA& fa, const Row
 // sets -- before it looks at any of them, so the sweep costs one memory round trip, not one per set.
 // bound of the sweep's spin (a test hook lowers it: kt_debug_handoff_fault); read once per sweep, next to the first granule loads
 __device__ unsigned int kt_sweep_spin_limit = 1u << 22;
+// ... and the bound that decides in practice: ticks of the constant 100 MHz clock (s_memrealtime) a wait may last.  A look costs an agent-scope
+// round trip (~1.5 us), so 2^22 looks would be seconds; 50 ms is three orders of magnitude above the longest legitimate wait (a workgroup kept
+// out of its compute unit by the tracker's own side streams: < 1 ms) and short enough for the tracker to fall back to the stepwise chain
+// within the frame (kt_tracker.hip: complete_frame).  kt_debug_wait_limit changes it.
+__device__ unsigned int kt_wait_limit_ticks = 5000000u;
+__device__ __forceinline__ unsigned long long kt_ticks() { return __builtin_amdgcn_s_memrealtime(); }
 
 template <int NS>
 __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&granules)[NS], float* const (&total)[NS])
@@ -235,6 +250,8 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&
             bool ok;
             unsigned int spins = 0;
             const unsigned int spin_limit = *(volatile const unsigned int*)&kt_sweep_spin_limit;
+            const unsigned int tick_limit = *(volatile const unsigned int*)&kt_wait_limit_ticks;
+            const unsigned long long tick0 = kt_ticks();
             for (;;) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -247,7 +264,7 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) ok = ok && g[s][q] != KT_GRANULE_SENTINEL;
-                if (__all(ok) || ++spins > spin_limit) break;
+                if (__all(ok) || ++spins > spin_limit || ((spins & 15u) == 0 && kt_ticks() - tick0 > tick_limit)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             const bool all_ok = __all(ok);
@@ -364,8 +381,10 @@ struct kt_icp_args {
     int keep29;                // KT_MODE_ICP_SOLVE: also leave the 29 sums in state->icp29 (kt_icp_track's last iteration: the caller's A)
     // kt_icp_level_kernel (round 5): n_iter Gauss-Newton iterations of ONE pyramid level in ONE launch.  The pose goes from an iteration's
     // solving workgroup to the others as 12 granules {float, seq} tagged seq0 + iteration; Rcurr / tcurr then carry the frame's PREVIOUS pose
-    // (also the starting pose of the frame's first launch), Rprev_inv / tprev as always.
-    int n_iter; unsigned int seq0; unsigned long long* pose_gran; unsigned long long* granules2;
+    // (also the starting pose of the frame's first launch), Rprev_inv / tprev as always.  level_gran: KT_LEVEL_SETS granule sets, iteration
+    // `it` of the launch reduces through set `it` (round 6: a set is published into once per LAUNCH, so its hand-back is ordered against the next
+    // publish by a kernel boundary, like kt_icp_kernel's).  pose_gran[KT_POSE_ABORT]: {., seq} of the iteration whose sweep gave up.
+    int n_iter; unsigned int seq0; unsigned long long* pose_gran; unsigned long long* level_gran;
 };
 
 struct kt_icp_row {
@@ -560,35 +579,47 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
         else if (threadIdx.x < 25) pose_f[threadIdx.x - 16] = a.Rcurr.m[threadIdx.x - 16];
         else if (threadIdx.x < 28) pose_f[threadIdx.x - 16] = a.tprev[threadIdx.x - 25];
     }
+    if (threadIdx.x == 12) s_pose[12] = 0.0f;
     const int n = a.cols * a.rows;
     // the first pixel this thread is asked for in every iteration (kt_reduce29_publish: p = tid of batch 0)
     const int t0 = blockIdx.x * 32, nk_blk = (n - t0 + KT_VT_TOTAL - 1) / KT_VT_TOTAL;
     const int pf_i = ((int)threadIdx.x < min(KT_KBATCH, nk_blk) * 32) ? min(t0 + ((int)threadIdx.x & 31) + ((int)threadIdx.x >> 5) * KT_VT_TOTAL, n - 1) : -1;
     for (int it = 0; it < a.n_iter; ++it) {
-        unsigned long long* const gran = (it & 1) ? a.granules2 : a.granules;
+        unsigned long long* const gran = a.level_gran + (size_t)it * KT_LEVEL_SET_STRIDE;
         if (it > 0) {
             fn.pf_i = -1;
             if (!sweeper) {
                 if (pf_i >= 0) { fn.fetch_curr(pf_i, fn.pf_v, fn.pf_n); fn.pf_i = pf_i; }   // in flight while the pose is awaited
                 if (threadIdx.x < 64) {
+                    // Wait for the pose of iteration it - 1: 12 granules tagged with its sequence number.  Bounded (looks, and twice the sweep's
+                    // time bound: a sweep that succeeds at the edge of ITS bound must still find its pollers waiting).  A workgroup whose wait
+                    // gives up, or that finds the launch aborted (the sweeping workgroup's own wait gave up: granule KT_POSE_ABORT carries
+                    // the iteration), LEAVES the kernel: it publishes nothing further, so the sweep of the next iteration cannot complete
+                    // and the time-out is reported by the one workgroup that writes the state -- an error cannot be lost between two
+                    // writers (advisor, round 5: a poller's `handoff_timeout = 1` could be overwritten by the sweeper's first-iteration store).
                     const int lane = (int)threadIdx.x;
                     const unsigned int want = a.seq0 + (unsigned int)it - 1u;
                     const unsigned int spin_limit = min(*(volatile const unsigned int*)&kt_sweep_spin_limit, 1u << 20);
+                    const unsigned int tick_limit = 2u * *(volatile const unsigned int*)&kt_wait_limit_ticks;
+                    const unsigned long long tick0 = kt_ticks();
                     unsigned long long g = 0;
                     unsigned int spins = 0;
-                    bool ok;
+                    bool ok, gone;
                     for (;;) {
-                        if (lane < 12) g = __hip_atomic_load(&a.pose_gran[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = lane >= 12 || (unsigned int)(g >> 32) == want;
-                        if (__all(ok) || ++spins > spin_limit) break;
+                        if (lane < 13) g = __hip_atomic_load(&a.pose_gran[lane == 12 ? KT_POSE_ABORT : lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int ahead = (int)((unsigned int)(g >> 32) - want);
+                        ok = lane >= 12 || ahead == 0;
+                        gone = lane == 12 && ahead >= 0 && ahead < a.n_iter;   // the launch was aborted at or after the iteration waited for
+                        if (__all(ok) || __any(gone) || ++spins > spin_limit || ((spins & 15u) == 0 && kt_ticks() - tick0 > tick_limit)) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    const bool got = __all(ok);
+                    const bool got = __all(ok) && !__any(gone);
                     if (lane < 12) s_pose[lane] = __uint_as_float((unsigned int)g);
-                    if (lane == 12) { s_pose[12] = got ? 0.0f : 1.0f; if (!got) a.state->handoff_timeout = 1; }   // (reported by complete_frame)
+                    if (lane == 12) s_pose[12] = got ? 0.0f : 1.0f;
                 }
             }
             __syncthreads();   // (the solving workgroup: its tail wrote s_pose)
+            if (s_pose[12] != 0.0f) return;   // workgroup-uniform: no pose (see above)
             // (wave-uniform values: into scalar registers, where kt_icp_kernel's arguments live too -- as per-lane copies they cost 12 VGPRs)
             const auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
             for (int k = 0; k < 9; ++k) fn.Rcurr.m[k] = uni(s_pose[k]);
@@ -600,6 +631,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
         kt_reduce29_sweep(gran, total);
         // ICPOdometry.cpp:127-178, as kt_icp_kernel's KT_MODE_ICP_SOLVE epilogue
         if (threadIdx.x < 42) sys[threadIdx.x] = (double)total[kt_sys_slot(threadIdx.x)];
+        const bool timed_out = total[KT_RED_SLOTS - 1] != 0.0f;   // (workgroup-uniform: read behind the sweep's closing barrier)
         __syncthreads();
         if (threadIdx.x == 64) {
             a.state->last_residual[0] = total[27];
@@ -609,11 +641,16 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
                 for (int k = 0; k < 9; ++k) { a.state->Rprev[k] = a.Rcurr.m[k]; a.state->Rprev_inv[k] = a.Rprev_inv.m[k]; }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) a.state->tprev[k] = a.tprev[k];
-                a.state->handoff_timeout = total[KT_RED_SLOTS - 1] != 0.0f ? 1 : 0;
-            } else if (total[KT_RED_SLOTS - 1] != 0.0f) {
+                a.state->handoff_timeout = timed_out ? 1 : 0;
+            } else if (timed_out) {
                 a.state->handoff_timeout = 1;
             }
+            // a sweep that gave up ends the launch: the waiting workgroups are told which iteration it was and leave, and so does this one
+            // (the frame has no pose: the set-up kernel parks its fusion, the host re-runs its odometry in the stepwise form)
+            if (timed_out)
+                __hip_atomic_store(&a.pose_gran[KT_POSE_ABORT], (unsigned long long)(a.seq0 + (unsigned int)it) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (timed_out) return;
         if (threadIdx.x < 64) kt_solve_and_update_wave(a.state, sys, pose_d, pose_f, tail_work, a.pose_gran, a.seq0 + (unsigned int)it, s_pose);
     }
 }
@@ -625,9 +662,20 @@ int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
     if (c->fault_skip > 0) --c->fault_skip;
     else if (c->fault_count > 0) { --c->fault_count; a.fault = 1; }
     if (a.n_iter > 0) {
-        a.granules2 = kt_second_granules(c);
+        static_assert(KT_LEVEL_SET_STRIDE >= KT_RED_PAIRS * KT_RED_BLOCKS, "a granule set per iteration");
+        if ((size_t)KT_LEVEL_SET_BASE + (size_t)KT_LEVEL_SETS * KT_LEVEL_SET_STRIDE > (size_t)32 * c->red_max_blocks || a.n_iter > KT_LEVEL_SETS) {
+            kt_set_error("kt_icp_level_kernel: %d iterations do not fit the hand-off buffer", a.n_iter);
+            return KT_ERR_ARG;
+        }
+        a.level_gran = (unsigned long long*)c->red_partials + KT_LEVEL_SET_BASE;
         a.pose_gran = c->pose_gran;
-        hipLaunchKernelGGL(kt_icp_level_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
+        if (kt_icp_coop_launch()) {
+            // the runtime's promise that the whole grid is resident at once (the workgroups wait for each other inside the launch)
+            void* args[1] = {(void*)&a};
+            KT_HIP(hipLaunchCooperativeKernel((const void*)kt_icp_level_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), args, 0, c->stream));
+        } else {
+            hipLaunchKernelGGL(kt_icp_level_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
+        }
     } else {
         hipLaunchKernelGGL(kt_icp_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
     }
@@ -661,7 +709,7 @@ extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3
     a.Rcurr = *Rcurr; a.Rprev_inv = *Rprev_inv;
     for (int k = 0; k < 3; ++k) { a.tcurr[k] = tcurr[k]; a.tprev[k] = tprev[k]; }
     a.state = nullptr; a.first = 0; a.out29 = c->red_out; a.mode = KT_MODE_HOST; a.keep29 = 0;
-    a.n_iter = 0; a.seq0 = 0; a.pose_gran = nullptr; a.granules2 = nullptr;
+    a.n_iter = 0; a.seq0 = 0; a.pose_gran = nullptr; a.level_gran = nullptr;
     int s = kt_icp_launch(c, a);
     if (s != KT_OK) return s;
     KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * KT_RED_SLOTS, hipMemcpyDeviceToHost, c->stream));
@@ -676,7 +724,7 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
                        int mode, const kt_track_state* init, int keep29)
 {
     kt_icp_args a;
-    a.n_iter = 0; a.seq0 = 0; a.pose_gran = nullptr; a.granules2 = nullptr;
+    a.n_iter = 0; a.seq0 = 0; a.pose_gran = nullptr; a.level_gran = nullptr;
     a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
     a.intr = *intr; a.cols = cols; a.rows = rows; kt_icp_set_thresholds(a, dist_thres, angle_thres);
     a.state = state; a.out29 = nullptr; a.mode = mode;
@@ -705,10 +753,14 @@ int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr
     memcpy(a.Rcurr.m, frame->Rprev, sizeof(a.Rcurr.m));
     memcpy(a.Rprev_inv.m, frame->Rprev_inv, sizeof(a.Rprev_inv.m));
     for (int k = 0; k < 3; ++k) { a.tcurr[k] = frame->tprev[k]; a.tprev[k] = frame->tprev[k]; }
-    a.n_iter = n_iter;
-    a.seq0 = c->odo_seq + 1u;
-    c->odo_seq += (unsigned int)n_iter;
-    return kt_icp_launch(c, a);
+    for (int done = 0; done < n_iter; done += KT_LEVEL_SETS) {   // (the tracker's levels run 4, 5 and 10 iterations: one launch each)
+        a.n_iter = n_iter - done < KT_LEVEL_SETS ? n_iter - done : KT_LEVEL_SETS;
+        a.seq0 = c->odo_seq + 1u;
+        c->odo_seq += (unsigned int)a.n_iter;
+        KT_TRY(kt_icp_launch(c, a));
+        a.first = 0;
+    }
+    return KT_OK;
 }
 
 // ICPOdometry::getIncrementalTransformation (ICPOdometry.cpp:68-186) as ONE entry point (SURVEY 8(b) export list): pose in / pose out,
@@ -1319,10 +1371,13 @@ extern "C" int kt_debug_handoff_fault(kt_ctx* c, int skip, int count, unsigned i
         unsigned int* d = nullptr;
         KT_HIP(hipMalloc((void**)&d, sizeof(unsigned int)));
         KT_HIP(hipMemsetAsync(d, 0, sizeof(unsigned int), c->stream));
-        // the two [15][256] kt_reduce29 sets (the second one starts at 32 * KT_RED_BLOCKS: kt_second_granules)
+        // the two [15][256] kt_reduce29 sets (the second one starts at 32 * KT_RED_BLOCKS: kt_second_granules) and the level kernel's per-iteration sets
         for (int set = 0; set < 2; ++set)
             hipLaunchKernelGGL(kt_granules_dirty_kernel, dim3(4), dim3(256), 0, c->stream, (const unsigned long long*)c->red_partials + set * 32 * KT_RED_BLOCKS,
                                KT_RED_PAIRS * KT_RED_BLOCKS, d);
+        for (int set = 0; set < KT_LEVEL_SETS; ++set)
+            hipLaunchKernelGGL(kt_granules_dirty_kernel, dim3(4), dim3(256), 0, c->stream,
+                               (const unsigned long long*)c->red_partials + KT_LEVEL_SET_BASE + set * KT_LEVEL_SET_STRIDE, KT_RED_PAIRS * KT_RED_BLOCKS, d);
         KT_HIP(hipMemcpyAsync(dirty_out, d, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
         KT_HIP(hipStreamSynchronize(c->stream));
         KT_HIP(hipFree(d));
@@ -1340,20 +1395,37 @@ extern "C" int kt_debug_icp_levels(int on) { kt_icp_levels_override = on < 0 ? -
 // The level kernel's workgroups wait for each other INSIDE the launch (a pose needs every workgroup's granules), so all KT_RED_GRID of them must
 // be resident at once: a device (or a partition of one) that cannot hold the whole grid would run the first wave of workgroups into their bounded
 // waits.  Checked once per process against the occupancy the runtime reports; such a device keeps the launch per iteration.
-static bool kt_icp_levels_fit()
+static bool kt_icp_levels_fit(int dev)
 {
-    static const bool fit = []() {
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kt_icp_level_kernel, KT_RED_THREADS, 0) != hipSuccess) return false;
-        return (long long)cus * per_cu >= KT_RED_GRID;
-    }();
-    return fit;
+    static int fit[64];   // per device: 0 unknown, 1 fits, -1 does not (advisor, round 5: the answer was taken for the CURRENT device and kept for the process)
+    if (dev < 0 || dev >= 64) return false;
+    if (fit[dev] == 0) {
+        int cus = 0, per_cu = 0, prev = 0;
+        bool ok = hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess;
+        ok = ok && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+        ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kt_icp_level_kernel, KT_RED_THREADS, 0) == hipSuccess;
+        (void)hipSetDevice(prev);
+        fit[dev] = (ok && (long long)cus * per_cu >= KT_RED_GRID) ? 1 : -1;
+    }
+    return fit[dev] > 0;
 }
-bool kt_icp_levels_selected()
+// KT_ICP_COOP=1: launch the level kernel through hipLaunchCooperativeKernel (A/B: profiles/r06_experiments.md)
+bool kt_icp_coop_launch()
+{
+    static const bool on = []() { const char* e = getenv("KT_ICP_COOP"); return e && atoi(e) != 0; }();
+    return on;
+}
+bool kt_icp_levels_selected(int device)
 {
     const char* e = getenv("KT_ICP_LEVELS");
     const bool env = e ? atoi(e) != 0 : KT_ICP_LEVELS_DEFAULT != 0;
-    return (kt_icp_levels_override < 0 ? env : kt_icp_levels_override != 0) && kt_icp_levels_fit();
+    return (kt_icp_levels_override < 0 ? env : kt_icp_levels_override != 0) && kt_icp_levels_fit(device);
+}
+// test / tuning hook: the time bound of the hand-off waits in ticks of the 100 MHz clock (0 = the default, 50 ms)
+extern "C" int kt_debug_wait_limit(kt_ctx* c, unsigned int ticks)
+{
+    KT_ARG(c);
+    const unsigned int v = ticks ? ticks : 5000000u;
+    KT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(kt_wait_limit_ticks), &v, sizeof(v), 0, hipMemcpyHostToDevice, c->stream));
+    return KT_OK;
 }

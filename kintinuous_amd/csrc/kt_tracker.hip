@@ -64,6 +64,9 @@ struct Pending { const uint16_t* depth; const uint8_t* rgb; int set; const uint1
 #define KT_NSLOTS 4   // host-frame staging: frame in flight + two read-aheads + the one being filled
 #define KT_NODO 8     // ring of "odometry of frame f enqueued" events
 
+#ifndef KT_SIDE_GATE_DEFAULT
+#define KT_SIDE_GATE_DEFAULT 2
+#endif
 enum { ST_PYRAMID = 0, ST_ODOMETRY, ST_SHIFT, ST_INTEGRATE, ST_RAYCAST, ST_RESIZE, ST_TSDF23, ST_COUNT };
 
 }  // namespace
@@ -167,6 +170,20 @@ struct kt_tracker {
     struct PlanSlot { kt_tsdf_plan plan; hipEvent_t done; long long ordinal; float R[9], t[3], theta, tau; int wrap[3]; int set; const uint16_t* depth; const uint8_t* rgb; };
     bool icp_levels;   // ICP-only odometry: one launch per pyramid level (kt_icp_level_kernel) instead of one per iteration, while this tracker is alone
     bool last_icp_levels;   // ... and whether the last frame's chain took that form
+    bool counted;           // this tracker is in kt_live_trackers (a create that failed early is not)
+    // A hand-off time-out is not the end of the frame (round 6): complete_frame re-runs the frame's odometry in the stepwise form, and the
+    // level form stays off for icp_demote more frames (doubling per relapse: something -- another process on the GPU, a CU-masked queue --
+    // keeps its grid from being resident; the stepwise chain needs no co-residency and gives the same bits).
+    int icp_demote, icp_demote_len;
+    long long odo_fallbacks;   // frames whose odometry was re-run (kt_tracker_odometry_fallbacks)
+    int out_last_set;          // RGB-D "last" set of the frame in flight (for that re-run)
+    // Side-stream gate (round 6).  The read-ahead of frame f + 1 is enqueued the moment the host has seen the pose of frame f - 1 -- exactly
+    // when that frame's voxel kernel starts -- and the voxel kernel deals its task list STATICALLY over the resident waves: workgroups of
+    // another stream on some compute units make those the slowest, and the launch is as long as its slowest SIMD (farwall768: 0.60 ms alone,
+    // 0.85 next to the 1280x960 read-ahead).  With the gate on, the side streams start with a one-thread kernel that sleeps until the ray cast
+    // of the frame in flight has started (kt_raycast_kernel stores the frame's sequence number into gate_dev: no event, no packet on the main
+    // stream), so the read-ahead runs beside the ray cast -- whose workgroups are handed out dynamically -- and the next odometry.
+    unsigned int* gate_dev; int side_gate;   // side_gate: 0 off, 1 on
     PlanSlot plans[3]; hipStream_t plan_stream;          // (three: frame f + 1 is planned while the voxel kernels of f and f - 1 may still read theirs)
     int plan_sel; bool plan_enabled; float plan_margin_scale;
     // test hooks (kt_tracker_debug_plan_*): the pose every frame WILL arrive at, taken from an identical earlier run, as the prediction;
@@ -534,15 +551,28 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
     // The level form is used only while this is the ONLY live tracker of the process (decided per frame, icp_odometry): its workgroups wait for
     // each other inside a launch and need the whole machine, so anything that keeps compute units busy next to it for long -- a second tracker
     // fed from the same host (scripts/multistream_one_gpu.py) -- can keep its last workgroup out until the bounded waits give up.  The
-    // tracker's own side streams are finite per frame and its main-stream kernels are ordered behind the launch.  Processes that share ONE GPU
-    // must set KT_ICP_LEVELS=0 themselves.
-    t->icp_levels = kt_icp_levels_selected();
+    // tracker's own side streams are finite per frame and its main-stream kernels are ordered behind the launch.  What this process cannot
+    // see -- another process on the same GPU -- is handled per frame: a launch whose waits give up (50 ms) aborts, complete_frame re-runs the
+    // frame's odometry in the stepwise form and keeps the level form off for a while (icp_demote).
+    t->icp_levels = kt_icp_levels_selected(ctx->device);
     t->last_icp_levels = false;
+    t->icp_demote = 0; t->icp_demote_len = 64; t->odo_fallbacks = 0; t->out_last_set = -1;
     kt_live_trackers.fetch_add(1);
+    t->counted = true;
     for (int k = 0; k < 3; ++k) {
         KT_TRY(kt_tsdf_plan_alloc(&t->plans[k].plan, cfg->N));
         KT_HIP(hipEventCreateWithFlags(&t->plans[k].done, KT_EV_DEVICE));
         t->plans[k].ordinal = -1; t->plans[k].set = -1; t->plans[k].depth = nullptr; t->plans[k].rgb = nullptr;
+    }
+    KT_TRY(dev_alloc(&t->gate_dev, 4, true));
+    {
+        // KT_SIDE_GATE: 0 never, 1 always, 2 (default) on dense views only -- the rule that picks 32 x 2 wave-columns (more than 1.5 pixels per
+        // voxel column: the voxel kernel is the frame's longest and its launch is dense)
+        const char* e = getenv("KT_SIDE_GATE");
+        const int mode = e ? atoi(e) : KT_SIDE_GATE_DEFAULT;
+        int wcx = 0, wcy = 0, xg = 0, yg = 0;
+        kt_tsdf_plan_shape(cfg->cols, cfg->rows, cfg->N, &wcx, &wcy, &xg, &yg);
+        t->side_gate = mode == 1 || (mode == 2 && wcx == 32) ? 1 : 0;
     }
     t->plan_enabled = getenv("KT_NO_PLAN") == nullptr;   // (A/B switch: every frame through the in-stream pre-pass)
     t->plan_margin_scale = getenv("KT_PLAN_MARGIN_SCALE") ? (float)atof(getenv("KT_PLAN_MARGIN_SCALE")) : 1.0f;   // (tests: 0 makes every plan miss)
@@ -572,7 +602,7 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
 int kt_tracker_destroy(kt_tracker* t)
 {
     if (!t) return KT_OK;
-    kt_live_trackers.fetch_sub(1);
+    if (t->counted) kt_live_trackers.fetch_sub(1);   // (advisor, round 5: a create that failed before it was counted took the counter to -1)
     (void)hipStreamSynchronize(t->ctx->stream);
     (void)join_slice_jobs(t);
     if (t->worker.joinable()) {
@@ -626,6 +656,7 @@ int kt_tracker_destroy(kt_tracker* t)
         if (t->plans[k].done) (void)hipEventDestroy(t->plans[k].done);
     }
     (void)hipFree(t->fp_dev);
+    (void)hipFree(t->gate_dev);
     (void)hipFree(t->bricks);
     for (int k = 0; k < 2; ++k) (void)hipFree(t->wrkc_carry[k]);
     delete t;
@@ -699,7 +730,7 @@ static int odometry_end(kt_tracker* t)
 }
 
 // ICPOdometry::getIncrementalTransformation, ICPOdometry.cpp:68-186
-static int icp_odometry(kt_tracker* t)
+static int icp_odometry(kt_tracker* t, bool stepwise_only = false)
 {
     int iters[KT_LEVELS] = {10, 5, 4, 0};
     if (t->cfg.fast_odometry) { iters[0] = 0; iters[1] = 10; iters[2] = 5; iters[3] = 0; }
@@ -714,7 +745,8 @@ static int icp_odometry(kt_tracker* t)
     memcpy(init.tcurr, t->tlast, sizeof(init.tcurr));
     kt_mat33_inverse(init.Rprev, init.Rprev_inv);  // ICPOdometry.cpp:81
     bool first = true;
-    t->last_icp_levels = t->icp_levels && kt_live_trackers.load() == 1;
+    t->last_icp_levels = !stepwise_only && t->icp_levels && t->icp_demote == 0 && kt_live_trackers.load() == 1;
+    if (!stepwise_only && t->icp_demote > 0) --t->icp_demote;
     if (t->last_icp_levels) {   // one launch per level: the iterations of a level hand the pose over inside the kernel (kt_track.hip: kt_icp_level_kernel)
         for (int l = KT_LEVELS - 1; l >= 0; --l) {
             if (iters[l] <= 0) continue;
@@ -977,7 +1009,7 @@ static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv
 
 // [H] integrate (:864-876) + [I] raycast (:880-890) + [J] predicted-map pyramid (:892-899, fused into the raycast epilogue), with
 // the pose taken from fp_dev; wrap = the tracker's current v_wrap_copy
-static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, const uint8_t* colors, const kt_tsdf_plan* plan = nullptr)
+static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, const uint8_t* colors, const kt_tsdf_plan* plan)
 {
     kt_ctx* c = t->ctx;
     const int cols = t->cfg.cols, rows = t->cfg.rows, N = t->N;
@@ -1000,7 +1032,7 @@ static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, con
     float* np_[3] = {t->nmaps_g_prev[1], t->nmaps_g_prev[2], t->nmaps_g_prev[3]};
     KT_TRY(kt_raycast_impl(c, &t->intr, &dummy_R, dummy_t, t->tranc_dist, t->volume_size, t->tsdf, t->vmaps_g_prev[0], t->nmaps_g_prev[0], cols, rows,
                            t->v_wrap_copy, t->vmap_curr_color, t->color, N, t->counting ? t->steps_dev : nullptr, pyr ? vp : nullptr,
-                           pyr ? np_ : nullptr, t->fp_dev, t->bricks));
+                           pyr ? np_ : nullptr, t->fp_dev, t->bricks, t->gate_dev, t->frame_seq));
     KT_TRY(ev_end(t, ST_RAYCAST));
     return KT_OK;
 }
@@ -1243,7 +1275,7 @@ static int finish_pose(kt_tracker* t, float Rcurr[9], float tcurr[3], bool specu
         // the fusion the device parked (or that was never enqueued), with the final pose and wrap
         v_wrap_copy_update(t);
         KT_TRY(launch_setup(t, 1, Rcurr, tcurr));
-        KT_TRY(enqueue_fusion(t, t->out_set, t->out_depth, t->out_rgb));
+        KT_TRY(enqueue_fusion(t, t->out_set, t->out_depth, t->out_rgb, nullptr));
     }
     v_wrap_copy_update(t);
     ++t->global_time;
@@ -1352,38 +1384,60 @@ static int plan_ahead(kt_tracker* t, const Pending& next, long long ordinal)
 // Host half of the frame enqueued by the last kt_tracker_process_frame call: wait for its pose (the copy-stream event, NOT the
 // fusion kernels), do the pose bookkeeping of KintinuousTracker.cpp:574-595, 903-909 and, when the volume has to shift
 // (:627-833), run the shift and redo the fusion the device parked.  Called at the start of the next frame and by every getter.
+// the ONE host wait of a frame: spin on the sequence word the set-up kernel posts after the odometry iterations (the GPU goes straight on
+// to integrate / raycast meanwhile)
+static int wait_for_pose(kt_tracker* t)
+{
+    const auto w0 = std::chrono::steady_clock::now();
+    volatile unsigned int* seq = &t->mirror->seq;
+    long long spins = 0;
+    while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != t->frame_seq) {
+        if ((++spins & 0xfff) == 0) {
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            if (waited > 30.0) {
+                const hipError_t e = hipStreamQuery(t->ctx->stream);
+                kt_set_error("tracker: no pose from the device after 30 s (stream status: %s)", hipGetErrorString(e));
+                return KT_ERR_STATE;
+            }
+            if (waited > 0.002) std::this_thread::yield();
+        }
+    }
+    t->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+    return KT_OK;
+}
+
 static int complete_frame(kt_tracker* t)
 {
     if (!t->outstanding) return KT_OK;
     t->outstanding = false;
     kt_ctx* c = t->ctx;
-    {
-        // the ONE host wait of the frame: spin on the sequence word the set-up kernel posts after the odometry iterations (the GPU
-        // goes straight on to integrate / raycast meanwhile)
-        const auto w0 = std::chrono::steady_clock::now();
-        volatile unsigned int* seq = &t->mirror->seq;
-        long long spins = 0;
-        while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != t->frame_seq) {
-            if ((++spins & 0xfff) == 0) {
-                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-                if (waited > 30.0) {
-                    const hipError_t e = hipStreamQuery(c->stream);
-                    kt_set_error("tracker: no pose from the device after 30 s (stream status: %s)", hipGetErrorString(e));
-                    return KT_ERR_STATE;
-                }
-                if (waited > 0.002) std::this_thread::yield();
-            }
-        }
-        t->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-    }
+    KT_TRY(wait_for_pose(t));
     if (t->out_ordinal + 1 > t->frames_observed) t->frames_observed = t->out_ordinal + 1;
     ev_collect(t);
     if (t->mirror->handoff_timeout) {
-        // the granule buffer is in an undefined state (kt_track.hip: kt_refill_granules): refill it behind everything enqueued so far,
-        // before the caller's next frame (or its reset) launches another reduction
-        (void)kt_refill_granules(c);
-        kt_set_error("odometry: inter-workgroup hand-off timed out");
-        return KT_ERR_STATE;
+        // An inter-workgroup hand-off of this frame's odometry gave up (kt_track.hip): the frame has no pose, and the set-up kernel parked its
+        // fusion (skip = 1).  The reference's icpStep is stream-ordered and cannot fail this way (reduce.cu:347-419), so neither may the frame:
+        // the hand-off buffer is refilled (a sweep that gave up leaves it undefined: kt_refill_granules) and the odometry runs again, one
+        // launch per iteration, from the frame's starting pose -- rmats_ / tvecs_.back() have not moved, the frame set and the previous
+        // frame's predicted maps are untouched -- followed by the set-up kernel and the fusion exactly as process_frame enqueued them.
+        // Only if THAT chain reports a time-out as well (no co-residency is involved: a fault, not contention) is the frame an error.
+        KT_TRY(kt_refill_granules(c));
+        ++t->odo_fallbacks;
+        t->icp_demote = t->icp_demote_len;
+        if (t->icp_demote_len < 65536) t->icp_demote_len *= 2;
+        select_set(t, t->out_set);
+        const bool icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
+        if (icp) KT_TRY(icp_odometry(t, true));
+        else KT_TRY(rgbd_odometry(t, t->out_set, t->out_last_set));
+        if (++t->frame_seq == 0) t->frame_seq = 1;
+        KT_TRY(launch_setup(t, 0, nullptr, nullptr));
+        if (t->out_speculated) KT_TRY(enqueue_fusion(t, t->out_set, t->out_depth, t->out_rgb, t->plan_sel >= 0 ? &t->plans[t->plan_sel].plan : nullptr));
+        KT_TRY(wait_for_pose(t));
+        if (t->mirror->handoff_timeout) {
+            (void)kt_refill_granules(c);   // before the caller's next frame (or its reset) launches another reduction
+            kt_set_error("odometry: inter-workgroup hand-off timed out (also in the stepwise re-run of the frame)");
+            return KT_ERR_STATE;
+        }
     }
     float Rcurr[9], tcurr[3];
     memcpy(Rcurr, t->mirror->R, sizeof(Rcurr));
@@ -1483,6 +1537,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     const int last_set = t->prev_set;   // "last" of RGBDOdometry for this frame
     t->prev_set = set;
     t->out_set = set;
+    t->out_last_set = last_set;
     t->carry_sel ^= 1;                  // the state the previous tracked frame left becomes "before this frame"
 
     if (t->global_time == 0) {  // [B] :481-557
@@ -1616,6 +1671,17 @@ int kt_tracker_prefetch_frame_host(kt_tracker* t, const uint16_t* depth_host, co
     return prefetch_impl(t, t->depth_stage[slot], t->rgb_stage[slot], depth_host, rgb_host);
 }
 
+// One thread that sleeps until *flag has reached `want` (the ray cast of that frame has started), bounded in time: a frame whose fusion never
+// runs (an error path) must not hold the side stream.
+__global__ void kt_gate_kernel(const unsigned int* flag, unsigned int want, unsigned int tick_limit)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > tick_limit) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 static int prefetch_impl(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors, const uint16_t* depth_host, const uint8_t* rgb_host)
 {
     if (t->pending.size() >= 2) { kt_set_error("kt_tracker_prefetch_frame: two read-ahead frames are already outstanding"); return KT_ERR_STATE; }
@@ -1629,6 +1695,12 @@ static int prefetch_impl(kt_tracker* t, const uint16_t* depth_raw, const uint8_t
     t->last_assigned = set;
     KT_TRY(wait_frame_consumed(t, t->pre_stream, t->sets[set].user));
     t->pre_ctx.device = t->ctx->device;
+    if (t->side_gate && t->global_time > 0 && !t->has_trajectory) {
+        // the frame just observed is in its voxel kernel now: hold the read-ahead (and, behind its `ready` event, the plan stream) until
+        // that frame's ray cast starts; 20 ms bound
+        hipLaunchKernelGGL(kt_gate_kernel, dim3(1), dim3(1), 0, t->pre_stream, t->gate_dev, t->frame_seq, 2000000u);
+        KT_LAUNCH_CHECK();
+    }
     KT_TRY(build_frame_set(t, &t->pre_ctx, set, depth_raw, colors));
     KT_HIP(hipEventRecord(t->sets[set].ready, t->pre_stream));
     t->pending.push_back(Pending{depth_raw, colors, set, depth_host, rgb_host});
@@ -1871,6 +1943,14 @@ int kt_tracker_slice_processed(kt_tracker* t, int i, kt_point_xyzrgbnormal* out)
     return KT_OK;
 }
 
+int kt_tracker_odometry_fallbacks(kt_tracker* t, long long* out)
+{
+    KT_ARG(t && out);
+    KT_TRY(complete_frame(t));
+    *out = t->odo_fallbacks;
+    return KT_OK;
+}
+
 int kt_tracker_plan_stats(kt_tracker* t, long long out2[2])
 {
     KT_ARG(t && out2);
@@ -1932,3 +2012,4 @@ int kt_tracker_export_poses_device(kt_tracker* t, int k, float* dst_dev)
 }  // extern "C"
 
 extern "C" int kt_tracker_debug_icp_levels(kt_tracker* t) { return t && t->last_icp_levels ? 1 : 0; }
+extern "C" int kt_tracker_debug_side_gate(kt_tracker* t) { return t ? t->side_gate : 0; }

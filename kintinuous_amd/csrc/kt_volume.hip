@@ -1935,6 +1935,10 @@ struct kt_raycast_args {
     float* vpyr[3]; float* npyr[3];
     const kt_frame_params* fp;  // when set: R / t come from the device
     const unsigned char* bricks; int nb;   // optional negative-brick flags maintained by tsdf23 (N % 32 == 0, nb^3 <= KT_RC_MAX_BRICKS)
+    // tracker only: a device word that receives gate_seq when this launch STARTS (and is not parked) -- i.e. when the voxel kernel in front of
+    // it on the stream has drained.  The tracker's side streams wait for it (kt_tracker.hip: kt_gate_kernel) instead of running beside the
+    // voxel kernel; no event, no marker packet on this stream.
+    unsigned int* gate; unsigned int gate_seq;
 };
 
 struct kt_rc {
@@ -2094,6 +2098,7 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
     kt_raycast_args a = a_in;
     if (a.fp) {
         if (a.fp->skip) return;  // parked for the host's shift path; the predicted maps are rebuilt there
+        if (a.gate && (blockIdx.x | blockIdx.y | threadIdx.x) == 0) __hip_atomic_store(a.gate, a.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < 9; ++k) a.R.m[k] = a.fp->R[k];
         a.tx = a.fp->t[0]; a.ty = a.fp->t[1]; a.tz = a.fp->t[2];
@@ -2349,7 +2354,7 @@ int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const
                     const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
                     const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,
                     unsigned long long* steps_dev, float* const* vpyr, float* const* npyr, const kt_frame_params* fp,
-                    const unsigned char* bricks)
+                    const unsigned char* bricks, unsigned int* gate, unsigned int gate_seq)
 {
     KT_ARG(c && intr && Rcurr && tcurr && volume_size && volume && vmap && nmap && voxel_wrap && vmap_curr_color && color_volume);
     KT_ARG(N > 0 && cols > 0 && rows > 0);
@@ -2370,6 +2375,7 @@ int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const
     a.vmap_color = (uchar4*)vmap_curr_color;
     a.steps = steps_dev;
     a.fp = fp;
+    a.gate = gate; a.gate_seq = gate_seq;
     const bool pyr = vpyr && npyr;
     for (int k = 0; k < 3; ++k) { a.vpyr[k] = pyr ? vpyr[k] : nullptr; a.npyr[k] = pyr ? npyr[k] : nullptr; }
     if (pyr) KT_ARG((cols % 8) == 0 && (rows % 8) == 0);

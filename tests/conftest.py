@@ -22,7 +22,7 @@ def pytest_configure(config):
 # files: the only tests whose outcome can depend on scheduling -- go LAST.  Unknown modules keep their place in the middle.
 _ORDER = ["test_golden_ref", "test_golden", "test_gpu_configs", "test_gpu_fullsize", "test_gpu_image", "test_gpu_track", "test_gpu_solve",
           "test_gpu_volume", "test_gpu_sweep", "test_gpu_tol", "test_gpu_tracker", "test_slice_process", "test_pcd", "test_jpeg", "test_gpu_comm"]
-_LAST = ["test_gpu_bench_cli", "test_gpu_host_shell"]
+_LAST = ["test_gpu_bench_cli", "test_gpu_two_process", "test_gpu_host_shell"]
 
 
 def pytest_collection_modifyitems(session, config, items):

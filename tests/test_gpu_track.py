@@ -228,40 +228,86 @@ def test_a_reported_handoff_timeout_leaves_a_clean_buffer(ctx, oracle_mod, small
 
 @pytest.mark.parametrize("levels", [1, 0])
 def test_tracker_recovers_from_a_handoff_timeout(ctx, small_scene, levels):
-    """The tracker's form of the same: the last odometry launch of a frame times out -> the frame's getter reports it, nothing is fused with
-    the pose-less frame, the buffer is clean, and after kt_tracker_reset the sequence gives the poses and the volume of an undisturbed run.
-    Both forms of the ICP chain: one launch per pyramid level (kt_icp_level_kernel: 3 launches per frame, every iteration of the faulted
-    launch loses the publisher) and one launch per iteration (19)."""
+    """The tracker's form of the same (round 6: a time-out is no longer the end of the frame).  The reference's icpStep is stream-ordered and cannot
+    time out (reduce.cu:347-419); here the last odometry launch of a frame loses a publisher -> its sweep gives up, the level kernel aborts the
+    launch (the waiting workgroups leave), the set-up kernel parks the fusion, and complete_frame re-runs the frame's odometry one launch per
+    iteration from the frame's starting pose: NO error, the frame's pose and every later pose and both volumes equal to an undisturbed run's,
+    the fallback counted, the level form off for the frames behind it.  A fault that also hits the re-run IS reported; the buffer is clean
+    afterwards and a reset sequence gives the undisturbed results again.  Both forms of the ICP chain."""
     from kintinuous_amd import abi
     cam, frames, traj = small_scene
     cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
-    abi._chk(abi.lib().kt_debug_icp_levels(levels))
-    try:
-        trk = abi.Tracker(ctx, cfg)
-    finally:
-        abi._chk(abi.lib().kt_debug_icp_levels(-1))
 
-    def run():
+    def make():
+        abi._chk(abi.lib().kt_debug_icp_levels(levels))
+        try:
+            return abi.Tracker(ctx, cfg)
+        finally:
+            abi._chk(abi.lib().kt_debug_icp_levels(-1))
+
+    def run(trk, fault_at=None, fault=None):
         poses = []
         for k, (d, rgb) in enumerate(frames[:5]):
+            if k == fault_at:
+                trk.pose()
+                fault()
             trk.process_frame_host(d, rgb, 33333 * k)
             poses.append(np.concatenate([x.ravel() for x in trk.pose()]))
         return np.array(poses), trk.volume().copy(), trk.color_volume().copy()
 
+    form = lambda t: abi.lib().kt_tracker_debug_icp_levels(t.h)
+    trk = make()
     try:
-        P0, V0, C0 = run()
+        P0, V0, C0 = run(trk)
+        assert trk.odometry_fallbacks() == 0 and form(trk) == levels
         trk.reset()
+        # frame 2: its last launch (of 3, or of 10 + 5 + 4) loses workgroup 0
+        P1, V1, C1 = run(trk, 2, lambda: _handoff_fault(ctx, 2 if levels else 18, 1, spin_limit=64, want_dirty=False))
+        assert trk.odometry_fallbacks() == 1
+        assert np.array_equal(P0.view(np.uint32), P1.view(np.uint32)) and np.array_equal(V0, V1) and np.array_equal(C0, C1)
+        assert form(trk) == 0          # demoted: the frames behind a fallback run the stepwise chain
+        assert _handoff_fault(ctx, 0, 0) == 0
+        trk.close()
+        # every launch from frame 2 on loses the publisher: the re-run gives up as well -> reported
+        trk = make()
         for k in range(2):
             trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
         trk.pose()
-        _handoff_fault(ctx, 2 if levels else 18, 1, spin_limit=64, want_dirty=False)   # frame 2: its last launch (of 3, or of 10 + 5 + 4) faulted
+        _handoff_fault(ctx, 0, 1000, spin_limit=64, want_dirty=False)
         trk.process_frame_host(frames[2][0], frames[2][1], 33333 * 2)
         with pytest.raises(abi.KtError, match="timed out"):
             trk.pose()
         assert _handoff_fault(ctx, 0, 0) == 0
         trk.reset()
-        P1, V1, C1 = run()
-        assert np.array_equal(P0, P1) and np.array_equal(V0, V1) and np.array_equal(C0, C1)
+        P2, V2, C2 = run(trk)
+        assert np.array_equal(P0.view(np.uint32), P2.view(np.uint32)) and np.array_equal(V0, V2) and np.array_equal(C0, C2)
     finally:
         _handoff_fault(ctx, 0, 0, spin_limit=1 << 22, want_dirty=False)
+        trk.close()
+
+
+def test_hand_off_waits_are_bounded_in_time(ctx, small_scene):
+    """The bound that decides in practice is wall time (s_memrealtime), not a number of looks: with the look limit left at its default
+    (2^22 agent-scope round trips: seconds) a launch that loses a publisher must give up within the time limit -- lowered here to 2 ms so that
+    the test can tell the two apart -- and the frame must still complete through the stepwise re-run."""
+    import time
+    from kintinuous_amd import abi
+    cam, frames, traj = small_scene
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
+    trk = abi.Tracker(ctx, cfg)
+    try:
+        for k in range(2):
+            trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
+        trk.pose()
+        abi._chk(abi.lib().kt_debug_wait_limit(ctx.h, 200000))   # 2 ms
+        _handoff_fault(ctx, 0, 1, want_dirty=False)             # look limit untouched
+        t0 = time.perf_counter()
+        trk.process_frame_host(frames[2][0], frames[2][1], 33333 * 2)
+        trk.pose()
+        dt = time.perf_counter() - t0
+        assert trk.odometry_fallbacks() == 1
+        assert dt < 0.5, dt    # 2 ms of waiting + the re-run; the look limit alone would be seconds
+    finally:
+        abi._chk(abi.lib().kt_debug_wait_limit(ctx.h, 0))
+        _handoff_fault(ctx, 0, 0, want_dirty=False)
         trk.close()
