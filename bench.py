@@ -283,8 +283,8 @@ def main():
     contract_ab = None
     if abi.lib().kt_debug_tsdf_kernel().decode() == "kt_tsdf23_lean_kernel" and rank == 0 and world == 1 and args.warmup + args.steps >= 20 and not args.no_contract_ab:
         n_ab = min(args.warmup + args.steps, 60)
-        def alone_ms(tol):
-            abi._chk(abi.lib().kt_debug_tsdf_contract(1 if tol else 0))
+        def alone_ms(contract):   # 0 bit-exact, 1 survey-8c, 2 the speed-of-light measurement variant (kt_tsdf23_sol_kernel)
+            abi._chk(abi.lib().kt_debug_tsdf_contract(int(contract)))
             trk.reset()
             for i in range(n_ab - 16):
                 step(i, announce_next=False)
@@ -297,10 +297,13 @@ def main():
             trk.enable_profiling(0)
             return ms_
         try:
-            ab = [alone_ms(False), alone_ms(True), alone_ms(False), alone_ms(True)]
+            ab = [alone_ms(0), alone_ms(1), alone_ms(2), alone_ms(0), alone_ms(1), alone_ms(2)]
         finally:
             abi._chk(abi.lib().kt_debug_tsdf_contract(-1))
-        contract_ab = {"frames": [n_ab - 16, n_ab], "bit_exact_alone_ms": [round(ab[0], 5), round(ab[2], 5)], "survey8c_alone_ms": [round(ab[1], 5), round(ab[3], 5)]}
+        contract_ab = {"frames": [n_ab - 16, n_ab], "bit_exact_alone_ms": [round(ab[0], 5), round(ab[3], 5)], "survey8c_alone_ms": [round(ab[1], 5), round(ab[4], 5)],
+                       # NOT a contract: the per-voxel arithmetic the reference's --prec-div=false --prec-sqrt=false build executes, same loads / stores / predicates /
+                       # task list (kt_tsdf23_sol_kernel); what no arithmetic contract of this decomposition can beat
+                       "speed_of_light_alone_ms": [round(ab[2], 5), round(ab[5], 5)]}
     U = float(np.mean(Us))
     Lok = [x for x in Ls if x]
     lane_eff = round(sum(u for u, _ in Lok) / max(1, sum(l for _, l in Lok)), 4) if Lok else None
@@ -477,11 +480,13 @@ def roofline_stress(ctx, abi, synth):
     side_gate = int(abi.lib().kt_tracker_debug_side_gate(trk.h))
     ms, n, frame_ms = run(False)
     ms_p, n_p, frame_ms_p = run(True, 12)
-    tol = None
+    tol = sol = None
     if abi.lib().kt_debug_tsdf_kernel().decode() == "kt_tsdf23_lean_kernel":   # the A/B of the contracts (skipped when the run itself is under survey-8c)
         abi._chk(abi.lib().kt_debug_tsdf_contract(1))
         try:
             tol = (run(False), run(True, 12))
+            abi._chk(abi.lib().kt_debug_tsdf_contract(2))
+            sol = run(False)
         finally:
             abi._chk(abi.lib().kt_debug_tsdf_contract(-1))
     trk.reset()
@@ -505,6 +510,11 @@ def roofline_stress(ctx, abi, synth):
            "traffic": traffic[0], "traffic_ratio": traffic[1], "traffic_source": traffic[2],
            "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n, "U_voxels_updated": U, "frame_ms": round(frame_ms, 3),
            "side_gate": side_gate}
+    if sol:
+        # the falsifiable form of "the exactness contract is not what keeps this launch from 0.60" (VERDICT r5 item 1d): the SAME launch -- task list,
+        # loads, stores, predicates -- with the per-voxel arithmetic of the reference's --prec-div=false --prec-sqrt=false build (kt_tsdf23_sol_kernel)
+        out["speed_of_light"] = {"kernel": "kt_tsdf23_sol_kernel", "frac_alone": frac(sol[0]), "avg_launch_ms_alone": sol[0],
+                                 "note": "measurement variant, results are not the reference's; never the headline"}
     if tol:
         out["survey8c"] = {"kernel": "kt_tsdf23_tol_kernel", "frac_alone": frac(tol[0][0]), "avg_launch_ms_alone": tol[0][0],
                            "frac_pipelined": frac(tol[1][0]), "avg_launch_ms_pipelined": tol[1][0]}

@@ -138,9 +138,6 @@ _PROTOS = {
     "kt_tracker_enable_slice_stage": (_i, [_vp, _i, _i, _i]),
     "kt_tracker_slice_processed_info": (_i, [_vp, _i, C.POINTER(C.c_longlong)]),
     "kt_tracker_slice_processed": (_i, [_vp, _i, _vp]),
-    "kt_debug_stream": (_i, [_vp, _vp, _sz, _i, _i]),
-    "kt_debug_stream_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
-    "kt_debug_valu_rates": (_i, [_vp, _i, _i, _i, _pd]),
     "kt_tracker_debug_pose_log": (_i, [_vp, _i, _pf, _i, C.POINTER(C.c_int)]),
     "kt_tracker_debug_plan_truth": (_i, [_vp, _pf, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint]),
     "kt_debug_tsdf_lean": (_i, [_i]),
@@ -149,7 +146,6 @@ _PROTOS = {
     "kt_debug_sq_threshold": (_f, [_f, _i]),
     "kt_debug_icp_levels": (_i, [_i]),
     "kt_tracker_debug_icp_levels": (_i, [_vp]),
-    "kt_debug_div_check": (_i, [_vp, C.POINTER(C.c_uint)]),
     "kt_debug_icp_wg_times": (_i, [_vp, C.POINTER(C.c_ulonglong)]),
     "kt_debug_tsdf_timeline": (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),
     "kt_debug_solve_check": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i)]),
@@ -190,6 +186,32 @@ _PROTOS = {
 }
 
 ABI_SYMBOLS = tuple(_PROTOS.keys())
+
+# libkt_debug.so (csrc/kt_measure.h): measurement kernels kept out of the product library
+_MEASURE_PROTOS = {
+    "kt_debug_stream": (_i, [_vp, _vp, _sz, _i, _i]),
+    "kt_debug_stream_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
+    "kt_debug_valu_rates": (_i, [_vp, _i, _i, _i, _pd]),
+    "kt_debug_div_check": (_i, [_vp, C.POINTER(C.c_uint)]),
+}
+MEASURE_SYMBOLS = tuple(_MEASURE_PROTOS.keys())
+MEASURE_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkt_debug.so")
+_mlib = None
+
+
+def measure_lib() -> C.CDLL:
+    """Load libkt_debug.so (next to libkt_hip.so, which it links against)."""
+    global _mlib
+    if _mlib is None:
+        lib()
+        if not os.path.exists(MEASURE_LIB_PATH):
+            raise KtError(f"{MEASURE_LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+        l = C.CDLL(MEASURE_LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _MEASURE_PROTOS.items():
+            f = getattr(l, name)
+            f.restype, f.argtypes = res, args
+        _mlib = l
+    return _mlib
 
 _lib = None
 

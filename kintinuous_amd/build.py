@@ -15,7 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libkt_hip.so")
 BUILD_DIR = os.path.join(os.path.dirname(_HERE), "build")
-SOURCES = ["kt_context.hip", "kt_image.hip", "kt_volume.hip", "kt_track.hip", "kt_tracker.hip", "kt_hostmath.hip", "kt_comm.hip", "kt_slice.hip", "kt_cloud.hip", "kt_debug.hip"]
+SOURCES = ["kt_context.hip", "kt_image.hip", "kt_volume.hip", "kt_track.hip", "kt_tracker.hip", "kt_hostmath.hip", "kt_comm.hip", "kt_slice.hip", "kt_cloud.hip"]
+# measurement kernels (PMC calibration streams, instruction issue rates, the exhaustive division check): a library of their own, loaded by
+# scripts/ and one test -- the product library carries none of them
+DEBUG_OUT = os.path.join(_HERE, "libkt_debug.so")
+DEBUG_SOURCES = ["kt_debug.hip"]
 # -ffp-contract=off: a*b+c fuses only where __builtin_fmaf is written (bit-parity with the oracle);
 # IEEE division / sqrt are hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
@@ -35,9 +39,9 @@ def _deps():
 
 
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(DEBUG_OUT):
         return True
-    t = os.path.getmtime(OUT)
+    t = min(os.path.getmtime(OUT), os.path.getmtime(DEBUG_OUT))
     return any(os.path.getmtime(f) > t for f in _deps())
 
 
@@ -57,11 +61,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
             sys.stderr.write(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=len(SOURCES) + len(DEBUG_SOURCES)) as ex:
+        allobjs = list(ex.map(compile_one, SOURCES + DEBUG_SOURCES))
+    objs, dobjs = allobjs[:len(SOURCES)], allobjs[len(SOURCES):]
     r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DEBUG_OUT] + dobjs + ["-L", _HERE, "-lkt_hip", "-Wl,-rpath,$ORIGIN"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link of libkt_debug.so failed:\n{r.stderr}")
     return OUT
 
 

@@ -47,7 +47,7 @@ int kt_ctx_create(int device, kt_ctx** out)
     int s = kt_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate", __FILE__, __LINE__);
     if (s != KT_OK) { delete c; return s; }
     c->own_stream = true;
-    c->red_max_blocks = 4096;   // 1 MB of hand-off granules: the reduction sets, the residual words, one set per iteration of a level launch (kt_track.hip)
+    c->red_max_blocks = 2048;   // 512 KB of hand-off granules: the reduction sets, the residual words, the level kernel's two sets (kt_track.hip)
     KT_HIP(hipMalloc((void**)&c->red_partials, sizeof(double) * 32 * c->red_max_blocks));
     KT_HIP(hipMalloc((void**)&c->red_out, sizeof(float) * 64));
     KT_HIP(hipMalloc((void**)&c->counters, sizeof(unsigned int) * 16));

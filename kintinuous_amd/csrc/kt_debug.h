@@ -1,4 +1,5 @@
-/* kt_debug.h -- test, calibration and analysis hooks of libkt_hip.so.  NOT part of the drop-in boundary (include/kt_abi.h): nothing
+/* kt_debug.h -- test and analysis hooks of libkt_hip.so (the measurement kernels -- PMC calibration streams, instruction issue rates, the
+ * exhaustive division check -- live in libkt_debug.so: csrc/kt_measure.h).  NOT part of the drop-in boundary (include/kt_abi.h): nothing
  * here replaces a reference interface; the entry points exist for tests/, scripts/ and bench.py's diagnostics (kernel name, counters)
  * and may change without notice.  They are exported by the same library because they must run the product's own device code
  * (the voxel kernel's reciprocal chain, the Gauss-Newton tail, the granule hand-off ...) rather than a copy of it. */
@@ -16,17 +17,6 @@ extern "C" {
 int kt_tracker_debug_counts(kt_tracker* t, unsigned int out8_host[8]);
 /* diagnostics: the 29 ICP sums stashed by the last joint RGB-D + ICP iteration (or timing probes in instrumented builds) */
 int kt_tracker_debug_state(kt_tracker* t, float out29_host[29]);
-/* PMC calibration hook: stream `bytes` of a device buffer with 2- or 4-byte-per-lane coalesced accesses (the widths of the tsdf /
- * colour volume accesses); rmw = 0 reads, 1 reads and writes back.  Used by scripts/pmc_calibrate.py to scale FETCH_SIZE / WRITE_SIZE. */
-int kt_debug_stream(kt_ctx* ctx, void* buf, size_t bytes, int elem_size, int rmw);
-/* PMC calibration on the voxel kernel's own access pattern: a wave owns a 32 x 2 wave-column of an N x N x Z array and walks z, so an
- * access is two 32-lane rows (64 B at elem_size 2, 128 B at 4).  halves = 2 reads every element once; halves = 1 only the even
- * wave-columns (elem_size 2: the left 64 bytes of every 128-byte line).  N % 32 == 0, Z % 4 == 0. */
-int kt_debug_stream_rows(kt_ctx* ctx, void* buf, int N, int Z, int elem_size, int halves, int rmw);
-/* issue cost of one instruction kind (csrc/kt_debug.hip lists them) at waves_per_simd resident waves: out_host = {mean, max shader
- * ticks per wave for the loop, wave-instructions per wave, launch duration in ms, shader clock in MHz while the loop ran (s_memtime
- * against the 100 MHz s_memrealtime), first wave in .. last wave out in us, VALU per wave, SALU per wave} */
-int kt_debug_valu_rates(kt_ctx* ctx, int kind, int iters, int waves_per_simd, double out_host[8]);
 /* test hooks of the voxel pass planned ahead of its frame (csrc/kt_tracker.hip plan_ahead; tests/test_gpu_tracker.py):
  * kt_tracker_debug_pose_log: enable >= 0 switches the log of the poses the frames' set-up kernels saw (12 floats per frame: R row-major,
  * t; before that frame's own shift) on or off; out12n / n_frames, when given, receive it.
@@ -40,12 +30,13 @@ int kt_tracker_debug_plan_truth(kt_tracker* trk, const float* poses12n, int n_fr
  * round-3 kernel, -1 = back to the default (KT_TSDF_LEAN in the environment, else the build's).  Both store the same bits. */
 int kt_debug_tsdf_lean(int on);
 /* the arithmetic contract of the lean voxel kernel: 0 = bit-exact (default), 1 = "survey-8c" (kt_tsdf23_tol_kernel: SURVEY.md 8(c)'s parity
- * policy -- tsdf shorts within 1, colour bytes within 1 at near-ties, weights and voxel / pixel indices exact), -1 = environment / default */
+ * policy -- tsdf shorts within 1, colour bytes within 1 at rounding ties, voxel / pixel indices exact; weights exact except where the update
+ * predicate `sdf >= -trunc` is decided by the last bit of v_sqrt_f32: a voxel exactly at the -trunc edge may be updated by one kernel and not
+ * by the other -- 0 to 2 voxels of 135 M in tests/test_gpu_tol.py, a count, not a guarantee), 2 = "speed of light" (kt_tsdf23_sol_kernel: a
+ * MEASUREMENT variant with the per-voxel arithmetic the reference's --prec-div=false --prec-sqrt=false build would execute; its results are not
+ * the reference's and nothing but bench.py's roofline*.speed_of_light times it), -1 = environment / default */
 int kt_debug_tsdf_contract(int tol);
 const char* kt_debug_tsdf_kernel(void);   /* name of the voxel kernel the next N < 1024 launch uses (bench.py reports it) */
-/* test hook: the voxel kernel's division shortcut (table reciprocal + one correction) against the IEEE division for every finite float
- * numerator and every divisor 1..256: out_host = {mismatches, float bits of the largest |numerator| among them, mismatches at |n| >= 2^-100} */
-int kt_debug_div_check(kt_ctx* ctx, unsigned int out_host[3]);
 /* analysis hook (builds with -DKT_ICP_TIMING only; otherwise KT_ERR_STATE): per workgroup of the last reduction launch, 100 MHz stamps:
  * [0, 256) pixel loop entered, [256, 512) loop done, [512, 768) granules published */
 int kt_debug_icp_wg_times(kt_ctx* ctx, unsigned long long* out768_host);

@@ -1,4 +1,7 @@
-// kt_debug.hip -- measurement hooks that are not part of the data path (scripts/pmc_calibrate.py, scripts/valu_rates.py):
+// kt_debug.hip -- measurement hooks that are not part of the data path (scripts/pmc_calibrate.py, scripts/valu_rates.py).  Since round 6 this
+// file is a library of its own, libkt_debug.so (kintinuous_amd/build.py; declarations: csrc/kt_measure.h), linked against libkt_hip.so for the
+// context type and the error plumbing: the product library carries no measurement kernels.
+//   kt_debug_stream        PMC calibration on contiguous streams at tsdf23's access widths;
 //   kt_debug_stream_rows   PMC calibration on tsdf23's REAL access pattern: a wave owns a 32 x 2 wave-column and walks z, so every
 //                          access is two 32-lane rows (64 B of tsdf / 128 B of colour each), N^2 elements apart between z-steps;
 //   kt_debug_valu_rates    issue cost of the instruction kinds tsdf23 is made of, at 1..8 waves per SIMD (shader cycles per
@@ -355,6 +358,29 @@ extern "C" int kt_debug_valu_rates(kt_ctx* c, int kind, int iters, int waves_per
     (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
     free(h);
     KT_HIP(hipFree(ticks));
+    return KT_OK;
+}
+
+// PMC calibration hooks (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are uncalibrated for narrow accesses): stream a buffer
+// with exactly tsdf23's access widths -- 2 B per lane (tsdf) or 4 B per lane (colour), one contiguous segment per wave -- so the
+// counters can be scaled against a known byte count.  mode 0 = read, 1 = read-modify-write.
+template <typename T>
+__global__ __launch_bounds__(256) void kt_stream_kernel(T* __restrict__ p, size_t n, int rmw, unsigned int* __restrict__ sink)
+{
+    unsigned int acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        T v = p[i];
+        acc += (unsigned int)v;
+        if (rmw) p[i] = (T)(v + 1);
+    }
+    if (acc == 0x12345678u) *sink = acc;  // keeps the loads alive
+}
+extern "C" int kt_debug_stream(kt_ctx* c, void* buf, size_t bytes, int elem_size, int rmw)
+{
+    KT_ARG(c && buf && (elem_size == 2 || elem_size == 4));
+    if (elem_size == 2) hipLaunchKernelGGL(kt_stream_kernel<unsigned short>, dim3(8192), dim3(256), 0, c->stream, (unsigned short*)buf, bytes / 2, rmw, &c->counters[8]);
+    else hipLaunchKernelGGL(kt_stream_kernel<unsigned int>, dim3(8192), dim3(256), 0, c->stream, (unsigned int*)buf, bytes / 4, rmw, &c->counters[8]);
+    KT_LAUNCH_CHECK();
     return KT_OK;
 }
 

@@ -90,7 +90,7 @@ int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const
                     const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
                     const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,
                     unsigned long long* steps_dev, float* const* vpyr, float* const* npyr, const kt_frame_params* fp = nullptr,
-                    const unsigned char* bricks = nullptr, unsigned int* gate = nullptr, unsigned int gate_seq = 0);
+                    const unsigned char* bricks = nullptr);
 int kt_extract_cloud_slice_async(kt_ctx* c, const int16_t* volume, const float volume_size[3], kt_point_xyzrgb* output,
                                  size_t output_capacity, const int voxel_wrap[3], const uint8_t* color_volume, int minX, int maxX,
                                  int minY, int maxY, int minZ, int maxZ, int subsample, const int real_voxel_wrap[3], int N,
@@ -101,8 +101,8 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
                        int mode, const kt_track_state* init = nullptr, int keep29 = 0);
 int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr, const float* vmap_g_prev,
                         const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres, const kt_track_state* frame, int first, int n_iter);
+bool kt_icp_levels_forced();               // ... asked for explicitly
 bool kt_icp_levels_selected(int device);   // kt_track.hip: KT_ICP_LEVELS / kt_debug_icp_levels, and the device can hold the whole grid
-bool kt_icp_coop_launch();                 // kt_track.hip: KT_ICP_COOP
 int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
                            const float* last_depth, const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
                            int cols, int rows, kt_dataterm* corres_img, float max_depth_delta, const uint8_t* cand = nullptr,

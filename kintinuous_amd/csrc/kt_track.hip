@@ -69,35 +69,52 @@ struct kt_no_prefetch { __device__ __forceinline__ void operator()() const {} };
 // which the two half-waves of wave p hold -- and "the data is the flag": a granule is valid when it is not the SENTINEL (all ones: two
 // NaNs of a payload no arithmetic produces; a publisher that did hold 0xffffffff stores 0xfffffffe).  The sweeping wave writes the
 // sentinel back into every granule it has consumed; the next launch that publishes into the buffer is behind this one on the stream,
-// so the kernel boundary orders the two -- ALWAYS: a launch that runs several iterations (kt_icp_level_kernel) gives every iteration a
-// granule set of its own (kt_level_granules), so a hand-back and the next publish into the same word are never inside one launch
-// (advisor, round 5: two sets used in turn left that pair ordered only by a causal chain of relaxed accesses).
+// so the kernel boundary orders the two.  A launch that runs several iterations (kt_icp_level_kernel) uses two sets in turn and has no
+// boundary between a hand-back and the next publish into the same word (advisor, round 5: with the SWEEPER handing back, that pair was
+// ordered only by a causal chain of relaxed accesses through other addresses).  There the hand-back is the PUBLISHER's: once a workgroup
+// holds the pose of iteration it - 1 -- proof that the sweep of that iteration is over -- the lanes that stored its granules of set
+// (it - 1) & 1 store the sentinel over them, and the same lanes store the next data into that set one iteration later: two stores of one
+// thread to one address, ordered by the program; and the granule of iteration `it`, which the sweeper must see before it can look at
+// that set again, leaves only after the hand-back has completed (kt_publish_pair<ORDERED>).  The sweeper hands back the set of a launch's
+// LAST iteration only -- against the next launch, across the boundary, as everywhere else.  (One set per iteration, the other option the
+// advisor named, was measured first: 0.26 us per iteration -- the sets go cold in the memory-side cache; profiles/r06_experiments.md.)
 // (Rounds 2-3 tagged every 4-byte sum with a 4-byte epoch: twice the lines for the sweep to
 // fetch, and the sweep -- agent-scope loads go past the L2, one compute unit issues all of them -- is paid per LINE REQUEST:
 // profiles/r04_experiments.md.)  Place of workgroup wg's (= CUDA block wg / 4, warp wg % 4) granule of pair p: the four warps of a block
 // are 64 granules apart, so that the sweeping wave's q-th load -- lane b takes warp q of block b -- reads 512 contiguous bytes.
 #define KT_RED_PAIRS 15
 #define KT_GRANULE_SENTINEL 0xffffffffffffffffull
-// kt_icp_level_kernel: one granule set per iteration of a launch, behind everything else in the context's hand-off buffer (u64 indices;
-// [0, 8192) and [8192, 16384): the two kt_reduce29 sets, 16384..: the residual launch's words, kt_residual_granules / kt_residual_partials)
-#define KT_LEVEL_SETS 16
+// kt_icp_level_kernel: its two granule sets, behind everything else in the context's hand-off buffer (u64 indices; [0, 8192) and
+// [8192, 16384): the two kt_reduce29 sets, 16384..: the residual launch's words, kt_residual_granules / kt_residual_partials)
+#define KT_LEVEL_SETS 2
 #define KT_LEVEL_SET_STRIDE 4096      // >= KT_RED_PAIRS * KT_RED_BLOCKS = 3840
 #define KT_LEVEL_SET_BASE 32768
 #define KT_POSE_ABORT 15              // pose_gran[15]: {0, seq} of the iteration whose sweep gave up (same 128-byte line as the 12 pose granules)
 __device__ __forceinline__ int kt_granule_index(int pair, int wg) { return pair * KT_RED_BLOCKS + (wg & 3) * (KT_RED_BLOCKS / 4) + (wg >> 2); }
 // lane 0 of every wave p < 15 publishes {sum of product 2p (lanes 0..31), sum of product 2p + 1 (lanes 32..63)}
+// (ORDERED: every vector-memory operation this wave has issued -- its own hand-back stores of kt_handback_own -- has completed before the
+// granule leaves: s_waitcnt vmcnt(0), free at this point because the pixel loop has long consumed its last load)
+template <bool ORDERED = false>
 __device__ __forceinline__ void kt_publish_pair(unsigned long long* __restrict__ granules, float wsum)
 {
     unsigned int lo = __float_as_uint(wsum), hi = (unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(wsum), 32);
     lo = lo == 0xffffffffu ? 0xfffffffeu : lo;
     const int pair = threadIdx.x >> 6;
+    if constexpr (ORDERED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((threadIdx.x & 63) == 0 && pair < KT_RED_PAIRS)
         __hip_atomic_store(&granules[kt_granule_index(pair, blockIdx.x)], ((unsigned long long)hi << 32) | (unsigned long long)lo, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 }
+// A publisher hands its OWN granules of a set back (kt_icp_level_kernel, below): the same lanes that stored them store the sentinel.
+__device__ __forceinline__ void kt_handback_own(unsigned long long* __restrict__ granules)
+{
+    const int pair = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0 && pair < KT_RED_PAIRS)
+        __hip_atomic_store(&granules[kt_granule_index(pair, blockIdx.x)], KT_GRANULE_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 typedef float kt_rows_t[8][32];   // LDS staging rows[k][component][vt], KT_KBATCH of them
 
-template <typename RowFn>
+template <typename RowFn, bool ORDERED = false>
 __device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsigned long long* __restrict__ granules, kt_rows_t* rows)
 {
     KT_TS(0);
@@ -148,7 +165,7 @@ __device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsi
     KT_TS(1);
     // warp tree: the 32 lanes of a half-wave hold product `comp` of the 32 virtual threads of this CUDA warp
     const float wsum = kt_warp32_sum(acc);   // (threads of a product past the 29th hold 0)
-    kt_publish_pair(granules, wsum);
+    kt_publish_pair<ORDERED>(granules, wsum);
     KT_TS(2);
 }
 
@@ -228,8 +245,13 @@ __device__ unsigned int kt_sweep_spin_limit = 1u << 22;
 __device__ unsigned int kt_wait_limit_ticks = 5000000u;
 __device__ __forceinline__ unsigned long long kt_ticks() { return __builtin_amdgcn_s_memrealtime(); }
 
+// patience: multiplier of kt_wait_limit_ticks.  A launch whose workgroups wait for each other INSIDE it (kt_icp_level_kernel) must give up soon
+// -- while it waits it holds the compute units somebody else's workgroups may need to make the progress it is waiting for; the stream-ordered
+// kernels hold ONE compute unit while their sweep waits and nothing circular can involve them, so they wait 40 times longer (2 s): long enough
+// for another process's level launch to run into ITS bound and get out of the way (tests/test_gpu_two_process.py).
+// handback = false: the consumed granules are left as they are (kt_icp_level_kernel hands them back from the publishing side).
 template <int NS>
-__device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&granules)[NS], float* const (&total)[NS])
+__device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&granules)[NS], float* const (&total)[NS], unsigned int patience = 40u, bool handback = true)
 {
     const int tid = threadIdx.x;
     KT_TS(3);
@@ -250,8 +272,8 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&
             bool ok;
             unsigned int spins = 0;
             const unsigned int spin_limit = *(volatile const unsigned int*)&kt_sweep_spin_limit;
-            const unsigned int tick_limit = *(volatile const unsigned int*)&kt_wait_limit_ticks;
-            const unsigned long long tick0 = kt_ticks();
+            const unsigned long long tick_limit = (unsigned long long)*(volatile const unsigned int*)&kt_wait_limit_ticks * patience;
+            unsigned long long tick0 = 0;   // the clock is read from the 16th look on: a hand-off that completes at once never pays for it
             for (;;) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -264,11 +286,16 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) ok = ok && g[s][q] != KT_GRANULE_SENTINEL;
-                if (__all(ok) || ++spins > spin_limit || ((spins & 15u) == 0 && kt_ticks() - tick0 > tick_limit)) break;
+                if (__all(ok) || ++spins > spin_limit) break;
+                if ((spins & 15u) == 0) {
+                    const unsigned long long now = kt_ticks();
+                    if (spins == 16u) tick0 = now;
+                    else if (now - tick0 > tick_limit) break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
             const bool all_ok = __all(ok);
-            if (all_ok) {
+            if (all_ok && handback) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -299,11 +326,11 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&
     KT_TS(4);
 }
 
-__device__ __forceinline__ void kt_reduce29_sweep(unsigned long long* __restrict__ granules, float (&total)[KT_RED_SLOTS])
+__device__ __forceinline__ void kt_reduce29_sweep(unsigned long long* __restrict__ granules, float (&total)[KT_RED_SLOTS], unsigned int patience = 40u, bool handback = true)
 {
     unsigned long long* const gs[1] = {granules};
     float* const ts[1] = {total};
-    kt_reduce29_sweep_n<1>(gs, ts);
+    kt_reduce29_sweep_n<1>(gs, ts, patience, handback);
 }
 
 // `pre` runs in the sweeping workgroup between its publish and the sweep: the place to issue loads the epilogue will need
@@ -381,9 +408,9 @@ struct kt_icp_args {
     int keep29;                // KT_MODE_ICP_SOLVE: also leave the 29 sums in state->icp29 (kt_icp_track's last iteration: the caller's A)
     // kt_icp_level_kernel (round 5): n_iter Gauss-Newton iterations of ONE pyramid level in ONE launch.  The pose goes from an iteration's
     // solving workgroup to the others as 12 granules {float, seq} tagged seq0 + iteration; Rcurr / tcurr then carry the frame's PREVIOUS pose
-    // (also the starting pose of the frame's first launch), Rprev_inv / tprev as always.  level_gran: KT_LEVEL_SETS granule sets, iteration
-    // `it` of the launch reduces through set `it` (round 6: a set is published into once per LAUNCH, so its hand-back is ordered against the next
-    // publish by a kernel boundary, like kt_icp_kernel's).  pose_gran[KT_POSE_ABORT]: {., seq} of the iteration whose sweep gave up.
+    // (also the starting pose of the frame's first launch), Rprev_inv / tprev as always.  level_gran: two granule sets, iteration `it` of the
+    // launch reduces through set it & 1, handed back by its publishers (see the hand-off comment at the top).  pose_gran[KT_POSE_ABORT]:
+    // {., seq} of the iteration whose sweep gave up.
     int n_iter; unsigned int seq0; unsigned long long* pose_gran; unsigned long long* level_gran;
 };
 
@@ -571,6 +598,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
         fn.Rcurr = a.Rcurr;
         fn.tcurr = {a.tprev[0], a.tprev[1], a.tprev[2]};
     } else {         // the pose the previous launch left (the kernel boundary orders the accesses)
+        if (a.state->handoff_timeout) return;   // an earlier launch of this frame gave up: the frame has no pose, nothing here is worth waiting for
         for (int k = 0; k < 9; ++k) fn.Rcurr.m[k] = a.state->Rcurr[k];
         fn.tcurr = {a.state->tcurr[0], a.state->tcurr[1], a.state->tcurr[2]};
     }
@@ -585,7 +613,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
     const int t0 = blockIdx.x * 32, nk_blk = (n - t0 + KT_VT_TOTAL - 1) / KT_VT_TOTAL;
     const int pf_i = ((int)threadIdx.x < min(KT_KBATCH, nk_blk) * 32) ? min(t0 + ((int)threadIdx.x & 31) + ((int)threadIdx.x >> 5) * KT_VT_TOTAL, n - 1) : -1;
     for (int it = 0; it < a.n_iter; ++it) {
-        unsigned long long* const gran = a.level_gran + (size_t)it * KT_LEVEL_SET_STRIDE;
+        unsigned long long* const gran = a.level_gran + (size_t)(it & 1) * KT_LEVEL_SET_STRIDE;
         if (it > 0) {
             fn.pf_i = -1;
             if (!sweeper) {
@@ -601,7 +629,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
                     const unsigned int want = a.seq0 + (unsigned int)it - 1u;
                     const unsigned int spin_limit = min(*(volatile const unsigned int*)&kt_sweep_spin_limit, 1u << 20);
                     const unsigned int tick_limit = 2u * *(volatile const unsigned int*)&kt_wait_limit_ticks;
-                    const unsigned long long tick0 = kt_ticks();
+                    unsigned long long tick0 = 0;   // (read from the 16th look on, as in the sweep)
                     unsigned long long g = 0;
                     unsigned int spins = 0;
                     bool ok, gone;
@@ -610,7 +638,12 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
                         const int ahead = (int)((unsigned int)(g >> 32) - want);
                         ok = lane >= 12 || ahead == 0;
                         gone = lane == 12 && ahead >= 0 && ahead < a.n_iter;   // the launch was aborted at or after the iteration waited for
-                        if (__all(ok) || __any(gone) || ++spins > spin_limit || ((spins & 15u) == 0 && kt_ticks() - tick0 > tick_limit)) break;
+                        if (__all(ok) || __any(gone) || ++spins > spin_limit) break;
+                        if ((spins & 15u) == 0) {
+                            const unsigned long long now = kt_ticks();
+                            if (spins == 16u) tick0 = now;
+                            else if (now - tick0 > tick_limit) break;
+                        }
                         __builtin_amdgcn_s_sleep(1);
                     }
                     const bool got = __all(ok) && !__any(gone);
@@ -620,15 +653,18 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
             }
             __syncthreads();   // (the solving workgroup: its tail wrote s_pose)
             if (s_pose[12] != 0.0f) return;   // workgroup-uniform: no pose (see above)
+            // the pose of iteration it - 1 exists, so its sweep is over: this workgroup's granules of that iteration go back to the sentinel
+            // (the set is published into again at it + 1, by the same lanes)
+            kt_handback_own(a.level_gran + (size_t)((it - 1) & 1) * KT_LEVEL_SET_STRIDE);
             // (wave-uniform values: into scalar registers, where kt_icp_kernel's arguments live too -- as per-lane copies they cost 12 VGPRs)
             const auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
             for (int k = 0; k < 9; ++k) fn.Rcurr.m[k] = uni(s_pose[k]);
             fn.tcurr = {uni(s_pose[9]), uni(s_pose[10]), uni(s_pose[11])};
         }
         __shared__ kt_rows_t rows[KT_KBATCH];
-        kt_reduce29_publish(fn, n, gran, rows);
+        kt_reduce29_publish<kt_icp_row, true>(fn, n, gran, rows);
         if (!sweeper) continue;
-        kt_reduce29_sweep(gran, total);
+        kt_reduce29_sweep(gran, total, 1u, it + 1 == a.n_iter);   // (the last iteration's set: handed back here, against the next launch)
         // ICPOdometry.cpp:127-178, as kt_icp_kernel's KT_MODE_ICP_SOLVE epilogue
         if (threadIdx.x < 42) sys[threadIdx.x] = (double)total[kt_sys_slot(threadIdx.x)];
         const bool timed_out = total[KT_RED_SLOTS - 1] != 0.0f;   // (workgroup-uniform: read behind the sweep's closing barrier)
@@ -663,19 +699,17 @@ int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
     else if (c->fault_count > 0) { --c->fault_count; a.fault = 1; }
     if (a.n_iter > 0) {
         static_assert(KT_LEVEL_SET_STRIDE >= KT_RED_PAIRS * KT_RED_BLOCKS, "a granule set per iteration");
-        if ((size_t)KT_LEVEL_SET_BASE + (size_t)KT_LEVEL_SETS * KT_LEVEL_SET_STRIDE > (size_t)32 * c->red_max_blocks || a.n_iter > KT_LEVEL_SETS) {
-            kt_set_error("kt_icp_level_kernel: %d iterations do not fit the hand-off buffer", a.n_iter);
+        if ((size_t)KT_LEVEL_SET_BASE + (size_t)KT_LEVEL_SETS * KT_LEVEL_SET_STRIDE > (size_t)32 * c->red_max_blocks) {
+            kt_set_error("kt_icp_level_kernel: the hand-off buffer is too small");
             return KT_ERR_ARG;
         }
         a.level_gran = (unsigned long long*)c->red_partials + KT_LEVEL_SET_BASE;
         a.pose_gran = c->pose_gran;
-        if (kt_icp_coop_launch()) {
-            // the runtime's promise that the whole grid is resident at once (the workgroups wait for each other inside the launch)
-            void* args[1] = {(void*)&a};
-            KT_HIP(hipLaunchCooperativeKernel((const void*)kt_icp_level_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), args, 0, c->stream));
-        } else {
-            hipLaunchKernelGGL(kt_icp_level_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
-        }
+        // (Through hipLaunchCooperativeKernel -- the runtime's own promise of co-residency -- the default run measured 1858 frames/s against 3720:
+        // a cooperative launch is serialised against everything else on the device, profiles/r06_experiments.md.  Residency is checked once per
+        // device instead (kt_icp_levels_fit), every wait inside the launch is bounded in time, and a launch that gives up costs the frame a
+        // re-run, not an error: kt_tracker.hip complete_frame.)
+        hipLaunchKernelGGL(kt_icp_level_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
     } else {
         hipLaunchKernelGGL(kt_icp_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
     }
@@ -753,14 +787,10 @@ int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr
     memcpy(a.Rcurr.m, frame->Rprev, sizeof(a.Rcurr.m));
     memcpy(a.Rprev_inv.m, frame->Rprev_inv, sizeof(a.Rprev_inv.m));
     for (int k = 0; k < 3; ++k) { a.tcurr[k] = frame->tprev[k]; a.tprev[k] = frame->tprev[k]; }
-    for (int done = 0; done < n_iter; done += KT_LEVEL_SETS) {   // (the tracker's levels run 4, 5 and 10 iterations: one launch each)
-        a.n_iter = n_iter - done < KT_LEVEL_SETS ? n_iter - done : KT_LEVEL_SETS;
-        a.seq0 = c->odo_seq + 1u;
-        c->odo_seq += (unsigned int)a.n_iter;
-        KT_TRY(kt_icp_launch(c, a));
-        a.first = 0;
-    }
-    return KT_OK;
+    a.n_iter = n_iter;
+    a.seq0 = c->odo_seq + 1u;
+    c->odo_seq += (unsigned int)n_iter;
+    return kt_icp_launch(c, a);
 }
 
 // ICPOdometry::getIncrementalTransformation (ICPOdometry.cpp:68-186) as ONE entry point (SURVEY 8(b) export list): pose in / pose out,
@@ -1409,18 +1439,14 @@ static bool kt_icp_levels_fit(int dev)
     }
     return fit[dev] > 0;
 }
-// KT_ICP_COOP=1: launch the level kernel through hipLaunchCooperativeKernel (A/B: profiles/r06_experiments.md)
-bool kt_icp_coop_launch()
-{
-    static const bool on = []() { const char* e = getenv("KT_ICP_COOP"); return e && atoi(e) != 0; }();
-    return on;
-}
 bool kt_icp_levels_selected(int device)
 {
     const char* e = getenv("KT_ICP_LEVELS");
     const bool env = e ? atoi(e) != 0 : KT_ICP_LEVELS_DEFAULT != 0;
     return (kt_icp_levels_override < 0 ? env : kt_icp_levels_override != 0) && kt_icp_levels_fit(device);
 }
+// the form was asked for explicitly (environment or test hook): policies that would pick one themselves keep out
+bool kt_icp_levels_forced() { return kt_icp_levels_override >= 0 || getenv("KT_ICP_LEVELS") != nullptr; }
 // test / tuning hook: the time bound of the hand-off waits in ticks of the 100 MHz clock (0 = the default, 50 ms)
 extern "C" int kt_debug_wait_limit(kt_ctx* c, unsigned int ticks)
 {

@@ -178,12 +178,15 @@ struct kt_tracker {
     long long odo_fallbacks;   // frames whose odometry was re-run (kt_tracker_odometry_fallbacks)
     int out_last_set;          // RGB-D "last" set of the frame in flight (for that re-run)
     // Side-stream gate (round 6).  The read-ahead of frame f + 1 is enqueued the moment the host has seen the pose of frame f - 1 -- exactly
-    // when that frame's voxel kernel starts -- and the voxel kernel deals its task list STATICALLY over the resident waves: workgroups of
-    // another stream on some compute units make those the slowest, and the launch is as long as its slowest SIMD (farwall768: 0.60 ms alone,
-    // 0.85 next to the 1280x960 read-ahead).  With the gate on, the side streams start with a one-thread kernel that sleeps until the ray cast
-    // of the frame in flight has started (kt_raycast_kernel stores the frame's sequence number into gate_dev: no event, no packet on the main
-    // stream), so the read-ahead runs beside the ray cast -- whose workgroups are handed out dynamically -- and the next odometry.
-    unsigned int* gate_dev; int side_gate;   // side_gate: 0 off, 1 on
+    // when that frame's voxel kernel starts -- and the voxel kernel is a fixed grid of 8192 waves that fills EVERY wave slot of the chip and
+    // deals its task list statically over them: one foreign wave on one SIMD keeps one of its workgroups out until another has finished, and
+    // the launch is as long as its slowest SIMD (farwall768: 0.49 ms by the kernel trace with nothing beside it, 0.67 with a single sleeping
+    // wave of another stream resident -- profiles/r06_experiments.md, call 4; 0.85 next to the 1280x960 read-ahead).  With the gate on, the
+    // read-ahead stream waits for an event recorded between the voxel kernel and the ray cast (one marker packet on the main stream: 3-5 us of
+    // a millisecond frame), so the read-ahead runs beside the ray cast -- whose workgroups are handed out dynamically -- and the next odometry.
+    // (A first cut had the side stream start with a one-thread kernel sleeping on a device flag the ray cast set -- no packet on the main
+    // stream; that resident wave was itself the disturbance.)
+    hipEvent_t gate_ev; bool gate_armed; int side_gate;   // side_gate: 0 off, 1 on
     PlanSlot plans[3]; hipStream_t plan_stream;          // (three: frame f + 1 is planned while the voxel kernels of f and f - 1 may still read theirs)
     int plan_sel; bool plan_enabled; float plan_margin_scale;
     // test hooks (kt_tracker_debug_plan_*): the pose every frame WILL arrive at, taken from an identical earlier run, as the prediction;
@@ -564,7 +567,8 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
         KT_HIP(hipEventCreateWithFlags(&t->plans[k].done, KT_EV_DEVICE));
         t->plans[k].ordinal = -1; t->plans[k].set = -1; t->plans[k].depth = nullptr; t->plans[k].rgb = nullptr;
     }
-    KT_TRY(dev_alloc(&t->gate_dev, 4, true));
+    KT_HIP(hipEventCreateWithFlags(&t->gate_ev, KT_EV_DEVICE));
+    t->gate_armed = false;
     {
         // KT_SIDE_GATE: 0 never, 1 always, 2 (default) on dense views only -- the rule that picks 32 x 2 wave-columns (more than 1.5 pixels per
         // voxel column: the voxel kernel is the frame's longest and its launch is dense)
@@ -573,6 +577,12 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
         int wcx = 0, wcy = 0, xg = 0, yg = 0;
         kt_tsdf_plan_shape(cfg->cols, cfg->rows, cfg->N, &wcx, &wcy, &xg, &yg);
         t->side_gate = mode == 1 || (mode == 2 && wcx == 32) ? 1 : 0;
+        // A level launch takes every compute unit's whole register file: whatever the side streams have not finished when the odometry starts
+        // waits for it to end and then runs beside the voxel kernel after all.  On a dense view (1280x960: the pixel loops are long, the
+        // hand-over a level launch saves is 1.4 % of the frame) the odometry therefore stays one launch per iteration -- 48 VGPRs: read-ahead
+        // and plan run UNDER it -- and the plan's completion event, which the set-up kernel already waits for, keeps both out of the voxel kernel.
+        const char* d = getenv("KT_DENSE_STEPWISE");
+        if (mode == 2 && wcx == 32 && (d ? atoi(d) != 0 : true) && !kt_icp_levels_forced()) t->icp_levels = false;
     }
     t->plan_enabled = getenv("KT_NO_PLAN") == nullptr;   // (A/B switch: every frame through the in-stream pre-pass)
     t->plan_margin_scale = getenv("KT_PLAN_MARGIN_SCALE") ? (float)atof(getenv("KT_PLAN_MARGIN_SCALE")) : 1.0f;   // (tests: 0 makes every plan miss)
@@ -656,7 +666,7 @@ int kt_tracker_destroy(kt_tracker* t)
         if (t->plans[k].done) (void)hipEventDestroy(t->plans[k].done);
     }
     (void)hipFree(t->fp_dev);
-    (void)hipFree(t->gate_dev);
+    if (t->gate_ev) (void)hipEventDestroy(t->gate_ev);
     (void)hipFree(t->bricks);
     for (int k = 0; k < 2; ++k) (void)hipFree(t->wrkc_carry[k]);
     delete t;
@@ -1026,13 +1036,14 @@ static int enqueue_fusion(kt_tracker* t, int set, const uint16_t* depth_raw, con
                                   t->sets[set].scaled, t->v_wrap_copy, t->color, colors, t->sets[set].nmaps[0], !t->cfg.disable_color_angle, N,
                                   t->counting ? t->upd_dev : nullptr, t->sets[set].rec, t->fp_dev, t->bricks, t->sets[set].dpmax, plan));
     KT_TRY(ev_end(t, ST_INTEGRATE));
+    if (t->side_gate) { KT_HIP(hipEventRecord(t->gate_ev, c->stream)); t->gate_armed = true; }   // the voxel kernel has drained: the side streams may run
     KT_TRY(ev_begin(t, ST_RAYCAST));
     const bool pyr = icp || t->cfg.use_rgbd_icp;
     float* vp[3] = {t->vmaps_g_prev[1], t->vmaps_g_prev[2], t->vmaps_g_prev[3]};
     float* np_[3] = {t->nmaps_g_prev[1], t->nmaps_g_prev[2], t->nmaps_g_prev[3]};
     KT_TRY(kt_raycast_impl(c, &t->intr, &dummy_R, dummy_t, t->tranc_dist, t->volume_size, t->tsdf, t->vmaps_g_prev[0], t->nmaps_g_prev[0], cols, rows,
                            t->v_wrap_copy, t->vmap_curr_color, t->color, N, t->counting ? t->steps_dev : nullptr, pyr ? vp : nullptr,
-                           pyr ? np_ : nullptr, t->fp_dev, t->bricks, t->gate_dev, t->frame_seq));
+                           pyr ? np_ : nullptr, t->fp_dev, t->bricks));
     KT_TRY(ev_end(t, ST_RAYCAST));
     return KT_OK;
 }
@@ -1607,8 +1618,11 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     // enqueued: the GPU is still in the previous frame's voxel kernel and ray cast, which do not mind a few small workgroups next to
     // them; enqueued after the odometry (the first cut) the pre-pass ran next to the iterations, each of whose 256 workgroups needs a
     // whole CU, and cost them 10 us per frame.
-    if (t->plan_enabled && !t->pending.empty() && t->hist_n >= 2 && !t->cfg.dynamic_cube)
+    bool planned_next = false;
+    if (t->plan_enabled && !t->pending.empty() && t->hist_n >= 2 && !t->cfg.dynamic_cube) {
         KT_TRY(plan_ahead(t, t->pending.front(), ordinal + 1));
+        planned_next = t->plans[(ordinal + 1) % 3].ordinal == ordinal + 1;
+    }
     // [C] odometry :564-572 -- every Gauss-Newton iteration is enqueued; the pose stays on the device
     KT_TRY(ev_begin(t, ST_ODOMETRY));
     if (icp) KT_TRY(icp_odometry(t));
@@ -1619,6 +1633,10 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     if (++t->frame_seq == 0) t->frame_seq = 1;  // 0 is the mirror's initial value
     // the plan has had the 19 launches above to finish; a join is enqueued only if it has not (a wait packet is a bubble)
     if (t->plan_sel >= 0 && hipEventQuery(t->plans[t->plan_sel].done) != hipSuccess) KT_HIP(hipStreamWaitEvent(c->stream, t->plans[t->plan_sel].done, 0));
+    // gated side streams: what they were given for the NEXT frame (its read-ahead, then its plan) ends before this frame's voxel kernel starts
+    // -- one wait packet in front of the set-up kernel (3-5 us; the gate is on where the frame is a millisecond)
+    if (t->side_gate && planned_next) KT_HIP(hipStreamWaitEvent(c->stream, t->plans[(ordinal + 1) % 3].done, 0));
+    else if (t->side_gate && !t->pending.empty()) KT_HIP(hipStreamWaitEvent(c->stream, t->sets[t->pending.front().set].ready, 0));
     KT_TRY(launch_setup(t, 0, nullptr, nullptr));
     // -d: the cube may be repositioned once the pose is known, which changes the shift decision -- nothing to speculate on
     t->out_speculated = !t->cfg.dynamic_cube;
@@ -1671,17 +1689,6 @@ int kt_tracker_prefetch_frame_host(kt_tracker* t, const uint16_t* depth_host, co
     return prefetch_impl(t, t->depth_stage[slot], t->rgb_stage[slot], depth_host, rgb_host);
 }
 
-// One thread that sleeps until *flag has reached `want` (the ray cast of that frame has started), bounded in time: a frame whose fusion never
-// runs (an error path) must not hold the side stream.
-__global__ void kt_gate_kernel(const unsigned int* flag, unsigned int want, unsigned int tick_limit)
-{
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-        if (__builtin_amdgcn_s_memrealtime() - t0 > tick_limit) break;
-        __builtin_amdgcn_s_sleep(64);
-    }
-}
-
 static int prefetch_impl(kt_tracker* t, const uint16_t* depth_raw, const uint8_t* colors, const uint16_t* depth_host, const uint8_t* rgb_host)
 {
     if (t->pending.size() >= 2) { kt_set_error("kt_tracker_prefetch_frame: two read-ahead frames are already outstanding"); return KT_ERR_STATE; }
@@ -1695,11 +1702,10 @@ static int prefetch_impl(kt_tracker* t, const uint16_t* depth_raw, const uint8_t
     t->last_assigned = set;
     KT_TRY(wait_frame_consumed(t, t->pre_stream, t->sets[set].user));
     t->pre_ctx.device = t->ctx->device;
-    if (t->side_gate && t->global_time > 0 && !t->has_trajectory) {
+    if (t->side_gate && t->gate_armed) {
         // the frame just observed is in its voxel kernel now: hold the read-ahead (and, behind its `ready` event, the plan stream) until
-        // that frame's ray cast starts; 20 ms bound
-        hipLaunchKernelGGL(kt_gate_kernel, dim3(1), dim3(1), 0, t->pre_stream, t->gate_dev, t->frame_seq, 2000000u);
-        KT_LAUNCH_CHECK();
+        // that launch has drained -- the event enqueue_fusion recorded between the voxel kernel and the ray cast
+        KT_HIP(hipStreamWaitEvent(t->pre_stream, t->gate_ev, 0));
     }
     KT_TRY(build_frame_set(t, &t->pre_ctx, set, depth_raw, colors));
     KT_HIP(hipEventRecord(t->sets[set].ready, t->pre_stream));

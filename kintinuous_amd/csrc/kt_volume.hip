@@ -1231,12 +1231,19 @@ __device__ __forceinline__ float kt_min1(float x)   // min(1, x) as one v_min_f3
 // Consequences, counted by tests/test_gpu_tol.py against the bit-exact kernel at BASELINE configs 2 / 3 / 5: tsdf shorts differ by at
 // most 1 on a small fraction of the touched voxels, colour bytes by at most 1 at near-ties, weights never.  The bit-exact kernel stays
 // the default of the library, of every parity test and of bench.py's headline.
-template <bool COUNT, bool FAST, bool NT, bool TOL = false>
+// CT = 2, "speed of light" (round 6): a MEASUREMENT variant, never a product path.  Same task list, same loads, stores and
+// predicates as the kernels above; the per-voxel arithmetic cut down to what the reference's own build flags execute (CMakeLists.txt:47:
+// --prec-div=false --prec-sqrt=false, i.e. rcp.approx / sqrt.approx and no correction steps): v_rcp_f32 in the projection (no refinement
+// chain, no range test per task), v_sqrt_f32 everywhere, the running average and the colour blend without their residual corrections, the
+// stored tsdf unpacked with one multiply.  Its launch time on the same workload is what "the contract costs" means in numbers: if IT does not
+// reach BASELINE.json's 0.60 of the HBM roofline, no arithmetic contract of this decomposition does (bench.py: roofline*.speed_of_light).
+template <bool COUNT, bool FAST, bool NT, int CT = 0>
 __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, const kt_tsdf_bufs& m, const kt_tsdf_ztab* __restrict__ s_tab,
                                                    const float* __restrict__ s_rcp, int zb, int rem, unsigned int col_base2, int brick_xy,
                                                    float v_z, float& v_x, float& v_y, float dvx, float dvy, float r8, float v_g_part_norm,
                                                    float tranc_dist_inv, unsigned int& n_upd, unsigned int& n_img)
 {
+    constexpr bool TOL = CT >= 1, SOL = CT == 2;
     kt_pixrec rec[KT_TSDF_UNROLL];
     bool in_img[KT_TSDF_UNROLL];
     float r2[KT_TSDF_UNROLL];
@@ -1251,7 +1258,7 @@ __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, c
     for (int u = 0; u < KT_TSDF_UNROLL; ++u) {
         const kt_tsdf_ztab e = s_tab[zb + u];   // wave-uniform address: one broadcast ds_read_b128
         const float d = __builtin_fmaf(r8, e.zs, v_z);
-        const float inv_z = FAST ? kt_rcp_exact(d) : 1.0f / d;
+        const float inv_z = SOL ? __builtin_amdgcn_rcpf(d) : (FAST ? kt_rcp_exact(d) : 1.0f / d);
         const float px = __builtin_fmaf(v_x, inv_z, cxy.x), py = __builtin_fmaf(v_y, inv_z, cxy.y);
         unsigned int coo_x, coo_y;
         if constexpr (FAST) {
@@ -1315,7 +1322,7 @@ __device__ __forceinline__ void kt_tsdf_batch_lean(const kt_tsdf_lean_args& a, c
         // a voxel that already holds F = 1 (raw 32767) and sees tsdf = 1: (1 * W + 1) / (W + 1) == 1 exactly, the stored value stays
         const bool touch = !((tv[u] == 1.0f) & (raw[u] == (unsigned int)KT_DIVISOR));
         if (touch) {
-            const float tsdf_prev = kt_unpack_tsdf((short)raw[u]);
+            const float tsdf_prev = SOL ? (float)(short)raw[u] * (1.0f / 32767.0f) : kt_unpack_tsdf((short)raw[u]);
             // (F W + tsdf) / (W + 1), correctly rounded: y = RN(1 / (W + 1)) from the LDS table, q = RN(n y), one exact residual, one
             // correction (Markstein); kt_debug_div_check compares it with the division for every finite numerator and divisor 1..256
             const float num = __builtin_fmaf(tsdf_prev, weight_prev, tv[u]), den = weight_prev + 1.0f;
@@ -1385,7 +1392,7 @@ __device__ unsigned long long kt_tsdf_tl[KT_TSDF_WAVES * KT_TL_WORDS];
 #endif
 // FP: the pose and the parked flag come from the device (kt_frame_params, the tracker) -- a compile-time property so that the start-up
 // has no pointer test in front of its loads.
-template <bool COUNT, bool NT, bool FP, bool TOL>
+template <bool COUNT, bool NT, bool FP, int CT>
 __device__ __forceinline__ void kt_tsdf23_lean_body(const kt_tsdf_lean_args& a_in)
 {
 #ifdef KT_TSDF_TIMELINE
@@ -1506,18 +1513,18 @@ __device__ __forceinline__ void kt_tsdf23_lean_body(const kt_tsdf_lean_args& a_i
         const int z_last = min(wz0 + ((wz1 - wz0 + KT_TSDF_UNROLL - 1) & ~(KT_TSDF_UNROLL - 1)) - 1, N - 1);
         const float d_a = __builtin_fmaf(r8, s_tab[wz0].zs, v_z), d_b = __builtin_fmaf(r8, s_tab[z_last].zs, v_z);
         const bool d_ok = fminf(fabsf(d_a), fabsf(d_b)) >= 0x1p-20f && fmaxf(fabsf(d_a), fabsf(d_b)) <= 0x1p20f && (d_a < 0) == (d_b < 0);
-        const bool fast = __builtin_amdgcn_ballot_w64(!d_ok) == 0;
+        const bool fast = CT == 2 ? __builtin_amdgcn_ballot_w64((d_a < 0) != (d_b < 0)) == 0 : __builtin_amdgcn_ballot_w64(!d_ok) == 0;   // (speed of light: no range test)
         KT_TL(3);
         if (fast) {
             if (lane_ok & (d_a > 0)) {   // lanes behind the camera plane (1 / d < 0) never pass the in-image test
                 for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
-                    kt_tsdf_batch_lean<COUNT, true, NT, TOL>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
+                    kt_tsdf_batch_lean<COUNT, true, NT, CT>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
                     KT_TL(4);
                 }
             }
         } else if (lane_ok) {
             for (int zb = wz0; zb < wz1; zb += KT_TSDF_UNROLL) {
-                kt_tsdf_batch_lean<COUNT, false, NT, TOL>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
+                kt_tsdf_batch_lean<COUNT, false, NT, CT>(a, m, s_tab, s_rcp, zb, wz1 - zb, col_base * 2u, brick_xy, v_z, v_x, v_y, dvx, dvy, r8, v_g_part_norm, tranc_dist_inv, n_upd, n_img);
             }
         }
         if (COUNT) { n_batches += (unsigned int)((wz1 - wz0 + KT_TSDF_UNROLL - 1) / KT_TSDF_UNROLL); ++n_tasks_done; }
@@ -1537,12 +1544,17 @@ __device__ __forceinline__ void kt_tsdf23_lean_body(const kt_tsdf_lean_args& a_i
 template <bool COUNT, bool NT, bool FP>
 __global__ __launch_bounds__(64 * KT_TSDF_WPB, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_lean_kernel(const kt_tsdf_lean_args a_in)
 {
-    kt_tsdf23_lean_body<COUNT, NT, FP, false>(a_in);
+    kt_tsdf23_lean_body<COUNT, NT, FP, 0>(a_in);
 }
 template <bool COUNT, bool NT, bool FP>
 __global__ __launch_bounds__(64 * KT_TSDF_WPB, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_tol_kernel(const kt_tsdf_lean_args a_in)
 {
-    kt_tsdf23_lean_body<COUNT, NT, FP, true>(a_in);
+    kt_tsdf23_lean_body<COUNT, NT, FP, 1>(a_in);
+}
+template <bool COUNT, bool NT, bool FP>
+__global__ __launch_bounds__(64 * KT_TSDF_WPB, COUNT ? 6 : KT_TSDF_OCC) void kt_tsdf23_sol_kernel(const kt_tsdf_lean_args a_in)   // measurement only (see kt_tsdf_batch_lean)
+{
+    kt_tsdf23_lean_body<COUNT, NT, FP, 2>(a_in);
 }
 
 // scratch owned by the context for integrate (pixel records, z tables, intervals, task list), grown on demand
@@ -1700,16 +1712,23 @@ extern "C" int kt_debug_tsdf_timeline(kt_ctx* c, unsigned long long* out_host, i
 }
 // which arithmetic contract the lean voxel kernel runs under: 0 = bit-exact (the default), 1 = survey-8c (kt_tsdf23_tol_kernel, above);
 // -1 = back to the environment's (KT_TSDF_CONTRACT=survey8c) or the default.  Only the lean kernel has the second contract.
+// 2 = the speed-of-light measurement variant (kt_tsdf23_sol_kernel; KT_TSDF_CONTRACT=sol): results are NOT the reference's, bench.py only times it
 static int kt_tsdf_contract_override = -1;
-extern "C" int kt_debug_tsdf_contract(int tol) { kt_tsdf_contract_override = tol < 0 ? -1 : (tol != 0); return KT_OK; }
-static bool kt_tsdf_tol_selected()
+extern "C" int kt_debug_tsdf_contract(int tol) { kt_tsdf_contract_override = tol < 0 ? -1 : (tol > 2 ? 1 : tol); return KT_OK; }
+static int kt_tsdf_contract_selected()
 {
-    static const bool env = []() { const char* e = getenv("KT_TSDF_CONTRACT"); return e && (!strcmp(e, "survey8c") || !strcmp(e, "survey-8c") || !strcmp(e, "tol")); }();
-    return kt_tsdf_lean_selected() && (kt_tsdf_contract_override < 0 ? env : kt_tsdf_contract_override != 0);
+    static const int env = []() {
+        const char* e = getenv("KT_TSDF_CONTRACT");
+        if (!e) return 0;
+        if (!strcmp(e, "survey8c") || !strcmp(e, "survey-8c") || !strcmp(e, "tol")) return 1;
+        return (!strcmp(e, "sol") || !strcmp(e, "speed-of-light")) ? 2 : 0;
+    }();
+    return kt_tsdf_lean_selected() ? (kt_tsdf_contract_override < 0 ? env : kt_tsdf_contract_override) : 0;
 }
 extern "C" const char* kt_debug_tsdf_kernel(void)
 {
-    return kt_tsdf_lean_selected() ? (kt_tsdf_tol_selected() ? "kt_tsdf23_tol_kernel" : "kt_tsdf23_lean_kernel") : "kt_tsdf23_kernel";
+    static const char* const names[3] = {"kt_tsdf23_lean_kernel", "kt_tsdf23_tol_kernel", "kt_tsdf23_sol_kernel"};
+    return kt_tsdf_lean_selected() ? names[kt_tsdf_contract_selected()] : "kt_tsdf23_kernel";
 }
 
 // shared by the C entry point and the tracker (which wants the update count for the roofline report)
@@ -1792,9 +1811,11 @@ int kt_integrate_tsdf_impl(kt_ctx* c, const uint16_t* depth_raw, int cols, int r
         static const int nt_env = []() { const char* e = getenv("KT_TSDF_NT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
         const bool nt = nt_env >= 0 ? nt_env != 0 : a.wcl == 5;
         const dim3 lb(64 * KT_TSDF_WPB), lg(KT_TSDF_WAVES / KT_TSDF_WPB);
-        const bool tol = kt_tsdf_tol_selected();
+        const int contract = kt_tsdf_contract_selected();
+        const bool tol = contract == 1;
 #define KT_LEAN_LAUNCH(C, T) do { \
-            if (tol) { if (l.fp) hipLaunchKernelGGL((kt_tsdf23_tol_kernel<C, T, true>), lg, lb, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_tol_kernel<C, T, false>), lg, lb, lds, c->stream, l); } \
+            if (contract == 2) { if (l.fp) hipLaunchKernelGGL((kt_tsdf23_sol_kernel<C, T, true>), lg, lb, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_sol_kernel<C, T, false>), lg, lb, lds, c->stream, l); } \
+            else if (tol) { if (l.fp) hipLaunchKernelGGL((kt_tsdf23_tol_kernel<C, T, true>), lg, lb, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_tol_kernel<C, T, false>), lg, lb, lds, c->stream, l); } \
             else { if (l.fp) hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, true>), lg, lb, lds, c->stream, l); else hipLaunchKernelGGL((kt_tsdf23_lean_kernel<C, T, false>), lg, lb, lds, c->stream, l); } } while (0)
         if (updated_dev) { if (nt) KT_LEAN_LAUNCH(true, true); else KT_LEAN_LAUNCH(true, false); }
         else { if (nt) KT_LEAN_LAUNCH(false, true); else KT_LEAN_LAUNCH(false, false); }
@@ -1842,29 +1863,6 @@ extern "C" int kt_integrate_tsdf(kt_ctx* c, const uint16_t* depth_raw, int cols,
 {
     return kt_integrate_tsdf_impl(c, depth_raw, cols, rows, intr, volume_size, Rcurr_inv, tcurr, tranc_dist, volume,
                                   depth_raw_scaled, voxel_wrap, color_volume, colors, nmap_curr, angle_color, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-}
-
-// PMC calibration hooks (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are uncalibrated for narrow accesses): stream a buffer
-// with exactly tsdf23's access widths -- 2 B per lane (tsdf) or 4 B per lane (colour), one contiguous segment per wave -- so the
-// counters can be scaled against a known byte count.  mode 0 = read, 1 = read-modify-write.
-template <typename T>
-__global__ __launch_bounds__(256) void kt_stream_kernel(T* __restrict__ p, size_t n, int rmw, unsigned int* __restrict__ sink)
-{
-    unsigned int acc = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        T v = p[i];
-        acc += (unsigned int)v;
-        if (rmw) p[i] = (T)(v + 1);
-    }
-    if (acc == 0x12345678u) *sink = acc;  // keeps the loads alive
-}
-extern "C" int kt_debug_stream(kt_ctx* c, void* buf, size_t bytes, int elem_size, int rmw)
-{
-    KT_ARG(c && buf && (elem_size == 2 || elem_size == 4));
-    if (elem_size == 2) hipLaunchKernelGGL(kt_stream_kernel<unsigned short>, dim3(8192), dim3(256), 0, c->stream, (unsigned short*)buf, bytes / 2, rmw, &c->counters[8]);
-    else hipLaunchKernelGGL(kt_stream_kernel<unsigned int>, dim3(8192), dim3(256), 0, c->stream, (unsigned int*)buf, bytes / 4, rmw, &c->counters[8]);
-    KT_LAUNCH_CHECK();
-    return KT_OK;
 }
 
 // exhaustive check hook for kt_rcp_exact: every float d with 2^-20 <= |d| <= 2^20 (both signs) against the IEEE division
@@ -1935,10 +1933,6 @@ struct kt_raycast_args {
     float* vpyr[3]; float* npyr[3];
     const kt_frame_params* fp;  // when set: R / t come from the device
     const unsigned char* bricks; int nb;   // optional negative-brick flags maintained by tsdf23 (N % 32 == 0, nb^3 <= KT_RC_MAX_BRICKS)
-    // tracker only: a device word that receives gate_seq when this launch STARTS (and is not parked) -- i.e. when the voxel kernel in front of
-    // it on the stream has drained.  The tracker's side streams wait for it (kt_tracker.hip: kt_gate_kernel) instead of running beside the
-    // voxel kernel; no event, no marker packet on this stream.
-    unsigned int* gate; unsigned int gate_seq;
 };
 
 struct kt_rc {
@@ -2098,7 +2092,6 @@ __global__ __launch_bounds__(256) void kt_raycast_kernel(const kt_raycast_args a
     kt_raycast_args a = a_in;
     if (a.fp) {
         if (a.fp->skip) return;  // parked for the host's shift path; the predicted maps are rebuilt there
-        if (a.gate && (blockIdx.x | blockIdx.y | threadIdx.x) == 0) __hip_atomic_store(a.gate, a.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < 9; ++k) a.R.m[k] = a.fp->R[k];
         a.tx = a.fp->t[0]; a.ty = a.fp->t[1]; a.tz = a.fp->t[2];
@@ -2354,7 +2347,7 @@ int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const
                     const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
                     const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,
                     unsigned long long* steps_dev, float* const* vpyr, float* const* npyr, const kt_frame_params* fp,
-                    const unsigned char* bricks, unsigned int* gate, unsigned int gate_seq)
+                    const unsigned char* bricks)
 {
     KT_ARG(c && intr && Rcurr && tcurr && volume_size && volume && vmap && nmap && voxel_wrap && vmap_curr_color && color_volume);
     KT_ARG(N > 0 && cols > 0 && rows > 0);
@@ -2375,7 +2368,6 @@ int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const
     a.vmap_color = (uchar4*)vmap_curr_color;
     a.steps = steps_dev;
     a.fp = fp;
-    a.gate = gate; a.gate_seq = gate_seq;
     const bool pyr = vpyr && npyr;
     for (int k = 0; k < 3; ++k) { a.vpyr[k] = pyr ? vpyr[k] : nullptr; a.npyr[k] = pyr ? npyr[k] : nullptr; }
     if (pyr) KT_ARG((cols % 8) == 0 && (rows % 8) == 0);

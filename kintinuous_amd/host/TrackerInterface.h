@@ -36,7 +36,7 @@ class TrackerInterface : public ThreadObject {
 
     ThreadMutexObject<bool> endRequested;
     ThreadMutexObject<bool> handshakeTimedOut;   // (shell addition) the end-of-run hand-shake below gave up
-    int handshakeSeconds = 20;
+    int handshakeSeconds = 0;                    // (shell addition) 0 = wait for ever, as the reference does (TrackerInterface.cpp:66-69); > 0: give up after that many seconds
 
   private:
     // one turn of ThreadObject::run()'s loop (TrackerInterface.cpp:44-137)
@@ -60,15 +60,16 @@ class TrackerInterface : public ThreadObject {
             finalise();
             // the FINAL slice is out: keep waking the slice processor until it has taken it over (:66-69)
             // (the reference loops for ever, napping 33 ms before every look; here the flag is looked at first -- a run without a processor
-            // thread, or one that has finished already, pays no nap -- and the loop gives up after handshakeSeconds: a processor that
-            // is stuck or was never started must not hang join())
+            // thread, or one that has finished already, pays no nap.  The loop is the reference's: it ends when the processor has taken the
+            // FINAL slice, however long its backlog is (advisor, round 5: a 20 s default abandoned a processor that was merely behind); a
+            // caller that prefers an error to a hang sets handshakeSeconds and checks handshakeTimedOut)
             const uint64_t waitStart = Stopwatch::getCurrentSystemTime();
             while (!threadPack.cloudSliceProcessorFinished.getValue()) {
                 {
                     std::lock_guard<std::mutex> lock(frontend->cloudMutex);
                     frontend->cloudSignal.notify_all();
                 }
-                if (Stopwatch::getCurrentSystemTime() - waitStart > (uint64_t)handshakeSeconds * 1000000ull) {
+                if (handshakeSeconds > 0 && Stopwatch::getCurrentSystemTime() - waitStart > (uint64_t)handshakeSeconds * 1000000ull) {
                     std::fprintf(stderr, "TrackerInterface: the slice processor did not take the FINAL slice over within %d s\n", handshakeSeconds);
                     handshakeTimedOut.assignValue(true);
                     break;

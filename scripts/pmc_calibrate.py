@@ -13,11 +13,11 @@ abi._chk(abi.lib().kt_memset(ctx.h, buf.ptr, 1, buf.nbytes))
 ctx.sync()
 for elem, rmw in ((2, 0), (4, 0), (2, 1), (4, 1)):
     for rep in range(3):
-        abi._chk(abi.lib().kt_debug_stream(ctx.h, buf.ptr, 2 * GB, elem, rmw))
+        abi._chk(abi.measure_lib().kt_debug_stream(ctx.h, buf.ptr, 2 * GB, elem, rmw))
     ctx.sync()
 print("streamed 2 GiB per launch: u16 read, u32 read, u16 rmw, u32 rmw (3 launches each)")
 for elem, halves, rmw in ((2, 2, 0), (2, 1, 0), (4, 2, 0), (4, 1, 0), (2, 2, 1), (4, 2, 1)):
     for rep in range(3):
-        abi._chk(abi.lib().kt_debug_stream_rows(ctx.h, buf.ptr, N, N, elem, halves, rmw))
+        abi._chk(abi.measure_lib().kt_debug_stream_rows(ctx.h, buf.ptr, N, N, elem, halves, rmw))
     ctx.sync()
     print("rows: elem %d halves %d rmw %d: %d bytes read per launch" % (elem, halves, rmw, N * N * N * elem * halves // 2))

@@ -22,7 +22,7 @@ print("|---|---|---|---|---|")
 for kind, name in enumerate(KINDS):
     cells = []
     for w in (1, 2, 4, 8):
-        abi._chk(abi.lib().kt_debug_valu_rates(ctx.h, kind, 2000, w, out))
+        abi._chk(abi.measure_lib().kt_debug_valu_rates(ctx.h, kind, 2000, w, out))
         span_us, mhz, n = out[5], out[4], out[2]
         ns = span_us * 1e3 / (w * n)          # first wave in .. last wave out, per instruction of the SIMD's w waves
         cells.append("%.2f ns, %.2f cyc, %.0f MHz" % (ns, ns * mhz * 1e-3, mhz))

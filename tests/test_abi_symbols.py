@@ -22,15 +22,25 @@ def _declared_debug():
     return _names(os.path.join(ROOT, "kintinuous_amd", "csrc", "kt_debug.h"))
 
 
+def _declared_measure():
+    """Measurement kernels, a library of their own (libkt_debug.so): kintinuous_amd/csrc/kt_measure.h."""
+    return _names(os.path.join(ROOT, "kintinuous_amd", "csrc", "kt_measure.h"))
+
+
 def test_header_symbols_are_exported():
     from kintinuous_amd import abi, build
     build.build()
-    lib = ctypes.CDLL(abi.LIB_PATH)
+    lib = ctypes.CDLL(abi.LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     declared = _declared()
     assert len(declared) > 55
     missing = [n for n in declared + _declared_debug() if not hasattr(lib, n)]
     assert not missing, missing
     assert not [n for n in declared if "debug" in n]          # the product header declares no test hook
+    # the measurement kernels are NOT in the product library; libkt_debug.so exports them and loads without a GPU
+    assert not [n for n in _declared_measure() if hasattr(lib, n)]
+    mlib = ctypes.CDLL(abi.MEASURE_LIB_PATH)
+    assert _declared_measure() and not [n for n in _declared_measure() if not hasattr(mlib, n)]
+    assert set(abi.MEASURE_SYMBOLS) == set(_declared_measure())
 
 
 def test_binding_matches_header():

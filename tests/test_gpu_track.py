@@ -294,7 +294,11 @@ def test_hand_off_waits_are_bounded_in_time(ctx, small_scene):
     from kintinuous_amd import abi
     cam, frames, traj = small_scene
     cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
-    trk = abi.Tracker(ctx, cfg)
+    abi._chk(abi.lib().kt_debug_icp_levels(1))   # the level form (this small view is "dense" by the tracker's rule and would run stepwise)
+    try:
+        trk = abi.Tracker(ctx, cfg)
+    finally:
+        abi._chk(abi.lib().kt_debug_icp_levels(-1))
     try:
         for k in range(2):
             trk.process_frame_host(frames[k][0], frames[k][1], 33333 * k)

@@ -249,6 +249,6 @@ def test_running_average_division_all_floats(ctx):
     import ctypes as C
     from kintinuous_amd import abi
     out = (C.c_uint * 3)(1, 1, 1)
-    abi._chk(abi.lib().kt_debug_div_check(ctx.h, out))
+    abi._chk(abi.measure_lib().kt_debug_div_check(ctx.h, out))
     assert out[2] == 0, list(out)
     assert out[1] < 0x0d800000, hex(out[1])   # every differing numerator is below 2^-100

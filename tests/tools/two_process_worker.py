@@ -1,4 +1,5 @@
-"""One of two PROCESSES sharing GPU 0 (tests/test_gpu_two_process.py): the library's defaults, a 160x120 orbit into a 96^3 volume,
+"""One of two PROCESSES sharing GPU 0 (tests/test_gpu_two_process.py): the library's defaults, a 320x240 orbit into a 256^3 volume (a sparse
+view by the tracker's rule, like 640x480 into 512^3: the odometry takes the level form),
 `passes` passes of `frames` frames (reset in between).  Prints one JSON line: the poses of every pass as hex words, the number of
 odometry fallbacks, and whether the last frame ran the level form.  `--barrier DIR --me K --peers N` makes the workers start their frames
 together (files in DIR)."""
@@ -23,11 +24,11 @@ def main():
     ap.add_argument("--peers", type=int, default=1)
     a = ap.parse_args()
     from kintinuous_amd import abi, synth
-    cam = synth.Camera.small(160, 120)
+    cam = synth.Camera.small(320, 240)
     scene = synth.Scene("room")
     frames = [synth.render(scene, cam, R, c) for (R, c) in synth.orbit_trajectory(a.frames)]
     ctx = abi.Ctx(0)
-    cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, 256, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 0, 0, 0, 0)
     trk = abi.Tracker(ctx, cfg)
     trk.process_frame_host(frames[0][0], frames[0][1], 0)   # every kernel has had its first launch
     trk.pose()
