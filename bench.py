@@ -412,7 +412,7 @@ def committed_traffic(workload):
     quoted for the kernel it was measured on: the file records the sha256 of kt_volume.hip, and a stale measurement prints null.
     Returns (bytes per launch, bytes per launch / algorithmic bytes of the SAME launches, the file): the profiled run covers other frames than
     the timed region, so the ratio -- not the absolute -- is what compares with this line's algorithmic bytes."""
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_tsdf23_{workload}.json")
         try:
             j = json.load(open(f))

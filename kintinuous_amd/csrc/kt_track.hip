@@ -70,14 +70,15 @@ struct kt_no_prefetch { __device__ __forceinline__ void operator()() const {} };
 // NaNs of a payload no arithmetic produces; a publisher that did hold 0xffffffff stores 0xfffffffe).  The sweeping wave writes the
 // sentinel back into every granule it has consumed; the next launch that publishes into the buffer is behind this one on the stream,
 // so the kernel boundary orders the two.  A launch that runs several iterations (kt_icp_level_kernel) uses two sets in turn and has no
-// boundary between a hand-back and the next publish into the same word (advisor, round 5: with the SWEEPER handing back, that pair was
-// ordered only by a causal chain of relaxed accesses through other addresses).  There the hand-back is the PUBLISHER's: once a workgroup
-// holds the pose of iteration it - 1 -- proof that the sweep of that iteration is over -- the lanes that stored its granules of set
-// (it - 1) & 1 store the sentinel over them, and the same lanes store the next data into that set one iteration later: two stores of one
-// thread to one address, ordered by the program; and the granule of iteration `it`, which the sweeper must see before it can look at
-// that set again, leaves only after the hand-back has completed (kt_publish_pair<ORDERED>).  The sweeper hands back the set of a launch's
-// LAST iteration only -- against the next launch, across the boundary, as everywhere else.  (One set per iteration, the other option the
-// advisor named, was measured first: 0.26 us per iteration -- the sets go cold in the memory-side cache; profiles/r06_experiments.md.)
+// boundary between the hand-back of iteration `it` and the publish of iteration it + 2 into the same words (advisor, round 5: the pair was
+// ordered only by a causal chain of relaxed accesses).  There the chain is made explicit: every sweeping wave waits for its sentinel
+// stores to COMPLETE (they are write-through agent-scope stores: completed = performed at the memory side; s_waitcnt vmcnt(0), paid by
+// the fifteen sweeping waves -- 1..15 -- which have nothing else to do while wave 0 solves) and arrives at a workgroup barrier; the solving
+// wave, which sweeps nothing and so has no such stores of its own, passes the same barrier immediately before it stores the pose granules.  So: hand-back performed -> barrier -> pose stored -> pose observed by a
+// publisher's polling wave -> its workgroup's barrier -> that workgroup's stores of iterations it + 1, it + 2.  Cost against the unordered
+// form, same box: 3775 against 3790 frames/s.  (Measured alternatives, profiles/r06_experiments.md: one set per iteration -- +0.26 us per
+// iteration, the sets go cold in the memory-side cache; hand-back by the publishers' own lanes -- +0.5 us, 3840 scattered 8-byte stores per
+// iteration instead of 60 coalesced 512-byte ones; wave 0 sweeping as well and waiting for its own stores in the middle of its tail -- +0.1 us.)
 // (Rounds 2-3 tagged every 4-byte sum with a 4-byte epoch: twice the lines for the sweep to
 // fetch, and the sweep -- agent-scope loads go past the L2, one compute unit issues all of them -- is paid per LINE REQUEST:
 // profiles/r04_experiments.md.)  Place of workgroup wg's (= CUDA block wg / 4, warp wg % 4) granule of pair p: the four warps of a block
@@ -92,29 +93,18 @@ struct kt_no_prefetch { __device__ __forceinline__ void operator()() const {} };
 #define KT_POSE_ABORT 15              // pose_gran[15]: {0, seq} of the iteration whose sweep gave up (same 128-byte line as the 12 pose granules)
 __device__ __forceinline__ int kt_granule_index(int pair, int wg) { return pair * KT_RED_BLOCKS + (wg & 3) * (KT_RED_BLOCKS / 4) + (wg >> 2); }
 // lane 0 of every wave p < 15 publishes {sum of product 2p (lanes 0..31), sum of product 2p + 1 (lanes 32..63)}
-// (ORDERED: every vector-memory operation this wave has issued -- its own hand-back stores of kt_handback_own -- has completed before the
-// granule leaves: s_waitcnt vmcnt(0), free at this point because the pixel loop has long consumed its last load)
-template <bool ORDERED = false>
 __device__ __forceinline__ void kt_publish_pair(unsigned long long* __restrict__ granules, float wsum)
 {
     unsigned int lo = __float_as_uint(wsum), hi = (unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(wsum), 32);
     lo = lo == 0xffffffffu ? 0xfffffffeu : lo;
     const int pair = threadIdx.x >> 6;
-    if constexpr (ORDERED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((threadIdx.x & 63) == 0 && pair < KT_RED_PAIRS)
         __hip_atomic_store(&granules[kt_granule_index(pair, blockIdx.x)], ((unsigned long long)hi << 32) | (unsigned long long)lo, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 }
-// A publisher hands its OWN granules of a set back (kt_icp_level_kernel, below): the same lanes that stored them store the sentinel.
-__device__ __forceinline__ void kt_handback_own(unsigned long long* __restrict__ granules)
-{
-    const int pair = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0 && pair < KT_RED_PAIRS)
-        __hip_atomic_store(&granules[kt_granule_index(pair, blockIdx.x)], KT_GRANULE_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 typedef float kt_rows_t[8][32];   // LDS staging rows[k][component][vt], KT_KBATCH of them
 
-template <typename RowFn, bool ORDERED = false>
+template <typename RowFn>
 __device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsigned long long* __restrict__ granules, kt_rows_t* rows)
 {
     KT_TS(0);
@@ -165,7 +155,7 @@ __device__ __forceinline__ void kt_reduce29_publish(const RowFn& fn, int n, unsi
     KT_TS(1);
     // warp tree: the 32 lanes of a half-wave hold product `comp` of the 32 virtual threads of this CUDA warp
     const float wsum = kt_warp32_sum(acc);   // (threads of a product past the 29th hold 0)
-    kt_publish_pair<ORDERED>(granules, wsum);
+    kt_publish_pair(granules, wsum);
     KT_TS(2);
 }
 
@@ -249,9 +239,8 @@ __device__ __forceinline__ unsigned long long kt_ticks() { return __builtin_amdg
 // -- while it waits it holds the compute units somebody else's workgroups may need to make the progress it is waiting for; the stream-ordered
 // kernels hold ONE compute unit while their sweep waits and nothing circular can involve them, so they wait 40 times longer (2 s): long enough
 // for another process's level launch to run into ITS bound and get out of the way (tests/test_gpu_two_process.py).
-// handback = false: the consumed granules are left as they are (kt_icp_level_kernel hands them back from the publishing side).
 template <int NS>
-__device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&granules)[NS], float* const (&total)[NS], unsigned int patience = 40u, bool handback = true)
+__device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&granules)[NS], float* const (&total)[NS], unsigned int patience = 40u)
 {
     const int tid = threadIdx.x;
     KT_TS(3);
@@ -266,8 +255,10 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&
     // contiguous run.  Each wave re-reads its granules until none of them is the sentinel (bounded: a hand-off that never completes
     // raises slot 31 of total[], which the callers report as an error), then hands them back as sentinels for the next launch.
     {
-        const int w = tid >> 6, lane = tid & 63;
-        if (w < KT_RED_PAIRS) {   // (wave-uniform)
+        // (waves 1..15 sweep: wave 0 -- the one that solves -- issues no hand-back stores, so it has none to wait for before it publishes a
+        // pose in kt_icp_level_kernel)
+        const int w = (tid >> 6) - 1, lane = tid & 63;
+        if (w >= 0 && w < KT_RED_PAIRS) {   // (wave-uniform)
             unsigned long long g[NS][4];
             bool ok;
             unsigned int spins = 0;
@@ -295,7 +286,7 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&
                 __builtin_amdgcn_s_sleep(1);
             }
             const bool all_ok = __all(ok);
-            if (all_ok && handback) {
+            if (all_ok) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -326,11 +317,11 @@ __device__ __forceinline__ void kt_reduce29_sweep_n(unsigned long long* const (&
     KT_TS(4);
 }
 
-__device__ __forceinline__ void kt_reduce29_sweep(unsigned long long* __restrict__ granules, float (&total)[KT_RED_SLOTS], unsigned int patience = 40u, bool handback = true)
+__device__ __forceinline__ void kt_reduce29_sweep(unsigned long long* __restrict__ granules, float (&total)[KT_RED_SLOTS], unsigned int patience = 40u)
 {
     unsigned long long* const gs[1] = {granules};
     float* const ts[1] = {total};
-    kt_reduce29_sweep_n<1>(gs, ts, patience, handback);
+    kt_reduce29_sweep_n<1>(gs, ts, patience);
 }
 
 // `pre` runs in the sweeping workgroup between its publish and the sweep: the place to issue loads the epilogue will need
@@ -409,8 +400,8 @@ struct kt_icp_args {
     // kt_icp_level_kernel (round 5): n_iter Gauss-Newton iterations of ONE pyramid level in ONE launch.  The pose goes from an iteration's
     // solving workgroup to the others as 12 granules {float, seq} tagged seq0 + iteration; Rcurr / tcurr then carry the frame's PREVIOUS pose
     // (also the starting pose of the frame's first launch), Rprev_inv / tprev as always.  level_gran: two granule sets, iteration `it` of the
-    // launch reduces through set it & 1, handed back by its publishers (see the hand-off comment at the top).  pose_gran[KT_POSE_ABORT]:
-    // {., seq} of the iteration whose sweep gave up.
+    // launch reduces through set it & 1 (see the hand-off comment at the top).  pose_gran[KT_POSE_ABORT]: {., seq} of the iteration whose
+    // sweep gave up.
     int n_iter; unsigned int seq0; unsigned long long* pose_gran; unsigned long long* level_gran;
 };
 
@@ -653,18 +644,15 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
             }
             __syncthreads();   // (the solving workgroup: its tail wrote s_pose)
             if (s_pose[12] != 0.0f) return;   // workgroup-uniform: no pose (see above)
-            // the pose of iteration it - 1 exists, so its sweep is over: this workgroup's granules of that iteration go back to the sentinel
-            // (the set is published into again at it + 1, by the same lanes)
-            kt_handback_own(a.level_gran + (size_t)((it - 1) & 1) * KT_LEVEL_SET_STRIDE);
             // (wave-uniform values: into scalar registers, where kt_icp_kernel's arguments live too -- as per-lane copies they cost 12 VGPRs)
             const auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
             for (int k = 0; k < 9; ++k) fn.Rcurr.m[k] = uni(s_pose[k]);
             fn.tcurr = {uni(s_pose[9]), uni(s_pose[10]), uni(s_pose[11])};
         }
         __shared__ kt_rows_t rows[KT_KBATCH];
-        kt_reduce29_publish<kt_icp_row, true>(fn, n, gran, rows);
+        kt_reduce29_publish(fn, n, gran, rows);
         if (!sweeper) continue;
-        kt_reduce29_sweep(gran, total, 1u, it + 1 == a.n_iter);   // (the last iteration's set: handed back here, against the next launch)
+        kt_reduce29_sweep(gran, total, 1u);
         // ICPOdometry.cpp:127-178, as kt_icp_kernel's KT_MODE_ICP_SOLVE epilogue
         if (threadIdx.x < 42) sys[threadIdx.x] = (double)total[kt_sys_slot(threadIdx.x)];
         const bool timed_out = total[KT_RED_SLOTS - 1] != 0.0f;   // (workgroup-uniform: read behind the sweep's closing barrier)
@@ -687,7 +675,10 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
                 __hip_atomic_store(&a.pose_gran[KT_POSE_ABORT], (unsigned long long)(a.seq0 + (unsigned int)it) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (timed_out) return;
+        // hand-back performed before the pose leaves (see the hand-off comment at the top of the file): waves 1..15 wait for their stores and
+        // arrive at the barrier now; wave 0 passes it inside its tail, right in front of the pose granules' stores
         if (threadIdx.x < 64) kt_solve_and_update_wave(a.state, sys, pose_d, pose_f, tail_work, a.pose_gran, a.seq0 + (unsigned int)it, s_pose);
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     }
 }
 

@@ -558,9 +558,14 @@ __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, dou
     const float vt = v + pose_f[9 + oi];
     v = is_t ? vt : v;
     if (lane < 12) (&st->Rcurr[0])[lane] = v;   // Rcurr[9] and tcurr[3] are adjacent in kt_track_state
-    if (gran && lane < 12) {
-        __hip_atomic_store(&gran[lane], ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pose_lds[lane] = v;
+    if (gran) {
+        // (kt_icp_level_kernel: the other waves of the workgroup arrive here once their hand-back stores have completed -- the pose must not be
+        // observable before the granules it will be answered into are sentinels again; this wave sweeps nothing and has none of its own)
+        __builtin_amdgcn_s_barrier();
+        if (lane < 12) {
+            __hip_atomic_store(&gran[lane], ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pose_lds[lane] = v;
+        }
     }
     KT_MARK(11);
     KT_TS(6);

@@ -1,5 +1,5 @@
 # HBM-side traffic of the tsdf23 kernel for one workload: FETCH_SIZE and WRITE_SIZE in separate passes (kernel-trace only), written
-# as profiles-style JSON to gpurun_out/r05_pmc_tsdf23_<workload>.json (copy it to profiles/: bench.py quotes it as roofline.traffic
+# as profiles-style JSON to gpurun_out/r06_pmc_tsdf23_<workload>.json (copy it to profiles/: bench.py quotes it as roofline.traffic
 # as long as kt_volume.hip still has the recorded hash).   usage: pmc_traffic.sh <workload> <steps>
 cd /tmp && export TMPDIR=/tmp
 W=${1:-farwall768}; S=${2:-6}
@@ -15,7 +15,7 @@ out = {"kt_volume_hip_sha16": hashlib.sha256(open("$R/kintinuous_amd/csrc/kt_vol
        "calibration": "scripts/pmc_calibrate.sh on the kernel's own row pattern (profiles/r03_pmc_calibration_*.csv): traffic = 2 * FETCH_SIZE + WRITE_SIZE (KiB)"}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     fs = sorted(glob.glob("$R/gpurun_out/pmct_%s/*/*counter_collection.csv" % c), key=os.path.getmtime)
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(fs[-1])) if ("tsdf23_kernel<false" in r["Kernel_Name"] or "tsdf23_lean_kernel<false" in r["Kernel_Name"] or "tsdf23_tol_kernel<false" in r["Kernel_Name"]) and r["Counter_Name"] == c]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(fs[-1])) if ("tsdf23_kernel<false" in r["Kernel_Name"] or "tsdf23_lean_kernel<false" in r["Kernel_Name"] or "tsdf23_tol_kernel<false" in r["Kernel_Name"] or "tsdf23_sol_kernel<false" in r["Kernel_Name"]) and r["Counter_Name"] == c]
     out[c] = sum(vals) / len(vals)
     out["launches_" + c] = len(vals)
 out["traffic_bytes_per_launch"] = (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024
@@ -30,6 +30,6 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         break
     except Exception:
         pass
-json.dump(out, open("$R/gpurun_out/r05_pmc_tsdf23_$W.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/r06_pmc_tsdf23_$W.json", "w"), indent=1)
 print(json.dumps(out))
 PY
