@@ -101,6 +101,9 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
                        int mode, const kt_track_state* init = nullptr, int keep29 = 0);
 int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr, const float* vmap_g_prev,
                         const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres, const kt_track_state* frame, int first, int n_iter);
+int kt_icp_levels_device(kt_ctx* c, kt_track_state* state, int n_levels, const float* const* vmaps_curr, const float* const* nmaps_curr, const kt_intr* intrs,
+                         const float* const* vmaps_g_prev, const float* const* nmaps_g_prev, const int* cols, const int* rows, const int* n_iter,
+                         float dist_thres, float angle_thres, const kt_track_state* frame, int first);   // the levels of a frame in ONE launch
 bool kt_icp_levels_forced();               // ... asked for explicitly
 bool kt_icp_levels_selected(int device);   // kt_track.hip: KT_ICP_LEVELS / kt_debug_icp_levels, and the device can hold the whole grid
 int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,

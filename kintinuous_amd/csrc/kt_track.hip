@@ -403,12 +403,26 @@ struct kt_icp_args {
     // launch reduces through set it & 1 (see the hand-off comment at the top).  pose_gran[KT_POSE_ABORT]: {., seq} of the iteration whose
     // sweep gave up.
     int n_iter; unsigned int seq0; unsigned long long* pose_gran; unsigned long long* level_gran;
+    // round 6: ALL pyramid levels of a frame in one launch (two kernel boundaries and their first loads less per frame).  lv[0 .. n_levels) in
+    // the order they run (coarse to fine); n_iter above = the sum of theirs; the single-level fields above (maps, intr, cols, rows) are
+    // those of lv[0] and are re-pointed by the kernel at every level switch.
+    int n_levels;
+    struct level { const float* vmap_curr; const float* nmap_curr; const float* vmap_g_prev; const float* nmap_g_prev; kt_intr intr; int cols, rows, n_iter; } lv[KT_LEVELS];
 };
 
 struct kt_icp_row {
-    const kt_icp_args& a;
+    // what a pixel's row reads of the launch: the maps and the image geometry of the pyramid level (own copies, wave-uniform: kt_icp_level_kernel
+    // re-points them at every level switch), the two thresholds on the squares
+    struct view { const float* vmap_curr; const float* nmap_curr; const float* vmap_g_prev; const float* nmap_g_prev; kt_intr intr; int cols, rows; float dist2_le, sine2_le; } a;
     kt_mat33 Rcurr, Rprev_inv;
     f3 tcurr, tprev;
+    __device__ __forceinline__ explicit kt_icp_row(const kt_icp_args& k)
+        : a{k.vmap_curr, k.nmap_curr, k.vmap_g_prev, k.nmap_g_prev, k.intr, k.cols, k.rows, k.dist2_le, k.sine2_le} {}
+    __device__ __forceinline__ void set_level(const kt_icp_args::level& v)
+    {
+        a.vmap_curr = v.vmap_curr; a.nmap_curr = v.nmap_curr; a.vmap_g_prev = v.vmap_g_prev; a.nmap_g_prev = v.nmap_g_prev;
+        a.intr = v.intr; a.cols = v.cols; a.rows = v.rows;
+    }
     // kt_icp_level_kernel: the current frame's vertex / normal of pixel pf_i, requested before the pose of the previous iteration arrived
     int pf_i = -1;
     f3 pf_v = {0.f, 0.f, 0.f}, pf_n = {0.f, 0.f, 0.f};
@@ -495,7 +509,7 @@ static void kt_icp_set_thresholds(kt_icp_args& a, float dist_thres, float angle_
 __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_args a)
 {
     if (a.fault && blockIdx.x == 0) return;   // test hook (kt_debug_handoff_fault): a publisher that never arrives -> the sweep must give up
-    kt_icp_row fn{a};
+    kt_icp_row fn(a);
     if (a.state && !a.first) {
         // pose produced by the previous iteration's epilogue (kernel boundary orders the accesses)
         for (int k = 0; k < 9; ++k) { fn.Rcurr.m[k] = a.state->Rcurr[k]; fn.Rprev_inv.m[k] = a.state->Rprev_inv[k]; }
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
     __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
     __shared__ float s_pose[13];   // the pose of the iteration about to run (+ [12] != 0: it never came)
     const bool sweeper = kt_red_sweeps();
-    kt_icp_row fn{a};
+    kt_icp_row fn(a);
     fn.Rprev_inv = a.Rprev_inv;
     fn.tprev = {a.tprev[0], a.tprev[1], a.tprev[2]};
     if (a.first) {   // ICPOdometry.cpp:70-85: the frame starts from the previous pose
@@ -599,11 +613,14 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
         else if (threadIdx.x < 28) pose_f[threadIdx.x - 16] = a.tprev[threadIdx.x - 25];
     }
     if (threadIdx.x == 12) s_pose[12] = 0.0f;
-    const int n = a.cols * a.rows;
+    int it = 0;   // iteration of the launch, counted across the levels (sequence numbers, granule set parity)
+    for (int L = 0; L < a.n_levels; ++L) {
+    fn.set_level(a.lv[L]);
+    const int n = fn.a.cols * fn.a.rows;
     // the first pixel this thread is asked for in every iteration (kt_reduce29_publish: p = tid of batch 0)
     const int t0 = blockIdx.x * 32, nk_blk = (n - t0 + KT_VT_TOTAL - 1) / KT_VT_TOTAL;
     const int pf_i = ((int)threadIdx.x < min(KT_KBATCH, nk_blk) * 32) ? min(t0 + ((int)threadIdx.x & 31) + ((int)threadIdx.x >> 5) * KT_VT_TOTAL, n - 1) : -1;
-    for (int it = 0; it < a.n_iter; ++it) {
+    for (int lit = 0; lit < a.lv[L].n_iter; ++lit, ++it) {
         unsigned long long* const gran = a.level_gran + (size_t)(it & 1) * KT_LEVEL_SET_STRIDE;
         if (it > 0) {
             fn.pf_i = -1;
@@ -680,6 +697,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
         if (threadIdx.x < 64) kt_solve_and_update_wave(a.state, sys, pose_d, pose_f, tail_work, a.pose_gran, a.seq0 + (unsigned int)it, s_pose);
         else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     }
+    }
 }
 
 int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
@@ -734,7 +752,7 @@ extern "C" int kt_icp_step(kt_ctx* c, const kt_mat33* Rcurr, const float tcurr[3
     a.Rcurr = *Rcurr; a.Rprev_inv = *Rprev_inv;
     for (int k = 0; k < 3; ++k) { a.tcurr[k] = tcurr[k]; a.tprev[k] = tprev[k]; }
     a.state = nullptr; a.first = 0; a.out29 = c->red_out; a.mode = KT_MODE_HOST; a.keep29 = 0;
-    a.n_iter = 0; a.seq0 = 0; a.pose_gran = nullptr; a.level_gran = nullptr;
+    a.n_iter = 0; a.seq0 = 0; a.pose_gran = nullptr; a.level_gran = nullptr; a.n_levels = 0;
     int s = kt_icp_launch(c, a);
     if (s != KT_OK) return s;
     KT_HIP(hipMemcpyAsync(c->red_out_host, c->red_out, sizeof(float) * KT_RED_SLOTS, hipMemcpyDeviceToHost, c->stream));
@@ -749,7 +767,7 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
                        int mode, const kt_track_state* init, int keep29)
 {
     kt_icp_args a;
-    a.n_iter = 0; a.seq0 = 0; a.pose_gran = nullptr; a.level_gran = nullptr;
+    a.n_iter = 0; a.seq0 = 0; a.pose_gran = nullptr; a.level_gran = nullptr; a.n_levels = 0;
     a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
     a.intr = *intr; a.cols = cols; a.rows = rows; kt_icp_set_thresholds(a, dist_thres, angle_thres);
     a.state = state; a.out29 = nullptr; a.mode = mode;
@@ -765,23 +783,42 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
     return kt_icp_launch(c, a);
 }
 
-// n_iter iterations of one pyramid level in one launch (kt_icp_level_kernel).  frame: Rprev, tprev, Rprev_inv of the frame (the init record of the
-// stepwise form); first: the frame's first launch (the starting pose is the previous pose, the state is initialised).
-int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr, const float* vmap_g_prev,
-                        const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres, const kt_track_state* frame, int first, int n_iter)
+// The Gauss-Newton iterations of n_levels pyramid levels (in the order given: coarse to fine) in ONE launch (kt_icp_level_kernel).  frame: Rprev,
+// tprev, Rprev_inv of the frame (the init record of the stepwise form); first: the frame's first launch (the starting pose is the previous
+// pose, the state is initialised).
+int kt_icp_levels_device(kt_ctx* c, kt_track_state* state, int n_levels, const float* const* vmaps_curr, const float* const* nmaps_curr, const kt_intr* intrs,
+                         const float* const* vmaps_g_prev, const float* const* nmaps_g_prev, const int* cols, const int* rows, const int* n_iter,
+                         float dist_thres, float angle_thres, const kt_track_state* frame, int first)
 {
-    if (n_iter <= 0) return KT_OK;
+    KT_ARG(n_levels >= 1 && n_levels <= KT_LEVELS);
     kt_icp_args a;
-    a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
-    a.intr = *intr; a.cols = cols; a.rows = rows; kt_icp_set_thresholds(a, dist_thres, angle_thres);
+    memset(&a, 0, sizeof(a));
+    int total = 0, used = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        if (n_iter[l] <= 0) continue;
+        kt_icp_args::level& v = a.lv[used++];
+        v.vmap_curr = vmaps_curr[l]; v.nmap_curr = nmaps_curr[l]; v.vmap_g_prev = vmaps_g_prev[l]; v.nmap_g_prev = nmaps_g_prev[l];
+        v.intr = intrs[l]; v.cols = cols[l]; v.rows = rows[l]; v.n_iter = n_iter[l];
+        total += n_iter[l];
+    }
+    if (total <= 0) return KT_OK;
+    a.n_levels = used;
+    a.vmap_curr = a.lv[0].vmap_curr; a.nmap_curr = a.lv[0].nmap_curr; a.vmap_g_prev = a.lv[0].vmap_g_prev; a.nmap_g_prev = a.lv[0].nmap_g_prev;
+    a.intr = a.lv[0].intr; a.cols = a.lv[0].cols; a.rows = a.lv[0].rows; kt_icp_set_thresholds(a, dist_thres, angle_thres);
     a.state = state; a.out29 = nullptr; a.mode = KT_MODE_ICP_SOLVE; a.first = first ? 1 : 0; a.keep29 = 0;
     memcpy(a.Rcurr.m, frame->Rprev, sizeof(a.Rcurr.m));
     memcpy(a.Rprev_inv.m, frame->Rprev_inv, sizeof(a.Rprev_inv.m));
     for (int k = 0; k < 3; ++k) { a.tcurr[k] = frame->tprev[k]; a.tprev[k] = frame->tprev[k]; }
-    a.n_iter = n_iter;
+    a.n_iter = total;
     a.seq0 = c->odo_seq + 1u;
-    c->odo_seq += (unsigned int)n_iter;
+    c->odo_seq += (unsigned int)total;
     return kt_icp_launch(c, a);
+}
+// ... one level (the form round 5 launched three times per frame)
+int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr, const float* vmap_g_prev,
+                        const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres, const kt_track_state* frame, int first, int n_iter)
+{
+    return kt_icp_levels_device(c, state, 1, &vmap_curr, &nmap_curr, intr, &vmap_g_prev, &nmap_g_prev, &cols, &rows, &n_iter, dist_thres, angle_thres, frame, first);
 }
 
 // ICPOdometry::getIncrementalTransformation (ICPOdometry.cpp:68-186) as ONE entry point (SURVEY 8(b) export list): pose in / pose out,
@@ -890,6 +927,34 @@ int kt_rgb_residual_candidates(kt_ctx* c, float min_scale, const int16_t* dIdx, 
                        next_depth, cols, rows, min_scale, cand);
     KT_LAUNCH_CHECK();
     return KT_OK;
+}
+
+// residualKernel's per-pixel body (reduce.cu:718-760) for pixel k of the NEXT image, given the pose-independent half of its test (`candidate`):
+// the DataTerm, and whether it counts (valid); the loads that do not depend on the pose (depth and intensity of this pixel) are the caller's
+__device__ __forceinline__ bool kt_residual_pixel(const kt_residual_args& a, const float (&K)[9], const float (&kt)[3], int k, int cols, int rows, bool candidate,
+                                                  float d1, uint8_t ni, kt_dataterm& corres)
+{
+    corres.zero_x = corres.zero_y = corres.one_x = corres.one_y = 0;
+    corres.diff = 0.f;
+    corres.valid = 0;
+    corres.pad[0] = corres.pad[1] = corres.pad[2] = 0;
+    const int y = k / cols, x = k - y * cols;
+    const float xf = (float)x, yf = (float)y;
+    const float transformed_d1 = __builtin_fmaf(d1, __builtin_fmaf(K[6], xf, K[7] * yf) + K[8], kt[2]);
+    const int u0 = kt_f2i_rn(__builtin_fmaf(d1, __builtin_fmaf(K[0], xf, K[1] * yf) + K[2], kt[0]) / transformed_d1);
+    const int v0 = kt_f2i_rn(__builtin_fmaf(d1, __builtin_fmaf(K[3], xf, K[4] * yf) + K[5], kt[1]) / transformed_d1);
+    const bool inimg = candidate && u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows;
+    const int gi = inimg ? v0 * cols + u0 : 0;
+    const float d0 = a.last_depth[gi];
+    const uint8_t li = a.last_image[gi];
+    if (inimg && d0 > 0 && fabsf(transformed_d1 - d0) <= a.max_depth_delta && li != 0) {
+        corres.zero_x = (int16_t)u0; corres.zero_y = (int16_t)v0;
+        corres.one_x = (int16_t)x; corres.one_y = (int16_t)y;
+        corres.diff = (float)ni - (float)li;
+        corres.valid = 1;
+        return true;
+    }
+    return false;
 }
 
 #define KT_RES_THREADS 1024
@@ -1106,11 +1171,21 @@ struct kt_rgb_args {
 struct kt_rgb_row {
     const kt_rgb_args& a;
     float sigma;
+    // kt_joint_level_kernel: the DataTerms were stored by THIS workgroup a moment ago (same launch): read them past the compute unit's vector
+    // cache (workgroup-scope loads; the stores went through it to the XCD's L2, a line cached from the previous iteration's read would be stale)
+    bool own_terms = false;
     // RGBReduction::getProducts, reduce.cu:441-486.  Branch-free like kt_icp_row (the reference's early return for an invalid DataTerm
     // becomes a predicate, the gather indices of an invalid pixel are clamped to 0) and staged: fetch_term -> fetch_taps -> finish.
     struct taps { float X, Y, Z, gx, gy; };
     __device__ __forceinline__ kt_dataterm fetch_term(int i) const
     {
+        if (own_terms) {
+            const unsigned long long* q = (const unsigned long long*)&a.corres[i];
+            unsigned long long w[2];
+            w[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            w[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return *(const kt_dataterm*)&w[0];
+        }
         const int4 raw = *(const int4*)&a.corres[i];
         return *(const kt_dataterm*)&raw;
     }
@@ -1195,7 +1270,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_rgb_kernel(const kt_rgb_arg
 // kt_icp_kernel(KT_MODE_ICP_STASH) + kt_rgb_kernel(KT_MODE_JOINT_SOLVE) pair: one kernel boundary and one sweep less per iteration.
 __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_args ai, const kt_rgb_args ar)
 {
-    kt_icp_row fi{ai};
+    kt_icp_row fi(ai);
     for (int k = 0; k < 9; ++k) { fi.Rcurr.m[k] = ai.state->Rcurr[k]; fi.Rprev_inv.m[k] = ai.state->Rprev_inv[k]; }
     fi.tcurr = {ai.state->tcurr[0], ai.state->tcurr[1], ai.state->tcurr[2]};
     fi.tprev = {ai.state->tprev[0], ai.state->tprev[1], ai.state->tprev[2]};

@@ -520,6 +520,11 @@ __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, dou
         if (pi == 3) { crow[0] = 0.0; crow[1] = 0.0; crow[2] = 0.0; crow[3] = 1.0; }
     }
     KT_MARK(9);
+    // (the addresses of the tail's stores are formed HERE, from the scalar base: hoisted to the kernel's prologue they were lane-dependent
+    // 64-bit values alive across the whole pixel loop, and the register allocator of the multi-level kernel spilled them to scratch -- reloaded
+    // in front of every store, on the critical path)
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));   // (the stores below index with lane_t: their addresses cannot be formed before this point)
     // (9) resultRt = [R | t] * resultRt: element (pi, pj) on lane 4 pi + pj
     double prod = 0;
 #pragma unroll
@@ -527,7 +532,7 @@ __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, dou
     __builtin_amdgcn_wave_barrier();
     float* fw = (float*)work;   // [0, 16): the new increment in float
     if (lane < 16) {
-        st->resultRt[lane] = prod;
+        st->resultRt[lane_t] = prod;
         pose_d[lane] = prod;
         fw[lane] = (float)prod;
     }
@@ -557,14 +562,14 @@ __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, dou
     float v = (p0 * B[0] + p1 * B[1]) + p2 * B[2];
     const float vt = v + pose_f[9 + oi];
     v = is_t ? vt : v;
-    if (lane < 12) (&st->Rcurr[0])[lane] = v;   // Rcurr[9] and tcurr[3] are adjacent in kt_track_state
+    if (lane < 12) (&st->Rcurr[0])[lane_t] = v;   // Rcurr[9] and tcurr[3] are adjacent in kt_track_state
     if (gran) {
         // (kt_icp_level_kernel: the other waves of the workgroup arrive here once their hand-back stores have completed -- the pose must not be
         // observable before the granules it will be answered into are sentinels again; this wave sweeps nothing and has none of its own)
         __builtin_amdgcn_s_barrier();
         if (lane < 12) {
-            __hip_atomic_store(&gran[lane], ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pose_lds[lane] = v;
+            __hip_atomic_store(&gran[lane_t], ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pose_lds[lane_t] = v;
         }
     }
     KT_MARK(11);

@@ -757,13 +757,23 @@ static int icp_odometry(kt_tracker* t, bool stepwise_only = false)
     bool first = true;
     t->last_icp_levels = !stepwise_only && t->icp_levels && t->icp_demote == 0 && kt_live_trackers.load() == 1;
     if (!stepwise_only && t->icp_demote > 0) --t->icp_demote;
-    if (t->last_icp_levels) {   // one launch per level: the iterations of a level hand the pose over inside the kernel (kt_track.hip: kt_icp_level_kernel)
+    if (t->last_icp_levels) {
+        // ONE launch for the frame (round 6; round 5: one per level): the iterations of all levels hand the pose over inside the kernel
+        // (kt_track.hip: kt_icp_level_kernel); KT_ICP_ONE_LAUNCH=0 restores the launch per level for A/B runs
+        static const bool one_launch = []() { const char* e = getenv("KT_ICP_ONE_LAUNCH"); return !e || atoi(e) != 0; }();
+        const float* vc[KT_LEVELS]; const float* nc[KT_LEVELS]; const float* vg[KT_LEVELS]; const float* ng[KT_LEVELS];
+        kt_intr li[KT_LEVELS]; int cs[KT_LEVELS], rs[KT_LEVELS], its[KT_LEVELS], nl = 0;
         for (int l = KT_LEVELS - 1; l >= 0; --l) {
             if (iters[l] <= 0) continue;
-            const kt_intr li = lvl_intr(t->intr, l);
-            KT_TRY(kt_icp_level_device(t->ctx, t->state_dev, t->vmaps_curr[l], t->nmaps_curr[l], &li, t->vmaps_g_prev[l], t->nmaps_g_prev[l], lvl_cols(t, l),
-                                       lvl_rows(t, l), dist_thres, angle_thres, &init, first ? 1 : 0, iters[l]));
-            first = false;
+            vc[nl] = t->vmaps_curr[l]; nc[nl] = t->nmaps_curr[l]; vg[nl] = t->vmaps_g_prev[l]; ng[nl] = t->nmaps_g_prev[l];
+            li[nl] = lvl_intr(t->intr, l); cs[nl] = lvl_cols(t, l); rs[nl] = lvl_rows(t, l); its[nl] = iters[l];
+            ++nl;
+        }
+        if (one_launch) {
+            if (nl) KT_TRY(kt_icp_levels_device(t->ctx, t->state_dev, nl, vc, nc, li, vg, ng, cs, rs, its, dist_thres, angle_thres, &init, 1));
+        } else {
+            for (int k = 0; k < nl; ++k)
+                KT_TRY(kt_icp_level_device(t->ctx, t->state_dev, vc[k], nc[k], &li[k], vg[k], ng[k], cs[k], rs[k], dist_thres, angle_thres, &init, k == 0 ? 1 : 0, its[k]));
         }
         return odometry_end(t);
     }

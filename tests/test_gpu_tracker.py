@@ -661,7 +661,15 @@ def test_the_level_form_needs_to_be_alone(ctx, small_scene):
     g, _ = _cfgs(cam, 96)
     form = lambda t: abi.lib().kt_tracker_debug_icp_levels(t.h)
     last = lambda t: np.concatenate([x.ravel() for x in t.pose()]).view(np.uint32)
-    probe = abi.Tracker(ctx, g)   # alone, unless an earlier test of this process left a tracker open
+
+    def make():   # the level form asked for explicitly (round 6: this small view is "dense" by the tracker's rule and would default to the stepwise chain)
+        abi._chk(abi.lib().kt_debug_icp_levels(1))
+        try:
+            return abi.Tracker(ctx, g)
+        finally:
+            abi._chk(abi.lib().kt_debug_icp_levels(-1))
+
+    probe = make()   # alone, unless an earlier test of this process left a tracker open
     for k in range(2):
         probe.process_frame_host(frames[k][0], frames[k][1], 33333 * k)
     probe.pose()
@@ -669,8 +677,8 @@ def test_the_level_form_needs_to_be_alone(ctx, small_scene):
     probe.close()
     if not alone:
         pytest.skip("another tracker is alive in this process")
-    a = abi.Tracker(ctx, g)
-    b = abi.Tracker(ctx, g)
+    a = make()
+    b = make()
     for k, (d, rgb) in enumerate(frames):
         a.process_frame_host(d, rgb, 33333 * k)
         b.process_frame_host(d, rgb, 33333 * k)
