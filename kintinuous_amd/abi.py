@@ -145,6 +145,7 @@ _PROTOS = {
     "kt_debug_tsdf_contract": (_i, [_i]),
     "kt_debug_sq_threshold": (_f, [_f, _i]),
     "kt_debug_icp_levels": (_i, [_i]),
+    "kt_debug_ri_levels": (_i, [_i]),
     "kt_tracker_debug_icp_levels": (_i, [_vp]),
     "kt_debug_icp_wg_times": (_i, [_vp, C.POINTER(C.c_ulonglong)]),
     "kt_debug_tsdf_timeline": (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),

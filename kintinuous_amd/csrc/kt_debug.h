@@ -63,6 +63,9 @@ int kt_debug_wait_limit(kt_ctx* ctx, unsigned int ticks_100mhz);
 /* A/B hook: trackers created from now on run their ICP-only odometry as one launch per pyramid level (csrc/kt_track.hip: kt_icp_level_kernel) -- 1 --
  * or as one launch per iteration -- 0; -1 = KT_ICP_LEVELS in the environment, else the build's default.  Both give the same bits. */
 int kt_debug_icp_levels(int on);
+/* A/B hook: trackers created in -ri mode run their joint RGB-D + ICP odometry as one launch per pyramid level (kt_joint_level_kernel) -- 1 -- or as two
+ * launches per iteration -- 0; -1 = KT_RI_LEVELS in the environment, else off (the level form is bit-equal and measured slower: kt_tracker.hip) */
+int kt_debug_ri_levels(int on);
 int kt_tracker_debug_icp_levels(kt_tracker* trk);   /* 1: the tracker's last frame ran its ICP chain in the level form (only while it is the process's only live tracker) */
 int kt_tracker_debug_side_gate(kt_tracker* trk);    /* 1: the tracker's read-ahead waits for the ray cast of the frame in flight (KT_SIDE_GATE; csrc/kt_tracker.hip) */
 /* host arithmetic behind the ICP row's threshold tests (csrc/kt_track.hip: kt_icp_set_thresholds): the largest float X with

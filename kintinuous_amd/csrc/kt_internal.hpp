@@ -104,6 +104,7 @@ int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr
 int kt_icp_levels_device(kt_ctx* c, kt_track_state* state, int n_levels, const float* const* vmaps_curr, const float* const* nmaps_curr, const kt_intr* intrs,
                          const float* const* vmaps_g_prev, const float* const* nmaps_g_prev, const int* cols, const int* rows, const int* n_iter,
                          float dist_thres, float angle_thres, const kt_track_state* frame, int first);   // the levels of a frame in ONE launch
+bool kt_ri_levels_selected();             // -ri: one launch per pyramid level (kt_joint_level_kernel); off by default
 bool kt_icp_levels_forced();               // ... asked for explicitly
 bool kt_icp_levels_selected(int device);   // kt_track.hip: KT_ICP_LEVELS / kt_debug_icp_levels, and the device can hold the whole grid
 int kt_rgb_residual_device(kt_ctx* c, kt_track_state* state, float min_scale, const int16_t* dIdx, const int16_t* dIdy,
@@ -117,6 +118,11 @@ int kt_joint_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_cur
                          const float* vmap_g_prev, const float* nmap_g_prev, float dist_thres, float angle_thres,
                          const kt_dataterm* corres_img, const float* cloud, const int16_t* dIdx, const int16_t* dIdy, float sobel_scale,
                          int cols, int rows, const kt_level_k* next_k);
+int kt_joint_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr, const float* vmap_g_prev,
+                          const float* nmap_g_prev, float dist_thres, float angle_thres, kt_dataterm* corres_img, const float* cloud, const int16_t* dIdx,
+                          const int16_t* dIdy, float sobel_scale, float min_scale, const float* last_depth, const float* next_depth, const uint8_t* last_image,
+                          const uint8_t* next_image, float max_depth_delta, const uint8_t* cand, int cols, int rows, int n_iter, const kt_level_k* k_level,
+                          const kt_level_k* k_next);   // the -ri iterations of one pyramid level in ONE launch (kt_track.hip: kt_joint_level_kernel)
 int kt_rgb_step_device(kt_ctx* c, kt_track_state* state, const kt_dataterm* corres_img, const float* cloud, float fx, float fy,
                        const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows, int mode,
                        const kt_level_k* next_k);

@@ -87,7 +87,7 @@ struct kt_no_prefetch { __device__ __forceinline__ void operator()() const {} };
 #define KT_GRANULE_SENTINEL 0xffffffffffffffffull
 // kt_icp_level_kernel: its two granule sets, behind everything else in the context's hand-off buffer (u64 indices; [0, 8192) and
 // [8192, 16384): the two kt_reduce29 sets, 16384..: the residual launch's words, kt_residual_granules / kt_residual_partials)
-#define KT_LEVEL_SETS 2
+#define KT_LEVEL_SETS 4                // (kt_icp_level_kernel uses the first two; kt_joint_level_kernel two per reduction)
 #define KT_LEVEL_SET_STRIDE 4096      // >= KT_RED_PAIRS * KT_RED_BLOCKS = 3840
 #define KT_LEVEL_SET_BASE 32768
 #define KT_POSE_ABORT 15              // pose_gran[15]: {0, seq} of the iteration whose sweep gave up (same 128-byte line as the 12 pose granules)
@@ -810,6 +810,7 @@ int kt_icp_levels_device(kt_ctx* c, kt_track_state* state, int n_levels, const f
     memcpy(a.Rprev_inv.m, frame->Rprev_inv, sizeof(a.Rprev_inv.m));
     for (int k = 0; k < 3; ++k) { a.tcurr[k] = frame->tprev[k]; a.tprev[k] = frame->tprev[k]; }
     a.n_iter = total;
+    if (c->odo_seq > 0xfffff000u) c->odo_seq = 0;   // (2^32 iterations are 16 hours at 3800 frames/s)
     a.seq0 = c->odo_seq + 1u;
     c->odo_seq += (unsigned int)total;
     return kt_icp_launch(c, a);
@@ -1310,6 +1311,268 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_kernel(const kt_icp_a
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The -ri iterations of ONE pyramid level in one launch (round 6).  Until now an iteration was two launches because the
+// Jacobian rows of rgbStep need the GRID-WIDE correspondence count of computeRgbResidual (sigmaVal, RGBDOdometry.cpp:253) before a single
+// pixel can be weighed.  Here the 256 workgroups stay resident, as in kt_icp_level_kernel, and an iteration is
+//   R  every workgroup runs residualKernel's body (reduce.cu:718-760) for ITS OWN pixels -- the pixels its 32 virtual threads will reduce, so
+//      the DataTerms it writes (every pixel, quirk A.19) are read back by nobody else -- and publishes its {count, sum diff^2} as two tagged
+//      granules; every workgroup then collects the 512 granules (integer sums: any order) and forms sigmaVal for itself;
+//   J  kt_joint_kernel's pass: the ICP row and the RGB-D row of every pixel, both 29-sum reductions in the reference's order, two granule sets;
+//   T  the last workgroup sweeps both sets, combines A = A_rgbd + 100 A_icp, b = b_rgbd + 10 b_icp, solves, updates the pose and K R K^-1 / K t
+//      (kt_compute_krk) and publishes BOTH as 24 tagged granules, which the other workgroups poll.
+// Two in-kernel exchanges (0.7-1 us each) instead of two kernel boundaries and their first loads (2 x ~2.1 us), and the DataTerm image no longer
+// crosses the chip between two launches.  Arithmetic: kt_residual_kernel's and kt_joint_kernel's, operation for operation (tests: config 3
+// byte-equal to the oracle, tests/test_gpu_tracker.py level == stepwise).  Waits, abort and fallback: kt_icp_level_kernel's.
+// ------------------------------------------------------------------------------------------------
+#define KT_KRK_GRAN 16   // pose_gran[16 .. 28): K R K^-1 (9) and K t (3) of the iteration, tagged like the pose granules [0, 12)
+struct kt_joint_level_extra {
+    int n_iter; unsigned int seq0;
+    unsigned long long* pose_gran; unsigned long long* level_gran;   // level_gran: 4 sets: (it & 1) * 2 + {0: ICP, 1: RGB-D}
+    unsigned long long* res_gran;                                    // [2][KT_RED_BLOCKS] {seq << 32 | value}: count, sum diff^2
+    kt_level_k k_level, k_next;   // K of this level (iterations that stay on it) and of the level the iteration behind the launch runs at
+    unsigned int fault;
+};
+
+__global__ __launch_bounds__(KT_RED_THREADS) void kt_joint_level_kernel(const kt_icp_args ai, const kt_rgb_args ar, const kt_residual_args rr, const kt_joint_level_extra x)
+{
+    if (x.fault && blockIdx.x == 0) return;   // test hook (kt_debug_handoff_fault)
+    if (ai.state->handoff_timeout) return;    // an earlier launch of this frame gave up (the state is uploaded clean at the start of every -ri frame)
+    __shared__ kt_rows_t rows_icp[KT_KBATCH], rows_rgb[KT_KBATCH];   // 2 x 40 KB
+    __shared__ float total_icp[KT_RED_SLOTS], total[KT_RED_SLOTS];
+    __shared__ double sys[KT_SYS_DOUBLES], pose_d[KT_POSE_STAGE_DOUBLES], tail_work[KT_TAIL_WORK_DOUBLES];
+    __shared__ float pose_f[KT_POSE_STAGE_FLOATS];
+    __shared__ float s_pose[25];            // pose (12), K R K^-1 (9), K t (3) of the iteration about to run; [24] != 0: they never came
+    __shared__ unsigned int s_res[3];       // count, sum diff^2 of the iteration; [2] != 0: the partial sums never came
+    __shared__ unsigned int wsum[2][KT_RED_THREADS / 64];
+    const bool sweeper = kt_red_sweeps();
+    kt_icp_row fi(ai);
+    for (int k = 0; k < 9; ++k) { fi.Rcurr.m[k] = ai.state->Rcurr[k]; fi.Rprev_inv.m[k] = ai.state->Rprev_inv[k]; }
+    fi.tcurr = {ai.state->tcurr[0], ai.state->tcurr[1], ai.state->tcurr[2]};
+    fi.tprev = {ai.state->tprev[0], ai.state->tprev[1], ai.state->tprev[2]};
+    float K[9], kt[3];
+    for (int q = 0; q < 9; ++q) K[q] = ai.state->krkinv[q];
+    for (int q = 0; q < 3; ++q) kt[q] = ai.state->kt[q];
+    kt_rgb_row fr{ar, 0.0f};
+    fr.own_terms = true;
+    if (sweeper) {   // the solving workgroup's carry (kt_pose_stage's layout)
+        if (threadIdx.x < 16) pose_d[threadIdx.x] = ai.state->resultRt[threadIdx.x];
+        else if (threadIdx.x < 25) pose_f[threadIdx.x - 16] = ai.state->Rprev[threadIdx.x - 16];
+        else if (threadIdx.x < 28) pose_f[threadIdx.x - 16] = ai.state->tprev[threadIdx.x - 25];
+    }
+    if (threadIdx.x == 24) s_pose[24] = 0.0f;
+    const int cols = ai.cols, rows = ai.rows, n = cols * rows;
+    const int t0 = blockIdx.x * 32, nk_blk = (n - t0 + KT_VT_TOTAL - 1) / KT_VT_TOTAL;
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    for (int it = 0; it < x.n_iter; ++it) {
+        const unsigned int seq = x.seq0 + (unsigned int)it;
+        if (it > 0) {
+            if (!sweeper && threadIdx.x < 64) {
+                // pose + K R K^-1 + K t of iteration it - 1: 24 granules in two lines, and the abort granule (kt_icp_level_kernel's wait)
+                const unsigned int want = seq - 1u;
+                const unsigned int spin_limit = min(*(volatile const unsigned int*)&kt_sweep_spin_limit, 1u << 20);
+                const unsigned int tick_limit = 2u * *(volatile const unsigned int*)&kt_wait_limit_ticks;
+                unsigned long long tick0 = 0, g = 0;
+                unsigned int spins = 0;
+                const bool mine = lane < 13 || (lane >= KT_KRK_GRAN && lane < KT_KRK_GRAN + 12);
+                const int gi = lane == 12 ? KT_POSE_ABORT : lane;
+                bool ok, gone;
+                for (;;) {
+                    if (mine) g = __hip_atomic_load(&x.pose_gran[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int ahead = (int)((unsigned int)(g >> 32) - want);
+                    ok = !mine || lane == 12 || ahead == 0;
+                    gone = lane == 12 && ahead >= 0 && ahead < x.n_iter;
+                    if (__all(ok) || __any(gone) || ++spins > spin_limit) break;
+                    if ((spins & 15u) == 0) {
+                        const unsigned long long now = kt_ticks();
+                        if (spins == 16u) tick0 = now;
+                        else if (now - tick0 > tick_limit) break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const bool got = __all(ok) && !__any(gone);
+                if (lane < 12) s_pose[lane] = __uint_as_float((unsigned int)g);
+                if (lane >= KT_KRK_GRAN && lane < KT_KRK_GRAN + 12) s_pose[12 + lane - KT_KRK_GRAN] = __uint_as_float((unsigned int)g);
+                if (lane == 12) s_pose[24] = got ? 0.0f : 1.0f;
+            }
+            __syncthreads();   // (the solving workgroup: its tail wrote s_pose)
+            if (s_pose[24] != 0.0f) return;   // workgroup-uniform: no pose; the sweep of this iteration cannot complete and reports it
+            for (int k = 0; k < 9; ++k) fi.Rcurr.m[k] = uni(s_pose[k]);
+            fi.tcurr = {uni(s_pose[9]), uni(s_pose[10]), uni(s_pose[11])};
+            for (int k = 0; k < 9; ++k) K[k] = uni(s_pose[12 + k]);
+            for (int k = 0; k < 3; ++k) kt[k] = uni(s_pose[21 + k]);
+        }
+        // ---- R: computeRgbResidual for this workgroup's own pixels (the pixels of its 32 virtual threads, batch by batch like the reduction)
+        {
+            int cnt = 0;
+            unsigned int sig = 0;   // wraps modulo 2^32 like the reference's int sum
+            for (int kb = 0; kb < nk_blk; kb += KT_KBATCH) {
+                const int kcount = min(KT_KBATCH, nk_blk - kb);
+                for (int p = (int)threadIdx.x; p < kcount * 32; p += KT_RED_THREADS) {
+                    const int i = t0 + (p & 31) + (kb + (p >> 5)) * KT_VT_TOTAL;
+                    const bool inside = i < n;
+                    const int k = inside ? i : n - 1;
+                    const float d1 = rr.next_depth[k];
+                    const uint8_t ni = rr.next_image[k];
+                    const bool candidate = inside && rr.cand[k] != 0;
+                    kt_dataterm corres;
+                    corres.zero_x = corres.zero_y = corres.one_x = corres.one_y = 0; corres.diff = 0.f; corres.valid = 0;
+                    corres.pad[0] = corres.pad[1] = corres.pad[2] = 0;
+                    if (__builtin_amdgcn_ballot_w64(candidate) != 0) {   // wave-uniform: no candidate among these 64 pixels, no arithmetic
+                        if (kt_residual_pixel(rr, K, kt, k, cols, rows, candidate, d1, ni, corres)) {
+                            cnt += 1;
+                            sig += (unsigned int)kt_f2i_rz(corres.diff * corres.diff);
+                        }
+                    }
+                    // the first iteration of a level writes every DataTerm (quirk A.19), later ones only the candidates: the others are still zero
+                    if (inside && (it == 0 ? rr.write_all != 0 || candidate : candidate)) *(int4*)&rr.corres[k] = *(const int4*)&corres;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) { cnt += __shfl_down(cnt, off, 64); sig += __shfl_down(sig, off, 64); }
+            if (lane == 0) { wsum[0][wave] = (unsigned int)cnt; wsum[1][wave] = sig; }
+            // the DataTerm stores have reached the XCD's L2 (write-through) before any wave of the workgroup reads them back in J
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x < 2) {
+                unsigned int t = 0;
+#pragma unroll
+                for (int w = 0; w < KT_RED_THREADS / 64; ++w) t += wsum[threadIdx.x][w];
+                __hip_atomic_store(&x.res_gran[threadIdx.x * KT_RED_BLOCKS + blockIdx.x], ((unsigned long long)seq << 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // every workgroup collects all 2 x 256 partial sums (wave 1: the sums are integers, any order will do)
+            if (wave == 1) {
+                unsigned long long v[2][4];
+                const unsigned int spin_limit = min(*(volatile const unsigned int*)&kt_sweep_spin_limit, 1u << 20);
+                const unsigned int tick_limit = 2u * *(volatile const unsigned int*)&kt_wait_limit_ticks;
+                unsigned long long tick0 = 0;
+                unsigned int spins = 0;
+                bool ok;
+                for (;;) {
+#pragma unroll
+                    for (int which = 0; which < 2; ++which)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[which][q] = __hip_atomic_load(&x.res_gran[which * KT_RED_BLOCKS + lane + 64 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = true;
+#pragma unroll
+                    for (int which = 0; which < 2; ++which)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ok = ok && (unsigned int)(v[which][q] >> 32) == seq;
+                    if (__all(ok) || ++spins > spin_limit) break;
+                    if ((spins & 15u) == 0) {
+                        const unsigned long long now = kt_ticks();
+                        if (spins == 16u) tick0 = now;
+                        else if (now - tick0 > tick_limit) break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                unsigned int tot[2] = {0, 0};
+#pragma unroll
+                for (int which = 0; which < 2; ++which)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tot[which] += (unsigned int)v[which][q];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { tot[0] += __shfl_xor(tot[0], off, 64); tot[1] += __shfl_xor(tot[1], off, 64); }
+                if (lane == 0) { s_res[0] = tot[0]; s_res[1] = tot[1]; s_res[2] = __all(ok) ? 0u : 1u; }
+            }
+            __syncthreads();
+            if (s_res[2] != 0u && !sweeper) return;   // (the sweeper goes on: its sweep reports the time-out)
+        }
+        const int res_count = (int)s_res[0], res_sigma = (int)s_res[1];
+        fr.sigma = __builtin_sqrtf(((float)res_sigma / (float)res_count == 0) ? 1.0f : (float)res_count);   // RGBDOdometry.cpp:253 (kt_residual_sigma)
+        // ---- J: both rows of every pixel, both reductions (kt_joint_kernel's pass)
+        unsigned long long* const gran_icp = x.level_gran + (size_t)((it & 1) * 2) * KT_LEVEL_SET_STRIDE;
+        unsigned long long* const gran_rgb = gran_icp + KT_LEVEL_SET_STRIDE;
+        kt_reduce29_publish2(fi, fr, n, gran_icp, gran_rgb, rows_icp, rows_rgb);
+        if (!sweeper) continue;
+        // ---- T
+        {
+            unsigned long long* const gs[2] = {gran_icp, gran_rgb};
+            float* const ts[2] = {total_icp, total};   // the time-out flag lands in total[31]
+            kt_reduce29_sweep_n<2>(gs, ts, 1u);
+        }
+        const bool timed_out = total[KT_RED_SLOTS - 1] != 0.0f || s_res[2] != 0u;
+        if (threadIdx.x < 42) {   // RGBDOdometry.cpp:316-321: A = A_rgbd + w*w*A_icp, b = b_rgbd + w*b_icp, w = 10
+            const int slot = kt_sys_slot(threadIdx.x);
+            const double w = 10, v = (double)total[slot], vi = (double)total_icp[slot];
+            sys[threadIdx.x] = threadIdx.x < 36 ? v + w * w * vi : v + w * vi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 64) {
+            if (timed_out) {
+                ar.state->handoff_timeout = 1;
+                __hip_atomic_store(&x.pose_gran[KT_POSE_ABORT], (unsigned long long)seq << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ar.state->sigma_val = fr.sigma; ar.state->rgb_count = res_count; ar.state->rgb_sigma = res_sigma;   // (kept for observers)
+        }
+        if (timed_out) return;
+        if (threadIdx.x < 64) {
+            kt_solve_and_update_wave(ar.state, sys, pose_d, pose_f, tail_work, nullptr, 0, s_pose);
+            __builtin_amdgcn_wave_barrier();
+            // K R K^-1, K t for the iteration behind this one: at this level's K, or -- behind the launch's last iteration -- the next level's
+            if (threadIdx.x == 0) {
+                float krk[9], ktn[3];
+                kt_compute_krk(pose_d, it + 1 < x.n_iter ? x.k_level : x.k_next, krk, ktn);
+                for (int q = 0; q < 9; ++q) { ar.state->krkinv[q] = krk[q]; s_pose[12 + q] = krk[q]; }
+                for (int q = 0; q < 3; ++q) { ar.state->kt[q] = ktn[q]; s_pose[21 + q] = ktn[q]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the hand-back of both granule sets has completed in waves 1..15 (they arrive at the barrier once their stores have): now the
+            // pose and the warp may be seen
+            __builtin_amdgcn_s_barrier();
+            if (lane < 24) {
+                const float v = s_pose[lane];
+                __hip_atomic_store(&x.pose_gran[lane < 12 ? lane : KT_KRK_GRAN + lane - 12], ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
+// n_iter joint RGB-D + ICP iterations of one pyramid level in one launch (kt_joint_level_kernel).  k_level: this level's intrinsics; k_next: those of
+// the level the iteration BEHIND this launch runs at (the warp K R K^-1, K t is formed by the iteration in front of the one that uses it).
+int kt_joint_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr, const float* vmap_g_prev,
+                          const float* nmap_g_prev, float dist_thres, float angle_thres, kt_dataterm* corres_img, const float* cloud, const int16_t* dIdx,
+                          const int16_t* dIdy, float sobel_scale, float min_scale, const float* last_depth, const float* next_depth, const uint8_t* last_image,
+                          const uint8_t* next_image, float max_depth_delta, const uint8_t* cand, int cols, int rows, int n_iter, const kt_level_k* k_level,
+                          const kt_level_k* k_next)
+{
+    if (n_iter <= 0) return KT_OK;
+    KT_ARG(cand && k_level && k_next);
+    kt_icp_args a;
+    memset(&a, 0, sizeof(a));
+    a.vmap_curr = vmap_curr; a.nmap_curr = nmap_curr; a.vmap_g_prev = vmap_g_prev; a.nmap_g_prev = nmap_g_prev;
+    a.intr = *intr; a.cols = cols; a.rows = rows; kt_icp_set_thresholds(a, dist_thres, angle_thres);
+    a.state = state; a.out29 = nullptr; a.mode = KT_MODE_ICP_STASH;
+    kt_rgb_args r;
+    memset(&r, 0, sizeof(r));
+    r.corres = corres_img; r.sigma = 0.f; r.cloud = cloud; r.fx = intr->fx; r.fy = intr->fy; r.dIdx = dIdx; r.dIdy = dIdy;
+    r.sobel_scale = sobel_scale; r.cols = cols; r.rows = rows; r.state = state; r.mode = KT_MODE_JOINT_SOLVE; r.next_k = *k_level;
+    kt_residual_args rr;
+    memset(&rr, 0, sizeof(rr));
+    rr.min_scale = min_scale; rr.dIdx = dIdx; rr.dIdy = dIdy; rr.last_depth = last_depth; rr.next_depth = next_depth;
+    rr.last_image = last_image; rr.next_image = next_image; rr.corres = corres_img; rr.max_depth_delta = max_depth_delta;
+    rr.state = state; rr.cols = cols; rr.rows = rows; rr.cand = cand; rr.write_all = 1;
+    kt_joint_level_extra x;
+    x.n_iter = n_iter;
+    if (c->odo_seq > 0xfffff000u) c->odo_seq = 0;   // the tags never reach the buffer's fill pattern (all ones)
+    x.seq0 = c->odo_seq + 1u;
+    c->odo_seq += (unsigned int)n_iter;
+    x.pose_gran = c->pose_gran;
+    x.level_gran = (unsigned long long*)c->red_partials + KT_LEVEL_SET_BASE;
+    x.res_gran = kt_residual_granules(c) + 2048;
+    x.k_level = *k_level; x.k_next = *k_next;
+    x.fault = 0;
+    if (c->fault_skip > 0) --c->fault_skip;
+    else if (c->fault_count > 0) { --c->fault_count; x.fault = 1; }
+    hipLaunchKernelGGL(kt_joint_level_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a, r, rr, x);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
 int kt_joint_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr,
                          const float* vmap_g_prev, const float* nmap_g_prev, float dist_thres, float angle_thres,
                          const kt_dataterm* corres_img, const float* cloud, const int16_t* dIdx, const int16_t* dIdy, float sobel_scale,
@@ -1510,6 +1773,14 @@ bool kt_icp_levels_selected(int device)
     const char* e = getenv("KT_ICP_LEVELS");
     const bool env = e ? atoi(e) != 0 : KT_ICP_LEVELS_DEFAULT != 0;
     return (kt_icp_levels_override < 0 ? env : kt_icp_levels_override != 0) && kt_icp_levels_fit(device);
+}
+// -ri in the level form (kt_joint_level_kernel): off unless asked for (KT_RI_LEVELS=1 or the test hook)
+static int kt_ri_levels_override = -1;
+extern "C" int kt_debug_ri_levels(int on) { kt_ri_levels_override = on < 0 ? -1 : (on != 0); return KT_OK; }
+bool kt_ri_levels_selected()
+{
+    const char* e = getenv("KT_RI_LEVELS");
+    return kt_ri_levels_override < 0 ? (e && atoi(e) != 0) : kt_ri_levels_override != 0;
 }
 // the form was asked for explicitly (environment or test hook): policies that would pick one themselves keep out
 bool kt_icp_levels_forced() { return kt_icp_levels_override >= 0 || getenv("KT_ICP_LEVELS") != nullptr; }

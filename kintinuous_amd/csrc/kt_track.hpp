@@ -372,7 +372,8 @@ __device__ __forceinline__ double kt_lane_bcast(double v, int src)   // src: wav
 }
 
 // gran != nullptr (kt_icp_level_kernel: several iterations in one launch): the new pose also leaves as 12 tagged granules {float, seq} for the
-// other workgroups, which poll them ("the data is the flag", as in kt_reduce29), and as 12 floats in LDS (pose_lds) for this workgroup itself.
+// other workgroups, which poll them ("the data is the flag", as in kt_reduce29); pose_lds != nullptr: and as 12 floats in LDS for this workgroup
+// itself (kt_joint_level_kernel passes pose_lds alone and publishes pose AND K R K^-1 / K t together, behind its own barrier).
 __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, double* sys, double* pose_d, const float* pose_f, double* work,
                                                          unsigned long long* gran = nullptr, unsigned int seq = 0, float* pose_lds = nullptr)
 {
@@ -563,14 +564,13 @@ __device__ __forceinline__ void kt_solve_and_update_wave(kt_track_state* st, dou
     const float vt = v + pose_f[9 + oi];
     v = is_t ? vt : v;
     if (lane < 12) (&st->Rcurr[0])[lane_t] = v;   // Rcurr[9] and tcurr[3] are adjacent in kt_track_state
+    if (pose_lds && lane < 12) pose_lds[lane_t] = v;   // the resident kernels' own copy (kt_icp_level_kernel, kt_joint_level_kernel)
     if (gran) {
         // (kt_icp_level_kernel: the other waves of the workgroup arrive here once their hand-back stores have completed -- the pose must not be
         // observable before the granules it will be answered into are sentinels again; this wave sweeps nothing and has none of its own)
         __builtin_amdgcn_s_barrier();
-        if (lane < 12) {
+        if (lane < 12)
             __hip_atomic_store(&gran[lane_t], ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pose_lds[lane_t] = v;
-        }
     }
     KT_MARK(11);
     KT_TS(6);

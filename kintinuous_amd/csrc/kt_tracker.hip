@@ -790,7 +790,7 @@ static int icp_odometry(kt_tracker* t, bool stepwise_only = false)
 }
 
 // RGBDOdometry::getIncrementalTransformation, RGBDOdometry.cpp:165-393
-static int rgbd_odometry(kt_tracker* t, int set, int last_set)
+static int rgbd_odometry(kt_tracker* t, int set, int last_set, bool stepwise_only = false)
 {
     int iters[KT_LEVELS];
     if (!t->cfg.use_rgbd_icp) {
@@ -819,6 +819,30 @@ static int rgbd_odometry(kt_tracker* t, int set, int last_set)
     for (int l = KT_LEVELS - 1; l >= 0; --l)
         for (int j = 0; j < iters[l]; ++j) sched[ns++] = l;
     KT_TRY(odometry_begin(t, ns ? &lk[sched[0]] : nullptr));
+    // -ri: the iterations of a pyramid level in ONE launch (round 6, kt_track.hip: kt_joint_level_kernel), under the conditions of the ICP chain's
+    // level form (alone in the process, not demoted by a recent fallback, the grid fits the device).  OFF by default: bit-equal to the two
+    // launches per iteration (tests/test_gpu_tracker.py, config 3), but measured SLOWER on the crab-walk -- 1980 against 2100-2300 frames/s
+    // (profiles/r06_experiments.md, call 10): the odometry stage itself is no shorter (0.303 against 0.301 ms: what two kernel boundaries cost,
+    // the DataTerm round trip through the L2 and 186 spilled scalar registers cost back), and a resident 1024-thread launch keeps the RGB-D
+    // read-ahead (160 us per frame) out of every compute unit for the whole odometry.  KT_RI_LEVELS=1 / kt_debug_ri_levels(1) select it.
+    const bool ri_levels_env = kt_ri_levels_selected();
+    const bool ri_levels = t->cfg.use_rgbd_icp && !stepwise_only && ri_levels_env && t->icp_levels && t->icp_demote == 0 && kt_live_trackers.load() == 1;
+    if (t->cfg.use_rgbd_icp && !stepwise_only && t->icp_demote > 0) --t->icp_demote;
+    t->last_icp_levels = ri_levels;
+    if (ri_levels) {
+        for (int q = 0; q < ns;) {
+            const int l = sched[q];
+            int cnt = 0;
+            while (q + cnt < ns && sched[q + cnt] == l) ++cnt;
+            const kt_intr li = lvl_intr(t->intr, l);
+            const kt_level_k* k_next = &lk[q + cnt < ns ? sched[q + cnt] : l];
+            KT_TRY(kt_joint_level_device(t->ctx, t->state_dev, t->vmaps_curr[l], t->nmaps_curr[l], &li, t->vmaps_g_prev[l], t->nmaps_g_prev[l], dist_thres, angle_thres,
+                                         t->corres[l], last.cloud[l], next.dIdx[l], next.dIdy[l], (float)SOBEL_SCALE, rgbd_min_scale(l), last.depth_m[l], next.depth_m[l],
+                                         last.image[l], next.image[l], (float)MAX_DEPTH_DELTA, next.cand[l], lvl_cols(t, l), lvl_rows(t, l), cnt, &lk[l], k_next));
+            q += cnt;
+        }
+        return odometry_end(t);
+    }
     for (int q = 0; q < ns; ++q) {
         const int l = sched[q];
         const int cols = lvl_cols(t, l), rows = lvl_rows(t, l);
@@ -1449,7 +1473,7 @@ static int complete_frame(kt_tracker* t)
         select_set(t, t->out_set);
         const bool icp = !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
         if (icp) KT_TRY(icp_odometry(t, true));
-        else KT_TRY(rgbd_odometry(t, t->out_set, t->out_last_set));
+        else KT_TRY(rgbd_odometry(t, t->out_set, t->out_last_set, true));
         if (++t->frame_seq == 0) t->frame_seq = 1;
         KT_TRY(launch_setup(t, 0, nullptr, nullptr));
         if (t->out_speculated) KT_TRY(enqueue_fusion(t, t->out_set, t->out_depth, t->out_rgb, t->plan_sel >= 0 ? &t->plans[t->plan_sel].plan : nullptr));

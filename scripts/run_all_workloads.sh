@@ -1,5 +1,5 @@
-# every bench workload once; results -> gpurun_out/workloads_r04.jsonl
-out=gpurun_out/workloads_r04.jsonl; : > $out
+# every bench workload once; results -> gpurun_out/workloads_r06.jsonl
+out=gpurun_out/workloads_r06.jsonl; : > $out
 for w in orbit512 orbit256 crabwalk512 farwall768; do
   steps=200; [ $w = farwall768 ] && steps=40
   timeout 600 python bench.py --workload $w --steps $steps --warmup 10 --cpu-frames 6 --no-stress 2>gpurun_out/$w.err | tail -1 >> $out || echo "{\"workload\": \"$w\", \"failed\": true}" >> $out
@@ -7,7 +7,7 @@ for w in orbit512 orbit256 crabwalk512 farwall768; do
 done
 python - <<'PY'
 import json
-for l in open('gpurun_out/workloads_r04.jsonl'):
+for l in open('gpurun_out/workloads_r06.jsonl'):
     try: d=json.loads(l)
     except Exception as e: print('bad line', l[:200]); continue
     if 'value' not in d: print(d); continue

@@ -261,8 +261,8 @@ def test_tracker_recovers_from_a_handoff_timeout(ctx, small_scene, levels):
         P0, V0, C0 = run(trk)
         assert trk.odometry_fallbacks() == 0 and form(trk) == levels
         trk.reset()
-        # frame 2: its last launch (of 3, or of 10 + 5 + 4) loses workgroup 0
-        P1, V1, C1 = run(trk, 2, lambda: _handoff_fault(ctx, 2 if levels else 18, 1, spin_limit=64, want_dirty=False))
+        # frame 2: its launch (ONE for the whole frame in the level form; the last of 10 + 5 + 4 otherwise) loses workgroup 0
+        P1, V1, C1 = run(trk, 2, lambda: _handoff_fault(ctx, 0 if levels else 18, 1, spin_limit=64, want_dirty=False))
         assert trk.odometry_fallbacks() == 1
         assert np.array_equal(P0.view(np.uint32), P1.view(np.uint32)) and np.array_equal(V0, V1) and np.array_equal(C0, C1)
         assert form(trk) == 0          # demoted: the frames behind a fallback run the stepwise chain

@@ -648,6 +648,41 @@ def test_icp_chain_per_level_equals_per_iteration(ctx, small_scene):
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
+def test_ri_chain_per_level_equals_per_iteration(ctx, small_scene):
+    """-ri (joint RGB-D + ICP odometry, RGBDOdometry.cpp:165-393): one launch per pyramid level (round 6, kt_joint_level_kernel: the residual pass, the
+    grid-wide sigma and both reductions of every iteration inside one resident kernel) and two launches per iteration (kt_residual_kernel +
+    kt_joint_kernel) are the same arithmetic: every pose and both volumes bit-equal, with and without read-ahead."""
+    from kintinuous_amd import abi
+    cam, frames, traj = small_scene
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 6.0, 14, 2, 0, 0, 1, 0, 0, 0)
+    out = []
+    for levels, ahead in ((0, False), (1, False), (1, True)):
+        abi._chk(abi.lib().kt_debug_icp_levels(levels))
+        abi._chk(abi.lib().kt_debug_ri_levels(levels))   # (off by default: measured slower, kt_tracker.hip rgbd_odometry)
+        try:
+            trk = abi.Tracker(ctx, cfg)
+        finally:
+            abi._chk(abi.lib().kt_debug_icp_levels(-1))
+        dev = [(ctx.upload(d), ctx.upload(rgb)) for d, rgb in frames]
+        poses = []
+        for k in range(len(frames)):
+            if ahead and k + 1 < len(frames):
+                trk.prefetch_frame(dev[k + 1][0], dev[k + 1][1])
+            trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+            if not ahead:
+                poses.append(np.concatenate([x.ravel() for x in trk.pose()]))
+        if ahead:
+            poses = [trk.dense_pose(i)[1].ravel() for i in range(trk.num_poses())]
+        assert abi.lib().kt_tracker_debug_icp_levels(trk.h) == levels and trk.odometry_fallbacks() == 0
+        out.append((np.array(poses), trk.volume().copy(), trk.color_volume().copy()))
+        trk.close()
+        abi._chk(abi.lib().kt_debug_ri_levels(-1))
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    for k in (1, 2):
+        assert np.array_equal(out[0][1], out[k][1]) and np.array_equal(out[0][2], out[k][2])
+    assert np.abs(out[0][0][-1] - out[0][0][0]).max() > 1e-4    # it did track
+
+
 def test_the_level_form_needs_to_be_alone(ctx, small_scene):
     """kt_icp_level_kernel's workgroups wait for each other inside a launch and need the whole machine: a second tracker fed next to it can keep
     its last workgroup out until the bounded waits give up.  So the form is chosen per frame: only while the tracker is the process's only live
