@@ -576,13 +576,17 @@ static int tracker_create_impl(kt_tracker* t, kt_ctx* ctx, const kt_tracker_conf
         const int mode = e ? atoi(e) : KT_SIDE_GATE_DEFAULT;
         int wcx = 0, wcy = 0, xg = 0, yg = 0;
         kt_tsdf_plan_shape(cfg->cols, cfg->rows, cfg->N, &wcx, &wcy, &xg, &yg);
-        t->side_gate = mode == 1 || (mode == 2 && wcx == 32) ? 1 : 0;
+        // "dense view": the voxel pass's rule for 32 x 2 wave-columns AND an image beyond 640x480 -- the case where the voxel kernel is the frame's
+        // longest and the read-ahead is heavy (1280x960 into 768^3).  640x480 into 256^3 is dense by the first rule alone, but its voxel kernel is
+        // 21 us and its frame is the orbit's: gated and stepwise it ran at 3770 frames/s against 4100 (profiles/r06_experiments.md, call 12)
+        const bool dense = wcx == 32 && (long long)cfg->cols * cfg->rows > 640LL * 480LL;
+        t->side_gate = mode == 1 || (mode == 2 && dense) ? 1 : 0;
         // A level launch takes every compute unit's whole register file: whatever the side streams have not finished when the odometry starts
         // waits for it to end and then runs beside the voxel kernel after all.  On a dense view (1280x960: the pixel loops are long, the
         // hand-over a level launch saves is 1.4 % of the frame) the odometry therefore stays one launch per iteration -- 48 VGPRs: read-ahead
         // and plan run UNDER it -- and the plan's completion event, which the set-up kernel already waits for, keeps both out of the voxel kernel.
         const char* d = getenv("KT_DENSE_STEPWISE");
-        if (mode == 2 && wcx == 32 && (d ? atoi(d) != 0 : true) && !kt_icp_levels_forced()) t->icp_levels = false;
+        if (mode == 2 && dense && (d ? atoi(d) != 0 : true) && !kt_icp_levels_forced()) t->icp_levels = false;
     }
     t->plan_enabled = getenv("KT_NO_PLAN") == nullptr;   // (A/B switch: every frame through the in-stream pre-pass)
     t->plan_margin_scale = getenv("KT_PLAN_MARGIN_SCALE") ? (float)atof(getenv("KT_PLAN_MARGIN_SCALE")) : 1.0f;   // (tests: 0 makes every plan miss)

@@ -1229,7 +1229,9 @@ __device__ __forceinline__ float kt_min1(float x)   // min(1, x) as one v_min_f3
 // the residual test of the colour blend (k = rint(n * v_rcp_f32(den)): wrong only next to a .5 tie).  What it keeps: the projection's
 // exact reciprocal (the PIXEL a voxel reads must not change: "bit-exact on voxel indices"), every predicate, weight and store rule.
 // Consequences, counted by tests/test_gpu_tol.py against the bit-exact kernel at BASELINE configs 2 / 3 / 5: tsdf shorts differ by at
-// most 1 on a small fraction of the touched voxels, colour bytes by at most 1 at near-ties, weights never.  The bit-exact kernel stays
+// most 1 on a small fraction of the touched voxels, colour bytes by at most 1 at near-ties, weights on 0-2 voxels of 135 M (not a guarantee: the
+// update predicate `sdf >= -trunc` is decided by v_sqrt_f32 here, so a voxel within the root's last bit of the -trunc edge can be updated by one
+// kernel and not by the other -- advisor, round 5).  The bit-exact kernel stays
 // the default of the library, of every parity test and of bench.py's headline.
 // CT = 2, "speed of light" (round 6): a MEASUREMENT variant, never a product path.  Same task list, same loads, stores and
 // predicates as the kernels above; the per-voxel arithmetic cut down to what the reference's own build flags execute (CMakeLists.txt:47:

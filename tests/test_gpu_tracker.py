@@ -683,6 +683,52 @@ def test_ri_chain_per_level_equals_per_iteration(ctx, small_scene):
     assert np.abs(out[0][0][-1] - out[0][0][0]).max() > 1e-4    # it did track
 
 
+def test_side_gate_is_transparent(ctx, small_scene):
+    """KT_SIDE_GATE (round 6): with the gate on, the read-ahead stream waits for an event behind the voxel kernel of the frame in flight and the main
+    stream joins the side streams in front of the next set-up kernel -- a change of WHEN kernels run, never of what they compute.  A sequence with
+    read-ahead and volume shifts gives the same poses, slices and volumes with the gate off, on, and on with the odometry one launch per iteration
+    (the dense-view default)."""
+    import os
+    from kintinuous_amd import abi, synth
+    cam = synth.Camera.small(160, 120)
+    scene = synth.Scene("wall")
+    traj = synth.crabwalk_trajectory(420)
+    frames = [synth.render(scene, cam, *traj[i]) for i in range(40)]
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, 96, cam.fx, cam.fy, cam.cx, cam.cy, 7.0, 3, 2, 0, 0, 0, 0, 0, 0)
+    dev = [(ctx.upload(d), ctx.upload(rgb)) for d, rgb in frames]
+    out = []
+    saved = os.environ.get("KT_SIDE_GATE")
+    try:
+        for gate, levels in (("0", 1), ("1", 1), ("1", 0)):
+            os.environ["KT_SIDE_GATE"] = gate
+            abi._chk(abi.lib().kt_debug_icp_levels(levels))
+            try:
+                trk = abi.Tracker(ctx, cfg)
+            finally:
+                abi._chk(abi.lib().kt_debug_icp_levels(-1))
+            assert abi.lib().kt_tracker_debug_side_gate(trk.h) == int(gate)
+            for k in range(len(dev)):
+                if k + 1 < len(dev):
+                    trk.prefetch_frame(dev[k + 1][0], dev[k + 1][1])
+                trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+            poses = np.array([trk.dense_pose(i)[1].ravel() for i in range(trk.num_poses())])
+            # (the order of the points inside a slice is the extraction kernel's atomic order: compare slices as sorted sets of 32-byte points)
+            slices = [b"".join(sorted(bytes(r) for r in trk.slice(i)[0].view(np.uint8).reshape(-1, 32))) for i in range(trk.num_slices())]
+            out.append((poses, trk.volume().copy(), trk.color_volume().copy(), slices, trk.voxel_wrap().copy()))
+            assert trk.odometry_fallbacks() == 0
+            trk.close()
+    finally:
+        if saved is None:
+            os.environ.pop("KT_SIDE_GATE", None)
+        else:
+            os.environ["KT_SIDE_GATE"] = saved
+    assert np.abs(out[0][4]).max() > 0                      # the volume did shift
+    for k in (1, 2):
+        assert np.array_equal(out[0][0].view(np.uint32), out[k][0].view(np.uint32))
+        assert np.array_equal(out[0][1], out[k][1]) and np.array_equal(out[0][2], out[k][2])
+        assert out[0][3] == out[k][3] and np.array_equal(out[0][4], out[k][4])
+
+
 def test_the_level_form_needs_to_be_alone(ctx, small_scene):
     """kt_icp_level_kernel's workgroups wait for each other inside a launch and need the whole machine: a second tracker fed next to it can keep
     its last workgroup out until the bounded waits give up.  So the form is chosen per frame: only while the tracker is the process's only live
