@@ -350,7 +350,7 @@ def main():
         "roofline": {"kernel": voxel_kernel, "contract": "survey-8c" if voxel_kernel == "kt_tsdf23_tol_kernel" else "bit-exact", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                      "frac": achieved / peak,
                      "frac_is": "the launch inside the timed region, next to the read-ahead and plan streams (since round 5 they run beside the fusion kernels: the "
-                                "odometry of a pyramid level is one resident launch); frac_alone = the same launch with nothing else on the GPU",
+                                "odometry of a frame is one resident launch that takes every compute unit); frac_alone = the same launch with nothing else on the GPU",
                      "traffic": traffic, "traffic_ratio": traffic_ratio,
                      # not measured by this run: the committed rocprofv3 PMC passes of the same workload and the same kt_volume.hip
                      "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_tsdf23,
