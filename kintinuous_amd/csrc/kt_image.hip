@@ -818,60 +818,69 @@ __device__ __forceinline__ void kt_emit_maps(const int* __restrict__ tile, int t
         nmap[v * cols + u] = kt_nan();
 }
 
+// S = side of the level-3 tile a workgroup owns (4: rounds 1-5, 300 workgroups at 640x480; 2: round 6, 1200).  The kernel is latency bound --
+// a workgroup is a short chain of {load, barrier, filter, barrier ...} and 300 of them are 1.2 per compute unit -- so the smaller tile, which
+// recomputes more halo (2.2 x the level-0 loads), is the faster launch.  Tile widths: level 3: S + 1 (the +1 neighbour of the normal map), level 2:
+// 2 S + 5, level 1: 4 S + 13, level 0: 8 S + 29 (5 / 13 / 29 / 61 for S = 4).  kt_build_pyramid picks S by image size; KT_PYR_S=2|4 forces one.
+template <int S>
 __global__ __launch_bounds__(256) void kt_pyramid_kernel(const kt_pyr_args a)
 {
-    __shared__ int t0[KT_PYR_T0 * KT_PYR_T0], t1[KT_PYR_T1 * KT_PYR_T1], t2[KT_PYR_T2 * KT_PYR_T2], t3[KT_PYR_T3 * KT_PYR_T3];
+    constexpr int T3 = S + 1, T2 = 2 * S + 5, T1 = 4 * S + 13, T0 = 8 * S + 29;
+    static_assert(S == 2 || (T0 == KT_PYR_T0 && T1 == KT_PYR_T1 && T2 == KT_PYR_T2 && T3 == KT_PYR_T3), "tile widths");
+    __shared__ int t0[T0 * T0], t1[T1 * T1], t2[T2 * T2], t3[T3 * T3];
     const int tid = threadIdx.x;
-    const int o3x = blockIdx.x * 4, o3y = blockIdx.y * 4;
+    const int o3x = blockIdx.x * S, o3y = blockIdx.y * S;
     const int o2x = 2 * o3x, o2y = 2 * o3y, o1x = 4 * o3x, o1y = 4 * o3y, o0x = 8 * o3x, o0y = 8 * o3y;
     const int c0 = a.cols, r0 = a.rows, c1 = c0 / 2, r1 = r0 / 2, c2 = c1 / 2, r2 = r1 / 2, c3 = c2 / 2, r3 = r2 / 2;
     // tile origins in their own level's pixel coordinates
     const int t0x = o0x - 14, t0y = o0y - 14, t1x = o1x - 6, t1y = o1y - 6, t2x = o2x - 2, t2y = o2y - 2, t3x = o3x, t3y = o3y;
-    for (int i = tid; i < KT_PYR_T0 * KT_PYR_T0; i += 256) {
-        const int ly = i / KT_PYR_T0, lx = i - ly * KT_PYR_T0;
+    for (int i = tid; i < T0 * T0; i += 256) {
+        const int ly = i / T0, lx = i - ly * T0;
         const int gx = t0x + lx, gy = t0y + ly;
         t0[i] = (gx >= 0 && gy >= 0 && gx < c0 && gy < r0) ? (int)a.d0[gy * c0 + gx] : -1;
     }
     __syncthreads();
-    for (int i = tid; i < KT_PYR_T1 * KT_PYR_T1; i += 256) {
-        const int ly = i / KT_PYR_T1, lx = i - ly * KT_PYR_T1;
-        t1[i] = kt_pyr_px(t0, KT_PYR_T0, t0x, t0y, c0, r0, t1x + lx, t1y + ly);
+    for (int i = tid; i < T1 * T1; i += 256) {
+        const int ly = i / T1, lx = i - ly * T1;
+        t1[i] = kt_pyr_px(t0, T0, t0x, t0y, c0, r0, t1x + lx, t1y + ly);
     }
     __syncthreads();
-    for (int i = tid; i < KT_PYR_T2 * KT_PYR_T2; i += 256) {
-        const int ly = i / KT_PYR_T2, lx = i - ly * KT_PYR_T2;
-        t2[i] = kt_pyr_px(t1, KT_PYR_T1, t1x, t1y, c1, r1, t2x + lx, t2y + ly);
+    for (int i = tid; i < T2 * T2; i += 256) {
+        const int ly = i / T2, lx = i - ly * T2;
+        t2[i] = kt_pyr_px(t1, T1, t1x, t1y, c1, r1, t2x + lx, t2y + ly);
     }
     __syncthreads();
-    if (tid < KT_PYR_T3 * KT_PYR_T3) {
-        const int ly = tid / KT_PYR_T3, lx = tid - ly * KT_PYR_T3;
-        t3[tid] = kt_pyr_px(t2, KT_PYR_T2, t2x, t2y, c2, r2, t3x + lx, t3y + ly);
+    if (tid < T3 * T3) {
+        const int ly = tid / T3, lx = tid - ly * T3;
+        t3[tid] = kt_pyr_px(t2, T2, t2x, t2y, c2, r2, t3x + lx, t3y + ly);
     }
     __syncthreads();
     // ---- outputs: depth levels 1..3 of the owned tiles, vertex + normal maps of all levels --------
-    {   // level 0: 32 x 32 pixels, 4 per thread
-        for (int i = tid; i < 32 * 32; i += 256) {
-            const int ly = i >> 5, lx = i & 31;
-            kt_emit_maps(t0, KT_PYR_T0, t0x, t0y, c0, r0, o0x + lx, o0y + ly, a.fx_inv[0], a.fy_inv[0], a.cx[0], a.cy[0], a.vmap[0], a.nmap[0]);
+    {   // level 0: 8 S x 8 S pixels
+        for (int i = tid; i < 64 * S * S; i += 256) {
+            const int ly = i / (8 * S), lx = i - ly * (8 * S);
+            kt_emit_maps(t0, T0, t0x, t0y, c0, r0, o0x + lx, o0y + ly, a.fx_inv[0], a.fy_inv[0], a.cx[0], a.cy[0], a.vmap[0], a.nmap[0]);
         }
     }
-    {   // level 1: 16 x 16
-        const int ly = tid >> 4, lx = tid & 15;
+    if (tid < 16 * S * S) {   // level 1: 4 S x 4 S
+        const int ly = tid / (4 * S), lx = tid - ly * (4 * S);
         const int u = o1x + lx, v = o1y + ly;
-        if (u < c1 && v < r1) a.d[0][v * c1 + u] = (uint16_t)t1[(v - t1y) * KT_PYR_T1 + (u - t1x)];
-        kt_emit_maps(t1, KT_PYR_T1, t1x, t1y, c1, r1, u, v, a.fx_inv[1], a.fy_inv[1], a.cx[1], a.cy[1], a.vmap[1], a.nmap[1]);
+        if (u < c1 && v < r1) a.d[0][v * c1 + u] = (uint16_t)t1[(v - t1y) * T1 + (u - t1x)];
+        kt_emit_maps(t1, T1, t1x, t1y, c1, r1, u, v, a.fx_inv[1], a.fy_inv[1], a.cx[1], a.cy[1], a.vmap[1], a.nmap[1]);
     }
-    if (tid < 64) {  // level 2: 8 x 8
-        const int ly = tid >> 3, lx = tid & 7;
+    // levels 2 and 3 on the waves that have the least to do above
+    const int q2 = 255 - tid;
+    if (q2 < 4 * S * S) {  // level 2: 2 S x 2 S
+        const int ly = q2 / (2 * S), lx = q2 - ly * (2 * S);
         const int u = o2x + lx, v = o2y + ly;
-        if (u < c2 && v < r2) a.d[1][v * c2 + u] = (uint16_t)t2[(v - t2y) * KT_PYR_T2 + (u - t2x)];
-        kt_emit_maps(t2, KT_PYR_T2, t2x, t2y, c2, r2, u, v, a.fx_inv[2], a.fy_inv[2], a.cx[2], a.cy[2], a.vmap[2], a.nmap[2]);
-    } else if (tid < 80) {  // level 3: 4 x 4
-        const int q = tid - 64;
-        const int ly = q >> 2, lx = q & 3;
+        if (u < c2 && v < r2) a.d[1][v * c2 + u] = (uint16_t)t2[(v - t2y) * T2 + (u - t2x)];
+        kt_emit_maps(t2, T2, t2x, t2y, c2, r2, u, v, a.fx_inv[2], a.fy_inv[2], a.cx[2], a.cy[2], a.vmap[2], a.nmap[2]);
+    } else if (q2 < 5 * S * S) {  // level 3: S x S
+        const int q = q2 - 4 * S * S;
+        const int ly = q / S, lx = q - ly * S;
         const int u = o3x + lx, v = o3y + ly;
-        if (u < c3 && v < r3) a.d[2][v * c3 + u] = (uint16_t)t3[(v - t3y) * KT_PYR_T3 + (u - t3x)];
-        kt_emit_maps(t3, KT_PYR_T3, t3x, t3y, c3, r3, u, v, a.fx_inv[3], a.fy_inv[3], a.cx[3], a.cy[3], a.vmap[3], a.nmap[3]);
+        if (u < c3 && v < r3) a.d[2][v * c3 + u] = (uint16_t)t3[(v - t3y) * T3 + (u - t3x)];
+        kt_emit_maps(t3, T3, t3x, t3y, c3, r3, u, v, a.fx_inv[3], a.fy_inv[3], a.cx[3], a.cy[3], a.vmap[3], a.nmap[3]);
     }
 }
 
@@ -893,7 +902,12 @@ extern "C" int kt_build_pyramid(kt_ctx* c, const kt_intr* intr, const uint16_t* 
     }
     a.cols = cols; a.rows = rows;
     const int c3 = cols / 8, r3 = rows / 8;
-    hipLaunchKernelGGL(kt_pyramid_kernel, dim3(kt_div_up(c3, 4), kt_div_up(r3, 4)), dim3(256), 0, c->stream, a);
+    // measured (profiles/r06_experiments.md, call 17): 640x480 -- 24 against 31 us alone with the small tile, the frame rate unchanged (in the frame the
+    // launch shares the GPU with the ray cast either way); 1280x960 -- the small tile is 24 us SLOWER (4800 workgroups re-loading halos).  So: by image size.
+    static const int forced = []() { const char* e = getenv("KT_PYR_S"); const int v = e ? atoi(e) : 0; return v == 2 || v == 4 ? v : 0; }();
+    const int tile = forced ? forced : ((long long)cols * rows <= 640LL * 480LL ? 2 : 4);
+    if (tile == 4) hipLaunchKernelGGL(kt_pyramid_kernel<4>, dim3(kt_div_up(c3, 4), kt_div_up(r3, 4)), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(kt_pyramid_kernel<2>, dim3(kt_div_up(c3, 2), kt_div_up(r3, 2)), dim3(256), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
