@@ -103,7 +103,8 @@ int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr
                         const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres, const kt_track_state* frame, int first, int n_iter);
 int kt_icp_levels_device(kt_ctx* c, kt_track_state* state, int n_levels, const float* const* vmaps_curr, const float* const* nmaps_curr, const kt_intr* intrs,
                          const float* const* vmaps_g_prev, const float* const* nmaps_g_prev, const int* cols, const int* rows, const int* n_iter,
-                         float dist_thres, float angle_thres, const kt_track_state* frame, int first);   // the levels of a frame in ONE launch
+                         float dist_thres, float angle_thres, const kt_track_state* frame, int first,
+                         const struct kt_setup_args* fused_setup = nullptr);   // the levels of a frame in ONE launch (+ its set-up in the epilogue: kt_setup.hpp)
 bool kt_ri_levels_selected();             // -ri: one launch per pyramid level (kt_joint_level_kernel); off by default
 bool kt_icp_levels_forced();               // ... asked for explicitly
 bool kt_icp_levels_selected(int device);   // kt_track.hip: KT_ICP_LEVELS / kt_debug_icp_levels, and the device can hold the whole grid

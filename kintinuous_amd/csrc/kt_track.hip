@@ -24,6 +24,7 @@
 //            none of them is the sentinel, hands them back as sentinels, folds blocks and the final tree and, in the
 //            device-resident path, solves the 6x6 system and updates the pose.  No ticket, no fence, no epoch.
 #include "kt_internal.hpp"
+#include "kt_setup.hpp"
 
 #include <string.h>
 #include <stdlib.h>
@@ -584,10 +585,55 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_kernel(const kt_icp_arg
 // Unlike two kernels on two streams (the overlapped chain that was measured and dropped), one kernel cannot starve itself: all of its
 // workgroups are dispatched before any of them waits for more than the first pose.
 // ------------------------------------------------------------------------------------------------
+// Wave 0 of a publishing workgroup waits for the pose of the iteration tagged `want`: 12 granules tagged with its sequence number, and -- lane 12 --
+// the abort granule.  Bounded (looks, and `patience` x twice the sweep's time bound: a sweep that succeeds at the edge of ITS bound must still find
+// its pollers waiting).  s_pose[0 .. 12) receive the pose, s_pose[12] != 0: it never came, or the launch was aborted at or after that iteration.
+__device__ __forceinline__ void kt_level_wait_pose(const kt_icp_args& a, unsigned int want, float* s_pose, unsigned int patience = 1u)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned int spin_limit = patience > 1u ? 0xffffffffu : min(*(volatile const unsigned int*)&kt_sweep_spin_limit, 1u << 20);
+    const unsigned long long tick_limit = 2ull * *(volatile const unsigned int*)&kt_wait_limit_ticks * patience;
+    unsigned long long tick0 = 0;   // (read from the 16th look on, as in the sweep)
+    unsigned long long g = 0;
+    unsigned int spins = 0;
+    bool ok, gone;
+    for (;;) {
+        if (lane < 13) g = __hip_atomic_load(&a.pose_gran[lane == 12 ? KT_POSE_ABORT : lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ahead = (int)((unsigned int)(g >> 32) - want);
+        ok = lane >= 12 || ahead == 0;
+        gone = lane == 12 && ahead >= 0 && ahead < a.n_iter;   // the launch was aborted at or after the iteration waited for
+        if (__all(ok) || __any(gone) || ++spins > spin_limit) break;
+        if ((spins & 15u) == 0) {
+            const unsigned long long now = kt_ticks();
+            if (spins == 16u) tick0 = now;
+            else if (now - tick0 > tick_limit) break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const bool got = __all(ok) && !__any(gone);
+    if (lane < 12) s_pose[lane] = __uint_as_float((unsigned int)g);
+    if (lane == 12) s_pose[12] = got ? 0.0f : 1.0f;
+}
+
+// The set-up's arguments are the launch's SECOND kernel argument, read from the kernel-argument segment where they are used: as ordinary by-value
+// uses their ~70 scalars were loaded at the kernel's entry and lived -- spilled -- across the whole iteration loop (15 VGPRs to scratch in the hot
+// path).  The address is laundered so that no load can be hoisted above this point.
+__device__ __forceinline__ const kt_setup_args* kt_level_setup_args()
+{
+    static_assert(alignof(kt_setup_args) <= 8 && alignof(kt_icp_args) <= 8, "kernel-argument layout");
+    // (the OFFSET is laundered, not the pointer: the address stays in the constant address space, so the fields arrive through the scalar cache like
+    // any kernel argument -- as flat loads of a laundered generic pointer they were vector reads of the host-visible argument buffer, microseconds each)
+    unsigned int off = (unsigned int)((sizeof(kt_icp_args) + 7ull) & ~7ull);
+    asm volatile("" : "+s"(off));
+    typedef __attribute__((address_space(4))) const char* kt_karg_ptr;
+    kt_karg_ptr k = (kt_karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    return (const kt_setup_args*)(k + off);
+}
+
 #ifdef KT_ICP_LEVEL_WAVES   // A/B builds: waves per SIMD the register budget is cut for (8: 64 VGPRs = two workgroups per compute unit)
-__global__ __launch_bounds__(KT_RED_THREADS, KT_ICP_LEVEL_WAVES) void kt_icp_level_kernel(const kt_icp_args a)
+__global__ __launch_bounds__(KT_RED_THREADS, KT_ICP_LEVEL_WAVES) void kt_icp_level_kernel(const kt_icp_args a, const kt_setup_args su)
 #else
-__global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_icp_args a)
+__global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_icp_args a, const kt_setup_args su)
 #endif
 {
     if (a.fault && blockIdx.x == 0) return;   // test hook (kt_debug_handoff_fault)
@@ -614,6 +660,7 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
     }
     if (threadIdx.x == 12) s_pose[12] = 0.0f;
     int it = 0;   // iteration of the launch, counted across the levels (sequence numbers, granule set parity)
+    bool aborted = false;
     for (int L = 0; L < a.n_levels; ++L) {
     fn.set_level(a.lv[L]);
     const int n = fn.a.cols * fn.a.rows;
@@ -626,38 +673,12 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
             fn.pf_i = -1;
             if (!sweeper) {
                 if (pf_i >= 0) { fn.fetch_curr(pf_i, fn.pf_v, fn.pf_n); fn.pf_i = pf_i; }   // in flight while the pose is awaited
-                if (threadIdx.x < 64) {
-                    // Wait for the pose of iteration it - 1: 12 granules tagged with its sequence number.  Bounded (looks, and twice the sweep's
-                    // time bound: a sweep that succeeds at the edge of ITS bound must still find its pollers waiting).  A workgroup whose wait
-                    // gives up, or that finds the launch aborted (the sweeping workgroup's own wait gave up: granule KT_POSE_ABORT carries
-                    // the iteration), LEAVES the kernel: it publishes nothing further, so the sweep of the next iteration cannot complete
-                    // and the time-out is reported by the one workgroup that writes the state -- an error cannot be lost between two
-                    // writers (advisor, round 5: a poller's `handoff_timeout = 1` could be overwritten by the sweeper's first-iteration store).
-                    const int lane = (int)threadIdx.x;
-                    const unsigned int want = a.seq0 + (unsigned int)it - 1u;
-                    const unsigned int spin_limit = min(*(volatile const unsigned int*)&kt_sweep_spin_limit, 1u << 20);
-                    const unsigned int tick_limit = 2u * *(volatile const unsigned int*)&kt_wait_limit_ticks;
-                    unsigned long long tick0 = 0;   // (read from the 16th look on, as in the sweep)
-                    unsigned long long g = 0;
-                    unsigned int spins = 0;
-                    bool ok, gone;
-                    for (;;) {
-                        if (lane < 13) g = __hip_atomic_load(&a.pose_gran[lane == 12 ? KT_POSE_ABORT : lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const int ahead = (int)((unsigned int)(g >> 32) - want);
-                        ok = lane >= 12 || ahead == 0;
-                        gone = lane == 12 && ahead >= 0 && ahead < a.n_iter;   // the launch was aborted at or after the iteration waited for
-                        if (__all(ok) || __any(gone) || ++spins > spin_limit) break;
-                        if ((spins & 15u) == 0) {
-                            const unsigned long long now = kt_ticks();
-                            if (spins == 16u) tick0 = now;
-                            else if (now - tick0 > tick_limit) break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    const bool got = __all(ok) && !__any(gone);
-                    if (lane < 12) s_pose[lane] = __uint_as_float((unsigned int)g);
-                    if (lane == 12) s_pose[12] = got ? 0.0f : 1.0f;
-                }
+                // Wait for the pose of iteration it - 1 (kt_level_wait_pose).  A workgroup whose wait gives up, or that finds the launch aborted (the
+                // sweeping workgroup's own wait gave up: granule KT_POSE_ABORT carries the iteration), LEAVES the kernel: it publishes nothing
+                // further, so the sweep of the next iteration cannot complete and the time-out is reported by the one workgroup that writes the
+                // state -- an error cannot be lost between two writers (advisor, round 5: a poller's `handoff_timeout = 1` could be overwritten
+                // by the sweeper's first-iteration store).
+                if (threadIdx.x < 64) kt_level_wait_pose(a, a.seq0 + (unsigned int)it - 1u, s_pose);
             }
             __syncthreads();   // (the solving workgroup: its tail wrote s_pose)
             if (s_pose[12] != 0.0f) return;   // workgroup-uniform: no pose (see above)
@@ -691,16 +712,49 @@ __global__ __launch_bounds__(KT_RED_THREADS) void kt_icp_level_kernel(const kt_i
             if (timed_out)
                 __hip_atomic_store(&a.pose_gran[KT_POSE_ABORT], (unsigned long long)(a.seq0 + (unsigned int)it) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (timed_out) return;
+        if (timed_out) { aborted = true; goto kt_level_done; }   // (workgroup-uniform)
         // hand-back performed before the pose leaves (see the hand-off comment at the top of the file): waves 1..15 wait for their stores and
         // arrive at the barrier now; wave 0 passes it inside its tail, right in front of the pose granules' stores
         if (threadIdx.x < 64) kt_solve_and_update_wave(a.state, sys, pose_d, pose_f, tail_work, a.pose_gran, a.seq0 + (unsigned int)it, s_pose);
         else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     }
     }
+    // ---- the frame's set-up in the launch's epilogue (round 6; csrc/kt_setup.hpp).  Until now the 255 publishing workgroups left after their last
+    // granules and a launch of its own (kt_frame_setup_kernel: a kernel boundary, 300-odd small workgroups, 8 us in the frame) turned the result
+    // into what the fusion kernels read.  Here every workgroup waits for the FINAL pose like for any other (the solving workgroup needs nothing
+    // from anybody at this point: the wait cannot be part of a cycle), takes its share of the carry and checkpoint blocks, and the solving
+    // workgroup's first two waves are block 0 -- pose, shift decision, plan check, z tables, the host's mirror.
+kt_level_done:
+    const kt_setup_args* sp = kt_level_setup_args();
+    if (aborted) {
+        // (only the sweeping workgroup gets here.  Fused set-up: the host waits for the mirror -- it is told that the frame has no pose; the
+        // fusion kernels are parked)
+        if (sp->fused && threadIdx.x < 128) {
+            float Rl[9], tl[3];
+            for (int k = 0; k < 9; ++k) Rl[k] = a.Rcurr.m[k];
+            for (int k = 0; k < 3; ++k) tl[k] = a.tprev[k];
+            kt_setup_block0(*sp, Rl, tl, 1, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
+        }
+        return;
+    }
+    if (sp->fused) {
+        if (!sweeper) {
+            if (threadIdx.x < 64) kt_level_wait_pose(a, a.seq0 + (unsigned int)a.n_iter - 1u, s_pose, 40u);
+        }
+        __syncthreads();
+        if (s_pose[12] != 0.0f) return;
+        float R[9], tv[3];
+        for (int k = 0; k < 9; ++k) R[k] = s_pose[k];
+        for (int k = 0; k < 3; ++k) tv[k] = s_pose[9 + k];
+        const int nside = sp->carry_groups + sp->walk_groups;
+        for (int vb = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 8); vb < nside; vb += KT_RED_GRID * 4)
+            kt_setup_side_block(*sp, vb + 1, (int)(threadIdx.x & 255), R, tv);
+        if (sweeper && threadIdx.x < 128) kt_setup_block0(*sp, R, tv, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
+    }
 }
 
-int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
+int kt_icp_launch(kt_ctx* c, kt_icp_args& a, const kt_setup_args* fused_setup = nullptr);
+int kt_icp_launch(kt_ctx* c, kt_icp_args& a, const kt_setup_args* fused_setup)
 {
     a.granules = (unsigned long long*)c->red_partials;
     a.fault = 0;
@@ -718,7 +772,10 @@ int kt_icp_launch(kt_ctx* c, kt_icp_args& a)
         // a cooperative launch is serialised against everything else on the device, profiles/r06_experiments.md.  Residency is checked once per
         // device instead (kt_icp_levels_fit), every wait inside the launch is bounded in time, and a launch that gives up costs the frame a
         // re-run, not an error: kt_tracker.hip complete_frame.)
-        hipLaunchKernelGGL(kt_icp_level_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
+        kt_setup_args su;
+        if (fused_setup) su = *fused_setup;
+        else { memset(&su, 0, sizeof(su)); su.fused = 0; }
+        hipLaunchKernelGGL(kt_icp_level_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a, su);
     } else {
         hipLaunchKernelGGL(kt_icp_kernel, dim3(KT_RED_GRID), dim3(KT_RED_THREADS), 0, c->stream, a);
     }
@@ -788,7 +845,7 @@ int kt_icp_step_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr,
 // pose, the state is initialised).
 int kt_icp_levels_device(kt_ctx* c, kt_track_state* state, int n_levels, const float* const* vmaps_curr, const float* const* nmaps_curr, const kt_intr* intrs,
                          const float* const* vmaps_g_prev, const float* const* nmaps_g_prev, const int* cols, const int* rows, const int* n_iter,
-                         float dist_thres, float angle_thres, const kt_track_state* frame, int first)
+                         float dist_thres, float angle_thres, const kt_track_state* frame, int first, const kt_setup_args* fused_setup)
 {
     KT_ARG(n_levels >= 1 && n_levels <= KT_LEVELS);
     kt_icp_args a;
@@ -813,13 +870,13 @@ int kt_icp_levels_device(kt_ctx* c, kt_track_state* state, int n_levels, const f
     if (c->odo_seq > 0xfffff000u) c->odo_seq = 0;   // (2^32 iterations are 16 hours at 3800 frames/s)
     a.seq0 = c->odo_seq + 1u;
     c->odo_seq += (unsigned int)total;
-    return kt_icp_launch(c, a);
+    return kt_icp_launch(c, a, fused_setup);
 }
 // ... one level (the form round 5 launched three times per frame)
 int kt_icp_level_device(kt_ctx* c, kt_track_state* state, const float* vmap_curr, const float* nmap_curr, const kt_intr* intr, const float* vmap_g_prev,
                         const float* nmap_g_prev, int cols, int rows, float dist_thres, float angle_thres, const kt_track_state* frame, int first, int n_iter)
 {
-    return kt_icp_levels_device(c, state, 1, &vmap_curr, &nmap_curr, intr, &vmap_g_prev, &nmap_g_prev, &cols, &rows, &n_iter, dist_thres, angle_thres, frame, first);
+    return kt_icp_levels_device(c, state, 1, &vmap_curr, &nmap_curr, intr, &vmap_g_prev, &nmap_g_prev, &cols, &rows, &n_iter, dist_thres, angle_thres, frame, first, nullptr);
 }
 
 // ICPOdometry::getIncrementalTransformation (ICPOdometry.cpp:68-186) as ONE entry point (SURVEY 8(b) export list): pose in / pose out,

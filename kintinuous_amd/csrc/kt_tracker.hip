@@ -6,6 +6,7 @@
 // Host-side state (pose lists, shift decision, slices, dense pose graph) restates
 // KintinuousTracker.cpp:71-182, 262-382, 575-667, 1003-1048, 1075-1085, 1156-1208.
 #include "kt_internal.hpp"
+#include "kt_setup.hpp"
 
 #include <limits.h>
 #include <stdlib.h>
@@ -53,13 +54,7 @@ struct FrameSet {
 // and the frame being read ahead.  A set is recycled behind odo_ev (wait_frame_consumed).
 #define KT_NSETS 3
 
-// the host's window on the frame in flight: written by kt_frame_setup_kernel straight into pinned, device-mapped host memory
-// (payload, system-scope fence, then seq), polled by complete_frame() -- no copy, no event, no driver call on the critical path
-struct PoseMirror {
-    float R[9], t[3];
-    int skip, handoff_timeout;
-    unsigned int seq;
-};
+typedef kt_pose_mirror PoseMirror;   // csrc/kt_setup.hpp: the host's window on the frame in flight
 struct Pending { const uint16_t* depth; const uint8_t* rgb; int set; const uint16_t* depth_host; const uint8_t* rgb_host; };
 #define KT_NSLOTS 4   // host-frame staging: frame in flight + two read-aheads + the one being filled
 #define KT_NODO 8     // ring of "odometry of frame f enqueued" events
@@ -177,6 +172,7 @@ struct kt_tracker {
     int icp_demote, icp_demote_len;
     long long odo_fallbacks;   // frames whose odometry was re-run (kt_tracker_odometry_fallbacks)
     int out_last_set;          // RGB-D "last" set of the frame in flight (for that re-run)
+    bool setup_fused;          // the frame's set-up ran in the epilogue of its odometry launch (kt_icp_level_kernel): no kt_frame_setup_kernel was enqueued
     // Side-stream gate (round 6).  The read-ahead of frame f + 1 is enqueued the moment the host has seen the pose of frame f - 1 -- exactly
     // when that frame's voxel kernel starts -- and the voxel kernel is a fixed grid of 8192 waves that fills EVERY wave slot of the chip and
     // deals its task list statically over them: one foreign wave on one SIMD keeps one of its workgroups out until another has finished, and
@@ -743,6 +739,8 @@ static int odometry_end(kt_tracker* t)
     return ev_end(t, ST_ODOMETRY);  // the pose stays on the device; complete_frame() reads it one frame later
 }
 
+static int fill_setup_args(kt_tracker* t, int mode, const float* R, const float* tv, kt_setup_args& a);
+
 // ICPOdometry::getIncrementalTransformation, ICPOdometry.cpp:68-186
 static int icp_odometry(kt_tracker* t, bool stepwise_only = false)
 {
@@ -759,6 +757,7 @@ static int icp_odometry(kt_tracker* t, bool stepwise_only = false)
     memcpy(init.tcurr, t->tlast, sizeof(init.tcurr));
     kt_mat33_inverse(init.Rprev, init.Rprev_inv);  // ICPOdometry.cpp:81
     bool first = true;
+    t->setup_fused = false;
     t->last_icp_levels = !stepwise_only && t->icp_levels && t->icp_demote == 0 && kt_live_trackers.load() == 1;
     if (!stepwise_only && t->icp_demote > 0) --t->icp_demote;
     if (t->last_icp_levels) {
@@ -774,7 +773,22 @@ static int icp_odometry(kt_tracker* t, bool stepwise_only = false)
             ++nl;
         }
         if (one_launch) {
-            if (nl) KT_TRY(kt_icp_levels_device(t->ctx, t->state_dev, nl, vc, nc, li, vg, ng, cs, rs, its, dist_thres, angle_thres, &init, 1));
+            // ... and, optionally, the frame's set-up in that launch's epilogue (kt_setup.hpp; KT_ICP_FUSED_SETUP=1).  OFF by default: same poses and
+            // volumes (tests/test_gpu_tracker.py), no faster where it was meant to be -- the serial odometry + set-up stage 0.153 ms either way: the
+            // epilogue's checkpoint walks and z tables take what the kernel boundary took -- and SLOWER in the pipelined frame, 3790 against 3936 frames/s:
+            // 256 full-CU workgroups that stay resident 5 us longer keep the waiting side-stream kernels out for as long, and those then run beside the
+            // voxel kernel (0.15 against 0.19 of the roofline in the region; profiles/r06_experiments.md, call 19).
+            // The epilogue's checkpoint blocks read the plan: the plan stream is joined in front of the launch instead of in front of the set-up.
+            const char* fe = getenv("KT_ICP_FUSED_SETUP");
+            const bool fuse_env = fe && atoi(fe) != 0;
+            kt_setup_args su;
+            t->setup_fused = fuse_env && !stepwise_only && nl > 0;
+            if (t->setup_fused) {
+                if (t->plan_sel >= 0 && hipEventQuery(t->plans[t->plan_sel].done) != hipSuccess) KT_HIP(hipStreamWaitEvent(t->ctx->stream, t->plans[t->plan_sel].done, 0));
+                KT_TRY(fill_setup_args(t, 0, nullptr, nullptr, su));
+                su.fused = 1;
+            }
+            if (nl) KT_TRY(kt_icp_levels_device(t->ctx, t->state_dev, nl, vc, nc, li, vg, ng, cs, rs, its, dist_thres, angle_thres, &init, 1, t->setup_fused ? &su : nullptr));
         } else {
             for (int k = 0; k < nl; ++k)
                 KT_TRY(kt_icp_level_device(t->ctx, t->state_dev, vc[k], nc[k], &li[k], vg[k], ng[k], cs[k], rs[k], dist_thres, angle_thres, &init, k == 0 ? 1 : 0, its[k]));
@@ -868,160 +882,32 @@ static int rgbd_odometry(kt_tracker* t, int set, int last_set, bool stepwise_onl
     return odometry_end(t);
 }
 
-__host__ __device__ static int voxel_trans(float translation, float voxel, int thresh)
-{
-    // KintinuousTracker.cpp:640-667
-    const int f = (int)floorf(translation / voxel);
-    if (f < 0) return (-thresh > f) ? -thresh : f;
-    return thresh < f ? thresh : f;
-}
-
 // ---- frame set-up on the device ---------------------------------------------------------------------------------------
-// Runs after the last odometry iteration.  Turns the device-resident Gauss-Newton result into what the fusion kernels need:
-// the final pose (RGB-D jump guard applied), its inverse, the z tables of tsdf23 (quirk A.17: a sequential float recurrence)
-// and the shift decision of KintinuousTracker.cpp:627-667 -- a frame that must shift the volume first is parked (skip = 1)
-// and redone by the host's shift path in complete_frame().  mode 1 = pose supplied by the host (that redo).
-struct kt_setup_args {
-    kt_track_state* st; kt_frame_params* fp;
-    PoseMirror* mirror; unsigned int seq;
-    float* vgz; float* zs; int N; float cell_z;
-    int mode, rgbd_guard;
-    float R[9], t[3];
-    float basis[3], voxel[3]; int thresh;
-    kt_pixrec* rec; const float* carry_cur; float* carry_next; int npix;
-    // planned frames (kt_volume.hip "planning ahead"): the prediction and margins the plan was made with -- the pose is checked against
-    // them -- and what the checkpoint workgroups need: the plan's wave-column ranges, where the checkpoints go, the walk's constants
-    int carry_groups;
-    const unsigned int* plan_wrange; float2* plan_walk0;
-    float plan_R[9], plan_t[3], plan_theta, plan_tau;
-    int wx, wy, wcx, wcy, XG, YG;        // storage wrap (x, y), wave-column shape and grid
-    float cell_x, cell_y, fx, fy;
-};
-
-// the pose the frame is fused with: the odometry's result, or the previous pose when the RGB-D jump guard discards the increment
-// (RGBDOdometry.cpp:383-387).  A pure function of the tracking state: every workgroup that needs it computes the same bits.
-__device__ __forceinline__ void kt_setup_final_pose(const kt_setup_args& a, float R[9], float tv[3])
-{
-    for (int k = 0; k < 9; ++k) R[k] = a.st->Rcurr[k];
-    for (int k = 0; k < 3; ++k) tv[k] = a.st->tcurr[k];
-    if (a.rgbd_guard) {
-        const float d0 = tv[0] - a.st->tprev[0], d1 = tv[1] - a.st->tprev[1], d2 = tv[2] - a.st->tprev[2];
-        if ((double)__builtin_sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
-            for (int k = 0; k < 9; ++k) R[k] = a.st->Rprev[k];
-            for (int k = 0; k < 3; ++k) tv[k] = a.st->tprev[k];
-        }
-    }
-}
-
-// Workgroup 0 (one wave) is the set-up proper; workgroups 1.. maintain the colour-weight carry of KT_REC_STALE_NZ pixels, 1024 pixels
-// each: a pixel without a valid normal takes the weight the carry holds (and passes it on), every other pixel deposits its own.
-// A pure function of (rec flags, rec.wrkc of valid pixels, carry_cur): running it twice for a frame (mode 0, then the mode 1 redo
-// after a shift) changes nothing.  mode 2 = carry only (first frame).
+// Runs after the last odometry iteration (csrc/kt_setup.hpp: what it does, shared with the epilogue of kt_icp_level_kernel).  A frame that
+// must shift the volume first is parked (skip = 1) and redone by the host's shift path in complete_frame().
+// Workgroup 0 (two waves) is the set-up proper; workgroups 1.. are the carry and checkpoint blocks.
 __global__ __launch_bounds__(256) void kt_frame_setup_kernel(const kt_setup_args a)
 {
-    if ((int)blockIdx.x > a.carry_groups) {
-        // Checkpoint workgroups of a planned frame, one wave per wave-column of the plan: the walk of v_x, v_y from z = 0 to the
-        // wave-column's first z for its 64 columns, with the pose the odometry has just produced (the plan itself was made for a
-        // prediction; the checkpoints are DEFINED by the frame's own pose, quirk A.17).
-        const int w = ((int)blockIdx.x - 1 - a.carry_groups) * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-        if (w >= a.XG * a.YG) return;
-        const unsigned int r = a.plan_wrange[w];
-        const int zc = (int)(r & 0xffffu);
-        if (zc >= (int)(r >> 16)) return;   // no task in this wave-column
-        const int sx = (w % a.XG) * a.wcx + lane % a.wcx, sy = (w / a.XG) * a.wcy + lane / a.wcx;
-        if (sx >= a.N || sy >= a.N) return;
-        float R[9], tv[3], Rinv[9];
-        kt_setup_final_pose(a, R, tv);
-        kt_mat33_inverse(R, Rinv);
-        a.plan_walk0[(size_t)sy * a.N + sx] = kt_tsdf_walk_checkpoint(Rinv, tv[0], tv[1], tv[2], a.cell_x, a.cell_y, a.cell_z, a.fx, a.fy, sx, sy, a.wx, a.wy, a.N, zc);
-        return;
-    }
     if (blockIdx.x > 0) {
-        const int base = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = base + k * 256;
-            if (p < a.npix) {
-                const bool stale = (a.rec[p].rgbf & KT_REC_STALE_NZ) != 0;
-                const float w = stale ? a.carry_cur[p] : a.rec[p].wrkc;
-                a.carry_next[p] = w;
-                if (stale) a.rec[p].wrkc = w;
-            }
-        }
+        float R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tv[3] = {0, 0, 0};
+        if ((int)blockIdx.x > a.carry_groups) kt_setup_final_pose(a, R, tv);   // (the checkpoint blocks of a planned frame: mode 0)
+        kt_setup_side_block(a, (int)blockIdx.x, (int)threadIdx.x, R, tv);
         return;
     }
-    // Two waves of workgroup 0 do the set-up proper, each from its own copy of the (cheap, deterministic) pose arithmetic: wave 0 writes
-    // what the device-side consumers read and walks the z tables; wave 1 tells the host -- its system-scope fence costs 2-3 us and would
-    // otherwise sit in front of the walk.
     if (threadIdx.x >= 128 || a.mode == 2) return;
-    const int role = (int)(threadIdx.x >> 6);
-    if (role == 1 && a.mode != 0) return;
     float R[9], tv[3];
-    int skip = 0;
-    if (a.mode == 0) {
-        kt_setup_final_pose(a, R, tv);
-        for (int k = 0; k < 3; ++k) {
-            const int vt = voxel_trans(tv[k] - a.basis[k], a.voxel[k], a.thresh);
-            if (vt >= a.thresh || vt <= -a.thresh) skip = 1;
-        }
-        if (a.st->handoff_timeout) skip = 1;   // no pose: nothing may be fused with it (complete_frame reports the error)
-        if (a.plan_wrange && !skip) {
-            // The plan is conservative for every pose within plan_theta (rotation) and plan_tau (translation) of the prediction:
-            // |R - R^|_F = 2 sqrt(2) sin(angle / 2) <= sqrt(2) angle.  Outside: skip = 2, the host fuses the frame through the in-stream
-            // pre-pass instead (the enqueued voxel kernel and ray cast do nothing).
-            float dr = 0.0f, dt = 0.0f;
-            for (int k = 0; k < 9; ++k) dr += (R[k] - a.plan_R[k]) * (R[k] - a.plan_R[k]);
-            for (int k = 0; k < 3; ++k) dt += (tv[k] - a.plan_t[k]) * (tv[k] - a.plan_t[k]);
-            if (!(__builtin_sqrtf(dr) <= 1.40f * a.plan_theta && __builtin_sqrtf(dt) <= 0.99f * a.plan_tau)) skip = 2;
-        }
-    } else {
+    if (a.mode == 0) kt_setup_final_pose(a, R, tv);
+    else {
         for (int k = 0; k < 9; ++k) R[k] = a.R[k];
         for (int k = 0; k < 3; ++k) tv[k] = a.t[k];
     }
-    const int lane = threadIdx.x & 63;
-    if (role == 1) {
-        if (lane == 0) {
-            // what the host needs: the final pose and whether the fusion kernels run -- straight into its memory
-            for (int k = 0; k < 9; ++k) a.mirror->R[k] = R[k];
-            for (int k = 0; k < 3; ++k) a.mirror->t[k] = tv[k];
-            a.mirror->skip = skip;
-            a.mirror->handoff_timeout = a.st->handoff_timeout;
-            __threadfence_system();
-            __hip_atomic_store(&a.mirror->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        return;
-    }
-    float Rinv[9];
-    kt_mat33_inverse(R, Rinv);
-    if (lane == 2) {
-        for (int k = 0; k < 9; ++k) { a.fp->R[k] = R[k]; a.fp->Rinv[k] = Rinv[k]; }
-        for (int k = 0; k < 3; ++k) a.fp->t[k] = tv[k];
-        a.fp->skip = skip;
-        // (the tracking state's pose is left as the odometry wrote it: the checkpoint workgroups of this launch read it, and the
-        // next frame starts from the host's copy of the final pose)
-        if (a.mode == 0) a.st->fusion_skipped = skip;
-    }
-    // lane 0 walks v_g_z, lane 1 walks z_scaled: the same dependent float adds as tsdf23's z loop (tsdf_volume.cu:560-640),
-    // 16 at a time in registers so the chain runs at add latency
-    if (lane < 2 && !skip) {
-        float acc = lane == 0 ? __builtin_fmaf(0 + 0.5f, a.cell_z, -tv[2]) : 0.0f;
-        float* tab = lane == 0 ? a.vgz : a.zs;
-        int z = 0;
-        for (; z + 16 <= a.N; z += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { v[u] = acc; acc += a.cell_z; }
-#pragma unroll
-            for (int u = 0; u < 16; u += 4) *(float4*)&tab[z + u] = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
-        }
-        for (; z < a.N; ++z) { tab[z] = acc; acc += a.cell_z; }
-    }
+    kt_setup_block0(a, R, tv, a.mode == 0 ? a.st->handoff_timeout : 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
 }
 
-static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv)
+// the arguments of the frame's set-up (kt_setup.hpp) as the tracker stands: for kt_frame_setup_kernel, or for the epilogue of the odometry launch
+static int fill_setup_args(kt_tracker* t, int mode, const float* R, const float* tv, kt_setup_args& a)
 {
     KT_TRY(kt_integrate_tables(t->ctx, t->cfg.cols, t->cfg.rows, t->N, &t->vgz_dev, &t->zs_dev));  // may have been regrown by another user of the context
-    kt_setup_args a;
     a.st = t->state_dev; a.fp = t->fp_dev; a.vgz = t->vgz_dev; a.zs = t->zs_dev; a.N = t->N;
     a.mirror = t->mirror; a.seq = t->frame_seq;
     a.cell_z = t->volume_size[2] / t->N;
@@ -1035,10 +921,12 @@ static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv
     a.carry_cur = t->wrkc_carry[t->carry_sel];
     a.carry_next = t->wrkc_carry[t->carry_sel ^ 1];
     a.npix = t->cfg.cols * t->cfg.rows;
-    const int carry_groups = t->cfg.disable_color_angle ? 0 : (a.npix + 1023) / 1024;   // without the angle weight wrkc is 2 everywhere
-    a.carry_groups = carry_groups;
+    a.carry_groups = t->cfg.disable_color_angle ? 0 : (a.npix + 1023) / 1024;   // without the angle weight wrkc is 2 everywhere
     a.plan_wrange = nullptr; a.plan_walk0 = nullptr;
-    int walk_groups = 0;
+    a.walk_groups = 0;
+    a.fused = 0;
+    a.wx = a.wy = a.wcx = a.wcy = a.XG = a.YG = 0; a.cell_x = a.cell_y = a.fx = a.fy = 0.0f; a.plan_theta = a.plan_tau = 0.0f;
+    memset(a.plan_R, 0, sizeof(a.plan_R)); memset(a.plan_t, 0, sizeof(a.plan_t));
     if (mode == 0 && t->plan_sel >= 0) {
         const kt_tracker::PlanSlot& pl = t->plans[t->plan_sel];
         a.plan_wrange = pl.plan.wrange; a.plan_walk0 = pl.plan.walk0;
@@ -1048,9 +936,16 @@ static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv
         a.wx = t->v_wrap_copy[0] % t->N; a.wy = t->v_wrap_copy[1] % t->N;
         a.cell_x = t->volume_size[0] / t->N; a.cell_y = t->volume_size[1] / t->N;
         a.fx = t->intr.fx; a.fy = t->intr.fy;
-        walk_groups = (a.XG * a.YG + 3) / 4;
+        a.walk_groups = (a.XG * a.YG + 3) / 4;
     }
-    hipLaunchKernelGGL(kt_frame_setup_kernel, dim3(1 + carry_groups + walk_groups), dim3(256), 0, t->ctx->stream, a);
+    return KT_OK;
+}
+
+static int launch_setup(kt_tracker* t, int mode, const float* R, const float* tv)
+{
+    kt_setup_args a;
+    KT_TRY(fill_setup_args(t, mode, R, tv, a));
+    hipLaunchKernelGGL(kt_frame_setup_kernel, dim3(1 + a.carry_groups + a.walk_groups), dim3(256), 0, t->ctx->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
@@ -1662,20 +1557,22 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
         planned_next = t->plans[(ordinal + 1) % 3].ordinal == ordinal + 1;
     }
     // [C] odometry :564-572 -- every Gauss-Newton iteration is enqueued; the pose stays on the device
+    v_wrap_copy_update(t);
+    if (++t->frame_seq == 0) t->frame_seq = 1;  // 0 is the mirror's initial value (before the odometry: its launch may carry the set-up, which posts it)
+    t->setup_fused = false;
     KT_TRY(ev_begin(t, ST_ODOMETRY));
     if (icp) KT_TRY(icp_odometry(t));
     else KT_TRY(rgbd_odometry(t, set, last_set));
     // device-side frame set-up (which also posts the pose into the host's PoseMirror), then the fusion kernels -- enqueued right
     // here, speculatively, on the assumption that the volume does not shift
     v_wrap_copy_update(t);
-    if (++t->frame_seq == 0) t->frame_seq = 1;  // 0 is the mirror's initial value
     // the plan has had the 19 launches above to finish; a join is enqueued only if it has not (a wait packet is a bubble)
     if (t->plan_sel >= 0 && hipEventQuery(t->plans[t->plan_sel].done) != hipSuccess) KT_HIP(hipStreamWaitEvent(c->stream, t->plans[t->plan_sel].done, 0));
     // gated side streams: what they were given for the NEXT frame (its read-ahead, then its plan) ends before this frame's voxel kernel starts
     // -- one wait packet in front of the set-up kernel (3-5 us; the gate is on where the frame is a millisecond)
     if (t->side_gate && planned_next) KT_HIP(hipStreamWaitEvent(c->stream, t->plans[(ordinal + 1) % 3].done, 0));
     else if (t->side_gate && !t->pending.empty()) KT_HIP(hipStreamWaitEvent(c->stream, t->sets[t->pending.front().set].ready, 0));
-    KT_TRY(launch_setup(t, 0, nullptr, nullptr));
+    if (!t->setup_fused) KT_TRY(launch_setup(t, 0, nullptr, nullptr));
     // -d: the cube may be repositioned once the pose is known, which changes the shift decision -- nothing to speculate on
     t->out_speculated = !t->cfg.dynamic_cube;
     if (t->out_speculated) KT_TRY(enqueue_fusion(t, set, depth_raw, colors, t->plan_sel >= 0 ? &t->plans[t->plan_sel].plan : nullptr));

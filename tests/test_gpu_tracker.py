@@ -729,6 +729,45 @@ def test_side_gate_is_transparent(ctx, small_scene):
         assert out[0][3] == out[k][3] and np.array_equal(out[0][4], out[k][4])
 
 
+def test_fused_setup_is_transparent(ctx):
+    """KT_ICP_FUSED_SETUP=1 (round 6, off by default: measured no faster): the frame's set-up -- final pose, shift decision, plan check, z tables,
+    colour-weight carry, the plan's walk checkpoints, the host's mirror -- runs in the epilogue of the odometry's single launch (csrc/kt_setup.hpp)
+    instead of in kt_frame_setup_kernel.  Same code, another home: poses, slices and volumes identical on a read-ahead sequence with planned frames
+    and volume shifts, and as many plans accepted."""
+    import os
+    from kintinuous_amd import abi, synth
+    cam = synth.Camera.small(320, 240)
+    scene = synth.Scene("wall")
+    traj = synth.crabwalk_trajectory(420)
+    frames = [synth.render(scene, cam, *traj[i]) for i in range(40)]
+    cfg = abi.TrackerConfig(cam.cols, cam.rows, 256, cam.fx, cam.fy, cam.cx, cam.cy, 7.0, 6, 2, 0, 0, 0, 0, 0, 0)   # a sparse view: the level form
+    dev = [(ctx.upload(d), ctx.upload(rgb)) for d, rgb in frames]
+    out = []
+    saved = os.environ.get("KT_ICP_FUSED_SETUP")
+    try:
+        for fused in ("0", "1"):
+            os.environ["KT_ICP_FUSED_SETUP"] = fused
+            trk = abi.Tracker(ctx, cfg)
+            for k in range(len(dev)):
+                if k + 1 < len(dev):
+                    trk.prefetch_frame(dev[k + 1][0], dev[k + 1][1])
+                trk.process_frame(dev[k][0], dev[k][1], 33333 * k)
+            poses = np.array([trk.dense_pose(i)[1].ravel() for i in range(trk.num_poses())])
+            slices = [b"".join(sorted(bytes(r) for r in trk.slice(i)[0].view(np.uint8).reshape(-1, 32))) for i in range(trk.num_slices())]
+            assert abi.lib().kt_tracker_debug_icp_levels(trk.h) == 1 and trk.odometry_fallbacks() == 0
+            out.append((poses, trk.volume().copy(), trk.color_volume().copy(), slices, trk.voxel_wrap().copy(), trk.plan_stats()))
+            trk.close()
+    finally:
+        if saved is None:
+            os.environ.pop("KT_ICP_FUSED_SETUP", None)
+        else:
+            os.environ["KT_ICP_FUSED_SETUP"] = saved
+    assert np.abs(out[0][4]).max() > 0 and out[0][5][0] > 10          # the volume shifted, frames were planned
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert out[0][3] == out[1][3] and np.array_equal(out[0][4], out[1][4]) and out[0][5] == out[1][5]
+
+
 def test_the_level_form_needs_to_be_alone(ctx, small_scene):
     """kt_icp_level_kernel's workgroups wait for each other inside a launch and need the whole machine: a second tracker fed next to it can keep
     its last workgroup out until the bounded waits give up.  So the form is chosen per frame: only while the tracker is the process's only live
