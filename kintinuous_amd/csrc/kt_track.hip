@@ -620,7 +620,7 @@ __device__ __forceinline__ void kt_level_wait_pose(const kt_icp_args& a, unsigne
 // path).  The address is laundered so that no load can be hoisted above this point.
 __device__ __forceinline__ const kt_setup_args* kt_level_setup_args()
 {
-    static_assert(alignof(kt_setup_args) <= 8 && alignof(kt_icp_args) <= 8, "kernel-argument layout");
+    static_assert(alignof(kt_setup_args) == 8 && alignof(kt_icp_args) == 8, "kernel-argument layout: the second argument starts at the first one's size rounded up to 8");
     // (the OFFSET is laundered, not the pointer: the address stays in the constant address space, so the fields arrive through the scalar cache like
     // any kernel argument -- as flat loads of a laundered generic pointer they were vector reads of the host-visible argument buffer, microseconds each)
     unsigned int off = (unsigned int)((sizeof(kt_icp_args) + 7ull) & ~7ull);
