@@ -754,69 +754,7 @@ extern "C" int kt_generate_depth(kt_ctx* c, const kt_mat33* R_inv, const float t
 #define KT_PYR_T2 13
 #define KT_PYR_T3 5
 
-struct kt_pyr_args {
-    const uint16_t* d0;
-    uint16_t* d[3];          // depth levels 1..3
-    float* vmap[4]; float* nmap[4];
-    int cols, rows;          // level 0
-    float fx_inv[4], fy_inv[4], cx[4], cy[4];
-};
-
-// pyrDownGaussKernel body (bilateral_pyrdown.cu:101-136) reading the source level from an LDS tile whose (0,0) is the
-// source pixel (tox, toy); returns -1 for destinations outside the destination image.
-__device__ __forceinline__ int kt_pyr_px(const int* __restrict__ tile, int tw, int tox, int toy, int scols, int srows, int x, int y)
-{
-    const int dcols = scols / 2, drows = srows / 2;
-    if (x < 0 || y < 0 || x >= dcols || y >= drows) return -1;
-    const int D = 5;
-    const float sigma_color = 30.0f;
-    const int center = tile[(2 * y - toy) * tw + (2 * x - tox)];
-    const int x_mi = max(0, 2 * x - D / 2) - 2 * x;
-    const int y_mi = max(0, 2 * y - D / 2) - 2 * y;
-    const int x_ma = min(scols, 2 * x - D / 2 + D) - 2 * x;
-    const int y_ma = min(srows, 2 * y - D / 2 + D) - 2 * y;
-    float sum = 0, wall = 0;
-    for (int yi = y_mi; yi < y_ma; ++yi)
-        for (int xi = x_mi; xi < x_ma; ++xi) {
-            const int val = tile[(2 * y + yi - toy) * tw + (2 * x + xi - tox)];
-            if ((float)abs(val - center) < 3 * sigma_color) {
-                const int axi = abs(xi), ayi = abs(yi);
-                const float wx = axi == 0 ? 0.375f : (axi == 1 ? 0.25f : 0.0625f);
-                const float wy = ayi == 0 ? 0.375f : (ayi == 1 ? 0.25f : 0.0625f);
-                sum = __builtin_fmaf((float)val * wx, wy, sum);
-                wall = __builtin_fmaf(wx, wy, wall);
-            }
-        }
-    return (int)(uint16_t)kt_f2i_rz(sum / wall);
-}
-
-// computeVmapKernel + computeNmapKernel (maps.cu:56-120) for pixel (u, v) of a level whose depth sits in an LDS tile
-__device__ __forceinline__ void kt_emit_maps(const int* __restrict__ tile, int tw, int tox, int toy, int cols, int rows, int u, int v,
-                                             float fx_inv, float fy_inv, float cx, float cy, float* __restrict__ vmap, float* __restrict__ nmap)
-{
-    if (u >= cols || v >= rows) return;
-    const float z00 = (float)tile[(v - toy) * tw + (u - tox)] / 1000.f;
-    f3 v00 = {kt_nan(), 0.f, 0.f};
-    if (z00 != 0) {
-        v00 = {z00 * ((float)u - cx) * fx_inv, z00 * ((float)v - cy) * fy_inv, z00};
-        vmap[v * cols + u] = v00.x;
-        vmap[(v + rows) * cols + u] = v00.y;
-        vmap[(v + 2 * rows) * cols + u] = v00.z;
-    } else
-        vmap[v * cols + u] = kt_nan();
-    if (u == cols - 1 || v == rows - 1) { nmap[v * cols + u] = kt_nan(); return; }
-    const float z01 = (float)tile[(v - toy) * tw + (u + 1 - tox)] / 1000.f;
-    const float z10 = (float)tile[(v + 1 - toy) * tw + (u - tox)] / 1000.f;
-    if (z00 != 0 && z01 != 0 && z10 != 0) {
-        const f3 v01 = {z01 * ((float)(u + 1) - cx) * fx_inv, z01 * ((float)v - cy) * fy_inv, z01};
-        const f3 v10 = {z10 * ((float)u - cx) * fx_inv, z10 * ((float)(v + 1) - cy) * fy_inv, z10};
-        const f3 r = kt_normalized(kt_cross(kt_sub(v01, v00), kt_sub(v10, v00)));
-        nmap[v * cols + u] = r.x;
-        nmap[(v + rows) * cols + u] = r.y;
-        nmap[(v + 2 * rows) * cols + u] = r.z;
-    } else
-        nmap[v * cols + u] = kt_nan();
-}
+#include "kt_pyramid.hpp"   // kt_pyr_args, kt_pyr_px, kt_emit_maps, kt_pyramid23_block
 
 // S = side of the level-3 tile a workgroup owns (4: rounds 1-5, 300 workgroups at 640x480; 2: round 6, 1200).  The kernel is latency bound --
 // a workgroup is a short chain of {load, barrier, filter, barrier ...} and 300 of them are 1.2 per compute unit -- so the smaller tile, which
@@ -884,30 +822,87 @@ __global__ __launch_bounds__(256) void kt_pyramid_kernel(const kt_pyr_args a)
     }
 }
 
+// Round 6, the two-launch form.  The one-launch kernel above recomputes halos through three levels: with the 2 x 2 tile a workgroup builds 21 x 21
+// level-1 pixels to own 8 x 8 of them (6.9 x), and the level-1 filter -- 25 taps a pixel -- is where its 24 us go.  Split where the halo is
+// cheapest: kt_pyramid01_kernel owns 16 x 16 pixels of level 0 (21 x 21 loaded) and builds their 8 x 8 (+1: the normal map's neighbour, 9 x 9 =
+// 1.27 x) level-1 pixels, maps of both levels; kt_pyramid23_kernel starts from the level-1 depth the first one wrote and is the old kernel without
+// its level 0.  Same kt_pyr_px / kt_emit_maps on the same inputs: every output bit as before.  A launch boundary (~2 us) against 14 us of recomputation.
+__global__ __launch_bounds__(256) void kt_pyramid01_kernel(const kt_pyr_args a)
+{
+    constexpr int T0 = 21, T1 = 9;
+    __shared__ int t0[T0 * T0], t1[T1 * T1];
+    const int tid = threadIdx.x;
+    const int o1x = blockIdx.x * 8, o1y = blockIdx.y * 8, o0x = 2 * o1x, o0y = 2 * o1y;
+    const int c0 = a.cols, r0 = a.rows, c1 = c0 / 2, r1 = r0 / 2;
+    const int t0x = o0x - 2, t0y = o0y - 2;
+    for (int i = tid; i < T0 * T0; i += 256) {
+        const int ly = i / T0, lx = i - ly * T0;
+        const int gx = t0x + lx, gy = t0y + ly;
+        t0[i] = (gx >= 0 && gy >= 0 && gx < c0 && gy < r0) ? (int)a.d0[gy * c0 + gx] : -1;
+    }
+    __syncthreads();
+    if (tid >= 256 - T1 * T1) {   // level 1 on the last two waves; the first two go straight to the level-0 maps
+        const int q = 255 - tid, ly = q / T1, lx = q - ly * T1;
+        t1[q] = kt_pyr_px(t0, T0, t0x, t0y, c0, r0, o1x + lx, o1y + ly);
+    }
+    kt_emit_maps(t0, T0, t0x, t0y, c0, r0, o0x + (tid & 15), o0y + (tid >> 4), a.fx_inv[0], a.fy_inv[0], a.cx[0], a.cy[0], a.vmap[0], a.nmap[0]);
+    __syncthreads();
+    if (tid < 64) {
+        const int ly = tid >> 3, lx = tid & 7;
+        const int u = o1x + lx, v = o1y + ly;
+        if (u < c1 && v < r1) a.d[0][v * c1 + u] = (uint16_t)t1[ly * T1 + lx];
+        kt_emit_maps(t1, T1, o1x, o1y, c1, r1, u, v, a.fx_inv[1], a.fy_inv[1], a.cx[1], a.cy[1], a.vmap[1], a.nmap[1]);
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void kt_pyramid23_kernel(const kt_pyr_args a) { kt_pyramid23_block<S>(a, blockIdx.x, blockIdx.y, threadIdx.x); }
+
+int kt_pyr_args_fill(kt_pyr_args* a, const kt_intr* intr, const uint16_t* depth0, int cols, int rows, uint16_t* const depths_out[3], float* const vmaps[4],
+                     float* const nmaps[4])
+{
+    KT_ARG(a && intr && depth0 && depths_out && vmaps && nmaps && cols > 0 && rows > 0);
+    KT_ARG((cols % 8) == 0 && (rows % 8) == 0);
+    a->d0 = depth0;
+    for (int l = 0; l < 3; ++l) { KT_ARG(depths_out[l]); a->d[l] = depths_out[l]; }
+    for (int l = 0; l < 4; ++l) {
+        KT_ARG(vmaps[l] && nmaps[l]);
+        a->vmap[l] = vmaps[l]; a->nmap[l] = nmaps[l];
+        const int div = 1 << l;  // Intr::operator() internal.h:255-259, then createVMap's 1.f / fx (maps.cu:135)
+        const float fx = intr->fx / div, fy = intr->fy / div;
+        a->fx_inv[l] = 1.f / fx; a->fy_inv[l] = 1.f / fy;
+        a->cx[l] = intr->cx / div; a->cy[l] = intr->cy / div;
+    }
+    a->cols = cols; a->rows = rows;
+    return KT_OK;
+}
+int kt_pyramid01_launch(kt_ctx* c, const kt_pyr_args* a)
+{
+    hipLaunchKernelGGL(kt_pyramid01_kernel, dim3(kt_div_up(a->cols / 2, 8), kt_div_up(a->rows / 2, 8)), dim3(256), 0, c->stream, *a);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
 extern "C" int kt_build_pyramid(kt_ctx* c, const kt_intr* intr, const uint16_t* depth0, int cols, int rows, uint16_t* const depths_out[3],
                                 float* const vmaps[4], float* const nmaps[4])
 {
-    KT_ARG(c && intr && depth0 && depths_out && vmaps && nmaps && cols > 0 && rows > 0);
-    KT_ARG((cols % 8) == 0 && (rows % 8) == 0);
+    KT_ARG(c);
     kt_pyr_args a;
-    a.d0 = depth0;
-    for (int l = 0; l < 3; ++l) { KT_ARG(depths_out[l]); a.d[l] = depths_out[l]; }
-    for (int l = 0; l < 4; ++l) {
-        KT_ARG(vmaps[l] && nmaps[l]);
-        a.vmap[l] = vmaps[l]; a.nmap[l] = nmaps[l];
-        const int div = 1 << l;  // Intr::operator() internal.h:255-259, then createVMap's 1.f / fx (maps.cu:135)
-        const float fx = intr->fx / div, fy = intr->fy / div;
-        a.fx_inv[l] = 1.f / fx; a.fy_inv[l] = 1.f / fy;
-        a.cx[l] = intr->cx / div; a.cy[l] = intr->cy / div;
-    }
-    a.cols = cols; a.rows = rows;
+    KT_TRY(kt_pyr_args_fill(&a, intr, depth0, cols, rows, depths_out, vmaps, nmaps));
     const int c3 = cols / 8, r3 = rows / 8;
-    // measured (profiles/r06_experiments.md, call 17): 640x480 -- 24 against 31 us alone with the small tile, the frame rate unchanged (in the frame the
-    // launch shares the GPU with the ray cast either way); 1280x960 -- the small tile is 24 us SLOWER (4800 workgroups re-loading halos).  So: by image size.
-    static const int forced = []() { const char* e = getenv("KT_PYR_S"); const int v = e ? atoi(e) : 0; return v == 2 || v == 4 ? v : 0; }();
-    const int tile = forced ? forced : ((long long)cols * rows <= 640LL * 480LL ? 2 : 4);
-    if (tile == 4) hipLaunchKernelGGL(kt_pyramid_kernel<4>, dim3(kt_div_up(c3, 4), kt_div_up(r3, 4)), dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL(kt_pyramid_kernel<2>, dim3(kt_div_up(c3, 2), kt_div_up(r3, 2)), dim3(256), 0, c->stream, a);
+    // KT_PYR_FORM: 1 = the one-launch kernel (rounds 1-6; KT_PYR_S=2|4 its tile), 2 = two launches (default), 3 = two launches, small tile in the second
+    static const int form = []() { const char* e = getenv("KT_PYR_FORM"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 3 ? v : 2; }();
+    if (form == 1) {
+        // measured (profiles/r06_experiments.md, call 17): 640x480 -- 24 against 31 us alone with the small tile; 1280x960 -- the small tile is 24 us SLOWER
+        static const int forced = []() { const char* e = getenv("KT_PYR_S"); const int v = e ? atoi(e) : 0; return v == 2 || v == 4 ? v : 0; }();
+        const int tile = forced ? forced : ((long long)cols * rows <= 640LL * 480LL ? 2 : 4);
+        if (tile == 4) hipLaunchKernelGGL(kt_pyramid_kernel<4>, dim3(kt_div_up(c3, 4), kt_div_up(r3, 4)), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL(kt_pyramid_kernel<2>, dim3(kt_div_up(c3, 2), kt_div_up(r3, 2)), dim3(256), 0, c->stream, a);
+    } else {
+        hipLaunchKernelGGL(kt_pyramid01_kernel, dim3(kt_div_up(cols / 2, 8), kt_div_up(rows / 2, 8)), dim3(256), 0, c->stream, a);
+        if (form == 2) hipLaunchKernelGGL(kt_pyramid23_kernel<4>, dim3(kt_div_up(c3, 4), kt_div_up(r3, 4)), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL(kt_pyramid23_kernel<2>, dim3(kt_div_up(c3, 2), kt_div_up(r3, 2)), dim3(256), 0, c->stream, a);
+    }
     KT_LAUNCH_CHECK();
     return KT_OK;
 }

@@ -86,6 +86,12 @@ size_t kt_integrate_rec_bytes(int cols, int rows);
 int kt_integrate_prepare(kt_ctx* c, const uint16_t* depth_raw, const uint8_t* colors, const float* nmap_curr, int cols, int rows,
                          const kt_intr* intr, int angle_color, float* depth_raw_scaled, void* rec, float* dpmax);
 size_t kt_integrate_dpmax_bytes(int cols, int rows);
+struct kt_pyr_args;
+int kt_pyr_args_fill(kt_pyr_args* a, const kt_intr* intr, const uint16_t* depth0, int cols, int rows, uint16_t* const depths_out[3], float* const vmaps[4],
+                     float* const nmaps[4]);
+int kt_pyramid01_launch(kt_ctx* c, const kt_pyr_args* a);
+int kt_frame_prepare(kt_ctx* c, const kt_intr* intr, const uint16_t* depth_filtered, uint16_t* const depths_out[3], float* const vmaps[4], float* const nmaps[4],
+                     const uint16_t* depth_raw, const uint8_t* colors, int cols, int rows, int angle_color, float* depth_raw_scaled, void* rec, float* dpmax);
 int kt_raycast_impl(kt_ctx* c, const kt_intr* intr, const kt_mat33* Rcurr, const float tcurr[3], float tranc_dist,
                     const float volume_size[3], const int16_t* volume, float* vmap, float* nmap, int cols, int rows,
                     const int voxel_wrap[3], uint8_t* vmap_curr_color, const uint8_t* color_volume, int N,

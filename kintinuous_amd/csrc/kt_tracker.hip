@@ -298,12 +298,18 @@ static int build_frame_set(kt_tracker* t, kt_ctx* cx, int q, const uint16_t* dep
     // the odometry provider objects of the ctor (KintinuousTracker.cpp:128-178): ground truth wins over the RGB-D flags
     const bool icp = !t->has_trajectory && !(t->cfg.use_rgbd || t->cfg.use_rgbd_icp);
     const bool rgbd = !t->has_trajectory && !icp;
+    static const bool fused_prepare = []() { const char* e = getenv("KT_PREPARE_FUSED"); return e ? atoi(e) != 0 : true; }();
     if (icp || t->cfg.use_rgbd_icp || !t->cfg.disable_color_angle) {
         KT_TRY(kt_bilateral_filter(cx, depth_raw, fs.depths[0], cols, rows));
         uint16_t* dl[3] = {fs.depths[1], fs.depths[2], fs.depths[3]};
-        KT_TRY(kt_build_pyramid(cx, &t->intr, fs.depths[0], cols, rows, dl, fs.vmaps, fs.nmaps));
-    }
-    KT_TRY(kt_integrate_prepare(cx, depth_raw, colors, fs.nmaps[0], cols, rows, &t->intr, !t->cfg.disable_color_angle, fs.scaled, fs.rec, fs.dpmax));
+        if (fused_prepare)   // pyramid + scaleDepth + pixel records in three launches (kt_volume.hip)
+            KT_TRY(kt_frame_prepare(cx, &t->intr, fs.depths[0], dl, fs.vmaps, fs.nmaps, depth_raw, colors, cols, rows, !t->cfg.disable_color_angle, fs.scaled, fs.rec, fs.dpmax));
+        else {
+            KT_TRY(kt_build_pyramid(cx, &t->intr, fs.depths[0], cols, rows, dl, fs.vmaps, fs.nmaps));
+            KT_TRY(kt_integrate_prepare(cx, depth_raw, colors, fs.nmaps[0], cols, rows, &t->intr, !t->cfg.disable_color_angle, fs.scaled, fs.rec, fs.dpmax));
+        }
+    } else
+        KT_TRY(kt_integrate_prepare(cx, depth_raw, colors, fs.nmaps[0], cols, rows, &t->intr, !t->cfg.disable_color_angle, fs.scaled, fs.rec, fs.dpmax));
     if (rgbd) {
         // RGBDOdometry::populateRGBDData (RGBDOdometry.cpp:140-158), the derivative images of the frame as "next" (:296-300) and its
         // point clouds as "last" (:186): all functions of the frame alone

@@ -8,6 +8,7 @@
 // index rotated by voxel_wrap (tsdf_volume.cu:612).  Kernels are laid out so that the 64 lanes of a
 // wave own 64 consecutive STORAGE x of one (y, z) line: 128 B of tsdf + 256 B of colour per access.
 #include "kt_internal.hpp"
+#include "kt_pyramid.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -50,19 +51,46 @@ struct kt_integrate_tables {  // incremental z walk of tsdf23 (quirk A.17), iden
 // One workgroup = a 32-pixel-wide strip of `passes` x 8 rows.  With tile_raw set (the tracker's read-ahead path) passes x 8 is the tile edge T of
 // the depth-range map (8, 16 or 32: kt_dpt_log2), so a workgroup covers 32 / T whole tiles and leaves their raw maxima of |scaled depth| --
 // round 4 spent a launch of its own on them (kt_tile_max_kernel: 5 us of launch latency on the read-ahead stream).
-__global__ __launch_bounds__(256) void kt_scale_depth_kernel(const uint16_t* __restrict__ depth, float* __restrict__ scaled,
-                                                             kt_pixrec* __restrict__ rec, const uint8_t* __restrict__ colors,
-                                                             const float* __restrict__ nmap, int cols, int rows, kt_intr intr,
-                                                             int angle_color, int passes, float* __restrict__ tile_raw, int tl2, int tcols)
+// Round 6: the 7 x 7 window of the angleColor test (scaleDepth, tsdf_volume.cu:490-527) is read from an LDS copy of the strip with its 3-pixel rim
+// instead of 49 global loads per pixel (13 us alone at 640x480 -> 4).  The window is clipped and upper-exclusive like the bilateral filter's (quirk
+// A.5): cx runs over [max(x - 3, 0), min(x + 4, cols - 1)), so the last column and the last row are never taps.  A cell outside
+// [0, cols - 1) x [0, rows - 1) holds a value no depth is within 200 of, and what is counted is the taps WITHIN 200 of the centre:
+//     count = (Dp == 0) ? n_window : n_window - n_near        (the reference counts  |Dp - tap| > 200 || Dp == 0  over the clipped window)
+// -- integers, the same number.  The centre is read from the image itself (a pixel of the last column is a centre, never a tap).
+#define KT_SD_RIM 3
+#define KT_SD_LW (32 + 2 * KT_SD_RIM)
+#define KT_SD_FAR 0x00ffffffu
+struct kt_sd_args {
+    const uint16_t* depth; float* scaled; kt_pixrec* rec; const uint8_t* colors; const float* nmap;
+    int cols, rows; kt_intr intr; int angle_color, passes;
+    float* tile_raw; int tl2, tcols;
+    int strips_x;   // workgroups per strip row (the fused launch numbers them linearly)
+};
+__device__ __forceinline__ void kt_scale_depth_block(const kt_sd_args& a, int block_x, int block_y, int tx_, int ty_)
 {
+    const uint16_t* __restrict__ depth = a.depth; float* __restrict__ scaled = a.scaled; kt_pixrec* __restrict__ rec = a.rec;
+    const uint8_t* __restrict__ colors = a.colors; const float* __restrict__ nmap = a.nmap;
+    const int cols = a.cols, rows = a.rows, angle_color = a.angle_color, passes = a.passes, tl2 = a.tl2, tcols = a.tcols;
+    const kt_intr intr = a.intr;
+    float* __restrict__ tile_raw = a.tile_raw;
+    __shared__ unsigned int s_win[(32 + 2 * KT_SD_RIM) * KT_SD_LW];   // up to 4 passes of 8 rows + the rim
     __shared__ unsigned int s_tile[4];   // raw maxima of the strip's tiles, as the bit patterns of non-negative floats (ordered like them)
-    if (tile_raw) {
-        if (threadIdx.y == 0 && threadIdx.x < 4) s_tile[threadIdx.x] = 0u;
-        __syncthreads();
+    const int tid = ty_ * 32 + tx_;
+    if (tile_raw && tid < 4) s_tile[tid] = 0u;
+    const int bx = block_x * 32, by = block_y * passes * 8;
+    if (angle_color) {
+        const int lh = passes * 8 + 2 * KT_SD_RIM;
+        for (int i = tid; i < lh * KT_SD_LW; i += 256) {
+            const int ty = i / KT_SD_LW, tx = i - ty * KT_SD_LW;
+            const int gx = bx + tx - KT_SD_RIM, gy = by + ty - KT_SD_RIM;
+            const bool tap = gx >= 0 && gy >= 0 && gx < cols - 1 && gy < rows - 1;
+            s_win[i] = tap ? (unsigned int)depth[gy * cols + gx] : KT_SD_FAR;
+        }
     }
-    const int x = threadIdx.x + blockIdx.x * blockDim.x;
+    __syncthreads();
+    const int x = tx_ + bx;
     for (int pass = 0; pass < passes; ++pass) {
-        const int y = threadIdx.y + (blockIdx.y * passes + pass) * blockDim.y;
+        const int y = ty_ + by + pass * 8;
         float out = 0.0f;
         if (x < cols && y < rows) {
             int Dp = depth[y * cols + x];
@@ -71,12 +99,19 @@ __global__ __launch_bounds__(256) void kt_scale_depth_kernel(const uint16_t* __r
             float lambda = __builtin_sqrtf(__builtin_fmaf(xl, xl, yl * yl) + 1);
             if (angle_color) {
                 const int ky = 7, kx = 7;
-                int ty = min(y - ky / 2 + ky, rows - 1);
-                int tx = min(x - kx / 2 + kx, cols - 1);
-                int count = 0;
-                for (int cy = max(y - ky / 2, 0); cy < ty; ++cy)
-                    for (int cx = max(x - kx / 2, 0); cx < tx; ++cx)
-                        if (abs(Dp - (int)depth[cy * cols + cx]) > 200 || Dp == 0) count++;
+                const int ty = min(y - ky / 2 + ky, rows - 1), tx = min(x - kx / 2 + kx, cols - 1);
+                const int n_window = max(ty - max(y - ky / 2, 0), 0) * max(tx - max(x - kx / 2, 0), 0);
+                const unsigned int* w = &s_win[(ty_ + pass * 8) * KT_SD_LW + tx_];   // the window's top-left cell
+                int n_near = 0;
+#pragma unroll
+                for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 7; ++dx) {
+                        unsigned int d;
+                        asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"((unsigned int)Dp), "v"(w[dy * KT_SD_LW + dx]));
+                        n_near += d <= 200u ? 1 : 0;
+                    }
+                const int count = Dp == 0 ? n_window : n_window - n_near;
                 out = (count > 5) ? (float)(-Dp) * lambda / 1000.f : (float)Dp * lambda / 1000.f;
             } else
                 out = (float)Dp * lambda / 1000.f;
@@ -101,14 +136,26 @@ __global__ __launch_bounds__(256) void kt_scale_depth_kernel(const uint16_t* __r
             // a wave is two rows of 32 pixels; a tile takes 2^tl2 consecutive lanes of each: fold them, then one LDS atomic per tile and row
             float m = fabsf(out);   // (0 outside the image)
             for (int off = 1; off < (1 << tl2) && off < 32; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-            if ((threadIdx.x & ((1 << tl2) - 1)) == 0) atomicMax(&s_tile[threadIdx.x >> tl2], __float_as_uint(m));
+            if ((tx_ & ((1 << tl2) - 1)) == 0) atomicMax(&s_tile[tx_ >> tl2], __float_as_uint(m));
         }
     }
     if (tile_raw) {
         __syncthreads();
-        const int g = threadIdx.x, tx = (blockIdx.x * 32 >> tl2) + g;
-        if (threadIdx.y == 0 && g < (32 >> tl2) && tx < tcols) tile_raw[blockIdx.y * tcols + tx] = __uint_as_float(s_tile[g]);
+        const int g = tx_, tx = (block_x * 32 >> tl2) + g;
+        if (ty_ == 0 && g < (32 >> tl2) && tx < tcols) tile_raw[block_y * tcols + tx] = __uint_as_float(s_tile[g]);
     }
+}
+
+__global__ __launch_bounds__(256) void kt_scale_depth_kernel(const kt_sd_args a) { kt_scale_depth_block(a, blockIdx.x, blockIdx.y, threadIdx.x, threadIdx.y); }
+
+// The tracker's frame preparation in one launch behind kt_pyramid01_kernel: pyramid levels 2 and 3 (from the level-1 depth) and scaleDepth + pixel
+// records (from the level-0 normal map) depend on that launch only, not on each other -- one grid, the pyramid's 4 x 4 level-3 tiles first (the
+// longer chain of barriers), then the strips: a launch boundary less on the read-ahead stream and the two latency chains side by side.
+__global__ __launch_bounds__(256) void kt_prepare_fused_kernel(const kt_pyr_args pa, const kt_sd_args sa, int n23x, int n23)
+{
+    if ((int)blockIdx.x < n23) { kt_pyramid23_block<4>(pa, blockIdx.x % n23x, blockIdx.x / n23x, threadIdx.x); return; }
+    const int b = blockIdx.x - n23;
+    kt_scale_depth_block(sa, b % sa.strips_x, b / sa.strips_x, threadIdx.x & 31, threadIdx.x >> 5);
 }
 
 // Coarse map of the largest |scaled depth| per T x T pixel tile: lets the interval pre-pass bound, per voxel column, how far
@@ -182,17 +229,30 @@ __global__ __launch_bounds__(1024) void kt_tile_finish_kernel(float* __restrict_
         dpmax[KT_DPT_MAX_TILES + KT_DPT_COARSE_TILES] = all;
     }
 }
+static kt_sd_args kt_sd_args_fill(const uint16_t* depth_raw, float* depth_raw_scaled, kt_pixrec* rec, const uint8_t* colors, const float* nmap_curr, int cols, int rows,
+                                  const kt_intr& intr, int angle_color, float* dpmax)
+{
+    kt_sd_args a;
+    a.depth = depth_raw; a.scaled = depth_raw_scaled; a.rec = rec; a.colors = colors; a.nmap = nmap_curr;
+    a.cols = cols; a.rows = rows; a.intr = intr; a.angle_color = angle_color;
+    a.tl2 = (dpmax && rec) ? kt_dpt_log2(cols, rows) : 0;
+    a.passes = a.tl2 ? (1 << a.tl2) / 8 : 1;
+    a.tcols = a.tl2 ? kt_div_up(cols, 1 << a.tl2) : 0;
+    a.tile_raw = a.tl2 ? dpmax + KT_DPT_RAW : nullptr;
+    a.strips_x = kt_div_up(cols, 32);
+    return a;
+}
+static void kt_launch_tile_finish(kt_ctx* c, const kt_sd_args& a, float* dpmax)
+{
+    if (a.tl2) hipLaunchKernelGGL(kt_tile_finish_kernel, dim3(1), dim3(1024), 0, c->stream, dpmax, a.tl2, a.tcols, kt_div_up(a.rows, 1 << a.tl2), kt_div_up(a.cols, 32), kt_div_up(a.rows, 32));
+}
 // scaleDepth + the pixel records and, when a depth-range map is wanted, its raw tile maxima from the same launch and the finishing launch
 static void kt_launch_scale_depth(kt_ctx* c, const uint16_t* depth_raw, float* depth_raw_scaled, kt_pixrec* rec, const uint8_t* colors, const float* nmap_curr,
                                   int cols, int rows, const kt_intr& intr, int angle_color, float* dpmax)
 {
-    const int tl2 = (dpmax && rec) ? kt_dpt_log2(cols, rows) : 0;
-    const int passes = tl2 ? (1 << tl2) / 8 : 1;
-    const int tcols = tl2 ? kt_div_up(cols, 1 << tl2) : 0, trows = tl2 ? kt_div_up(rows, 1 << tl2) : 0;
-    dim3 bs(32, 8), gs(kt_div_up(cols, 32), kt_div_up(rows, 8 * passes));
-    hipLaunchKernelGGL(kt_scale_depth_kernel, gs, bs, 0, c->stream, depth_raw, depth_raw_scaled, rec, colors, nmap_curr, cols, rows, intr, angle_color, passes,
-                       tl2 ? dpmax + KT_DPT_RAW : nullptr, tl2, tcols);
-    if (tl2) hipLaunchKernelGGL(kt_tile_finish_kernel, dim3(1), dim3(1024), 0, c->stream, dpmax, tl2, tcols, trows, kt_div_up(cols, 32), kt_div_up(rows, 32));
+    const kt_sd_args a = kt_sd_args_fill(depth_raw, depth_raw_scaled, rec, colors, nmap_curr, cols, rows, intr, angle_color, dpmax);
+    hipLaunchKernelGGL(kt_scale_depth_kernel, dim3(a.strips_x, kt_div_up(rows, 8 * a.passes)), dim3(32, 8), 0, c->stream, a);
+    kt_launch_tile_finish(c, a, dpmax);
 }
 
 struct kt_tsdf23_args {
@@ -1854,6 +1914,25 @@ int kt_integrate_prepare(kt_ctx* c, const uint16_t* depth_raw, const uint8_t* co
                          const kt_intr* intr, int angle_color, float* depth_raw_scaled, void* rec, float* dpmax)
 {
     kt_launch_scale_depth(c, depth_raw, depth_raw_scaled, (kt_pixrec*)rec, colors, nmap_curr, cols, rows, *intr, angle_color, dpmax);
+    KT_LAUNCH_CHECK();
+    return KT_OK;
+}
+
+// [A] of processFrame behind the bilateral filter, as the tracker enqueues it: pyramid levels 0 / 1 (kt_pyramid01_kernel), then ONE launch for
+// levels 2 / 3 and scaleDepth + pixel records (kt_prepare_fused_kernel), then the tile map's finishing workgroup.  Same outputs as
+// kt_build_pyramid + kt_integrate_prepare, bit for bit (the same block functions).
+int kt_frame_prepare(kt_ctx* c, const kt_intr* intr, const uint16_t* depth_filtered, uint16_t* const depths_out[3], float* const vmaps[4], float* const nmaps[4],
+                     const uint16_t* depth_raw, const uint8_t* colors, int cols, int rows, int angle_color, float* depth_raw_scaled, void* rec, float* dpmax)
+{
+    KT_ARG(c && intr && depth_filtered && depths_out && vmaps && nmaps && depth_raw && colors && depth_raw_scaled && rec);
+    kt_pyr_args pa;
+    KT_TRY(kt_pyr_args_fill(&pa, intr, depth_filtered, cols, rows, depths_out, vmaps, nmaps));
+    KT_TRY(kt_pyramid01_launch(c, &pa));
+    const kt_sd_args sa = kt_sd_args_fill(depth_raw, depth_raw_scaled, (kt_pixrec*)rec, colors, nmaps[0], cols, rows, *intr, angle_color, dpmax);
+    const int n23x = kt_div_up(cols / 8, 4), n23 = n23x * kt_div_up(rows / 8, 4);
+    const int nsd = sa.strips_x * kt_div_up(rows, 8 * sa.passes);
+    hipLaunchKernelGGL(kt_prepare_fused_kernel, dim3(n23 + nsd), dim3(256), 0, c->stream, pa, sa, n23x, n23);
+    kt_launch_tile_finish(c, sa, dpmax);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }
