@@ -1272,7 +1272,7 @@ static void plan_rand_unit(kt_tracker* t, float v[3])
     }
 }
 
-static int plan_ahead(kt_tracker* t, const Pending& next, long long ordinal)
+static int plan_ahead(kt_tracker* t, const Pending& next, long long ordinal, int increments)
 {
     const int set = next.set;
     kt_tracker::PlanSlot& pl = t->plans[ordinal % 3];
@@ -1282,12 +1282,13 @@ static int plan_ahead(kt_tracker* t, const Pending& next, long long ordinal)
         for (int j = 0; j < 3; ++j) D[i * 3 + j] = t->hist_R[0][0 * 3 + i] * t->hist_R[1][0 * 3 + j] + t->hist_R[0][1 * 3 + i] * t->hist_R[1][1 * 3 + j] + t->hist_R[0][2 * 3 + i] * t->hist_R[1][2 * 3 + j];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) D2[i * 3 + j] = D[i * 3 + 0] * D[0 * 3 + j] + D[i * 3 + 1] * D[1 * 3 + j] + D[i * 3 + 2] * D[2 * 3 + j];
-    for (int i = 0; i < 3; ++i)       // R^ = R(f-1) D^2
+    if (increments == 1) memcpy(D2, D, sizeof(D2));
+    for (int i = 0; i < 3; ++i)       // R^ = R(f-1) D^increments
         for (int j = 0; j < 3; ++j) Rp[i * 3 + j] = t->Rlast[i * 3 + 0] * D2[0 * 3 + j] + t->Rlast[i * 3 + 1] * D2[1 * 3 + j] + t->Rlast[i * 3 + 2] * D2[2 * 3 + j];
     float step = 0.0f, turn = 0.0f;
     for (int k = 0; k < 3; ++k) {
         const float d = t->hist_gc[1][k] - t->hist_gc[0][k];
-        tp[k] = t->tlast[k] + 2.0f * d;
+        tp[k] = t->tlast[k] + (float)increments * d;
         step += d * d;
     }
     for (int k = 0; k < 9; ++k) turn += (D[k] - ((k % 4 == 0) ? 1.0f : 0.0f)) * (D[k] - ((k % 4 == 0) ? 1.0f : 0.0f));
@@ -1544,23 +1545,35 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     // shifted since (plan_ahead)
     t->plan_sel = -1;
     v_wrap_copy_update(t);
-    {
+    bool planned_next = false;
+    // KT_PLAN_CURRENT (default 1, round 6): the plan of THIS frame, made right here from the last pose the host has seen plus ONE increment.  It runs
+    // on the plan stream beside the previous frame's fusion kernels like the next frame's did, has this frame's whole odometry launch to finish, and
+    // predicts one step instead of two (a constant-velocity error grows with the square of the horizon: tighter margins, fewer misses, and a plan
+    // made AFTER a shift instead of one the shift invalidates).  0: rounds 4-5, the read-ahead frame's plan two increments out.
+    static const bool plan_current = []() { const char* e = getenv("KT_PLAN_CURRENT"); return e ? atoi(e) != 0 : true; }();
+    if (plan_current) {
+        if (t->plan_enabled && read_ahead && t->hist_n >= 2 && !t->cfg.dynamic_cube) {
+            // on a gated (dense) view the plan stream is held like the read-ahead: not beside the voxel kernel that is running now
+            if (t->side_gate && t->gate_armed) KT_HIP(hipStreamWaitEvent(t->plan_stream, t->gate_ev, 0));
+            KT_TRY(plan_ahead(t, Pending{depth_raw, colors, set, nullptr, nullptr}, ordinal, 1));
+            if (t->plans[ordinal % 3].ordinal == ordinal) t->plan_sel = (int)(ordinal % 3);
+        }
+    } else {
         const kt_tracker::PlanSlot& pl = t->plans[ordinal % 3];
         // the plan of THIS frame: made for this ordinal, from this frame's set and buffers (a caller may process another read-ahead
         // than the one that was planned for), for the storage wrap that still holds
         if (read_ahead && pl.ordinal == ordinal && pl.set == set && pl.depth == depth_raw && pl.rgb == colors &&
             memcmp(pl.wrap, t->v_wrap_copy, sizeof(t->v_wrap_copy)) == 0)
             t->plan_sel = (int)(ordinal % 3);
-    }
-    // The frame that has been read ahead comes next: plan its voxel pass now, for the pose predicted two increments past the last one
-    // the host has seen (-d repositions the cube once the pose is known: nothing to plan for).  NOW = before this frame's odometry is
-    // enqueued: the GPU is still in the previous frame's voxel kernel and ray cast, which do not mind a few small workgroups next to
-    // them; enqueued after the odometry (the first cut) the pre-pass ran next to the iterations, each of whose 256 workgroups needs a
-    // whole CU, and cost them 10 us per frame.
-    bool planned_next = false;
-    if (t->plan_enabled && !t->pending.empty() && t->hist_n >= 2 && !t->cfg.dynamic_cube) {
-        KT_TRY(plan_ahead(t, t->pending.front(), ordinal + 1));
-        planned_next = t->plans[(ordinal + 1) % 3].ordinal == ordinal + 1;
+        // The frame that has been read ahead comes next: plan its voxel pass now, for the pose predicted two increments past the last one
+        // the host has seen (-d repositions the cube once the pose is known: nothing to plan for).  NOW = before this frame's odometry is
+        // enqueued: the GPU is still in the previous frame's voxel kernel and ray cast, which do not mind a few small workgroups next to
+        // them; enqueued after the odometry (the first cut) the pre-pass ran next to the iterations, each of whose 256 workgroups needs a
+        // whole CU, and cost them 10 us per frame.
+        if (t->plan_enabled && !t->pending.empty() && t->hist_n >= 2 && !t->cfg.dynamic_cube) {
+            KT_TRY(plan_ahead(t, t->pending.front(), ordinal + 1, 2));
+            planned_next = t->plans[(ordinal + 1) % 3].ordinal == ordinal + 1;
+        }
     }
     // [C] odometry :564-572 -- every Gauss-Newton iteration is enqueued; the pose stays on the device
     v_wrap_copy_update(t);
