@@ -741,92 +741,22 @@ extern "C" int kt_generate_depth(kt_ctx* c, const kt_mat33* R_inv, const float t
 }
 
 // ================================================================================================
-// Fused pyramid build: pyrDown x3 + createVMap x4 + createNMap x4 in ONE launch
+// Pyramid build: pyrDown x3 + createVMap x4 + createNMap x4 in TWO launches
 // (KintinuousTracker.cpp:469-478 issues 11 kernels for this; each is launch-latency bound at VGA).
-// One workgroup owns a 4x4 tile of level 3 (= 8x8 / 16x16 / 32x32 at levels 2 / 1 / 0).  The level-0 depth it needs,
-// including the 5x5 pyrDown halos of all three levels and the +1 neighbours of the normal map (61 x 61 pixels), is
-// staged in LDS; levels 1..3 are built tile-locally in LDS with exactly pyrDownGaussKernel's arithmetic, then vertex and
-// normal maps of all four levels are emitted from LDS.  Halo pixels are recomputed by neighbouring workgroups with
-// identical inputs, so every output is bit-identical to running the separate kernels.
+// Depth tiles with their 5x5 pyrDown halos and the +1 neighbours of the normal map are staged in LDS; the next level is built tile-locally
+// in LDS with exactly pyrDownGaussKernel's arithmetic, then vertex and normal maps are emitted from LDS.  Halo pixels are recomputed by
+// neighbouring workgroups with identical inputs, so every output is bit-identical to running the separate kernels.
+// Rounds 1-5 did all four levels in ONE launch (a workgroup owned a 4 x 4 tile of level 3 and loaded 61 x 61 pixels of level 0): three levels of
+// halo made it rebuild 3.3 x (6.9 x with the 2 x 2 tile that was faster at 640x480) of the level-1 pixels, and the level-1 filter -- 25 taps a
+// pixel -- is where its 24-31 us went.  Split where the halo is cheapest (scripts/pyramid_forms.py: 14.7 against 17.2 us at 640x480, 26.2
+// against 28.2 at 1280x960, after the tap loop was unrolled in both; 31 -> 24 -> 17 -> 15 over the round):
+//   kt_pyramid01_kernel   owns 16 x 16 pixels of level 0 (21 x 21 loaded), builds their 8 x 8 (+1: the normal map's neighbour: 9 x 9 = 1.27 x)
+//                         level-1 pixels, writes the level-1 depth and the maps of both levels;
+//   kt_pyramid23_kernel   starts from the level-1 depth: a 4 x 4 tile of level 3 per workgroup, levels 2 and 3 from a 29 x 29 level-1 tile.
+// The tracker puts the second one into the same launch as scaleDepth (kt_prepare_fused_kernel, kt_volume.hip).
 // ================================================================================================
-#define KT_PYR_T0 61
-#define KT_PYR_T1 29
-#define KT_PYR_T2 13
-#define KT_PYR_T3 5
-
 #include "kt_pyramid.hpp"   // kt_pyr_args, kt_pyr_px, kt_emit_maps, kt_pyramid23_block
 
-// S = side of the level-3 tile a workgroup owns (4: rounds 1-5, 300 workgroups at 640x480; 2: round 6, 1200).  The kernel is latency bound --
-// a workgroup is a short chain of {load, barrier, filter, barrier ...} and 300 of them are 1.2 per compute unit -- so the smaller tile, which
-// recomputes more halo (2.2 x the level-0 loads), is the faster launch.  Tile widths: level 3: S + 1 (the +1 neighbour of the normal map), level 2:
-// 2 S + 5, level 1: 4 S + 13, level 0: 8 S + 29 (5 / 13 / 29 / 61 for S = 4).  kt_build_pyramid picks S by image size; KT_PYR_S=2|4 forces one.
-template <int S>
-__global__ __launch_bounds__(256) void kt_pyramid_kernel(const kt_pyr_args a)
-{
-    constexpr int T3 = S + 1, T2 = 2 * S + 5, T1 = 4 * S + 13, T0 = 8 * S + 29;
-    static_assert(S == 2 || (T0 == KT_PYR_T0 && T1 == KT_PYR_T1 && T2 == KT_PYR_T2 && T3 == KT_PYR_T3), "tile widths");
-    __shared__ int t0[T0 * T0], t1[T1 * T1], t2[T2 * T2], t3[T3 * T3];
-    const int tid = threadIdx.x;
-    const int o3x = blockIdx.x * S, o3y = blockIdx.y * S;
-    const int o2x = 2 * o3x, o2y = 2 * o3y, o1x = 4 * o3x, o1y = 4 * o3y, o0x = 8 * o3x, o0y = 8 * o3y;
-    const int c0 = a.cols, r0 = a.rows, c1 = c0 / 2, r1 = r0 / 2, c2 = c1 / 2, r2 = r1 / 2, c3 = c2 / 2, r3 = r2 / 2;
-    // tile origins in their own level's pixel coordinates
-    const int t0x = o0x - 14, t0y = o0y - 14, t1x = o1x - 6, t1y = o1y - 6, t2x = o2x - 2, t2y = o2y - 2, t3x = o3x, t3y = o3y;
-    for (int i = tid; i < T0 * T0; i += 256) {
-        const int ly = i / T0, lx = i - ly * T0;
-        const int gx = t0x + lx, gy = t0y + ly;
-        t0[i] = (gx >= 0 && gy >= 0 && gx < c0 && gy < r0) ? (int)a.d0[gy * c0 + gx] : -1;
-    }
-    __syncthreads();
-    for (int i = tid; i < T1 * T1; i += 256) {
-        const int ly = i / T1, lx = i - ly * T1;
-        t1[i] = kt_pyr_px(t0, T0, t0x, t0y, c0, r0, t1x + lx, t1y + ly);
-    }
-    __syncthreads();
-    for (int i = tid; i < T2 * T2; i += 256) {
-        const int ly = i / T2, lx = i - ly * T2;
-        t2[i] = kt_pyr_px(t1, T1, t1x, t1y, c1, r1, t2x + lx, t2y + ly);
-    }
-    __syncthreads();
-    if (tid < T3 * T3) {
-        const int ly = tid / T3, lx = tid - ly * T3;
-        t3[tid] = kt_pyr_px(t2, T2, t2x, t2y, c2, r2, t3x + lx, t3y + ly);
-    }
-    __syncthreads();
-    // ---- outputs: depth levels 1..3 of the owned tiles, vertex + normal maps of all levels --------
-    {   // level 0: 8 S x 8 S pixels
-        for (int i = tid; i < 64 * S * S; i += 256) {
-            const int ly = i / (8 * S), lx = i - ly * (8 * S);
-            kt_emit_maps(t0, T0, t0x, t0y, c0, r0, o0x + lx, o0y + ly, a.fx_inv[0], a.fy_inv[0], a.cx[0], a.cy[0], a.vmap[0], a.nmap[0]);
-        }
-    }
-    if (tid < 16 * S * S) {   // level 1: 4 S x 4 S
-        const int ly = tid / (4 * S), lx = tid - ly * (4 * S);
-        const int u = o1x + lx, v = o1y + ly;
-        if (u < c1 && v < r1) a.d[0][v * c1 + u] = (uint16_t)t1[(v - t1y) * T1 + (u - t1x)];
-        kt_emit_maps(t1, T1, t1x, t1y, c1, r1, u, v, a.fx_inv[1], a.fy_inv[1], a.cx[1], a.cy[1], a.vmap[1], a.nmap[1]);
-    }
-    // levels 2 and 3 on the waves that have the least to do above
-    const int q2 = 255 - tid;
-    if (q2 < 4 * S * S) {  // level 2: 2 S x 2 S
-        const int ly = q2 / (2 * S), lx = q2 - ly * (2 * S);
-        const int u = o2x + lx, v = o2y + ly;
-        if (u < c2 && v < r2) a.d[1][v * c2 + u] = (uint16_t)t2[(v - t2y) * T2 + (u - t2x)];
-        kt_emit_maps(t2, T2, t2x, t2y, c2, r2, u, v, a.fx_inv[2], a.fy_inv[2], a.cx[2], a.cy[2], a.vmap[2], a.nmap[2]);
-    } else if (q2 < 5 * S * S) {  // level 3: S x S
-        const int q = q2 - 4 * S * S;
-        const int ly = q / S, lx = q - ly * S;
-        const int u = o3x + lx, v = o3y + ly;
-        if (u < c3 && v < r3) a.d[2][v * c3 + u] = (uint16_t)t3[(v - t3y) * T3 + (u - t3x)];
-        kt_emit_maps(t3, T3, t3x, t3y, c3, r3, u, v, a.fx_inv[3], a.fy_inv[3], a.cx[3], a.cy[3], a.vmap[3], a.nmap[3]);
-    }
-}
-
-// Round 6, the two-launch form.  The one-launch kernel above recomputes halos through three levels: with the 2 x 2 tile a workgroup builds 21 x 21
-// level-1 pixels to own 8 x 8 of them (6.9 x), and the level-1 filter -- 25 taps a pixel -- is where its 24 us go.  Split where the halo is
-// cheapest: kt_pyramid01_kernel owns 16 x 16 pixels of level 0 (21 x 21 loaded) and builds their 8 x 8 (+1: the normal map's neighbour, 9 x 9 =
-// 1.27 x) level-1 pixels, maps of both levels; kt_pyramid23_kernel starts from the level-1 depth the first one wrote and is the old kernel without
-// its level 0.  Same kt_pyr_px / kt_emit_maps on the same inputs: every output bit as before.  A launch boundary (~2 us) against 14 us of recomputation.
 __global__ __launch_bounds__(256) void kt_pyramid01_kernel(const kt_pyr_args a)
 {
     constexpr int T0 = 21, T1 = 9;
@@ -890,19 +820,8 @@ extern "C" int kt_build_pyramid(kt_ctx* c, const kt_intr* intr, const uint16_t* 
     kt_pyr_args a;
     KT_TRY(kt_pyr_args_fill(&a, intr, depth0, cols, rows, depths_out, vmaps, nmaps));
     const int c3 = cols / 8, r3 = rows / 8;
-    // KT_PYR_FORM: 1 = the one-launch kernel (rounds 1-6; KT_PYR_S=2|4 its tile), 2 = two launches (default), 3 = two launches, small tile in the second
-    static const int form = []() { const char* e = getenv("KT_PYR_FORM"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 3 ? v : 2; }();
-    if (form == 1) {
-        // measured (profiles/r06_experiments.md, call 17): 640x480 -- 24 against 31 us alone with the small tile; 1280x960 -- the small tile is 24 us SLOWER
-        static const int forced = []() { const char* e = getenv("KT_PYR_S"); const int v = e ? atoi(e) : 0; return v == 2 || v == 4 ? v : 0; }();
-        const int tile = forced ? forced : ((long long)cols * rows <= 640LL * 480LL ? 2 : 4);
-        if (tile == 4) hipLaunchKernelGGL(kt_pyramid_kernel<4>, dim3(kt_div_up(c3, 4), kt_div_up(r3, 4)), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL(kt_pyramid_kernel<2>, dim3(kt_div_up(c3, 2), kt_div_up(r3, 2)), dim3(256), 0, c->stream, a);
-    } else {
-        hipLaunchKernelGGL(kt_pyramid01_kernel, dim3(kt_div_up(cols / 2, 8), kt_div_up(rows / 2, 8)), dim3(256), 0, c->stream, a);
-        if (form == 2) hipLaunchKernelGGL(kt_pyramid23_kernel<4>, dim3(kt_div_up(c3, 4), kt_div_up(r3, 4)), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL(kt_pyramid23_kernel<2>, dim3(kt_div_up(c3, 2), kt_div_up(r3, 2)), dim3(256), 0, c->stream, a);
-    }
+    KT_TRY(kt_pyramid01_launch(c, &a));
+    hipLaunchKernelGGL(kt_pyramid23_kernel<4>, dim3(kt_div_up(c3, 4), kt_div_up(r3, 4)), dim3(256), 0, c->stream, a);
     KT_LAUNCH_CHECK();
     return KT_OK;
 }

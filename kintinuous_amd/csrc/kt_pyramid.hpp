@@ -66,7 +66,7 @@ __device__ __forceinline__ void kt_emit_maps(const int* __restrict__ tile, int t
         nmap[v * cols + u] = kt_nan();
 }
 
-// S = side of the level-3 tile a workgroup owns; tile widths: level 3: S + 1, level 2: 2 S + 5, level 1: 4 S + 13 (as in kt_pyramid_kernel)
+// S = side of the level-3 tile a workgroup owns; tile widths: level 3: S + 1, level 2: 2 S + 5, level 1: 4 S + 13
 template <int S>
 __device__ __forceinline__ void kt_pyramid23_block(const kt_pyr_args& a, int block_x, int block_y, int tid)
 {

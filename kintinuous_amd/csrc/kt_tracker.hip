@@ -156,12 +156,10 @@ struct kt_tracker {
     // colour weight carried across frames for pixels without a valid normal (KT_REC_STALE_NZ): [carry_sel] = state before the frame
     // in flight, [carry_sel ^ 1] = state after it
     float* wrkc_carry[2]; int carry_sel;
-    // Planning ahead (kt_volume.hip): the voxel kernel's task plan of frame f + 1 is made for a PREDICTED pose on plan_stream as soon as
-    // the frame has been read ahead, i.e. while the odometry of frame f iterates on the main stream (a latency-bound chain that leaves the
-    // compute units idle) -- two frames ahead of the last pose the host has seen.  plan_sel: the slot the frame in flight was enqueued
-    // with, -1 = none (the in-stream pre-pass ran).
-    // a plan belongs to ONE read-ahead frame: the frame set it was built from and the frame's buffers identify it (the ordinal alone does
-    // not: the caller may skip a read-ahead, and the pre-pass intervals depend on that frame's depth)
+    // Planning ahead (kt_volume.hip): the voxel kernel's task plan of a read-ahead frame is made for a PREDICTED pose on plan_stream at the start of
+    // the frame's kt_tracker_process_frame call -- before its odometry is enqueued, one increment past the last pose the host has seen -- and has the
+    // odometry launch to finish.  plan_sel: the slot the frame in flight was enqueued with, -1 = none (the in-stream pre-pass ran).
+    // (set / depth / rgb / wrap: what the plan was built from -- kept for drop_plans_of_set and the debug state)
     struct PlanSlot { kt_tsdf_plan plan; hipEvent_t done; long long ordinal; float R[9], t[3], theta, tau; int wrap[3]; int set; const uint16_t* depth; const uint8_t* rgb; };
     bool icp_levels;   // ICP-only odometry: one launch per pyramid level (kt_icp_level_kernel) instead of one per iteration, while this tracker is alone
     bool last_icp_levels;   // ... and whether the last frame's chain took that form
@@ -183,7 +181,7 @@ struct kt_tracker {
     // (A first cut had the side stream start with a one-thread kernel sleeping on a device flag the ray cast set -- no packet on the main
     // stream; that resident wave was itself the disturbance.)
     hipEvent_t gate_ev; bool gate_armed; int side_gate;   // side_gate: 0 off, 1 on
-    PlanSlot plans[3]; hipStream_t plan_stream;          // (three: frame f + 1 is planned while the voxel kernels of f and f - 1 may still read theirs)
+    PlanSlot plans[3]; hipStream_t plan_stream;          // (three: frame f is planned while the voxel kernels of f - 1 and f - 2 may still read theirs)
     int plan_sel; bool plan_enabled; float plan_margin_scale;
     // test hooks (kt_tracker_debug_plan_*): the pose every frame WILL arrive at, taken from an identical earlier run, as the prediction;
     // an offset of fr * theta about a random axis and ft * tau along a random direction on top of the prediction; fixed margins; a log
@@ -1272,23 +1270,20 @@ static void plan_rand_unit(kt_tracker* t, float v[3])
     }
 }
 
-static int plan_ahead(kt_tracker* t, const Pending& next, long long ordinal, int increments)
+static int plan_ahead(kt_tracker* t, const Pending& next, long long ordinal)
 {
     const int set = next.set;
     kt_tracker::PlanSlot& pl = t->plans[ordinal % 3];
     pl.ordinal = -1; pl.set = -1;
-    float D[9], D2[9], Rp[9], tp[3];
+    float D[9], Rp[9], tp[3];
     for (int i = 0; i < 3; ++i)       // D = R(f-2)^T R(f-1)
         for (int j = 0; j < 3; ++j) D[i * 3 + j] = t->hist_R[0][0 * 3 + i] * t->hist_R[1][0 * 3 + j] + t->hist_R[0][1 * 3 + i] * t->hist_R[1][1 * 3 + j] + t->hist_R[0][2 * 3 + i] * t->hist_R[1][2 * 3 + j];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) D2[i * 3 + j] = D[i * 3 + 0] * D[0 * 3 + j] + D[i * 3 + 1] * D[1 * 3 + j] + D[i * 3 + 2] * D[2 * 3 + j];
-    if (increments == 1) memcpy(D2, D, sizeof(D2));
-    for (int i = 0; i < 3; ++i)       // R^ = R(f-1) D^increments
-        for (int j = 0; j < 3; ++j) Rp[i * 3 + j] = t->Rlast[i * 3 + 0] * D2[0 * 3 + j] + t->Rlast[i * 3 + 1] * D2[1 * 3 + j] + t->Rlast[i * 3 + 2] * D2[2 * 3 + j];
+    for (int i = 0; i < 3; ++i)       // R^ = R(f-1) D
+        for (int j = 0; j < 3; ++j) Rp[i * 3 + j] = t->Rlast[i * 3 + 0] * D[0 * 3 + j] + t->Rlast[i * 3 + 1] * D[1 * 3 + j] + t->Rlast[i * 3 + 2] * D[2 * 3 + j];
     float step = 0.0f, turn = 0.0f;
     for (int k = 0; k < 3; ++k) {
         const float d = t->hist_gc[1][k] - t->hist_gc[0][k];
-        tp[k] = t->tlast[k] + (float)increments * d;
+        tp[k] = t->tlast[k] + d;
         step += d * d;
     }
     for (int k = 0; k < 9; ++k) turn += (D[k] - ((k % 4 == 0) ? 1.0f : 0.0f)) * (D[k] - ((k % 4 == 0) ? 1.0f : 0.0f));
@@ -1545,35 +1540,16 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     // shifted since (plan_ahead)
     t->plan_sel = -1;
     v_wrap_copy_update(t);
-    bool planned_next = false;
-    // KT_PLAN_CURRENT (default 1, round 6): the plan of THIS frame, made right here from the last pose the host has seen plus ONE increment.  It runs
-    // on the plan stream beside the previous frame's fusion kernels like the next frame's did, has this frame's whole odometry launch to finish, and
-    // predicts one step instead of two (a constant-velocity error grows with the square of the horizon: tighter margins, fewer misses, and a plan
-    // made AFTER a shift instead of one the shift invalidates).  0: rounds 4-5, the read-ahead frame's plan two increments out.
-    static const bool plan_current = []() { const char* e = getenv("KT_PLAN_CURRENT"); return e ? atoi(e) != 0 : true; }();
-    if (plan_current) {
-        if (t->plan_enabled && read_ahead && t->hist_n >= 2 && !t->cfg.dynamic_cube) {
-            // on a gated (dense) view the plan stream is held like the read-ahead: not beside the voxel kernel that is running now
-            if (t->side_gate && t->gate_armed) KT_HIP(hipStreamWaitEvent(t->plan_stream, t->gate_ev, 0));
-            KT_TRY(plan_ahead(t, Pending{depth_raw, colors, set, nullptr, nullptr}, ordinal, 1));
-            if (t->plans[ordinal % 3].ordinal == ordinal) t->plan_sel = (int)(ordinal % 3);
-        }
-    } else {
-        const kt_tracker::PlanSlot& pl = t->plans[ordinal % 3];
-        // the plan of THIS frame: made for this ordinal, from this frame's set and buffers (a caller may process another read-ahead
-        // than the one that was planned for), for the storage wrap that still holds
-        if (read_ahead && pl.ordinal == ordinal && pl.set == set && pl.depth == depth_raw && pl.rgb == colors &&
-            memcmp(pl.wrap, t->v_wrap_copy, sizeof(t->v_wrap_copy)) == 0)
-            t->plan_sel = (int)(ordinal % 3);
-        // The frame that has been read ahead comes next: plan its voxel pass now, for the pose predicted two increments past the last one
-        // the host has seen (-d repositions the cube once the pose is known: nothing to plan for).  NOW = before this frame's odometry is
-        // enqueued: the GPU is still in the previous frame's voxel kernel and ray cast, which do not mind a few small workgroups next to
-        // them; enqueued after the odometry (the first cut) the pre-pass ran next to the iterations, each of whose 256 workgroups needs a
-        // whole CU, and cost them 10 us per frame.
-        if (t->plan_enabled && !t->pending.empty() && t->hist_n >= 2 && !t->cfg.dynamic_cube) {
-            KT_TRY(plan_ahead(t, t->pending.front(), ordinal + 1, 2));
-            planned_next = t->plans[(ordinal + 1) % 3].ordinal == ordinal + 1;
-        }
+    // The plan of THIS frame, made right here from the last pose the host has seen plus ONE increment (round 6; rounds 4-5 planned the read-ahead
+    // frame, two increments out, behind that frame's read-ahead).  It runs on the plan stream beside the previous frame's fusion kernels, has this
+    // frame's whole odometry launch to finish, and predicts one step instead of two -- a constant-velocity error grows with the square of the
+    // horizon: tighter margins, fewer misses (221 / 1 against 214 / 2 on the orbit), and a plan made AFTER a shift instead of one the shift invalidates.
+    // (-d repositions the cube once the pose is known: nothing to plan for.)
+    if (t->plan_enabled && read_ahead && t->hist_n >= 2 && !t->cfg.dynamic_cube) {
+        // on a gated (dense) view the plan stream is held like the read-ahead: not beside the voxel kernel that is running now
+        if (t->side_gate && t->gate_armed) KT_HIP(hipStreamWaitEvent(t->plan_stream, t->gate_ev, 0));
+        KT_TRY(plan_ahead(t, Pending{depth_raw, colors, set, nullptr, nullptr}, ordinal));
+        if (t->plans[ordinal % 3].ordinal == ordinal) t->plan_sel = (int)(ordinal % 3);
     }
     // [C] odometry :564-572 -- every Gauss-Newton iteration is enqueued; the pose stays on the device
     v_wrap_copy_update(t);
@@ -1589,8 +1565,7 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     if (t->plan_sel >= 0 && hipEventQuery(t->plans[t->plan_sel].done) != hipSuccess) KT_HIP(hipStreamWaitEvent(c->stream, t->plans[t->plan_sel].done, 0));
     // gated side streams: what they were given for the NEXT frame (its read-ahead, then its plan) ends before this frame's voxel kernel starts
     // -- one wait packet in front of the set-up kernel (3-5 us; the gate is on where the frame is a millisecond)
-    if (t->side_gate && planned_next) KT_HIP(hipStreamWaitEvent(c->stream, t->plans[(ordinal + 1) % 3].done, 0));
-    else if (t->side_gate && !t->pending.empty()) KT_HIP(hipStreamWaitEvent(c->stream, t->sets[t->pending.front().set].ready, 0));
+    if (t->side_gate && !t->pending.empty()) KT_HIP(hipStreamWaitEvent(c->stream, t->sets[t->pending.front().set].ready, 0));
     if (!t->setup_fused) KT_TRY(launch_setup(t, 0, nullptr, nullptr));
     // -d: the cube may be repositioned once the pose is known, which changes the shift decision -- nothing to speculate on
     t->out_speculated = !t->cfg.dynamic_cube;
