@@ -346,7 +346,7 @@ def main():
                                 "max": round(float(periods.max()), 4),
                                 # the slowest calls (index in the timed region, ms): shift frames and whatever else stalls the caller
                                 "slowest": [[int(i), round(float(periods[i]), 3)] for i in np.argsort(periods)[::-1][:4]]},
-                   "slices_by_direction": slices_by_dim},
+                   "slices_by_direction": slices_by_dim, **({"periods_ms": [round(float(x), 3) for x in periods]} if os.environ.get("KT_BENCH_PERIODS") else {})},
         "roofline": {"kernel": voxel_kernel, "contract": "survey-8c" if voxel_kernel == "kt_tsdf23_tol_kernel" else "bit-exact", "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                      "frac": achieved / peak,
                      "frac_is": "the launch inside the timed region, next to the read-ahead and plan streams (since round 5 they run beside the fusion kernels: the "
