@@ -105,7 +105,7 @@ struct kt_tracker {
     // odo_ev[f % KT_NODO]: recorded on the main stream between fusion(f - 1) and fusion(f), in -p mode only -- there the host never
     // waits for a pose, so a lagging GPU's fusion could otherwise read a frame set the read-ahead stream has recycled (wait_frame_consumed).
     hipEvent_t odo_ev[8];
-    long long slot_frame[4];           // ordinal of the frame that consumed staging slot k (-1: none)
+    long long slot_frame[KT_NSLOTS];           // ordinal of the frame that consumed staging slot k (-1: none)
     hipStream_t pre_stream;
     kt_ctx pre_ctx;                    // the context with pre_stream as its stream (image kernels only)
     size_t cloud_cap;
