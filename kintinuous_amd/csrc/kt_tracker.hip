@@ -207,6 +207,7 @@ struct kt_tracker {
 };
 
 static int join_slice_jobs(kt_tracker* t);
+static int plan_frame(kt_tracker* t, const struct Pending& frame, long long ordinal);
 static int lvl_cols(const kt_tracker* t, int l) { return t->cfg.cols >> l; }
 static int lvl_rows(const kt_tracker* t, int l) { return t->cfg.rows >> l; }
 static kt_intr lvl_intr(kt_intr k, int l)  // Intr::operator() internal.h:255-259
@@ -1327,6 +1328,20 @@ static int plan_ahead(kt_tracker* t, const Pending& next, long long ordinal)
     return KT_OK;
 }
 
+// plan `frame` as the frame with this ordinal, if planning applies; sets plan_sel when the frame is the one being handed over (ordinal ==
+// frames_started - 1 is decided by the caller: process_frame passes its own ordinal and takes plan_sel from the slot)
+static int plan_frame(kt_tracker* t, const Pending& frame, long long ordinal)
+{
+    // (-d repositions the cube once the pose is known, a ground-truth trajectory supplies the pose on the host: nothing to plan for)
+    if (!(t->plan_enabled && t->hist_n >= 2 && !t->cfg.dynamic_cube && !t->has_trajectory)) return KT_OK;
+    // on a gated (dense) view the plan stream is held like the read-ahead: not beside the voxel kernel that is running now
+    if (t->side_gate && t->gate_armed) KT_HIP(hipStreamWaitEvent(t->plan_stream, t->gate_ev, 0));
+    v_wrap_copy_update(t);
+    KT_TRY(plan_ahead(t, frame, ordinal));
+    if (t->plans[ordinal % 3].ordinal == ordinal && ordinal == t->frames_started - 1) t->plan_sel = (int)(ordinal % 3);
+    return KT_OK;
+}
+
 // Host half of the frame enqueued by the last kt_tracker_process_frame call: wait for its pose (the copy-stream event, NOT the
 // fusion kernels), do the pose bookkeeping of KintinuousTracker.cpp:574-595, 903-909 and, when the volume has to shift
 // (:627-833), run the shift and redo the fusion the device parked.  Called at the start of the next frame and by every getter.
@@ -1545,11 +1560,18 @@ static int process_frame_impl(kt_tracker* t, const uint16_t* depth_raw, const ui
     // frame's whole odometry launch to finish, and predicts one step instead of two -- a constant-velocity error grows with the square of the
     // horizon: tighter margins, fewer misses (221 / 1 against 214 / 2 on the orbit), and a plan made AFTER a shift instead of one the shift invalidates.
     // (-d repositions the cube once the pose is known: nothing to plan for.)
-    if (t->plan_enabled && read_ahead && t->hist_n >= 2 && !t->cfg.dynamic_cube) {
-        // on a gated (dense) view the plan stream is held like the read-ahead: not beside the voxel kernel that is running now
-        if (t->side_gate && t->gate_armed) KT_HIP(hipStreamWaitEvent(t->plan_stream, t->gate_ev, 0));
-        KT_TRY(plan_ahead(t, Pending{depth_raw, colors, set, nullptr, nullptr}, ordinal));
-        if (t->plans[ordinal % 3].ordinal == ordinal) t->plan_sel = (int)(ordinal % 3);
+    // Made by whichever call sees the previous pose first: kt_tracker_prefetch_frame of the NEXT frame, when the caller announces in front of
+    // the hand-over (plan_frame_to_come: the plan is then on its stream before the read-ahead's four launches are enqueued, ~15 us of host time
+    // earlier -- it has the previous frame's fusion kernels to run beside, and what is still queued when the odometry launch takes the machine
+    // waits that launch out and delays the set-up kernel), or this call.
+    if (read_ahead) {
+        const kt_tracker::PlanSlot& pl = t->plans[ordinal % 3];
+        // a plan made for this ordinal belongs to this frame only if it was made from this frame's set and buffers (the caller may hand over
+        // another announced frame than the one that was next in line) for the storage wrap that still holds
+        if (pl.ordinal == ordinal && pl.set == set && pl.depth == depth_raw && pl.rgb == colors && memcmp(pl.wrap, t->v_wrap_copy, sizeof(t->v_wrap_copy)) == 0)
+            t->plan_sel = (int)(ordinal % 3);
+        else
+            KT_TRY(plan_frame(t, Pending{depth_raw, colors, set, nullptr, nullptr}, ordinal));
     }
     // [C] odometry :564-572 -- every Gauss-Newton iteration is enqueued; the pose stays on the device
     v_wrap_copy_update(t);
@@ -1626,6 +1648,9 @@ static int prefetch_impl(kt_tracker* t, const uint16_t* depth_raw, const uint8_t
     // RGB-D "last" reads of odometry(F - 1).  So a set last consumed by frame <= F - 2 is free; the set of frame F - 1 (its fusion
     // may still run, and it is RGB-D "last" for frame F) and the sets of outstanding read-aheads are not.
     KT_TRY(complete_frame(t));
+    // the frame that will be handed over next is known (announced earlier) and so is the pose in front of it: plan it NOW, before this frame's
+    // read-ahead goes to its stream (process_frame_impl: "made by whichever call sees the previous pose first")
+    if (!t->pending.empty() && t->plans[t->frames_started % 3].ordinal != t->frames_started) KT_TRY(plan_frame(t, t->pending.front(), t->frames_started));
     const int set = pick_free_set(t);   // exists: 3 sets, at most 1 other read-ahead outstanding here
     if (set < 0) { kt_set_error("kt_tracker_prefetch_frame: no free frame set"); return KT_ERR_STATE; }
     t->last_assigned = set;
