@@ -1,7 +1,7 @@
 #!/bin/bash
 # robustness: soak runs in every odometry mode and gate setting, and the GPU suite three times
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/c45; mkdir -p $O
+O=gpurun_out/c15; mkdir -p $O
 export TMPDIR=/tmp
 for mode in icp rgbd_icp rgbd; do
   timeout 900 python tests/tools/soak.py $mode 2>&1 | tail -2 | tee -a $O/soak.log
