@@ -16,9 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "tools", "two_process_worker.py")
 
 
-def _spawn(args):
+def _spawn(args, extra_env=None):
     env = dict(os.environ)
     env.pop("KT_ICP_LEVELS", None)   # both default settings
+    env.pop("KT_PREPARE_FUSED", None)
+    env.update(extra_env or {})
     return subprocess.Popen([sys.executable, WORKER] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
 
 
@@ -37,3 +39,13 @@ def test_two_processes_share_one_gpu(tmp_path):
         for one_pass in r["poses"]:
             assert one_pass == solo["poses"][0]      # bit-equal to the solo run, every pass, both processes
     print("two processes on one GPU: fallbacks %s, seconds %s (solo %.2f for one pass)" % ([r["fallbacks"] for r in res], [round(r["seconds"], 2) for r in res], solo["seconds"]))
+
+
+def test_fused_frame_preparation_equals_the_separate_launches():
+    """Round 6: the tracker prepares a frame with kt_frame_prepare (kt_pyramid01_kernel, then pyramid levels 2 / 3 and scaleDepth + pixel records
+    in ONE launch) instead of kt_build_pyramid + kt_integrate_prepare.  The switch is read once per process, hence two processes: the same
+    sequence with KT_PREPARE_FUSED=0 and with the default must leave the same poses and the same volumes, bit for bit.  (Both forms are compared
+    with the oracle elsewhere -- the tracker tests run the fused form, test_gpu_image.py / test_gpu_volume.py the stand-alone entry points.)"""
+    a = _result(_spawn(["--frames", "24", "--passes", "1"]))
+    b = _result(_spawn(["--frames", "24", "--passes", "1"], {"KT_PREPARE_FUSED": "0"}))
+    assert a["poses"] == b["poses"] and a["volumes_sha256"] == b["volumes_sha256"]

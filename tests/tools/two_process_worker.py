@@ -1,6 +1,6 @@
 """One of two PROCESSES sharing GPU 0 (tests/test_gpu_two_process.py): the library's defaults, a 320x240 orbit into a 256^3 volume (a sparse
 view by the tracker's rule, like 640x480 into 512^3: the odometry takes the level form),
-`passes` passes of `frames` frames (reset in between).  Prints one JSON line: the poses of every pass as hex words, the number of
+`passes` passes of `frames` frames (reset in between).  Prints one JSON line: the poses of every pass as hex words, a hash of the volumes the last pass left, the number of
 odometry fallbacks, and whether the last frame ran the level form.  `--barrier DIR --me K --peers N` makes the workers start their frames
 together (files in DIR)."""
 import argparse
@@ -51,7 +51,9 @@ def main():
             poses.append(np.concatenate([x.ravel() for x in trk.pose()]).astype(np.float32))
         out.append(np.array(poses).view(np.uint32).ravel().tolist())
     dt = time.perf_counter() - t0
-    res = {"poses": out, "fallbacks": trk.odometry_fallbacks(), "level_form_last": int(abi.lib().kt_tracker_debug_icp_levels(trk.h)), "seconds": dt}
+    import hashlib
+    vol_sha = hashlib.sha256(trk.volume().tobytes() + trk.color_volume().tobytes()).hexdigest()   # the volumes the last pass left
+    res = {"poses": out, "volumes_sha256": vol_sha, "fallbacks": trk.odometry_fallbacks(), "level_form_last": int(abi.lib().kt_tracker_debug_icp_levels(trk.h)), "seconds": dt}
     trk.close()
     ctx.close()
     print(json.dumps(res))
